@@ -1,0 +1,222 @@
+/*
+ * wheeledlab_amd.h -- C ABI of the MI355X (gfx950) env.step() hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own: its hot path is
+ * `isaaclab.envs.ManagerBasedRLEnv.step()` (registered at
+ * source/wheeledlab_tasks/wheeledlab_tasks/__init__.py:14-23) calling *up* into the reference's action terms
+ * and mdp functions and *down* into PhysX.  Each entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types: device pointers are `void*`-compatible raw pointers, the stream is a
+ *     `void*` holding a hipStream_t (NULL = default stream).
+ *   - the caller owns every buffer; the library allocates nothing and keeps no global state.
+ *   - asynchronous on the given stream, re-entrant, no internal synchronisation.
+ *   - return 0 (WL_OK) or a negative WL_E* code; never throws.
+ *   - per-env state is structure-of-arrays: a float matrix `state[WL_S_COUNT][stride]`, row = field,
+ *     column = env, `stride >= n_envs`, `stride % 64 == 0`, base 16-byte aligned.
+ *   - quaternions are (w, x, y, z); velocities in `state` are world-frame (IsaacLab `root_state_w` order).
+ */
+#ifndef WHEELEDLAB_AMD_H
+#define WHEELEDLAB_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WL_ABI_VERSION 3
+
+enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
+
+/* ---- rows of the SoA state matrix -------------------------------------------------------------------- */
+enum WlStateField {
+    /* root state, IsaacLab `root_state_w` order: link position, orientation, COM linear vel, angular vel */
+    WL_S_PX = 0, WL_S_PY, WL_S_PZ,
+    WL_S_QW, WL_S_QX, WL_S_QY, WL_S_QZ,
+    WL_S_VX, WL_S_VY, WL_S_VZ,
+    WL_S_WX, WL_S_WY, WL_S_WZ,
+    /* wheel spin [rad/s], reference wheel order (rc_car_actions.py:62): back-left, back-right, front-left, front-right */
+    WL_S_WHEEL_BL, WL_S_WHEEL_BR, WL_S_WHEEL_FL, WL_S_WHEEL_FR,
+    /* steering joint (both front steer joints share target and gains -> one value), position [rad] and rate */
+    WL_S_STEER_POS, WL_S_STEER_VEL,
+    /* last raw action (ActionManager.action), 2 floats */
+    WL_S_ACT0, WL_S_ACT1,
+    /* interval-event timers (push_robots_hf / push_robots_lf time_left), seconds */
+    WL_S_TIMER_HF, WL_S_TIMER_LF,
+    /* per-env domain-randomised constants (startup events): wheel static / dynamic friction, rear throttle
+       damping, total mass.  Read-only inside step. */
+    WL_S_MU_S, WL_S_MU_D, WL_S_DAMP, WL_S_MASS,
+    /* per-term episode reward sums (RewardManager._episode_sums), WL_MAX_REW_TERMS rows */
+    WL_S_EPSUM0,
+    WL_S_COUNT = WL_S_EPSUM0 + 8
+};
+#define WL_N_DYN 23          /* rows [0, WL_N_DYN) are read AND written every step */
+#define WL_MAX_REW_TERMS 8
+
+/* ---- drift task: reward term slots (DriftRewardsCfg order, mushr_drift_env_cfg.py:246-299) ------------ */
+enum WlDriftRewTerm {
+    WL_DR_SIDE_SLIP = 0, WL_DR_VEL, WL_DR_PROGRESS, WL_DR_TLGR, WL_DR_TURN_ENERGY, WL_DR_CROSS_TRACK,
+    WL_DR_TERM_PENS, WL_DR_NTERMS
+};
+
+/* ---- metric accumulators (device float[WL_M_COUNT], caller zeroes them when it has consumed them) ----- */
+enum WlMetric {
+    WL_M_EPSUM0 = 0,                 /* [0,8): sum over reset envs of episode_sum[term]                   */
+    WL_M_RESETS = 8,                 /* number of env resets                                              */
+    WL_M_TIMEOUTS = 9,               /* Episode_Termination/time_out count                                */
+    WL_M_TERM0 = 10,                 /* [10,14): counts of the task's `terminated` terms                  */
+    WL_M_NONFINITE = 14,             /* envs whose state went non-finite (they are force-reset)           */
+    WL_M_EPLEN = 15,                 /* sum of episode lengths (steps) over reset envs                    */
+    WL_M_COUNT = 16
+};
+
+/* ---- vehicle + contact model (replaces PhysX for this path; designed) -------- */
+typedef struct WlVehicleParams {
+    float gravity;            /* 9.81 */
+    float half_wheelbase_f;   /* CoM -> front axle [m]  (base_length 0.325 split; common/actions.py:18)       */
+    float half_wheelbase_r;   /* CoM -> rear axle [m]                                                         */
+    float half_track;         /* base_width / 2 = 0.1                                                         */
+    float wheel_radius;       /* 0.05                                                                         */
+    float wheel_z;            /* wheel-centre height in the root-link frame (root origin rests at ground)    */
+    float cg_z;               /* CoM height in the root-link frame                                            */
+    float gyr_x, gyr_y, gyr_z;/* radii of gyration: I = m * gyr^2 (mass is per-env)                           */
+    float wheel_inertia;      /* spin inertia of one wheel [kg m^2]                                           */
+    float wheel_damping;      /* bearing damping [N m s/rad]                                                  */
+    float susp_k, susp_c;     /* vertical tyre+suspension spring / damper per wheel                           */
+    float ground_mu_s, ground_mu_d;  /* terrain material, combined by "multiply" (mushr_drift_env_cfg.py:45-50) */
+    float slip_peak;          /* normalised slip at peak friction                                             */
+    float v_min;              /* low-speed regularisation of the slip denominator [m/s]                       */
+    /* DC motor on throttle joints (hound.py:13-21,40-43): tau = damp*(w_tgt-w) clipped to the DC curve       */
+    float motor_sat, motor_limit, motor_vel_limit;
+    int32_t drive;            /* 0 = rear wheel drive (front passive, hound.py:44-51), 1 = 4WD               */
+    /* implicit PD on the steer joints (hound.py:5-12)                                                        */
+    float steer_kp, steer_kd, steer_effort, steer_vel_limit, steer_inertia;
+    int32_t substeps;         /* integrator sub-steps per sim.dt (1 for dt<=0.01)                             */
+} WlVehicleParams;
+
+/* ---- action term (AckermannAction.process_actions, ackermann_actions.py:119-133) ---------------------- */
+typedef struct WlActionParams {
+    float scale[2], offset[2];
+    int32_t bounding;         /* 0 none, 1 clip(-1,1), 2 tanh                                                 */
+    int32_t no_reverse;       /* clamp processed throttle >= 0                                                */
+    int32_t clip_wrapper;     /* 1: apply the ClipAction wrapper (clip_action.py:27) before everything        */
+    int32_t map;              /* 0 RCCarRWDAction, 1 RCCar4WDAction (rc_car_actions.py:12-29 / 36-64)         */
+    float base_length, base_width, wheel_radius;
+} WlActionParams;
+
+typedef struct WlDriftParams {
+    float sim_dt;             /* 0.005 (mushr_drift_env_cfg.py:393)                                           */
+    int32_t decimation;       /* 4     (:394)                                                                 */
+    int32_t max_episode_length; /* ceil(5 s / 0.02 s) = 250 (:396)                                            */
+    WlActionParams action;
+    WlVehicleParams vehicle;
+    /* track geometry (:27-32) */
+    float straight, r_in, r_out, r_line;
+    /* reward weights in WlDriftRewTerm order and term params (:246-299); weight 0 => term skipped            */
+    float weight[WL_MAX_REW_TERMS];
+    float slip_min, slip_max, slip_min_vx;
+    float speed_target, speed_offset;
+    float tlgr_thresh;
+    float ctd_offset, ctd_p;
+    /* observation corruption (common/observations.py:27-50, enable at mushr_drift_env_cfg.py:399)            */
+    int32_t enable_corruption;
+    float noise_std[4];       /* pos, euler, lin vel, ang vel                                                 */
+    /* reset (drifting/mdp/events.py:102-133)                                                                 */
+    int32_t num_ref_points;
+    float pos_noise, yaw_noise;
+    /* interval pushes (mushr_drift_env_cfg.py:121-143)                                                        */
+    int32_t enable_pushes;
+    float hf_interval[2], hf_vel_x, hf_vel_y, hf_vel_yaw;
+    float lf_interval[2], lf_vel_yaw;
+    int32_t log_episode_sums; /* maintain WL_S_EPSUM rows + WL_M_EPSUM metrics                                */
+} WlDriftParams;
+
+/* ---- device buffers of one env batch ------------------------------------------------------------------ */
+typedef struct WlEnvBuffers {
+    float* state;             /* [WL_S_COUNT][stride]                                                         */
+    int32_t* episode_len;     /* [n]  episode_length_buf                                                      */
+    const float* ref_poses;   /* [3][32]: x, y, yaw(rad) of the pre-sampled reference poses (events.py:31)     */
+    float* metrics;           /* [WL_M_COUNT] accumulators (atomicAdd)                                        */
+    int64_t stride;
+    int32_t n_envs;
+} WlEnvBuffers;
+
+/* ---- outputs of one step -------------------------------------------------------------------------------- */
+typedef struct WlStepOut {
+    float* obs;               /* [n][obs_dim] row-major, what the policy consumes                            */
+    float* reward;            /* [n]                                                                          */
+    uint8_t* terminated;      /* [n]                                                                          */
+    uint8_t* truncated;       /* [n]                                                                          */
+} WlStepOut;
+
+int wl_version(void);
+/* number of HIP devices visible, or WL_ENODEV */
+int wl_device_count(void);
+const char* wl_strerror(int code);
+
+/*
+ * Fused drift-task env.step(): replaces, for all n envs in ONE kernel launch, what IsaacLab's
+ * ManagerBasedRLEnv.step() does with the reference's plugins:
+ *   ClipAction (clip_action.py:27) -> AckermannAction.process_actions (ackermann_actions.py:119-133)
+ *   -> decimation x [RCCarRWDAction map (rc_car_actions.py:12-29) -> actuators (hound.py:4-52) -> rigid body +
+ *      4 tyre contacts (replaces PhysX)] -> time_out + cart_off_track (mushr_drift_env_cfg.py:343-362)
+ *   -> 7 reward terms x weight x step_dt (:160-299) -> in-kernel reset along the track (drifting/mdp/events.py:102-133)
+ *   -> interval pushes (:121-143) -> 14-dim noisy observation (common/observations.py:24-54).
+ * `actions` is [n][2] row-major (device).  `noise` is NULL (in-kernel Philox4x32-10 keyed by (seed, env, step))
+ * or a device float[12][stride] of standard normals used instead (parity mode).
+ * `step` is IsaacLab's common_step_counter BEFORE this step.
+ */
+int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* actions, const float* noise,
+                  const WlStepOut* out, uint64_t seed, uint64_t step, void* stream);
+
+/*
+ * K consecutive fused steps with pre-staged actions [K][n][2]; outputs of step k are written at
+ * obs + k*obs_step_stride (floats), reward + k*vec_step_stride, terminated/truncated + k*vec_step_stride
+ * (strides 0 = overwrite).  This is the rollout inner loop of the reference's runner
+ * (modified_rsl_rl_runner.py:70-73) minus the policy.
+ */
+int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float* actions, const WlStepOut* out,
+                     int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps, uint64_t seed,
+                     uint64_t step0, void* stream);
+
+/*
+ * Drift mdp terms only, on caller-supplied state tensors (the parity entry point: "outputs match the reference
+ * mdp terms on identical state tensors").  All inputs are SoA float[k][stride] device arrays:
+ *   pos[3], quat[4], lin_vel_b[3], ang_vel_b[3], ang_vel_w[3], steer_pos[2], last_action[2].
+ * Outputs: terms[WL_DR_NTERMS][stride] UNWEIGHTED term values (side_slip .. is_terminated),
+ *          reward[n] = sum_i weight_i * term_i * step_dt, terminated[n] (cart_off_track), obs[n][14] (no noise).
+ * Replaces mushr_drift_env_cfg.py:160-240,343-348; wheeledlab/envs/mdp/observations.py:9-12.
+ */
+int wl_drift_mdp(const WlDriftParams* p, int32_t n, int64_t stride, const float* pos, const float* quat,
+                 const float* lin_vel_b, const float* ang_vel_b, const float* ang_vel_w, const float* steer_pos,
+                 const float* last_action, const uint8_t* timed_out, float* terms, float* reward,
+                 uint8_t* terminated, float* obs, void* stream);
+
+/*
+ * Action term only: ClipAction + process_actions + the RWD / 4WD joint-target map (parity entry point).
+ * actions [n][2] -> processed [n][2] (v m/s, delta rad), steer_target [n][2] (= tan delta, both joints),
+ * wheel_target [n][4] rad/s in order bl, br, fl, fr (RWD writes fl = fr = 0).
+ * Replaces ackermann_actions.py:119-145, rc_car_actions.py:12-29,36-64.
+ */
+int wl_action_map(const WlActionParams* a, int32_t n, const float* actions, float* processed, float* steer_target,
+                  float* wheel_target, void* stream);
+
+/*
+ * Reset every env in `mask` (uint8[n], NULL = all) exactly as the in-kernel reset does (events.py:102-133),
+ * also re-arming push timers and zeroing episode_len / last action / episode sums.  Used by env.reset().
+ */
+int wl_drift_reset(const WlDriftParams* p, const WlEnvBuffers* b, const uint8_t* mask, uint64_t seed,
+                   uint64_t step, void* stream);
+
+/* Observation only (env.reset() / get_observations()): 14-dim policy obs from the current state. */
+int wl_drift_observe(const WlDriftParams* p, const WlEnvBuffers* b, const float* noise, float* obs, uint64_t seed,
+                     uint64_t step, void* stream);
+
+/* Raw Philox4x32-10 uniforms as used in-kernel: out[4][n] for counter (env, step, stream_id). Test hook. */
+int wl_philox_uniform(int32_t n, uint64_t seed, uint64_t step, uint32_t stream_id, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHEELEDLAB_AMD_H */

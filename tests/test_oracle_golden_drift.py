@@ -1,0 +1,106 @@
+"""Pin the oracle (numpy restatement) to the golden vectors produced by the reference's own functions
+(tests/golden/gen_golden.py).  CPU only.  Tolerances: float outputs 1e-6 abs + 1e-6 rel (both sides fp32,
+different libm paths for atan2/sqrt); boolean / integer outputs bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import drift_mdp as M
+from oracle import drift_reset as R
+from oracle import mathlib as ml
+from oracle import params as P
+
+TOL = dict(rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["n256", "edges"])
+def test_drift_terms_match_reference(golden, tag):
+    g = golden(f"drift_mdp_{tag}")
+    p = P.drift_params()
+    steer = g["joint_pos"][:, 0:2]
+    np.testing.assert_allclose(M.side_slip(g["lin_vel_b"], p.slip_min, p.slip_max, p.slip_min_vx), g["side_slip"], **TOL)
+    np.testing.assert_allclose(M.vel_dist(g["lin_vel_b"], p.speed_target, p.speed_offset), g["vel_dist"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(M.track_progress_rate(g["ang_vel_w"]), g["track_progress_rate"])
+    np.testing.assert_allclose(M.turn_left_go_right(steer, g["ang_vel_b"], p.tlgr_thresh), g["turn_left_go_right"], **TOL)
+    np.testing.assert_allclose(M.energy_through_turn(g["pos"], g["lin_vel_b"], p.straight), g["energy_through_turn"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(M.cross_track_dist(g["pos"], p.straight, p.r_line, p.ctd_offset, p.ctd_p), g["cross_track_dist"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_array_equal(M.in_range(g["pos"], p.straight, p.r_in), g["in_range"])
+    np.testing.assert_array_equal(M.off_track(g["pos"], p.straight, p.r_out), g["off_track"])
+    np.testing.assert_array_equal(M.cart_off_track(g["pos"], p.straight, p.r_in, p.r_out), g["cart_off_track"])
+    np.testing.assert_array_equal(np.asarray(p.weight[:7], np.float32), g["weights"])
+
+
+def test_action_terms_match_reference(golden):
+    g = golden("actions")
+    for tag, ap in (("rwd", P.mushr_action(0)), ("4wd", P.mushr_action(1)),
+                    ("f1tenth", P.mushr_action(1, base_length=0.365, base_width=0.284))):
+        assert np.allclose(g[f"{tag}_geom"], [ap.base_length, ap.base_width, ap.wheel_radius, *ap.scale])
+        # the wrapper clip is not part of the action term: golden raw == input
+        np.testing.assert_array_equal(g[f"{tag}_raw"], g["actions"])
+        proc = M.process_actions(g["actions"], ap)
+        np.testing.assert_allclose(proc, g[f"{tag}_processed"], **TOL)
+        fn = M.rwd_targets if tag == "rwd" else M.fwd_targets
+        steer, wheel = fn(proc[:, 0], proc[:, 1], ap)
+        np.testing.assert_allclose(steer, g[f"{tag}_steer_pos_target"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(wheel, g[f"{tag}_wheel_vel_target"], rtol=1e-5, atol=1e-4)
+    ap = P.mushr_action(1)
+    proc = M.process_actions(g["4wd_special_actions"], ap)
+    steer, wheel = M.fwd_targets(proc[:, 0], proc[:, 1], ap)
+    np.testing.assert_allclose(wheel, g["4wd_special_wheel_vel_target"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(steer, g["4wd_special_steer_pos_target"], rtol=1e-6, atol=1e-6)
+    # base class (tanh bounding, reverse allowed, true Ackermann angles)
+    ap = P.mushr_action(1)
+    ap.bounding, ap.no_reverse = 2, 0
+    proc = M.process_actions(g["actions"], ap)
+    np.testing.assert_allclose(proc, g["base_processed"], **TOL)
+    steer, wheel = M.ackermann_base_targets(proc[:, 0], proc[:, 1], ap)
+    np.testing.assert_allclose(steer, g["base_steer_pos_target"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(wheel, g["base_wheel_vel_target"], rtol=1e-5, atol=1e-4)
+
+
+def test_reset_along_track_matches_reference(golden):
+    g = golden("reset_track")
+    ref = R.reference_poses(g["u_dists"])
+    np.testing.assert_allclose(ref, g["reference_poses"], rtol=1e-6, atol=2e-5)  # degrees: 2e-5 abs on ~300
+    pose, vel = R.reset_pose(g["reference_poses"], g["idx"], g["u_xy"], g["u_yaw"], 0.5, 1.0)
+    np.testing.assert_allclose(pose, g["pose"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(vel, g["vel"])
+    # the in-kernel table is the same data in radians
+    t = R.ref_pose_table(g["reference_poses"])
+    assert t.shape == (3, 32)
+    np.testing.assert_allclose(t[2, :20], np.deg2rad(g["reference_poses"][:, 1, 2]), rtol=1e-6)
+
+
+def test_curriculum_matches_reference(golden):
+    g = golden("curriculum")
+    w = [10.0, 0.0, -5000.0]
+    got = []
+    for step in g["steps"]:
+        for k in range(3):
+            inc, epi, mx = g["params"][k]
+            w[k] = R.increase_reward_weight_over_time(int(step), 250, w[k], inc, int(epi), mx)
+        got.append(list(w))
+    np.testing.assert_array_equal(np.array(got), g["weights"])
+    assert got[-1] == [230.0, 60.0, -11000.0]  # max_increases + 1 increments
+
+
+def test_math_self_consistency():
+    """unpinned helpers: round trips and known answers"""
+    rng = np.random.RandomState(0)
+    rpy = np.stack([rng.uniform(-3, 3, 500), rng.uniform(-1.5, 1.5, 500), rng.uniform(-3, 3, 500)], -1).astype(np.float32)
+    q = ml.quat_from_euler_xyz(rpy[:, 0], rpy[:, 1], rpy[:, 2])
+    np.testing.assert_allclose(np.linalg.norm(q, axis=-1), 1.0, atol=1e-6)
+    r, p, y = ml.euler_xyz_from_quat(q)
+    wrap = lambda a: np.mod(a, 2 * np.pi)
+    d = lambda a, b: np.abs(np.mod(a - b + np.pi, 2 * np.pi) - np.pi)
+    assert d(r, wrap(rpy[:, 0])).max() < 2e-4 and d(p, wrap(rpy[:, 1])).max() < 2e-4 and d(y, wrap(rpy[:, 2])).max() < 2e-4
+    assert (r >= 0).all() and (r < 2 * np.pi + 1e-6).all()
+    Rm = ml.matrix_from_quat(q)
+    np.testing.assert_allclose(np.einsum("nij,nkj->nik", Rm, Rm), np.broadcast_to(np.eye(3), Rm.shape), atol=2e-6)
+    v = rng.normal(size=(500, 3)).astype(np.float32)
+    np.testing.assert_allclose(ml.rotate(q, ml.rotate_inverse(q, v)), v, atol=2e-6)
+    # yaw 90 deg maps body x to world y
+    q90 = ml.quat_from_euler_xyz(0.0, 0.0, np.pi / 2)
+    np.testing.assert_allclose(ml.rotate(q90[None], np.array([[1.0, 0, 0]])), [[0, 1, 0]], atol=1e-6)
+    # identity -> zero angles; small negative yaw wraps to just below 2pi (reference quirk)
+    _, _, yw = ml.euler_xyz_from_quat(ml.quat_from_euler_xyz(0.0, 0.0, -0.01)[None])
+    assert abs(yw[0] - (2 * np.pi - 0.01)) < 1e-5
