@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the fused drift env.step() hot path (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank / GPU)
+
+A "step" is one env.step() of ALL envs of the shard: one launch of the fused HIP kernel (action term -> 4 physics
+sub-steps -> terminations -> rewards -> resets -> pushes -> 14-dim observation).  Workload (config.workload): drift
+task, 4096 envs per GPU, flat terrain, synthetic U(-1,1) actions pre-staged in HBM, outputs written into a
+[128, n, ...] rollout storage exactly as an on-policy runner would keep them (modified_rsl_rl_runner.py:70-73).
+Env shards are independent (weak scaling); the only collective is the episode-metric all-reduce (RCCL) once per
+128-step rollout -- the reference's logging cadence (rsl_rl_ppo_cfg.py:6).
+
+The JSON line carries `roofline` (HBM-bound kernel: algorithmic bytes per launch / mean launch duration measured
+with HIP events on the launch stream) and `cpu_baseline` (the torch-CPU port of the reference's mdp path, timed on
+this box's host cores on a bounded sample; baseline, not target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+ENVS_PER_GPU = 4096
+ROLLOUT = 128            # num_steps_per_env of the reference's PPO config
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+# algorithmic HBM bytes per env-step of the fused drift kernel:
+#   reads : 23 dynamic rows + 4 randomisation rows + 7 episode sums (fp32) + episode_len (i32) + action (2 fp32)
+#   writes: 23 dynamic rows + 7 episode sums + episode_len + obs 14 fp32 + reward fp32 + terminated u8 + truncated u8
+BYTES_READ = (23 + 4 + 7) * 4 + 4 + 8
+BYTES_WRITE = (23 + 7) * 4 + 4 + 14 * 4 + 4 + 2
+BYTES_PER_ENV_STEP = BYTES_READ + BYTES_WRITE
+
+
+def cpu_baseline(n_envs: int, budget_s: float = 12.0):
+    """torch-CPU port of the reference's drift mdp path (oracle/torch_mdp.py) on the host cores."""
+    from oracle import torch_mdp as T
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: torch.rand(*s, generator=g)
+    pos = torch.cat([r(n_envs, 2) * 4 - 2, torch.zeros(n_envs, 1)], -1)
+    yaw = r(n_envs) * 6.28
+    quat = torch.stack([torch.cos(yaw / 2), torch.zeros(n_envs), torch.zeros(n_envs), torch.sin(yaw / 2)], -1)
+    vb, wb, ww = r(n_envs, 3) * 3, r(n_envs, 3) - 0.5, r(n_envs, 3) - 0.5
+    steer = r(n_envs, 2) - 0.5
+    act = r(n_envs, 2) * 2 - 1
+    ep = torch.zeros(n_envs, dtype=torch.int32)
+    w = [10.0, -5.0, 40.0, 0.0, 20.0, -50.0, -5000.0]
+    scale, off = torch.tensor([3.0, 0.488]), torch.zeros(2)
+    with torch.inference_mode():
+        for _ in range(20):
+            T.mdp_step(pos, quat, vb, wb, ww, steer, act, ep, w, scale, off)
+        t0 = time.perf_counter()
+        iters = 0
+        while True:
+            for _ in range(50):
+                T.mdp_step(pos, quat, vb, wb, ww, steer, act, ep, w, scale, off)
+            iters += 50
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
+    return {"value": n_envs * iters / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} passes of the drift mdp path (action term + 2 terminations + 7 rewards + noisy 14-dim "
+                      f"obs; no physics exists on the reference's CPU side) on {n_envs} envs, torch {torch.__version__} "
+                      f"CPU, {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="also print a large-N sweep (extra JSON lines on stderr)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from wheeledlab_amd.core import DriftBatch
+
+    n = args.envs_per_gpu
+    env = DriftBatch(n, device=dev, seed=42, env_offset=rank * n)
+    env.reset()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    actions = torch.rand(ROLLOUT, n, 2, device=dev, generator=g) * 2 - 1
+    obs_buf = torch.zeros(ROLLOUT, n, 14, device=dev)
+    rew_buf = torch.zeros(ROLLOUT, n, device=dev)
+    term_buf = torch.zeros(ROLLOUT, n, dtype=torch.uint8, device=dev)
+    trunc_buf = torch.zeros(ROLLOUT, n, dtype=torch.uint8, device=dev)
+    metric_sum = torch.zeros_like(env.metrics)
+
+    def run(k_steps):
+        done = 0
+        while done < k_steps:
+            k = min(ROLLOUT, k_steps - done)
+            env.rollout(actions[:k], obs_buf, rew_buf, term_buf, trunc_buf)
+            done += k
+            if k == ROLLOUT:  # episode-metric reduction at the logging cadence
+                m = env.metrics.clone()
+                env.metrics.zero_()
+                if dist is not None:
+                    dist.all_reduce(m)
+                metric_sum.add_(m)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(args.steps)
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    t = torch.tensor([wall], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+
+    # kernel-only duration: K back-to-back launches of the fused step between two events on the launch stream
+    env.rollout(actions, obs_buf, rew_buf, term_buf, trunc_buf)
+    torch.cuda.synchronize()
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 8
+    k0.record()
+    for _ in range(reps):
+        env.rollout(actions, obs_buf, rew_buf, term_buf, trunc_buf)
+    k1.record()
+    torch.cuda.synchronize()
+    launch_us = k0.elapsed_time(k1) * 1e3 / (reps * ROLLOUT)
+    achieved = BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
+
+    sweep = []
+    if args.sweep and rank == 0:
+        for big in (65536, 1048576, 4194304):
+            e2 = DriftBatch(big, device=dev, seed=42)
+            e2.reset()
+            a2 = torch.rand(8, big, 2, device=dev) * 2 - 1
+            for _ in range(3):
+                e2.rollout(a2)
+            torch.cuda.synchronize()
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(6):
+                e2.rollout(a2)
+            s1.record()
+            torch.cuda.synchronize()
+            us = s0.elapsed_time(s1) * 1e3 / 48
+            sweep.append({"n_envs": big, "us_per_step": round(us, 2), "env_steps_per_s": big / (us * 1e-6),
+                          "achieved_GBs": BYTES_PER_ENV_STEP * big / (us * 1e-6) / 1e9})
+            del e2, a2
+
+    if rank == 0:
+        total_envs = n * world
+        line = {
+            "metric": "env steps/sec (whole node), drift task @ 4096 envs/GPU",
+            "value": total_envs * args.steps / wall,
+            "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"RSS_DRIFT_CONFIG drift task, {n} envs/GPU, flat terrain, fused dynamics+mdp HIP "
+                                   f"kernel, U(-1,1) actions pre-staged in HBM, {ROLLOUT}-step rollout storage",
+                       "envs_per_gpu": n, "total_envs": total_envs, "decimation": 4, "sim_dt": 0.005,
+                       "parallelism": f"env-shard x{world}, metric all-reduce / {ROLLOUT} steps"},
+            "gpu_event_ms_per_step": gpu_ms / args.steps,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "drift_step_kernel<FlatGround>", "launch_us": launch_us,
+                         "bytes_per_env_step": BYTES_PER_ENV_STEP, "envs_per_launch": n},
+            "episode_metrics": {"resets": float(metric_sum[8]), "timeouts": float(metric_sum[9]),
+                                "out_of_bounds": float(metric_sum[10]), "nonfinite": float(metric_sum[14])},
+        }
+        if sweep:
+            line["large_n_sweep"] = sweep
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -140,6 +140,7 @@ typedef struct WlEnvBuffers {
     float* metrics;           /* [WL_M_COUNT] accumulators (atomicAdd)                                        */
     int64_t stride;
     int32_t n_envs;
+    int32_t env_offset;       /* global id of env 0 of this shard (rank * n_envs): keys the RNG streams            */
 } WlEnvBuffers;
 
 /* ---- outputs of one step -------------------------------------------------------------------------------- */

@@ -1,0 +1,94 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/wheeledlab_amd.h
+declares, the ctypes structs match the header's layout, and the product's default parameters equal the oracle's."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+from oracle import params as OP
+from wheeledlab_amd import _abi as A
+from wheeledlab_amd import params as PP
+
+HEADER = os.path.join(ROOT, "include", "wheeledlab_amd.h")
+
+
+def _ensure_built():
+    if not os.path.exists(A.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+
+
+def test_library_exports_every_declared_symbol():
+    _ensure_built()
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)  # prose in comments also mentions the entry points
+    declared = set(re.findall(r"\b(wl_[a-z0-9_]+)\s*\(", src))
+    assert declared == set(A.SIGNATURES), (declared ^ set(A.SIGNATURES))
+    lib = A.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.wl_version() == A.WL_ABI_VERSION
+    assert lib.wl_strerror(-3).decode().startswith("buffer alignment")
+
+
+def test_struct_layout_matches_header(tmp_path):
+    """compile a tiny C program against the header and compare sizeof / offsetof with ctypes"""
+    probe = tmp_path / "probe.c"
+    probe.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "wheeledlab_amd.h"\n'
+        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %d %d\\n\", sizeof(WlDriftParams), sizeof(WlVehicleParams),"
+        " sizeof(WlActionParams), sizeof(WlEnvBuffers), sizeof(WlStepOut), offsetof(WlDriftParams, vehicle),"
+        " offsetof(WlDriftParams, weight), offsetof(WlDriftParams, log_episode_sums), offsetof(WlEnvBuffers, stride),"
+        " (int)WL_S_COUNT, (int)WL_M_COUNT);return 0;}\n")
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [C.sizeof(A.WlDriftParams), C.sizeof(A.WlVehicleParams), C.sizeof(A.WlActionParams), C.sizeof(A.WlEnvBuffers),
+            C.sizeof(A.WlStepOut), A.WlDriftParams.vehicle.offset, A.WlDriftParams.weight.offset,
+            A.WlDriftParams.log_episode_sums.offset, A.WlEnvBuffers.stride.offset, A.S_COUNT, A.M_COUNT]
+    assert got == want
+
+
+def _cmp(prod, orc, path=""):
+    for k, v in prod.items():
+        o = getattr(orc, k)
+        if isinstance(v, dict):
+            _cmp(v, o, path + k + ".")
+        elif isinstance(v, list):
+            assert [float(x) for x in o] == pytest.approx(v, rel=1e-6), path + k
+        else:
+            assert float(o) == pytest.approx(float(v), rel=1e-6), path + k
+
+
+def test_product_defaults_equal_oracle_defaults():
+    _cmp(PP.struct_to_dict(PP.drift_params()), OP.drift_params())
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    _ensure_built()
+    lib = A.load()
+    p = PP.drift_params()
+    b = A.WlEnvBuffers()  # all null
+    out = A.WlStepOut()
+    assert lib.wl_drift_step(C.byref(p), C.byref(b), None, None, C.byref(out), 0, 0, None) == -1
+    assert lib.wl_action_map(C.byref(p.action), 0, None, None, None, None, None) == -1
+    assert lib.wl_philox_uniform(0, 0, 0, 0, None, None) == -1
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(A.HipExtensionMissing):
+        A.load(str(tmp_path / "nope.so"))
+
+
+def test_product_does_not_import_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "wheeledlab_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
+                    bad.append(f)
+    assert not bad

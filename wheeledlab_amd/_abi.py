@@ -1,0 +1,129 @@
+"""ctypes mirror of include/wheeledlab_amd.h (the C-ABI drop-in boundary) and the loader of the HIP library.
+
+The product path has NO fallback: if ``libwheeledlab_amd.so`` is missing or a symbol cannot be resolved this module
+raises at import / call time (``HipExtensionMissing``); nothing under ``wheeledlab_amd`` imports ``oracle``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+WL_ABI_VERSION = 3
+WL_MAX_REW_TERMS = 8
+
+# WlStateField
+(S_PX, S_PY, S_PZ, S_QW, S_QX, S_QY, S_QZ, S_VX, S_VY, S_VZ, S_WX, S_WY, S_WZ, S_WHEEL_BL, S_WHEEL_BR, S_WHEEL_FL,
+ S_WHEEL_FR, S_STEER_POS, S_STEER_VEL, S_ACT0, S_ACT1, S_TIMER_HF, S_TIMER_LF, S_MU_S, S_MU_D, S_DAMP, S_MASS,
+ S_EPSUM0) = range(28)
+S_COUNT = S_EPSUM0 + 8
+N_DYN = 23
+# WlMetric
+M_EPSUM0, M_RESETS, M_TIMEOUTS, M_TERM0, M_NONFINITE, M_EPLEN, M_COUNT = 0, 8, 9, 10, 14, 15, 16
+# WlDriftRewTerm
+DRIFT_TERM_NAMES = ("side_slip", "vel", "progress", "tlgr", "turn_energy", "cross_track", "term_pens")
+
+ERRORS = {0: "ok", -1: "invalid argument", -2: "kernel launch failed", -3: "buffer alignment / stride violation",
+          -4: "no HIP device"}
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+class WlError(RuntimeError):
+    pass
+
+
+class WlVehicleParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "gravity", "half_wheelbase_f", "half_wheelbase_r", "half_track", "wheel_radius", "wheel_z", "cg_z", "gyr_x",
+        "gyr_y", "gyr_z", "wheel_inertia", "wheel_damping", "susp_k", "susp_c", "ground_mu_s", "ground_mu_d",
+        "slip_peak", "v_min", "motor_sat", "motor_limit", "motor_vel_limit")] + [("drive", C.c_int32)] + [
+        (n, C.c_float) for n in ("steer_kp", "steer_kd", "steer_effort", "steer_vel_limit", "steer_inertia")] + [
+        ("substeps", C.c_int32)]
+
+
+class WlActionParams(C.Structure):
+    _fields_ = [("scale", C.c_float * 2), ("offset", C.c_float * 2), ("bounding", C.c_int32),
+                ("no_reverse", C.c_int32), ("clip_wrapper", C.c_int32), ("map", C.c_int32),
+                ("base_length", C.c_float), ("base_width", C.c_float), ("wheel_radius", C.c_float)]
+
+
+class WlDriftParams(C.Structure):
+    _fields_ = [
+        ("sim_dt", C.c_float), ("decimation", C.c_int32), ("max_episode_length", C.c_int32),
+        ("action", WlActionParams), ("vehicle", WlVehicleParams),
+        ("straight", C.c_float), ("r_in", C.c_float), ("r_out", C.c_float), ("r_line", C.c_float),
+        ("weight", C.c_float * WL_MAX_REW_TERMS),
+        ("slip_min", C.c_float), ("slip_max", C.c_float), ("slip_min_vx", C.c_float),
+        ("speed_target", C.c_float), ("speed_offset", C.c_float), ("tlgr_thresh", C.c_float),
+        ("ctd_offset", C.c_float), ("ctd_p", C.c_float),
+        ("enable_corruption", C.c_int32), ("noise_std", C.c_float * 4),
+        ("num_ref_points", C.c_int32), ("pos_noise", C.c_float), ("yaw_noise", C.c_float),
+        ("enable_pushes", C.c_int32), ("hf_interval", C.c_float * 2), ("hf_vel_x", C.c_float),
+        ("hf_vel_y", C.c_float), ("hf_vel_yaw", C.c_float), ("lf_interval", C.c_float * 2),
+        ("lf_vel_yaw", C.c_float), ("log_episode_sums", C.c_int32),
+    ]
+
+
+class WlEnvBuffers(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("episode_len", C.c_void_p), ("ref_poses", C.c_void_p),
+                ("metrics", C.c_void_p), ("stride", C.c_int64), ("n_envs", C.c_int32), ("env_offset", C.c_int32)]
+
+
+class WlStepOut(C.Structure):
+    _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p)]
+
+
+_P = C.POINTER
+_vp, _u64, _i32, _i64 = C.c_void_p, C.c_uint64, C.c_int32, C.c_int64
+
+# every symbol include/wheeledlab_amd.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "wl_version": (C.c_int, []),
+    "wl_device_count": (C.c_int, []),
+    "wl_strerror": (C.c_char_p, [C.c_int]),
+    "wl_drift_step": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _vp, _P(WlStepOut), _u64, _u64, _vp]),
+    "wl_drift_rollout": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _P(WlStepOut), _i64, _i64, _i32, _u64,
+                                   _u64, _vp]),
+    "wl_drift_mdp": (C.c_int, [_P(WlDriftParams), _i32, _i64] + [_vp] * 12),
+    "wl_action_map": (C.c_int, [_P(WlActionParams), _i32, _vp, _vp, _vp, _vp, _vp]),
+    "wl_drift_reset": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _u64, _u64, _vp]),
+    "wl_drift_observe": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _vp, _u64, _u64, _vp]),
+    "wl_philox_uniform": (C.c_int, [_i32, _u64, _u64, C.c_uint32, _vp, _vp]),
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwheeledlab_amd.so")
+_lib = None
+
+
+def load(path: str | None = None):
+    """dlopen the HIP library and bind every declared symbol.  Raises HipExtensionMissing -- never falls back."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise HipExtensionMissing(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise HipExtensionMissing(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipExtensionMissing(f"{path} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    v = lib.wl_version()
+    if v != WL_ABI_VERSION:
+        raise HipExtensionMissing(f"{path} has ABI version {v}, python expects {WL_ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise WlError(f"{what} failed: {ERRORS.get(rc, rc)} ({rc})")

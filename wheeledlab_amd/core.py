@@ -1,0 +1,130 @@
+"""DriftBatch: device buffers of one shard of drift envs + thin calls into the C ABI.
+
+PyTorch is plumbing here: it owns the HBM allocations and the stream; every kernel is ours (csrc/wl_drift.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _abi as A
+from .params import MUSHR_CHASSIS_MASS, drift_params
+
+
+def stadium_reference_poses(u: torch.Tensor, track_radius: float = 0.8, straight: float = 0.8) -> torch.Tensor:
+    """Pre-sampled reset poses on the stadium centre line: arclength u*L -> (x, y, yaw rad), [3, P].
+    Follows reset_root_state_along_track.generate_reference_poses (wheeledlab_tasks/drifting/mdp/events.py:33-100):
+    four pieces -- right straight (yaw 90 deg), top arc, left straight (yaw 270 deg), bottom arc."""
+    r, s = track_radius, straight
+    d = u.double() * (2.0 * math.pi * r + 4.0 * s)
+    x, y, yaw = torch.empty_like(d), torch.empty_like(d), torch.empty_like(d)
+    b1, b2, b3 = 2 * s, 2 * s + math.pi * r, 4 * s + math.pi * r
+    m = d < b1
+    x[m], y[m], yaw[m] = r, d[m] - s, math.pi / 2
+    m = (d >= b1) & (d < b2)
+    a = (d[m] - b1) / r
+    x[m], y[m], yaw[m] = r * torch.cos(a), s + r * torch.sin(a), math.pi / 2 + a
+    m = (d >= b2) & (d < b3)
+    x[m], y[m], yaw[m] = -r, s - (d[m] - b2), 1.5 * math.pi
+    m = d >= b3
+    a = (d[m] - b3) / r
+    x[m], y[m], yaw[m] = -r * torch.cos(a), -s - r * torch.sin(a), 1.5 * math.pi + a
+    return torch.stack([x, y, yaw]).float()
+
+
+class DriftBatch:
+    """n drift envs resident on one GPU as a SoA state matrix [S_COUNT, stride] (fp32)."""
+
+    OBS_DIM = 14
+
+    def __init__(self, n_envs: int, device="cuda:0", params: A.WlDriftParams | None = None, seed: int = 42,
+                 env_offset: int = 0, randomize: bool = True):
+        self.lib = A.load()  # raises HipExtensionMissing -- no fallback
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise A.HipExtensionMissing("DriftBatch needs a HIP device (device='cuda:N'); there is no CPU path")
+        self.n = int(n_envs)
+        self.stride = ((self.n + 63) // 64) * 64
+        self.p = params if params is not None else drift_params()
+        self.seed = int(seed)
+        self.env_offset = int(env_offset)
+        self.step_count = 0
+        dev = self.device
+        self.state = torch.zeros(A.S_COUNT, self.stride, dtype=torch.float32, device=dev)
+        self.episode_len = torch.zeros(self.stride, dtype=torch.int32, device=dev)
+        self.metrics = torch.zeros(A.M_COUNT, dtype=torch.float32, device=dev)
+        self.obs = torch.zeros(self.n, self.OBS_DIM, dtype=torch.float32, device=dev)
+        self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.terminated = torch.zeros(self.n, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(self.n, dtype=torch.uint8, device=dev)
+        g = torch.Generator().manual_seed(self.seed)
+        # reference poses are drawn ONCE at construction (events.py:31,35)
+        self.ref_table = torch.zeros(3, 32, dtype=torch.float32)
+        self.ref_table[:, : self.p.num_ref_points] = stadium_reference_poses(torch.rand(self.p.num_ref_points, generator=g))
+        self.ref_table = self.ref_table.to(dev)
+        self._startup_events(g, randomize)
+        self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), self.ref_table.data_ptr(),
+                                    self.metrics.data_ptr(), self.stride, self.n, self.env_offset)
+        self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
+                                self.truncated.data_ptr())
+
+    # startup events (mushr_drift_env_cfg.py:98-119, 145-154)
+    def _startup_events(self, g: torch.Generator, randomize: bool):
+        s, n = self.state, self.stride
+        s[A.S_QW] = 1.0
+        if randomize:
+            nb = 20  # randomize_rigid_body_material: 20 buckets, mu_d <= mu_s ("make_consistent")
+            mu_s = torch.rand(nb, generator=g) * 0.2 + 0.3
+            mu_d = torch.minimum(torch.rand(nb, generator=g) * 0.2 + 0.3, mu_s)
+            b = torch.randint(0, nb, (n,), generator=g)
+            s[A.S_MU_S], s[A.S_MU_D] = mu_s[b].to(self.device), mu_d[b].to(self.device)
+            s[A.S_DAMP] = (torch.rand(n, generator=g) * 40.0 + 10.0).to(self.device)      # randomize_actuator_gains abs U(10,50)
+            s[A.S_MASS] = (MUSHR_CHASSIS_MASS + torch.rand(n, generator=g) * 0.2 + 0.3).to(self.device)  # += U(0.3,0.5)
+        else:
+            s[A.S_MU_S], s[A.S_MU_D], s[A.S_DAMP], s[A.S_MASS] = 0.4, 0.4, 30.0, MUSHR_CHASSIS_MASS + 0.4
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, mask: torch.Tensor | None = None):
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        A.check(self.lib.wl_drift_reset(C.byref(self.p), C.byref(self._bufs), None if m is None else m.data_ptr(),
+                                        self.seed, self.step_count, self._stream()), "wl_drift_reset")
+
+    def observe(self, noise: torch.Tensor | None = None) -> torch.Tensor:
+        A.check(self.lib.wl_drift_observe(C.byref(self.p), C.byref(self._bufs),
+                                          None if noise is None else noise.data_ptr(), self.obs.data_ptr(), self.seed,
+                                          self.step_count, self._stream()), "wl_drift_observe")
+        return self.obs
+
+    def step(self, actions: torch.Tensor, noise: torch.Tensor | None = None):
+        """actions [n,2] fp32 on device -> (obs [n,14], reward [n], terminated u8 [n], truncated u8 [n]) (views)"""
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.shape != (self.n, 2):
+            actions = actions.to(torch.float32).reshape(self.n, 2).contiguous()
+        A.check(self.lib.wl_drift_step(C.byref(self.p), C.byref(self._bufs), actions.data_ptr(),
+                                       None if noise is None else noise.data_ptr(), C.byref(self._out), self.seed,
+                                       self.step_count, self._stream()), "wl_drift_step")
+        self.step_count += 1
+        return self.obs, self.reward, self.terminated, self.truncated
+
+    def rollout(self, actions: torch.Tensor, obs_out: torch.Tensor | None = None, rew_out: torch.Tensor | None = None,
+                term_out: torch.Tensor | None = None, trunc_out: torch.Tensor | None = None):
+        """K fused steps with pre-staged actions [K,n,2]; optional [K,...] output storage (else overwrite)."""
+        K = actions.shape[0]
+        assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
+        if obs_out is not None:
+            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr())
+            os_, vs_ = self.n * self.OBS_DIM, self.n
+        else:
+            out, os_, vs_ = self._out, 0, 0
+        A.check(self.lib.wl_drift_rollout(C.byref(self.p), C.byref(self._bufs), actions.data_ptr(), C.byref(out), os_,
+                                          vs_, K, self.seed, self.step_count, self._stream()), "wl_drift_rollout")
+        self.step_count += K
+
+    def read_metrics(self, zero: bool = True) -> torch.Tensor:
+        m = self.metrics.clone()
+        if zero:
+            self.metrics.zero_()
+        return m

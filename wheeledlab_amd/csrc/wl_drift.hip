@@ -1,0 +1,481 @@
+// wl_drift.hip -- fused drift-task env.step() for gfx950 + the C ABI around it (include/wheeledlab_amd.h).
+//
+// One launch = one env.step() for all envs: action term -> decimation x (actuators + rigid body + tyres) ->
+// terminations -> rewards -> in-kernel reset -> interval pushes -> observation.  One lane owns one env; the SoA
+// state matrix is read once (coalesced 256 B per wavefront per row) and written once per env-step, all physics
+// sub-steps stay in VGPRs.  The [n][14] observation is transposed through LDS so the stores are contiguous per
+// wavefront; episode metrics are folded with LDS atomics and leave the block as <=16 global atomics.
+#include <hip/hip_runtime.h>
+
+#include "../../include/wheeledlab_amd.h"
+#include "wl_drift_terms.h"
+#include "wl_rng.h"
+#include "wl_vehicle.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kObsDim = 14;
+constexpr int kObsPad = 15;  // odd LDS row pitch: the transposing writes are bank-conflict free
+
+struct Rows {  // row accessor of the SoA state matrix
+    float* base;
+    int64_t stride;
+    WL_DEV float& operator()(int row, int env) const { return base[row * stride + env]; }
+};
+
+WL_DEV V3 ld3(const Rows& s, int row, int e) { return v3(s(row, e), s(row + 1, e), s(row + 2, e)); }
+WL_DEV void st3(const Rows& s, int row, int e, V3 v) {
+    s(row, e) = v.x;
+    s(row + 1, e) = v.y;
+    s(row + 2, e) = v.z;
+}
+
+struct ResetDraw {
+    V3 pos;
+    Quat q;
+    float timer_hf, timer_lf;
+};
+
+// reset_root_state_along_track.__call__ (drifting/mdp/events.py:119-133) + EventManager.reset interval re-arm
+WL_DEV ResetDraw draw_reset(const WlDriftParams& p, const float* __restrict__ ref, uint32_t gid, uint64_t step,
+                            uint64_t seed) {
+    const F4 u = philox_uniform4(gid, step, WL_RS_RESET, seed);
+    const int idx = min((int)(u.x * (float)p.num_ref_points), p.num_ref_points - 1);
+    ResetDraw r;
+    r.pos = v3(fmaf(2.f * u.y - 1.f, p.pos_noise, ref[idx]), fmaf(2.f * u.z - 1.f, p.pos_noise, ref[32 + idx]), 0.f);
+    const float yaw = fmaf(2.f * u.w - 1.f, p.yaw_noise, ref[64 + idx]);
+    float s, c;
+    sincosf(0.5f * yaw, &s, &c);
+    r.q = Quat{c, 0.f, 0.f, s};
+    const F4 t = philox_uniform4(gid, step, WL_RS_TIMERS, seed);
+    r.timer_hf = fmaf(t.x, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
+    r.timer_lf = fmaf(t.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
+    return r;
+}
+
+// BlindObsCfg.PolicyCfg (wheeledlab_tasks/common/observations.py:24-54) into this wave's LDS tile
+WL_DEV void write_obs_row(float* row, const WlDriftParams& p, V3 pos, Quat q, V3 vb, V3 wb, float a0, float a1,
+                          const float* nz /* 12 normals or nullptr */) {
+    const V3 e = euler_xyz_from_quat(q);
+    float o[12] = {pos.x, pos.y, pos.z, e.x, e.y, e.z, vb.x, vb.y, vb.z, wb.x, wb.y, wb.z};
+    if (nz) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) o[k] = fmaf(p.noise_std[k / 3], nz[k], o[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) row[k] = o[k];
+    row[12] = clampf(a0, -1.f, 1.f);
+    row[13] = clampf(a1, -1.f, 1.f);
+}
+
+WL_DEV void gen_normals(float nz[12], uint32_t gid, uint64_t step, uint64_t seed) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + s, seed);
+        box_muller(u.x, u.y, nz[4 * s + 0], nz[4 * s + 1]);
+        box_muller(u.z, u.w, nz[4 * s + 2], nz[4 * s + 3]);
+    }
+}
+
+// flush this block's LDS obs tile ([kBlock][kObsPad]) to obs[n][14]: contiguous dword stores per wavefront
+WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0, int n) {
+    const int n_valid = min(kBlock, n - block_env0);
+    const int total = n_valid * kObsDim;
+    float* dst = obs + (int64_t)block_env0 * kObsDim;
+    for (int f = threadIdx.x; f < total; f += kBlock) {
+        const int e = f / kObsDim, k = f - e * kObsDim;
+        dst[f] = tile[e * kObsPad + k];
+    }
+}
+
+template <class Ground>
+__global__ void __launch_bounds__(kBlock) drift_step_kernel(const WlDriftParams p, const WlEnvBuffers b,
+                                                            const float2* __restrict__ actions,
+                                                            const float* __restrict__ noise, const WlStepOut out,
+                                                            const uint64_t seed, const uint64_t step, const Ground ground) {
+    __shared__ float tile[kBlock * kObsPad];
+    __shared__ float blk_metrics[WL_M_COUNT];
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = e < b.n_envs;
+    if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
+    __syncthreads();
+    const Rows S{b.state, b.stride};
+    const WlVehicleParams& vp = p.vehicle;
+    bool any_done = false;
+    if (active) {
+        const uint32_t gid = (uint32_t)(b.env_offset + e);
+        // ---- action manager: ClipAction + process_actions + joint targets (once per env-step) ----
+        float2 a = actions[e];
+        float v_t, delta;
+        process_action(p.action, a.x, a.y, v_t, delta);
+        EnvConst ec;
+        joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
+        ec.mass = S(WL_S_MASS, e);
+        ec.inv_mass = rcp(ec.mass);
+        ec.mu_s = S(WL_S_MU_S, e) * vp.ground_mu_s;
+        ec.mu_d = fminf(S(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
+        ec.damp = S(WL_S_DAMP, e);
+        ec.Ib = v3(ec.mass * vp.gyr_x * vp.gyr_x, ec.mass * vp.gyr_y * vp.gyr_y, ec.mass * vp.gyr_z * vp.gyr_z);
+        ec.inv_Ib = v3(rcp(ec.Ib.x), rcp(ec.Ib.y), rcp(ec.Ib.z));
+        // ---- load state ----
+        VehState s;
+        V3 pos = ld3(S, WL_S_PX, e);
+        s.q = Quat{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+        s.v = ld3(S, WL_S_VX, e);
+        V3 ww = ld3(S, WL_S_WX, e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
+        s.th = S(WL_S_STEER_POS, e);
+        s.om = S(WL_S_STEER_VEL, e);
+        float timer_hf = S(WL_S_TIMER_HF, e), timer_lf = S(WL_S_TIMER_LF, e);
+        int ep_len = b.episode_len[e];
+        {
+            const Mat3 R = mat_from_quat(s.q);
+            s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);  // CoM = link origin + R (0,0,cg_z)
+            s.wb = mul_t(R, ww);
+        }
+        // ---- physics: decimation x substeps, everything in registers ----
+        const int n_sub = p.decimation * vp.substeps;
+        const float h = p.sim_dt / (float)vp.substeps, inv_h = rcp(h);
+        for (int k = 0; k < n_sub; ++k) vehicle_substep(vp, ec, s, h, inv_h, ground);
+        const Mat3 R = mat_from_quat(s.q);
+        ww = mul(R, s.wb);
+        pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
+        // ---- terminations (time_out, cart_off_track) + non-finite guard ----
+        ep_len += 1;
+        const bool truncated = ep_len >= p.max_episode_length;
+        const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y +
+                          ww.z + s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3] + s.th + s.om;
+        const bool finite = __builtin_isfinite(chk);
+        const bool terminated = !finite || cart_off_track(pos.x, pos.y, p.straight, p.r_in, p.r_out);
+        // ---- rewards on the post-physics state ----
+        V3 vb = mul_t(R, s.v);
+        DriftTerms tm = drift_terms(p, pos, vb, s.wb, ww.z, s.th, terminated, truncated);
+        const float step_dt = p.sim_dt * (float)p.decimation;
+        float reward = 0.f;
+        float epsum[WL_DR_NTERMS];
+#pragma unroll
+        for (int i = 0; i < WL_DR_NTERMS; ++i) {
+            const float w = p.weight[i];
+            const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;  // RewardManager skips w == 0
+            reward += c;
+            epsum[i] = p.log_episode_sums ? S(WL_S_EPSUM0 + i, e) + c : 0.f;
+        }
+        out.reward[e] = reward;
+        out.terminated[e] = terminated ? 1 : 0;
+        out.truncated[e] = truncated ? 1 : 0;
+        // ---- reset (done envs) ----
+        const bool done = terminated || truncated;
+        float a0 = a.x, a1 = a.y;
+        if (done) {
+            any_done = true;
+#pragma unroll
+            for (int i = 0; i < WL_DR_NTERMS; ++i) {
+                atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
+                epsum[i] = 0.f;
+            }
+            atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
+            if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
+            if (terminated) atomicAdd(&blk_metrics[WL_M_TERM0], 1.f);
+            if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
+            atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
+            if (!finite) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
+                s.th = s.om = 0.f;
+            }
+            const ResetDraw rd = draw_reset(p, b.ref_poses, gid, step, seed);
+            pos = rd.pos;
+            s.q = rd.q;
+            s.v = v3(0.f, 0.f, 0.f);
+            ww = v3(0.f, 0.f, 0.f);
+            timer_hf = rd.timer_hf;
+            timer_lf = rd.timer_lf;
+            ep_len = 0;
+            a0 = a1 = 0.f;  // ActionManager.reset zeroes `action` (last_action) of reset envs
+        }
+        // ---- interval events: push_by_setting_velocity (mushr_drift_env_cfg.py:121-143) ----
+        if (p.enable_pushes) {
+            timer_hf -= step_dt;
+            if (timer_hf < 1e-6f) {
+                const F4 u = philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
+                s.v.x = fmaf(2.f * u.x - 1.f, p.hf_vel_x, s.v.x);
+                s.v.y = fmaf(2.f * u.y - 1.f, p.hf_vel_y, s.v.y);
+                ww.z = fmaf(2.f * u.z - 1.f, p.hf_vel_yaw, ww.z);
+                timer_hf = fmaf(u.w, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
+            }
+            timer_lf -= step_dt;
+            if (timer_lf < 1e-6f) {
+                const F4 u = philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
+                ww.z = fmaf(2.f * u.x - 1.f, p.lf_vel_yaw, ww.z);
+                timer_lf = fmaf(u.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
+            }
+        }
+        // ---- store state ----
+        st3(S, WL_S_PX, e, pos);
+        S(WL_S_QW, e) = s.q.w;
+        S(WL_S_QX, e) = s.q.x;
+        S(WL_S_QY, e) = s.q.y;
+        S(WL_S_QZ, e) = s.q.z;
+        st3(S, WL_S_VX, e, s.v);
+        st3(S, WL_S_WX, e, ww);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S(WL_S_WHEEL_BL + i, e) = s.wheel[i];
+        S(WL_S_STEER_POS, e) = s.th;
+        S(WL_S_STEER_VEL, e) = s.om;
+        S(WL_S_ACT0, e) = a0;
+        S(WL_S_ACT1, e) = a1;
+        S(WL_S_TIMER_HF, e) = timer_hf;
+        S(WL_S_TIMER_LF, e) = timer_lf;
+        if (p.log_episode_sums) {
+#pragma unroll
+            for (int i = 0; i < WL_DR_NTERMS; ++i) S(WL_S_EPSUM0 + i, e) = epsum[i];
+        }
+        b.episode_len[e] = ep_len;
+        // ---- observation of the post-reset state ----
+        const Mat3 R2 = mat_from_quat(s.q);
+        vb = mul_t(R2, s.v);
+        const V3 wb2 = mul_t(R2, ww);
+        float nz[12];
+        const float* nzp = nullptr;
+        if (p.enable_corruption) {
+            if (noise) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) nz[k] = noise[k * b.stride + e];
+            } else {
+                gen_normals(nz, gid, step, seed);
+            }
+            nzp = nz;
+        }
+        write_obs_row(&tile[threadIdx.x * kObsPad], p, pos, s.q, vb, wb2, a0, a1, nzp);
+    }
+    __syncthreads();
+    flush_obs(tile, out.obs, blockIdx.x * kBlock, b.n_envs);
+    if (threadIdx.x < WL_M_COUNT) {
+        const float m = blk_metrics[threadIdx.x];
+        if (m != 0.f) atomicAdd(&b.metrics[threadIdx.x], m);
+    }
+    (void)any_done;
+}
+
+// ---- terms only, on caller-supplied state tensors (parity entry point) -----------------------------------
+__global__ void __launch_bounds__(kBlock) drift_mdp_kernel(const WlDriftParams p, int n, int64_t stride,
+                                                           const float* __restrict__ pos, const float* __restrict__ quat,
+                                                           const float* __restrict__ vb_, const float* __restrict__ wb_,
+                                                           const float* __restrict__ ww_, const float* __restrict__ steer,
+                                                           const float* __restrict__ act, const uint8_t* __restrict__ timed_out,
+                                                           float* __restrict__ terms, float* __restrict__ reward,
+                                                           uint8_t* __restrict__ terminated, float* __restrict__ obs) {
+    __shared__ float tile[kBlock * kObsPad];
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e < n) {
+        const V3 P = v3(pos[e], pos[stride + e], pos[2 * stride + e]);
+        const Quat q{quat[e], quat[stride + e], quat[2 * stride + e], quat[3 * stride + e]};
+        const V3 vb = v3(vb_[e], vb_[stride + e], vb_[2 * stride + e]);
+        const V3 wb = v3(wb_[e], wb_[stride + e], wb_[2 * stride + e]);
+        const float wwz = ww_[2 * stride + e];
+        const float sm = 0.5f * (steer[e] + steer[stride + e]);
+        const bool to = timed_out ? timed_out[e] != 0 : false;
+        const bool term = cart_off_track(P.x, P.y, p.straight, p.r_in, p.r_out);
+        const DriftTerms tm = drift_terms(p, P, vb, wb, wwz, sm, term, to);
+        const float step_dt = p.sim_dt * (float)p.decimation;
+        float r = 0.f;
+#pragma unroll
+        for (int i = 0; i < WL_DR_NTERMS; ++i) {
+            terms[i * stride + e] = tm.t[i];
+            if (p.weight[i] != 0.f) r += tm.t[i] * p.weight[i] * step_dt;
+        }
+        reward[e] = r;
+        terminated[e] = term ? 1 : 0;
+        write_obs_row(&tile[threadIdx.x * kObsPad], p, P, q, vb, wb, act[e], act[stride + e], nullptr);
+    }
+    __syncthreads();
+    flush_obs(tile, obs, blockIdx.x * kBlock, n);
+}
+
+__global__ void __launch_bounds__(kBlock) action_map_kernel(const WlActionParams ap, int n, const float2* __restrict__ actions,
+                                                            float2* __restrict__ processed, float2* __restrict__ steer_target,
+                                                            float4* __restrict__ wheel_target) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n) return;
+    float2 a = actions[e];
+    float v, delta, st, w[4];
+    process_action(ap, a.x, a.y, v, delta);
+    joint_targets(ap, v, delta, st, w);
+    processed[e] = make_float2(v, delta);
+    steer_target[e] = make_float2(st, st);
+    wheel_target[e] = make_float4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ void __launch_bounds__(kBlock) drift_reset_kernel(const WlDriftParams p, const WlEnvBuffers b,
+                                                             const uint8_t* __restrict__ mask, uint64_t seed, uint64_t step) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= b.n_envs) return;
+    if (mask && !mask[e]) return;
+    const Rows S{b.state, b.stride};
+    const ResetDraw rd = draw_reset(p, b.ref_poses, (uint32_t)(b.env_offset + e), step, seed);
+    st3(S, WL_S_PX, e, rd.pos);
+    S(WL_S_QW, e) = rd.q.w;
+    S(WL_S_QX, e) = rd.q.x;
+    S(WL_S_QY, e) = rd.q.y;
+    S(WL_S_QZ, e) = rd.q.z;
+    st3(S, WL_S_VX, e, v3(0.f, 0.f, 0.f));
+    st3(S, WL_S_WX, e, v3(0.f, 0.f, 0.f));
+    S(WL_S_ACT0, e) = 0.f;
+    S(WL_S_ACT1, e) = 0.f;
+    S(WL_S_TIMER_HF, e) = rd.timer_hf;
+    S(WL_S_TIMER_LF, e) = rd.timer_lf;
+#pragma unroll
+    for (int i = 0; i < WL_MAX_REW_TERMS; ++i) S(WL_S_EPSUM0 + i, e) = 0.f;
+    b.episode_len[e] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock) drift_observe_kernel(const WlDriftParams p, const WlEnvBuffers b,
+                                                               const float* __restrict__ noise, float* __restrict__ obs,
+                                                               uint64_t seed, uint64_t step) {
+    __shared__ float tile[kBlock * kObsPad];
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e < b.n_envs) {
+        const Rows S{b.state, b.stride};
+        const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+        const Mat3 R = mat_from_quat(q);
+        const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
+        float nz[12];
+        const float* nzp = nullptr;
+        if (p.enable_corruption) {
+            if (noise) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) nz[k] = noise[k * b.stride + e];
+            } else {
+                gen_normals(nz, (uint32_t)(b.env_offset + e), step, seed);
+            }
+            nzp = nz;
+        }
+        write_obs_row(&tile[threadIdx.x * kObsPad], p, ld3(S, WL_S_PX, e), q, vb, wb, S(WL_S_ACT0, e), S(WL_S_ACT1, e), nzp);
+    }
+    __syncthreads();
+    flush_obs(tile, obs, blockIdx.x * kBlock, b.n_envs);
+}
+
+__global__ void philox_uniform_kernel(int n, uint64_t seed, uint64_t step, uint32_t stream_id, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const F4 u = philox_uniform4((uint32_t)e, step, stream_id, seed);
+    out[e] = u.x;
+    out[n + e] = u.y;
+    out[2 * n + e] = u.z;
+    out[3 * n + e] = u.w;
+}
+
+inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? WL_OK : WL_ELAUNCH; }
+
+int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
+    if (!p || !b || !b->state || !b->episode_len || !b->ref_poses || !b->metrics) return WL_EINVAL;
+    if (b->n_envs <= 0 || b->stride < b->n_envs) return WL_EINVAL;
+    if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
+    if (p->decimation <= 0 || p->vehicle.substeps <= 0 || p->num_ref_points <= 0 || p->num_ref_points > 32) return WL_EINVAL;
+    if (!(p->sim_dt > 0.f)) return WL_EINVAL;
+    return WL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wl_version(void) { return WL_ABI_VERSION; }
+
+int wl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return WL_ENODEV;
+    return n;
+}
+
+const char* wl_strerror(int code) {
+    switch (code) {
+        case WL_OK: return "ok";
+        case WL_EINVAL: return "invalid argument";
+        case WL_ELAUNCH: return "kernel launch failed";
+        case WL_EALIGN: return "buffer alignment / stride violation";
+        case WL_ENODEV: return "no HIP device";
+        default: return "unknown error";
+    }
+}
+
+int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* actions, const float* noise,
+                  const WlStepOut* out, uint64_t seed, uint64_t step, void* stream) {
+    int rc = check_buffers(p, b);
+    if (rc != WL_OK) return rc;
+    if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated) return WL_EINVAL;
+    drift_step_kernel<FlatGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
+        *p, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{});
+    return launch_status();
+}
+
+int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float* actions, const WlStepOut* out,
+                     int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps, uint64_t seed, uint64_t step0,
+                     void* stream) {
+    int rc = check_buffers(p, b);
+    if (rc != WL_OK) return rc;
+    if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
+    const int grid = grid_for(b->n_envs);
+    for (int k = 0; k < n_steps; ++k) {
+        WlStepOut o = *out;
+        o.obs += k * obs_step_stride;
+        o.reward += k * vec_step_stride;
+        o.terminated += k * vec_step_stride;
+        o.truncated += k * vec_step_stride;
+        drift_step_kernel<FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+            *p, *b, (const float2*)(actions + (int64_t)k * b->n_envs * 2), nullptr, o, seed, step0 + (uint64_t)k,
+            FlatGround{});
+    }
+    return launch_status();
+}
+
+int wl_drift_mdp(const WlDriftParams* p, int32_t n, int64_t stride, const float* pos, const float* quat,
+                 const float* lin_vel_b, const float* ang_vel_b, const float* ang_vel_w, const float* steer_pos,
+                 const float* last_action, const uint8_t* timed_out, float* terms, float* reward, uint8_t* terminated,
+                 float* obs, void* stream) {
+    if (!p || n <= 0 || stride < n || !pos || !quat || !lin_vel_b || !ang_vel_b || !ang_vel_w || !steer_pos ||
+        !last_action || !terms || !reward || !terminated || !obs)
+        return WL_EINVAL;
+    drift_mdp_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(*p, n, stride, pos, quat, lin_vel_b, ang_vel_b,
+                                                                       ang_vel_w, steer_pos, last_action, timed_out, terms,
+                                                                       reward, terminated, obs);
+    return launch_status();
+}
+
+int wl_action_map(const WlActionParams* a, int32_t n, const float* actions, float* processed, float* steer_target,
+                  float* wheel_target, void* stream) {
+    if (!a || n <= 0 || !actions || !processed || !steer_target || !wheel_target) return WL_EINVAL;
+    if (((uintptr_t)wheel_target & 15u) || ((uintptr_t)actions & 7u)) return WL_EALIGN;
+    action_map_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(*a, n, (const float2*)actions, (float2*)processed,
+                                                                        (float2*)steer_target, (float4*)wheel_target);
+    return launch_status();
+}
+
+int wl_drift_reset(const WlDriftParams* p, const WlEnvBuffers* b, const uint8_t* mask, uint64_t seed, uint64_t step,
+                   void* stream) {
+    int rc = check_buffers(p, b);
+    if (rc != WL_OK) return rc;
+    drift_reset_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, mask, seed, step);
+    return launch_status();
+}
+
+int wl_drift_observe(const WlDriftParams* p, const WlEnvBuffers* b, const float* noise, float* obs, uint64_t seed,
+                     uint64_t step, void* stream) {
+    int rc = check_buffers(p, b);
+    if (rc != WL_OK) return rc;
+    if (!obs) return WL_EINVAL;
+    drift_observe_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, noise, obs, seed, step);
+    return launch_status();
+}
+
+int wl_philox_uniform(int32_t n, uint64_t seed, uint64_t step, uint32_t stream_id, float* out, void* stream) {
+    if (n <= 0 || !out) return WL_EINVAL;
+    philox_uniform_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, seed, step, stream_id, out);
+    return launch_status();
+}
+
+}  // extern "C"

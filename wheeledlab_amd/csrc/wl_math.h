@@ -1,0 +1,64 @@
+// wl_math.h -- small device math for the env kernels (gfx950).  One lane = one env; everything lives in VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WL_DEV __device__ __forceinline__
+
+struct V3 {
+    float x, y, z;
+};
+WL_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+WL_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+WL_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+WL_DEV V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+WL_DEV float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+WL_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+WL_DEV V3 fma3(float s, V3 a, V3 b) { return V3{fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)}; }
+
+// hardware reciprocal / rsqrt / sqrt (1 ulp class): the path is not IEEE-division sensitive, parity budget is 1e-5
+WL_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+WL_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+WL_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+WL_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+struct Quat {
+    float w, x, y, z;
+};
+
+// rotation matrix rows (body -> world) of a unit quaternion
+struct Mat3 {
+    V3 r0, r1, r2;
+};
+WL_DEV Mat3 mat_from_quat(Quat q) {
+    float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
+    float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
+    float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+    Mat3 m;
+    m.r0 = v3(1.f - 2.f * (yy + zz), 2.f * (xy - wz), 2.f * (xz + wy));
+    m.r1 = v3(2.f * (xy + wz), 1.f - 2.f * (xx + zz), 2.f * (yz - wx));
+    m.r2 = v3(2.f * (xz - wy), 2.f * (yz + wx), 1.f - 2.f * (xx + yy));
+    return m;
+}
+WL_DEV V3 mul(const Mat3& m, V3 v) { return v3(dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)); }
+WL_DEV V3 mul_t(const Mat3& m, V3 v) {
+    return v3(fmaf(m.r0.x, v.x, fmaf(m.r1.x, v.y, m.r2.x * v.z)), fmaf(m.r0.y, v.x, fmaf(m.r1.y, v.y, m.r2.y * v.z)),
+              fmaf(m.r0.z, v.x, fmaf(m.r1.z, v.y, m.r2.z * v.z)));
+}
+
+#define WL_TWO_PI 6.28318530717958647692f
+#define WL_PI 3.14159265358979323846f
+
+// python-style modulo into [0, 2pi) for |a| <= pi (atan2 / asin ranges)
+WL_DEV float wrap_2pi(float a) {
+    return a < 0.f ? a + WL_TWO_PI : a;  // == torch.remainder(a, 2pi) on this range (may round to 2pi itself)
+}
+
+// IsaacLab euler_xyz_from_quat (un-vendored; reference call site wheeledlab/envs/mdp/observations.py:11)
+WL_DEV V3 euler_xyz_from_quat(Quat q) {
+    float roll = atan2f(2.f * (q.w * q.x + q.y * q.z), 1.f - 2.f * (q.x * q.x + q.y * q.y));
+    float sp = 2.f * (q.w * q.y - q.z * q.x);
+    float pitch = fabsf(sp) >= 1.f ? copysignf(0.5f * WL_PI, sp) : asinf(sp);
+    float yaw = atan2f(2.f * (q.w * q.z + q.x * q.y), 1.f - 2.f * (q.y * q.y + q.z * q.z));
+    return v3(wrap_2pi(roll), wrap_2pi(pitch), wrap_2pi(yaw));
+}

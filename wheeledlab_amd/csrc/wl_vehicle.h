@@ -1,0 +1,153 @@
+// wl_vehicle.h -- rigid body + 4 tyre contacts, one integrator sub-step, all state in registers.
+// Replaces the PhysX articulation step of the reference (mushr_drift_env_cfg.py:393-394); model derivation in
+// DESIGN.md section 4, executable spec in oracle/vehicle.py.  Actuator constants: wheeledlab_assets/hound.py:4-52.
+#pragma once
+#include "../../include/wheeledlab_amd.h"
+#include "wl_math.h"
+
+struct VehState {
+    V3 x;        // CoM position, world
+    Quat q;      // body -> world
+    V3 v;        // CoM linear velocity, world
+    V3 wb;       // angular velocity, body frame
+    float wheel[4];  // spin, order bl, br, fl, fr
+    float th, om;    // steer angle / rate
+};
+
+struct EnvConst {   // per-env constants hoisted out of the sub-step loop
+    float mass, inv_mass;
+    float mu_s, mu_d;          // combined (wheel x ground) friction
+    float damp;                // throttle damping of driven wheels
+    V3 Ib, inv_Ib;             // body inertia diag
+    float steer_target;
+    float wheel_target[4];
+};
+
+struct FlatGround {
+    WL_DEV void sample(float, float, float& zg, V3& n) const {
+        zg = 0.f;
+        n = v3(0.f, 0.f, 1.f);
+    }
+};
+
+template <int WHEEL>  // 0 bl, 1 br, 2 fl, 3 fr
+WL_DEV void wheel_force(const WlVehicleParams& vp, const EnvConst& ec, const Mat3& R, V3 x, V3 v, V3 ww, float cs,
+                        float sn, float h, float inv_h, float zg, V3 n, float& w_spin, V3& Ftot, V3& Ttot) {
+    constexpr bool front = WHEEL >= 2;
+    constexpr bool left = (WHEEL & 1) == 0;
+    const float r = vp.wheel_radius;
+    const V3 pb = v3(front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, left ? vp.half_track : -vp.half_track,
+                     vp.wheel_z - vp.cg_z);
+    const V3 arm_c = mul(R, pb);
+    const float cz = x.z + arm_c.z;
+    const float pen = r - (cz - zg) * n.z;
+    const V3 arm = fma3(-r, n, arm_c);
+    const V3 vcp = v + cross(ww, arm);
+    const float vn = dot(vcp, n);
+    const float Fz = pen > 0.f ? fmaxf(fmaf(vp.susp_k, pen, -vp.susp_c * vn), 0.f) : 0.f;
+    // wheel heading projected into the contact plane
+    V3 hw = front ? v3(fmaf(R.r0.x, cs, R.r0.y * sn), fmaf(R.r1.x, cs, R.r1.y * sn), fmaf(R.r2.x, cs, R.r2.y * sn))
+                  : v3(R.r0.x, R.r1.x, R.r2.x);
+    V3 t = fma3(-dot(hw, n), n, hw);
+    const V3 tx = rsq(dot(t, t)) * t;
+    const V3 ty = cross(n, tx);
+    const float vcx = dot(vcp, tx), vcy = dot(vcp, ty);
+    const float w_i = w_spin;
+    const float vden = fmaxf(vp.v_min, vp.slip_peak * fmaxf(fabsf(vcx), fabsf(w_i * r)));
+    const float inv_vden = rcp(vden);
+    const float sx = (w_i * r - vcx) * inv_vden, sy = -vcy * inv_vden;
+    const float sig = fsqrt(fmaf(sx, sx, sy * sy));
+    const float inv_sig = rcp(fmaxf(sig, 1.f));
+    const float gq = sig <= 1.f ? ec.mu_s * (2.f - sig) : fmaf(ec.mu_s - ec.mu_d, inv_sig, ec.mu_d) * inv_sig;
+    const float K = Fz * gq * inv_vden;
+    const bool driven = (vp.drive == 1) || !front;
+    const float d = driven ? ec.damp : 0.f;
+    const float wt = ec.wheel_target[WHEEL];
+    // DC-motor torque window at the current spin (IsaacLab DCMotor, hound.py:13-21)
+    const float rel = w_i * rcp(vp.motor_vel_limit);
+    const float tau_hi = clampf(vp.motor_sat * (1.f - rel), 0.f, vp.motor_limit);
+    const float tau_lo = clampf(vp.motor_sat * (-1.f - rel), -vp.motor_limit, 0.f);
+    const float Iw_h = vp.wheel_inertia * inv_h;
+    // implicit spin update with the tyre's secant stiffness (unconditionally stable)
+    const float A = Iw_h + vp.wheel_damping + K * r * r;
+    const float rhs0 = fmaf(Iw_h, w_i, r * K * vcx);
+    const float w_u = fmaf(d, wt, rhs0) * rcp(A + d);
+    const float tau = clampf(d * (wt - w_u), tau_lo, tau_hi);
+    float w_n = (rhs0 + tau) * rcp(A);
+    float Fx = K * fmaf(w_n, r, -vcx);
+    float Fy = -K * vcy;
+    const float Fmax = ec.mu_s * Fz;
+    const float mag2 = fmaf(Fx, Fx, Fy * Fy);
+    if (mag2 > Fmax * Fmax) {   // friction-circle saturation: re-solve the wheel against the force actually applied
+        const float scale = Fmax * rsq(fmaxf(mag2, 1e-30f));
+        Fx *= scale;
+        Fy *= scale;
+        const float A2 = Iw_h + vp.wheel_damping;
+        const float rhs2 = fmaf(Iw_h, w_i, -r * Fx);
+        const float w_u2 = fmaf(d, wt, rhs2) * rcp(A2 + d);
+        const float tau2 = clampf(d * (wt - w_u2), tau_lo, tau_hi);
+        w_n = (rhs2 + tau2) * rcp(A2);
+    }
+    w_spin = w_n;
+    const V3 Fi = fma3(Fz, n, fma3(Fx, tx, Fy * ty));
+    Ftot = Ftot + Fi;
+    Ttot = Ttot + cross(arm, Fi);
+}
+
+template <class Ground>
+WL_DEV void vehicle_substep(const WlVehicleParams& vp, const EnvConst& ec, VehState& s, float h, float inv_h,
+                            const Ground& ground) {
+    // steering: implicit PD drive, effort- and rate-limited (hound.py:5-12)
+    {
+        const float invJ = rcp(vp.steer_inertia);
+        const float e = ec.steer_target - s.th;
+        float om_n = fmaf(h * vp.steer_kp * invJ, e, s.om) * rcp(1.f + h * vp.steer_kd * invJ + h * h * vp.steer_kp * invJ);
+        const float tau = clampf(vp.steer_inertia * (om_n - s.om) * inv_h, -vp.steer_effort, vp.steer_effort);
+        om_n = clampf(fmaf(h * invJ, tau, s.om), -vp.steer_vel_limit, vp.steer_vel_limit);
+        s.th = fmaf(h, om_n, s.th);
+        s.om = om_n;
+    }
+    const Mat3 R = mat_from_quat(s.q);
+    const V3 ww = mul(R, s.wb);
+    float sn, cs;
+    sincosf(s.th, &sn, &cs);
+    V3 F = v3(0.f, 0.f, 0.f), T = v3(0.f, 0.f, 0.f);
+    // ground under each wheel centre
+    float zg[4];
+    V3 nn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool front = i >= 2, left = (i & 1) == 0;
+        const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;
+        const float bz = vp.wheel_z - vp.cg_z;
+        const float cx = s.x.x + fmaf(R.r0.x, bx, fmaf(R.r0.y, by, R.r0.z * bz));
+        const float cy = s.x.y + fmaf(R.r1.x, bx, fmaf(R.r1.y, by, R.r1.z * bz));
+        ground.sample(cx, cy, zg[i], nn[i]);
+    }
+    wheel_force<0>(vp, ec, R, s.x, s.v, ww, cs, sn, h, inv_h, zg[0], nn[0], s.wheel[0], F, T);
+    wheel_force<1>(vp, ec, R, s.x, s.v, ww, cs, sn, h, inv_h, zg[1], nn[1], s.wheel[1], F, T);
+    wheel_force<2>(vp, ec, R, s.x, s.v, ww, cs, sn, h, inv_h, zg[2], nn[2], s.wheel[2], F, T);
+    wheel_force<3>(vp, ec, R, s.x, s.v, ww, cs, sn, h, inv_h, zg[3], nn[3], s.wheel[3], F, T);
+    F.z -= ec.mass * vp.gravity;
+    s.v = fma3(h * ec.inv_mass, F, s.v);
+    const V3 Tb = mul_t(R, T);
+    const V3 Iw = v3(ec.Ib.x * s.wb.x, ec.Ib.y * s.wb.y, ec.Ib.z * s.wb.z);
+    const V3 gyro = cross(s.wb, Iw);
+    s.wb = v3(fmaf(h * ec.inv_Ib.x, Tb.x - gyro.x, s.wb.x), fmaf(h * ec.inv_Ib.y, Tb.y - gyro.y, s.wb.y),
+              fmaf(h * ec.inv_Ib.z, Tb.z - gyro.z, s.wb.z));
+    const V3 w2 = mul(R, s.wb);
+    s.x = fma3(h, s.v, s.x);
+    const float hh = 0.5f * h;
+    Quat q = s.q;
+    Quat dq;
+    dq.w = -w2.x * q.x - w2.y * q.y - w2.z * q.z;
+    dq.x = w2.x * q.w + w2.y * q.z - w2.z * q.y;
+    dq.y = -w2.x * q.z + w2.y * q.w + w2.z * q.x;
+    dq.z = w2.x * q.y - w2.y * q.x + w2.z * q.w;
+    q.w = fmaf(hh, dq.w, q.w);
+    q.x = fmaf(hh, dq.x, q.x);
+    q.y = fmaf(hh, dq.y, q.y);
+    q.z = fmaf(hh, dq.z, q.z);
+    const float inv_n = rsq(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    s.q = Quat{q.w * inv_n, q.x * inv_n, q.y * inv_n, q.z * inv_n};
+}
