@@ -41,8 +41,7 @@ def cpu_baseline(n_envs: int, budget_s: float = 12.0):
     """torch-CPU port of the reference's drift mdp path (oracle/torch_mdp.py) on the host cores."""
     from oracle import torch_mdp as T
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    host_cores = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
     r = lambda *s: torch.rand(*s, generator=g)
     pos = torch.cat([r(n_envs, 2) * 4 - 2, torch.zeros(n_envs, 1)], -1)
@@ -54,22 +53,27 @@ def cpu_baseline(n_envs: int, budget_s: float = 12.0):
     ep = torch.zeros(n_envs, dtype=torch.int32)
     w = [10.0, -5.0, 40.0, 0.0, 20.0, -50.0, -5000.0]
     scale, off = torch.tensor([3.0, 0.488]), torch.zeros(2)
-    with torch.inference_mode():
-        for _ in range(20):
-            T.mdp_step(pos, quat, vb, wb, ww, steer, act, ep, w, scale, off)
-        t0 = time.perf_counter()
-        iters = 0
-        while True:
-            for _ in range(50):
+    best = None
+    # small elementwise ops do not scale with intra-op threads: time 1 thread and a modest pool, report the faster
+    for cores in sorted({1, min(8, host_cores)}):
+        torch.set_num_threads(cores)
+        with torch.inference_mode():
+            for _ in range(5):
                 T.mdp_step(pos, quat, vb, wb, ww, steer, act, ep, w, scale, off)
-            iters += 50
-            if time.perf_counter() - t0 > budget_s:
-                break
-        dt = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            iters = 0
+            while time.perf_counter() - t0 < budget_s / 2:
+                for _ in range(10):
+                    T.mdp_step(pos, quat, vb, wb, ww, steer, act, ep, w, scale, off)
+                iters += 10
+            dt = time.perf_counter() - t0
+        if best is None or iters / dt > best[1] / best[2]:
+            best = (cores, iters, dt)
+    cores, iters, dt = best
     return {"value": n_envs * iters / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{iters} passes of the drift mdp path (action term + 2 terminations + 7 rewards + noisy 14-dim "
                       f"obs; no physics exists on the reference's CPU side) on {n_envs} envs, torch {torch.__version__} "
-                      f"CPU, {cores} threads, {dt:.1f} s"}
+                      f"CPU, best of 1 / {min(8, host_cores)} intra-op threads on a {host_cores}-core host, {dt:.1f} s"}
 
 
 def main():

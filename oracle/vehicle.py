@@ -93,8 +93,10 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
         A = Iw / h + bw + K * r * r
         rhs0 = Iw * w_i / h + r * K * vcx
         w_u = (rhs0 + d * wt) / (A + d)
-        tau = np.clip(d * (wt - w_u), lo, hi)
-        w_n = (rhs0 + tau) / A
+        # unclipped motor: take w_u itself (tau = d (wt - w_u) cancels catastrophically near the target)
+        tau_u = d * (wt - w_u)
+        tau = np.clip(tau_u, lo, hi)
+        w_n = np.where(tau == tau_u, w_u, (rhs0 + tau) / A)
         Fx = K * (w_n * r - vcx)
         Fy = -K * vcy
         Fmax = mu_s * Fz
@@ -106,8 +108,9 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
         A2 = Iw / h + bw
         rhs2 = Iw * w_i / h - r * Fx
         w_u2 = (rhs2 + d * wt) / (A2 + d)
-        tau2 = np.clip(d * (wt - w_u2), lo, hi)
-        w_n = np.where(over, (rhs2 + tau2) / A2, w_n)
+        tau_u2 = d * (wt - w_u2)
+        tau2 = np.clip(tau_u2, lo, hi)
+        w_n = np.where(over, np.where(tau2 == tau_u2, w_u2, (rhs2 + tau2) / A2), w_n)
         new_wheel[:, i] = w_n
         Fi = Fz[:, None] * nrm + Fx[:, None] * tx + Fy[:, None] * ty
         Ftot += Fi

@@ -224,7 +224,11 @@ def test_full_size_properties(lib, n):
     qn = (st[3:7] ** 2).sum(0).sqrt()
     assert (qn - 1).abs().max() < 1e-5                     # unit quaternions
     assert (obs[:, 12:14].abs() <= 1).all()                 # last_action clip
-    assert (obs[:, 3:6] >= 0).all() and (obs[:, 3:6] < 2 * np.pi + 1e-5).all()   # euler wrapped to [0, 2pi)
+    env.p.enable_corruption = 0
+    clean = env.observe().clone()
+    env.p.enable_corruption = 1
+    assert (clean[:, 3:6] >= 0).all() and (clean[:, 3:6] < 2 * np.pi + 1e-5).all()   # euler wrapped to [0, 2pi)
+    assert torch.equal(clean[:, 0:3], env.state[0:3, :n].T)                          # root_pos_w passes through
     ep = env.episode_len[:n]
     assert (ep >= 0).all() and (ep < 250).all()
     m = env.metrics.cpu().numpy()

@@ -103,6 +103,10 @@ def load(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # PyTorch (the owner of the HBM allocations and streams we are handed) bundles its own libamdhip64.so with the same
+    # SONAME as /opt/rocm's.  It must be in the process BEFORE our library is dlopen'ed so that both bind to ONE HIP
+    # runtime; the other order gives two runtimes and every launch on torch memory fails.
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise HipExtensionMissing(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

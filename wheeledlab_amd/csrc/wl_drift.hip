@@ -369,6 +369,9 @@ __global__ void philox_uniform_kernel(int n, uint64_t seed, uint64_t step, uint3
 }
 
 inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
+// The host process (PyTorch) may leave a benign sticky error (e.g. hipErrorNotReady from an event query) in this
+// thread's HIP error slot: clear it before the launch so launch_status() reports only our own launch.
+inline void clear_error() { (void)hipGetLastError(); }
 inline int launch_status() { return hipGetLastError() == hipSuccess ? WL_OK : WL_ELAUNCH; }
 
 int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
@@ -408,6 +411,7 @@ int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* ac
     int rc = check_buffers(p, b);
     if (rc != WL_OK) return rc;
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated) return WL_EINVAL;
+    clear_error();
     drift_step_kernel<FlatGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
         *p, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{});
     return launch_status();
@@ -419,6 +423,7 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
     int rc = check_buffers(p, b);
     if (rc != WL_OK) return rc;
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
+    clear_error();
     const int grid = grid_for(b->n_envs);
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = *out;
@@ -440,6 +445,7 @@ int wl_drift_mdp(const WlDriftParams* p, int32_t n, int64_t stride, const float*
     if (!p || n <= 0 || stride < n || !pos || !quat || !lin_vel_b || !ang_vel_b || !ang_vel_w || !steer_pos ||
         !last_action || !terms || !reward || !terminated || !obs)
         return WL_EINVAL;
+    clear_error();
     drift_mdp_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(*p, n, stride, pos, quat, lin_vel_b, ang_vel_b,
                                                                        ang_vel_w, steer_pos, last_action, timed_out, terms,
                                                                        reward, terminated, obs);
@@ -450,6 +456,7 @@ int wl_action_map(const WlActionParams* a, int32_t n, const float* actions, floa
                   float* wheel_target, void* stream) {
     if (!a || n <= 0 || !actions || !processed || !steer_target || !wheel_target) return WL_EINVAL;
     if (((uintptr_t)wheel_target & 15u) || ((uintptr_t)actions & 7u)) return WL_EALIGN;
+    clear_error();
     action_map_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(*a, n, (const float2*)actions, (float2*)processed,
                                                                         (float2*)steer_target, (float4*)wheel_target);
     return launch_status();
@@ -459,6 +466,7 @@ int wl_drift_reset(const WlDriftParams* p, const WlEnvBuffers* b, const uint8_t*
                    void* stream) {
     int rc = check_buffers(p, b);
     if (rc != WL_OK) return rc;
+    clear_error();
     drift_reset_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, mask, seed, step);
     return launch_status();
 }
@@ -468,12 +476,14 @@ int wl_drift_observe(const WlDriftParams* p, const WlEnvBuffers* b, const float*
     int rc = check_buffers(p, b);
     if (rc != WL_OK) return rc;
     if (!obs) return WL_EINVAL;
+    clear_error();
     drift_observe_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, noise, obs, seed, step);
     return launch_status();
 }
 
 int wl_philox_uniform(int32_t n, uint64_t seed, uint64_t step, uint32_t stream_id, float* out, void* stream) {
     if (n <= 0 || !out) return WL_EINVAL;
+    clear_error();
     philox_uniform_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, seed, step, stream_id, out);
     return launch_status();
 }

@@ -72,8 +72,11 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const EnvConst& ec, const Mat
     const float A = Iw_h + vp.wheel_damping + K * r * r;
     const float rhs0 = fmaf(Iw_h, w_i, r * K * vcx);
     const float w_u = fmaf(d, wt, rhs0) * rcp(A + d);
-    const float tau = clampf(d * (wt - w_u), tau_lo, tau_hi);
-    float w_n = (rhs0 + tau) * rcp(A);
+    // tau = d (wt - w_u) cancels catastrophically near the target (d / A ~ 3e3 amplifies the rounding of w_u), so
+    // the unclipped branch takes w_u itself and only a clipped (constant) torque is pushed through the wheel equation
+    const float tau_u = d * (wt - w_u);
+    const float tau = clampf(tau_u, tau_lo, tau_hi);
+    float w_n = (tau == tau_u) ? w_u : (rhs0 + tau) * rcp(A);
     float Fx = K * fmaf(w_n, r, -vcx);
     float Fy = -K * vcy;
     const float Fmax = ec.mu_s * Fz;
@@ -85,8 +88,9 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const EnvConst& ec, const Mat
         const float A2 = Iw_h + vp.wheel_damping;
         const float rhs2 = fmaf(Iw_h, w_i, -r * Fx);
         const float w_u2 = fmaf(d, wt, rhs2) * rcp(A2 + d);
-        const float tau2 = clampf(d * (wt - w_u2), tau_lo, tau_hi);
-        w_n = (rhs2 + tau2) * rcp(A2);
+        const float tau_u2 = d * (wt - w_u2);
+        const float tau2 = clampf(tau_u2, tau_lo, tau_hi);
+        w_n = (tau2 == tau_u2) ? w_u2 : (rhs2 + tau2) * rcp(A2);
     }
     w_spin = w_n;
     const V3 Fi = fma3(Fz, n, fma3(Fx, tx, Fy * ty));
