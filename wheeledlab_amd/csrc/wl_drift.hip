@@ -46,7 +46,7 @@ WL_DEV ResetDraw draw_reset(const WlDriftParams& p, const float* __restrict__ re
     r.pos = v3(fmaf(2.f * u.y - 1.f, p.pos_noise, ref[idx]), fmaf(2.f * u.z - 1.f, p.pos_noise, ref[32 + idx]), 0.f);
     const float yaw = fmaf(2.f * u.w - 1.f, p.yaw_noise, ref[64 + idx]);
     float s, c;
-    sincosf(0.5f * yaw, &s, &c);
+    sincos_fast(0.5f * yaw, s, c);
     r.q = Quat{c, 0.f, 0.f, s};
     const F4 t = philox_uniform4(gid, step, WL_RS_TIMERS, seed);
     r.timer_hf = fmaf(t.x, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
@@ -55,27 +55,38 @@ WL_DEV ResetDraw draw_reset(const WlDriftParams& p, const float* __restrict__ re
 }
 
 // BlindObsCfg.PolicyCfg (wheeledlab_tasks/common/observations.py:24-54) into this wave's LDS tile
+struct Noise12 {
+    float z[12];
+};
+
 WL_DEV void write_obs_row(float* row, const WlDriftParams& p, V3 pos, Quat q, V3 vb, V3 wb, float a0, float a1,
-                          const float* nz /* 12 normals or nullptr */) {
+                          const Noise12& nz /* 12 standard normals (zeros when corruption is off) */) {
     const V3 e = euler_xyz_from_quat(q);
-    float o[12] = {pos.x, pos.y, pos.z, e.x, e.y, e.z, vb.x, vb.y, vb.z, wb.x, wb.y, wb.z};
-    if (nz) {
+    const float o[12] = {pos.x, pos.y, pos.z, e.x, e.y, e.z, vb.x, vb.y, vb.z, wb.x, wb.y, wb.z};
 #pragma unroll
-        for (int k = 0; k < 12; ++k) o[k] = fmaf(p.noise_std[k / 3], nz[k], o[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) row[k] = o[k];
+    for (int k = 0; k < 12; ++k) row[k] = fmaf(p.noise_std[k / 3], nz.z[k], o[k]);
     row[12] = clampf(a0, -1.f, 1.f);
     row[13] = clampf(a1, -1.f, 1.f);
 }
 
-WL_DEV void gen_normals(float nz[12], uint32_t gid, uint64_t step, uint64_t seed) {
+WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise, int64_t stride, int e, uint32_t gid,
+                         uint64_t step, uint64_t seed) {
+    Noise12 nz;
+    if (!p.enable_corruption) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + s, seed);
-        box_muller(u.x, u.y, nz[4 * s + 0], nz[4 * s + 1]);
-        box_muller(u.z, u.w, nz[4 * s + 2], nz[4 * s + 3]);
+        for (int k = 0; k < 12; ++k) nz.z[k] = 0.f;
+    } else if (noise) {   // parity mode: caller-supplied standard normals [12][stride]
+#pragma unroll
+        for (int k = 0; k < 12; ++k) nz.z[k] = noise[k * stride + e];
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + s, seed);
+            box_muller(u.x, u.y, nz.z[4 * s + 0], nz.z[4 * s + 1]);
+            box_muller(u.z, u.w, nz.z[4 * s + 2], nz.z[4 * s + 3]);
+        }
     }
+    return nz;
 }
 
 // flush this block's LDS obs tile ([kBlock][kObsPad]) to obs[n][14]: contiguous dword stores per wavefront
@@ -237,18 +248,8 @@ __global__ void __launch_bounds__(kBlock) drift_step_kernel(const WlDriftParams 
         const Mat3 R2 = mat_from_quat(s.q);
         vb = mul_t(R2, s.v);
         const V3 wb2 = mul_t(R2, ww);
-        float nz[12];
-        const float* nzp = nullptr;
-        if (p.enable_corruption) {
-            if (noise) {
-#pragma unroll
-                for (int k = 0; k < 12; ++k) nz[k] = noise[k * b.stride + e];
-            } else {
-                gen_normals(nz, gid, step, seed);
-            }
-            nzp = nz;
-        }
-        write_obs_row(&tile[threadIdx.x * kObsPad], p, pos, s.q, vb, wb2, a0, a1, nzp);
+        const Noise12 nz = obs_noise(p, noise, b.stride, e, gid, step, seed);
+        write_obs_row(&tile[threadIdx.x * kObsPad], p, pos, s.q, vb, wb2, a0, a1, nz);
     }
     __syncthreads();
     flush_obs(tile, out.obs, blockIdx.x * kBlock, b.n_envs);
@@ -288,7 +289,10 @@ __global__ void __launch_bounds__(kBlock) drift_mdp_kernel(const WlDriftParams p
         }
         reward[e] = r;
         terminated[e] = term ? 1 : 0;
-        write_obs_row(&tile[threadIdx.x * kObsPad], p, P, q, vb, wb, act[e], act[stride + e], nullptr);
+        Noise12 zero;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) zero.z[k] = 0.f;
+        write_obs_row(&tile[threadIdx.x * kObsPad], p, P, q, vb, wb, act[e], act[stride + e], zero);
     }
     __syncthreads();
     flush_obs(tile, obs, blockIdx.x * kBlock, n);
@@ -341,18 +345,8 @@ __global__ void __launch_bounds__(kBlock) drift_observe_kernel(const WlDriftPara
         const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
         const Mat3 R = mat_from_quat(q);
         const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
-        float nz[12];
-        const float* nzp = nullptr;
-        if (p.enable_corruption) {
-            if (noise) {
-#pragma unroll
-                for (int k = 0; k < 12; ++k) nz[k] = noise[k * b.stride + e];
-            } else {
-                gen_normals(nz, (uint32_t)(b.env_offset + e), step, seed);
-            }
-            nzp = nz;
-        }
-        write_obs_row(&tile[threadIdx.x * kObsPad], p, ld3(S, WL_S_PX, e), q, vb, wb, S(WL_S_ACT0, e), S(WL_S_ACT1, e), nzp);
+        const Noise12 nz = obs_noise(p, noise, b.stride, e, (uint32_t)(b.env_offset + e), step, seed);
+        write_obs_row(&tile[threadIdx.x * kObsPad], p, ld3(S, WL_S_PX, e), q, vb, wb, S(WL_S_ACT0, e), S(WL_S_ACT1, e), nz);
     }
     __syncthreads();
     flush_obs(tile, obs, blockIdx.x * kBlock, b.n_envs);

@@ -21,6 +21,14 @@ WL_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 WL_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 WL_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 WL_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// hardware sin / cos take REVOLUTIONS (v_sin_f32 / v_cos_f32, ~1e-6 abs): used where the argument is a bounded angle
+#define WL_INV_TWO_PI 0.15915494309189533577f
+WL_DEV void sincos_rev(float rev, float& s, float& c) {
+    s = __builtin_amdgcn_sinf(rev);
+    c = __builtin_amdgcn_cosf(rev);
+}
+WL_DEV void sincos_fast(float rad, float& s, float& c) { sincos_rev(rad * WL_INV_TWO_PI, s, c); }
+WL_DEV float log_fast(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }  // v_log_f32 is log2
 
 struct Quat {
     float w, x, y, z;

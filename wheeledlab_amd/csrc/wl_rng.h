@@ -33,9 +33,9 @@ WL_DEV F4 philox_uniform4(uint32_t env, uint64_t step, uint32_t stream, uint64_t
 
 // two standard normals from two uniforms (Box-Muller)
 WL_DEV void box_muller(float u0, float u1, float& z0, float& z1) {
-    float r = fsqrt(-2.f * logf(1.f - u0));
+    const float r = fsqrt(-2.f * log_fast(1.f - u0));
     float s, c;
-    sincosf(WL_TWO_PI * u1, &s, &c);
+    sincos_rev(u1, s, c);  // angle = 2 pi u1 is exactly u1 revolutions
     z0 = r * c;
     z1 = r * s;
 }

@@ -114,7 +114,7 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const EnvConst& ec, VehSt
     const Mat3 R = mat_from_quat(s.q);
     const V3 ww = mul(R, s.wb);
     float sn, cs;
-    sincosf(s.th, &sn, &cs);
+    sincos_fast(s.th, sn, cs);   // |th| <= tan(0.488) rad: hardware sin/cos, ~1e-6 abs
     V3 F = v3(0.f, 0.f, 0.f), T = v3(0.f, 0.f, 0.f);
     // ground under each wheel centre
     float zg[4];
