@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 3
+#define WL_ABI_VERSION 4
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -137,10 +137,12 @@ typedef struct WlEnvBuffers {
     float* state;             /* [WL_S_COUNT][stride]                                                         */
     int32_t* episode_len;     /* [n]  episode_length_buf                                                      */
     const float* ref_poses;   /* [3][32]: x, y, yaw(rad) of the pre-sampled reference poses (events.py:31)     */
-    float* metrics;           /* [WL_M_COUNT] accumulators (atomicAdd)                                        */
+    float* metrics;           /* [metrics_slots][WL_M_COUNT] accumulators (atomicAdd into slot step % slots)  */
     int64_t stride;
     int32_t n_envs;
     int32_t env_offset;       /* global id of env 0 of this shard (rank * n_envs): keys the RNG streams            */
+    int32_t metrics_slots;    /* 1: one accumulator the caller zeroes; R > 1: ring of per-step slots, the step    */
+                              /* kernel accumulates into slot (step % R) and clears slot ((step + 1) % R)         */
 } WlEnvBuffers;
 
 /* ---- outputs of one step -------------------------------------------------------------------------------- */

@@ -1,0 +1,130 @@
+"""Host logic of the drop-in surface that needs no GPU: configclass semantics, the task registry, cfg -> kernel
+parameter flattening, curriculum scalar logic against the reference's golden trajectory."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from wheeledlab_amd import params as PP
+from wheeledlab_amd import registry, tasks  # noqa: F401  (registers the ids)
+from wheeledlab_amd.envs import mdp
+from wheeledlab_amd.envs.configclass import configclass
+from wheeledlab_amd.envs.flatten import flatten_drift_cfg
+from wheeledlab_amd.envs.managers_cfg import RewardTermCfg
+from wheeledlab_amd.tasks.drifting import MushrDriftPlayEnvCfg, MushrDriftRLEnvCfg
+
+
+def test_configclass_semantics():
+    @configclass
+    class A:
+        x: int = 1
+        lst: list = [1, 2]
+
+        def __post_init__(self):
+            self.y = self.x * 2
+
+    @configclass
+    class B(A):
+        z = A()
+
+    a, b = A(), A(x=3)
+    a.lst.append(9)
+    assert b.lst == [1, 2] and b.y == 6 and A().lst == [1, 2]      # defaults are deep-copied per instance
+    c = B()
+    assert c.z.x == 1 and c.replace(x=5).x == 5 and c.x == 1
+    assert B().to_dict()["z"]["lst"] == [1, 2]
+    with pytest.raises(TypeError):
+        A(nope=1)
+
+
+def test_registry_has_reference_ids():
+    assert "Isaac-MushrDriftRL-v0" in registry.registered_ids()
+    s = registry.spec("Isaac-MushrDriftRL-v0")
+    assert set(s.kwargs) == {"env_cfg_entry_point", "rsl_rl_cfg_entry_point", "play_env_cfg_entry_point"}
+    cfg = registry.parse_env_cfg("Isaac-MushrDriftRL-v0", device="cuda:0", num_envs=16)
+    assert cfg.scene.num_envs == 16 and cfg.sim.dt == 0.005 and cfg.decimation == 4 and cfg.episode_length_s == 5
+    agent = registry.load_cfg_from_registry("Isaac-MushrDriftRL-v0", "rsl_rl_cfg_entry_point")
+    assert agent.num_steps_per_env == 128 and agent.policy.actor_hidden_dims == [64, 64]
+
+
+def _struct_eq(a, b, path=""):
+    for name, _ in a._fields_:
+        x, y = getattr(a, name), getattr(b, name)
+        if hasattr(x, "_fields_"):
+            _struct_eq(x, y, path + name + ".")
+        elif hasattr(x, "__len__"):
+            assert list(x) == pytest.approx(list(y), rel=1e-6), path + name
+        else:
+            assert x == pytest.approx(y, rel=1e-6), path + name
+
+
+def test_flatten_rss_drift_cfg_equals_kernel_defaults():
+    flat = flatten_drift_cfg(MushrDriftRLEnvCfg())
+    want = PP.drift_params()
+    want.action.clip_wrapper = 0          # the ClipAction wrapper is applied by the harness, not by the env cfg
+    _struct_eq(flat.params, want)
+    assert flat.startup.wheel_mu_s == (0.3, 0.5) and flat.startup.mu_buckets == 20 and flat.startup.damping == (10.0, 50.0)
+    assert flat.startup.mass_add == (0.3, 0.5)
+    assert [n for n, _ in flat.reward_names] == ["side_slip", "vel", "progress", "tlgr", "turn_energy", "cross_track", "term_pens"]
+    assert flat.termination_names == {"time_out": "time_out", 0: "out_of_bounds"}
+    assert [n for n, _ in flat.curriculum] == ["more_slip", "more_tlgr", "more_term_pens"]
+
+
+def test_flatten_overrides_and_play_cfg():
+    cfg = MushrDriftRLEnvCfg()
+    cfg.rewards.side_slip.weight = 100.0                      # the documented Hydra override (wheeledlab_rl/docs/README.md:68-72)
+    cfg.rewards.cross_track.params["track_radius"] = 1.0
+    cfg.observations.policy.enable_corruption = False
+    p = flatten_drift_cfg(cfg).params
+    assert p.weight[0] == 100.0 and p.r_line == 1.0 and p.enable_corruption == 0
+    play = flatten_drift_cfg(MushrDriftPlayEnvCfg())
+    assert list(play.params.weight) == [0.0] * 8 and play.params.max_episode_length == 2 ** 31 - 1
+    assert play.params.r_out > 1e20 and play.params.pos_noise == 0.0 and play.params.yaw_noise == 0.0
+
+
+def test_flatten_rejects_what_the_kernel_cannot_express():
+    cfg = MushrDriftRLEnvCfg()
+    cfg.rewards.extra = RewardTermCfg(func=lambda env: None, weight=1.0)      # custom reward: allowed, evaluated after the kernel
+    type(cfg.rewards).__cfg_fields__ = {**type(cfg.rewards).__cfg_fields__, "extra": None}
+    try:
+        flat = flatten_drift_cfg(cfg)
+        assert [n for n, _ in flat.custom_rewards] == ["extra"]
+    finally:
+        type(cfg.rewards).__cfg_fields__.pop("extra")
+    cfg = MushrDriftRLEnvCfg()
+    cfg.scene.terrain.physics_material.friction_combine_mode = "average"
+    with pytest.raises(NotImplementedError):
+        flatten_drift_cfg(cfg)
+    cfg = MushrDriftRLEnvCfg()
+    cfg.terminations.out_of_bounds.func = lambda env: None
+    with pytest.raises(NotImplementedError):
+        flatten_drift_cfg(cfg)
+
+
+class _FakeRM:
+    def __init__(self, w):
+        self.c = {k: RewardTermCfg(func=None, weight=v) for k, v in w.items()}
+
+    def get_term_cfg(self, n):
+        return self.c[n]
+
+    def set_term_cfg(self, n, c):
+        self.c[n] = c
+
+
+def test_curriculum_matches_reference_golden(golden):
+    g = golden("curriculum")
+
+    class E:
+        max_episode_length = 250
+        common_step_counter = 0
+    env = E()
+    env.reward_manager = _FakeRM({"side_slip": 10.0, "tlgr": 0.0, "term_pens": -5000.0})
+    cur = flatten_drift_cfg(MushrDriftRLEnvCfg()).curriculum
+    got = []
+    for step in g["steps"]:
+        env.common_step_counter = int(step)
+        for _, term in cur:
+            mdp.increase_reward_weight_over_time(env, None, **term.params)
+        got.append([env.reward_manager.c[k].weight for k in ("side_slip", "tlgr", "term_pens")])
+    np.testing.assert_array_equal(np.array(got), g["weights"])

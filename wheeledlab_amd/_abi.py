@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 3
+WL_ABI_VERSION = 4
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -68,7 +68,8 @@ class WlDriftParams(C.Structure):
 
 class WlEnvBuffers(C.Structure):
     _fields_ = [("state", C.c_void_p), ("episode_len", C.c_void_p), ("ref_poses", C.c_void_p),
-                ("metrics", C.c_void_p), ("stride", C.c_int64), ("n_envs", C.c_int32), ("env_offset", C.c_int32)]
+                ("metrics", C.c_void_p), ("stride", C.c_int64), ("n_envs", C.c_int32), ("env_offset", C.c_int32),
+                ("metrics_slots", C.c_int32)]
 
 
 class WlStepOut(C.Structure):

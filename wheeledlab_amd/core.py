@@ -40,7 +40,7 @@ class DriftBatch:
     OBS_DIM = 14
 
     def __init__(self, n_envs: int, device="cuda:0", params: A.WlDriftParams | None = None, seed: int = 42,
-                 env_offset: int = 0, randomize: bool = True):
+                 env_offset: int = 0, randomize: bool = True, metrics_slots: int = 1, startup=None):
         self.lib = A.load()  # raises HipExtensionMissing -- no fallback
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -54,36 +54,49 @@ class DriftBatch:
         dev = self.device
         self.state = torch.zeros(A.S_COUNT, self.stride, dtype=torch.float32, device=dev)
         self.episode_len = torch.zeros(self.stride, dtype=torch.int32, device=dev)
-        self.metrics = torch.zeros(A.M_COUNT, dtype=torch.float32, device=dev)
+        self.metrics_slots = int(metrics_slots)
+        self.metrics = torch.zeros(self.metrics_slots, A.M_COUNT, dtype=torch.float32, device=dev)
+        if self.metrics_slots == 1:
+            self.metrics = self.metrics[0]
         self.obs = torch.zeros(self.n, self.OBS_DIM, dtype=torch.float32, device=dev)
         self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
-        self.terminated = torch.zeros(self.n, dtype=torch.uint8, device=dev)
-        self.truncated = torch.zeros(self.n, dtype=torch.uint8, device=dev)
+        # torch.bool is one byte holding 0 / 1: the kernel's uint8 outputs land in it directly
+        self.terminated = torch.zeros(self.n, dtype=torch.bool, device=dev)
+        self.truncated = torch.zeros(self.n, dtype=torch.bool, device=dev)
         g = torch.Generator().manual_seed(self.seed)
         # reference poses are drawn ONCE at construction (events.py:31,35)
         self.ref_table = torch.zeros(3, 32, dtype=torch.float32)
-        self.ref_table[:, : self.p.num_ref_points] = stadium_reference_poses(torch.rand(self.p.num_ref_points, generator=g))
+        tr = (startup.track_radius, startup.track_straight) if startup is not None else (0.8, 0.8)
+        self.ref_table[:, : self.p.num_ref_points] = stadium_reference_poses(torch.rand(self.p.num_ref_points, generator=g), *tr)
         self.ref_table = self.ref_table.to(dev)
-        self._startup_events(g, randomize)
+        self._startup_events(g, randomize, startup)
         self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), self.ref_table.data_ptr(),
-                                    self.metrics.data_ptr(), self.stride, self.n, self.env_offset)
+                                    self.metrics.data_ptr(), self.stride, self.n, self.env_offset, self.metrics_slots)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
                                 self.truncated.data_ptr())
 
     # startup events (mushr_drift_env_cfg.py:98-119, 145-154)
-    def _startup_events(self, g: torch.Generator, randomize: bool):
+    def _startup_events(self, g: torch.Generator, randomize: bool, su=None):
         s, n = self.state, self.stride
         s[A.S_QW] = 1.0
-        if randomize:
-            nb = 20  # randomize_rigid_body_material: 20 buckets, mu_d <= mu_s ("make_consistent")
-            mu_s = torch.rand(nb, generator=g) * 0.2 + 0.3
-            mu_d = torch.minimum(torch.rand(nb, generator=g) * 0.2 + 0.3, mu_s)
-            b = torch.randint(0, nb, (n,), generator=g)
-            s[A.S_MU_S], s[A.S_MU_D] = mu_s[b].to(self.device), mu_d[b].to(self.device)
-            s[A.S_DAMP] = (torch.rand(n, generator=g) * 40.0 + 10.0).to(self.device)      # randomize_actuator_gains abs U(10,50)
-            s[A.S_MASS] = (MUSHR_CHASSIS_MASS + torch.rand(n, generator=g) * 0.2 + 0.3).to(self.device)  # += U(0.3,0.5)
-        else:
-            s[A.S_MU_S], s[A.S_MU_D], s[A.S_DAMP], s[A.S_MASS] = 0.4, 0.4, 30.0, MUSHR_CHASSIS_MASS + 0.4
+        if su is None:  # the RSS drift defaults
+            from .envs.flatten import StartupSpec
+            su = StartupSpec(wheel_mu_s=(0.3, 0.5), wheel_mu_d=(0.3, 0.5), mu_buckets=20, mu_consistent=True,
+                             damping=(10.0, 50.0), mass_add=(0.3, 0.5))
+        if not randomize:
+            mid = lambda r: 0.5 * (r[0] + r[1])
+            s[A.S_MU_S], s[A.S_MU_D] = mid(su.wheel_mu_s), min(mid(su.wheel_mu_d), mid(su.wheel_mu_s))
+            s[A.S_DAMP], s[A.S_MASS] = mid(su.damping), su.chassis_mass + mid(su.mass_add)
+            return
+        u = lambda r, k: torch.rand(k, generator=g) * (r[1] - r[0]) + r[0]
+        nb = max(1, su.mu_buckets)  # randomize_rigid_body_material: bucketed materials, mu_d <= mu_s if "make_consistent"
+        mu_s, mu_d = u(su.wheel_mu_s, nb), u(su.wheel_mu_d, nb)
+        if su.mu_consistent:
+            mu_d = torch.minimum(mu_d, mu_s)
+        b = torch.randint(0, nb, (n,), generator=g)
+        s[A.S_MU_S], s[A.S_MU_D] = mu_s[b].to(self.device), mu_d[b].to(self.device)
+        s[A.S_DAMP] = u(su.damping, n).to(self.device)                       # randomize_actuator_gains, "abs"
+        s[A.S_MASS] = (su.chassis_mass + u(su.mass_add, n)).to(self.device)  # randomize_rigid_body_mass, "add"
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -110,6 +110,10 @@ __global__ void __launch_bounds__(kBlock) drift_step_kernel(const WlDriftParams 
     const int e = blockIdx.x * kBlock + threadIdx.x;
     const bool active = e < b.n_envs;
     if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
+    // per-step metric ring: accumulate into slot step % R, clear the slot the NEXT launch will use
+    const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
+    if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
+        b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
     __syncthreads();
     const Rows S{b.state, b.stride};
     const WlVehicleParams& vp = p.vehicle;
@@ -255,7 +259,7 @@ __global__ void __launch_bounds__(kBlock) drift_step_kernel(const WlDriftParams 
     flush_obs(tile, out.obs, blockIdx.x * kBlock, b.n_envs);
     if (threadIdx.x < WL_M_COUNT) {
         const float m = blk_metrics[threadIdx.x];
-        if (m != 0.f) atomicAdd(&b.metrics[threadIdx.x], m);
+        if (m != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], m);
     }
     (void)any_done;
 }
@@ -372,6 +376,7 @@ int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
     if (!p || !b || !b->state || !b->episode_len || !b->ref_poses || !b->metrics) return WL_EINVAL;
     if (b->n_envs <= 0 || b->stride < b->n_envs) return WL_EINVAL;
     if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
+    if (b->metrics_slots < 1) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || p->num_ref_points <= 0 || p->num_ref_points > 32) return WL_EINVAL;
     if (!(p->sim_dt > 0.f)) return WL_EINVAL;
     return WL_OK;

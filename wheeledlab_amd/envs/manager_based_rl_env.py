@@ -1,0 +1,326 @@
+"""ManagerBasedRLEnv -- the drop-in host surface of the fused env.step().
+
+Same constructor and attribute names as `isaaclab.envs.ManagerBasedRLEnv`, the class the reference registers its
+tasks with (wheeledlab_tasks/__init__.py:14-63) and the callers rely on (scripts/train_rl.py:70-116,
+utils/modified_rsl_rl_runner.py:47-109): `step/reset/seed/close`, `num_envs`, `device`, `max_episode_length`,
+`common_step_counter`, `episode_length_buf`, `reward_manager.get_term_cfg/set_term_cfg`, `scene[...]`,
+`action_space`, `unwrapped.single_action_space`, `cfg`, `extras["log"]`.
+
+step() is ONE launch of the fused HIP kernel; the managers below are thin views/config holders, not executors."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from .. import _abi as A
+from ..core import DriftBatch
+from .configclass import fields_of
+from .flatten import flatten_drift_cfg
+from .scene import SceneView
+
+
+class Box:
+    """minimal gymnasium.spaces.Box stand-in (gymnasium is not a dependency): low/high are assignable, as
+    scripts/train_rl.py:73-74 does"""
+
+    def __init__(self, low, high, shape, dtype=torch.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+    def sample(self, generator=None, device="cpu"):
+        lo = -1.0 if not math.isfinite(float(self.low)) else float(self.low)
+        hi = 1.0 if not math.isfinite(float(self.high)) else float(self.high)
+        return torch.rand(self.shape, generator=generator, device=device) * (hi - lo) + lo
+
+    def __repr__(self):
+        return f"Box({self.low}, {self.high}, {self.shape})"
+
+
+class RewardManager:
+    def __init__(self, env, flat):
+        self._env = env
+        self._cfgs = dict((k, v) for k, v in fields_of(env.cfg.rewards) if hasattr(v, "func")) if env.cfg.rewards else {}
+        self._slots = dict(flat.reward_names)
+        self._custom = [n for n, _ in flat.custom_rewards]
+
+    @property
+    def active_terms(self):
+        return list(self._cfgs)
+
+    def get_term_cfg(self, name):
+        return self._cfgs[name]
+
+    def set_term_cfg(self, name, cfg):
+        self._cfgs[name] = cfg
+        if name in self._slots:  # push the new weight into the kernel's parameter block
+            self._env._batch.p.weight[self._slots[name]] = float(cfg.weight)
+
+    @property
+    def episode_sums(self):
+        b = self._env._batch
+        return {n: b.state[A.S_EPSUM0 + s, : b.n] for n, s in self._slots.items()}
+
+    _episode_sums = episode_sums
+
+
+class TerminationManager:
+    def __init__(self, env, flat):
+        self._env, self._names = env, flat.termination_names
+
+    @property
+    def active_terms(self):
+        return list(self._names.values())
+
+    @property
+    def terminated(self):
+        return self._env._batch.terminated
+
+    @property
+    def time_outs(self):
+        return self._env._batch.truncated
+
+    @property
+    def dones(self):
+        return self.terminated | self.time_outs
+
+    def get_term(self, name):
+        if name == self._names.get("time_out"):
+            return self.time_outs
+        if name == self._names.get(0):
+            return self.terminated
+        raise KeyError(name)
+
+
+class ActionManager:
+    def __init__(self, env):
+        self._env = env
+        name, acfg = [(k, v) for k, v in fields_of(env.cfg.actions) if hasattr(v, "class_type")][0]
+        self._terms = {name: acfg.class_type(acfg, env)}
+        self.prev_action = torch.zeros(env.num_envs, 2, device=env.device)
+
+    @property
+    def total_action_dim(self):
+        return 2
+
+    @property
+    def action(self):
+        b = self._env._batch
+        return b.state[A.S_ACT0:A.S_ACT0 + 2, : b.n].T
+
+    def get_term(self, name):
+        return self._terms[name]
+
+    @property
+    def active_terms(self):
+        return list(self._terms)
+
+
+class ObservationManager:
+    def __init__(self, env):
+        self._env = env
+        self.group_obs_dim = {"policy": (DriftBatch.OBS_DIM,)}
+        self.active_terms = {"policy": [k for k, v in fields_of(env.cfg.observations.policy) if hasattr(v, "func")]}
+
+    def compute(self):
+        return {"policy": self._env._batch.observe()}
+
+
+class EpisodeLog(dict):
+    """extras["log"]: IsaacLab's per-reset statistics (`Episode_Reward/<term>` = mean over the envs that were reset of
+    episode_sum / episode_length_s; `Episode_Termination/<term>` = count), evaluated LAZILY from one slot of the
+    device-side metric ring so that stepping never synchronises with the host.  Values are 0-dim device tensors;
+    with no reset in the step the means are NaN (IsaacLab would omit the keys: use nanmean, or cfg.sync_episode_log)."""
+
+    def __init__(self, slot, reward_slots, term_names, episode_length_s):
+        super().__init__()
+        self._slot, self._len_s = slot, episode_length_s
+        self._keys = {f"Episode_Reward/{n}": ("r", s) for n, s in reward_slots.items()}
+        if "time_out" in term_names:
+            self._keys[f"Episode_Termination/{term_names['time_out']}"] = ("c", A.M_TIMEOUTS)
+        if 0 in term_names:
+            self._keys[f"Episode_Termination/{term_names[0]}"] = ("c", A.M_TERM0)
+        self._keys["Metrics/resets"] = ("c", A.M_RESETS)
+        self._keys["Metrics/nonfinite_envs"] = ("c", A.M_NONFINITE)
+
+    def __missing__(self, key):
+        kind, idx = self._keys[key]
+        m = self._slot
+        v = m[idx] if kind == "c" else m[A.M_EPSUM0 + idx] / m[A.M_RESETS] / self._len_s
+        self[key] = v
+        return v
+
+    def __contains__(self, key):
+        return key in self._keys
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def keys(self):
+        return self._keys.keys()
+
+    def items(self):
+        return [(k, self[k]) for k in self._keys]
+
+    def __len__(self):
+        return len(self._keys)
+
+
+class ManagerBasedRLEnv:
+    metadata = {"render_modes": [None]}
+    is_vector_env = True
+
+    def __init__(self, cfg, render_mode=None, **kwargs):
+        self.cfg = cfg
+        self.render_mode = render_mode
+        self.num_envs = int(cfg.scene.num_envs)
+        self.device = torch.device(cfg.sim.device)
+        flat = flatten_drift_cfg(cfg)
+        self._flat = flat
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        seed = 42 if cfg.seed is None else int(cfg.seed)
+        self._batch = DriftBatch(self.num_envs, device=self.device, params=flat.params, seed=seed,
+                                 env_offset=rank * self.num_envs, metrics_slots=int(cfg.metrics_slots),
+                                 startup=flat.startup)
+        self.scene = SceneView(self._batch, cfg.scene)
+        self.common_step_counter = 0
+        self.step_dt = cfg.sim.dt * cfg.decimation
+        self.physics_dt = cfg.sim.dt
+        self.max_episode_length_s = cfg.episode_length_s
+        self.max_episode_length = math.ceil(cfg.episode_length_s / self.step_dt)
+        self.action_manager = ActionManager(self)
+        self.observation_manager = ObservationManager(self)
+        self.reward_manager = RewardManager(self, flat)
+        self.termination_manager = TerminationManager(self, flat)
+        self._event_terms = {}
+        for name, term in ([(k, v) for k, v in fields_of(cfg.events) if hasattr(v, "func")] if cfg.events else []):
+            if isinstance(term.func, type):  # class-type terms are instantiated with (cfg, env), as IsaacLab does
+                self._event_terms[name] = term.func(term, self)
+        self.single_action_space = Box(-math.inf, math.inf, (2,))
+        self.action_space = Box(-math.inf, math.inf, (self.num_envs, 2))
+        self.single_observation_space = {"policy": Box(-math.inf, math.inf, (DriftBatch.OBS_DIM,))}
+        self.observation_space = {"policy": Box(-math.inf, math.inf, (self.num_envs, DriftBatch.OBS_DIM))}
+        self.extras = {}
+        self.obs_buf = {}
+        self._clip_actions = False
+        self._sim_step_counter = 0
+
+    # ---- gym.Env surface --------------------------------------------------------------------------------------
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def episode_length_buf(self):
+        return self._batch.episode_len[: self.num_envs]
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):  # the RSL-RL runner assigns it for init_at_random_ep_len
+        self._batch.episode_len[: self.num_envs] = value.to(torch.int32)
+
+    @property
+    def reward_buf(self):
+        return self._batch.reward
+
+    @property
+    def reset_buf(self):
+        return self._batch.terminated | self._batch.truncated
+
+    def seed(self, seed: int = -1) -> int:
+        if seed is not None and seed >= 0:
+            self._batch.seed = int(seed)
+            torch.manual_seed(seed)
+        return self._batch.seed
+
+    def set_clip_actions(self, on: bool = True):
+        """fold the ClipAction wrapper (wheeledlab_rl/utils/clip_action.py:27) into the kernel's action stage"""
+        self._clip_actions = bool(on)
+        self._batch.p.action.clip_wrapper = int(on)
+
+    def reset(self, seed=None, options=None):
+        if seed is not None:
+            self.seed(seed)
+        self._batch.reset()
+        self.extras = {}
+        self.obs_buf = {"policy": self._batch.observe()}
+        return self.obs_buf, self.extras
+
+    def step(self, action: torch.Tensor):
+        b = self._batch
+        self.action_manager.prev_action = action
+        slot = b.metrics[b.step_count % b.metrics_slots] if b.metrics_slots > 1 else b.metrics
+        obs, rew, terminated, truncated = b.step(action)
+        self.common_step_counter += 1
+        self._sim_step_counter += self.cfg.decimation
+        # custom (non-fused) reward terms: user torch code on the device, RewardManager semantics
+        for name, term in self._flat.custom_rewards:
+            if term.weight != 0.0:
+                f = term.func
+                rew += f(self, **term.params) * term.weight * self.step_dt
+        # curriculum: evaluated inside _reset_idx in IsaacLab, i.e. on steps where >= 1 env resets; every built-in
+        # term is a no-op off episode boundaries, so the (synchronising) any() runs once per max_episode_length steps
+        if self._flat.curriculum and self.common_step_counter % self.max_episode_length == 0:
+            if bool((terminated | truncated).any()):
+                for name, term in self._flat.curriculum:
+                    term.func(self, None, **term.params)
+        if self.cfg.sync_episode_log:
+            if bool((terminated | truncated).any()):
+                self.extras["log"] = dict(self._episode_log(slot).items())
+            else:
+                self.extras.pop("log", None)
+        else:
+            self.extras["log"] = self._episode_log(slot)
+        self.obs_buf = {"policy": obs}
+        return self.obs_buf, rew, terminated, truncated, self.extras
+
+    def _episode_log(self, slot):
+        return EpisodeLog(slot, self.reward_manager._slots, self._flat.termination_names, self.max_episode_length_s)
+
+    def episode_metrics(self, window: int | None = None, reduce_ranks: bool = True):
+        """aggregate of the last `window` per-step metric slots as one [WL_M_COUNT] vector; across ranks it is ONE
+        sum all-reduce (RCCL over xGMI) -- the only collective of the env-sharded multi-GPU path"""
+        b = self._batch
+        if b.metrics_slots > 1:
+            R = b.metrics_slots
+            w = min(window or R - 1, R - 1, b.step_count)
+            idx = [(b.step_count - 1 - i) % R for i in range(w)]
+            m = b.metrics[idx].sum(0) if idx else torch.zeros(A.M_COUNT, device=self.device)
+        else:
+            m = b.metrics.clone()
+        if reduce_ranks and torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(m)
+        return m
+
+    def render(self):
+        return None
+
+    def close(self):
+        self._batch = None
+
+    # ---- plugin support: built-in mdp terms evaluate through the terms-only kernel on the current state ----------
+    def _eval_drift_terms(self, overrides: dict):
+        b = self._batch
+        p = A.WlDriftParams.from_buffer_copy(b.p)
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        d = self.scene["robot"].data
+        n, stride = b.n, b.stride
+
+        def soa(t):
+            out = torch.zeros(t.shape[1], stride, device=self.device)
+            out[:, :n] = t.T
+            return out
+        pos, quat = soa(d.root_pos_w - self.scene.env_origins), soa(d.root_quat_w)
+        vb, wb, ww = soa(d.root_lin_vel_b), soa(d.root_ang_vel_b), soa(d.root_ang_vel_w)
+        steer, act = soa(d.joint_pos[:, 0:2]), soa(self.action_manager.action)
+        terms = torch.zeros(A.WL_MAX_REW_TERMS, stride, device=self.device)
+        rew = torch.zeros(n, device=self.device)
+        term = torch.zeros(n, dtype=torch.bool, device=self.device)
+        obs = torch.zeros(n, DriftBatch.OBS_DIM, device=self.device)
+        A.check(b.lib.wl_drift_mdp(C.byref(p), n, stride, pos.data_ptr(), quat.data_ptr(), vb.data_ptr(), wb.data_ptr(),
+                                   ww.data_ptr(), steer.data_ptr(), act.data_ptr(), b.truncated.data_ptr(),
+                                   terms.data_ptr(), rew.data_ptr(), term.data_ptr(), obs.data_ptr(), b._stream()),
+                "wl_drift_mdp")
+        return terms[:, :n], term, rew, obs

@@ -1,0 +1,232 @@
+"""mdp term library: the names the reference's task configs import from `isaaclab.envs.mdp`, `wheeledlab.envs.mdp`
+and define at module level in their cfg files -- here as *kernel-backed* callables.
+
+Each built-in term `f(env, **params) -> Tensor[N]` carries `wl_kernel_slot` metadata: when it appears in a task
+config the flattening step (`flatten.py`) turns (func, params, weight) into fields of the fused kernel's parameter
+struct, so the hot path never calls it.  Called directly (user code, tests), it evaluates through the terms-only HIP
+entry point `wl_drift_mdp` on the env's current state -- there is one implementation of the arithmetic, in csrc/."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from .. import _abi as A
+from .managers_cfg import ManagerTermBase, SceneEntityCfg
+
+_ROBOT = SceneEntityCfg("robot")
+
+# ---- state accessors (isaaclab.envs.mdp public API used by the reference) ---------------------------------------
+
+
+def root_pos_w(env, asset_cfg=_ROBOT):
+    return env.scene[asset_cfg.name].data.root_pos_w - env.scene.env_origins
+
+
+def root_quat_w(env, asset_cfg=_ROBOT):
+    return env.scene[asset_cfg.name].data.root_quat_w
+
+
+def root_lin_vel_w(env, asset_cfg=_ROBOT):
+    return env.scene[asset_cfg.name].data.root_lin_vel_w
+
+
+def base_lin_vel(env, asset_cfg=_ROBOT):
+    return env.scene[asset_cfg.name].data.root_lin_vel_b
+
+
+def base_ang_vel(env, asset_cfg=_ROBOT):
+    return env.scene[asset_cfg.name].data.root_ang_vel_b
+
+
+def joint_pos(env, asset_cfg=_ROBOT):
+    return env.scene[asset_cfg.name].data.joint_pos[:, asset_cfg.joint_ids]
+
+
+def joint_vel(env, asset_cfg=_ROBOT):
+    if asset_cfg.joint_names is not None and isinstance(asset_cfg.joint_ids, slice):
+        asset_cfg.resolve(env.scene)
+    return env.scene[asset_cfg.name].data.joint_vel[:, asset_cfg.joint_ids]
+
+
+def last_action(env, action_name=None):
+    return env.action_manager.action
+
+
+def generated_commands(env, command_name):
+    return env.command_manager.get_command(command_name)
+
+
+def euler_xyz_from_quat(q):
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    roll = torch.atan2(2.0 * (w * x + y * z), 1 - 2 * (x * x + y * y))
+    sp = 2.0 * (w * y - z * x)
+    pitch = torch.where(sp.abs() >= 1, torch.copysign(torch.full_like(sp, math.pi / 2), sp), torch.asin(sp.clamp(-1, 1)))
+    yaw = torch.atan2(2.0 * (w * z + x * y), 1 - 2 * (y * y + z * z))
+    return roll % (2 * math.pi), pitch % (2 * math.pi), yaw % (2 * math.pi)
+
+
+def root_euler_xyz(env, asset_cfg=_ROBOT):
+    """wheeledlab.envs.mdp.root_euler_xyz (wheeledlab/envs/mdp/observations.py:9-12)"""
+    return torch.stack(euler_xyz_from_quat(root_quat_w(env, asset_cfg)), dim=-1)
+
+
+def _kernel_term(kind, slot, param_map=None):
+    """decorator: tag a built-in term with its slot in the fused kernel (+ cfg-param -> struct-field map)"""
+    def deco(fn):
+        fn.wl_kind, fn.wl_slot, fn.wl_params = kind, slot, dict(param_map or {})
+        return fn
+    return deco
+
+
+def _drift_row(env, slot, overrides):
+    """evaluate one unweighted drift reward term through wl_drift_mdp on the current state"""
+    return env._eval_drift_terms(overrides)[0][slot]
+
+
+# ---- drift task reward terms (reference: wheeledlab_tasks/drifting/mushr_drift_env_cfg.py:160-240) --------------
+
+@_kernel_term("reward", 0, {"min_thresh": "slip_min", "max_thresh": "slip_max", "min_vel_x": "slip_min_vx"})
+def side_slip(env, min_thresh: float, max_thresh: float, min_vel_x: float = 0.5):
+    return _drift_row(env, 0, dict(slip_min=min_thresh, slip_max=max_thresh, slip_min_vx=min_vel_x))
+
+
+@_kernel_term("reward", 1, {"speed_target": "speed_target", "offset": "speed_offset"})
+def vel_dist(env, speed_target: float = 3.0, offset: float = -9.0):
+    return _drift_row(env, 1, dict(speed_target=speed_target, speed_offset=offset))
+
+
+@_kernel_term("reward", 2)
+def track_progress_rate(env):
+    return _drift_row(env, 2, {})
+
+
+@_kernel_term("reward", 3, {"ang_vel_thresh": "tlgr_thresh"})
+def turn_left_go_right(env, ang_vel_thresh: float = math.pi / 4):
+    return _drift_row(env, 3, dict(tlgr_thresh=ang_vel_thresh))
+
+
+@_kernel_term("reward", 4, {"straight": "straight"})
+def energy_through_turn(env, straight: float):
+    return _drift_row(env, 4, dict(straight=straight))
+
+
+@_kernel_term("reward", 5, {"straight": "straight", "track_radius": "r_line", "offset": "ctd_offset", "p": "ctd_p"})
+def cross_track_dist(env, straight: float, track_radius: float = 1.15, offset: float = -1.0, p: float = 1.0):
+    return _drift_row(env, 5, dict(straight=straight, r_line=track_radius, ctd_offset=offset, ctd_p=p))
+
+
+class is_terminated_term(ManagerTermBase):
+    """isaaclab.envs.mdp.rewards.is_terminated_term: 1 where one of `term_keys` fired and the env did not time out"""
+    wl_kind, wl_slot, wl_params = "reward", 6, {}
+
+    def __call__(self, env, term_keys=".*"):
+        tm = env.termination_manager
+        return (tm.terminated & ~tm.time_outs).float()
+
+
+class rewards:  # namespace alias: the reference spells it `mdp.rewards.is_terminated_term`
+    is_terminated_term = is_terminated_term
+
+
+# ---- terminations ------------------------------------------------------------------------------------------------
+
+@_kernel_term("termination", "time_out")
+def time_out(env):
+    return env.episode_length_buf >= env.max_episode_length
+
+
+@_kernel_term("termination", 0, {"straight": "straight", "corner_in_radius": "r_in", "corner_out_radius": "r_out"})
+def cart_off_track(env, straight: float, corner_in_radius: float, corner_out_radius: float):
+    return env._eval_drift_terms(dict(straight=straight, r_in=corner_in_radius, r_out=corner_out_radius))[1]
+
+
+def off_track(env, straight, corner_out_radius):
+    """mushr_drift_env_cfg.py:210-217 -- int 0/1; only the outer bound (inner radius disabled)"""
+    return env._eval_drift_terms(dict(straight=straight, r_in=0.0, r_out=corner_out_radius))[1].long()
+
+
+def in_range(env, straight, corner_in_radius):
+    """mushr_drift_env_cfg.py:201-208 -- int 0/1; only the inner bound (outer radius disabled)"""
+    return env._eval_drift_terms(dict(straight=straight, r_in=corner_in_radius, r_out=1e30))[1].long()
+
+
+# ---- events (startup / reset / interval): markers consumed by flatten.py ------------------------------------------
+
+def _event(kind):
+    def deco(fn):
+        fn.wl_kind, fn.wl_event = "event", kind
+        return fn
+    return deco
+
+
+class reset_root_state_along_track(ManagerTermBase):
+    """drifting/mdp/events.py:10-133 -- executed inside the fused kernel (and by wl_drift_reset); this class only
+    carries the parameters and exposes the pre-sampled `reference_poses` like the reference's term does."""
+    wl_kind, wl_event = "event", "reset_along_track"
+
+    def __init__(self, cfg, env):
+        super().__init__(cfg, env)
+        self.num_points = cfg.params.get("num_points", 20)
+
+    @property
+    def reference_poses(self):
+        t = self._env._batch.ref_table[:, : self.num_points]  # x, y, yaw(rad)
+        pos = torch.stack([t[0], t[1], torch.zeros_like(t[0])], -1)
+        ori = torch.stack([torch.zeros_like(t[0]), torch.zeros_like(t[0]), torch.rad2deg(t[2])], -1)
+        return torch.stack([pos, ori], dim=1)
+
+    def __call__(self, env, env_ids, track_radius=0.8, track_straight_dist=0.8, num_points=20, asset_cfg=_ROBOT,
+                 pos_noise=0.0, yaw_noise=0.0):
+        mask = torch.zeros(env.num_envs, dtype=torch.uint8, device=env.device)
+        mask[env_ids] = 1
+        env._batch.reset(mask)
+
+
+@_event("wheel_friction")
+def randomize_rigid_body_material(env, env_ids, static_friction_range, dynamic_friction_range, restitution_range,
+                                  num_buckets, asset_cfg=None, make_consistent=False):
+    raise RuntimeError("startup event: applied by the env constructor (flatten.py), not callable per step")
+
+
+@_event("actuator_gains")
+def randomize_actuator_gains(env, env_ids, asset_cfg=None, stiffness_distribution_params=None,
+                             damping_distribution_params=None, operation="abs", distribution="uniform"):
+    raise RuntimeError("startup event: applied by the env constructor (flatten.py), not callable per step")
+
+
+@_event("base_mass")
+def randomize_rigid_body_mass(env, env_ids, asset_cfg=None, mass_distribution_params=None, operation="add",
+                              distribution="uniform", recompute_inertia=True):
+    raise RuntimeError("startup event: applied by the env constructor (flatten.py), not callable per step")
+
+
+@_event("push")
+def push_by_setting_velocity(env, env_ids, velocity_range, asset_cfg=_ROBOT):
+    """isaaclab mdp.push_by_setting_velocity: root vel (world) += U(range); interval pushes run in-kernel, this
+    direct call is for user code"""
+    b = env._batch
+    n = len(env_ids) if not isinstance(env_ids, slice) else b.n
+    for key, row in (("x", A.S_VX), ("y", A.S_VY), ("z", A.S_VZ), ("roll", A.S_WX), ("pitch", A.S_WY), ("yaw", A.S_WZ)):
+        lo, hi = velocity_range.get(key, (0.0, 0.0))
+        if lo != 0.0 or hi != 0.0:
+            b.state[row, env_ids] += torch.rand(n, device=b.device) * (hi - lo) + lo
+
+
+# ---- curriculum (wheeledlab/envs/mdp/curriculums.py:10-35) ----------------------------------------------------------
+
+def increase_reward_weight_over_time(env, env_ids, reward_term_name: str, increase: float,
+                                     episodes_per_increase: int = 1, max_increases=math.inf):
+    """Raise a reward weight every `episodes_per_increase` episodes (host scalar logic, evaluated on steps where at
+    least one env resets).  NB: performs max_increases + 1 increments, like the reference (`>` not `>=`)."""
+    num_episodes = env.common_step_counter // env.max_episode_length
+    num_increases = num_episodes // episodes_per_increase
+    if num_increases > max_increases:
+        return
+    if env.common_step_counter % env.max_episode_length != 0:
+        return
+    if (num_episodes + 1) % episodes_per_increase == 0:
+        term_cfg = env.reward_manager.get_term_cfg(reward_term_name)
+        term_cfg.weight += increase
+        env.reward_manager.set_term_cfg(reward_term_name, term_cfg)

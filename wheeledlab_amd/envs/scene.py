@@ -1,0 +1,146 @@
+"""Scene / articulation views over the SoA state matrix, exposing the attribute names the reference's term
+functions read (`env.scene["robot"].data.root_pos_w`, `.find_joints(...)`, `env.scene.env_origins`, ...; census in
+SURVEY.md section 8b).  These are cold-path conveniences for user plugins: [N,k] tensors are assembled from the
+[k][N] rows with torch ops on the device.  The fused kernels never go through them."""
+from __future__ import annotations
+
+import re
+
+import torch
+
+from .. import _abi as A
+
+MUSHR_JOINT_NAMES = [
+    "front_left_wheel_steer", "front_right_wheel_steer",
+    "back_left_wheel_throttle", "back_right_wheel_throttle",
+    "front_left_wheel_throttle", "front_right_wheel_throttle",
+    "front_left_wheel_suspension", "front_right_wheel_suspension",
+    "back_left_wheel_suspension", "back_right_wheel_suspension",
+]
+
+
+def quat_rotate_inverse(q: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """body = R(q)^T world, q = (w, x, y, z)"""
+    w, u = q[:, 0:1], q[:, 1:4]
+    return v * (2.0 * w * w - 1.0) - torch.cross(u, v, dim=-1) * w * 2.0 + u * (u * v).sum(-1, keepdim=True) * 2.0
+
+
+class ArticulationData:
+    def __init__(self, batch):
+        self._b = batch
+
+    def _rows(self, r0, k):
+        b = self._b
+        return b.state[r0:r0 + k, : b.n].T.contiguous()
+
+    @property
+    def root_pos_w(self):
+        return self._rows(A.S_PX, 3)
+
+    root_link_pos_w = root_pos_w
+
+    @property
+    def root_quat_w(self):
+        return self._rows(A.S_QW, 4)
+
+    root_link_quat_w = root_quat_w
+
+    @property
+    def root_lin_vel_w(self):
+        return self._rows(A.S_VX, 3)
+
+    root_com_lin_vel_w = root_lin_vel_w
+
+    @property
+    def root_ang_vel_w(self):
+        return self._rows(A.S_WX, 3)
+
+    root_link_ang_vel_w = root_ang_vel_w
+    root_com_ang_vel_w = root_ang_vel_w
+
+    @property
+    def root_lin_vel_b(self):
+        return quat_rotate_inverse(self.root_quat_w, self.root_lin_vel_w)
+
+    @property
+    def root_ang_vel_b(self):
+        return quat_rotate_inverse(self.root_quat_w, self.root_ang_vel_w)
+
+    @property
+    def root_state_w(self):
+        return self._rows(A.S_PX, 13)
+
+    @property
+    def root_vel_w(self):
+        return self._rows(A.S_VX, 6)
+
+    @property
+    def default_root_state(self):
+        d = torch.zeros(self._b.n, 13, device=self._b.device)
+        d[:, 3] = 1.0
+        return d
+
+    @property
+    def joint_pos(self):
+        b = self._b
+        jp = torch.zeros(b.n, len(MUSHR_JOINT_NAMES), device=b.device)
+        jp[:, 0] = jp[:, 1] = b.state[A.S_STEER_POS, : b.n]
+        return jp  # wheel spin angles are not integrated (no term reads them); suspension deflection is implicit
+
+    @property
+    def joint_vel(self):
+        b = self._b
+        jv = torch.zeros(b.n, len(MUSHR_JOINT_NAMES), device=b.device)
+        jv[:, 0] = jv[:, 1] = b.state[A.S_STEER_VEL, : b.n]
+        jv[:, 2], jv[:, 3] = b.state[A.S_WHEEL_BL, : b.n], b.state[A.S_WHEEL_BR, : b.n]
+        jv[:, 4], jv[:, 5] = b.state[A.S_WHEEL_FL, : b.n], b.state[A.S_WHEEL_FR, : b.n]
+        return jv
+
+
+class ArticulationView:
+    def __init__(self, batch, joint_names=MUSHR_JOINT_NAMES):
+        self._b = batch
+        self.data = ArticulationData(batch)
+        self.joint_names = list(joint_names)
+        self.num_instances = batch.n
+
+    def find_joints(self, name_keys, joint_subset=None, preserve_order=False):
+        keys = [name_keys] if isinstance(name_keys, str) else list(name_keys)
+        ids, names = [], []
+        for i, n in enumerate(self.joint_names):
+            if any(re.fullmatch(k, n) for k in keys):
+                ids.append(i)
+                names.append(n)
+        return ids, names
+
+    # plugin reset events (e.g. a user `reset_root_state_*` term) write through these
+    def write_root_pose_to_sim(self, pose, env_ids=None):
+        ids = slice(None) if env_ids is None else env_ids
+        self._b.state[A.S_PX:A.S_PX + 7, ids] = pose.T.to(torch.float32)
+
+    def write_root_velocity_to_sim(self, vel, env_ids=None):
+        ids = slice(None) if env_ids is None else env_ids
+        self._b.state[A.S_VX:A.S_VX + 6, ids] = vel.T.to(torch.float32)
+
+
+class SceneView:
+    def __init__(self, batch, cfg=None):
+        self._b = batch
+        self.cfg = cfg
+        self.num_envs = batch.n
+        self.env_origins = torch.zeros(batch.n, 3, device=batch.device)  # env_spacing = 0 (mushr_drift_env_cfg.py:373)
+        self.articulations = {"robot": ArticulationView(batch)}
+        self.sensors = {}
+        self.terrain = getattr(cfg, "terrain", None)
+
+    def __getitem__(self, key):
+        if key in self.articulations:
+            return self.articulations[key]
+        if key in self.sensors:
+            return self.sensors[key]
+        if key == "terrain":
+            return self.terrain
+        raise KeyError(key)
+
+    def keys(self):
+        return list(self.articulations) + list(self.sensors) + ["terrain"]
