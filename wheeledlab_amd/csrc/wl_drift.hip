@@ -15,6 +15,9 @@
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef WL_MIN_WAVES
+#define WL_MIN_WAVES 2   // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for
+#endif
 constexpr int kObsDim = 14;
 constexpr int kObsPad = 15;  // odd LDS row pitch: the transposing writes are bank-conflict free
 
@@ -101,10 +104,11 @@ WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0
 }
 
 template <class Ground>
-__global__ void __launch_bounds__(kBlock) drift_step_kernel(const WlDriftParams p, const WlEnvBuffers b,
+__global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const WlDriftParams p, const WlEnvBuffers b,
                                                             const float2* __restrict__ actions,
                                                             const float* __restrict__ noise, const WlStepOut out,
-                                                            const uint64_t seed, const uint64_t step, const Ground ground) {
+                                                            const uint64_t seed, const uint64_t step, const Ground ground,
+                                                            const VehDerived vd) {
     __shared__ float tile[kBlock * kObsPad];
     __shared__ float blk_metrics[WL_M_COUNT];
     const int e = blockIdx.x * kBlock + threadIdx.x;
@@ -126,13 +130,10 @@ __global__ void __launch_bounds__(kBlock) drift_step_kernel(const WlDriftParams 
         process_action(p.action, a.x, a.y, v_t, delta);
         EnvConst ec;
         joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-        ec.mass = S(WL_S_MASS, e);
-        ec.inv_mass = rcp(ec.mass);
+        env_const_mass(ec, vp, vd, S(WL_S_MASS, e));
         ec.mu_s = S(WL_S_MU_S, e) * vp.ground_mu_s;
         ec.mu_d = fminf(S(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
         ec.damp = S(WL_S_DAMP, e);
-        ec.Ib = v3(ec.mass * vp.gyr_x * vp.gyr_x, ec.mass * vp.gyr_y * vp.gyr_y, ec.mass * vp.gyr_z * vp.gyr_z);
-        ec.inv_Ib = v3(rcp(ec.Ib.x), rcp(ec.Ib.y), rcp(ec.Ib.z));
         // ---- load state ----
         VehState s;
         V3 pos = ld3(S, WL_S_PX, e);
@@ -143,17 +144,24 @@ __global__ void __launch_bounds__(kBlock) drift_step_kernel(const WlDriftParams 
         for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
         s.th = S(WL_S_STEER_POS, e);
         s.om = S(WL_S_STEER_VEL, e);
+#ifndef WL_LATE_LOADS
         float timer_hf = S(WL_S_TIMER_HF, e), timer_lf = S(WL_S_TIMER_LF, e);
         int ep_len = b.episode_len[e];
+#endif
         {
             const Mat3 R = mat_from_quat(s.q);
             s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);  // CoM = link origin + R (0,0,cg_z)
             s.wb = mul_t(R, ww);
         }
         // ---- physics: decimation x substeps, everything in registers ----
-        const int n_sub = p.decimation * vp.substeps;
-        const float h = p.sim_dt / (float)vp.substeps, inv_h = rcp(h);
-        for (int k = 0; k < n_sub; ++k) vehicle_substep(vp, ec, s, h, inv_h, ground);
+        for (int k = 0; k < vd.n_sub; ++k) vehicle_substep(vp, vd, ec, s, ground);
+#ifdef WL_LATE_LOADS
+        // rows that only the bookkeeping tail needs are fetched after the physics loop: they would otherwise sit in
+        // VGPRs through all sub-steps (occupancy); other resident waves cover the latency
+        asm volatile("" ::: "memory");
+        float timer_hf = S(WL_S_TIMER_HF, e), timer_lf = S(WL_S_TIMER_LF, e);
+        int ep_len = b.episode_len[e];
+#endif
         const Mat3 R = mat_from_quat(s.q);
         ww = mul(R, s.wb);
         pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
@@ -412,7 +420,8 @@ int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* ac
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated) return WL_EINVAL;
     clear_error();
     drift_step_kernel<FlatGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
-        *p, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{});
+        *p, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{},
+        derive_vehicle(p->vehicle, p->sim_dt, p->decimation));
     return launch_status();
 }
 
@@ -424,6 +433,7 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
     clear_error();
     const int grid = grid_for(b->n_envs);
+    const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = *out;
         o.obs += k * obs_step_stride;
@@ -432,7 +442,7 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
         o.truncated += k * vec_step_stride;
         drift_step_kernel<FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
             *p, *b, (const float2*)(actions + (int64_t)k * b->n_envs * 2), nullptr, o, seed, step0 + (uint64_t)k,
-            FlatGround{});
+            FlatGround{}, vd);
     }
     return launch_status();
 }

@@ -15,13 +15,54 @@ struct VehState {
 };
 
 struct EnvConst {   // per-env constants hoisted out of the sub-step loop
-    float mass, inv_mass;
+    float weight, h_inv_mass;  // m g ; h / m
     float mu_s, mu_d;          // combined (wheel x ground) friction
     float damp;                // throttle damping of driven wheels
-    V3 Ib, inv_Ib;             // body inertia diag
+    V3 Ib, h_inv_Ib;           // body inertia diag ; h / I
     float steer_target;
     float wheel_target[4];
 };
+
+
+// Uniform constants derived from WlVehicleParams + dt.  gfx950 has no scalar float ALU: anything computed from
+// uniform parameters inside the kernel lands in VGPRs and, being loop-invariant, stays there through every sub-step.
+// The C-ABI wrappers compute these once on the host instead, so in-kernel they are SGPR operands.
+struct VehDerived {
+    float h, inv_h, half_h;                 // sub-step length
+    float steer_a, steer_b;                 // h kp / J ;  1 / (1 + h kd / J + h^2 kp / J)
+    float steer_J_h, steer_h_J;             // J / h ; h / J
+    float zrel;                             // wheel centre z relative to the CoM (body frame)
+    float Iw_h, A0;                         // wheel inertia / h ; Iw_h + bearing damping
+    float inv_wlim;                         // 1 / motor_vel_limit
+    float r2;                               // wheel radius squared
+    int32_t n_sub;                          // decimation * substeps
+};
+
+inline VehDerived derive_vehicle(const WlVehicleParams& vp, float sim_dt, int decimation) {
+    VehDerived d;
+    d.h = sim_dt / (float)vp.substeps;
+    d.inv_h = 1.f / d.h;
+    d.half_h = 0.5f * d.h;
+    const float invJ = 1.f / vp.steer_inertia;
+    d.steer_a = d.h * vp.steer_kp * invJ;
+    d.steer_b = 1.f / (1.f + d.h * vp.steer_kd * invJ + d.h * d.h * vp.steer_kp * invJ);
+    d.steer_J_h = vp.steer_inertia * d.inv_h;
+    d.steer_h_J = d.h * invJ;
+    d.zrel = vp.wheel_z - vp.cg_z;
+    d.Iw_h = vp.wheel_inertia * d.inv_h;
+    d.A0 = d.Iw_h + vp.wheel_damping;
+    d.inv_wlim = 1.f / vp.motor_vel_limit;
+    d.r2 = vp.wheel_radius * vp.wheel_radius;
+    d.n_sub = decimation * vp.substeps;
+    return d;
+}
+
+WL_DEV void env_const_mass(EnvConst& ec, const WlVehicleParams& vp, const VehDerived& vd, float mass) {
+    ec.weight = mass * vp.gravity;
+    ec.h_inv_mass = vd.h * rcp(mass);
+    ec.Ib = v3(mass * (vp.gyr_x * vp.gyr_x), mass * (vp.gyr_y * vp.gyr_y), mass * (vp.gyr_z * vp.gyr_z));
+    ec.h_inv_Ib = v3(vd.h * rcp(ec.Ib.x), vd.h * rcp(ec.Ib.y), vd.h * rcp(ec.Ib.z));
+}
 
 struct FlatGround {
     WL_DEV void sample(float, float, float& zg, V3& n) const {
@@ -31,13 +72,13 @@ struct FlatGround {
 };
 
 template <int WHEEL>  // 0 bl, 1 br, 2 fl, 3 fr
-WL_DEV void wheel_force(const WlVehicleParams& vp, const EnvConst& ec, const Mat3& R, V3 x, V3 v, V3 ww, float cs,
-                        float sn, float h, float inv_h, float zg, V3 n, float& w_spin, V3& Ftot, V3& Ttot) {
+WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Mat3& R, V3 x, V3 v,
+                        V3 ww, float cs, float sn, float zg, V3 n, float& w_spin, V3& Ftot, V3& Ttot) {
     constexpr bool front = WHEEL >= 2;
     constexpr bool left = (WHEEL & 1) == 0;
     const float r = vp.wheel_radius;
     const V3 pb = v3(front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, left ? vp.half_track : -vp.half_track,
-                     vp.wheel_z - vp.cg_z);
+                     vd.zrel);
     const V3 arm_c = mul(R, pb);
     const float cz = x.z + arm_c.z;
     const float pen = r - (cz - zg) * n.z;
@@ -64,12 +105,12 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const EnvConst& ec, const Mat
     const float d = driven ? ec.damp : 0.f;
     const float wt = ec.wheel_target[WHEEL];
     // DC-motor torque window at the current spin (IsaacLab DCMotor, hound.py:13-21)
-    const float rel = w_i * rcp(vp.motor_vel_limit);
+    const float rel = w_i * vd.inv_wlim;
     const float tau_hi = clampf(vp.motor_sat * (1.f - rel), 0.f, vp.motor_limit);
     const float tau_lo = clampf(vp.motor_sat * (-1.f - rel), -vp.motor_limit, 0.f);
-    const float Iw_h = vp.wheel_inertia * inv_h;
+    const float Iw_h = vd.Iw_h;
     // implicit spin update with the tyre's secant stiffness (unconditionally stable)
-    const float A = Iw_h + vp.wheel_damping + K * r * r;
+    const float A = fmaf(K, vd.r2, vd.A0);
     const float rhs0 = fmaf(Iw_h, w_i, r * K * vcx);
     const float w_u = fmaf(d, wt, rhs0) * rcp(A + d);
     // tau = d (wt - w_u) cancels catastrophically near the target (d / A ~ 3e3 amplifies the rounding of w_u), so
@@ -85,7 +126,7 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const EnvConst& ec, const Mat
         const float scale = Fmax * rsq(fmaxf(mag2, 1e-30f));
         Fx *= scale;
         Fy *= scale;
-        const float A2 = Iw_h + vp.wheel_damping;
+        const float A2 = vd.A0;
         const float rhs2 = fmaf(Iw_h, w_i, -r * Fx);
         const float w_u2 = fmaf(d, wt, rhs2) * rcp(A2 + d);
         const float tau_u2 = d * (wt - w_u2);
@@ -99,15 +140,15 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const EnvConst& ec, const Mat
 }
 
 template <class Ground>
-WL_DEV void vehicle_substep(const WlVehicleParams& vp, const EnvConst& ec, VehState& s, float h, float inv_h,
+WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
                             const Ground& ground) {
+    const float h = vd.h;
     // steering: implicit PD drive, effort- and rate-limited (hound.py:5-12)
     {
-        const float invJ = rcp(vp.steer_inertia);
         const float e = ec.steer_target - s.th;
-        float om_n = fmaf(h * vp.steer_kp * invJ, e, s.om) * rcp(1.f + h * vp.steer_kd * invJ + h * h * vp.steer_kp * invJ);
-        const float tau = clampf(vp.steer_inertia * (om_n - s.om) * inv_h, -vp.steer_effort, vp.steer_effort);
-        om_n = clampf(fmaf(h * invJ, tau, s.om), -vp.steer_vel_limit, vp.steer_vel_limit);
+        float om_n = fmaf(vd.steer_a, e, s.om) * vd.steer_b;
+        const float tau = clampf(vd.steer_J_h * (om_n - s.om), -vp.steer_effort, vp.steer_effort);
+        om_n = clampf(fmaf(vd.steer_h_J, tau, s.om), -vp.steer_vel_limit, vp.steer_vel_limit);
         s.th = fmaf(h, om_n, s.th);
         s.om = om_n;
     }
@@ -123,25 +164,34 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const EnvConst& ec, VehSt
     for (int i = 0; i < 4; ++i) {
         const bool front = i >= 2, left = (i & 1) == 0;
         const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;
-        const float bz = vp.wheel_z - vp.cg_z;
+        const float bz = vd.zrel;
         const float cx = s.x.x + fmaf(R.r0.x, bx, fmaf(R.r0.y, by, R.r0.z * bz));
         const float cy = s.x.y + fmaf(R.r1.x, bx, fmaf(R.r1.y, by, R.r1.z * bz));
         ground.sample(cx, cy, zg[i], nn[i]);
     }
-    wheel_force<0>(vp, ec, R, s.x, s.v, ww, cs, sn, h, inv_h, zg[0], nn[0], s.wheel[0], F, T);
-    wheel_force<1>(vp, ec, R, s.x, s.v, ww, cs, sn, h, inv_h, zg[1], nn[1], s.wheel[1], F, T);
-    wheel_force<2>(vp, ec, R, s.x, s.v, ww, cs, sn, h, inv_h, zg[2], nn[2], s.wheel[2], F, T);
-    wheel_force<3>(vp, ec, R, s.x, s.v, ww, cs, sn, h, inv_h, zg[3], nn[3], s.wheel[3], F, T);
-    F.z -= ec.mass * vp.gravity;
-    s.v = fma3(h * ec.inv_mass, F, s.v);
+#ifdef WL_SEQ_WHEELS
+#define WL_WHEEL_FENCE() __builtin_amdgcn_sched_barrier(0)   // one wheel's temporaries live at a time (occupancy)
+#else
+#define WL_WHEEL_FENCE()
+#endif
+    wheel_force<0>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg[0], nn[0], s.wheel[0], F, T);
+    WL_WHEEL_FENCE();
+    wheel_force<1>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg[1], nn[1], s.wheel[1], F, T);
+    WL_WHEEL_FENCE();
+    wheel_force<2>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg[2], nn[2], s.wheel[2], F, T);
+    WL_WHEEL_FENCE();
+    wheel_force<3>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg[3], nn[3], s.wheel[3], F, T);
+    WL_WHEEL_FENCE();
+    F.z -= ec.weight;
+    s.v = fma3(ec.h_inv_mass, F, s.v);
     const V3 Tb = mul_t(R, T);
     const V3 Iw = v3(ec.Ib.x * s.wb.x, ec.Ib.y * s.wb.y, ec.Ib.z * s.wb.z);
     const V3 gyro = cross(s.wb, Iw);
-    s.wb = v3(fmaf(h * ec.inv_Ib.x, Tb.x - gyro.x, s.wb.x), fmaf(h * ec.inv_Ib.y, Tb.y - gyro.y, s.wb.y),
-              fmaf(h * ec.inv_Ib.z, Tb.z - gyro.z, s.wb.z));
+    s.wb = v3(fmaf(ec.h_inv_Ib.x, Tb.x - gyro.x, s.wb.x), fmaf(ec.h_inv_Ib.y, Tb.y - gyro.y, s.wb.y),
+              fmaf(ec.h_inv_Ib.z, Tb.z - gyro.z, s.wb.z));
     const V3 w2 = mul(R, s.wb);
     s.x = fma3(h, s.v, s.x);
-    const float hh = 0.5f * h;
+    const float hh = vd.half_h;
     Quat q = s.q;
     Quat dq;
     dq.w = -w2.x * q.x - w2.y * q.y - w2.z * q.z;
