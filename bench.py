@@ -37,6 +37,17 @@ BYTES_WRITE = (23 + 7) * 4 + 4 + 14 * 4 + 4 + 2
 BYTES_PER_ENV_STEP = BYTES_READ + BYTES_WRITE
 
 
+def pmc_traffic(n_envs: int):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json); bench.py cannot
+    profile itself, so the number is the one measured with tools/pmc_run.py on the same kernel and env count."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        e = json.load(open(f)).get("entries", {}).get(str(n_envs))
+        if e:
+            return e["traffic_bytes"], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def cpu_baseline(n_envs: int, budget_s: float = 12.0):
     """torch-CPU port of the reference's drift mdp path (oracle/torch_mdp.py) on the host cores."""
     from oracle import torch_mdp as T
@@ -159,6 +170,7 @@ def main():
     torch.cuda.synchronize()
     launch_us = k0.elapsed_time(k1) * 1e3 / (reps * ROLLOUT)
     achieved = BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
+    traffic, traffic_src = pmc_traffic(n)
 
     sweep = []
     if args.sweep and rank == 0:
@@ -196,7 +208,7 @@ def main():
                        "parallelism": f"env-shard x{world}, metric all-reduce / {ROLLOUT} steps"},
             "gpu_event_ms_per_step": gpu_ms / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "drift_step_kernel<FlatGround>", "launch_us": launch_us,
                          "bytes_per_env_step": BYTES_PER_ENV_STEP, "envs_per_launch": n},
             "episode_metrics": {"resets": float(metric_sum[8]), "timeouts": float(metric_sum[9]),
