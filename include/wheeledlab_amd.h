@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 4
+#define WL_ABI_VERSION 5
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -49,7 +49,10 @@ enum WlStateField {
     WL_S_MU_S, WL_S_MU_D, WL_S_DAMP, WL_S_MASS,
     /* per-term episode reward sums (RewardManager._episode_sums), WL_MAX_REW_TERMS rows */
     WL_S_EPSUM0,
-    WL_S_COUNT = WL_S_EPSUM0 + 8
+    /* goal command of the elevation task (UniformPose2dCommand): target in the yaw-aligned base frame (x, y), world
+       target (x, y), heading, time left until resampling */
+    WL_S_CMD_BX = WL_S_EPSUM0 + 8, WL_S_CMD_BY, WL_S_TGT_X, WL_S_TGT_Y, WL_S_TGT_H, WL_S_CMD_TIMER,
+    WL_S_COUNT
 };
 #define WL_N_DYN 23          /* rows [0, WL_N_DYN) are read AND written every step */
 #define WL_MAX_REW_TERMS 8
@@ -215,6 +218,75 @@ int wl_drift_reset(const WlDriftParams* p, const WlEnvBuffers* b, const uint8_t*
 /* Observation only (env.reset() / get_observations()): 14-dim policy obs from the current state. */
 int wl_drift_observe(const WlDriftParams* p, const WlEnvBuffers* b, const float* noise, float* obs, uint64_t seed,
                      uint64_t step, void* stream);
+
+/* ======================================================================================================== */
+/* Elevation task (wheeledlab_tasks/elevation/mushr_elevation_env_cfg.py)                                   */
+/* ======================================================================================================== */
+
+/* terrain: regular-grid heightfield, height[iy][ix] row-major, world x = x0 + ix*cell. Replaces the terrain mesh
+ * `Terrains/huge_compact.usd` (:95-108) for BOTH wheel contact and the ray-caster (:132-142). Outside the grid the
+ * ground is the extra plane at z = outside_z (:120-128) and height-scan rays miss. */
+typedef struct WlHeightField {
+    const float* height;
+    int32_t nx, ny;
+    float x0, y0, cell, outside_z;
+} WlHeightField;
+
+enum WlElevRewTerm { WL_ER_GOAL_PROGRESS = 0, WL_ER_HIGHER_ELEVATION, WL_ER_FALLING, WL_ER_STUCK_PENALTY, WL_ER_NTERMS };
+/* `terminated` terms, counted in metrics[WL_M_TERM0 + k] */
+enum WlElevTermTerm { WL_ET_BELOW_MIN_HEIGHT = 0, WL_ET_STUCK, WL_ET_ROLLOVER, WL_ET_AT_GOAL, WL_ET_NTERMS };
+
+#define WL_ELEV_SCAN_N 26                      /* GridPatternCfg(size 2.5, resolution 0.1) -> 26 x 26 rays (:139)   */
+#define WL_ELEV_OBS_DIM (13 + WL_ELEV_SCAN_N * WL_ELEV_SCAN_N)   /* 689 (:61-86)                                  */
+
+typedef struct WlElevParams {
+    float sim_dt;             /* 0.01 (:461)                                                                  */
+    int32_t decimation;       /* 10   (:462)                                                                  */
+    int32_t max_episode_length; /* ceil(20 s / 0.1 s) = 200 (:465)                                            */
+    WlActionParams action;    /* Mushr4WDActionCfg (common/actions.py:29-47)                                  */
+    WlVehicleParams vehicle;  /* MUSHR_SUS_CFG 4WD, motor limit 0.25 (hound.py:13-21)                         */
+    float weight[WL_MAX_REW_TERMS];   /* WlElevRewTerm order: 200, 5000, 0, -200 (:286-305)                   */
+    float min_height;         /* root_height_below_minimum 0.15 (:356-359)                                    */
+    float stuck_min_vel, stuck_wheel_spin, stuck_vel_cap;   /* 0.02, 5.0 (:360-366), forward_vel cap 1.2 (:157)  */
+    float upright_cos;        /* cos(60 deg): rollover when R33 < this (:217-222, 368-371)                     */
+    float goal_dist;          /* 0.5 (:373-376)                                                               */
+    float fall_vel;           /* 0.10 (:251-254)                                                              */
+    float elev_z0, elev_min, elev_min_vel;   /* 0.19, 0.1, 0.1 (:166-173)                                      */
+    float progress_offset;    /* 5 (:249)                                                                     */
+    float reset_xy, reset_yaw, reset_vel[2], reset_z, spawn_clearance;   /* :409-419, :147-149                 */
+    float cmd_xy, cmd_heading, cmd_resample_s;                           /* :425-435                           */
+    float scan_size, scan_res, scan_offset, obs_clip;                    /* :74-82, :139                       */
+    int32_t log_episode_sums;
+} WlElevParams;
+
+/*
+ * Fused elevation env.step(): action term (RCCar4WDAction, rc_car_actions.py:36-64) -> decimation x substeps rigid
+ * body + 4 tyre contacts on the heightfield -> terminations (:349-376) -> rewards (:286-305) -> reset
+ * (isaaclab reset_root_state_uniform, :409-419) -> goal command update (:425-435) in ONE launch (lane = env), then
+ * a second launch (block = env) that assembles the 689-dim observation incl. the 26 x 26 height map (:44-48,61-86).
+ * `b->ref_poses` is unused (may be NULL).  obs is [n][WL_ELEV_OBS_DIM].
+ */
+int wl_elev_step(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* actions,
+                 const WlStepOut* out, uint64_t seed, uint64_t step, void* stream);
+int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* actions,
+                    const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps,
+                    uint64_t seed, uint64_t step0, void* stream);
+int wl_elev_reset(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const uint8_t* mask,
+                  uint64_t seed, uint64_t step, void* stream);
+/* observation only (ObservationManager.compute over ElevationObsCfg :57-88) */
+int wl_elev_observe(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, float* obs, void* stream);
+/*
+ * Elevation mdp terms on caller-supplied state tensors (parity entry point). SoA inputs float[k][stride]:
+ * pos[3], quat[4], lin_vel_b[3], lin_vel_w[3], wheel_vel[4], command[2]; optional ray inputs sensor_z[n],
+ * hit_z[n_rays][stride] (NULL to skip).  Outputs: terms[4][stride] unweighted (goal_progress_rate,
+ * higher_elevation, is_falling_penalty, is_terminated(stuck)), flags[4][stride] bytes (below_min_height, stuck,
+ * rollover, at_goal), goal_rel[2][stride], height_map[n_rays][stride] (unclipped world_height_map).
+ * Replaces mushr_elevation_env_cfg.py:44-55,155-173,217-222,239-254,268-273,339-347.
+ */
+int wl_elev_mdp(const WlElevParams* p, int32_t n, int64_t stride, const float* pos, const float* quat,
+                const float* lin_vel_b, const float* lin_vel_w, const float* wheel_vel, const float* command,
+                const uint8_t* timed_out, int32_t n_rays, const float* sensor_z, const float* hit_z, float* terms,
+                uint8_t* flags, float* goal_rel, float* height_map, void* stream);
 
 /* Raw Philox4x32-10 uniforms as used in-kernel: out[4][n] for counter (env, step, stream_id). Test hook. */
 int wl_philox_uniform(int32_t n, uint64_t seed, uint64_t step, uint32_t stream_id, float* out, void* stream);

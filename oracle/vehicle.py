@@ -86,6 +86,9 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
         sig_safe = np.maximum(sig, F(1))
         gq = np.where(sig <= 1, mu_s * (F(2) - sig), (mu_d + (mu_s - mu_d) / sig_safe) / sig_safe)
         K = Fz * gq / vden
+        # explicit-stepping stability cap: the tyre may not take out more than half of this wheel's share of the
+        # body's momentum per sub-step (binds only for high-friction tasks at low speed; never in the drift task)
+        K = np.minimum(K, F(0.125) * mass / h).astype(F)
         driven = (vp.drive == 1) or (not front)
         d = damp if driven else np.zeros_like(damp)
         wt = wheel_target[:, i]

@@ -8,15 +8,20 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 4
+WL_ABI_VERSION = 5
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
 (S_PX, S_PY, S_PZ, S_QW, S_QX, S_QY, S_QZ, S_VX, S_VY, S_VZ, S_WX, S_WY, S_WZ, S_WHEEL_BL, S_WHEEL_BR, S_WHEEL_FL,
  S_WHEEL_FR, S_STEER_POS, S_STEER_VEL, S_ACT0, S_ACT1, S_TIMER_HF, S_TIMER_LF, S_MU_S, S_MU_D, S_DAMP, S_MASS,
  S_EPSUM0) = range(28)
-S_COUNT = S_EPSUM0 + 8
+S_CMD_BX, S_CMD_BY, S_TGT_X, S_TGT_Y, S_TGT_H, S_CMD_TIMER = range(S_EPSUM0 + 8, S_EPSUM0 + 14)
+S_COUNT = S_EPSUM0 + 14
 N_DYN = 23
+ELEV_SCAN_N = 26
+ELEV_OBS_DIM = 13 + ELEV_SCAN_N * ELEV_SCAN_N
+ELEV_TERM_NAMES = ("vel_towards_goal", "height_z", "falling_penalty", "termination_penalty")
+ELEV_DONE_NAMES = ("cart_out_of_bounds", "stuck", "rollover", "at_goal")
 # WlMetric
 M_EPSUM0, M_RESETS, M_TIMEOUTS, M_TERM0, M_NONFINITE, M_EPLEN, M_COUNT = 0, 8, 9, 10, 14, 15, 16
 # WlDriftRewTerm
@@ -66,6 +71,25 @@ class WlDriftParams(C.Structure):
     ]
 
 
+class WlHeightField(C.Structure):
+    _fields_ = [("height", C.c_void_p), ("nx", C.c_int32), ("ny", C.c_int32), ("x0", C.c_float), ("y0", C.c_float),
+                ("cell", C.c_float), ("outside_z", C.c_float)]
+
+
+class WlElevParams(C.Structure):
+    _fields_ = [
+        ("sim_dt", C.c_float), ("decimation", C.c_int32), ("max_episode_length", C.c_int32),
+        ("action", WlActionParams), ("vehicle", WlVehicleParams), ("weight", C.c_float * WL_MAX_REW_TERMS),
+        ("min_height", C.c_float), ("stuck_min_vel", C.c_float), ("stuck_wheel_spin", C.c_float),
+        ("stuck_vel_cap", C.c_float), ("upright_cos", C.c_float), ("goal_dist", C.c_float), ("fall_vel", C.c_float),
+        ("elev_z0", C.c_float), ("elev_min", C.c_float), ("elev_min_vel", C.c_float), ("progress_offset", C.c_float),
+        ("reset_xy", C.c_float), ("reset_yaw", C.c_float), ("reset_vel", C.c_float * 2), ("reset_z", C.c_float),
+        ("spawn_clearance", C.c_float), ("cmd_xy", C.c_float), ("cmd_heading", C.c_float),
+        ("cmd_resample_s", C.c_float), ("scan_size", C.c_float), ("scan_res", C.c_float), ("scan_offset", C.c_float),
+        ("obs_clip", C.c_float), ("log_episode_sums", C.c_int32),
+    ]
+
+
 class WlEnvBuffers(C.Structure):
     _fields_ = [("state", C.c_void_p), ("episode_len", C.c_void_p), ("ref_poses", C.c_void_p),
                 ("metrics", C.c_void_p), ("stride", C.c_int64), ("n_envs", C.c_int32), ("env_offset", C.c_int32),
@@ -92,6 +116,12 @@ SIGNATURES = {
     "wl_drift_reset": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _u64, _u64, _vp]),
     "wl_drift_observe": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _vp, _u64, _u64, _vp]),
     "wl_philox_uniform": (C.c_int, [_i32, _u64, _u64, C.c_uint32, _vp, _vp]),
+    "wl_elev_step": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _P(WlStepOut), _u64, _u64, _vp]),
+    "wl_elev_rollout": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _P(WlStepOut), _i64, _i64,
+                                  _i32, _u64, _u64, _vp]),
+    "wl_elev_reset": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _u64, _u64, _vp]),
+    "wl_elev_observe": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _vp]),
+    "wl_elev_mdp": (C.c_int, [_P(WlElevParams), _i32, _i64] + [_vp] * 7 + [_i32] + [_vp] * 7),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwheeledlab_amd.so")

@@ -141,3 +141,82 @@ class DriftBatch:
         if zero:
             self.metrics.zero_()
         return m
+
+
+class ElevBatch:
+    """n elevation-task envs on one GPU (same SoA state matrix; rows WL_S_CMD_* carry the goal command)."""
+
+    OBS_DIM = A.ELEV_OBS_DIM
+
+    def __init__(self, n_envs: int, device="cuda:0", params: A.WlElevParams | None = None, seed: int = 42,
+                 env_offset: int = 0, heightfield=None, metrics_slots: int = 1, mass_add=(0.2, 0.5),
+                 wheel_mu=(2.0, 1.0), damping: float = 1000.0):
+        from .params import elev_params
+        from .terrain import synthetic_heightfield
+        self.lib = A.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise A.HipExtensionMissing("ElevBatch needs a HIP device; there is no CPU path")
+        self.n, self.stride = int(n_envs), ((int(n_envs) + 63) // 64) * 64
+        self.p = params if params is not None else elev_params()
+        self.seed, self.env_offset, self.step_count = int(seed), int(env_offset), 0
+        dev = self.device
+        self.state = torch.zeros(A.S_COUNT, self.stride, dtype=torch.float32, device=dev)
+        self.episode_len = torch.zeros(self.stride, dtype=torch.int32, device=dev)
+        self.metrics_slots = int(metrics_slots)
+        self.metrics = torch.zeros(self.metrics_slots, A.M_COUNT, dtype=torch.float32, device=dev)
+        if self.metrics_slots == 1:
+            self.metrics = self.metrics[0]
+        self.obs = torch.zeros(self.n, self.OBS_DIM, dtype=torch.float32, device=dev)
+        self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.terminated = torch.zeros(self.n, dtype=torch.bool, device=dev)
+        self.truncated = torch.zeros(self.n, dtype=torch.bool, device=dev)
+        h, x0, y0, cell = heightfield if heightfield is not None else synthetic_heightfield()
+        self.height = torch.as_tensor(h, dtype=torch.float32).contiguous().to(dev)
+        self._hf = A.WlHeightField(self.height.data_ptr(), self.height.shape[1], self.height.shape[0], float(x0), float(y0),
+                                   float(cell), 0.0)
+        # startup events (elevation cfg :387-407): wheel friction fixed (2.0, 1.0), base mass += U(0.2, 0.5)
+        g = torch.Generator().manual_seed(self.seed)
+        s = self.state
+        s[A.S_QW] = 1.0
+        s[A.S_MU_S], s[A.S_MU_D], s[A.S_DAMP] = wheel_mu[0], wheel_mu[1], damping
+        s[A.S_MASS] = (MUSHR_CHASSIS_MASS + torch.rand(self.stride, generator=g) * (mass_add[1] - mass_add[0]) + mass_add[0]).to(dev)
+        self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics.data_ptr(),
+                                    self.stride, self.n, self.env_offset, self.metrics_slots)
+        self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
+                                self.truncated.data_ptr())
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, mask: torch.Tensor | None = None):
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        A.check(self.lib.wl_elev_reset(C.byref(self.p), C.byref(self._bufs), C.byref(self._hf),
+                                       None if m is None else m.data_ptr(), self.seed, self.step_count, self._stream()),
+                "wl_elev_reset")
+
+    def observe(self) -> torch.Tensor:
+        A.check(self.lib.wl_elev_observe(C.byref(self.p), C.byref(self._bufs), C.byref(self._hf), self.obs.data_ptr(),
+                                         self._stream()), "wl_elev_observe")
+        return self.obs
+
+    def step(self, actions: torch.Tensor):
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.shape != (self.n, 2):
+            actions = actions.to(torch.float32).reshape(self.n, 2).contiguous()
+        A.check(self.lib.wl_elev_step(C.byref(self.p), C.byref(self._bufs), C.byref(self._hf), actions.data_ptr(),
+                                      C.byref(self._out), self.seed, self.step_count, self._stream()), "wl_elev_step")
+        self.step_count += 1
+        return self.obs, self.reward, self.terminated, self.truncated
+
+    def rollout(self, actions: torch.Tensor, obs_out=None, rew_out=None, term_out=None, trunc_out=None):
+        K = actions.shape[0]
+        assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
+        if obs_out is not None:
+            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr())
+            os_, vs_ = self.n * self.OBS_DIM, self.n
+        else:
+            out, os_, vs_ = self._out, 0, 0
+        A.check(self.lib.wl_elev_rollout(C.byref(self.p), C.byref(self._bufs), C.byref(self._hf), actions.data_ptr(),
+                                         C.byref(out), os_, vs_, K, self.seed, self.step_count, self._stream()),
+                "wl_elev_rollout")
+        self.step_count += K

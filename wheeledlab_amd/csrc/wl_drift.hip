@@ -8,31 +8,18 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/wheeledlab_amd.h"
+#include "wl_kernel_common.h"
 #include "wl_drift_terms.h"
 #include "wl_rng.h"
 #include "wl_vehicle.h"
 
 namespace {
 
-constexpr int kBlock = 256;
 #ifndef WL_MIN_WAVES
 #define WL_MIN_WAVES 2   // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for
 #endif
 constexpr int kObsDim = 14;
 constexpr int kObsPad = 15;  // odd LDS row pitch: the transposing writes are bank-conflict free
-
-struct Rows {  // row accessor of the SoA state matrix
-    float* base;
-    int64_t stride;
-    WL_DEV float& operator()(int row, int env) const { return base[row * stride + env]; }
-};
-
-WL_DEV V3 ld3(const Rows& s, int row, int e) { return v3(s(row, e), s(row + 1, e), s(row + 2, e)); }
-WL_DEV void st3(const Rows& s, int row, int e, V3 v) {
-    s(row, e) = v.x;
-    s(row + 1, e) = v.y;
-    s(row + 2, e) = v.z;
-}
 
 struct ResetDraw {
     V3 pos;
@@ -373,12 +360,6 @@ __global__ void philox_uniform_kernel(int n, uint64_t seed, uint64_t step, uint3
     out[2 * n + e] = u.z;
     out[3 * n + e] = u.w;
 }
-
-inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
-// The host process (PyTorch) may leave a benign sticky error (e.g. hipErrorNotReady from an event query) in this
-// thread's HIP error slot: clear it before the launch so launch_status() reports only our own launch.
-inline void clear_error() { (void)hipGetLastError(); }
-inline int launch_status() { return hipGetLastError() == hipSuccess ? WL_OK : WL_ELAUNCH; }
 
 int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
     if (!p || !b || !b->state || !b->episode_len || !b->ref_poses || !b->metrics) return WL_EINVAL;

@@ -1,0 +1,435 @@
+// wl_elev.hip -- elevation task (wheeledlab_tasks/elevation/mushr_elevation_env_cfg.py) for gfx950.
+//
+// Two launches per env.step():
+//   1. elev_step_kernel  (lane = env): 4WD action term -> decimation x substeps of the rigid body + 4 tyre contacts on
+//      the heightfield (bilinear height + normal gathers, L2-resident grid) -> terminations -> rewards -> in-kernel
+//      reset -> goal-command update.  State is read once / written once; sub-steps stay in VGPRs.
+//   2. elev_obs_kernel   (block = env): the 689-dim observation.  Lane 0 of the block computes the 13 proprioceptive
+//      values into LDS; all 256 threads cast the 26 x 26 yaw-aligned height rays (4 gathers each) and the row is
+//      written with contiguous dword stores -- this launch carries ~90 % of the task's HBM bytes (2.7 KB / env).
+#include <hip/hip_runtime.h>
+
+#include "../../include/wheeledlab_amd.h"
+#include "wl_kernel_common.h"
+#include "wl_drift_terms.h"   // process_action / joint_targets (shared action term)
+#include "wl_rng.h"
+#include "wl_vehicle.h"
+
+namespace {
+
+enum ElevStream : uint32_t { ES_RESET = 0, ES_CMD_RESET = 1, ES_CMD_RESAMPLE = 2 };
+
+// bilinear heightfield sampler (spec: oracle/heightfield.py::sample)
+struct HeightFieldGround {
+    WlHeightField f;
+    float inv_cell;
+    WL_DEV bool sample_full(float x, float y, float& z, V3& n) const {
+        const float u = (x - f.x0) * inv_cell, v = (y - f.y0) * inv_cell;
+        const bool inside = u >= 0.f && v >= 0.f && u < (float)(f.nx - 1) && v < (float)(f.ny - 1);
+        const float uc = fminf(fmaxf(u, 0.f), (float)(f.nx - 1) - 1e-3f), vc = fminf(fmaxf(v, 0.f), (float)(f.ny - 1) - 1e-3f);
+        const float fi = floorf(uc), fj = floorf(vc);
+        const int i = (int)fi, j = (int)fj;
+        const float fu = uc - fi, fv = vc - fj;
+        const float* row0 = f.height + (int64_t)j * f.nx + i;
+        const float h00 = row0[0], h10 = row0[1], h01 = row0[f.nx], h11 = row0[f.nx + 1];
+        const float a = fmaf(fu, h10 - h00, h00), b = fmaf(fu, h11 - h01, h01);
+        const float zz = fmaf(fv, b - a, a);
+        const float dzdx = fmaf(fv, (h11 - h01) - (h10 - h00), h10 - h00) * inv_cell;
+        const float dzdy = (b - a) * inv_cell;
+        const float inv_len = rsq(fmaf(dzdx, dzdx, fmaf(dzdy, dzdy, 1.f)));
+        z = inside ? zz : f.outside_z;
+        n = inside ? v3(-dzdx * inv_len, -dzdy * inv_len, inv_len) : v3(0.f, 0.f, 1.f);
+        return inside;
+    }
+    WL_DEV void sample(float x, float y, float& z, V3& n) const { (void)sample_full(x, y, z, n); }
+};
+
+// cos / sin of the yaw of IsaacLab's yaw_quat(q) without the atan2 round trip
+WL_DEV void yaw_cs(Quat q, float& c, float& s) {
+    const float a = 1.f - 2.f * (q.y * q.y + q.z * q.z), b = 2.f * (q.w * q.z + q.x * q.y);
+    const float inv = rsq(fmaf(a, a, b * b));
+    c = a * inv;
+    s = b * inv;
+}
+
+WL_DEV float sym(float u, float a) { return (2.f * u - 1.f) * a; }
+
+struct ElevTerms {
+    float t[WL_ER_NTERMS];
+    bool flag[WL_ET_NTERMS];
+};
+
+// elevation mdp terms (citations: mushr_elevation_env_cfg.py)
+WL_DEV ElevTerms elev_terms(const WlElevParams& p, V3 pos, float up_dot, V3 vb, V3 vw, float wheel_sum, float cbx, float cby,
+                            bool timed_out) {
+    ElevTerms r;
+    const float gx = cbx - pos.x, gy = cby - pos.y;   // goal vector: base-frame command minus world position (:50-55 quirk)
+    r.flag[WL_ET_BELOW_MIN_HEIGHT] = pos.z < p.min_height;                                            // :356-359
+    r.flag[WL_ET_STUCK] = fminf(vb.x, p.stuck_vel_cap) < p.stuck_min_vel && wheel_sum > p.stuck_wheel_spin;   // :342-347
+    r.flag[WL_ET_ROLLOVER] = up_dot < p.upright_cos;                                                  // :217-222, 339-340
+    r.flag[WL_ET_AT_GOAL] = sqrtf(fmaf(gx, gx, gy * gy)) < p.goal_dist;                               // :268-273
+    r.t[WL_ER_GOAL_PROGRESS] = p.progress_offset + fmaf(vw.x, gx, vw.y * gy) / sqrtf(fmaf(gx, gx, gy * gy));   // :239-249
+    const float z = pos.z - p.elev_z0;
+    r.t[WL_ER_HIGHER_ELEVATION] = clampf((z > p.elev_min && vb.x > p.elev_min_vel) ? z : 0.f, 0.f, 1.f);       // :166-173
+    r.t[WL_ER_FALLING] = vb.z > p.fall_vel ? 1.f : 0.f;                                               // :251-254
+    r.t[WL_ER_STUCK_PENALTY] = (r.flag[WL_ET_STUCK] && !timed_out) ? 1.f : 0.f;                       // :301-305
+    return r;
+}
+
+struct ElevReset {
+    V3 pos;
+    Quat q;
+    float vx, vy, tgt_x, tgt_y, tgt_h;
+};
+
+// isaaclab reset_root_state_uniform with the ranges of :409-419 + UniformPose2dCommand resample (:425-435)
+WL_DEV ElevReset draw_elev_reset(const WlElevParams& p, const HeightFieldGround& g, uint32_t gid, uint64_t step, uint64_t seed) {
+    const F4 u = philox_uniform4(gid, step, ES_RESET, seed);
+    const F4 c = philox_uniform4(gid, step, ES_CMD_RESET, seed);
+    ElevReset r;
+    const float x = sym(u.x, p.reset_xy), y = sym(u.y, p.reset_xy);
+    float zt;
+    V3 n;
+    g.sample(x, y, zt, n);
+    r.pos = v3(x, y, fmaxf(p.reset_z, zt + p.spawn_clearance));
+    float s, cc;
+    sincos_fast(0.5f * sym(u.z, p.reset_yaw), s, cc);
+    r.q = Quat{cc, 0.f, 0.f, s};
+    r.vx = fmaf(u.w, p.reset_vel[1] - p.reset_vel[0], p.reset_vel[0]);
+    r.vy = fmaf(c.w, p.reset_vel[1] - p.reset_vel[0], p.reset_vel[0]);
+    r.tgt_x = sym(c.x, p.cmd_xy);
+    r.tgt_y = sym(c.y, p.cmd_xy);
+    r.tgt_h = sym(c.z, p.cmd_heading);
+    return r;
+}
+
+__global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
+                                                           const float2* __restrict__ actions, const WlStepOut out,
+                                                           const uint64_t seed, const uint64_t step, const VehDerived vd) {
+    __shared__ float blk_metrics[WL_M_COUNT];
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
+    const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
+    if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
+        b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
+    __syncthreads();
+    const Rows S{b.state, b.stride};
+    const WlVehicleParams& vp = p.vehicle;
+    if (e < b.n_envs) {
+        const uint32_t gid = (uint32_t)(b.env_offset + e);
+        float2 a = actions[e];
+        float v_t, delta;
+        process_action(p.action, a.x, a.y, v_t, delta);
+        EnvConst ec;
+        joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
+        env_const_mass(ec, vp, vd, S(WL_S_MASS, e));
+        ec.mu_s = S(WL_S_MU_S, e) * vp.ground_mu_s;
+        ec.mu_d = fminf(S(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
+        ec.damp = S(WL_S_DAMP, e);
+        VehState s;
+        V3 pos = ld3(S, WL_S_PX, e);
+        s.q = Quat{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+        s.v = ld3(S, WL_S_VX, e);
+        V3 ww = ld3(S, WL_S_WX, e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
+        s.th = S(WL_S_STEER_POS, e);
+        s.om = S(WL_S_STEER_VEL, e);
+        {
+            const Mat3 R = mat_from_quat(s.q);
+            s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
+            s.wb = mul_t(R, ww);
+        }
+        for (int k = 0; k < vd.n_sub; ++k) vehicle_substep(vp, vd, ec, s, ground);
+        asm volatile("" ::: "memory");   // bookkeeping rows are fetched after the physics loop (register pressure)
+        const Mat3 R = mat_from_quat(s.q);
+        ww = mul(R, s.wb);
+        pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
+        int ep_len = b.episode_len[e] + 1;
+        const bool truncated = ep_len >= p.max_episode_length;
+        const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y +
+                          ww.z + s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3] + s.th + s.om;
+        const bool finite = __builtin_isfinite(chk);
+        const V3 vb = mul_t(R, s.v);
+        // terminations / rewards use the command as the PREVIOUS step's command update left it (IsaacLab step order)
+        float cbx = S(WL_S_CMD_BX, e), cby = S(WL_S_CMD_BY, e);
+        const float wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
+        const ElevTerms tm = elev_terms(p, pos, R.r2.z, vb, s.v, wheel_sum, cbx, cby, truncated);
+        const bool terminated = !finite || tm.flag[0] || tm.flag[1] || tm.flag[2] || tm.flag[3];
+        const float step_dt = p.sim_dt * (float)p.decimation;
+        float reward = 0.f;
+        float epsum[WL_ER_NTERMS];
+#pragma unroll
+        for (int i = 0; i < WL_ER_NTERMS; ++i) {
+            const float w = p.weight[i];
+            const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;
+            reward += c;
+            epsum[i] = p.log_episode_sums ? S(WL_S_EPSUM0 + i, e) + c : 0.f;
+        }
+        out.reward[e] = reward;
+        out.terminated[e] = terminated ? 1 : 0;
+        out.truncated[e] = truncated ? 1 : 0;
+        float a0 = a.x, a1 = a.y;
+        float tgt_x = S(WL_S_TGT_X, e), tgt_y = S(WL_S_TGT_Y, e), tgt_h = S(WL_S_TGT_H, e), cmd_timer = S(WL_S_CMD_TIMER, e);
+        if (terminated || truncated) {
+#pragma unroll
+            for (int i = 0; i < WL_ER_NTERMS; ++i) {
+                atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
+                epsum[i] = 0.f;
+            }
+            atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
+            if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
+#pragma unroll
+            for (int k = 0; k < WL_ET_NTERMS; ++k)
+                if (finite && tm.flag[k]) atomicAdd(&blk_metrics[WL_M_TERM0 + k], 1.f);
+            if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
+            atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
+            if (!finite) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
+                s.th = s.om = 0.f;
+            }
+            const ElevReset rd = draw_elev_reset(p, ground, gid, step, seed);
+            pos = rd.pos;
+            s.q = rd.q;
+            s.v = v3(rd.vx, rd.vy, 0.f);
+            ww = v3(0.f, 0.f, 0.f);
+            tgt_x = rd.tgt_x;
+            tgt_y = rd.tgt_y;
+            tgt_h = rd.tgt_h;
+            cmd_timer = p.cmd_resample_s;
+            ep_len = 0;
+            a0 = a1 = 0.f;
+        }
+        // command manager: count down, resample expired targets, re-express the target in the yaw-aligned base frame
+        cmd_timer -= step_dt;
+        if (cmd_timer <= 0.f) {
+            const F4 u = philox_uniform4(gid, step, ES_CMD_RESAMPLE, seed);
+            tgt_x = sym(u.x, p.cmd_xy);
+            tgt_y = sym(u.y, p.cmd_xy);
+            tgt_h = sym(u.z, p.cmd_heading);
+            cmd_timer = p.cmd_resample_s;
+        }
+        {
+            float c, sn;
+            yaw_cs(s.q, c, sn);
+            const float dx = tgt_x - pos.x, dy = tgt_y - pos.y;
+            cbx = fmaf(c, dx, sn * dy);
+            cby = fmaf(-sn, dx, c * dy);
+        }
+        st3(S, WL_S_PX, e, pos);
+        S(WL_S_QW, e) = s.q.w;
+        S(WL_S_QX, e) = s.q.x;
+        S(WL_S_QY, e) = s.q.y;
+        S(WL_S_QZ, e) = s.q.z;
+        st3(S, WL_S_VX, e, s.v);
+        st3(S, WL_S_WX, e, ww);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S(WL_S_WHEEL_BL + i, e) = s.wheel[i];
+        S(WL_S_STEER_POS, e) = s.th;
+        S(WL_S_STEER_VEL, e) = s.om;
+        S(WL_S_ACT0, e) = a0;
+        S(WL_S_ACT1, e) = a1;
+        if (p.log_episode_sums) {
+#pragma unroll
+            for (int i = 0; i < WL_ER_NTERMS; ++i) S(WL_S_EPSUM0 + i, e) = epsum[i];
+        }
+        S(WL_S_CMD_BX, e) = cbx;
+        S(WL_S_CMD_BY, e) = cby;
+        S(WL_S_TGT_X, e) = tgt_x;
+        S(WL_S_TGT_Y, e) = tgt_y;
+        S(WL_S_TGT_H, e) = tgt_h;
+        S(WL_S_CMD_TIMER, e) = cmd_timer;
+        b.episode_len[e] = ep_len;
+    }
+    __syncthreads();
+    if (threadIdx.x < WL_M_COUNT) {
+        const float m = blk_metrics[threadIdx.x];
+        if (m != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], m);
+    }
+}
+
+// ElevationObsCfg.ConcatObs (:61-86): goal_rel(2) | euler(3) | v_b clip +-10 (3) | w_b clip +-10 (3) | last action clip +-1
+// (2) | world_height_map 26 x 26 clip +-10 (:44-48).  One block per env.
+__global__ void __launch_bounds__(kBlock) elev_obs_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
+                                                          float* __restrict__ obs) {
+    __shared__ float prop[16];
+    const int e = blockIdx.x;
+    const Rows S{b.state, b.stride};
+    const float px = S(WL_S_PX, e), py = S(WL_S_PY, e), pz = S(WL_S_PZ, e);
+    const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+    if (threadIdx.x == 0) {
+        const Mat3 R = mat_from_quat(q);
+        const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
+        const V3 eu = euler_xyz_from_quat(q);
+        const float gx = S(WL_S_CMD_BX, e) - px, gy = S(WL_S_CMD_BY, e) - py;
+        prop[0] = gx != gx ? 0.f : gx;   // nan_to_num(nan=0) (:55); +-inf are left to the policy as in the reference
+        prop[1] = gy != gy ? 0.f : gy;
+        prop[2] = eu.x;
+        prop[3] = eu.y;
+        prop[4] = eu.z;
+        prop[5] = clampf(vb.x, -p.obs_clip, p.obs_clip);
+        prop[6] = clampf(vb.y, -p.obs_clip, p.obs_clip);
+        prop[7] = clampf(vb.z, -p.obs_clip, p.obs_clip);
+        prop[8] = clampf(wb.x, -p.obs_clip, p.obs_clip);
+        prop[9] = clampf(wb.y, -p.obs_clip, p.obs_clip);
+        prop[10] = clampf(wb.z, -p.obs_clip, p.obs_clip);
+        prop[11] = clampf(S(WL_S_ACT0, e), -1.f, 1.f);
+        prop[12] = clampf(S(WL_S_ACT1, e), -1.f, 1.f);
+    }
+    float c, s;
+    yaw_cs(q, c, s);
+    float* row = obs + (int64_t)e * WL_ELEV_OBS_DIM;
+    const float g0 = -0.5f * p.scan_size;
+    for (int k = threadIdx.x; k < WL_ELEV_SCAN_N * WL_ELEV_SCAN_N; k += kBlock) {
+        const int iy = k / WL_ELEV_SCAN_N, ix = k - iy * WL_ELEV_SCAN_N;   // meshgrid "xy": x fastest
+        const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
+        const float wx = px + (c * lx - s * ly), wy = py + (s * lx + c * ly);
+        float hz;
+        V3 n;
+        const bool hit = ground.sample_full(wx, wy, hz, n);
+        // world_height_map = -(sensor_z - hit_z - offset) + (root_z - plane_init_value); rays that miss return +inf
+        const float val = hit ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
+        row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
+    }
+    __syncthreads();
+    if (threadIdx.x < 13) row[threadIdx.x] = prop[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kBlock) elev_reset_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
+                                                            const uint8_t* __restrict__ mask, uint64_t seed, uint64_t step) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= b.n_envs) return;
+    if (mask && !mask[e]) return;
+    const Rows S{b.state, b.stride};
+    const ElevReset rd = draw_elev_reset(p, ground, (uint32_t)(b.env_offset + e), step, seed);
+    st3(S, WL_S_PX, e, rd.pos);
+    S(WL_S_QW, e) = rd.q.w;
+    S(WL_S_QX, e) = rd.q.x;
+    S(WL_S_QY, e) = rd.q.y;
+    S(WL_S_QZ, e) = rd.q.z;
+    st3(S, WL_S_VX, e, v3(rd.vx, rd.vy, 0.f));
+    st3(S, WL_S_WX, e, v3(0.f, 0.f, 0.f));
+    S(WL_S_ACT0, e) = 0.f;
+    S(WL_S_ACT1, e) = 0.f;
+#pragma unroll
+    for (int i = 0; i < WL_MAX_REW_TERMS; ++i) S(WL_S_EPSUM0 + i, e) = 0.f;
+    S(WL_S_TGT_X, e) = rd.tgt_x;
+    S(WL_S_TGT_Y, e) = rd.tgt_y;
+    S(WL_S_TGT_H, e) = rd.tgt_h;
+    S(WL_S_CMD_TIMER, e) = p.cmd_resample_s;
+    float c, sn;
+    yaw_cs(rd.q, c, sn);
+    const float dx = rd.tgt_x - rd.pos.x, dy = rd.tgt_y - rd.pos.y;
+    S(WL_S_CMD_BX, e) = fmaf(c, dx, sn * dy);
+    S(WL_S_CMD_BY, e) = fmaf(-sn, dx, c * dy);
+    b.episode_len[e] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock) elev_mdp_kernel(const WlElevParams p, int n, int64_t stride, const float* __restrict__ pos,
+                                                          const float* __restrict__ quat, const float* __restrict__ vb_,
+                                                          const float* __restrict__ vw_, const float* __restrict__ wheel,
+                                                          const float* __restrict__ cmd, const uint8_t* __restrict__ timed_out,
+                                                          int n_rays, const float* __restrict__ sensor_z,
+                                                          const float* __restrict__ hit_z, float* __restrict__ terms,
+                                                          uint8_t* __restrict__ flags, float* __restrict__ goal_rel,
+                                                          float* __restrict__ hmap) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n) return;
+    const V3 P = v3(pos[e], pos[stride + e], pos[2 * stride + e]);
+    const Quat q{quat[e], quat[stride + e], quat[2 * stride + e], quat[3 * stride + e]};
+    const V3 vb = v3(vb_[e], vb_[stride + e], vb_[2 * stride + e]);
+    const V3 vw = v3(vw_[e], vw_[stride + e], vw_[2 * stride + e]);
+    const float ws = wheel[e] + wheel[stride + e] + wheel[2 * stride + e] + wheel[3 * stride + e];
+    const float cbx = cmd[e], cby = cmd[stride + e];
+    const Mat3 R = mat_from_quat(q);
+    const ElevTerms tm = elev_terms(p, P, R.r2.z, vb, vw, ws, cbx, cby, timed_out ? timed_out[e] != 0 : false);
+#pragma unroll
+    for (int i = 0; i < WL_ER_NTERMS; ++i) terms[i * stride + e] = tm.t[i];
+#pragma unroll
+    for (int i = 0; i < WL_ET_NTERMS; ++i) flags[i * stride + e] = tm.flag[i] ? 1 : 0;
+    const float gx = cbx - P.x, gy = cby - P.y;
+    goal_rel[e] = gx != gx ? 0.f : gx;
+    goal_rel[stride + e] = gy != gy ? 0.f : gy;
+    if (hit_z) {
+        const float sz = sensor_z[e];
+        for (int k = 0; k < n_rays; ++k) hmap[k * stride + e] = -(sz - hit_z[k * stride + e] - p.scan_offset) + (P.z - p.elev_z0);
+    }
+}
+
+int check_elev(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf) {
+    if (!p || !b || !hf || !b->state || !b->episode_len || !b->metrics || !hf->height) return WL_EINVAL;
+    if (b->n_envs <= 0 || b->stride < b->n_envs || b->metrics_slots < 1) return WL_EINVAL;
+    if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
+    if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f)) return WL_EINVAL;
+    if (hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f)) return WL_EINVAL;
+    return WL_OK;
+}
+
+HeightFieldGround make_ground(const WlHeightField* hf) { return HeightFieldGround{*hf, 1.f / hf->cell}; }
+
+}  // namespace
+
+extern "C" {
+
+int wl_elev_step(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* actions,
+                 const WlStepOut* out, uint64_t seed, uint64_t step, void* stream) {
+    return wl_elev_rollout(p, b, hf, actions, out, 0, 0, 1, seed, step, stream);
+}
+
+int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* actions,
+                    const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps, uint64_t seed,
+                    uint64_t step0, void* stream) {
+    int rc = check_elev(p, b, hf);
+    if (rc != WL_OK) return rc;
+    if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
+    const HeightFieldGround g = make_ground(hf);
+    const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
+    clear_error();
+    for (int k = 0; k < n_steps; ++k) {
+        WlStepOut o = *out;
+        o.obs += k * obs_step_stride;
+        o.reward += k * vec_step_stride;
+        o.terminated += k * vec_step_stride;
+        o.truncated += k * vec_step_stride;
+        elev_step_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
+            *p, *b, g, (const float2*)(actions + (int64_t)k * b->n_envs * 2), o, seed, step0 + (uint64_t)k, vd);
+        elev_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
+    }
+    return launch_status();
+}
+
+int wl_elev_reset(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const uint8_t* mask, uint64_t seed,
+                  uint64_t step, void* stream) {
+    int rc = check_elev(p, b, hf);
+    if (rc != WL_OK) return rc;
+    clear_error();
+    elev_reset_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), mask, seed, step);
+    return launch_status();
+}
+
+int wl_elev_observe(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, float* obs, void* stream) {
+    int rc = check_elev(p, b, hf);
+    if (rc != WL_OK) return rc;
+    if (!obs) return WL_EINVAL;
+    clear_error();
+    elev_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), obs);
+    return launch_status();
+}
+
+int wl_elev_mdp(const WlElevParams* p, int32_t n, int64_t stride, const float* pos, const float* quat, const float* lin_vel_b,
+                const float* lin_vel_w, const float* wheel_vel, const float* command, const uint8_t* timed_out, int32_t n_rays,
+                const float* sensor_z, const float* hit_z, float* terms, uint8_t* flags, float* goal_rel, float* height_map,
+                void* stream) {
+    if (!p || n <= 0 || stride < n || !pos || !quat || !lin_vel_b || !lin_vel_w || !wheel_vel || !command || !terms || !flags ||
+        !goal_rel)
+        return WL_EINVAL;
+    if (hit_z && (!sensor_z || !height_map || n_rays <= 0)) return WL_EINVAL;
+    clear_error();
+    elev_mdp_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(*p, n, stride, pos, quat, lin_vel_b, lin_vel_w, wheel_vel,
+                                                                      command, timed_out, n_rays, sensor_z, hit_z, terms, flags,
+                                                                      goal_rel, height_map);
+    return launch_status();
+}
+
+}  // extern "C"

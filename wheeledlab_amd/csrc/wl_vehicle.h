@@ -16,6 +16,7 @@ struct VehState {
 
 struct EnvConst {   // per-env constants hoisted out of the sub-step loop
     float weight, h_inv_mass;  // m g ; h / m
+    float K_cap;               // 0.125 m / h
     float mu_s, mu_d;          // combined (wheel x ground) friction
     float damp;                // throttle damping of driven wheels
     V3 Ib, h_inv_Ib;           // body inertia diag ; h / I
@@ -60,6 +61,7 @@ inline VehDerived derive_vehicle(const WlVehicleParams& vp, float sim_dt, int de
 WL_DEV void env_const_mass(EnvConst& ec, const WlVehicleParams& vp, const VehDerived& vd, float mass) {
     ec.weight = mass * vp.gravity;
     ec.h_inv_mass = vd.h * rcp(mass);
+    ec.K_cap = 0.125f * mass * vd.inv_h;
     ec.Ib = v3(mass * (vp.gyr_x * vp.gyr_x), mass * (vp.gyr_y * vp.gyr_y), mass * (vp.gyr_z * vp.gyr_z));
     ec.h_inv_Ib = v3(vd.h * rcp(ec.Ib.x), vd.h * rcp(ec.Ib.y), vd.h * rcp(ec.Ib.z));
 }
@@ -100,7 +102,8 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const E
     const float sig = fsqrt(fmaf(sx, sx, sy * sy));
     const float inv_sig = rcp(fmaxf(sig, 1.f));
     const float gq = sig <= 1.f ? ec.mu_s * (2.f - sig) : fmaf(ec.mu_s - ec.mu_d, inv_sig, ec.mu_d) * inv_sig;
-    const float K = Fz * gq * inv_vden;
+    // explicit-stepping stability cap: at most half of this wheel's share of the body momentum per sub-step
+    const float K = fminf(Fz * gq * inv_vden, ec.K_cap);
     const bool driven = (vp.drive == 1) || !front;
     const float d = driven ? ec.damp : 0.f;
     const float wt = ec.wheel_target[WHEEL];

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import math
 
-from ._abi import WlActionParams, WlDriftParams, WlVehicleParams
+from ._abi import WlActionParams, WlDriftParams, WlElevParams, WlVehicleParams
 
 MUSHR_NOMINAL_MASS = 3.4  # 3.0 kg chassis + mean U(0.3, 0.5) added base mass (mushr_drift_env_cfg.py:145-154)
 MUSHR_CHASSIS_MASS = 3.0
@@ -68,6 +68,29 @@ def drift_params() -> WlDriftParams:
     p.hf_vel_x, p.hf_vel_y, p.hf_vel_yaw = 0.1, 0.03, 0.3
     p.lf_interval[0], p.lf_interval[1] = 0.8, 1.2
     p.lf_vel_yaw = 0.6
+    p.log_episode_sums = 1
+    return p
+
+
+def elev_params() -> WlElevParams:
+    """MushrElevationRLEnvCfg (wheeledlab_tasks/elevation/mushr_elevation_env_cfg.py:438-469) flattened"""
+    p = WlElevParams()
+    p.sim_dt, p.decimation = 0.01, 10                                   # :461-462
+    p.max_episode_length = math.ceil(20.0 / (0.01 * 10))                # :465
+    p.action = mushr_action(1)                                          # :446 Mushr4WDActionCfg
+    p.vehicle = mushr_vehicle(drive=1, motor_limit=0.25, substeps=2, ground_mu=(1.0, 1.0))   # :130, :102-107
+    for i, w in enumerate((200.0, 5000.0, 0.0, -200.0, 0.0, 0.0, 0.0, 0.0)):                  # :286-305
+        p.weight[i] = w
+    p.min_height = 0.15                                                 # :356-359
+    p.stuck_min_vel, p.stuck_wheel_spin, p.stuck_vel_cap = 0.02, 5.0, 1.2     # :360-366, :157
+    p.upright_cos, p.goal_dist = math.cos(math.radians(60.0)), 0.5     # :368-376
+    p.fall_vel = 0.10                                                   # :251-254
+    p.elev_z0, p.elev_min, p.elev_min_vel, p.progress_offset = 0.19, 0.1, 0.1, 5.0   # :166-173, :249
+    p.reset_xy, p.reset_yaw = 19.0, 3.14                                # :409-419
+    p.reset_vel[0], p.reset_vel[1] = 0.1, 0.2
+    p.reset_z, p.spawn_clearance = 0.25, 0.06                           # :147-149 (terrain.height); clearance: designed
+    p.cmd_xy, p.cmd_heading, p.cmd_resample_s = 19.0, 3.14, 10.0        # :425-435
+    p.scan_size, p.scan_res, p.scan_offset, p.obs_clip = 2.5, 0.1, 0.084, 10.0   # :139, :74-82
     p.log_episode_sums = 1
     return p
 
