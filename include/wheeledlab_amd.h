@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 5
+#define WL_ABI_VERSION 6
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -287,6 +287,76 @@ int wl_elev_mdp(const WlElevParams* p, int32_t n, int64_t stride, const float* p
                 const float* lin_vel_b, const float* lin_vel_w, const float* wheel_vel, const float* command,
                 const uint8_t* timed_out, int32_t n_rays, const float* sensor_z, const float* hit_z, float* terms,
                 uint8_t* flags, float* goal_rel, float* height_map, void* stream);
+
+/* ======================================================================================================== */
+/* Visual task (wheeledlab_tasks/visual/mushr_visual_env_cfg.py)                                            */
+/* ======================================================================================================== */
+
+#define WL_VIS_IMG_H 60
+#define WL_VIS_IMG_W 80
+#define WL_VIS_CROP 20                          /* rows dropped from the top: H // 3 (mdp_sensors/observations.py:79) */
+#define WL_VIS_NPIX ((WL_VIS_IMG_H - WL_VIS_CROP) * WL_VIS_IMG_W)   /* 3200                                        */
+#define WL_VIS_OBS_DIM (WL_VIS_NPIX + 8)        /* 3208 (mushr_visual_env_cfg.py:38-58)                               */
+
+enum WlVisualRewTerm { WL_VR_TRAVERSABLE = 0, WL_VR_FORWARD_VEL, WL_VR_NTERMS };
+
+/* traversability map (visual/utils/__init__.py:60-86): map[iy][ix] bytes, 1 = traversable, plus the list of
+ * traversable cells (iy, ix) in nonzero order used for spawning (utils/__init__.py:188-202). */
+typedef struct WlTravMap {
+    const uint8_t* map;        /* [rows][cols] */
+    const int32_t* cells;      /* [n_cells][2] = (iy, ix) */
+    int32_t rows, cols, n_cells;
+    float row_spacing, col_spacing;
+} WlTravMap;
+
+typedef struct WlVisualParams {
+    float sim_dt;              /* 0.02 (:435)                                                                */
+    int32_t decimation;        /* 10   (:436)                                                                */
+    int32_t max_episode_length;/* ceil(10 s / 0.2 s) = 50 (:439)                                             */
+    WlActionParams action;     /* Mushr4WDActionCfg                                                          */
+    WlVehicleParams vehicle;   /* 4WD, ground friction 2.0 / 2.0 (:130-135)                                  */
+    float weight[WL_MAX_REW_TERMS];   /* traversable_reward 5, forward_vel 7 (:375-385)                      */
+    float reset_z;             /* 0.1 (:203)                                                                 */
+    /* pinhole camera (:230-246): intrinsics from focal length / apertures; pose in the body frame is designed     */
+    float cam_pos[3];
+    float fx, fy, cx, cy;
+    float sky;                 /* grey level of rays that miss the plane                                     */
+    /* augmentation of this call (torchvision ColorJitter brightness / contrast + GaussianBlur(5) sigma,
+       mdp_sensors/observations.py:21-23,82-84); 1, 1, 0 = none                                              */
+    float brightness, contrast, blur_sigma;
+    int32_t log_episode_sums;
+} WlVisualParams;
+
+/*
+ * Fused visual env.step(): 4WD action term -> decimation x substeps on the flat plane -> time_out + out_of_map
+ * (:390-398) -> traversable_reward (:309-312, lookup traversability_utils.py:68-88) + forward_vel (:370-371) -> reset
+ * onto a random traversable cell (visual/mdp/events.py:11-42) in one launch (lane = env); then the observation launch
+ * (block = env): 40 x 80 ray-cast grey image of the traversability plane staged in LDS, brightness / contrast / 5x5
+ * Gaussian blur / grayscale / normalise (mdp_sensors/observations.py:75-87), + base_lin_vel, base_ang_vel,
+ * last_action.  obs is [n][WL_VIS_OBS_DIM].
+ */
+int wl_visual_step(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const float* actions,
+                   const WlStepOut* out, uint64_t seed, uint64_t step, void* stream);
+int wl_visual_rollout(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const float* actions,
+                      const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps,
+                      uint64_t seed, uint64_t step0, void* stream);
+int wl_visual_reset(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const uint8_t* mask,
+                    uint64_t seed, uint64_t step, void* stream);
+int wl_visual_observe(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, float* obs, void* stream);
+/*
+ * Visual mdp terms on caller-supplied tensors (parity entry point): pos[3][stride], lin_vel_b[3][stride] ->
+ * terms[2][stride] (traversable_reward, forward_vel), out_of_map[n] bytes, map indices x_idx[n], y_idx[n] (int32).
+ * Replaces mushr_visual_env_cfg.py:309-312,370-371,390-398 and traversability_utils.py:68-88.
+ */
+int wl_visual_mdp(const WlVisualParams* p, const WlTravMap* m, int32_t n, int64_t stride, const float* pos,
+                  const float* lin_vel_b, float* terms, uint8_t* out_of_map, int32_t* x_idx, int32_t* y_idx,
+                  void* stream);
+/*
+ * Extension (BASELINE.json config 5; unused in the reference, mdp_sensors/observations.py:89-95): per-pixel
+ * distance_to_image_plane of the same camera against a heightfield (ray march + bisection), depth [n][60][80].
+ */
+int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, float max_depth,
+                    float* depth, void* stream);
 
 /* Raw Philox4x32-10 uniforms as used in-kernel: out[4][n] for counter (env, step, stream_id). Test hook. */
 int wl_philox_uniform(int32_t n, uint64_t seed, uint64_t step, uint32_t stream_id, float* out, void* stream);

@@ -1,0 +1,161 @@
+"""Visual task on the GPU: traversability lookup / rewards / termination vs the reference's golden outputs, fused step
++ ray-cast camera observation vs the oracle, augmentation chain, depth extension.  Everything through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import visual_mdp as VM
+from oracle import visual_step as OS
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def trav(golden):
+    g = golden("visual_trav")
+    return np.unpackbits(g["full_map_packed"])[: 500 * 500].reshape(500, 500).astype(bool)
+
+
+def _batch(n, trav, seed=3):
+    from wheeledlab_amd.core import VisualBatch
+    env = VisualBatch(n, device=DEV, seed=seed, trav_map=trav)
+    env.reset()
+    torch.cuda.synchronize()
+    return env
+
+
+def test_visual_mdp_kernel_matches_reference_golden(golden, trav):
+    from wheeledlab_amd import _abi as A
+    env = _batch(64, trav)
+    for name, key_pos in (("visual_mdp", "pos"), ("visual_trav", "xy")):
+        g = golden(name)
+        pos = g[key_pos]
+        n = pos.shape[0]
+        stride = ((n + 63) // 64) * 64
+        P = torch.zeros(3, stride)
+        P[: pos.shape[1], :n] = torch.from_numpy(np.ascontiguousarray(pos.T))
+        vb = torch.zeros(3, stride)
+        if "lin_vel_b" in g:
+            vb[:, :n] = torch.from_numpy(np.ascontiguousarray(g["lin_vel_b"].T))
+        P, vb = P.to(DEV), vb.to(DEV)
+        terms = torch.zeros(2, stride, device=DEV)
+        oom = torch.zeros(n, dtype=torch.uint8, device=DEV)
+        xi = torch.zeros(n, dtype=torch.int32, device=DEV)
+        yi = torch.zeros(n, dtype=torch.int32, device=DEV)
+        rc = env.lib.wl_visual_mdp(C.byref(env.p), C.byref(env._map), n, stride, P.data_ptr(), vb.data_ptr(), terms.data_ptr(),
+                                   oom.data_ptr(), xi.data_ptr(), yi.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        if name == "visual_mdp":                       # outputs of the reference's reward / termination functions
+            np.testing.assert_array_equal(terms[0, :n].cpu().numpy(), g["traversable_reward"])
+            np.testing.assert_array_equal(terms[1, :n].cpu().numpy(), g["forward_vel"])
+            np.testing.assert_array_equal(oom.cpu().numpy().astype(bool), g["out_of_map"])
+        else:                                          # outputs of TraversabilityHashmapUtil.get_map_id / get_traversability
+            np.testing.assert_array_equal(xi.cpu().numpy(), g["x_idx"])   # bit-exact incl. cell-boundary cases
+            np.testing.assert_array_equal(yi.cpu().numpy(), g["y_idx"])
+            np.testing.assert_array_equal(terms[0, :n].cpu().numpy() > 0, g["trav"])
+
+
+def test_visual_reset_and_camera_match_oracle(trav):
+    env = _batch(128, trav, seed=11)
+    st = env.state.cpu().numpy()
+    p = OS.visual_params()
+    o = np.zeros_like(st)
+    o[3] = 1
+    o[23:27] = st[23:27]
+    ep = np.ones(st.shape[1], np.int32)
+    cells = OS.spawn_cells(trav)
+    OS.reset_envs(p, o, ep, cells, np.arange(128), 11, 0)
+    np.testing.assert_allclose(st[:, :128], o[:, :128], rtol=1e-6, atol=2e-6)
+    assert trav[VM.get_map_id(st[0, :128], st[1, :128])[1], VM.get_map_id(st[0, :128], st[1, :128])[0]].all()   # spawned on the path
+    for aug in ((1.0, 1.0, 0.0), (1.4, 0.85, 1.7), (0.5, 1.15, 0.4)):
+        env.p.brightness, env.p.contrast, env.p.blur_sigma = aug
+        p.brightness, p.contrast, p.blur_sigma = aug
+        obs = env.observe().cpu().numpy()
+        want = OS.observe(p, st[:, :128].copy(), trav)
+        assert obs.shape == (128, 3208)
+        d = np.abs(obs - want)
+        # pixel rays that graze a cell boundary may resolve to the neighbouring cell (fp32 ray maths): count them
+        bad = (d[:, :3200] > 2e-3).mean()
+        assert bad < 2e-3, (aug, bad)
+        assert d[:, 3200:].max() < 1e-5
+        assert np.median(d[:, :3200]) < 1e-5
+    # the image shows something: both colours and the sky band are present
+    env.p.brightness, env.p.contrast, env.p.blur_sigma = 1.0, 1.0, 0.0
+    img = env.observe()[:, :3200]
+    assert (img > 0.9).any() and (img < -0.9).any() and ((img.abs() < 0.05).float().mean() > 0.1)
+
+
+def test_visual_fused_step_matches_oracle_single_steps(trav):
+    n = 256
+    env = _batch(n, trav, seed=5)
+    p = OS.visual_params()
+    cells = OS.spawn_cells(trav)
+    rng = np.random.RandomState(0)
+    for k in range(12):
+        st = env.state.cpu().numpy().copy()
+        ep = env.episode_len.cpu().numpy().copy()
+        if k == 6:
+            ep[: n // 4] = 49
+            st[0, n // 4: n // 2] = 124.9                      # about to leave the map -> out_of_map termination
+            st[7, n // 4: n // 2] = 3.0
+            env.episode_len.copy_(torch.from_numpy(ep))
+            env.state.copy_(torch.from_numpy(st))
+        a = rng.uniform(-1.2, 1.2, (n, 2)).astype(np.float32)
+        met0 = env.metrics.cpu().numpy().astype(np.float64)
+        obs, rew, term, trunc = env.step(torch.from_numpy(a).to(DEV))
+        torch.cuda.synchronize()
+        met = np.zeros(16)
+        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, trav, cells, a, 5, k, met)
+        got = env.state.cpu().numpy()
+        np.testing.assert_array_equal(trunc.cpu().numpy(), o_trunc)
+        bad = term.cpu().numpy() != o_term
+        assert bad.sum() <= 1
+        ok = ~bad
+        err = np.abs(got[:21, :n] - st[:21, :n]) / (5e-4 + 5e-4 * np.abs(st[:21, :n]))
+        touchy = (err.max(0) > 1.0) & ok                       # wheel touch-down within the step (10 cm spawn drop)
+        assert touchy.sum() <= max(2, n // 50), (k, int(touchy.sum()))
+        ok &= ~touchy
+        np.testing.assert_allclose(got[:21, :n][:, ok], st[:21, :n][:, ok], rtol=5e-4, atol=5e-4, err_msg=f"step {k}")
+        cell_flip = np.abs(rew.cpu().numpy() - o_rew) > 0.5    # +-1 traversability flips exactly on a cell edge
+        assert (cell_flip & ok).sum() <= 1
+        sel = ok & ~cell_flip
+        np.testing.assert_allclose(rew.cpu().numpy()[sel], o_rew[sel], rtol=2e-3, atol=2e-3)
+        d = np.abs(obs.cpu().numpy() - o_obs)[sel]
+        assert d[:, 3200:].max() < 3e-3 and (d[:, :3200] > 2e-3).mean() < 5e-3
+        if not bad.any():
+            dm = env.metrics.cpu().numpy().astype(np.float64) - met0
+            np.testing.assert_allclose(dm[8:16], met[8:16], atol=1e-3)
+    assert env.metrics[10] > 0 and env.metrics[9] > 0          # both out_of_map and time_out were exercised
+
+
+def test_visual_full_size_properties_and_depth(trav):
+    n = 4096
+    env = _batch(n, trav, seed=1)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    resets = 0
+    for k in range(60):
+        env.sample_augmentation()
+        obs, rew, term, trunc = env.step(torch.rand(n, 2, device=DEV, generator=g) * 2 - 1)
+        resets += int((term | trunc).sum())
+    torch.cuda.synchronize()
+    assert torch.isfinite(env.state[:, :n]).all() and torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert (obs[:, :3200].abs() <= 1.0 + 1e-6).all() and (obs[:, 3206:].abs() <= 1).all()
+    assert (env.episode_len[:n] < 50).all() and env.metrics[8] == resets and env.metrics[14] == 0
+    # depth extension on a flat heightfield == analytic ray/plane distance
+    flat = (np.zeros((64, 64), np.float32), -200.0, -200.0, 400.0 / 63)
+    dep = env.depth(flat, max_depth=30.0)
+    assert dep.shape == (n, 60, 80) and torch.isfinite(dep).all()
+    st = env.state[:, :n].cpu().numpy()
+    e = int(np.argmax((np.abs(st[0]) < 100) & (np.abs(st[1]) < 100)))
+    from oracle.mathlib import matrix_from_quat
+    R = matrix_from_quat(st[3:7, e][None])[0]
+    o = st[0:3, e] + R @ np.array(list(env.p.cam_pos), np.float32)
+    row, col = 50, 40
+    d_b = np.array([1.0, -((col + 0.5 - env.p.cx) / env.p.fx), -((row + 0.5 - env.p.cy) / env.p.fy)], np.float32)
+    d_w = R @ d_b
+    assert d_w[2] < 0
+    assert abs(float(dep[e, row, col]) - (-o[2] / d_w[2])) < 0.03

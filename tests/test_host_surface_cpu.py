@@ -128,3 +128,16 @@ def test_curriculum_matches_reference_golden(golden):
             mdp.increase_reward_weight_over_time(env, None, **term.params)
         got.append([env.reward_manager.c[k].weight for k in ("side_slip", "tlgr", "term_pens")])
     np.testing.assert_array_equal(np.array(got), g["weights"])
+
+
+def test_product_map_generator_reproduces_the_reference_map(golden):
+    """same numpy seed, same draw order => the reference's 500 x 500 traversability map bit for bit"""
+    from wheeledlab_amd.travmap import generate_traversability_map, spawn_cells
+    g = golden("visual_trav")
+    want = np.unpackbits(g["full_map_packed"])[: 500 * 500].reshape(500, 500).astype(bool)
+    np.random.seed(0)
+    got = generate_traversability_map()
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(generate_traversability_map((20, 20), (20, 20), (10, 10), 1, np.random.RandomState(0)).shape, (20, 20))
+    cells = spawn_cells(want)
+    assert cells.shape[1] == 2 and want[cells[:, 0], cells[:, 1]].all() and len(cells) == want.sum()

@@ -23,3 +23,32 @@ def test_elevation_terms_match_reference(golden):
     np.testing.assert_array_equal(E.close_to_goal(g["pos"], g["command"]), g["close_to_goal"])
     np.testing.assert_array_equal(g["weights"], np.array([200.0, 5000.0, 0.0, -200.0], np.float32))
     assert g["close_to_goal"].sum() >= 4 and g["stuck"].sum() >= 1 and g["upright_bool"].sum() >= 10   # branches are exercised
+
+
+def test_visual_map_generation_and_lookup_match_reference(golden):
+    from oracle import visual_mdp as V
+    g = golden("visual_trav")
+    np.random.seed(0)
+    np.testing.assert_array_equal(V.generate_env_map((20, 20), (10, 10), 1), g["env_map_20"])
+    np.random.seed(0)
+    full = V.generate_map()
+    want = np.unpackbits(g["full_map_packed"])[: 500 * 500].reshape(500, 500).astype(bool)
+    np.testing.assert_array_equal(full, want)                      # same numpy seed -> same 500 x 500 map, bit for bit
+    np.random.seed(1)
+    poses = np.array(V.generate_random_poses(64, 0.5, 0.5, full))
+    np.testing.assert_allclose(poses, g["poses"], rtol=0, atol=1e-12)
+    xi, yi = V.get_map_id(g["xy"][:, 0], g["xy"][:, 1])
+    np.testing.assert_array_equal(xi, g["x_idx"])
+    np.testing.assert_array_equal(yi, g["y_idx"])
+    np.testing.assert_array_equal(V.get_traversability(full, g["xy"]), g["trav"])
+    assert want[yi[:64], xi[:64]].all()                             # spawn poses sit on traversable cells
+
+
+def test_visual_terms_match_reference(golden):
+    from oracle import visual_mdp as V
+    g = golden("visual_mdp")
+    full = np.unpackbits(golden("visual_trav")["full_map_packed"])[: 500 * 500].reshape(500, 500).astype(bool)
+    np.testing.assert_array_equal(V.traversable_reward(full, g["pos"]), g["traversable_reward"])
+    np.testing.assert_array_equal(V.forward_vel(g["lin_vel_b"]), g["forward_vel"])
+    np.testing.assert_array_equal(V.out_of_map(g["pos"]), g["out_of_map"])
+    np.testing.assert_array_equal(g["weights"], np.array([5.0, 7.0], np.float32))

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 5
+WL_ABI_VERSION = 6
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -90,6 +90,25 @@ class WlElevParams(C.Structure):
     ]
 
 
+class WlTravMap(C.Structure):
+    _fields_ = [("map", C.c_void_p), ("cells", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("n_cells", C.c_int32), ("row_spacing", C.c_float), ("col_spacing", C.c_float)]
+
+
+class WlVisualParams(C.Structure):
+    _fields_ = [
+        ("sim_dt", C.c_float), ("decimation", C.c_int32), ("max_episode_length", C.c_int32),
+        ("action", WlActionParams), ("vehicle", WlVehicleParams), ("weight", C.c_float * WL_MAX_REW_TERMS),
+        ("reset_z", C.c_float), ("cam_pos", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+        ("cy", C.c_float), ("sky", C.c_float), ("brightness", C.c_float), ("contrast", C.c_float),
+        ("blur_sigma", C.c_float), ("log_episode_sums", C.c_int32),
+    ]
+
+
+VIS_NPIX = 40 * 80
+VIS_OBS_DIM = VIS_NPIX + 8
+
+
 class WlEnvBuffers(C.Structure):
     _fields_ = [("state", C.c_void_p), ("episode_len", C.c_void_p), ("ref_poses", C.c_void_p),
                 ("metrics", C.c_void_p), ("stride", C.c_int64), ("n_envs", C.c_int32), ("env_offset", C.c_int32),
@@ -122,6 +141,13 @@ SIGNATURES = {
     "wl_elev_reset": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _u64, _u64, _vp]),
     "wl_elev_observe": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _vp]),
     "wl_elev_mdp": (C.c_int, [_P(WlElevParams), _i32, _i64] + [_vp] * 7 + [_i32] + [_vp] * 7),
+    "wl_visual_step": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _P(WlStepOut), _u64, _u64, _vp]),
+    "wl_visual_rollout": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _P(WlStepOut), _i64, _i64,
+                                    _i32, _u64, _u64, _vp]),
+    "wl_visual_reset": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _u64, _u64, _vp]),
+    "wl_visual_observe": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _vp]),
+    "wl_visual_mdp": (C.c_int, [_P(WlVisualParams), _P(WlTravMap), _i32, _i64] + [_vp] * 7),
+    "wl_visual_depth": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlHeightField), C.c_float, _vp, _vp]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwheeledlab_amd.so")

@@ -220,3 +220,103 @@ class ElevBatch:
                                          C.byref(out), os_, vs_, K, self.seed, self.step_count, self._stream()),
                 "wl_elev_rollout")
         self.step_count += K
+
+
+class VisualBatch:
+    """n visual-task envs on one GPU: flat black/white traversability plane + ray-cast grey camera."""
+
+    OBS_DIM = A.VIS_OBS_DIM
+
+    def __init__(self, n_envs: int, device="cuda:0", params=None, seed: int = 42, env_offset: int = 0, trav_map=None,
+                 spacing=(0.5, 0.5), metrics_slots: int = 1, wheel_mu=(0.5, 0.5), damping: float = 1000.0,
+                 mass: float = MUSHR_CHASSIS_MASS):
+        import numpy as np
+
+        from .params import visual_params
+        from .travmap import generate_traversability_map, spawn_cells
+        self.lib = A.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise A.HipExtensionMissing("VisualBatch needs a HIP device; there is no CPU path")
+        self.n, self.stride = int(n_envs), ((int(n_envs) + 63) // 64) * 64
+        self.p = params if params is not None else visual_params()
+        self.seed, self.env_offset, self.step_count = int(seed), int(env_offset), 0
+        dev = self.device
+        self.state = torch.zeros(A.S_COUNT, self.stride, dtype=torch.float32, device=dev)
+        self.episode_len = torch.zeros(self.stride, dtype=torch.int32, device=dev)
+        self.metrics_slots = int(metrics_slots)
+        self.metrics = torch.zeros(self.metrics_slots, A.M_COUNT, dtype=torch.float32, device=dev)
+        if self.metrics_slots == 1:
+            self.metrics = self.metrics[0]
+        self.obs = torch.zeros(self.n, self.OBS_DIM, dtype=torch.float32, device=dev)
+        self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.terminated = torch.zeros(self.n, dtype=torch.bool, device=dev)
+        self.truncated = torch.zeros(self.n, dtype=torch.bool, device=dev)
+        if trav_map is None:  # generated at construction from a seeded RNG (the reference uses the global numpy RNG)
+            trav_map = generate_traversability_map(rng=np.random.RandomState(self.seed))
+        trav_map = np.ascontiguousarray(np.asarray(trav_map, dtype=bool))
+        self.trav_map = torch.from_numpy(trav_map.astype(np.uint8)).to(dev)
+        self.cells = torch.from_numpy(spawn_cells(trav_map)).contiguous().to(dev)
+        self._map = A.WlTravMap(self.trav_map.data_ptr(), self.cells.data_ptr(), trav_map.shape[0], trav_map.shape[1],
+                                self.cells.shape[0], float(spacing[0]), float(spacing[1]))
+        s = self.state
+        s[A.S_QW] = 1.0
+        s[A.S_MU_S], s[A.S_MU_D], s[A.S_DAMP], s[A.S_MASS] = wheel_mu[0], wheel_mu[1], damping, mass
+        self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics.data_ptr(),
+                                    self.stride, self.n, self.env_offset, self.metrics_slots)
+        self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
+                                self.truncated.data_ptr())
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def sample_augmentation(self, generator: torch.Generator | None = None):
+        """one (brightness, contrast, blur sigma) per call, like torchvision's ColorJitter(brightness=.8, contrast=.2)
+        and GaussianBlur(5, sigma=(0.1, 5)) on a batched tensor (mdp_sensors/observations.py:21-23)"""
+        u = torch.rand(3, generator=generator)
+        self.p.brightness = float(0.2 + 1.6 * u[0])
+        self.p.contrast = float(0.8 + 0.4 * u[1])
+        self.p.blur_sigma = float(0.1 + 4.9 * u[2])
+
+    def reset(self, mask: torch.Tensor | None = None):
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        A.check(self.lib.wl_visual_reset(C.byref(self.p), C.byref(self._bufs), C.byref(self._map),
+                                         None if m is None else m.data_ptr(), self.seed, self.step_count, self._stream()),
+                "wl_visual_reset")
+
+    def observe(self) -> torch.Tensor:
+        A.check(self.lib.wl_visual_observe(C.byref(self.p), C.byref(self._bufs), C.byref(self._map), self.obs.data_ptr(),
+                                           self._stream()), "wl_visual_observe")
+        return self.obs
+
+    def step(self, actions: torch.Tensor):
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.shape != (self.n, 2):
+            actions = actions.to(torch.float32).reshape(self.n, 2).contiguous()
+        A.check(self.lib.wl_visual_step(C.byref(self.p), C.byref(self._bufs), C.byref(self._map), actions.data_ptr(),
+                                        C.byref(self._out), self.seed, self.step_count, self._stream()), "wl_visual_step")
+        self.step_count += 1
+        return self.obs, self.reward, self.terminated, self.truncated
+
+    def rollout(self, actions: torch.Tensor, obs_out=None, rew_out=None, term_out=None, trunc_out=None):
+        K = actions.shape[0]
+        assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
+        if obs_out is not None:
+            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr())
+            os_, vs_ = self.n * self.OBS_DIM, self.n
+        else:
+            out, os_, vs_ = self._out, 0, 0
+        A.check(self.lib.wl_visual_rollout(C.byref(self.p), C.byref(self._bufs), C.byref(self._map), actions.data_ptr(),
+                                           C.byref(out), os_, vs_, K, self.seed, self.step_count, self._stream()),
+                "wl_visual_rollout")
+        self.step_count += K
+
+    def depth(self, heightfield, max_depth: float = 20.0) -> torch.Tensor:
+        """extension: distance_to_image_plane of the camera against a heightfield -> [n, 60, 80]"""
+        h, x0, y0, cell = heightfield
+        ht = torch.as_tensor(h, dtype=torch.float32).contiguous().to(self.device)
+        hf = A.WlHeightField(ht.data_ptr(), ht.shape[1], ht.shape[0], float(x0), float(y0), float(cell), 0.0)
+        out = torch.zeros(self.n, 60, 80, device=self.device)
+        A.check(self.lib.wl_visual_depth(C.byref(self.p), C.byref(self._bufs), C.byref(hf), float(max_depth),
+                                         out.data_ptr(), self._stream()), "wl_visual_depth")
+        torch.cuda.current_stream(self.device).synchronize()  # `ht` must outlive the launch
+        return out

@@ -1,0 +1,428 @@
+// wl_visual.hip -- visual task (wheeledlab_tasks/visual/mushr_visual_env_cfg.py) for gfx950.
+//
+// Two launches per env.step():
+//   1. visual_step_kernel (lane = env): 4WD action term -> sub-steps on the flat plane -> time_out / out_of_map ->
+//      traversable_reward (byte-map gather) + forward_vel -> reset onto a random traversable cell.
+//   2. visual_obs_kernel  (block = env): the 3208-dim observation.  3200 camera rays against the z = 0 plane with a
+//      traversability-map lookup each; the 40 x 80 image is staged in LDS (12.8 KB) so that the contrast mean
+//      (block reduction) and the separable 5x5 Gaussian blur (second LDS plane) never leave the CU; the row is
+//      written once with contiguous dword stores -- 12.8 KB / env, ~98 % of the task's HBM bytes.
+#include <hip/hip_runtime.h>
+
+#include "../../include/wheeledlab_amd.h"
+#include "wl_kernel_common.h"
+#include "wl_drift_terms.h"
+#include "wl_rng.h"
+#include "wl_vehicle.h"
+#include "wl_heightfield.h"
+
+namespace {
+
+constexpr int kImgH = WL_VIS_IMG_H - WL_VIS_CROP, kImgW = WL_VIS_IMG_W;
+
+// TraversabilityHashmapUtil.get_map_id (visual/utils/traversability_utils.py:83-88): float32 arithmetic, truncation
+// toward zero (`.long()`), clamp to the map.
+WL_DEV void map_id(const WlTravMap& m, float x, float y, int& xi, int& yi) {
+    const float width = (float)m.rows * m.row_spacing, height = (float)m.cols * m.col_spacing;
+    const float fx = (x + 0.5f * width + 0.5f * m.row_spacing) / m.row_spacing;
+    const float fy = (y + 0.5f * height + 0.5f * m.col_spacing) / m.col_spacing;
+    // float -> int conversion saturates on gfx950 (v_cvt_i32_f32), NaN -> 0: both end up clamped like torch's long()
+    xi = min(max((int)fx, 0), m.rows - 1);
+    yi = min(max((int)fy, 0), m.cols - 1);
+}
+WL_DEV bool traversable(const WlTravMap& m, float x, float y) {
+    int xi, yi;
+    map_id(m, x, y, xi, yi);
+    return m.map[yi * m.cols + xi] != 0;   // map[y_idx, x_idx] (:78)
+}
+// out_of_map (mushr_visual_env_cfg.py:390-398)
+WL_DEV bool out_of_map(const WlTravMap& m, float x, float y) {
+    const float hw = 0.5f * (float)m.rows * m.row_spacing, hh = 0.5f * (float)m.cols * m.col_spacing;
+    return x > hw || x < -hw || y > hh || y < -hh;
+}
+
+struct VisReset {
+    V3 pos;
+    Quat q;
+};
+// visual/mdp/events.py:11-42 + generate_random_poses (utils/__init__.py:188-202): random traversable cell, z 0.1,
+// yaw U(0, 360 deg), zero velocity
+WL_DEV VisReset draw_visual_reset(const WlVisualParams& p, const WlTravMap& m, uint32_t gid, uint64_t step, uint64_t seed) {
+    const F4 u = philox_uniform4(gid, step, 0, seed);
+    const int k = min((int)(u.x * (float)m.n_cells), m.n_cells - 1);
+    const int iy = m.cells[2 * k], ix = m.cells[2 * k + 1];
+    VisReset r;
+    r.pos = v3(((float)ix - (float)(m.cols / 2)) * m.row_spacing, ((float)iy - (float)(m.rows / 2)) * m.col_spacing, p.reset_z);
+    float s, c;
+    sincos_rev(0.5f * u.y, s, c);   // yaw = 2 pi u  ->  yaw / 2 = u / 2 revolutions
+    r.q = Quat{c, 0.f, 0.f, s};
+    return r;
+}
+
+__global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
+                                                             const float2* __restrict__ actions, const WlStepOut out,
+                                                             const uint64_t seed, const uint64_t step, const VehDerived vd) {
+    __shared__ float blk_metrics[WL_M_COUNT];
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
+    const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
+    if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
+        b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
+    __syncthreads();
+    const Rows S{b.state, b.stride};
+    const WlVehicleParams& vp = p.vehicle;
+    if (e < b.n_envs) {
+        const uint32_t gid = (uint32_t)(b.env_offset + e);
+        float2 a = actions[e];
+        float v_t, delta;
+        process_action(p.action, a.x, a.y, v_t, delta);
+        EnvConst ec;
+        joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
+        env_const_mass(ec, vp, vd, S(WL_S_MASS, e));
+        ec.mu_s = S(WL_S_MU_S, e) * vp.ground_mu_s;
+        ec.mu_d = fminf(S(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
+        ec.damp = S(WL_S_DAMP, e);
+        VehState s;
+        V3 pos = ld3(S, WL_S_PX, e);
+        s.q = Quat{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+        s.v = ld3(S, WL_S_VX, e);
+        V3 ww = ld3(S, WL_S_WX, e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
+        s.th = S(WL_S_STEER_POS, e);
+        s.om = S(WL_S_STEER_VEL, e);
+        {
+            const Mat3 R = mat_from_quat(s.q);
+            s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
+            s.wb = mul_t(R, ww);
+        }
+        const FlatGround ground{};
+        for (int k = 0; k < vd.n_sub; ++k) vehicle_substep(vp, vd, ec, s, ground);
+        asm volatile("" ::: "memory");
+        const Mat3 R = mat_from_quat(s.q);
+        ww = mul(R, s.wb);
+        pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
+        int ep_len = b.episode_len[e] + 1;
+        const bool truncated = ep_len >= p.max_episode_length;
+        const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y +
+                          ww.z + s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3] + s.th + s.om;
+        const bool finite = __builtin_isfinite(chk);
+        const bool oom = finite && out_of_map(m, pos.x, pos.y);
+        const bool terminated = !finite || oom;
+        const V3 vb = mul_t(R, s.v);
+        float t[WL_VR_NTERMS];
+        t[WL_VR_TRAVERSABLE] = finite ? (traversable(m, pos.x, pos.y) ? 1.f : -1.f) : 0.f;   // :309-312
+        t[WL_VR_FORWARD_VEL] = vb.x;                                                          // :370-371
+        const float step_dt = p.sim_dt * (float)p.decimation;
+        float reward = 0.f;
+        float epsum[WL_VR_NTERMS];
+#pragma unroll
+        for (int i = 0; i < WL_VR_NTERMS; ++i) {
+            const float w = p.weight[i];
+            const float c = (w != 0.f && finite) ? t[i] * w * step_dt : 0.f;
+            reward += c;
+            epsum[i] = p.log_episode_sums ? S(WL_S_EPSUM0 + i, e) + c : 0.f;
+        }
+        out.reward[e] = reward;
+        out.terminated[e] = terminated ? 1 : 0;
+        out.truncated[e] = truncated ? 1 : 0;
+        float a0 = a.x, a1 = a.y;
+        if (terminated || truncated) {
+#pragma unroll
+            for (int i = 0; i < WL_VR_NTERMS; ++i) {
+                atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
+                epsum[i] = 0.f;
+            }
+            atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
+            if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
+            if (oom) atomicAdd(&blk_metrics[WL_M_TERM0], 1.f);
+            if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
+            atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
+            if (!finite) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
+                s.th = s.om = 0.f;
+            }
+            const VisReset rd = draw_visual_reset(p, m, gid, step, seed);
+            pos = rd.pos;
+            s.q = rd.q;
+            s.v = v3(0.f, 0.f, 0.f);
+            ww = v3(0.f, 0.f, 0.f);
+            ep_len = 0;
+            a0 = a1 = 0.f;
+        }
+        st3(S, WL_S_PX, e, pos);
+        S(WL_S_QW, e) = s.q.w;
+        S(WL_S_QX, e) = s.q.x;
+        S(WL_S_QY, e) = s.q.y;
+        S(WL_S_QZ, e) = s.q.z;
+        st3(S, WL_S_VX, e, s.v);
+        st3(S, WL_S_WX, e, ww);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S(WL_S_WHEEL_BL + i, e) = s.wheel[i];
+        S(WL_S_STEER_POS, e) = s.th;
+        S(WL_S_STEER_VEL, e) = s.om;
+        S(WL_S_ACT0, e) = a0;
+        S(WL_S_ACT1, e) = a1;
+        if (p.log_episode_sums) {
+#pragma unroll
+            for (int i = 0; i < WL_VR_NTERMS; ++i) S(WL_S_EPSUM0 + i, e) = epsum[i];
+        }
+        b.episode_len[e] = ep_len;
+    }
+    __syncthreads();
+    if (threadIdx.x < WL_M_COUNT) {
+        const float v = blk_metrics[threadIdx.x];
+        if (v != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], v);
+    }
+}
+
+// camera ray of pixel (row, col) of the FULL 60 x 80 image in the body frame: optical axis = body +x, image right =
+// body -y, image down = body -z (ROS optical convention of the reference's camera offset, :241-243)
+WL_DEV V3 pixel_ray_body(const WlVisualParams& p, int row, int col) {
+    return v3(1.f, -(((float)col + 0.5f - p.cx) / p.fx), -(((float)row + 0.5f - p.cy) / p.fy));
+}
+
+WL_DEV float block_sum(float v, float* scratch /* [kBlock/64] */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) t += scratch[w];
+    return t;
+}
+
+WL_DEV int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// VisualObsCfg.PolicyCfg (:38-58): camera (3200) | base_lin_vel (3) | base_ang_vel (3) | last_action clip +-1 (2)
+__global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
+                                                            float* __restrict__ obs) {
+    __shared__ float img[kImgH * kImgW];
+    __shared__ float tmp[kImgH * kImgW];
+    __shared__ float red[kBlock / 64];
+    const int e = blockIdx.x;
+    const Rows S{b.state, b.stride};
+    const V3 pos = ld3(S, WL_S_PX, e);
+    const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+    const Mat3 R = mat_from_quat(q);
+    const V3 o = pos + mul(R, v3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
+    const float half_w = 0.5f * (float)m.rows * m.row_spacing, half_h = 0.5f * (float)m.cols * m.col_spacing;
+    // ---- render: one ray per pixel against the z = 0 plane ----
+    float part = 0.f;
+    for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) {
+        const int r = k / kImgW, c = k - r * kImgW;
+        const V3 d = mul(R, pixel_ray_body(p, r + WL_VIS_CROP, c));
+        float v = p.sky;
+        if (d.z < -1e-6f) {
+            const float t = -o.z / d.z;
+            const float hx = fmaf(t, d.x, o.x), hy = fmaf(t, d.y, o.y);
+            const bool on_map = fabsf(hx) <= half_w && fabsf(hy) <= half_h;
+            v = (on_map && traversable(m, hx, hy)) ? 1.f : 0.f;   // white path on black (utils/__init__.py:47-50)
+        }
+        v = clampf(v * p.brightness, 0.f, 1.f);                    // ColorJitter brightness
+        img[k] = v;
+        part += v;
+    }
+    if (p.contrast != 1.f) {                                       // ColorJitter contrast: blend with the grey mean
+        const float mean = 0.9999f * block_sum(part, red) * (1.f / (float)(kImgH * kImgW));
+        for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock)
+            img[k] = clampf(fmaf(p.contrast, img[k], (1.f - p.contrast) * mean), 0.f, 1.f);
+    }
+    __syncthreads();
+    const float* src = img;
+    if (p.blur_sigma > 0.f) {                                      // GaussianBlur(5, sigma), reflect padding, separable
+        float w[5];
+        float wsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const float x = (float)(j - 2) / p.blur_sigma;
+            w[j] = __expf(-0.5f * x * x);
+            wsum += w[j];
+        }
+        const float inv = 1.f / wsum;
+        for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) {
+            const int r = k / kImgW, c = k - r * kImgW;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc = fmaf(w[j] * inv, img[r * kImgW + reflect(c + j - 2, kImgW)], acc);
+            tmp[k] = acc;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) {
+            const int r = k / kImgW, c = k - r * kImgW;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) acc = fmaf(w[j] * inv, tmp[reflect(r + j - 2, kImgH) * kImgW + c], acc);
+            img[k] = acc;
+        }
+        __syncthreads();
+    }
+    // ---- grayscale (0.2989 + 0.587 + 0.114 = 0.9999 of a grey pixel) + Normalize([0.5], [0.5]) + flatten ----
+    float* row = obs + (int64_t)e * WL_VIS_OBS_DIM;
+    for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) row[k] = (src[k] * 0.9999f - 0.5f) / 0.5f;
+    if (threadIdx.x == 0) {
+        const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
+        float* t = row + WL_VIS_NPIX;
+        t[0] = vb.x; t[1] = vb.y; t[2] = vb.z;
+        t[3] = wb.x; t[4] = wb.y; t[5] = wb.z;
+        t[6] = clampf(S(WL_S_ACT0, e), -1.f, 1.f);
+        t[7] = clampf(S(WL_S_ACT1, e), -1.f, 1.f);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) visual_reset_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
+                                                              const uint8_t* __restrict__ mask, uint64_t seed, uint64_t step) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= b.n_envs) return;
+    if (mask && !mask[e]) return;
+    const Rows S{b.state, b.stride};
+    const VisReset rd = draw_visual_reset(p, m, (uint32_t)(b.env_offset + e), step, seed);
+    st3(S, WL_S_PX, e, rd.pos);
+    S(WL_S_QW, e) = rd.q.w;
+    S(WL_S_QX, e) = rd.q.x;
+    S(WL_S_QY, e) = rd.q.y;
+    S(WL_S_QZ, e) = rd.q.z;
+    st3(S, WL_S_VX, e, v3(0.f, 0.f, 0.f));
+    st3(S, WL_S_WX, e, v3(0.f, 0.f, 0.f));
+    S(WL_S_ACT0, e) = 0.f;
+    S(WL_S_ACT1, e) = 0.f;
+#pragma unroll
+    for (int i = 0; i < WL_MAX_REW_TERMS; ++i) S(WL_S_EPSUM0 + i, e) = 0.f;
+    b.episode_len[e] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock) visual_mdp_kernel(const WlVisualParams p, const WlTravMap m, int n, int64_t stride,
+                                                            const float* __restrict__ pos, const float* __restrict__ vb,
+                                                            float* __restrict__ terms, uint8_t* __restrict__ oom,
+                                                            int32_t* __restrict__ x_idx, int32_t* __restrict__ y_idx) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n) return;
+    const float x = pos[e], y = pos[stride + e];
+    int xi, yi;
+    map_id(m, x, y, xi, yi);
+    x_idx[e] = xi;
+    y_idx[e] = yi;
+    terms[e] = m.map[yi * m.cols + xi] ? 1.f : -1.f;
+    terms[stride + e] = vb[e];
+    oom[e] = out_of_map(m, x, y) ? 1 : 0;
+}
+
+// depth extension: distance_to_image_plane of the camera against a heightfield (march 0.05 m steps along the optical
+// axis, then 6 bisection steps); rays that leave the grid hit the z = outside_z plane
+__global__ void __launch_bounds__(kBlock) visual_depth_kernel(const WlVisualParams p, const WlEnvBuffers b, const HeightFieldGround g,
+                                                              float max_depth, float* __restrict__ depth) {
+    const int e = blockIdx.x;
+    const Rows S{b.state, b.stride};
+    const V3 pos = ld3(S, WL_S_PX, e);
+    const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+    const Mat3 R = mat_from_quat(q);
+    const V3 o = pos + mul(R, v3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
+    for (int k = threadIdx.x; k < WL_VIS_IMG_H * WL_VIS_IMG_W; k += kBlock) {
+        const int r = k / WL_VIS_IMG_W, c = k - r * WL_VIS_IMG_W;
+        const V3 d = mul(R, pixel_ray_body(p, r, c));   // |d.x_body| = 1: the ray parameter IS the image-plane distance
+        float t0 = 0.f, t1 = 0.f, res = max_depth;
+        bool found = false;
+        for (float t = 0.05f; t <= max_depth; t += 0.05f) {
+            float z;
+            V3 n;
+            g.sample(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), z, n);
+            if (fmaf(t, d.z, o.z) <= z) {
+                t0 = t - 0.05f;
+                t1 = t;
+                found = true;
+                break;
+            }
+        }
+        if (found) {
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const float tm = 0.5f * (t0 + t1);
+                float z;
+                V3 n;
+                g.sample(fmaf(tm, d.x, o.x), fmaf(tm, d.y, o.y), z, n);
+                if (fmaf(tm, d.z, o.z) <= z) t1 = tm; else t0 = tm;
+            }
+            res = 0.5f * (t0 + t1);
+        }
+        depth[(int64_t)e * WL_VIS_IMG_H * WL_VIS_IMG_W + k] = res;
+    }
+}
+
+int check_visual(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m) {
+    if (!p || !b || !m || !b->state || !b->episode_len || !b->metrics || !m->map || !m->cells) return WL_EINVAL;
+    if (b->n_envs <= 0 || b->stride < b->n_envs || b->metrics_slots < 1 || m->n_cells <= 0) return WL_EINVAL;
+    if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
+    if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f) || m->rows <= 0 || m->cols <= 0) return WL_EINVAL;
+    return WL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wl_visual_step(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const float* actions,
+                   const WlStepOut* out, uint64_t seed, uint64_t step, void* stream) {
+    return wl_visual_rollout(p, b, m, actions, out, 0, 0, 1, seed, step, stream);
+}
+
+int wl_visual_rollout(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const float* actions,
+                      const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps, uint64_t seed,
+                      uint64_t step0, void* stream) {
+    int rc = check_visual(p, b, m);
+    if (rc != WL_OK) return rc;
+    if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
+    const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
+    clear_error();
+    for (int k = 0; k < n_steps; ++k) {
+        WlStepOut o = *out;
+        o.obs += k * obs_step_stride;
+        o.reward += k * vec_step_stride;
+        o.terminated += k * vec_step_stride;
+        o.truncated += k * vec_step_stride;
+        visual_step_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
+            *p, *b, *m, (const float2*)(actions + (int64_t)k * b->n_envs * 2), o, seed, step0 + (uint64_t)k, vd);
+        visual_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, o.obs);
+    }
+    return launch_status();
+}
+
+int wl_visual_reset(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const uint8_t* mask, uint64_t seed,
+                    uint64_t step, void* stream) {
+    int rc = check_visual(p, b, m);
+    if (rc != WL_OK) return rc;
+    clear_error();
+    visual_reset_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, mask, seed, step);
+    return launch_status();
+}
+
+int wl_visual_observe(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, float* obs, void* stream) {
+    int rc = check_visual(p, b, m);
+    if (rc != WL_OK) return rc;
+    if (!obs) return WL_EINVAL;
+    clear_error();
+    visual_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, obs);
+    return launch_status();
+}
+
+int wl_visual_mdp(const WlVisualParams* p, const WlTravMap* m, int32_t n, int64_t stride, const float* pos,
+                  const float* lin_vel_b, float* terms, uint8_t* out_of_map_, int32_t* x_idx, int32_t* y_idx, void* stream) {
+    if (!p || !m || !m->map || n <= 0 || stride < n || !pos || !lin_vel_b || !terms || !out_of_map_ || !x_idx || !y_idx)
+        return WL_EINVAL;
+    clear_error();
+    visual_mdp_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(*p, *m, n, stride, pos, lin_vel_b, terms, out_of_map_,
+                                                                        x_idx, y_idx);
+    return launch_status();
+}
+
+int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, float max_depth, float* depth,
+                    void* stream) {
+    if (!p || !b || !hf || !b->state || !hf->height || !depth || b->n_envs <= 0 || !(max_depth > 0.f)) return WL_EINVAL;
+    clear_error();
+    visual_depth_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), max_depth, depth);
+    return launch_status();
+}
+
+}  // extern "C"

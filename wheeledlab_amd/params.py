@@ -107,3 +107,23 @@ def struct_to_dict(s) -> dict:
         else:
             out[name] = v
     return out
+
+
+def visual_params():
+    """MushrVisualRLEnvCfg (wheeledlab_tasks/visual/mushr_visual_env_cfg.py:412-444) flattened"""
+    from ._abi import WlVisualParams
+    p = WlVisualParams()
+    p.sim_dt, p.decimation = 0.02, 10                                   # :435-436
+    p.max_episode_length = math.ceil(10.0 / (0.02 * 10))                # :439
+    p.action = mushr_action(1)
+    p.vehicle = mushr_vehicle(drive=1, motor_limit=0.25, substeps=4, ground_mu=(2.0, 2.0))   # :130-135; h = 0.005
+    for i, w in enumerate((5.0, 7.0, 0, 0, 0, 0, 0, 0)):                # :375-385
+        p.weight[i] = w
+    p.reset_z = 0.1                                                     # :203
+    p.cam_pos[0], p.cam_pos[1], p.cam_pos[2] = 0.23, 0.0, 0.18          # designed (camera_link pose is in the missing USD)
+    p.fx = 80 * 1.9299999475479126 / 3.8959999084472656                 # :236-238
+    p.fy = 60 * 1.9299999475479126 / 2.453000068664551
+    p.cx, p.cy = 40.0, 30.0
+    p.sky, p.brightness, p.contrast, p.blur_sigma = 0.5, 1.0, 1.0, 0.0
+    p.log_episode_sums = 1
+    return p
