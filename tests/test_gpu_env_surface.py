@@ -124,3 +124,68 @@ def test_sync_episode_log_mode_matches_isaaclab_semantics():
         else:
             assert "log" not in extras
     assert seen > 0
+
+
+@pytest.mark.parametrize("task,obs_dim,n", [("Isaac-MushrElevationRL-v0", 689, 256), ("Isaac-MushrVisualRL-v0", 3208, 128),
+                                            ("Isaac-F1TenthDriftRL-v0", 14, 256)])
+def test_other_registered_tasks_run_through_the_same_surface(task, obs_dim, n):
+    from wheeledlab_amd import registry, tasks  # noqa: F401
+    from wheeledlab_amd.rl import ClipAction, RslRlVecEnvWrapper
+    cfg = registry.parse_env_cfg(task, device=DEV, num_envs=n)
+    env = registry.make(task, cfg=cfg)
+    env.action_space.low, env.action_space.high = -1.0, 1.0
+    env = RslRlVecEnvWrapper(ClipAction(env))
+    assert env.num_obs == obs_dim and env.num_actions == 2
+    obs, _ = env.get_observations()
+    assert obs.shape == (n, obs_dim)
+    done_total = 0
+    for _ in range(60):
+        obs, rew, dones, infos = env.step(torch.randn(n, 2, device=DEV))
+        done_total += int(dones.sum())
+    assert obs.shape == (n, obs_dim) and torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert done_total > 0 and float(env.unwrapped.episode_metrics()[8]) == done_total
+    log = infos["log"]
+    assert any(k.startswith("Episode_Termination/") for k in log.keys())
+
+
+def test_elevation_and_visual_plugin_terms_match_oracle():
+    from oracle import elev_mdp as OE
+    from oracle import visual_mdp as OV
+    from wheeledlab_amd import registry, tasks  # noqa: F401
+    from wheeledlab_amd.envs import mdp
+    # ---- elevation ----
+    cfg = registry.parse_env_cfg("Isaac-MushrElevationRL-v0", device=DEV, num_envs=200)
+    env = registry.make("Isaac-MushrElevationRL-v0", cfg=cfg)
+    env.reset()
+    for _ in range(15):
+        env.step(torch.rand(200, 2, device=DEV) * 2 - 1)
+    d = env.scene["robot"].data
+    pos, vb, vw = mdp.root_pos_w(env).cpu().numpy(), mdp.base_lin_vel(env).cpu().numpy(), mdp.root_lin_vel_w(env).cpu().numpy()
+    cmd = mdp.generated_commands(env, "goal_pose")
+    assert cmd.shape == (200, 4)
+    cmd = cmd.cpu().numpy()
+    R, T = cfg.rewards, cfg.terminations
+    np.testing.assert_allclose(R.vel_towards_goal.func(env).cpu(), OE.goal_progress_rate(pos, vw, cmd), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(R.height_z.func(env).cpu(), OE.higher_elevation(pos, vb), rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(R.falling_penalty.func(env).cpu().numpy(), OE.is_falling_penalty(vb))
+    wheels = mdp.joint_vel(env, mdp.SceneEntityCfg("robot", joint_names=".*throttle")).cpu().numpy()
+    assert wheels.shape == (200, 4)
+    np.testing.assert_array_equal(T.stuck.func(env, **T.stuck.params).cpu().numpy(), OE.stuck(vb, wheels))
+    np.testing.assert_array_equal(T.at_goal.func(env, **T.at_goal.params).cpu().numpy(), OE.close_to_goal(pos, cmd))
+    np.testing.assert_array_equal(T.cart_out_of_bounds.func(env, **T.cart_out_of_bounds.params).cpu().numpy(), pos[:, 2] < 0.15)
+    np.testing.assert_allclose(mdp.goal_relative_xyz(env).cpu(), OE.goal_relative_xyz(pos, cmd), rtol=1e-6, atol=1e-6)
+    assert mdp.world_height_map(env).shape == (200, 676)
+    assert env.termination_manager.get_term("stuck").shape == (200,)
+    # ---- visual ----
+    cfg = registry.parse_env_cfg("Isaac-MushrVisualRL-v0", device=DEV, num_envs=100)
+    env = registry.make("Isaac-MushrVisualRL-v0", cfg=cfg)
+    env.reset()
+    for _ in range(5):
+        env.step(torch.rand(100, 2, device=DEV) * 2 - 1)
+    pos = mdp.root_pos_w(env).cpu().numpy()
+    trav = env._batch.trav_map.cpu().numpy().astype(bool)
+    np.testing.assert_array_equal(cfg.rewards.traversablility.func(env).cpu().numpy(), OV.traversable_reward(trav, pos))
+    np.testing.assert_array_equal(cfg.terminations.out_range.func(env).cpu().numpy(), OV.out_of_map(pos))
+    np.testing.assert_allclose(cfg.rewards.vel_rew.func(env).cpu(), mdp.base_lin_vel(env)[:, 0].cpu())
+    img = mdp.camera_data_rgb_flattened(env)
+    assert img.shape == (100, 3200) and (img.abs() <= 1 + 1e-6).all()

@@ -26,3 +26,15 @@ MUSHR_CFG = ArticulationCfg(usd_path="Robots/UWPRL/mushr_nano.usd", joint_names=
 MUSHR_SUS_CFG = MUSHR_CFG.replace(usd_path="Robots/UWRLL/mushr_nano_v2.usd", joint_names=list(MUSHR_JOINT_NAMES),
                                   actuators=HOUND_SUS_ACTUATOR_CFG)
 MUSHR_SUS_2WD_CFG = MUSHR_SUS_CFG.replace(actuators=HOUND_SUS_2WD_ACTUATOR_CFG)
+
+# F1Tenth (wheeledlab_assets/f1tenth.py:9-64): 4WD, all throttle joints driven
+F1TENTH_JOINT_NAMES = ["rotator_left", "rotator_right", "wheel_back_left", "wheel_back_right", "wheel_front_left",
+                       "wheel_front_right"]
+F1TENTH_4WD_ACTUATOR_CFG = {
+    "steering_joints": ImplicitActuatorCfg(joint_names_expr=["rotator_(left|right)"], velocity_limit=10.0, effort_limit=2.5,
+                                           stiffness=120.0, damping=8.0, friction=0.0),
+    "throttle_joints": DCMotorCfg(joint_names_expr=[".*wheel_(back|front)_.*"], saturation_effort=1.0, effort_limit=0.25,
+                                  velocity_limit=400.0, stiffness=0, damping=1100.0, friction=0.0),
+}
+F1TENTH_CFG = ArticulationCfg(usd_path="Robots/F1TENTH/f1tenth.usd", joint_names=F1TENTH_JOINT_NAMES,
+                              actuators=F1TENTH_4WD_ACTUATOR_CFG)

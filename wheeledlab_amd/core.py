@@ -34,6 +34,29 @@ def stadium_reference_poses(u: torch.Tensor, track_radius: float = 0.8, straight
     return torch.stack([x, y, yaw]).float()
 
 
+def apply_startup_events(state: torch.Tensor, su, g: torch.Generator, randomize: bool = True):
+    """startup-mode events (domain randomisation, applied once): bucketed wheel friction
+    (isaaclab randomize_rigid_body_material), throttle damping (randomize_actuator_gains, "abs"), base mass
+    (randomize_rigid_body_mass, "add" onto / "abs" instead of the chassis mass).  Reference configs:
+    mushr_drift_env_cfg.py:98-119,145-154; elevation cfg :387-407; visual cfg :264-299."""
+    n, dev = state.shape[1], state.device
+    state[A.S_QW] = 1.0
+    if not randomize:
+        mid = lambda r: 0.5 * (r[0] + r[1])
+        state[A.S_MU_S], state[A.S_MU_D] = mid(su.wheel_mu_s), min(mid(su.wheel_mu_d), mid(su.wheel_mu_s))
+        state[A.S_DAMP], state[A.S_MASS] = mid(su.damping), su.chassis_mass + mid(su.mass_add)
+        return
+    u = lambda r, k: torch.rand(k, generator=g) * (r[1] - r[0]) + r[0]
+    nb = max(1, su.mu_buckets)
+    mu_s, mu_d = u(su.wheel_mu_s, nb), u(su.wheel_mu_d, nb)
+    if su.mu_consistent:
+        mu_d = torch.minimum(mu_d, mu_s)
+    b = torch.randint(0, nb, (n,), generator=g)
+    state[A.S_MU_S], state[A.S_MU_D] = mu_s[b].to(dev), mu_d[b].to(dev)
+    state[A.S_DAMP] = u(su.damping, n).to(dev)
+    state[A.S_MASS] = (su.chassis_mass + u(su.mass_add, n)).to(dev)
+
+
 class DriftBatch:
     """n drift envs resident on one GPU as a SoA state matrix [S_COUNT, stride] (fp32)."""
 
@@ -77,26 +100,11 @@ class DriftBatch:
 
     # startup events (mushr_drift_env_cfg.py:98-119, 145-154)
     def _startup_events(self, g: torch.Generator, randomize: bool, su=None):
-        s, n = self.state, self.stride
-        s[A.S_QW] = 1.0
         if su is None:  # the RSS drift defaults
             from .envs.flatten import StartupSpec
             su = StartupSpec(wheel_mu_s=(0.3, 0.5), wheel_mu_d=(0.3, 0.5), mu_buckets=20, mu_consistent=True,
                              damping=(10.0, 50.0), mass_add=(0.3, 0.5))
-        if not randomize:
-            mid = lambda r: 0.5 * (r[0] + r[1])
-            s[A.S_MU_S], s[A.S_MU_D] = mid(su.wheel_mu_s), min(mid(su.wheel_mu_d), mid(su.wheel_mu_s))
-            s[A.S_DAMP], s[A.S_MASS] = mid(su.damping), su.chassis_mass + mid(su.mass_add)
-            return
-        u = lambda r, k: torch.rand(k, generator=g) * (r[1] - r[0]) + r[0]
-        nb = max(1, su.mu_buckets)  # randomize_rigid_body_material: bucketed materials, mu_d <= mu_s if "make_consistent"
-        mu_s, mu_d = u(su.wheel_mu_s, nb), u(su.wheel_mu_d, nb)
-        if su.mu_consistent:
-            mu_d = torch.minimum(mu_d, mu_s)
-        b = torch.randint(0, nb, (n,), generator=g)
-        s[A.S_MU_S], s[A.S_MU_D] = mu_s[b].to(self.device), mu_d[b].to(self.device)
-        s[A.S_DAMP] = u(su.damping, n).to(self.device)                       # randomize_actuator_gains, "abs"
-        s[A.S_MASS] = (su.chassis_mass + u(su.mass_add, n)).to(self.device)  # randomize_rigid_body_mass, "add"
+        apply_startup_events(self.state, su, g, randomize)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -149,8 +157,7 @@ class ElevBatch:
     OBS_DIM = A.ELEV_OBS_DIM
 
     def __init__(self, n_envs: int, device="cuda:0", params: A.WlElevParams | None = None, seed: int = 42,
-                 env_offset: int = 0, heightfield=None, metrics_slots: int = 1, mass_add=(0.2, 0.5),
-                 wheel_mu=(2.0, 1.0), damping: float = 1000.0):
+                 env_offset: int = 0, heightfield=None, metrics_slots: int = 1, startup=None):
         from .params import elev_params
         from .terrain import synthetic_heightfield
         self.lib = A.load()
@@ -176,11 +183,11 @@ class ElevBatch:
         self._hf = A.WlHeightField(self.height.data_ptr(), self.height.shape[1], self.height.shape[0], float(x0), float(y0),
                                    float(cell), 0.0)
         # startup events (elevation cfg :387-407): wheel friction fixed (2.0, 1.0), base mass += U(0.2, 0.5)
-        g = torch.Generator().manual_seed(self.seed)
-        s = self.state
-        s[A.S_QW] = 1.0
-        s[A.S_MU_S], s[A.S_MU_D], s[A.S_DAMP] = wheel_mu[0], wheel_mu[1], damping
-        s[A.S_MASS] = (MUSHR_CHASSIS_MASS + torch.rand(self.stride, generator=g) * (mass_add[1] - mass_add[0]) + mass_add[0]).to(dev)
+        if startup is None:
+            from .envs.flatten import StartupSpec
+            startup = StartupSpec(wheel_mu_s=(2.0, 2.0), wheel_mu_d=(1.0, 1.0), mu_buckets=5, mu_consistent=False,
+                                  damping=(1000.0, 1000.0), mass_add=(0.2, 0.5))
+        apply_startup_events(self.state, startup, torch.Generator().manual_seed(self.seed))
         self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics.data_ptr(),
                                     self.stride, self.n, self.env_offset, self.metrics_slots)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
@@ -228,8 +235,7 @@ class VisualBatch:
     OBS_DIM = A.VIS_OBS_DIM
 
     def __init__(self, n_envs: int, device="cuda:0", params=None, seed: int = 42, env_offset: int = 0, trav_map=None,
-                 spacing=(0.5, 0.5), metrics_slots: int = 1, wheel_mu=(0.5, 0.5), damping: float = 1000.0,
-                 mass: float = MUSHR_CHASSIS_MASS):
+                 spacing=(0.5, 0.5), metrics_slots: int = 1, startup=None, map_kwargs=None):
         import numpy as np
 
         from .params import visual_params
@@ -253,15 +259,16 @@ class VisualBatch:
         self.terminated = torch.zeros(self.n, dtype=torch.bool, device=dev)
         self.truncated = torch.zeros(self.n, dtype=torch.bool, device=dev)
         if trav_map is None:  # generated at construction from a seeded RNG (the reference uses the global numpy RNG)
-            trav_map = generate_traversability_map(rng=np.random.RandomState(self.seed))
+            trav_map = generate_traversability_map(rng=np.random.RandomState(self.seed), **(map_kwargs or {}))
         trav_map = np.ascontiguousarray(np.asarray(trav_map, dtype=bool))
         self.trav_map = torch.from_numpy(trav_map.astype(np.uint8)).to(dev)
         self.cells = torch.from_numpy(spawn_cells(trav_map)).contiguous().to(dev)
         self._map = A.WlTravMap(self.trav_map.data_ptr(), self.cells.data_ptr(), trav_map.shape[0], trav_map.shape[1],
                                 self.cells.shape[0], float(spacing[0]), float(spacing[1]))
-        s = self.state
-        s[A.S_QW] = 1.0
-        s[A.S_MU_S], s[A.S_MU_D], s[A.S_DAMP], s[A.S_MASS] = wheel_mu[0], wheel_mu[1], damping, mass
+        if startup is None:
+            from .envs.flatten import StartupSpec
+            startup = StartupSpec(wheel_mu_s=(0.5, 0.5), wheel_mu_d=(0.5, 0.5), damping=(1000.0, 1000.0), mass_add=(0.0, 0.0))
+        apply_startup_events(self.state, startup, torch.Generator().manual_seed(self.seed))
         self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics.data_ptr(),
                                     self.stride, self.n, self.env_offset, self.metrics_slots)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),

@@ -15,9 +15,9 @@ import math
 import torch
 
 from .. import _abi as A
-from ..core import DriftBatch
+from ..core import DriftBatch, ElevBatch, VisualBatch
 from .configclass import fields_of
-from .flatten import flatten_drift_cfg
+from .flatten import flatten_cfg
 from .scene import SceneView
 
 
@@ -87,9 +87,12 @@ class TerminationManager:
     def get_term(self, name):
         if name == self._names.get("time_out"):
             return self.time_outs
-        if name == self._names.get(0):
-            return self.terminated
-        raise KeyError(name)
+        slots = [k for k, v in self._names.items() if v == name and k != "time_out"]
+        if not slots:
+            raise KeyError(name)
+        if self._env._task == "elevation":      # several `terminated` terms: re-evaluate the one asked for
+            return self._env._eval_elev_terms()["flags"][slots[0]]
+        return self.terminated
 
 
 class ActionManager:
@@ -116,10 +119,28 @@ class ActionManager:
         return list(self._terms)
 
 
+class CommandManager:
+    """elevation task: UniformPose2dCommand "goal_pose" -> [N, 4] (x_b, y_b, z_b, heading_b) (isaaclab, unpinned)"""
+
+    def __init__(self, env):
+        self._env = env
+        self.active_terms = ["goal_pose"] if env._task == "elevation" else []
+
+    def get_command(self, name):
+        if name != "goal_pose" or self._env._task != "elevation":
+            raise KeyError(name)
+        b = self._env._batch
+        s = b.state
+        q = s[A.S_QW:A.S_QW + 4, : b.n]
+        yaw = torch.atan2(2.0 * (q[0] * q[3] + q[1] * q[2]), 1.0 - 2.0 * (q[2] * q[2] + q[3] * q[3]))
+        hb = torch.remainder(s[A.S_TGT_H, : b.n] - yaw + math.pi, 2 * math.pi) - math.pi
+        return torch.stack([s[A.S_CMD_BX, : b.n], s[A.S_CMD_BY, : b.n], b.p.reset_z - s[A.S_PZ, : b.n], hb], dim=-1)
+
+
 class ObservationManager:
     def __init__(self, env):
         self._env = env
-        self.group_obs_dim = {"policy": (DriftBatch.OBS_DIM,)}
+        self.group_obs_dim = {"policy": (env._batch.OBS_DIM,)}
         self.active_terms = {"policy": [k for k, v in fields_of(env.cfg.observations.policy) if hasattr(v, "func")]}
 
     def compute(self):
@@ -138,8 +159,9 @@ class EpisodeLog(dict):
         self._keys = {f"Episode_Reward/{n}": ("r", s) for n, s in reward_slots.items()}
         if "time_out" in term_names:
             self._keys[f"Episode_Termination/{term_names['time_out']}"] = ("c", A.M_TIMEOUTS)
-        if 0 in term_names:
-            self._keys[f"Episode_Termination/{term_names[0]}"] = ("c", A.M_TERM0)
+        for k in range(4):
+            if k in term_names:
+                self._keys[f"Episode_Termination/{term_names[k]}"] = ("c", A.M_TERM0 + k)
         self._keys["Metrics/resets"] = ("c", A.M_RESETS)
         self._keys["Metrics/nonfinite_envs"] = ("c", A.M_NONFINITE)
 
@@ -175,15 +197,24 @@ class ManagerBasedRLEnv:
         self.render_mode = render_mode
         self.num_envs = int(cfg.scene.num_envs)
         self.device = torch.device(cfg.sim.device)
-        flat = flatten_drift_cfg(cfg)
+        flat = flatten_cfg(cfg)
         self._flat = flat
+        self._task = flat.task
         rank = 0
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank = torch.distributed.get_rank()
         seed = 42 if cfg.seed is None else int(cfg.seed)
-        self._batch = DriftBatch(self.num_envs, device=self.device, params=flat.params, seed=seed,
-                                 env_offset=rank * self.num_envs, metrics_slots=int(cfg.metrics_slots),
-                                 startup=flat.startup)
+        common = dict(device=self.device, params=flat.params, seed=seed, env_offset=rank * self.num_envs,
+                      metrics_slots=int(cfg.metrics_slots), startup=flat.startup)
+        if flat.task == "elevation":
+            self._batch = ElevBatch(self.num_envs, heightfield=flat.extra.get("heightfield"), **common)
+        elif flat.task == "visual":
+            x = flat.extra
+            self._batch = VisualBatch(self.num_envs, trav_map=x["map"], spacing=x["spacing"],
+                                      map_kwargs=dict(map_size=x["map_size"], env_size=x["env_size"],
+                                                      sub_group_size=x["group"], num_walkers=x["walkers"]), **common)
+        else:
+            self._batch = DriftBatch(self.num_envs, **common)
         self.scene = SceneView(self._batch, cfg.scene)
         self.common_step_counter = 0
         self.step_dt = cfg.sim.dt * cfg.decimation
@@ -191,6 +222,7 @@ class ManagerBasedRLEnv:
         self.max_episode_length_s = cfg.episode_length_s
         self.max_episode_length = math.ceil(cfg.episode_length_s / self.step_dt)
         self.action_manager = ActionManager(self)
+        self.command_manager = CommandManager(self)
         self.observation_manager = ObservationManager(self)
         self.reward_manager = RewardManager(self, flat)
         self.termination_manager = TerminationManager(self, flat)
@@ -200,8 +232,8 @@ class ManagerBasedRLEnv:
                 self._event_terms[name] = term.func(term, self)
         self.single_action_space = Box(-math.inf, math.inf, (2,))
         self.action_space = Box(-math.inf, math.inf, (self.num_envs, 2))
-        self.single_observation_space = {"policy": Box(-math.inf, math.inf, (DriftBatch.OBS_DIM,))}
-        self.observation_space = {"policy": Box(-math.inf, math.inf, (self.num_envs, DriftBatch.OBS_DIM))}
+        self.single_observation_space = {"policy": Box(-math.inf, math.inf, (self._batch.OBS_DIM,))}
+        self.observation_space = {"policy": Box(-math.inf, math.inf, (self.num_envs, self._batch.OBS_DIM))}
         self.extras = {}
         self.obs_buf = {}
         self._clip_actions = False
@@ -251,6 +283,8 @@ class ManagerBasedRLEnv:
         b = self._batch
         self.action_manager.prev_action = action
         slot = b.metrics[b.step_count % b.metrics_slots] if b.metrics_slots > 1 else b.metrics
+        if self._task == "visual" and self._flat.extra.get("augment"):
+            b.sample_augmentation()       # one ColorJitter / GaussianBlur draw per call, as torchvision does for a batch
         obs, rew, terminated, truncated = b.step(action)
         self.common_step_counter += 1
         self._sim_step_counter += self.cfg.decimation
@@ -298,6 +332,38 @@ class ManagerBasedRLEnv:
 
     def close(self):
         self._batch = None
+
+    def _soa(self, t):
+        b = self._batch
+        out = torch.zeros(t.shape[1], b.stride, device=self.device)
+        out[:, : b.n] = t.T
+        return out
+
+    def _eval_elev_terms(self):
+        """elevation mdp terms through wl_elev_mdp on the current state -> dict(terms [4,N], flags [4,N] bool, goal_rel [N,2])"""
+        b, d = self._batch, self.scene["robot"].data
+        n, stride = b.n, b.stride
+        ins = [self._soa(t) for t in (d.root_pos_w - self.scene.env_origins, d.root_quat_w, d.root_lin_vel_b, d.root_lin_vel_w,
+                                      d.joint_vel[:, 2:6], b.state[A.S_CMD_BX:A.S_CMD_BX + 2, :n].T)]
+        terms = torch.zeros(4, stride, device=self.device)
+        flags = torch.zeros(4, stride, dtype=torch.bool, device=self.device)
+        goal = torch.zeros(2, stride, device=self.device)
+        A.check(b.lib.wl_elev_mdp(C.byref(b.p), n, stride, *[t.data_ptr() for t in ins], b.truncated.data_ptr(), 0, None,
+                                  None, terms.data_ptr(), flags.data_ptr(), goal.data_ptr(), None, b._stream()), "wl_elev_mdp")
+        return dict(terms=terms[:, :n], flags=flags[:, :n], goal_rel=goal[:, :n].T)
+
+    def _eval_visual_terms(self):
+        """visual mdp terms through wl_visual_mdp on the current state"""
+        b, d = self._batch, self.scene["robot"].data
+        n, stride = b.n, b.stride
+        pos, vb = self._soa(d.root_pos_w - self.scene.env_origins), self._soa(d.root_lin_vel_b)
+        terms = torch.zeros(2, stride, device=self.device)
+        oom = torch.zeros(n, dtype=torch.bool, device=self.device)
+        xi = torch.zeros(n, dtype=torch.int32, device=self.device)
+        yi = torch.zeros(n, dtype=torch.int32, device=self.device)
+        A.check(b.lib.wl_visual_mdp(C.byref(b.p), C.byref(b._map), n, stride, pos.data_ptr(), vb.data_ptr(), terms.data_ptr(),
+                                    oom.data_ptr(), xi.data_ptr(), yi.data_ptr(), b._stream()), "wl_visual_mdp")
+        return dict(terms=terms[:, :n], out_of_map=oom, x_idx=xi, y_idx=yi)
 
     # ---- plugin support: built-in mdp terms evaluate through the terms-only kernel on the current state ----------
     def _eval_drift_terms(self, overrides: dict):

@@ -230,3 +230,117 @@ def increase_reward_weight_over_time(env, env_ids, reward_term_name: str, increa
         term_cfg = env.reward_manager.get_term_cfg(reward_term_name)
         term_cfg.weight += increase
         env.reward_manager.set_term_cfg(reward_term_name, term_cfg)
+
+
+# =====================================================================================================================
+# Elevation task terms (reference: wheeledlab_tasks/elevation/mushr_elevation_env_cfg.py) -- kernel-backed markers.
+# Direct calls evaluate through `wl_elev_mdp` on the env's current state.
+# =====================================================================================================================
+
+def _elev(env):
+    return env._eval_elev_terms()
+
+
+@_kernel_term("reward", 0)
+def goal_progress_rate(env):                                    # :239-249
+    return _elev(env)["terms"][0]
+
+
+@_kernel_term("reward", 1)
+def higher_elevation(env):                                      # :166-173
+    return _elev(env)["terms"][1]
+
+
+@_kernel_term("reward", 2, {"max_body_z_vel": "fall_vel"})
+def is_falling_penalty(env, max_body_z_vel: float = 0.10):      # :251-254 (the live, second definition)
+    return _elev(env)["terms"][2] > 0.5
+
+
+def forward_vel(env):                                           # elevation :155-157 clamps at 1.2; visual :370-371 does not
+    v = base_lin_vel(env)[:, 0]
+    return torch.clamp(v, max=1.2) if getattr(env, "_task", "") == "elevation" else v
+
+
+forward_vel.wl_kind, forward_vel.wl_slot, forward_vel.wl_params = "reward", 1, {}   # visual reward slot
+
+
+@_kernel_term("termination", 0, {"minimum_height": "min_height"})
+def root_height_below_minimum(env, minimum_height: float, asset_cfg=_ROBOT):   # isaaclab mdp (cfg :356-359)
+    return _elev(env)["flags"][0]
+
+
+@_kernel_term("termination", 1, {"min_vel": "stuck_min_vel", "wheel_spin_thr": "stuck_wheel_spin"})
+def stuck(env, min_vel, wheel_spin_thr):                        # :342-347
+    return _elev(env)["flags"][1]
+
+
+@_kernel_term("termination", 2, {"thresh_deg": "upright_cos"})
+def upright_bool(env, thresh_deg):                              # :339-340 via upright_penalty :217-222
+    return _elev(env)["flags"][2]
+
+
+@_kernel_term("termination", 3, {"dist": "goal_dist"})
+def close_to_goal(env, dist):                                   # :268-273
+    return _elev(env)["flags"][3]
+
+
+def goal_relative_xyz(env):                                     # :50-55
+    return _elev(env)["goal_rel"]
+
+
+def world_height_map(env, sensor_cfg=None, offset: float = 0.084, plane_init_value: float = 0.19):   # :44-48
+    return env._batch.observe()[:, 13:]
+
+
+def height_scan(env, sensor_cfg=None, offset: float = 0.5):
+    raise NotImplementedError("mdp.height_scan is fused into world_height_map (elev_obs_kernel)")
+
+
+@_event("reset_uniform")
+def reset_root_state_uniform(env, env_ids, pose_range, velocity_range, asset_cfg=_ROBOT):   # isaaclab mdp.events
+    mask = torch.zeros(env.num_envs, dtype=torch.uint8, device=env.device)
+    mask[env_ids] = 1
+    env._batch.reset(mask)
+
+
+# =====================================================================================================================
+# Visual task terms (reference: wheeledlab_tasks/visual/mushr_visual_env_cfg.py, mdp_sensors/observations.py)
+# =====================================================================================================================
+
+@_kernel_term("reward", 0)
+def traversable_reward(env):                                    # :309-312
+    return env._eval_visual_terms()["terms"][0]
+
+
+def is_traversable(env):                                        # :304-307
+    return (env._eval_visual_terms()["terms"][0] > 0).float()
+
+
+@_kernel_term("termination", 0)
+def out_of_map(env):                                            # :390-398
+    return env._eval_visual_terms()["out_of_map"]
+
+
+def camera_data_rgb_flattened_aug(env, sensor_cfg=None):        # mdp_sensors/observations.py:75-87
+    return env._batch.observe()[:, : A.VIS_NPIX]
+
+
+def camera_data_rgb_flattened(env, sensor_cfg=None):            # mdp_sensors/observations.py:64-73 (no augmentation)
+    b = env._batch
+    keep = (b.p.brightness, b.p.contrast, b.p.blur_sigma)
+    b.p.brightness, b.p.contrast, b.p.blur_sigma = 1.0, 1.0, 0.0
+    out = b.observe()[:, : A.VIS_NPIX].clone()
+    b.p.brightness, b.p.contrast, b.p.blur_sigma = keep
+    return out
+
+
+def raycast_depth(env, sensor_cfg=None, heightfield=None, max_depth: float = 20.0):   # mdp_sensors/observations.py:93-95
+    """extension (unused in the reference): distance_to_image_plane against a heightfield"""
+    return env._batch.depth(heightfield, max_depth)
+
+
+@_event("reset_traversable")
+def reset_root_state(env, env_ids, asset_cfg=_ROBOT):           # visual/mdp/events.py:11-42
+    mask = torch.zeros(env.num_envs, dtype=torch.uint8, device=env.device)
+    mask[env_ids] = 1
+    env._batch.reset(mask)

@@ -26,8 +26,9 @@ def quat_rotate_inverse(q: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
 
 
 class ArticulationData:
-    def __init__(self, batch):
+    def __init__(self, batch, n_joints=len(MUSHR_JOINT_NAMES)):
         self._b = batch
+        self._nj = n_joints
 
     def _rows(self, r0, k):
         b = self._b
@@ -83,14 +84,14 @@ class ArticulationData:
     @property
     def joint_pos(self):
         b = self._b
-        jp = torch.zeros(b.n, len(MUSHR_JOINT_NAMES), device=b.device)
+        jp = torch.zeros(b.n, self._nj, device=b.device)
         jp[:, 0] = jp[:, 1] = b.state[A.S_STEER_POS, : b.n]
         return jp  # wheel spin angles are not integrated (no term reads them); suspension deflection is implicit
 
     @property
     def joint_vel(self):
         b = self._b
-        jv = torch.zeros(b.n, len(MUSHR_JOINT_NAMES), device=b.device)
+        jv = torch.zeros(b.n, self._nj, device=b.device)
         jv[:, 0] = jv[:, 1] = b.state[A.S_STEER_VEL, : b.n]
         jv[:, 2], jv[:, 3] = b.state[A.S_WHEEL_BL, : b.n], b.state[A.S_WHEEL_BR, : b.n]
         jv[:, 4], jv[:, 5] = b.state[A.S_WHEEL_FL, : b.n], b.state[A.S_WHEEL_FR, : b.n]
@@ -100,8 +101,8 @@ class ArticulationData:
 class ArticulationView:
     def __init__(self, batch, joint_names=MUSHR_JOINT_NAMES):
         self._b = batch
-        self.data = ArticulationData(batch)
-        self.joint_names = list(joint_names)
+        self.joint_names = list(joint_names)   # layout: [steer L, steer R, rear L, rear R, front L, front R, (suspension x4)]
+        self.data = ArticulationData(batch, len(self.joint_names))
         self.num_instances = batch.n
 
     def find_joints(self, name_keys, joint_subset=None, preserve_order=False):
@@ -129,7 +130,8 @@ class SceneView:
         self.cfg = cfg
         self.num_envs = batch.n
         self.env_origins = torch.zeros(batch.n, 3, device=batch.device)  # env_spacing = 0 (mushr_drift_env_cfg.py:373)
-        self.articulations = {"robot": ArticulationView(batch)}
+        names = getattr(getattr(cfg, "robot", None), "joint_names", None) or MUSHR_JOINT_NAMES
+        self.articulations = {"robot": ArticulationView(batch, names)}
         self.sensors = {}
         self.terrain = getattr(cfg, "terrain", None)
 
