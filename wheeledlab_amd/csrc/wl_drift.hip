@@ -80,8 +80,8 @@ WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise
 }
 
 // flush this block's LDS obs tile ([kBlock][kObsPad]) to obs[n][14]: contiguous dword stores per wavefront
-WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0, int n) {
-    const int n_valid = min(kBlock, n - block_env0);
+WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0, int n, int envs_per_block = kBlock) {
+    const int n_valid = min(envs_per_block, n - block_env0);
     const int total = n_valid * kObsDim;
     float* dst = obs + (int64_t)block_env0 * kObsDim;
     for (int f = threadIdx.x; f < total; f += kBlock) {
@@ -90,15 +90,20 @@ WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0
     }
 }
 
-template <class Ground>
+// LANES = 1: lane per env (throughput form).  LANES = 4: quad per env, one wheel per lane (latency form, small n).
+template <int LANES, class Ground>
 __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const WlDriftParams p, const WlEnvBuffers b,
                                                             const float2* __restrict__ actions,
                                                             const float* __restrict__ noise, const WlStepOut out,
                                                             const uint64_t seed, const uint64_t step, const Ground ground,
                                                             const VehDerived vd) {
-    __shared__ float tile[kBlock * kObsPad];
+    constexpr int kEnvs = kBlock / LANES;   // envs per block
+    __shared__ float tile[kEnvs * kObsPad];
     __shared__ float blk_metrics[WL_M_COUNT];
-    const int e = blockIdx.x * kBlock + threadIdx.x;
+    const int le = threadIdx.x / LANES;             // env slot within the block
+    const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);   // this lane's wheel (quad form)
+    const bool lead = LANES == 1 || wid == 0;       // the lane that writes the env's shared rows / outputs
+    const int e = blockIdx.x * kEnvs + le;
     const bool active = e < b.n_envs;
     if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
     // per-step metric ring: accumulate into slot step % R, clear the slot the NEXT launch will use
@@ -127,8 +132,12 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         s.q = Quat{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
         s.v = ld3(S, WL_S_VX, e);
         V3 ww = ld3(S, WL_S_WX, e);
+        if constexpr (LANES == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
+            for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
+        } else {
+            s.wheel[0] = S(WL_S_WHEEL_BL + wid, e);
+        }
         s.th = S(WL_S_STEER_POS, e);
         s.om = S(WL_S_STEER_VEL, e);
 #ifndef WL_LATE_LOADS
@@ -141,7 +150,7 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
             s.wb = mul_t(R, ww);
         }
         // ---- physics: decimation x substeps, everything in registers ----
-        for (int k = 0; k < vd.n_sub; ++k) vehicle_substep(vp, vd, ec, s, ground);
+        for (int k = 0; k < vd.n_sub; ++k) vehicle_substep<LANES>(vp, vd, ec, s, ground, wid);
 #ifdef WL_LATE_LOADS
         // rows that only the bookkeeping tail needs are fetched after the physics loop: they would otherwise sit in
         // VGPRs through all sub-steps (occupancy); other resident waves cover the latency
@@ -155,8 +164,11 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         // ---- terminations (time_out, cart_off_track) + non-finite guard ----
         ep_len += 1;
         const bool truncated = ep_len >= p.max_episode_length;
+        float wheel_sum;
+        if constexpr (LANES == 1) wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
+        else wheel_sum = quad_sum(s.wheel[0]);
         const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y +
-                          ww.z + s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3] + s.th + s.om;
+                          ww.z + wheel_sum + s.th + s.om;
         const bool finite = __builtin_isfinite(chk);
         const bool terminated = !finite || cart_off_track(pos.x, pos.y, p.straight, p.r_in, p.r_out);
         // ---- rewards on the post-physics state ----
@@ -172,24 +184,27 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
             reward += c;
             epsum[i] = p.log_episode_sums ? S(WL_S_EPSUM0 + i, e) + c : 0.f;
         }
-        out.reward[e] = reward;
-        out.terminated[e] = terminated ? 1 : 0;
-        out.truncated[e] = truncated ? 1 : 0;
+        if (lead) {
+            out.reward[e] = reward;
+            out.terminated[e] = terminated ? 1 : 0;
+            out.truncated[e] = truncated ? 1 : 0;
+        }
         // ---- reset (done envs) ----
         const bool done = terminated || truncated;
         float a0 = a.x, a1 = a.y;
         if (done) {
             any_done = true;
+            if (lead) {
 #pragma unroll
-            for (int i = 0; i < WL_DR_NTERMS; ++i) {
-                atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
-                epsum[i] = 0.f;
+                for (int i = 0; i < WL_DR_NTERMS; ++i) atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
+                atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
+                if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
+                if (terminated) atomicAdd(&blk_metrics[WL_M_TERM0], 1.f);
+                if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
+                atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
             }
-            atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
-            if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
-            if (terminated) atomicAdd(&blk_metrics[WL_M_TERM0], 1.f);
-            if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
-            atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
+#pragma unroll
+            for (int i = 0; i < WL_DR_NTERMS; ++i) epsum[i] = 0.f;
             if (!finite) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
@@ -223,35 +238,43 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
             }
         }
         // ---- store state ----
-        st3(S, WL_S_PX, e, pos);
-        S(WL_S_QW, e) = s.q.w;
-        S(WL_S_QX, e) = s.q.x;
-        S(WL_S_QY, e) = s.q.y;
-        S(WL_S_QZ, e) = s.q.z;
-        st3(S, WL_S_VX, e, s.v);
-        st3(S, WL_S_WX, e, ww);
+        if constexpr (LANES == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S(WL_S_WHEEL_BL + i, e) = s.wheel[i];
-        S(WL_S_STEER_POS, e) = s.th;
-        S(WL_S_STEER_VEL, e) = s.om;
-        S(WL_S_ACT0, e) = a0;
-        S(WL_S_ACT1, e) = a1;
-        S(WL_S_TIMER_HF, e) = timer_hf;
-        S(WL_S_TIMER_LF, e) = timer_lf;
-        if (p.log_episode_sums) {
-#pragma unroll
-            for (int i = 0; i < WL_DR_NTERMS; ++i) S(WL_S_EPSUM0 + i, e) = epsum[i];
+            for (int i = 0; i < 4; ++i) S(WL_S_WHEEL_BL + i, e) = s.wheel[i];
+        } else {
+            S(WL_S_WHEEL_BL + wid, e) = s.wheel[0];
         }
-        b.episode_len[e] = ep_len;
+        if (lead) {
+            st3(S, WL_S_PX, e, pos);
+            S(WL_S_QW, e) = s.q.w;
+            S(WL_S_QX, e) = s.q.x;
+            S(WL_S_QY, e) = s.q.y;
+            S(WL_S_QZ, e) = s.q.z;
+            st3(S, WL_S_VX, e, s.v);
+            st3(S, WL_S_WX, e, ww);
+            S(WL_S_STEER_POS, e) = s.th;
+            S(WL_S_STEER_VEL, e) = s.om;
+            S(WL_S_ACT0, e) = a0;
+            S(WL_S_ACT1, e) = a1;
+            S(WL_S_TIMER_HF, e) = timer_hf;
+            S(WL_S_TIMER_LF, e) = timer_lf;
+            if (p.log_episode_sums) {
+#pragma unroll
+                for (int i = 0; i < WL_DR_NTERMS; ++i) S(WL_S_EPSUM0 + i, e) = epsum[i];
+            }
+            b.episode_len[e] = ep_len;
+        }
         // ---- observation of the post-reset state ----
         const Mat3 R2 = mat_from_quat(s.q);
         vb = mul_t(R2, s.v);
         const V3 wb2 = mul_t(R2, ww);
-        const Noise12 nz = obs_noise(p, noise, b.stride, e, gid, step, seed);
-        write_obs_row(&tile[threadIdx.x * kObsPad], p, pos, s.q, vb, wb2, a0, a1, nz);
+        if (lead) {
+            const Noise12 nz = obs_noise(p, noise, b.stride, e, gid, step, seed);
+            write_obs_row(&tile[le * kObsPad], p, pos, s.q, vb, wb2, a0, a1, nz);
+        }
     }
     __syncthreads();
-    flush_obs(tile, out.obs, blockIdx.x * kBlock, b.n_envs);
+    flush_obs(tile, out.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
     if (threadIdx.x < WL_M_COUNT) {
         const float m = blk_metrics[threadIdx.x];
         if (m != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], m);
@@ -400,9 +423,13 @@ int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* ac
     if (rc != WL_OK) return rc;
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated) return WL_EINVAL;
     clear_error();
-    drift_step_kernel<FlatGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
-        *p, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{},
-        derive_vehicle(p->vehicle, p->sim_dt, p->decimation));
+    const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
+    if (use_quad(b->n_envs))
+        drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
+            *p, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{}, vd);
+    else
+        drift_step_kernel<1, FlatGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
+            *p, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{}, vd);
     return launch_status();
 }
 
@@ -415,15 +442,20 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
     clear_error();
     const int grid = grid_for(b->n_envs);
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
+    const bool quad = use_quad(b->n_envs);
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = *out;
         o.obs += k * obs_step_stride;
         o.reward += k * vec_step_stride;
         o.terminated += k * vec_step_stride;
         o.truncated += k * vec_step_stride;
-        drift_step_kernel<FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-            *p, *b, (const float2*)(actions + (int64_t)k * b->n_envs * 2), nullptr, o, seed, step0 + (uint64_t)k,
-            FlatGround{}, vd);
+        const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
+        if (quad)
+            drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
+                *p, *b, a, nullptr, o, seed, step0 + (uint64_t)k, FlatGround{}, vd);
+        else
+            drift_step_kernel<1, FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+                *p, *b, a, nullptr, o, seed, step0 + (uint64_t)k, FlatGround{}, vd);
     }
     return launch_status();
 }

@@ -79,11 +79,15 @@ WL_DEV ElevReset draw_elev_reset(const WlElevParams& p, const HeightFieldGround&
     return r;
 }
 
+template <int LANES>
 __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
                                                            const float2* __restrict__ actions, const WlStepOut out,
                                                            const uint64_t seed, const uint64_t step, const VehDerived vd) {
     __shared__ float blk_metrics[WL_M_COUNT];
-    const int e = blockIdx.x * kBlock + threadIdx.x;
+    constexpr int kEnvs = kBlock / LANES;
+    const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);
+    const bool lead = LANES == 1 || wid == 0;
+    const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
     if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
     if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
@@ -107,8 +111,12 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
         s.q = Quat{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
         s.v = ld3(S, WL_S_VX, e);
         V3 ww = ld3(S, WL_S_WX, e);
+        if constexpr (LANES == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
+            for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
+        } else {
+            s.wheel[0] = S(WL_S_WHEEL_BL + wid, e);
+        }
         s.th = S(WL_S_STEER_POS, e);
         s.om = S(WL_S_STEER_VEL, e);
         {
@@ -116,20 +124,22 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
             s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
             s.wb = mul_t(R, ww);
         }
-        for (int k = 0; k < vd.n_sub; ++k) vehicle_substep(vp, vd, ec, s, ground);
+        for (int k = 0; k < vd.n_sub; ++k) vehicle_substep<LANES>(vp, vd, ec, s, ground, wid);
         asm volatile("" ::: "memory");   // bookkeeping rows are fetched after the physics loop (register pressure)
         const Mat3 R = mat_from_quat(s.q);
         ww = mul(R, s.wb);
         pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
         int ep_len = b.episode_len[e] + 1;
         const bool truncated = ep_len >= p.max_episode_length;
+        float wheel_sum;
+        if constexpr (LANES == 1) wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
+        else wheel_sum = quad_sum(s.wheel[0]);
         const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y +
-                          ww.z + s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3] + s.th + s.om;
+                          ww.z + wheel_sum + s.th + s.om;
         const bool finite = __builtin_isfinite(chk);
         const V3 vb = mul_t(R, s.v);
         // terminations / rewards use the command as the PREVIOUS step's command update left it (IsaacLab step order)
         float cbx = S(WL_S_CMD_BX, e), cby = S(WL_S_CMD_BY, e);
-        const float wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
         const ElevTerms tm = elev_terms(p, pos, R.r2.z, vb, s.v, wheel_sum, cbx, cby, truncated);
         const bool terminated = !finite || tm.flag[0] || tm.flag[1] || tm.flag[2] || tm.flag[3];
         const float step_dt = p.sim_dt * (float)p.decimation;
@@ -142,17 +152,17 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
             reward += c;
             epsum[i] = p.log_episode_sums ? S(WL_S_EPSUM0 + i, e) + c : 0.f;
         }
-        out.reward[e] = reward;
-        out.terminated[e] = terminated ? 1 : 0;
-        out.truncated[e] = truncated ? 1 : 0;
+        if (lead) {
+            out.reward[e] = reward;
+            out.terminated[e] = terminated ? 1 : 0;
+            out.truncated[e] = truncated ? 1 : 0;
+        }
         float a0 = a.x, a1 = a.y;
         float tgt_x = S(WL_S_TGT_X, e), tgt_y = S(WL_S_TGT_Y, e), tgt_h = S(WL_S_TGT_H, e), cmd_timer = S(WL_S_CMD_TIMER, e);
         if (terminated || truncated) {
+            if (lead) {
 #pragma unroll
-            for (int i = 0; i < WL_ER_NTERMS; ++i) {
-                atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
-                epsum[i] = 0.f;
-            }
+            for (int i = 0; i < WL_ER_NTERMS; ++i) atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
             atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
             if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
 #pragma unroll
@@ -160,6 +170,9 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
                 if (finite && tm.flag[k]) atomicAdd(&blk_metrics[WL_M_TERM0 + k], 1.f);
             if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
             atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
+            }
+#pragma unroll
+            for (int i = 0; i < WL_ER_NTERMS; ++i) epsum[i] = 0.f;
             if (!finite) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
@@ -193,30 +206,36 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
             cbx = fmaf(c, dx, sn * dy);
             cby = fmaf(-sn, dx, c * dy);
         }
-        st3(S, WL_S_PX, e, pos);
-        S(WL_S_QW, e) = s.q.w;
-        S(WL_S_QX, e) = s.q.x;
-        S(WL_S_QY, e) = s.q.y;
-        S(WL_S_QZ, e) = s.q.z;
-        st3(S, WL_S_VX, e, s.v);
-        st3(S, WL_S_WX, e, ww);
+        if constexpr (LANES == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S(WL_S_WHEEL_BL + i, e) = s.wheel[i];
-        S(WL_S_STEER_POS, e) = s.th;
-        S(WL_S_STEER_VEL, e) = s.om;
-        S(WL_S_ACT0, e) = a0;
-        S(WL_S_ACT1, e) = a1;
-        if (p.log_episode_sums) {
-#pragma unroll
-            for (int i = 0; i < WL_ER_NTERMS; ++i) S(WL_S_EPSUM0 + i, e) = epsum[i];
+            for (int i = 0; i < 4; ++i) S(WL_S_WHEEL_BL + i, e) = s.wheel[i];
+        } else {
+            S(WL_S_WHEEL_BL + wid, e) = s.wheel[0];
         }
-        S(WL_S_CMD_BX, e) = cbx;
-        S(WL_S_CMD_BY, e) = cby;
-        S(WL_S_TGT_X, e) = tgt_x;
-        S(WL_S_TGT_Y, e) = tgt_y;
-        S(WL_S_TGT_H, e) = tgt_h;
-        S(WL_S_CMD_TIMER, e) = cmd_timer;
-        b.episode_len[e] = ep_len;
+        if (lead) {
+            st3(S, WL_S_PX, e, pos);
+            S(WL_S_QW, e) = s.q.w;
+            S(WL_S_QX, e) = s.q.x;
+            S(WL_S_QY, e) = s.q.y;
+            S(WL_S_QZ, e) = s.q.z;
+            st3(S, WL_S_VX, e, s.v);
+            st3(S, WL_S_WX, e, ww);
+            S(WL_S_STEER_POS, e) = s.th;
+            S(WL_S_STEER_VEL, e) = s.om;
+            S(WL_S_ACT0, e) = a0;
+            S(WL_S_ACT1, e) = a1;
+            if (p.log_episode_sums) {
+    #pragma unroll
+                for (int i = 0; i < WL_ER_NTERMS; ++i) S(WL_S_EPSUM0 + i, e) = epsum[i];
+            }
+            S(WL_S_CMD_BX, e) = cbx;
+            S(WL_S_CMD_BY, e) = cby;
+            S(WL_S_TGT_X, e) = tgt_x;
+            S(WL_S_TGT_Y, e) = tgt_y;
+            S(WL_S_TGT_H, e) = tgt_h;
+            S(WL_S_CMD_TIMER, e) = cmd_timer;
+            b.episode_len[e] = ep_len;
+        }
     }
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
@@ -360,6 +379,7 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
     const HeightFieldGround g = make_ground(hf);
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
+    const bool quad = use_quad(b->n_envs);
     clear_error();
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = *out;
@@ -367,8 +387,11 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
         o.reward += k * vec_step_stride;
         o.terminated += k * vec_step_stride;
         o.truncated += k * vec_step_stride;
-        elev_step_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
-            *p, *b, g, (const float2*)(actions + (int64_t)k * b->n_envs * 2), o, seed, step0 + (uint64_t)k, vd);
+        const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
+        if (quad)
+            elev_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, a, o, seed, step0 + (uint64_t)k, vd);
+        else
+            elev_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, a, o, seed, step0 + (uint64_t)k, vd);
         elev_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
     }
     return launch_status();

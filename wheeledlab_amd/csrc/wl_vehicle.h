@@ -73,14 +73,14 @@ struct FlatGround {
     }
 };
 
-template <int WHEEL>  // 0 bl, 1 br, 2 fl, 3 fr
+// Contact + tyre + wheel-spin solve of ONE wheel.  `front` / `left` are compile-time constants in the lane-per-env
+// kernels (the call is inlined per wheel) and per-lane values in the quad kernels (one wheel per lane).
+// Returns the contact force on the body (world) and its torque about the CoM; updates the wheel spin.
 WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Mat3& R, V3 x, V3 v,
-                        V3 ww, float cs, float sn, float zg, V3 n, float& w_spin, V3& Ftot, V3& Ttot) {
-    constexpr bool front = WHEEL >= 2;
-    constexpr bool left = (WHEEL & 1) == 0;
+                        V3 ww, float cs, float sn, float zg, V3 n, bool front, bool left, float wt, float& w_spin,
+                        V3& Fi, V3& Ti) {
     const float r = vp.wheel_radius;
-    const V3 pb = v3(front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, left ? vp.half_track : -vp.half_track,
-                     vd.zrel);
+    const V3 pb = v3(front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, left ? vp.half_track : -vp.half_track, vd.zrel);
     const V3 arm_c = mul(R, pb);
     const float cz = x.z + arm_c.z;
     const float pen = r - (cz - zg) * n.z;
@@ -88,10 +88,10 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const E
     const V3 vcp = v + cross(ww, arm);
     const float vn = dot(vcp, n);
     const float Fz = pen > 0.f ? fmaxf(fmaf(vp.susp_k, pen, -vp.susp_c * vn), 0.f) : 0.f;
-    // wheel heading projected into the contact plane
-    V3 hw = front ? v3(fmaf(R.r0.x, cs, R.r0.y * sn), fmaf(R.r1.x, cs, R.r1.y * sn), fmaf(R.r2.x, cs, R.r2.y * sn))
-                  : v3(R.r0.x, R.r1.x, R.r2.x);
-    V3 t = fma3(-dot(hw, n), n, hw);
+    // wheel heading projected into the contact plane (front wheels are rotated by the steer angle)
+    const float hc = front ? cs : 1.f, hs = front ? sn : 0.f;
+    const V3 hw = v3(fmaf(R.r0.x, hc, R.r0.y * hs), fmaf(R.r1.x, hc, R.r1.y * hs), fmaf(R.r2.x, hc, R.r2.y * hs));
+    const V3 t = fma3(-dot(hw, n), n, hw);
     const V3 tx = rsq(dot(t, t)) * t;
     const V3 ty = cross(n, tx);
     const float vcx = dot(vcp, tx), vcy = dot(vcp, ty);
@@ -106,7 +106,6 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const E
     const float K = fminf(Fz * gq * inv_vden, ec.K_cap);
     const bool driven = (vp.drive == 1) || !front;
     const float d = driven ? ec.damp : 0.f;
-    const float wt = ec.wheel_target[WHEEL];
     // DC-motor torque window at the current spin (IsaacLab DCMotor, hound.py:13-21)
     const float rel = w_i * vd.inv_wlim;
     const float tau_hi = clampf(vp.motor_sat * (1.f - rel), 0.f, vp.motor_limit);
@@ -137,54 +136,22 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const E
         w_n = (tau2 == tau_u2) ? w_u2 : (rhs2 + tau2) * rcp(A2);
     }
     w_spin = w_n;
-    const V3 Fi = fma3(Fz, n, fma3(Fx, tx, Fy * ty));
-    Ftot = Ftot + Fi;
-    Ttot = Ttot + cross(arm, Fi);
+    Fi = fma3(Fz, n, fma3(Fx, tx, Fy * ty));
+    Ti = cross(arm, Fi);
 }
 
-template <class Ground>
-WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
-                            const Ground& ground) {
-    const float h = vd.h;
-    // steering: implicit PD drive, effort- and rate-limited (hound.py:5-12)
-    {
-        const float e = ec.steer_target - s.th;
-        float om_n = fmaf(vd.steer_a, e, s.om) * vd.steer_b;
-        const float tau = clampf(vd.steer_J_h * (om_n - s.om), -vp.steer_effort, vp.steer_effort);
-        om_n = clampf(fmaf(vd.steer_h_J, tau, s.om), -vp.steer_vel_limit, vp.steer_vel_limit);
-        s.th = fmaf(h, om_n, s.th);
-        s.om = om_n;
-    }
-    const Mat3 R = mat_from_quat(s.q);
-    const V3 ww = mul(R, s.wb);
-    float sn, cs;
-    sincos_fast(s.th, sn, cs);   // |th| <= tan(0.488) rad: hardware sin/cos, ~1e-6 abs
-    V3 F = v3(0.f, 0.f, 0.f), T = v3(0.f, 0.f, 0.f);
-    // ground under each wheel centre
-    float zg[4];
-    V3 nn[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const bool front = i >= 2, left = (i & 1) == 0;
-        const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;
-        const float bz = vd.zrel;
-        const float cx = s.x.x + fmaf(R.r0.x, bx, fmaf(R.r0.y, by, R.r0.z * bz));
-        const float cy = s.x.y + fmaf(R.r1.x, bx, fmaf(R.r1.y, by, R.r1.z * bz));
-        ground.sample(cx, cy, zg[i], nn[i]);
-    }
-#ifdef WL_SEQ_WHEELS
-#define WL_WHEEL_FENCE() __builtin_amdgcn_sched_barrier(0)   // one wheel's temporaries live at a time (occupancy)
-#else
-#define WL_WHEEL_FENCE()
-#endif
-    wheel_force<0>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg[0], nn[0], s.wheel[0], F, T);
-    WL_WHEEL_FENCE();
-    wheel_force<1>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg[1], nn[1], s.wheel[1], F, T);
-    WL_WHEEL_FENCE();
-    wheel_force<2>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg[2], nn[2], s.wheel[2], F, T);
-    WL_WHEEL_FENCE();
-    wheel_force<3>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg[3], nn[3], s.wheel[3], F, T);
-    WL_WHEEL_FENCE();
+// steering: implicit PD drive, effort- and rate-limited (hound.py:5-12)
+WL_DEV void steer_update(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s) {
+    const float e = ec.steer_target - s.th;
+    float om_n = fmaf(vd.steer_a, e, s.om) * vd.steer_b;
+    const float tau = clampf(vd.steer_J_h * (om_n - s.om), -vp.steer_effort, vp.steer_effort);
+    om_n = clampf(fmaf(vd.steer_h_J, tau, s.om), -vp.steer_vel_limit, vp.steer_vel_limit);
+    s.th = fmaf(vd.h, om_n, s.th);
+    s.om = om_n;
+}
+
+// semi-implicit Euler of the rigid body under the summed contact force F / torque T (world, about the CoM)
+WL_DEV void body_integrate(const VehDerived& vd, const EnvConst& ec, VehState& s, const Mat3& R, V3 F, V3 T) {
     F.z -= ec.weight;
     s.v = fma3(ec.h_inv_mass, F, s.v);
     const V3 Tb = mul_t(R, T);
@@ -193,7 +160,7 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
     s.wb = v3(fmaf(ec.h_inv_Ib.x, Tb.x - gyro.x, s.wb.x), fmaf(ec.h_inv_Ib.y, Tb.y - gyro.y, s.wb.y),
               fmaf(ec.h_inv_Ib.z, Tb.z - gyro.z, s.wb.z));
     const V3 w2 = mul(R, s.wb);
-    s.x = fma3(h, s.v, s.x);
+    s.x = fma3(vd.h, s.v, s.x);
     const float hh = vd.half_h;
     Quat q = s.q;
     Quat dq;
@@ -207,4 +174,56 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
     q.z = fmaf(hh, dq.z, q.z);
     const float inv_n = rsq(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
     s.q = Quat{q.w * inv_n, q.x * inv_n, q.y * inv_n, q.z * inv_n};
+}
+
+// sum over the 4 lanes of a quad with DPP quad_perm swaps (no LDS traffic); every lane gets the SAME bits
+WL_DEV float quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+WL_DEV V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
+
+// One integrator sub-step.
+//   LANES == 1: one lane owns the env and loops over its 4 wheels (throughput form: no redundant work).
+//   LANES == 4: a quad of lanes owns the env, lane `wid` owns wheel `wid` (s.wheel[0] is ITS spin); the body state is
+//               replicated, the wheel forces are summed across the quad with DPP.  Latency form for small env counts:
+//               the critical path per sub-step drops from 4 wheels to 1.
+template <int LANES, class Ground>
+WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
+                            const Ground& ground, int wid = 0) {
+    steer_update(vp, vd, ec, s);
+    const Mat3 R = mat_from_quat(s.q);
+    const V3 ww = mul(R, s.wb);
+    float sn, cs;
+    sincos_fast(s.th, sn, cs);   // |th| <= tan(0.488) rad: hardware sin/cos, ~1e-6 abs
+    V3 F = v3(0.f, 0.f, 0.f), T = v3(0.f, 0.f, 0.f);
+    if constexpr (LANES == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool front = i >= 2, left = (i & 1) == 0;
+            const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;
+            const float cx = s.x.x + fmaf(R.r0.x, bx, fmaf(R.r0.y, by, R.r0.z * vd.zrel));
+            const float cy = s.x.y + fmaf(R.r1.x, bx, fmaf(R.r1.y, by, R.r1.z * vd.zrel));
+            float zg;
+            V3 n, Fi, Ti;
+            ground.sample(cx, cy, zg, n);
+            wheel_force(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, ec.wheel_target[i], s.wheel[i], Fi, Ti);
+            F = F + Fi;
+            T = T + Ti;
+        }
+    } else {
+        const bool front = wid >= 2, left = (wid & 1) == 0;
+        const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;
+        const float cx = s.x.x + fmaf(R.r0.x, bx, fmaf(R.r0.y, by, R.r0.z * vd.zrel));
+        const float cy = s.x.y + fmaf(R.r1.x, bx, fmaf(R.r1.y, by, R.r1.z * vd.zrel));
+        float zg;
+        V3 n, Fi, Ti;
+        ground.sample(cx, cy, zg, n);
+        const float wt = wid == 0 ? ec.wheel_target[0] : wid == 1 ? ec.wheel_target[1] : wid == 2 ? ec.wheel_target[2] : ec.wheel_target[3];
+        wheel_force(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, wt, s.wheel[0], Fi, Ti);
+        F = quad_sum(Fi);
+        T = quad_sum(Ti);
+    }
+    body_integrate(vd, ec, s, R, F, T);
 }
