@@ -253,7 +253,9 @@ __global__ void __launch_bounds__(kBlock) elev_obs_kernel(const WlElevParams p, 
     const Rows S{b.state, b.stride};
     const float px = S(WL_S_PX, e), py = S(WL_S_PY, e), pz = S(WL_S_PZ, e);
     const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
-    if (threadIdx.x == 0) {
+    // the 13 proprioceptive values are one lane's work (2 atan2 + asin): give them to the LAST lane of the block,
+    // whose wave has the fewest rays (676 = 2 x 256 + 164), so they overlap with the other waves' ray casting
+    if (threadIdx.x == kBlock - 1) {
         const Mat3 R = mat_from_quat(q);
         const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
         const V3 eu = euler_xyz_from_quat(q);
@@ -276,13 +278,14 @@ __global__ void __launch_bounds__(kBlock) elev_obs_kernel(const WlElevParams p, 
     yaw_cs(q, c, s);
     float* row = obs + (int64_t)e * WL_ELEV_OBS_DIM;
     const float g0 = -0.5f * p.scan_size;
+    const float base = p.scan_offset - p.elev_z0;   // -(pz - hz - off) + (pz - z0) = (hz - pz + off) + (pz - z0)
+    (void)base;
     for (int k = threadIdx.x; k < WL_ELEV_SCAN_N * WL_ELEV_SCAN_N; k += kBlock) {
         const int iy = k / WL_ELEV_SCAN_N, ix = k - iy * WL_ELEV_SCAN_N;   // meshgrid "xy": x fastest
         const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
         const float wx = px + (c * lx - s * ly), wy = py + (s * lx + c * ly);
         float hz;
-        V3 n;
-        const bool hit = ground.sample_full(wx, wy, hz, n);
+        const bool hit = ground.sample_height(wx, wy, hz);
         // world_height_map = -(sensor_z - hit_z - offset) + (root_z - plane_init_value); rays that miss return +inf
         const float val = hit ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
         row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);

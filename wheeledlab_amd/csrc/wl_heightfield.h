@@ -28,6 +28,19 @@ struct HeightFieldGround {
         return inside;
     }
     WL_DEV void sample(float x, float y, float& z, V3& n) const { (void)sample_full(x, y, z, n); }
+    // height only (ray casting: no normal needed) -- same arithmetic as sample_full for z
+    WL_DEV bool sample_height(float x, float y, float& z) const {
+        const float u = (x - f.x0) * inv_cell, v = (y - f.y0) * inv_cell;
+        const bool inside = u >= 0.f && v >= 0.f && u < (float)(f.nx - 1) && v < (float)(f.ny - 1);
+        const float uc = fminf(fmaxf(u, 0.f), (float)(f.nx - 1) - 1e-3f), vc = fminf(fmaxf(v, 0.f), (float)(f.ny - 1) - 1e-3f);
+        const float fi = floorf(uc), fj = floorf(vc);
+        const float fu = uc - fi, fv = vc - fj;
+        const float* row0 = f.height + (int64_t)(int)fj * f.nx + (int)fi;
+        const float h00 = row0[0], h10 = row0[1], h01 = row0[f.nx], h11 = row0[f.nx + 1];
+        const float a = fmaf(fu, h10 - h00, h00), b = fmaf(fu, h11 - h01, h01);
+        z = inside ? fmaf(fv, b - a, a) : f.outside_z;
+        return inside;
+    }
 };
 
 inline HeightFieldGround make_ground(const WlHeightField* hf) { return HeightFieldGround{*hf, 1.f / hf->cell}; }

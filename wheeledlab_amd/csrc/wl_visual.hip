@@ -35,6 +35,20 @@ WL_DEV bool traversable(const WlTravMap& m, float x, float y) {
     map_id(m, x, y, xi, yi);
     return m.map[yi * m.cols + xi] != 0;   // map[y_idx, x_idx] (:78)
 }
+// render-path lookup: same cell function with reciprocal spacing (the camera is designed, not parity-pinned)
+struct MapFast {
+    float off_x, off_y, inv_rs, inv_cs, half_w, half_h;
+};
+WL_DEV MapFast map_fast(const WlTravMap& m) {
+    const float width = (float)m.rows * m.row_spacing, height = (float)m.cols * m.col_spacing;
+    return MapFast{0.5f * width + 0.5f * m.row_spacing, 0.5f * height + 0.5f * m.col_spacing, rcp(m.row_spacing),
+                   rcp(m.col_spacing), 0.5f * width, 0.5f * height};
+}
+WL_DEV bool traversable_fast(const WlTravMap& m, const MapFast& f, float x, float y) {
+    const int xi = min(max((int)((x + f.off_x) * f.inv_rs), 0), m.rows - 1);
+    const int yi = min(max((int)((y + f.off_y) * f.inv_cs), 0), m.cols - 1);
+    return m.map[yi * m.cols + xi] != 0;
+}
 // out_of_map (mushr_visual_env_cfg.py:390-398)
 WL_DEV bool out_of_map(const WlTravMap& m, float x, float y) {
     const float hw = 0.5f * (float)m.rows * m.row_spacing, hh = 0.5f * (float)m.cols * m.col_spacing;
@@ -229,23 +243,41 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
     const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
     const Mat3 R = mat_from_quat(q);
     const V3 o = pos + mul(R, v3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
-    const float half_w = 0.5f * (float)m.rows * m.row_spacing, half_h = 0.5f * (float)m.cols * m.col_spacing;
-    // ---- render: one ray per pixel against the z = 0 plane ----
+    const MapFast mf = map_fast(m);
+    const float inv_fx = rcp(p.fx), inv_fy = rcp(p.fy);
+    const bool plain = p.contrast == 1.f && !(p.blur_sigma > 0.f);   // no augmentation that needs the whole image
+    float* row = obs + (int64_t)e * WL_VIS_OBS_DIM;
+    if (threadIdx.x == kBlock - 1) {   // proprioception: the last lane (its wave renders the fewest pixels)
+        const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
+        float* t = row + WL_VIS_NPIX;
+        t[0] = vb.x; t[1] = vb.y; t[2] = vb.z;
+        t[3] = wb.x; t[4] = wb.y; t[5] = wb.z;
+        t[6] = clampf(S(WL_S_ACT0, e), -1.f, 1.f);
+        t[7] = clampf(S(WL_S_ACT1, e), -1.f, 1.f);
+    }
+    // ---- render: one ray per pixel against the z = 0 plane.  d = R (1, dy(col), dz(row)) ----
+    const V3 c0 = v3(R.r0.x, R.r1.x, R.r2.x), c1 = v3(R.r0.y, R.r1.y, R.r2.y), c2 = v3(R.r0.z, R.r1.z, R.r2.z);
     float part = 0.f;
     for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) {
         const int r = k / kImgW, c = k - r * kImgW;
-        const V3 d = mul(R, pixel_ray_body(p, r + WL_VIS_CROP, c));
+        const float dy = -(((float)c + 0.5f - p.cx) * inv_fx), dz = -(((float)(r + WL_VIS_CROP) + 0.5f - p.cy) * inv_fy);
+        const V3 d = fma3(dz, c2, fma3(dy, c1, c0));
         float v = p.sky;
         if (d.z < -1e-6f) {
-            const float t = -o.z / d.z;
+            const float t = -o.z * rcp(d.z);
             const float hx = fmaf(t, d.x, o.x), hy = fmaf(t, d.y, o.y);
-            const bool on_map = fabsf(hx) <= half_w && fabsf(hy) <= half_h;
-            v = (on_map && traversable(m, hx, hy)) ? 1.f : 0.f;   // white path on black (utils/__init__.py:47-50)
+            const bool on_map = fabsf(hx) <= mf.half_w && fabsf(hy) <= mf.half_h;
+            v = (on_map && traversable_fast(m, mf, hx, hy)) ? 1.f : 0.f;   // white path on black (utils/__init__.py:47-50)
         }
         v = clampf(v * p.brightness, 0.f, 1.f);                    // ColorJitter brightness
-        img[k] = v;
-        part += v;
+        if (plain) {
+            row[k] = (v * 0.9999f - 0.5f) * 2.f;                   // grayscale + Normalize([0.5], [0.5]) straight to HBM
+        } else {
+            img[k] = v;
+            part += v;
+        }
     }
+    if (plain) return;
     if (p.contrast != 1.f) {                                       // ColorJitter contrast: blend with the grey mean
         const float mean = 0.9999f * block_sum(part, red) * (1.f / (float)(kImgH * kImgW));
         for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock)
@@ -281,16 +313,7 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
         __syncthreads();
     }
     // ---- grayscale (0.2989 + 0.587 + 0.114 = 0.9999 of a grey pixel) + Normalize([0.5], [0.5]) + flatten ----
-    float* row = obs + (int64_t)e * WL_VIS_OBS_DIM;
-    for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) row[k] = (src[k] * 0.9999f - 0.5f) / 0.5f;
-    if (threadIdx.x == 0) {
-        const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
-        float* t = row + WL_VIS_NPIX;
-        t[0] = vb.x; t[1] = vb.y; t[2] = vb.z;
-        t[3] = wb.x; t[4] = wb.y; t[5] = wb.z;
-        t[6] = clampf(S(WL_S_ACT0, e), -1.f, 1.f);
-        t[7] = clampf(S(WL_S_ACT1, e), -1.f, 1.f);
-    }
+    for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) row[k] = (src[k] * 0.9999f - 0.5f) * 2.f;
 }
 
 __global__ void __launch_bounds__(kBlock) visual_reset_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
