@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
     if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
         b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
     __syncthreads();
-    const Rows S{b.state, b.stride};
+    const Rows S = make_rows(b.state, b.stride);
     const WlVehicleParams& vp = p.vehicle;
     bool any_done = false;
     if (active) {
@@ -122,26 +122,26 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         process_action(p.action, a.x, a.y, v_t, delta);
         EnvConst ec;
         joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-        env_const_mass(ec, vp, vd, S(WL_S_MASS, e));
-        ec.mu_s = S(WL_S_MU_S, e) * vp.ground_mu_s;
-        ec.mu_d = fminf(S(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
-        ec.damp = S(WL_S_DAMP, e);
+        env_const_mass(ec, vp, vd, S.ld(WL_S_MASS, e));
+        ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
+        ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
+        ec.damp = S.ld(WL_S_DAMP, e);
         // ---- load state ----
         VehState s;
         V3 pos = ld3(S, WL_S_PX, e);
-        s.q = Quat{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+        s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
         s.v = ld3(S, WL_S_VX, e);
         V3 ww = ld3(S, WL_S_WX, e);
         if constexpr (LANES == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
+            for (int i = 0; i < 4; ++i) s.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
         } else {
-            s.wheel[0] = S(WL_S_WHEEL_BL + wid, e);
+            s.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
         }
-        s.th = S(WL_S_STEER_POS, e);
-        s.om = S(WL_S_STEER_VEL, e);
+        s.th = S.ld(WL_S_STEER_POS, e);
+        s.om = S.ld(WL_S_STEER_VEL, e);
 #ifndef WL_LATE_LOADS
-        float timer_hf = S(WL_S_TIMER_HF, e), timer_lf = S(WL_S_TIMER_LF, e);
+        float timer_hf = S.ld(WL_S_TIMER_HF, e), timer_lf = S.ld(WL_S_TIMER_LF, e);
         int ep_len = b.episode_len[e];
 #endif
         {
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         // rows that only the bookkeeping tail needs are fetched after the physics loop: they would otherwise sit in
         // VGPRs through all sub-steps (occupancy); other resident waves cover the latency
         asm volatile("" ::: "memory");
-        float timer_hf = S(WL_S_TIMER_HF, e), timer_lf = S(WL_S_TIMER_LF, e);
+        float timer_hf = S.ld(WL_S_TIMER_HF, e), timer_lf = S.ld(WL_S_TIMER_LF, e);
         int ep_len = b.episode_len[e];
 #endif
         const Mat3 R = mat_from_quat(s.q);
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
             const float w = p.weight[i];
             const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;  // RewardManager skips w == 0
             reward += c;
-            epsum[i] = p.log_episode_sums ? S(WL_S_EPSUM0 + i, e) + c : 0.f;
+            epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;
         }
         if (lead) {
             out.reward[e] = reward;
@@ -240,27 +240,27 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         // ---- store state ----
         if constexpr (LANES == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) S(WL_S_WHEEL_BL + i, e) = s.wheel[i];
+            for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, s.wheel[i]);
         } else {
-            S(WL_S_WHEEL_BL + wid, e) = s.wheel[0];
+            S.st(WL_S_WHEEL_BL + wid, e, s.wheel[0]);
         }
         if (lead) {
             st3(S, WL_S_PX, e, pos);
-            S(WL_S_QW, e) = s.q.w;
-            S(WL_S_QX, e) = s.q.x;
-            S(WL_S_QY, e) = s.q.y;
-            S(WL_S_QZ, e) = s.q.z;
+            S.st(WL_S_QW, e, s.q.w);
+            S.st(WL_S_QX, e, s.q.x);
+            S.st(WL_S_QY, e, s.q.y);
+            S.st(WL_S_QZ, e, s.q.z);
             st3(S, WL_S_VX, e, s.v);
             st3(S, WL_S_WX, e, ww);
-            S(WL_S_STEER_POS, e) = s.th;
-            S(WL_S_STEER_VEL, e) = s.om;
-            S(WL_S_ACT0, e) = a0;
-            S(WL_S_ACT1, e) = a1;
-            S(WL_S_TIMER_HF, e) = timer_hf;
-            S(WL_S_TIMER_LF, e) = timer_lf;
+            S.st(WL_S_STEER_POS, e, s.th);
+            S.st(WL_S_STEER_VEL, e, s.om);
+            S.st(WL_S_ACT0, e, a0);
+            S.st(WL_S_ACT1, e, a1);
+            S.st(WL_S_TIMER_HF, e, timer_hf);
+            S.st(WL_S_TIMER_LF, e, timer_lf);
             if (p.log_episode_sums) {
 #pragma unroll
-                for (int i = 0; i < WL_DR_NTERMS; ++i) S(WL_S_EPSUM0 + i, e) = epsum[i];
+                for (int i = 0; i < WL_DR_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
             }
             b.episode_len[e] = ep_len;
         }
@@ -339,21 +339,21 @@ __global__ void __launch_bounds__(kBlock) drift_reset_kernel(const WlDriftParams
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= b.n_envs) return;
     if (mask && !mask[e]) return;
-    const Rows S{b.state, b.stride};
+    const Rows S = make_rows(b.state, b.stride);
     const ResetDraw rd = draw_reset(p, b.ref_poses, (uint32_t)(b.env_offset + e), step, seed);
     st3(S, WL_S_PX, e, rd.pos);
-    S(WL_S_QW, e) = rd.q.w;
-    S(WL_S_QX, e) = rd.q.x;
-    S(WL_S_QY, e) = rd.q.y;
-    S(WL_S_QZ, e) = rd.q.z;
+    S.st(WL_S_QW, e, rd.q.w);
+    S.st(WL_S_QX, e, rd.q.x);
+    S.st(WL_S_QY, e, rd.q.y);
+    S.st(WL_S_QZ, e, rd.q.z);
     st3(S, WL_S_VX, e, v3(0.f, 0.f, 0.f));
     st3(S, WL_S_WX, e, v3(0.f, 0.f, 0.f));
-    S(WL_S_ACT0, e) = 0.f;
-    S(WL_S_ACT1, e) = 0.f;
-    S(WL_S_TIMER_HF, e) = rd.timer_hf;
-    S(WL_S_TIMER_LF, e) = rd.timer_lf;
+    S.st(WL_S_ACT0, e, 0.f);
+    S.st(WL_S_ACT1, e, 0.f);
+    S.st(WL_S_TIMER_HF, e, rd.timer_hf);
+    S.st(WL_S_TIMER_LF, e, rd.timer_lf);
 #pragma unroll
-    for (int i = 0; i < WL_MAX_REW_TERMS; ++i) S(WL_S_EPSUM0 + i, e) = 0.f;
+    for (int i = 0; i < WL_MAX_REW_TERMS; ++i) S.st(WL_S_EPSUM0 + i, e, 0.f);
     b.episode_len[e] = 0;
 }
 
@@ -363,12 +363,12 @@ __global__ void __launch_bounds__(kBlock) drift_observe_kernel(const WlDriftPara
     __shared__ float tile[kBlock * kObsPad];
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e < b.n_envs) {
-        const Rows S{b.state, b.stride};
-        const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+        const Rows S = make_rows(b.state, b.stride);
+        const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
         const Mat3 R = mat_from_quat(q);
         const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
         const Noise12 nz = obs_noise(p, noise, b.stride, e, (uint32_t)(b.env_offset + e), step, seed);
-        write_obs_row(&tile[threadIdx.x * kObsPad], p, ld3(S, WL_S_PX, e), q, vb, wb, S(WL_S_ACT0, e), S(WL_S_ACT1, e), nz);
+        write_obs_row(&tile[threadIdx.x * kObsPad], p, ld3(S, WL_S_PX, e), q, vb, wb, S.ld(WL_S_ACT0, e), S.ld(WL_S_ACT1, e), nz);
     }
     __syncthreads();
     flush_obs(tile, obs, blockIdx.x * kBlock, b.n_envs);

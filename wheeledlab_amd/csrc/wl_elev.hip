@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
     if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
         b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
     __syncthreads();
-    const Rows S{b.state, b.stride};
+    const Rows S = make_rows(b.state, b.stride);
     const WlVehicleParams& vp = p.vehicle;
     if (e < b.n_envs) {
         const uint32_t gid = (uint32_t)(b.env_offset + e);
@@ -102,23 +102,23 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
         process_action(p.action, a.x, a.y, v_t, delta);
         EnvConst ec;
         joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-        env_const_mass(ec, vp, vd, S(WL_S_MASS, e));
-        ec.mu_s = S(WL_S_MU_S, e) * vp.ground_mu_s;
-        ec.mu_d = fminf(S(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
-        ec.damp = S(WL_S_DAMP, e);
+        env_const_mass(ec, vp, vd, S.ld(WL_S_MASS, e));
+        ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
+        ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
+        ec.damp = S.ld(WL_S_DAMP, e);
         VehState s;
         V3 pos = ld3(S, WL_S_PX, e);
-        s.q = Quat{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+        s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
         s.v = ld3(S, WL_S_VX, e);
         V3 ww = ld3(S, WL_S_WX, e);
         if constexpr (LANES == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
+            for (int i = 0; i < 4; ++i) s.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
         } else {
-            s.wheel[0] = S(WL_S_WHEEL_BL + wid, e);
+            s.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
         }
-        s.th = S(WL_S_STEER_POS, e);
-        s.om = S(WL_S_STEER_VEL, e);
+        s.th = S.ld(WL_S_STEER_POS, e);
+        s.om = S.ld(WL_S_STEER_VEL, e);
         {
             const Mat3 R = mat_from_quat(s.q);
             s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
         const bool finite = __builtin_isfinite(chk);
         const V3 vb = mul_t(R, s.v);
         // terminations / rewards use the command as the PREVIOUS step's command update left it (IsaacLab step order)
-        float cbx = S(WL_S_CMD_BX, e), cby = S(WL_S_CMD_BY, e);
+        float cbx = S.ld(WL_S_CMD_BX, e), cby = S.ld(WL_S_CMD_BY, e);
         const ElevTerms tm = elev_terms(p, pos, R.r2.z, vb, s.v, wheel_sum, cbx, cby, truncated);
         const bool terminated = !finite || tm.flag[0] || tm.flag[1] || tm.flag[2] || tm.flag[3];
         const float step_dt = p.sim_dt * (float)p.decimation;
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
             const float w = p.weight[i];
             const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;
             reward += c;
-            epsum[i] = p.log_episode_sums ? S(WL_S_EPSUM0 + i, e) + c : 0.f;
+            epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;
         }
         if (lead) {
             out.reward[e] = reward;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
             out.truncated[e] = truncated ? 1 : 0;
         }
         float a0 = a.x, a1 = a.y;
-        float tgt_x = S(WL_S_TGT_X, e), tgt_y = S(WL_S_TGT_Y, e), tgt_h = S(WL_S_TGT_H, e), cmd_timer = S(WL_S_CMD_TIMER, e);
+        float tgt_x = S.ld(WL_S_TGT_X, e), tgt_y = S.ld(WL_S_TGT_Y, e), tgt_h = S.ld(WL_S_TGT_H, e), cmd_timer = S.ld(WL_S_CMD_TIMER, e);
         if (terminated || truncated) {
             if (lead) {
 #pragma unroll
@@ -208,32 +208,32 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
         }
         if constexpr (LANES == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) S(WL_S_WHEEL_BL + i, e) = s.wheel[i];
+            for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, s.wheel[i]);
         } else {
-            S(WL_S_WHEEL_BL + wid, e) = s.wheel[0];
+            S.st(WL_S_WHEEL_BL + wid, e, s.wheel[0]);
         }
         if (lead) {
             st3(S, WL_S_PX, e, pos);
-            S(WL_S_QW, e) = s.q.w;
-            S(WL_S_QX, e) = s.q.x;
-            S(WL_S_QY, e) = s.q.y;
-            S(WL_S_QZ, e) = s.q.z;
+            S.st(WL_S_QW, e, s.q.w);
+            S.st(WL_S_QX, e, s.q.x);
+            S.st(WL_S_QY, e, s.q.y);
+            S.st(WL_S_QZ, e, s.q.z);
             st3(S, WL_S_VX, e, s.v);
             st3(S, WL_S_WX, e, ww);
-            S(WL_S_STEER_POS, e) = s.th;
-            S(WL_S_STEER_VEL, e) = s.om;
-            S(WL_S_ACT0, e) = a0;
-            S(WL_S_ACT1, e) = a1;
+            S.st(WL_S_STEER_POS, e, s.th);
+            S.st(WL_S_STEER_VEL, e, s.om);
+            S.st(WL_S_ACT0, e, a0);
+            S.st(WL_S_ACT1, e, a1);
             if (p.log_episode_sums) {
     #pragma unroll
-                for (int i = 0; i < WL_ER_NTERMS; ++i) S(WL_S_EPSUM0 + i, e) = epsum[i];
+                for (int i = 0; i < WL_ER_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
             }
-            S(WL_S_CMD_BX, e) = cbx;
-            S(WL_S_CMD_BY, e) = cby;
-            S(WL_S_TGT_X, e) = tgt_x;
-            S(WL_S_TGT_Y, e) = tgt_y;
-            S(WL_S_TGT_H, e) = tgt_h;
-            S(WL_S_CMD_TIMER, e) = cmd_timer;
+            S.st(WL_S_CMD_BX, e, cbx);
+            S.st(WL_S_CMD_BY, e, cby);
+            S.st(WL_S_TGT_X, e, tgt_x);
+            S.st(WL_S_TGT_Y, e, tgt_y);
+            S.st(WL_S_TGT_H, e, tgt_h);
+            S.st(WL_S_CMD_TIMER, e, cmd_timer);
             b.episode_len[e] = ep_len;
         }
     }
@@ -250,16 +250,16 @@ __global__ void __launch_bounds__(kBlock) elev_obs_kernel(const WlElevParams p, 
                                                           float* __restrict__ obs) {
     __shared__ float prop[16];
     const int e = blockIdx.x;
-    const Rows S{b.state, b.stride};
-    const float px = S(WL_S_PX, e), py = S(WL_S_PY, e), pz = S(WL_S_PZ, e);
-    const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+    const Rows S = make_rows(b.state, b.stride);
+    const float px = S.ld(WL_S_PX, e), py = S.ld(WL_S_PY, e), pz = S.ld(WL_S_PZ, e);
+    const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
     // the 13 proprioceptive values are one lane's work (2 atan2 + asin): give them to the LAST lane of the block,
     // whose wave has the fewest rays (676 = 2 x 256 + 164), so they overlap with the other waves' ray casting
     if (threadIdx.x == kBlock - 1) {
         const Mat3 R = mat_from_quat(q);
         const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
         const V3 eu = euler_xyz_from_quat(q);
-        const float gx = S(WL_S_CMD_BX, e) - px, gy = S(WL_S_CMD_BY, e) - py;
+        const float gx = S.ld(WL_S_CMD_BX, e) - px, gy = S.ld(WL_S_CMD_BY, e) - py;
         prop[0] = gx != gx ? 0.f : gx;   // nan_to_num(nan=0) (:55); +-inf are left to the policy as in the reference
         prop[1] = gy != gy ? 0.f : gy;
         prop[2] = eu.x;
@@ -271,8 +271,8 @@ __global__ void __launch_bounds__(kBlock) elev_obs_kernel(const WlElevParams p, 
         prop[8] = clampf(wb.x, -p.obs_clip, p.obs_clip);
         prop[9] = clampf(wb.y, -p.obs_clip, p.obs_clip);
         prop[10] = clampf(wb.z, -p.obs_clip, p.obs_clip);
-        prop[11] = clampf(S(WL_S_ACT0, e), -1.f, 1.f);
-        prop[12] = clampf(S(WL_S_ACT1, e), -1.f, 1.f);
+        prop[11] = clampf(S.ld(WL_S_ACT0, e), -1.f, 1.f);
+        prop[12] = clampf(S.ld(WL_S_ACT1, e), -1.f, 1.f);
     }
     float c, s;
     yaw_cs(q, c, s);
@@ -299,28 +299,28 @@ __global__ void __launch_bounds__(kBlock) elev_reset_kernel(const WlElevParams p
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= b.n_envs) return;
     if (mask && !mask[e]) return;
-    const Rows S{b.state, b.stride};
+    const Rows S = make_rows(b.state, b.stride);
     const ElevReset rd = draw_elev_reset(p, ground, (uint32_t)(b.env_offset + e), step, seed);
     st3(S, WL_S_PX, e, rd.pos);
-    S(WL_S_QW, e) = rd.q.w;
-    S(WL_S_QX, e) = rd.q.x;
-    S(WL_S_QY, e) = rd.q.y;
-    S(WL_S_QZ, e) = rd.q.z;
+    S.st(WL_S_QW, e, rd.q.w);
+    S.st(WL_S_QX, e, rd.q.x);
+    S.st(WL_S_QY, e, rd.q.y);
+    S.st(WL_S_QZ, e, rd.q.z);
     st3(S, WL_S_VX, e, v3(rd.vx, rd.vy, 0.f));
     st3(S, WL_S_WX, e, v3(0.f, 0.f, 0.f));
-    S(WL_S_ACT0, e) = 0.f;
-    S(WL_S_ACT1, e) = 0.f;
+    S.st(WL_S_ACT0, e, 0.f);
+    S.st(WL_S_ACT1, e, 0.f);
 #pragma unroll
-    for (int i = 0; i < WL_MAX_REW_TERMS; ++i) S(WL_S_EPSUM0 + i, e) = 0.f;
-    S(WL_S_TGT_X, e) = rd.tgt_x;
-    S(WL_S_TGT_Y, e) = rd.tgt_y;
-    S(WL_S_TGT_H, e) = rd.tgt_h;
-    S(WL_S_CMD_TIMER, e) = p.cmd_resample_s;
+    for (int i = 0; i < WL_MAX_REW_TERMS; ++i) S.st(WL_S_EPSUM0 + i, e, 0.f);
+    S.st(WL_S_TGT_X, e, rd.tgt_x);
+    S.st(WL_S_TGT_Y, e, rd.tgt_y);
+    S.st(WL_S_TGT_H, e, rd.tgt_h);
+    S.st(WL_S_CMD_TIMER, e, p.cmd_resample_s);
     float c, sn;
     yaw_cs(rd.q, c, sn);
     const float dx = rd.tgt_x - rd.pos.x, dy = rd.tgt_y - rd.pos.y;
-    S(WL_S_CMD_BX, e) = fmaf(c, dx, sn * dy);
-    S(WL_S_CMD_BY, e) = fmaf(-sn, dx, c * dy);
+    S.st(WL_S_CMD_BX, e, fmaf(c, dx, sn * dy));
+    S.st(WL_S_CMD_BY, e, fmaf(-sn, dx, c * dy));
     b.episode_len[e] = 0;
 }
 

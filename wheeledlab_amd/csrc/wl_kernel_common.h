@@ -10,17 +10,30 @@ namespace {
 
 constexpr int kBlock = 256;
 
-struct Rows {  // row accessor of the SoA state matrix
-    float* base;
-    int64_t stride;
-    WL_DEV float& operator()(int row, int env) const { return base[row * stride + env]; }
+// Row accessor of the SoA state matrix through a buffer resource: every access is `buffer_load/store_dword` with ONE
+// per-lane byte offset (4 * env, a single VGPR for the whole kernel) and a scalar row offset (row * stride * 4, SALU).
+// With flat `global_*` addressing the compiler materialises a 64-bit VGPR address per row and keeps ~40 of them live
+// across the physics loop; the buffer form removes ~80 VGPRs and the 64-bit address arithmetic.
+struct Rows {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int row_bytes;   // stride * 4
+    WL_DEV float ld(int row, int env) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, env * 4, row * row_bytes, 0));
+    }
+    WL_DEV void st(int row, int env, float v) const {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, env * 4, row * row_bytes, 0);
+    }
 };
+WL_DEV Rows make_rows(float* base, int64_t stride) {
+    // dword3 0x00020000: raw 32-bit data format on gfx90a / gfx94x / gfx950; num_records bounds the whole matrix
+    return Rows{__builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(stride * 4 * WL_S_COUNT), 0x00020000), (int)(stride * 4)};
+}
 
-WL_DEV V3 ld3(const Rows& s, int row, int e) { return v3(s(row, e), s(row + 1, e), s(row + 2, e)); }
+WL_DEV V3 ld3(const Rows& s, int row, int e) { return v3(s.ld(row, e), s.ld(row + 1, e), s.ld(row + 2, e)); }
 WL_DEV void st3(const Rows& s, int row, int e, V3 v) {
-    s(row, e) = v.x;
-    s(row + 1, e) = v.y;
-    s(row + 2, e) = v.z;
+    s.st(row, e, v.x);
+    s.st(row + 1, e, v.y);
+    s.st(row + 2, e, v.z);
 }
 
 inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }

@@ -199,6 +199,29 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
     sincos_fast(s.th, sn, cs);   // |th| <= tan(0.488) rad: hardware sin/cos, ~1e-6 abs
     V3 F = v3(0.f, 0.f, 0.f), T = v3(0.f, 0.f, 0.f);
     if constexpr (LANES == 1) {
+#ifndef WL_UNROLLED_WHEELS
+        // rolled wheel loop (default; -DWL_UNROLLED_WHEELS restores the 4x inlined form: 140 vs 121 VGPRs, 3 vs 4 waves/SIMD): one wheel's temporaries live at a time and the loop body is a quarter of the code; the
+        // loop counter is scalar, so picking the wheel's spin / target is a handful of s_cselect-driven moves
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const bool front = i >= 2, left = (i & 1) == 0;
+            const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;
+            const float cx = s.x.x + fmaf(R.r0.x, bx, fmaf(R.r0.y, by, R.r0.z * vd.zrel));
+            const float cy = s.x.y + fmaf(R.r1.x, bx, fmaf(R.r1.y, by, R.r1.z * vd.zrel));
+            float zg;
+            V3 n, Fi, Ti;
+            ground.sample(cx, cy, zg, n);
+            float w = i == 0 ? s.wheel[0] : i == 1 ? s.wheel[1] : i == 2 ? s.wheel[2] : s.wheel[3];
+            const float wt = i == 0 ? ec.wheel_target[0] : i == 1 ? ec.wheel_target[1] : i == 2 ? ec.wheel_target[2] : ec.wheel_target[3];
+            wheel_force(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, wt, w, Fi, Ti);
+            s.wheel[0] = i == 0 ? w : s.wheel[0];
+            s.wheel[1] = i == 1 ? w : s.wheel[1];
+            s.wheel[2] = i == 2 ? w : s.wheel[2];
+            s.wheel[3] = i == 3 ? w : s.wheel[3];
+            F = F + Fi;
+            T = T + Ti;
+        }
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool front = i >= 2, left = (i & 1) == 0;
@@ -212,6 +235,7 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
             F = F + Fi;
             T = T + Ti;
         }
+#endif
     } else {
         const bool front = wid >= 2, left = (wid & 1) == 0;
         const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
     if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
         b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
     __syncthreads();
-    const Rows S{b.state, b.stride};
+    const Rows S = make_rows(b.state, b.stride);
     const WlVehicleParams& vp = p.vehicle;
     if (e < b.n_envs) {
         const uint32_t gid = (uint32_t)(b.env_offset + e);
@@ -96,23 +96,23 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
         process_action(p.action, a.x, a.y, v_t, delta);
         EnvConst ec;
         joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-        env_const_mass(ec, vp, vd, S(WL_S_MASS, e));
-        ec.mu_s = S(WL_S_MU_S, e) * vp.ground_mu_s;
-        ec.mu_d = fminf(S(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
-        ec.damp = S(WL_S_DAMP, e);
+        env_const_mass(ec, vp, vd, S.ld(WL_S_MASS, e));
+        ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
+        ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
+        ec.damp = S.ld(WL_S_DAMP, e);
         VehState s;
         V3 pos = ld3(S, WL_S_PX, e);
-        s.q = Quat{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+        s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
         s.v = ld3(S, WL_S_VX, e);
         V3 ww = ld3(S, WL_S_WX, e);
         if constexpr (LANES == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s.wheel[i] = S(WL_S_WHEEL_BL + i, e);
+            for (int i = 0; i < 4; ++i) s.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
         } else {
-            s.wheel[0] = S(WL_S_WHEEL_BL + wid, e);
+            s.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
         }
-        s.th = S(WL_S_STEER_POS, e);
-        s.om = S(WL_S_STEER_VEL, e);
+        s.th = S.ld(WL_S_STEER_POS, e);
+        s.om = S.ld(WL_S_STEER_VEL, e);
         {
             const Mat3 R = mat_from_quat(s.q);
             s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
             const float w = p.weight[i];
             const float c = (w != 0.f && finite) ? t[i] * w * step_dt : 0.f;
             reward += c;
-            epsum[i] = p.log_episode_sums ? S(WL_S_EPSUM0 + i, e) + c : 0.f;
+            epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;
         }
         if (lead) {
             out.reward[e] = reward;
@@ -181,25 +181,25 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
         }
         if constexpr (LANES == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) S(WL_S_WHEEL_BL + i, e) = s.wheel[i];
+            for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, s.wheel[i]);
         } else {
-            S(WL_S_WHEEL_BL + wid, e) = s.wheel[0];
+            S.st(WL_S_WHEEL_BL + wid, e, s.wheel[0]);
         }
         if (lead) {
             st3(S, WL_S_PX, e, pos);
-            S(WL_S_QW, e) = s.q.w;
-            S(WL_S_QX, e) = s.q.x;
-            S(WL_S_QY, e) = s.q.y;
-            S(WL_S_QZ, e) = s.q.z;
+            S.st(WL_S_QW, e, s.q.w);
+            S.st(WL_S_QX, e, s.q.x);
+            S.st(WL_S_QY, e, s.q.y);
+            S.st(WL_S_QZ, e, s.q.z);
             st3(S, WL_S_VX, e, s.v);
             st3(S, WL_S_WX, e, ww);
-            S(WL_S_STEER_POS, e) = s.th;
-            S(WL_S_STEER_VEL, e) = s.om;
-            S(WL_S_ACT0, e) = a0;
-            S(WL_S_ACT1, e) = a1;
+            S.st(WL_S_STEER_POS, e, s.th);
+            S.st(WL_S_STEER_VEL, e, s.om);
+            S.st(WL_S_ACT0, e, a0);
+            S.st(WL_S_ACT1, e, a1);
             if (p.log_episode_sums) {
     #pragma unroll
-                for (int i = 0; i < WL_VR_NTERMS; ++i) S(WL_S_EPSUM0 + i, e) = epsum[i];
+                for (int i = 0; i < WL_VR_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
             }
             b.episode_len[e] = ep_len;
         }
@@ -238,9 +238,9 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
     __shared__ float tmp[kImgH * kImgW];
     __shared__ float red[kBlock / 64];
     const int e = blockIdx.x;
-    const Rows S{b.state, b.stride};
+    const Rows S = make_rows(b.state, b.stride);
     const V3 pos = ld3(S, WL_S_PX, e);
-    const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+    const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
     const Mat3 R = mat_from_quat(q);
     const V3 o = pos + mul(R, v3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
     const MapFast mf = map_fast(m);
@@ -252,8 +252,8 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
         float* t = row + WL_VIS_NPIX;
         t[0] = vb.x; t[1] = vb.y; t[2] = vb.z;
         t[3] = wb.x; t[4] = wb.y; t[5] = wb.z;
-        t[6] = clampf(S(WL_S_ACT0, e), -1.f, 1.f);
-        t[7] = clampf(S(WL_S_ACT1, e), -1.f, 1.f);
+        t[6] = clampf(S.ld(WL_S_ACT0, e), -1.f, 1.f);
+        t[7] = clampf(S.ld(WL_S_ACT1, e), -1.f, 1.f);
     }
     // ---- render: one ray per pixel against the z = 0 plane.  d = R (1, dy(col), dz(row)) ----
     const V3 c0 = v3(R.r0.x, R.r1.x, R.r2.x), c1 = v3(R.r0.y, R.r1.y, R.r2.y), c2 = v3(R.r0.z, R.r1.z, R.r2.z);
@@ -321,19 +321,19 @@ __global__ void __launch_bounds__(kBlock) visual_reset_kernel(const WlVisualPara
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= b.n_envs) return;
     if (mask && !mask[e]) return;
-    const Rows S{b.state, b.stride};
+    const Rows S = make_rows(b.state, b.stride);
     const VisReset rd = draw_visual_reset(p, m, (uint32_t)(b.env_offset + e), step, seed);
     st3(S, WL_S_PX, e, rd.pos);
-    S(WL_S_QW, e) = rd.q.w;
-    S(WL_S_QX, e) = rd.q.x;
-    S(WL_S_QY, e) = rd.q.y;
-    S(WL_S_QZ, e) = rd.q.z;
+    S.st(WL_S_QW, e, rd.q.w);
+    S.st(WL_S_QX, e, rd.q.x);
+    S.st(WL_S_QY, e, rd.q.y);
+    S.st(WL_S_QZ, e, rd.q.z);
     st3(S, WL_S_VX, e, v3(0.f, 0.f, 0.f));
     st3(S, WL_S_WX, e, v3(0.f, 0.f, 0.f));
-    S(WL_S_ACT0, e) = 0.f;
-    S(WL_S_ACT1, e) = 0.f;
+    S.st(WL_S_ACT0, e, 0.f);
+    S.st(WL_S_ACT1, e, 0.f);
 #pragma unroll
-    for (int i = 0; i < WL_MAX_REW_TERMS; ++i) S(WL_S_EPSUM0 + i, e) = 0.f;
+    for (int i = 0; i < WL_MAX_REW_TERMS; ++i) S.st(WL_S_EPSUM0 + i, e, 0.f);
     b.episode_len[e] = 0;
 }
 
@@ -358,9 +358,9 @@ __global__ void __launch_bounds__(kBlock) visual_mdp_kernel(const WlVisualParams
 __global__ void __launch_bounds__(kBlock) visual_depth_kernel(const WlVisualParams p, const WlEnvBuffers b, const HeightFieldGround g,
                                                               float max_depth, float* __restrict__ depth) {
     const int e = blockIdx.x;
-    const Rows S{b.state, b.stride};
+    const Rows S = make_rows(b.state, b.stride);
     const V3 pos = ld3(S, WL_S_PX, e);
-    const Quat q{S(WL_S_QW, e), S(WL_S_QX, e), S(WL_S_QY, e), S(WL_S_QZ, e)};
+    const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
     const Mat3 R = mat_from_quat(q);
     const V3 o = pos + mul(R, v3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
     for (int k = threadIdx.x; k < WL_VIS_IMG_H * WL_VIS_IMG_W; k += kBlock) {
