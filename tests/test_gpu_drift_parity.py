@@ -106,7 +106,8 @@ def test_action_map_matches_reference_golden(lib, golden):
         assert lib.wl_action_map(C.byref(ap), n, a.data_ptr(), proc.data_ptr(), st.data_ptr(), wh.data_ptr(), None) == 0
         torch.cuda.synchronize()
         np.testing.assert_allclose(proc.cpu().numpy(), g[f"{tag}_processed"], rtol=1e-6, atol=1e-6)
-        np.testing.assert_allclose(st.cpu().numpy(), g[f"{tag}_steer_pos_target"], rtol=2e-6, atol=2e-6)
+        # tan(delta) comes from the hardware sin / cos units (bounded steering angle): 5e-6 abs
+        np.testing.assert_allclose(st.cpu().numpy(), g[f"{tag}_steer_pos_target"], rtol=5e-6, atol=5e-6)
         w = wh.cpu().numpy()
         if tag == "rwd":
             np.testing.assert_allclose(w[:, :2], g["rwd_wheel_vel_target"], rtol=1e-6, atol=1e-5)

@@ -59,8 +59,12 @@ WL_DEV void write_obs_row(float* row, const WlDriftParams& p, V3 pos, Quat q, V3
     row[13] = clampf(a1, -1.f, 1.f);
 }
 
+// LANES == 4: lanes 0..2 of the quad each draw ONE Philox block (4 normals) and the 12 values are gathered with DPP
+// quad broadcasts -- one Philox + two Box-Muller on the critical path instead of three + six.  Must be called by all
+// four lanes of the quad.
+template <int LANES>
 WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise, int64_t stride, int e, uint32_t gid,
-                         uint64_t step, uint64_t seed) {
+                         uint64_t step, uint64_t seed, int wid = 0) {
     Noise12 nz;
     if (!p.enable_corruption) {
 #pragma unroll
@@ -68,6 +72,14 @@ WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise
     } else if (noise) {   // parity mode: caller-supplied standard normals [12][stride]
 #pragma unroll
         for (int k = 0; k < 12; ++k) nz.z[k] = noise[k * stride + e];
+    } else if constexpr (LANES == 4) {
+        const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + (uint32_t)min(wid, 2), seed);
+        float z0, z1, z2, z3;
+        box_muller(u.x, u.y, z0, z1);
+        box_muller(u.z, u.w, z2, z3);
+        nz.z[0] = quad_bcast<0>(z0); nz.z[1] = quad_bcast<0>(z1); nz.z[2] = quad_bcast<0>(z2); nz.z[3] = quad_bcast<0>(z3);
+        nz.z[4] = quad_bcast<1>(z0); nz.z[5] = quad_bcast<1>(z1); nz.z[6] = quad_bcast<1>(z2); nz.z[7] = quad_bcast<1>(z3);
+        nz.z[8] = quad_bcast<2>(z0); nz.z[9] = quad_bcast<2>(z1); nz.z[10] = quad_bcast<2>(z2); nz.z[11] = quad_bcast<2>(z3);
     } else {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -149,6 +161,12 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
             s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);  // CoM = link origin + R (0,0,cg_z)
             s.wb = mul_t(R, ww);
         }
+        // quad form has registers to spare: fetch the episode-sum rows now so their latency hides behind the physics
+        float epsum_in[WL_DR_NTERMS];
+        if constexpr (LANES == 4) {
+#pragma unroll
+            for (int i = 0; i < WL_DR_NTERMS; ++i) epsum_in[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) : 0.f;
+        }
         // ---- physics: decimation x substeps, everything in registers ----
         for (int k = 0; k < vd.n_sub; ++k) vehicle_substep<LANES>(vp, vd, ec, s, ground, wid);
 #ifdef WL_LATE_LOADS
@@ -182,7 +200,8 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
             const float w = p.weight[i];
             const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;  // RewardManager skips w == 0
             reward += c;
-            epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;
+            if constexpr (LANES == 4) epsum[i] = epsum_in[i] + c;
+            else epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;
         }
         if (lead) {
             out.reward[e] = reward;
@@ -268,10 +287,8 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         const Mat3 R2 = mat_from_quat(s.q);
         vb = mul_t(R2, s.v);
         const V3 wb2 = mul_t(R2, ww);
-        if (lead) {
-            const Noise12 nz = obs_noise(p, noise, b.stride, e, gid, step, seed);
-            write_obs_row(&tile[le * kObsPad], p, pos, s.q, vb, wb2, a0, a1, nz);
-        }
+        const Noise12 nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // all lanes of the quad
+        if (lead) write_obs_row(&tile[le * kObsPad], p, pos, s.q, vb, wb2, a0, a1, nz);
     }
     __syncthreads();
     flush_obs(tile, out.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
@@ -367,7 +384,7 @@ __global__ void __launch_bounds__(kBlock) drift_observe_kernel(const WlDriftPara
         const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
         const Mat3 R = mat_from_quat(q);
         const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
-        const Noise12 nz = obs_noise(p, noise, b.stride, e, (uint32_t)(b.env_offset + e), step, seed);
+        const Noise12 nz = obs_noise<1>(p, noise, b.stride, e, (uint32_t)(b.env_offset + e), step, seed);
         write_obs_row(&tile[threadIdx.x * kObsPad], p, ld3(S, WL_S_PX, e), q, vb, wb, S.ld(WL_S_ACT0, e), S.ld(WL_S_ACT1, e), nz);
     }
     __syncthreads();

@@ -30,7 +30,7 @@ WL_DEV void process_action(const WlActionParams& ap, float& a0, float& a1, float
 // (wheeledlab/envs/mdp/actions/rc_car_actions.py:12-29, 36-64): steer joint target = tan(delta);
 // wheel velocity targets in order bl, br, fl, fr.
 WL_DEV void joint_targets(const WlActionParams& ap, float v, float delta, float& steer, float w[4]) {
-    const float t = tanf(delta);
+    const float t = tan_fast(delta);   // hardware sin/cos: |delta| <= scale[1] (0.488 rad), abs error ~1e-6
     steer = t;
     const float inv_r = 1.f / ap.wheel_radius;
     if (ap.map == 0) {

@@ -28,6 +28,12 @@ WL_DEV void sincos_rev(float rev, float& s, float& c) {
     c = __builtin_amdgcn_cosf(rev);
 }
 WL_DEV void sincos_fast(float rad, float& s, float& c) { sincos_rev(rad * WL_INV_TWO_PI, s, c); }
+// tan of a bounded steering angle (|x| <= 0.5 rad in every registered task) from the hardware sin / cos
+WL_DEV float tan_fast(float rad) {
+    float s, c;
+    sincos_fast(rad, s, c);
+    return s * __builtin_amdgcn_rcpf(c);
+}
 WL_DEV float log_fast(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }  // v_log_f32 is log2
 
 struct Quat {
