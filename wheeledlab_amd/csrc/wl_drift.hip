@@ -24,6 +24,7 @@ constexpr int kObsPad = 15;  // odd LDS row pitch: the transposing writes are ba
 struct ResetDraw {
     V3 pos;
     Quat q;
+    float yaw;   // the drawn yaw (rad, unwrapped): roll = pitch = 0, so the reset pose's Euler angles are (0, 0, yaw)
     float timer_hf, timer_lf;
 };
 
@@ -38,6 +39,7 @@ WL_DEV ResetDraw draw_reset(const WlDriftParams& p, const float* __restrict__ re
     float s, c;
     sincos_fast(0.5f * yaw, s, c);
     r.q = Quat{c, 0.f, 0.f, s};
+    r.yaw = yaw;
     const F4 t = philox_uniform4(gid, step, WL_RS_TIMERS, seed);
     r.timer_hf = fmaf(t.x, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
     r.timer_lf = fmaf(t.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
@@ -49,9 +51,8 @@ struct Noise12 {
     float z[12];
 };
 
-WL_DEV void write_obs_row(float* row, const WlDriftParams& p, V3 pos, Quat q, V3 vb, V3 wb, float a0, float a1,
-                          const Noise12& nz /* 12 standard normals (zeros when corruption is off) */) {
-    const V3 e = euler_xyz_from_quat(q);
+WL_DEV void write_obs_row(float* row, const WlDriftParams& p, V3 pos, V3 e /* euler xyz, wrapped */, V3 vb, V3 wb, float a0,
+                          float a1, const Noise12& nz /* 12 standard normals (zeros when corruption is off) */) {
     const float o[12] = {pos.x, pos.y, pos.z, e.x, e.y, e.z, vb.x, vb.y, vb.z, wb.x, wb.y, wb.z};
 #pragma unroll
     for (int k = 0; k < 12; ++k) row[k] = fmaf(p.noise_std[k / 3], nz.z[k], o[k]);
@@ -191,7 +192,23 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         const bool terminated = !finite || cart_off_track(pos.x, pos.y, p.straight, p.r_in, p.r_out);
         // ---- rewards on the post-physics state ----
         V3 vb = mul_t(R, s.v);
-        DriftTerms tm = drift_terms(p, pos, vb, s.wb, ww.z, s.th, terminated, truncated);
+        // side-slip angle and the three Euler angles are four atan2s (asin(x) == atan2(x, sqrt(1 - x^2))): the quad form
+        // evaluates them as ONE atan2 with per-lane arguments and DPP-broadcasts the results
+        float slip_angle;
+        V3 euler;
+        if constexpr (LANES == 4) {
+            const Quat q = s.q;
+            const float sp = 2.f * (q.w * q.y - q.z * q.x);
+            const float ay = wid == 0 ? vb.y : wid == 1 ? 2.f * (q.w * q.x + q.y * q.z) : wid == 2 ? sp : 2.f * (q.w * q.z + q.x * q.y);
+            const float ax = wid == 0 ? vb.x : wid == 1 ? 1.f - 2.f * (q.x * q.x + q.y * q.y)
+                           : wid == 2 ? fsqrt(fmaxf(1.f - sp * sp, 0.f)) : 1.f - 2.f * (q.y * q.y + q.z * q.z);
+            const float ang = atan2f(ay, ax);
+            slip_angle = quad_bcast<0>(ang);
+            euler = v3(wrap_2pi(quad_bcast<1>(ang)), wrap_2pi(quad_bcast<2>(ang)), wrap_2pi(quad_bcast<3>(ang)));
+        } else {
+            slip_angle = atan2f(vb.y, vb.x);
+        }
+        DriftTerms tm = drift_terms(p, pos, vb, s.wb, ww.z, s.th, terminated, truncated, slip_angle);
         const float step_dt = p.sim_dt * (float)p.decimation;
         float reward = 0.f;
         float epsum[WL_DR_NTERMS];
@@ -232,6 +249,7 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
             const ResetDraw rd = draw_reset(p, b.ref_poses, gid, step, seed);
             pos = rd.pos;
             s.q = rd.q;
+            if constexpr (LANES == 4) euler = v3(0.f, 0.f, rd.yaw - WL_TWO_PI * floorf(rd.yaw * WL_INV_TWO_PI));
             s.v = v3(0.f, 0.f, 0.f);
             ww = v3(0.f, 0.f, 0.f);
             timer_hf = rd.timer_hf;
@@ -288,7 +306,8 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         vb = mul_t(R2, s.v);
         const V3 wb2 = mul_t(R2, ww);
         const Noise12 nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // all lanes of the quad
-        if (lead) write_obs_row(&tile[le * kObsPad], p, pos, s.q, vb, wb2, a0, a1, nz);
+        if constexpr (LANES == 1) euler = euler_xyz_from_quat(s.q);
+        if (lead) write_obs_row(&tile[le * kObsPad], p, pos, euler, vb, wb2, a0, a1, nz);
     }
     __syncthreads();
     flush_obs(tile, out.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
@@ -318,7 +337,7 @@ __global__ void __launch_bounds__(kBlock) drift_mdp_kernel(const WlDriftParams p
         const float sm = 0.5f * (steer[e] + steer[stride + e]);
         const bool to = timed_out ? timed_out[e] != 0 : false;
         const bool term = cart_off_track(P.x, P.y, p.straight, p.r_in, p.r_out);
-        const DriftTerms tm = drift_terms(p, P, vb, wb, wwz, sm, term, to);
+        const DriftTerms tm = drift_terms(p, P, vb, wb, wwz, sm, term, to, atan2f(vb.y, vb.x));
         const float step_dt = p.sim_dt * (float)p.decimation;
         float r = 0.f;
 #pragma unroll
@@ -331,7 +350,7 @@ __global__ void __launch_bounds__(kBlock) drift_mdp_kernel(const WlDriftParams p
         Noise12 zero;
 #pragma unroll
         for (int k = 0; k < 12; ++k) zero.z[k] = 0.f;
-        write_obs_row(&tile[threadIdx.x * kObsPad], p, P, q, vb, wb, act[e], act[stride + e], zero);
+        write_obs_row(&tile[threadIdx.x * kObsPad], p, P, euler_xyz_from_quat(q), vb, wb, act[e], act[stride + e], zero);
     }
     __syncthreads();
     flush_obs(tile, obs, blockIdx.x * kBlock, n);
@@ -385,7 +404,8 @@ __global__ void __launch_bounds__(kBlock) drift_observe_kernel(const WlDriftPara
         const Mat3 R = mat_from_quat(q);
         const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
         const Noise12 nz = obs_noise<1>(p, noise, b.stride, e, (uint32_t)(b.env_offset + e), step, seed);
-        write_obs_row(&tile[threadIdx.x * kObsPad], p, ld3(S, WL_S_PX, e), q, vb, wb, S.ld(WL_S_ACT0, e), S.ld(WL_S_ACT1, e), nz);
+        write_obs_row(&tile[threadIdx.x * kObsPad], p, ld3(S, WL_S_PX, e), euler_xyz_from_quat(q), vb, wb, S.ld(WL_S_ACT0, e),
+                      S.ld(WL_S_ACT1, e), nz);
     }
     __syncthreads();
     flush_obs(tile, obs, blockIdx.x * kBlock, b.n_envs);

@@ -59,10 +59,14 @@ WL_DEV bool cart_off_track(float x, float y, float straight, float r_in, float r
 
 // ---- rewards ------------------------------------------------------------------------------------------------
 // side_slip (:219-230)
-WL_DEV float side_slip(V3 vb, float min_thresh, float max_thresh, float min_vel_x) {
-    float ang = fabsf(atan2f(vb.y, vb.x));
-    if (fabsf(vb.x) < min_vel_x || ang > max_thresh) ang = 0.f;
+// `slip_angle` = atan2(v_by, v_bx), passed in so that the quad kernels can batch it with the Euler-angle atan2s
+WL_DEV float side_slip_from_angle(float slip_angle, float vbx, float min_thresh, float max_thresh, float min_vel_x) {
+    float ang = fabsf(slip_angle);
+    if (fabsf(vbx) < min_vel_x || ang > max_thresh) ang = 0.f;
     return ang < min_thresh ? 0.f : ang;
+}
+WL_DEV float side_slip(V3 vb, float min_thresh, float max_thresh, float min_vel_x) {
+    return side_slip_from_angle(atan2f(vb.y, vb.x), vb.x, min_thresh, max_thresh, min_vel_x);
 }
 // vel_dist (:167-171)
 WL_DEV float vel_dist(V3 vb, float target, float offset) {
@@ -95,9 +99,9 @@ struct DriftTerms {
 // all 7 unweighted reward terms (DriftRewardsCfg :246-299); is_terminated_term is IsaacLab's
 // (terminated by a non-time-out term) * (not timed out)
 WL_DEV DriftTerms drift_terms(const WlDriftParams& p, V3 pos, V3 vb, V3 wb, float wwz, float steer_mean, bool terminated,
-                              bool timed_out) {
+                              bool timed_out, float slip_angle) {
     DriftTerms r;
-    r.t[WL_DR_SIDE_SLIP] = side_slip(vb, p.slip_min, p.slip_max, p.slip_min_vx);
+    r.t[WL_DR_SIDE_SLIP] = side_slip_from_angle(slip_angle, vb.x, p.slip_min, p.slip_max, p.slip_min_vx);
     r.t[WL_DR_VEL] = vel_dist(vb, p.speed_target, p.speed_offset);
     r.t[WL_DR_PROGRESS] = wwz;   // track_progress_rate (:160-165): world-frame yaw rate of the root link
     r.t[WL_DR_TLGR] = turn_left_go_right(steer_mean, wb.z, p.tlgr_thresh);
