@@ -172,6 +172,26 @@ def main():
     achieved = BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
     traffic, traffic_src = pmc_traffic(n)
 
+    # secondary: the same workload driven step by step through the drop-in Python surface
+    # (registry.make -> ClipAction -> RslRlVecEnvWrapper.step), i.e. what a Python RL loop sees per env.step() call
+    py_rate = None
+    if rank == 0:
+        from wheeledlab_amd import registry, tasks  # noqa: F401
+        from wheeledlab_amd.rl import ClipAction, RslRlVecEnvWrapper
+        cfg = registry.parse_env_cfg("Isaac-MushrDriftRL-v0", device=str(dev), num_envs=n)
+        e = registry.make("Isaac-MushrDriftRL-v0", cfg=cfg)
+        e.action_space.low, e.action_space.high = -1.0, 1.0
+        w = RslRlVecEnvWrapper(ClipAction(e))
+        for i in range(64):
+            w.step(actions[i % ROLLOUT])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(1024):
+            w.step(actions[i % ROLLOUT])
+        torch.cuda.synchronize()
+        py_rate = n * 1024 / (time.perf_counter() - t1)
+        del w, e
+
     sweep = []
     if args.sweep and rank == 0:
         for big in (65536, 1048576, 4194304):
@@ -214,6 +234,7 @@ def main():
             "episode_metrics": {"resets": float(metric_sum[8]), "timeouts": float(metric_sum[9]),
                                 "out_of_bounds": float(metric_sum[10]), "nonfinite": float(metric_sum[14])},
         }
+        line["python_surface_env_steps_per_s"] = py_rate
         if sweep:
             line["large_n_sweep"] = sweep
         if world == 1 and not args.no_cpu_baseline:
