@@ -175,7 +175,7 @@ def main():
     # secondary: the same workload driven step by step through the drop-in Python surface
     # (registry.make -> ClipAction -> RslRlVecEnvWrapper.step), i.e. what a Python RL loop sees per env.step() call
     py_rate = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         from wheeledlab_amd import registry, tasks  # noqa: F401
         from wheeledlab_amd.rl import ClipAction, RslRlVecEnvWrapper
         cfg = registry.parse_env_cfg("Isaac-MushrDriftRL-v0", device=str(dev), num_envs=n)

@@ -77,6 +77,42 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.wl_philox_uniform(0, 0, 0, 0, None, None) == -1
 
 
+def test_layout_of_task_structs_and_misuse_codes(tmp_path):
+    """elevation / visual parameter structs match the header; stride / alignment violations are refused before launch"""
+    probe = tmp_path / "probe2.c"
+    probe.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "wheeledlab_amd.h"\n'
+        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %d %d\\n\", sizeof(WlElevParams), sizeof(WlVisualParams),"
+        " sizeof(WlHeightField), sizeof(WlTravMap), offsetof(WlElevParams, weight), offsetof(WlVisualParams, cam_pos),"
+        " (int)WL_ELEV_OBS_DIM, (int)WL_VIS_OBS_DIM);return 0;}\n")
+    exe = tmp_path / "probe2"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [C.sizeof(A.WlElevParams), C.sizeof(A.WlVisualParams), C.sizeof(A.WlHeightField), C.sizeof(A.WlTravMap),
+            A.WlElevParams.weight.offset, A.WlVisualParams.cam_pos.offset, A.ELEV_OBS_DIM, A.VIS_OBS_DIM]
+    assert got == want
+    _ensure_built()
+    lib = A.load()
+    p = PP.drift_params()
+    buf = (C.c_float * 4096)()
+    base = C.addressof(buf)
+    out = A.WlStepOut(base, base, base, base)
+    ok_bufs = dict(state=base, episode_len=base, ref_poses=base, metrics=base)
+    bad_stride = A.WlEnvBuffers(stride=100, n_envs=100, env_offset=0, metrics_slots=1, **ok_bufs)       # stride % 64 != 0
+    assert lib.wl_drift_step(C.byref(p), C.byref(bad_stride), base, None, C.byref(out), 0, 0, None) == -3
+    misaligned = A.WlEnvBuffers(stride=128, n_envs=100, env_offset=0, metrics_slots=1, **{**ok_bufs, "state": base + 4})
+    assert lib.wl_drift_step(C.byref(p), C.byref(misaligned), base, None, C.byref(out), 0, 0, None) == -3
+    short = A.WlEnvBuffers(stride=64, n_envs=100, env_offset=0, metrics_slots=1, **ok_bufs)              # stride < n_envs
+    assert lib.wl_drift_step(C.byref(p), C.byref(short), base, None, C.byref(out), 0, 0, None) == -1
+    zero_slots = A.WlEnvBuffers(stride=128, n_envs=100, env_offset=0, metrics_slots=0, **ok_bufs)
+    assert lib.wl_drift_step(C.byref(p), C.byref(zero_slots), base, None, C.byref(out), 0, 0, None) == -1
+    p.num_ref_points = 33
+    good = A.WlEnvBuffers(stride=128, n_envs=100, env_offset=0, metrics_slots=1, **ok_bufs)
+    assert lib.wl_drift_step(C.byref(p), C.byref(good), base, None, C.byref(out), 0, 0, None) == -1      # > 32 ref poses
+    ep = PP.elev_params()
+    assert lib.wl_elev_step(C.byref(ep), C.byref(good), None, base, C.byref(out), 0, 0, None) == -1      # no heightfield
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(A.HipExtensionMissing):
         A.load(str(tmp_path / "nope.so"))
