@@ -4,9 +4,10 @@
 //   1. elev_step_kernel  (lane = env): 4WD action term -> decimation x substeps of the rigid body + 4 tyre contacts on
 //      the heightfield (bilinear height + normal gathers, L2-resident grid) -> terminations -> rewards -> in-kernel
 //      reset -> goal-command update.  State is read once / written once; sub-steps stay in VGPRs.
-//   2. elev_obs_kernel   (block = env): the 689-dim observation.  Lane 0 of the block computes the 13 proprioceptive
-//      values into LDS; all 256 threads cast the 26 x 26 yaw-aligned height rays (4 gathers each) and the row is
-//      written with contiguous dword stores -- this launch carries ~90 % of the task's HBM bytes (2.7 KB / env).
+//      The step kernel also writes the 13 proprioceptive values of the observation row.
+//   2. elev_scan_kernel  (block = env): the 26 x 26 yaw-aligned height rays (4 L2-resident gathers each), written with
+//      contiguous dword stores -- this launch carries ~90 % of the task's HBM bytes (2.7 KB / env).  (Staging the patch
+//      in LDS was measured 2x slower: the patch has 5.9 k cells, the rays read only 2.7 k corners.)
 #include <hip/hip_runtime.h>
 
 #include "../../include/wheeledlab_amd.h"
@@ -50,6 +51,39 @@ WL_DEV ElevTerms elev_terms(const WlElevParams& p, V3 pos, float up_dot, V3 vb, 
     r.t[WL_ER_FALLING] = vb.z > p.fall_vel ? 1.f : 0.f;                                               // :251-254
     r.t[WL_ER_STUCK_PENALTY] = (r.flag[WL_ET_STUCK] && !timed_out) ? 1.f : 0.f;                       // :301-305
     return r;
+}
+
+// the 13 proprioceptive observation values of ElevationObsCfg.ConcatObs (:61-73), written straight into the env's
+// observation row by the lane-per-env kernels (step / prop); the block-per-env scan kernel adds the 676 map values
+template <int LANES>
+WL_DEV void write_elev_prop(const WlElevParams& p, float* __restrict__ row, V3 pos, Quat q, V3 vb, V3 wb, float cbx, float cby,
+                            float a0, float a1, int wid, bool lead) {
+    V3 eu;
+    if constexpr (LANES == 4) {   // roll / pitch / yaw as one lane-parallel atan2 (asin x = atan2(x, sqrt(1 - x^2)))
+        const float sp = 2.f * (q.w * q.y - q.z * q.x);
+        const float ay = wid == 1 ? 2.f * (q.w * q.x + q.y * q.z) : wid == 2 ? sp : 2.f * (q.w * q.z + q.x * q.y);
+        const float ax = wid == 1 ? 1.f - 2.f * (q.x * q.x + q.y * q.y) : wid == 2 ? fsqrt(fmaxf(1.f - sp * sp, 0.f))
+                                                                                  : 1.f - 2.f * (q.y * q.y + q.z * q.z);
+        const float ang = atan2f(ay, ax);
+        eu = v3(wrap_2pi(quad_bcast<1>(ang)), wrap_2pi(quad_bcast<2>(ang)), wrap_2pi(quad_bcast<3>(ang)));
+    } else {
+        eu = euler_xyz_from_quat(q);
+    }
+    if (!lead) return;
+    const float gx = cbx - pos.x, gy = cby - pos.y;
+    row[0] = gx != gx ? 0.f : gx;   // nan_to_num(nan=0) (:55); +-inf are left to the policy as in the reference
+    row[1] = gy != gy ? 0.f : gy;
+    row[2] = eu.x;
+    row[3] = eu.y;
+    row[4] = eu.z;
+    row[5] = clampf(vb.x, -p.obs_clip, p.obs_clip);
+    row[6] = clampf(vb.y, -p.obs_clip, p.obs_clip);
+    row[7] = clampf(vb.z, -p.obs_clip, p.obs_clip);
+    row[8] = clampf(wb.x, -p.obs_clip, p.obs_clip);
+    row[9] = clampf(wb.y, -p.obs_clip, p.obs_clip);
+    row[10] = clampf(wb.z, -p.obs_clip, p.obs_clip);
+    row[11] = clampf(a0, -1.f, 1.f);
+    row[12] = clampf(a1, -1.f, 1.f);
 }
 
 struct ElevReset {
@@ -236,6 +270,10 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
             S.st(WL_S_CMD_TIMER, e, cmd_timer);
             b.episode_len[e] = ep_len;
         }
+        // proprioceptive part of the observation, from the post-reset state (all lanes of a quad take part)
+        const Mat3 R2 = mat_from_quat(s.q);
+        write_elev_prop<LANES>(p, out.obs + (int64_t)e * WL_ELEV_OBS_DIM, pos, s.q, mul_t(R2, s.v), mul_t(R2, ww), cbx, cby, a0, a1,
+                               wid, lead);
     }
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
@@ -244,42 +282,18 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
     }
 }
 
-// ElevationObsCfg.ConcatObs (:61-86): goal_rel(2) | euler(3) | v_b clip +-10 (3) | w_b clip +-10 (3) | last action clip +-1
-// (2) | world_height_map 26 x 26 clip +-10 (:44-48).  One block per env.
-__global__ void __launch_bounds__(kBlock) elev_obs_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
-                                                          float* __restrict__ obs) {
-    __shared__ float prop[16];
+// world_height_map (:44-48): the 26 x 26 yaw-aligned height scan, clipped to +-10, into obs[e][13:689].  One block per
+// env; the env's 13 proprioceptive values are written by the lane-per-env kernels (step / prop).
+__global__ void __launch_bounds__(kBlock) elev_scan_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
+                                                           float* __restrict__ obs) {
     const int e = blockIdx.x;
     const Rows S = make_rows(b.state, b.stride);
     const float px = S.ld(WL_S_PX, e), py = S.ld(WL_S_PY, e), pz = S.ld(WL_S_PZ, e);
     const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
-    // the 13 proprioceptive values are one lane's work (2 atan2 + asin): give them to the LAST lane of the block,
-    // whose wave has the fewest rays (676 = 2 x 256 + 164), so they overlap with the other waves' ray casting
-    if (threadIdx.x == kBlock - 1) {
-        const Mat3 R = mat_from_quat(q);
-        const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
-        const V3 eu = euler_xyz_from_quat(q);
-        const float gx = S.ld(WL_S_CMD_BX, e) - px, gy = S.ld(WL_S_CMD_BY, e) - py;
-        prop[0] = gx != gx ? 0.f : gx;   // nan_to_num(nan=0) (:55); +-inf are left to the policy as in the reference
-        prop[1] = gy != gy ? 0.f : gy;
-        prop[2] = eu.x;
-        prop[3] = eu.y;
-        prop[4] = eu.z;
-        prop[5] = clampf(vb.x, -p.obs_clip, p.obs_clip);
-        prop[6] = clampf(vb.y, -p.obs_clip, p.obs_clip);
-        prop[7] = clampf(vb.z, -p.obs_clip, p.obs_clip);
-        prop[8] = clampf(wb.x, -p.obs_clip, p.obs_clip);
-        prop[9] = clampf(wb.y, -p.obs_clip, p.obs_clip);
-        prop[10] = clampf(wb.z, -p.obs_clip, p.obs_clip);
-        prop[11] = clampf(S.ld(WL_S_ACT0, e), -1.f, 1.f);
-        prop[12] = clampf(S.ld(WL_S_ACT1, e), -1.f, 1.f);
-    }
     float c, s;
     yaw_cs(q, c, s);
     float* row = obs + (int64_t)e * WL_ELEV_OBS_DIM;
     const float g0 = -0.5f * p.scan_size;
-    const float base = p.scan_offset - p.elev_z0;   // -(pz - hz - off) + (pz - z0) = (hz - pz + off) + (pz - z0)
-    (void)base;
     for (int k = threadIdx.x; k < WL_ELEV_SCAN_N * WL_ELEV_SCAN_N; k += kBlock) {
         const int iy = k / WL_ELEV_SCAN_N, ix = k - iy * WL_ELEV_SCAN_N;   // meshgrid "xy": x fastest
         const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
@@ -290,8 +304,18 @@ __global__ void __launch_bounds__(kBlock) elev_obs_kernel(const WlElevParams p, 
         const float val = hit ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
         row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
     }
-    __syncthreads();
-    if (threadIdx.x < 13) row[threadIdx.x] = prop[threadIdx.x];
+}
+
+// proprioceptive part only, lane per env: used by wl_elev_observe (reset / get_observations path)
+__global__ void __launch_bounds__(kBlock) elev_prop_kernel(const WlElevParams p, const WlEnvBuffers b, float* __restrict__ obs) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= b.n_envs) return;
+    const Rows S = make_rows(b.state, b.stride);
+    const V3 pos = ld3(S, WL_S_PX, e);
+    const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+    const Mat3 R = mat_from_quat(q);
+    write_elev_prop<1>(p, obs + (int64_t)e * WL_ELEV_OBS_DIM, pos, q, mul_t(R, ld3(S, WL_S_VX, e)), mul_t(R, ld3(S, WL_S_WX, e)),
+                       S.ld(WL_S_CMD_BX, e), S.ld(WL_S_CMD_BY, e), S.ld(WL_S_ACT0, e), S.ld(WL_S_ACT1, e), 0, true);
 }
 
 __global__ void __launch_bounds__(kBlock) elev_reset_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
@@ -395,7 +419,7 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
             elev_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, a, o, seed, step0 + (uint64_t)k, vd);
         else
             elev_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, a, o, seed, step0 + (uint64_t)k, vd);
-        elev_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
+        elev_scan_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
     }
     return launch_status();
 }
@@ -414,7 +438,8 @@ int wl_elev_observe(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
     if (rc != WL_OK) return rc;
     if (!obs) return WL_EINVAL;
     clear_error();
-    elev_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), obs);
+    elev_prop_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, obs);
+    elev_scan_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), obs);
     return launch_status();
 }
 

@@ -235,7 +235,6 @@ WL_DEV int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i :
 __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
                                                             float* __restrict__ obs) {
     __shared__ float img[kImgH * kImgW];
-    __shared__ float tmp[kImgH * kImgW];
     __shared__ float red[kBlock / 64];
     const int e = blockIdx.x;
     const Rows S = make_rows(b.state, b.stride);
@@ -278,15 +277,13 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
         }
     }
     if (plain) return;
-    if (p.contrast != 1.f) {                                       // ColorJitter contrast: blend with the grey mean
-        const float mean = 0.9999f * block_sum(part, red) * (1.f / (float)(kImgH * kImgW));
-        for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock)
-            img[k] = clampf(fmaf(p.contrast, img[k], (1.f - p.contrast) * mean), 0.f, 1.f);
-    }
-    __syncthreads();
-    const float* src = img;
-    if (p.blur_sigma > 0.f) {                                      // GaussianBlur(5, sigma), reflect padding, separable
-        float w[5];
+    // ---- augmentation on the LDS-resident image.  One 4 x 4 output patch per thread (10 x 20 patches = 200 threads):
+    // the 8 x 8 input neighbourhood is read once (contrast blend applied on the fly), both passes of the separable 5-tap
+    // Gaussian run in registers, and each patch row leaves as one 16-byte store.
+    const float mean = 0.9999f * block_sum(part, red) * (1.f / (float)(kImgH * kImgW));   // also orders the img writes
+    const float cc = p.contrast, cm = (1.f - p.contrast) * mean;   // ColorJitter contrast: blend with the grey mean
+    float w[5] = {0.f, 0.f, 1.f, 0.f, 0.f};
+    if (p.blur_sigma > 0.f) {                                      // GaussianBlur(5, sigma): torchvision's kernel1d
         float wsum = 0.f;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -295,25 +292,45 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
             wsum += w[j];
         }
         const float inv = 1.f / wsum;
-        for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) {
-            const int r = k / kImgW, c = k - r * kImgW;
-            float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < 5; ++j) acc = fmaf(w[j] * inv, img[r * kImgW + reflect(c + j - 2, kImgW)], acc);
-            tmp[k] = acc;
-        }
-        __syncthreads();
-        for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) {
-            const int r = k / kImgW, c = k - r * kImgW;
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) acc = fmaf(w[j] * inv, tmp[reflect(r + j - 2, kImgH) * kImgW + c], acc);
-            img[k] = acc;
-        }
-        __syncthreads();
+        for (int j = 0; j < 5; ++j) w[j] *= inv;
     }
-    // ---- grayscale (0.2989 + 0.587 + 0.114 = 0.9999 of a grey pixel) + Normalize([0.5], [0.5]) + flatten ----
-    for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) row[k] = (src[k] * 0.9999f - 0.5f) * 2.f;
+    constexpr int kPatchCols = kImgW / 4, kPatches = (kImgH / 4) * kPatchCols;
+    if (threadIdx.x < kPatches) {
+        const int pr = (threadIdx.x / kPatchCols) * 4, pc = (threadIdx.x % kPatchCols) * 4;
+        int ro[8], co[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ro[i] = reflect(pr + i - 2, kImgH) * kImgW;           // reflect padding (torchvision)
+            co[i] = reflect(pc + i - 2, kImgW);
+        }
+        float hrow[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = img[ro[i] + co[j]];
+                if (cc != 1.f) v[j] = clampf(fmaf(cc, v[j], cm), 0.f, 1.f);
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                hrow[i][o] = fmaf(w[0], v[o], fmaf(w[1], v[o + 1], fmaf(w[2], v[o + 2], fmaf(w[3], v[o + 3], w[4] * v[o + 4]))));
+        }
+#pragma unroll
+        for (int orow = 0; orow < 4; ++orow) {
+            float4 out4;
+            float* o4 = reinterpret_cast<float*>(&out4);
+#pragma unroll
+            for (int oc = 0; oc < 4; ++oc) {
+                const float g = fmaf(w[0], hrow[orow][oc], fmaf(w[1], hrow[orow + 1][oc], fmaf(w[2], hrow[orow + 2][oc],
+                                fmaf(w[3], hrow[orow + 3][oc], w[4] * hrow[orow + 4][oc]))));
+                o4[oc] = (g * 0.9999f - 0.5f) * 2.f;             // grayscale + Normalize([0.5], [0.5])
+            }
+            // row base = e * 3208 floats = e * 12832 B (16-B aligned), patch column is a multiple of 4 floats
+            *reinterpret_cast<float4*>(row + (pr + orow) * kImgW + pc) = out4;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(kBlock) visual_reset_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
