@@ -284,9 +284,15 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
 
 // world_height_map (:44-48): the 26 x 26 yaw-aligned height scan, clipped to +-10, into obs[e][13:689].  One block per
 // env; the env's 13 proprioceptive values are written by the lane-per-env kernels (step / prop).
+constexpr int kScanThreads = 128;                       // threads per env: 676 rays -> 5.3 per thread
+constexpr int kScanEnvsPerBlock = kBlock / kScanThreads;
+// 4096 envs x 128 threads = 8192 wavefronts = exactly one resident round of the chip (32 waves x 256 CUs); with 256
+// threads per env the launch needs two rounds and each round pays the pose-load + gather latency chain again.
 __global__ void __launch_bounds__(kBlock) elev_scan_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
                                                            float* __restrict__ obs) {
-    const int e = blockIdx.x;
+    const int e = blockIdx.x * kScanEnvsPerBlock + threadIdx.x / kScanThreads;
+    if (e >= b.n_envs) return;
+    const int tid = threadIdx.x % kScanThreads;
     const Rows S = make_rows(b.state, b.stride);
     const float px = S.ld(WL_S_PX, e), py = S.ld(WL_S_PY, e), pz = S.ld(WL_S_PZ, e);
     const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
@@ -294,15 +300,27 @@ __global__ void __launch_bounds__(kBlock) elev_scan_kernel(const WlElevParams p,
     yaw_cs(q, c, s);
     float* row = obs + (int64_t)e * WL_ELEV_OBS_DIM;
     const float g0 = -0.5f * p.scan_size;
-    for (int k = threadIdx.x; k < WL_ELEV_SCAN_N * WL_ELEV_SCAN_N; k += kBlock) {
+    // software-pipelined: all of this lane's rays issue their gathers first (12 x 8 B in flight per lane), then blend and
+    // store -- a rolled loop would pay the gather latency once per ray
+    constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N;
+    constexpr int kIter = (kRays + kScanThreads - 1) / kScanThreads;
+    HeightFieldGround::Corners cr[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const int k = min(tid + it * kScanThreads, kRays - 1);
         const int iy = k / WL_ELEV_SCAN_N, ix = k - iy * WL_ELEV_SCAN_N;   // meshgrid "xy": x fastest
         const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
-        const float wx = px + (c * lx - s * ly), wy = py + (s * lx + c * ly);
-        float hz;
-        const bool hit = ground.sample_height(wx, wy, hz);
-        // world_height_map = -(sensor_z - hit_z - offset) + (root_z - plane_init_value); rays that miss return +inf
-        const float val = hit ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
-        row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
+        cr[it] = ground.corners(px + (c * lx - s * ly), py + (s * lx + c * ly));
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const int k = tid + it * kScanThreads;
+        if (k < kRays) {
+            const float hz = ground.blend(cr[it]);
+            // world_height_map = -(sensor_z - hit_z - offset) + (root_z - plane_init_value); rays that miss return +inf
+            const float val = cr[it].inside ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
+            row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
+        }
     }
 }
 
@@ -419,7 +437,7 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
             elev_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, a, o, seed, step0 + (uint64_t)k, vd);
         else
             elev_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, a, o, seed, step0 + (uint64_t)k, vd);
-        elev_scan_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
+        elev_scan_kernel<<<(b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
     }
     return launch_status();
 }
@@ -439,7 +457,7 @@ int wl_elev_observe(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
     if (!obs) return WL_EINVAL;
     clear_error();
     elev_prop_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, obs);
-    elev_scan_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), obs);
+    elev_scan_kernel<<<(b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock, kBlock, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), obs);
     return launch_status();
 }
 

@@ -5,6 +5,10 @@
 
 namespace {
 
+// two horizontally adjacent cells as ONE 8-byte gather (the address is only 4-byte aligned: fine for global loads on
+// gfx9+); halves the number of gather instructions per bilinear sample
+typedef float wl_float2_u __attribute__((ext_vector_type(2), aligned(4)));
+
 // bilinear heightfield sampler (spec: oracle/heightfield.py::sample)
 struct HeightFieldGround {
     WlHeightField f;
@@ -28,6 +32,29 @@ struct HeightFieldGround {
         return inside;
     }
     WL_DEV void sample(float x, float y, float& z, V3& n) const { (void)sample_full(x, y, z, n); }
+    // split form of sample_height for software pipelining: `corners` issues the two 8-byte gathers, `blend` consumes them
+    struct Corners {
+        wl_float2_u lo, hi;
+        float fu, fv;
+        bool inside;
+    };
+    WL_DEV Corners corners(float x, float y) const {
+        Corners c;
+        const float u = (x - f.x0) * inv_cell, v = (y - f.y0) * inv_cell;
+        c.inside = u >= 0.f && v >= 0.f && u < (float)(f.nx - 1) && v < (float)(f.ny - 1);
+        const float uc = fminf(fmaxf(u, 0.f), (float)(f.nx - 1) - 1e-3f), vc = fminf(fmaxf(v, 0.f), (float)(f.ny - 1) - 1e-3f);
+        const float fi = floorf(uc), fj = floorf(vc);
+        c.fu = uc - fi;
+        c.fv = vc - fj;
+        const float* row0 = f.height + (int)fj * f.nx + (int)fi;
+        c.lo = *reinterpret_cast<const wl_float2_u*>(row0);
+        c.hi = *reinterpret_cast<const wl_float2_u*>(row0 + f.nx);
+        return c;
+    }
+    WL_DEV float blend(const Corners& c) const {
+        const float a = fmaf(c.fu, c.lo.y - c.lo.x, c.lo.x), b = fmaf(c.fu, c.hi.y - c.hi.x, c.hi.x);
+        return c.inside ? fmaf(c.fv, b - a, a) : f.outside_z;
+    }
     // height only (ray casting: no normal needed) -- same arithmetic as sample_full for z
     WL_DEV bool sample_height(float x, float y, float& z) const {
         const float u = (x - f.x0) * inv_cell, v = (y - f.y0) * inv_cell;
@@ -36,8 +63,9 @@ struct HeightFieldGround {
         const float fi = floorf(uc), fj = floorf(vc);
         const float fu = uc - fi, fv = vc - fj;
         const float* row0 = f.height + (int64_t)(int)fj * f.nx + (int)fi;
-        const float h00 = row0[0], h10 = row0[1], h01 = row0[f.nx], h11 = row0[f.nx + 1];
-        const float a = fmaf(fu, h10 - h00, h00), b = fmaf(fu, h11 - h01, h01);
+        const wl_float2_u lo = *reinterpret_cast<const wl_float2_u*>(row0);
+        const wl_float2_u hi = *reinterpret_cast<const wl_float2_u*>(row0 + f.nx);
+        const float a = fmaf(fu, lo.y - lo.x, lo.x), b = fmaf(fu, hi.y - hi.x, hi.x);
         z = inside ? fmaf(fv, b - a, a) : f.outside_z;
         return inside;
     }
