@@ -172,6 +172,22 @@ def main():
     achieved = BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
     traffic, traffic_src = pmc_traffic(n)
 
+    # secondary: the same K-step rollouts as ONE persistent launch each (state in registers across steps; only possible
+    # with pre-staged actions, so it is NOT the headline: a policy in the loop needs one launch per env.step())
+    persistent = None
+    if rank == 0 and world == 1 and n <= 32768:
+        env.rollout(actions, obs_buf, rew_buf, term_buf, trunc_buf, persistent=True)
+        torch.cuda.synchronize()
+        p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p0.record()
+        for _ in range(reps):
+            env.rollout(actions, obs_buf, rew_buf, term_buf, trunc_buf, persistent=True)
+        p1.record()
+        torch.cuda.synchronize()
+        pus = p0.elapsed_time(p1) * 1e3 / (reps * ROLLOUT)
+        persistent = {"us_per_step": pus, "env_steps_per_s": n / (pus * 1e-6), "steps_per_launch": ROLLOUT,
+                      "kernel": "drift_rollout_kernel<FlatGround>"}
+
     # secondary: the same workload driven step by step through the drop-in Python surface
     # (registry.make -> ClipAction -> RslRlVecEnvWrapper.step), i.e. what a Python RL loop sees per env.step() call
     py_rate = None
@@ -235,6 +251,7 @@ def main():
                                 "out_of_bounds": float(metric_sum[10]), "nonfinite": float(metric_sum[14])},
         }
         line["python_surface_env_steps_per_s"] = py_rate
+        line["persistent_rollout"] = persistent
         if sweep:
             line["large_n_sweep"] = sweep
         if world == 1 and not args.no_cpu_baseline:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 6
+#define WL_ABI_VERSION 7
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -185,6 +185,17 @@ int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* ac
 int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float* actions, const WlStepOut* out,
                      int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps, uint64_t seed,
                      uint64_t step0, void* stream);
+
+/*
+ * Same contract as wl_drift_rollout, executed as ONE persistent launch (quad form): each env's rows stay in registers
+ * across the K steps; per step only the action is read and obs / reward / flags are written.  Results are identical to
+ * K calls of wl_drift_step.  Episode metrics of all K steps accumulate into ring slot (step0 % R) and slot
+ * ((step0 + K) % R) is cleared for the next launch (K % R must not be 0 when R > 1).  For pre-staged action sequences
+ * (open-loop evaluation, sampling-based MPC); a policy in the loop needs wl_drift_step.
+ */
+int wl_drift_rollout_persistent(const WlDriftParams* p, const WlEnvBuffers* b, const float* actions,
+                                const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps,
+                                uint64_t seed, uint64_t step0, void* stream);
 
 /*
  * Drift mdp terms only, on caller-supplied state tensors (the parity entry point: "outputs match the reference

@@ -208,6 +208,50 @@ def test_rollout_api_equals_step_api(lib):
     assert e1.step_count == e2.step_count == K
 
 
+@pytest.mark.parametrize("n,ring", [(512, 1), (4096, 64), (100, 1)])
+def test_persistent_rollout_matches_stepping(lib, n, ring):
+    """wl_drift_rollout_persistent keeps the rows in registers across K steps and must reproduce K wl_drift_step calls.
+    The two kernels inline the same step function but the compiler contracts FMAs differently in each, so equality is
+    to fp32 rounding on the first steps and to trajectory-divergence tolerance at the end of the rollout."""
+    from wheeledlab_amd.core import DriftBatch
+    K = 37
+    a = torch.rand(K, n, 2, device=DEV) * 2.4 - 1.2
+    e1 = DriftBatch(n, device=DEV, seed=13, metrics_slots=ring)
+    e2 = DriftBatch(n, device=DEV, seed=13, metrics_slots=ring)
+    e1.reset(), e2.reset()
+    for env in (e1, e2):                       # start mid-episode so that time-outs happen inside the rollout
+        env.episode_len[: n // 3] = 230
+    e1.p.enable_corruption = e2.p.enable_corruption = 0          # compare clean observations
+    obs_all = torch.zeros(K, n, 14, device=DEV)
+    rew_all = torch.zeros(K, n, device=DEV)
+    te = torch.zeros(K, n, dtype=torch.bool, device=DEV)
+    tr = torch.zeros(K, n, dtype=torch.bool, device=DEV)
+    e1.rollout(a, obs_all, rew_all, te, tr, persistent=True)
+    msum = torch.zeros(16, device=DEV)
+    same = torch.ones(n, dtype=torch.bool, device=DEV)            # envs whose discrete events agreed so far
+    for k in range(K):
+        slot = e2.metrics[e2.step_count % ring] if ring > 1 else None
+        obs, rew, term, trunc = e2.step(a[k])
+        assert torch.equal(trunc, tr[k]), k
+        same &= term == te[k]
+        d = (obs - obs_all[k]).abs()
+        d[:, 3:6] = torch.minimum(d[:, 3:6], (2 * np.pi - d[:, 3:6]).abs())
+        tol = 2e-5 if k < 3 else 5e-3                              # rounding first, then (bounded) divergence
+        assert d[same].max() < tol, (k, float(d[same].max()))
+        if ring > 1:
+            msum += slot
+    assert same.float().mean() > 0.99
+    ds = (e1.state[:23, :n] - e2.state[:23, :n]).abs()[:, same]
+    assert ds[:13].max() < 5e-3 and torch.equal(e1.episode_len[:n][same], e2.episode_len[:n][same])
+    assert tr.any() and e1.step_count == e2.step_count == K
+    if bool(same.all()):
+        m1 = e1.metrics[0] if ring > 1 else e1.metrics
+        m2 = msum if ring > 1 else e2.metrics
+        assert torch.allclose(m1[8:], m2[8:]) and torch.allclose(m1[:8], m2[:8], rtol=1e-3, atol=0.5)
+    if ring > 1:   # all K steps' metrics land in the rollout's first slot; the slot after the rollout is clean
+        assert (e1.metrics[K % ring] == 0).all()
+
+
 @pytest.mark.parametrize("n", [4096, 32768])
 def test_full_size_properties(lib, n):
     """size-independent invariants at BASELINE.json's sizes (4096 / GPU, 32768 = 8 x 4096)"""

@@ -22,5 +22,15 @@ for name, cls, K in (("drift", DriftBatch, 128), ("elevation", ElevBatch, 32), (
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (4 * K)
         res[f"{name}@{n}"] = {"us_per_step": round(us, 2), "env_steps_per_s": round(n / us * 1e6), "obs_GBs": round(n * env.OBS_DIM * 4 / us / 1e3, 1)}
+        if name == "drift" and n <= 32768:
+            env.rollout(a, persistent=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(4):
+                env.rollout(a, persistent=True)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (4 * K)
+            res[f"drift_persistent@{n}"] = {"us_per_step": round(us, 2), "env_steps_per_s": round(n / us * 1e6)}
         del env, a
 print(json.dumps(res))

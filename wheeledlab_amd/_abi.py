@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 6
+WL_ABI_VERSION = 7
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -130,6 +130,8 @@ SIGNATURES = {
     "wl_drift_step": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _vp, _P(WlStepOut), _u64, _u64, _vp]),
     "wl_drift_rollout": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _P(WlStepOut), _i64, _i64, _i32, _u64,
                                    _u64, _vp]),
+    "wl_drift_rollout_persistent": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _P(WlStepOut), _i64, _i64, _i32,
+                                              _u64, _u64, _vp]),
     "wl_drift_mdp": (C.c_int, [_P(WlDriftParams), _i32, _i64] + [_vp] * 12),
     "wl_action_map": (C.c_int, [_P(WlActionParams), _i32, _vp, _vp, _vp, _vp, _vp]),
     "wl_drift_reset": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _u64, _u64, _vp]),

@@ -131,8 +131,9 @@ class DriftBatch:
         return self.obs, self.reward, self.terminated, self.truncated
 
     def rollout(self, actions: torch.Tensor, obs_out: torch.Tensor | None = None, rew_out: torch.Tensor | None = None,
-                term_out: torch.Tensor | None = None, trunc_out: torch.Tensor | None = None):
-        """K fused steps with pre-staged actions [K,n,2]; optional [K,...] output storage (else overwrite)."""
+                term_out: torch.Tensor | None = None, trunc_out: torch.Tensor | None = None, persistent: bool = False):
+        """K fused steps with pre-staged actions [K,n,2]; optional [K,...] output storage (else overwrite).
+        persistent=True runs them as ONE launch with the state held in registers (wl_drift_rollout_persistent)."""
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
         if obs_out is not None:
@@ -140,8 +141,9 @@ class DriftBatch:
             os_, vs_ = self.n * self.OBS_DIM, self.n
         else:
             out, os_, vs_ = self._out, 0, 0
-        A.check(self.lib.wl_drift_rollout(C.byref(self.p), C.byref(self._bufs), actions.data_ptr(), C.byref(out), os_,
-                                          vs_, K, self.seed, self.step_count, self._stream()), "wl_drift_rollout")
+        fn = self.lib.wl_drift_rollout_persistent if persistent else self.lib.wl_drift_rollout
+        A.check(fn(C.byref(self.p), C.byref(self._bufs), actions.data_ptr(), C.byref(out), os_, vs_, K, self.seed,
+                   self.step_count, self._stream()), "wl_drift_rollout")
         self.step_count += K
 
     def read_metrics(self, zero: bool = True) -> torch.Tensor:

@@ -103,6 +103,235 @@ WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0
     }
 }
 
+// Register image of one env's rows of the state matrix (memory form: root-link position, world-frame velocities).
+struct DriftRows {
+    V3 pos;
+    Quat q;
+    V3 v, ww;
+    float wheel[4];   // quad form: wheel[0] is this lane's wheel
+    float th, om;
+    float a0, a1;     // last raw action
+    float timer_hf, timer_lf;
+    float epsum[WL_DR_NTERMS];   // quad form only (the lane form streams these rows late to save registers)
+    int ep_len;
+};
+
+template <int LANES>
+WL_DEV void load_rows(const Rows& S, const WlEnvBuffers& b, const WlDriftParams& p, int e, int wid, DriftRows& r) {
+    r.pos = ld3(S, WL_S_PX, e);
+    r.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+    r.v = ld3(S, WL_S_VX, e);
+    r.ww = ld3(S, WL_S_WX, e);
+    if constexpr (LANES == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
+    } else {
+        r.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
+#pragma unroll
+        for (int i = 0; i < WL_DR_NTERMS; ++i) r.epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) : 0.f;
+    }
+    r.th = S.ld(WL_S_STEER_POS, e);
+    r.om = S.ld(WL_S_STEER_VEL, e);
+    r.timer_hf = S.ld(WL_S_TIMER_HF, e);
+    r.timer_lf = S.ld(WL_S_TIMER_LF, e);
+    r.ep_len = b.episode_len[e];
+}
+
+template <int LANES>
+WL_DEV void store_rows(const Rows& S, const WlEnvBuffers& b, const WlDriftParams& p, int e, int wid, bool lead,
+                       const DriftRows& r) {
+    if constexpr (LANES == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, r.wheel[i]);
+    } else {
+        S.st(WL_S_WHEEL_BL + wid, e, r.wheel[0]);
+    }
+    if (!lead) return;
+    st3(S, WL_S_PX, e, r.pos);
+    S.st(WL_S_QW, e, r.q.w);
+    S.st(WL_S_QX, e, r.q.x);
+    S.st(WL_S_QY, e, r.q.y);
+    S.st(WL_S_QZ, e, r.q.z);
+    st3(S, WL_S_VX, e, r.v);
+    st3(S, WL_S_WX, e, r.ww);
+    S.st(WL_S_STEER_POS, e, r.th);
+    S.st(WL_S_STEER_VEL, e, r.om);
+    S.st(WL_S_ACT0, e, r.a0);
+    S.st(WL_S_ACT1, e, r.a1);
+    S.st(WL_S_TIMER_HF, e, r.timer_hf);
+    S.st(WL_S_TIMER_LF, e, r.timer_lf);
+    if constexpr (LANES == 4) {
+        if (p.log_episode_sums) {
+#pragma unroll
+            for (int i = 0; i < WL_DR_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, r.epsum[i]);
+        }
+    }
+    b.episode_len[e] = r.ep_len;
+}
+
+// per-env constants that do not change during a rollout
+WL_DEV void load_env_const(const Rows& S, const WlVehicleParams& vp, const VehDerived& vd, int e, EnvConst& ec) {
+    env_const_mass(ec, vp, vd, S.ld(WL_S_MASS, e));
+    ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
+    ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
+    ec.damp = S.ld(WL_S_DAMP, e);
+}
+
+// ONE env.step() on the register image `r` (shared by the per-step kernel and the persistent rollout kernel): action
+// term -> physics -> terminations -> rewards -> reset -> pushes -> observation row into the block's LDS tile.
+// Writes reward / flags to `out` (already offset to this step); accumulates episode metrics into `blk_metrics` (LDS).
+template <int LANES, class Ground>
+WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const VehDerived& vd, const Ground& ground,
+                           const Rows& S, EnvConst& ec, DriftRows& r, float2 a, const float* __restrict__ noise,
+                           const WlStepOut& out, int e, int le, int wid, bool lead, uint32_t gid, uint64_t seed, uint64_t step,
+                           float* tile, float* blk_metrics) {
+    const WlVehicleParams& vp = p.vehicle;
+    // ---- action manager: ClipAction + process_actions + joint targets (once per env-step) ----
+    float v_t, delta;
+    process_action(p.action, a.x, a.y, v_t, delta);
+    joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
+    // ---- memory form -> integrator form (CoM position, body-frame angular velocity) ----
+    VehState s;
+    s.q = r.q;
+    s.v = r.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.wheel[i] = r.wheel[i];
+    s.th = r.th;
+    s.om = r.om;
+    {
+        const Mat3 R = mat_from_quat(s.q);
+        s.x = r.pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);  // CoM = link origin + R (0,0,cg_z)
+        s.wb = mul_t(R, r.ww);
+    }
+    // ---- physics: decimation x substeps, everything in registers ----
+    for (int k = 0; k < vd.n_sub; ++k) vehicle_substep<LANES>(vp, vd, ec, s, ground, wid);
+    const Mat3 R = mat_from_quat(s.q);
+    V3 ww = mul(R, s.wb);
+    V3 pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
+    // ---- terminations (time_out, cart_off_track) + non-finite guard ----
+    int ep_len = r.ep_len + 1;
+    const bool truncated = ep_len >= p.max_episode_length;
+    float wheel_sum;
+    if constexpr (LANES == 1) wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
+    else wheel_sum = quad_sum(s.wheel[0]);
+    const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y + ww.z +
+                      wheel_sum + s.th + s.om;
+    const bool finite = __builtin_isfinite(chk);
+    const bool terminated = !finite || cart_off_track(pos.x, pos.y, p.straight, p.r_in, p.r_out);
+    // ---- rewards on the post-physics state ----
+    V3 vb = mul_t(R, s.v);
+    // side-slip angle and the three Euler angles are four atan2s (asin(x) == atan2(x, sqrt(1 - x^2))): the quad form
+    // evaluates them as ONE atan2 with per-lane arguments and DPP-broadcasts the results
+    float slip_angle;
+    V3 euler;
+    if constexpr (LANES == 4) {
+        const Quat q = s.q;
+        const float sp = 2.f * (q.w * q.y - q.z * q.x);
+        const float ay = wid == 0 ? vb.y : wid == 1 ? 2.f * (q.w * q.x + q.y * q.z) : wid == 2 ? sp : 2.f * (q.w * q.z + q.x * q.y);
+        const float ax = wid == 0 ? vb.x : wid == 1 ? 1.f - 2.f * (q.x * q.x + q.y * q.y)
+                       : wid == 2 ? fsqrt(fmaxf(1.f - sp * sp, 0.f)) : 1.f - 2.f * (q.y * q.y + q.z * q.z);
+        const float ang = atan2f(ay, ax);
+        slip_angle = quad_bcast<0>(ang);
+        euler = v3(wrap_2pi(quad_bcast<1>(ang)), wrap_2pi(quad_bcast<2>(ang)), wrap_2pi(quad_bcast<3>(ang)));
+    } else {
+        slip_angle = atan2f(vb.y, vb.x);
+    }
+    DriftTerms tm = drift_terms(p, pos, vb, s.wb, ww.z, s.th, terminated, truncated, slip_angle);
+    const float step_dt = p.sim_dt * (float)p.decimation;
+    float reward = 0.f;
+    float epsum[WL_DR_NTERMS];
+#pragma unroll
+    for (int i = 0; i < WL_DR_NTERMS; ++i) {
+        const float w = p.weight[i];
+        const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;  // RewardManager skips w == 0
+        reward += c;
+        if constexpr (LANES == 4) epsum[i] = r.epsum[i] + c;
+        else epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;   // lane form: streamed late
+    }
+    if (lead) {
+        out.reward[e] = reward;
+        out.terminated[e] = terminated ? 1 : 0;
+        out.truncated[e] = truncated ? 1 : 0;
+    }
+    // ---- reset (done envs) ----
+    float a0 = a.x, a1 = a.y, timer_hf = r.timer_hf, timer_lf = r.timer_lf;
+    if (terminated || truncated) {
+        if (lead) {
+#pragma unroll
+            for (int i = 0; i < WL_DR_NTERMS; ++i) atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
+            atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
+            if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
+            if (terminated) atomicAdd(&blk_metrics[WL_M_TERM0], 1.f);
+            if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
+            atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
+        }
+#pragma unroll
+        for (int i = 0; i < WL_DR_NTERMS; ++i) epsum[i] = 0.f;
+        if (!finite) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
+            s.th = s.om = 0.f;
+        }
+        const ResetDraw rd = draw_reset(p, b.ref_poses, gid, step, seed);
+        pos = rd.pos;
+        s.q = rd.q;
+        if constexpr (LANES == 4) euler = v3(0.f, 0.f, rd.yaw - WL_TWO_PI * floorf(rd.yaw * WL_INV_TWO_PI));
+        s.v = v3(0.f, 0.f, 0.f);
+        ww = v3(0.f, 0.f, 0.f);
+        timer_hf = rd.timer_hf;
+        timer_lf = rd.timer_lf;
+        ep_len = 0;
+        a0 = a1 = 0.f;  // ActionManager.reset zeroes `action` (last_action) of reset envs
+    }
+    // ---- interval events: push_by_setting_velocity (mushr_drift_env_cfg.py:121-143) ----
+    if (p.enable_pushes) {
+        timer_hf -= step_dt;
+        if (timer_hf < 1e-6f) {
+            const F4 u = philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
+            s.v.x = fmaf(2.f * u.x - 1.f, p.hf_vel_x, s.v.x);
+            s.v.y = fmaf(2.f * u.y - 1.f, p.hf_vel_y, s.v.y);
+            ww.z = fmaf(2.f * u.z - 1.f, p.hf_vel_yaw, ww.z);
+            timer_hf = fmaf(u.w, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
+        }
+        timer_lf -= step_dt;
+        if (timer_lf < 1e-6f) {
+            const F4 u = philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
+            ww.z = fmaf(2.f * u.x - 1.f, p.lf_vel_yaw, ww.z);
+            timer_lf = fmaf(u.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
+        }
+    }
+    // ---- back to memory form ----
+    r.pos = pos;
+    r.q = s.q;
+    r.v = s.v;
+    r.ww = ww;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.wheel[i] = s.wheel[i];
+    r.th = s.th;
+    r.om = s.om;
+    r.a0 = a0;
+    r.a1 = a1;
+    r.timer_hf = timer_hf;
+    r.timer_lf = timer_lf;
+    r.ep_len = ep_len;
+    if constexpr (LANES == 4) {
+#pragma unroll
+        for (int i = 0; i < WL_DR_NTERMS; ++i) r.epsum[i] = epsum[i];
+    } else {
+        if (p.log_episode_sums) {
+#pragma unroll
+            for (int i = 0; i < WL_DR_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
+        }
+    }
+    // ---- observation of the post-reset state ----
+    const Mat3 R2 = mat_from_quat(s.q);
+    vb = mul_t(R2, s.v);
+    const V3 wb2 = mul_t(R2, ww);
+    const Noise12 nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // all lanes of the quad
+    if constexpr (LANES == 1) euler = euler_xyz_from_quat(s.q);
+    if (lead) write_obs_row(&tile[le * kObsPad], p, pos, euler, vb, wb2, a0, a1, nz);
+}
+
 // LANES = 1: lane per env (throughput form).  LANES = 4: quad per env, one wheel per lane (latency form, small n).
 template <int LANES, class Ground>
 __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const WlDriftParams p, const WlEnvBuffers b,
@@ -117,197 +346,22 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
     const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);   // this lane's wheel (quad form)
     const bool lead = LANES == 1 || wid == 0;       // the lane that writes the env's shared rows / outputs
     const int e = blockIdx.x * kEnvs + le;
-    const bool active = e < b.n_envs;
     if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
     // per-step metric ring: accumulate into slot step % R, clear the slot the NEXT launch will use
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
     if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
         b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
     __syncthreads();
-    const Rows S = make_rows(b.state, b.stride);
-    const WlVehicleParams& vp = p.vehicle;
-    bool any_done = false;
-    if (active) {
-        const uint32_t gid = (uint32_t)(b.env_offset + e);
-        // ---- action manager: ClipAction + process_actions + joint targets (once per env-step) ----
-        float2 a = actions[e];
-        float v_t, delta;
-        process_action(p.action, a.x, a.y, v_t, delta);
+    if (e < b.n_envs) {
+        const Rows S = make_rows(b.state, b.stride);
         EnvConst ec;
-        joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-        env_const_mass(ec, vp, vd, S.ld(WL_S_MASS, e));
-        ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
-        ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
-        ec.damp = S.ld(WL_S_DAMP, e);
-        // ---- load state ----
-        VehState s;
-        V3 pos = ld3(S, WL_S_PX, e);
-        s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
-        s.v = ld3(S, WL_S_VX, e);
-        V3 ww = ld3(S, WL_S_WX, e);
-        if constexpr (LANES == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
-        } else {
-            s.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
-        }
-        s.th = S.ld(WL_S_STEER_POS, e);
-        s.om = S.ld(WL_S_STEER_VEL, e);
-#ifndef WL_LATE_LOADS
-        float timer_hf = S.ld(WL_S_TIMER_HF, e), timer_lf = S.ld(WL_S_TIMER_LF, e);
-        int ep_len = b.episode_len[e];
-#endif
-        {
-            const Mat3 R = mat_from_quat(s.q);
-            s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);  // CoM = link origin + R (0,0,cg_z)
-            s.wb = mul_t(R, ww);
-        }
-        // quad form has registers to spare: fetch the episode-sum rows now so their latency hides behind the physics
-        float epsum_in[WL_DR_NTERMS];
-        if constexpr (LANES == 4) {
-#pragma unroll
-            for (int i = 0; i < WL_DR_NTERMS; ++i) epsum_in[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) : 0.f;
-        }
-        // ---- physics: decimation x substeps, everything in registers ----
-        for (int k = 0; k < vd.n_sub; ++k) vehicle_substep<LANES>(vp, vd, ec, s, ground, wid);
-#ifdef WL_LATE_LOADS
-        // rows that only the bookkeeping tail needs are fetched after the physics loop: they would otherwise sit in
-        // VGPRs through all sub-steps (occupancy); other resident waves cover the latency
-        asm volatile("" ::: "memory");
-        float timer_hf = S.ld(WL_S_TIMER_HF, e), timer_lf = S.ld(WL_S_TIMER_LF, e);
-        int ep_len = b.episode_len[e];
-#endif
-        const Mat3 R = mat_from_quat(s.q);
-        ww = mul(R, s.wb);
-        pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
-        // ---- terminations (time_out, cart_off_track) + non-finite guard ----
-        ep_len += 1;
-        const bool truncated = ep_len >= p.max_episode_length;
-        float wheel_sum;
-        if constexpr (LANES == 1) wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
-        else wheel_sum = quad_sum(s.wheel[0]);
-        const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y +
-                          ww.z + wheel_sum + s.th + s.om;
-        const bool finite = __builtin_isfinite(chk);
-        const bool terminated = !finite || cart_off_track(pos.x, pos.y, p.straight, p.r_in, p.r_out);
-        // ---- rewards on the post-physics state ----
-        V3 vb = mul_t(R, s.v);
-        // side-slip angle and the three Euler angles are four atan2s (asin(x) == atan2(x, sqrt(1 - x^2))): the quad form
-        // evaluates them as ONE atan2 with per-lane arguments and DPP-broadcasts the results
-        float slip_angle;
-        V3 euler;
-        if constexpr (LANES == 4) {
-            const Quat q = s.q;
-            const float sp = 2.f * (q.w * q.y - q.z * q.x);
-            const float ay = wid == 0 ? vb.y : wid == 1 ? 2.f * (q.w * q.x + q.y * q.z) : wid == 2 ? sp : 2.f * (q.w * q.z + q.x * q.y);
-            const float ax = wid == 0 ? vb.x : wid == 1 ? 1.f - 2.f * (q.x * q.x + q.y * q.y)
-                           : wid == 2 ? fsqrt(fmaxf(1.f - sp * sp, 0.f)) : 1.f - 2.f * (q.y * q.y + q.z * q.z);
-            const float ang = atan2f(ay, ax);
-            slip_angle = quad_bcast<0>(ang);
-            euler = v3(wrap_2pi(quad_bcast<1>(ang)), wrap_2pi(quad_bcast<2>(ang)), wrap_2pi(quad_bcast<3>(ang)));
-        } else {
-            slip_angle = atan2f(vb.y, vb.x);
-        }
-        DriftTerms tm = drift_terms(p, pos, vb, s.wb, ww.z, s.th, terminated, truncated, slip_angle);
-        const float step_dt = p.sim_dt * (float)p.decimation;
-        float reward = 0.f;
-        float epsum[WL_DR_NTERMS];
-#pragma unroll
-        for (int i = 0; i < WL_DR_NTERMS; ++i) {
-            const float w = p.weight[i];
-            const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;  // RewardManager skips w == 0
-            reward += c;
-            if constexpr (LANES == 4) epsum[i] = epsum_in[i] + c;
-            else epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;
-        }
-        if (lead) {
-            out.reward[e] = reward;
-            out.terminated[e] = terminated ? 1 : 0;
-            out.truncated[e] = truncated ? 1 : 0;
-        }
-        // ---- reset (done envs) ----
-        const bool done = terminated || truncated;
-        float a0 = a.x, a1 = a.y;
-        if (done) {
-            any_done = true;
-            if (lead) {
-#pragma unroll
-                for (int i = 0; i < WL_DR_NTERMS; ++i) atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
-                atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
-                if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
-                if (terminated) atomicAdd(&blk_metrics[WL_M_TERM0], 1.f);
-                if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
-                atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
-            }
-#pragma unroll
-            for (int i = 0; i < WL_DR_NTERMS; ++i) epsum[i] = 0.f;
-            if (!finite) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
-                s.th = s.om = 0.f;
-            }
-            const ResetDraw rd = draw_reset(p, b.ref_poses, gid, step, seed);
-            pos = rd.pos;
-            s.q = rd.q;
-            if constexpr (LANES == 4) euler = v3(0.f, 0.f, rd.yaw - WL_TWO_PI * floorf(rd.yaw * WL_INV_TWO_PI));
-            s.v = v3(0.f, 0.f, 0.f);
-            ww = v3(0.f, 0.f, 0.f);
-            timer_hf = rd.timer_hf;
-            timer_lf = rd.timer_lf;
-            ep_len = 0;
-            a0 = a1 = 0.f;  // ActionManager.reset zeroes `action` (last_action) of reset envs
-        }
-        // ---- interval events: push_by_setting_velocity (mushr_drift_env_cfg.py:121-143) ----
-        if (p.enable_pushes) {
-            timer_hf -= step_dt;
-            if (timer_hf < 1e-6f) {
-                const F4 u = philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
-                s.v.x = fmaf(2.f * u.x - 1.f, p.hf_vel_x, s.v.x);
-                s.v.y = fmaf(2.f * u.y - 1.f, p.hf_vel_y, s.v.y);
-                ww.z = fmaf(2.f * u.z - 1.f, p.hf_vel_yaw, ww.z);
-                timer_hf = fmaf(u.w, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
-            }
-            timer_lf -= step_dt;
-            if (timer_lf < 1e-6f) {
-                const F4 u = philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
-                ww.z = fmaf(2.f * u.x - 1.f, p.lf_vel_yaw, ww.z);
-                timer_lf = fmaf(u.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
-            }
-        }
-        // ---- store state ----
-        if constexpr (LANES == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, s.wheel[i]);
-        } else {
-            S.st(WL_S_WHEEL_BL + wid, e, s.wheel[0]);
-        }
-        if (lead) {
-            st3(S, WL_S_PX, e, pos);
-            S.st(WL_S_QW, e, s.q.w);
-            S.st(WL_S_QX, e, s.q.x);
-            S.st(WL_S_QY, e, s.q.y);
-            S.st(WL_S_QZ, e, s.q.z);
-            st3(S, WL_S_VX, e, s.v);
-            st3(S, WL_S_WX, e, ww);
-            S.st(WL_S_STEER_POS, e, s.th);
-            S.st(WL_S_STEER_VEL, e, s.om);
-            S.st(WL_S_ACT0, e, a0);
-            S.st(WL_S_ACT1, e, a1);
-            S.st(WL_S_TIMER_HF, e, timer_hf);
-            S.st(WL_S_TIMER_LF, e, timer_lf);
-            if (p.log_episode_sums) {
-#pragma unroll
-                for (int i = 0; i < WL_DR_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
-            }
-            b.episode_len[e] = ep_len;
-        }
-        // ---- observation of the post-reset state ----
-        const Mat3 R2 = mat_from_quat(s.q);
-        vb = mul_t(R2, s.v);
-        const V3 wb2 = mul_t(R2, ww);
-        const Noise12 nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // all lanes of the quad
-        if constexpr (LANES == 1) euler = euler_xyz_from_quat(s.q);
-        if (lead) write_obs_row(&tile[le * kObsPad], p, pos, euler, vb, wb2, a0, a1, nz);
+        DriftRows r;
+        const float2 a = actions[e];
+        load_env_const(S, p.vehicle, vd, e, ec);
+        load_rows<LANES>(S, b, p, e, wid, r);
+        drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, le, wid, lead, (uint32_t)(b.env_offset + e), seed,
+                              step, tile, blk_metrics);
+        store_rows<LANES>(S, b, p, e, wid, lead, r);
     }
     __syncthreads();
     flush_obs(tile, out.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
@@ -315,7 +369,60 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         const float m = blk_metrics[threadIdx.x];
         if (m != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], m);
     }
-    (void)any_done;
+}
+
+// Persistent rollout (quad form): K consecutive env.step()s in ONE launch with pre-staged actions [K][n][2].  The env's
+// rows stay in registers across steps -- per step only the action is read and obs / reward / flags are written -- so the
+// launch boundary, the state round trip through L2 and its address arithmetic are paid once per rollout.  Episode
+// metrics of all K steps accumulate into ring slot (step0 % R); slot ((step0 + K) % R) is cleared for the next launch.
+template <class Ground>
+__global__ void __launch_bounds__(kBlock) drift_rollout_kernel(const WlDriftParams p, const WlEnvBuffers b,
+                                                               const float2* __restrict__ actions, const WlStepOut out,
+                                                               const int64_t obs_step_stride, const int64_t vec_step_stride,
+                                                               const int n_steps, const uint64_t seed, const uint64_t step0,
+                                                               const Ground ground, const VehDerived vd) {
+    constexpr int LANES = 4, kEnvs = kBlock / LANES;
+    __shared__ float tile[kEnvs * kObsPad];
+    __shared__ float blk_metrics[WL_M_COUNT];
+    const int le = threadIdx.x / LANES, wid = threadIdx.x & 3;
+    const bool lead = wid == 0;
+    const int e = blockIdx.x * kEnvs + le;
+    const bool active = e < b.n_envs;
+    if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
+    const int m_slot = b.metrics_slots > 1 ? (int)(step0 % (uint64_t)b.metrics_slots) : 0;
+    if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
+        b.metrics[(int)((step0 + (uint64_t)n_steps) % (uint64_t)b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
+    __syncthreads();
+    const Rows S = make_rows(b.state, b.stride);
+    EnvConst ec;
+    DriftRows r;
+    float2 a_next = make_float2(0.f, 0.f);
+    if (active) {
+        load_env_const(S, p.vehicle, vd, e, ec);
+        load_rows<LANES>(S, b, p, e, wid, r);
+        if (n_steps > 0) a_next = actions[e];
+    }
+    for (int k = 0; k < n_steps; ++k) {
+        WlStepOut o = out;
+        o.obs += k * obs_step_stride;
+        o.reward += k * vec_step_stride;
+        o.terminated += k * vec_step_stride;
+        o.truncated += k * vec_step_stride;
+        if (active) {
+            const float2 a = a_next;
+            if (k + 1 < n_steps) a_next = actions[(int64_t)(k + 1) * b.n_envs + e];   // prefetch: hidden behind the physics
+            drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, nullptr, o, e, le, wid, lead, (uint32_t)(b.env_offset + e), seed,
+                                  step0 + (uint64_t)k, tile, blk_metrics);
+        }
+        __syncthreads();
+        flush_obs(tile, o.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
+        __syncthreads();   // the tile is rewritten by the next step
+    }
+    if (active) store_rows<LANES>(S, b, p, e, wid, lead, r);
+    if (threadIdx.x < WL_M_COUNT) {
+        const float m = blk_metrics[threadIdx.x];
+        if (m != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], m);
+    }
 }
 
 // ---- terms only, on caller-supplied state tensors (parity entry point) -----------------------------------
@@ -494,6 +601,20 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
             drift_step_kernel<1, FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
                 *p, *b, a, nullptr, o, seed, step0 + (uint64_t)k, FlatGround{}, vd);
     }
+    return launch_status();
+}
+
+int wl_drift_rollout_persistent(const WlDriftParams* p, const WlEnvBuffers* b, const float* actions, const WlStepOut* out,
+                                int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps, uint64_t seed, uint64_t step0,
+                                void* stream) {
+    int rc = check_buffers(p, b);
+    if (rc != WL_OK) return rc;
+    if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
+    if (b->metrics_slots > 1 && n_steps % b->metrics_slots == 0 && n_steps > 0) return WL_EINVAL;   // ring slot aliasing
+    clear_error();
+    drift_rollout_kernel<FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
+        *p, *b, (const float2*)actions, *out, obs_step_stride, vec_step_stride, n_steps, seed, step0, FlatGround{},
+        derive_vehicle(p->vehicle, p->sim_dt, p->decimation));
     return launch_status();
 }
 
