@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 7
+#define WL_ABI_VERSION 9
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -146,6 +146,8 @@ typedef struct WlEnvBuffers {
     int32_t env_offset;       /* global id of env 0 of this shard (rank * n_envs): keys the RNG streams            */
     int32_t metrics_slots;    /* 1: one accumulator the caller zeroes; R > 1: ring of per-step slots, the step    */
                               /* kernel accumulates into slot (step % R) and clears slot ((step + 1) % R)         */
+    int32_t lanes;            /* step-kernel form: 0 = choose by env count, 1 = lane per env, 4 = quad per env    */
+    int32_t reserved;
 } WlEnvBuffers;
 
 /* ---- outputs of one step -------------------------------------------------------------------------------- */
@@ -154,6 +156,8 @@ typedef struct WlStepOut {
     float* reward;            /* [n]                                                                          */
     uint8_t* terminated;      /* [n]                                                                          */
     uint8_t* truncated;       /* [n]                                                                          */
+    int64_t* dones;           /* [n] terminated | truncated as int64 (what RSL-RL's runner consumes,             */
+                              /* modified_rsl_rl_runner.py:73,101); may be NULL                                   */
 } WlStepOut;
 
 int wl_version(void);

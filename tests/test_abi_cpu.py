@@ -96,7 +96,7 @@ def test_layout_of_task_structs_and_misuse_codes(tmp_path):
     p = PP.drift_params()
     buf = (C.c_float * 4096)()
     base = C.addressof(buf)
-    out = A.WlStepOut(base, base, base, base)
+    out = A.WlStepOut(base, base, base, base, None)
     ok_bufs = dict(state=base, episode_len=base, ref_poses=base, metrics=base)
     bad_stride = A.WlEnvBuffers(stride=100, n_envs=100, env_offset=0, metrics_slots=1, **ok_bufs)       # stride % 64 != 0
     assert lib.wl_drift_step(C.byref(p), C.byref(bad_stride), base, None, C.byref(out), 0, 0, None) == -3

@@ -140,13 +140,15 @@ def test_reset_kernel_matches_oracle(lib):
     assert d.max() <= 0.5 * np.sqrt(2) + 1e-5
 
 
+@pytest.mark.parametrize("lanes", [4, 1])
 @pytest.mark.parametrize("mode", ["philox", "noise_tensor", "no_corruption"])
-def test_fused_step_matches_oracle_single_steps(lib, mode):
+def test_fused_step_matches_oracle_single_steps(lib, mode, lanes):
     """Each step starts from the device state (copied to the host), so differences do not accumulate:
     tolerance 2e-4 abs/rel on state (4 sub-steps of fp32 with hardware rcp/rsq vs numpy), rewards 2e-3 abs
     (weights up to 5000 * dt amplify), observation 1e-3."""
     n = 1024
     env = _fresh(n, seed=5)
+    env.set_lanes(lanes)      # both forms of the step kernel: quad-per-env (latency) and lane-per-env (throughput)
     p = OP.drift_params()
     if mode == "no_corruption":
         env.p.enable_corruption = 0

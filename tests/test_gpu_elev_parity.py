@@ -88,9 +88,11 @@ def test_elev_reset_and_observation_match_oracle():
     assert obs.shape == (200, 689)
 
 
-def test_elev_fused_step_matches_oracle_single_steps():
+@pytest.mark.parametrize("lanes", [4, 1])
+def test_elev_fused_step_matches_oracle_single_steps(lanes):
     n = 512
     env, hf = _fresh(n, seed=5)
+    env.set_lanes(lanes)
     p = OS.elev_params()
     rng = np.random.RandomState(0)
     flips = 0

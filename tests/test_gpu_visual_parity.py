@@ -89,9 +89,11 @@ def test_visual_reset_and_camera_match_oracle(trav):
     assert (img > 0.9).any() and (img < -0.9).any() and ((img.abs() < 0.05).float().mean() > 0.1)
 
 
-def test_visual_fused_step_matches_oracle_single_steps(trav):
+@pytest.mark.parametrize("lanes", [4, 1])
+def test_visual_fused_step_matches_oracle_single_steps(trav, lanes):
     n = 256
     env = _batch(n, trav, seed=5)
+    env.set_lanes(lanes)
     p = OS.visual_params()
     cells = OS.spawn_cells(trav)
     rng = np.random.RandomState(0)

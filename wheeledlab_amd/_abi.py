@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 7
+WL_ABI_VERSION = 9
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -112,11 +112,12 @@ VIS_OBS_DIM = VIS_NPIX + 8
 class WlEnvBuffers(C.Structure):
     _fields_ = [("state", C.c_void_p), ("episode_len", C.c_void_p), ("ref_poses", C.c_void_p),
                 ("metrics", C.c_void_p), ("stride", C.c_int64), ("n_envs", C.c_int32), ("env_offset", C.c_int32),
-                ("metrics_slots", C.c_int32)]
+                ("metrics_slots", C.c_int32), ("lanes", C.c_int32), ("reserved", C.c_int32)]
 
 
 class WlStepOut(C.Structure):
-    _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p)]
+    _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p),
+                ("dones", C.c_void_p)]
 
 
 _P = C.POINTER

@@ -86,6 +86,7 @@ class DriftBatch:
         # torch.bool is one byte holding 0 / 1: the kernel's uint8 outputs land in it directly
         self.terminated = torch.zeros(self.n, dtype=torch.bool, device=dev)
         self.truncated = torch.zeros(self.n, dtype=torch.bool, device=dev)
+        self.dones = torch.zeros(self.n, dtype=torch.long, device=dev)   # terminated | truncated, as RSL-RL consumes it
         g = torch.Generator().manual_seed(self.seed)
         # reference poses are drawn ONCE at construction (events.py:31,35)
         self.ref_table = torch.zeros(3, 32, dtype=torch.float32)
@@ -94,9 +95,9 @@ class DriftBatch:
         self.ref_table = self.ref_table.to(dev)
         self._startup_events(g, randomize, startup)
         self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), self.ref_table.data_ptr(),
-                                    self.metrics.data_ptr(), self.stride, self.n, self.env_offset, self.metrics_slots)
+                                    self.metrics.data_ptr(), self.stride, self.n, self.env_offset, self.metrics_slots, 0, 0)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
-                                self.truncated.data_ptr())
+                                self.truncated.data_ptr(), self.dones.data_ptr())
 
     # startup events (mushr_drift_env_cfg.py:98-119, 145-154)
     def _startup_events(self, g: torch.Generator, randomize: bool, su=None):
@@ -108,6 +109,11 @@ class DriftBatch:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_lanes(self, lanes: int = 0):
+        """step-kernel form: 0 = by env count (quad up to 32768 envs), 1 = lane per env, 4 = quad per env"""
+        assert lanes in (0, 1, 4)
+        self._bufs.lanes = lanes
 
     def reset(self, mask: torch.Tensor | None = None):
         m = None if mask is None else mask.to(torch.uint8).contiguous()
@@ -137,7 +143,7 @@ class DriftBatch:
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
         if obs_out is not None:
-            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr())
+            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(), None)
             os_, vs_ = self.n * self.OBS_DIM, self.n
         else:
             out, os_, vs_ = self._out, 0, 0
@@ -180,6 +186,7 @@ class ElevBatch:
         self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.terminated = torch.zeros(self.n, dtype=torch.bool, device=dev)
         self.truncated = torch.zeros(self.n, dtype=torch.bool, device=dev)
+        self.dones = torch.zeros(self.n, dtype=torch.long, device=dev)   # terminated | truncated, as RSL-RL consumes it
         h, x0, y0, cell = heightfield if heightfield is not None else synthetic_heightfield()
         self.height = torch.as_tensor(h, dtype=torch.float32).contiguous().to(dev)
         self._hf = A.WlHeightField(self.height.data_ptr(), self.height.shape[1], self.height.shape[0], float(x0), float(y0),
@@ -191,12 +198,17 @@ class ElevBatch:
                                   damping=(1000.0, 1000.0), mass_add=(0.2, 0.5))
         apply_startup_events(self.state, startup, torch.Generator().manual_seed(self.seed))
         self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics.data_ptr(),
-                                    self.stride, self.n, self.env_offset, self.metrics_slots)
+                                    self.stride, self.n, self.env_offset, self.metrics_slots, 0, 0)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
-                                self.truncated.data_ptr())
+                                self.truncated.data_ptr(), self.dones.data_ptr())
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_lanes(self, lanes: int = 0):
+        """step-kernel form: 0 = by env count (quad up to 32768 envs), 1 = lane per env, 4 = quad per env"""
+        assert lanes in (0, 1, 4)
+        self._bufs.lanes = lanes
 
     def reset(self, mask: torch.Tensor | None = None):
         m = None if mask is None else mask.to(torch.uint8).contiguous()
@@ -221,7 +233,7 @@ class ElevBatch:
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
         if obs_out is not None:
-            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr())
+            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(), None)
             os_, vs_ = self.n * self.OBS_DIM, self.n
         else:
             out, os_, vs_ = self._out, 0, 0
@@ -260,6 +272,7 @@ class VisualBatch:
         self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.terminated = torch.zeros(self.n, dtype=torch.bool, device=dev)
         self.truncated = torch.zeros(self.n, dtype=torch.bool, device=dev)
+        self.dones = torch.zeros(self.n, dtype=torch.long, device=dev)   # terminated | truncated, as RSL-RL consumes it
         if trav_map is None:  # generated at construction from a seeded RNG (the reference uses the global numpy RNG)
             trav_map = generate_traversability_map(rng=np.random.RandomState(self.seed), **(map_kwargs or {}))
         trav_map = np.ascontiguousarray(np.asarray(trav_map, dtype=bool))
@@ -272,12 +285,17 @@ class VisualBatch:
             startup = StartupSpec(wheel_mu_s=(0.5, 0.5), wheel_mu_d=(0.5, 0.5), damping=(1000.0, 1000.0), mass_add=(0.0, 0.0))
         apply_startup_events(self.state, startup, torch.Generator().manual_seed(self.seed))
         self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics.data_ptr(),
-                                    self.stride, self.n, self.env_offset, self.metrics_slots)
+                                    self.stride, self.n, self.env_offset, self.metrics_slots, 0, 0)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
-                                self.truncated.data_ptr())
+                                self.truncated.data_ptr(), self.dones.data_ptr())
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_lanes(self, lanes: int = 0):
+        """step-kernel form: 0 = by env count (quad up to 32768 envs), 1 = lane per env, 4 = quad per env"""
+        assert lanes in (0, 1, 4)
+        self._bufs.lanes = lanes
 
     def sample_augmentation(self, generator: torch.Generator | None = None):
         """one (brightness, contrast, blur sigma) per call, like torchvision's ColorJitter(brightness=.8, contrast=.2)
@@ -310,7 +328,7 @@ class VisualBatch:
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
         if obs_out is not None:
-            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr())
+            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(), None)
             os_, vs_ = self.n * self.OBS_DIM, self.n
         else:
             out, os_, vs_ = self._out, 0, 0

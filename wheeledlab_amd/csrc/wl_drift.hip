@@ -252,6 +252,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         out.reward[e] = reward;
         out.terminated[e] = terminated ? 1 : 0;
         out.truncated[e] = truncated ? 1 : 0;
+        if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
     }
     // ---- reset (done envs) ----
     float a0 = a.x, a1 = a.y, timer_hf = r.timer_hf, timer_lf = r.timer_lf;
@@ -408,6 +409,7 @@ __global__ void __launch_bounds__(kBlock) drift_rollout_kernel(const WlDriftPara
         o.reward += k * vec_step_stride;
         o.terminated += k * vec_step_stride;
         o.truncated += k * vec_step_stride;
+        if (o.dones) o.dones += k * vec_step_stride;
         if (active) {
             const float2 a = a_next;
             if (k + 1 < n_steps) a_next = actions[(int64_t)(k + 1) * b.n_envs + e];   // prefetch: hidden behind the physics
@@ -532,7 +534,7 @@ int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
     if (!p || !b || !b->state || !b->episode_len || !b->ref_poses || !b->metrics) return WL_EINVAL;
     if (b->n_envs <= 0 || b->stride < b->n_envs) return WL_EINVAL;
     if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
-    if (b->metrics_slots < 1) return WL_EINVAL;
+    if (b->metrics_slots < 1 || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || p->num_ref_points <= 0 || p->num_ref_points > 32) return WL_EINVAL;
     if (!(p->sim_dt > 0.f)) return WL_EINVAL;
     return WL_OK;
@@ -568,7 +570,7 @@ int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* ac
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated) return WL_EINVAL;
     clear_error();
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
-    if (use_quad(b->n_envs))
+    if (use_quad(b))
         drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
             *p, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{}, vd);
     else
@@ -586,13 +588,14 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
     clear_error();
     const int grid = grid_for(b->n_envs);
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
-    const bool quad = use_quad(b->n_envs);
+    const bool quad = use_quad(b);
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = *out;
         o.obs += k * obs_step_stride;
         o.reward += k * vec_step_stride;
         o.terminated += k * vec_step_stride;
         o.truncated += k * vec_step_stride;
+        if (o.dones) o.dones += k * vec_step_stride;
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
         if (quad)
             drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(

@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
             out.reward[e] = reward;
             out.terminated[e] = terminated ? 1 : 0;
             out.truncated[e] = truncated ? 1 : 0;
+            if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
         }
         float a0 = a.x, a1 = a.y;
         float tgt_x = S.ld(WL_S_TGT_X, e), tgt_y = S.ld(WL_S_TGT_Y, e), tgt_h = S.ld(WL_S_TGT_H, e), cmd_timer = S.ld(WL_S_CMD_TIMER, e);
@@ -424,7 +425,7 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
     const HeightFieldGround g = make_ground(hf);
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
-    const bool quad = use_quad(b->n_envs);
+    const bool quad = use_quad(b);
     clear_error();
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = *out;
@@ -432,6 +433,7 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
         o.reward += k * vec_step_stride;
         o.terminated += k * vec_step_stride;
         o.truncated += k * vec_step_stride;
+        if (o.dones) o.dones += k * vec_step_stride;
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
         if (quad)
             elev_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, a, o, seed, step0 + (uint64_t)k, vd);

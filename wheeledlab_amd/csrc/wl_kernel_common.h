@@ -1,7 +1,6 @@
 // wl_kernel_common.h -- helpers shared by the per-task translation units.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 
 #include "../../include/wheeledlab_amd.h"
 #include "wl_math.h"
@@ -43,11 +42,10 @@ inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 #ifndef WL_QUAD_MAX_ENVS
 #define WL_QUAD_MAX_ENVS 32768
 #endif
-inline bool use_quad(int n_envs) {
-    static const char* force = getenv("WL_FORCE_LANES");   // "1" / "4": testing hook
-    if (force && force[0] == '1') return false;
-    if (force && force[0] == '4') return true;
-    return n_envs <= WL_QUAD_MAX_ENVS;
+inline bool use_quad(const WlEnvBuffers* b) {
+    if (b->lanes == 1) return false;
+    if (b->lanes == 4) return true;
+    return b->n_envs <= WL_QUAD_MAX_ENVS;
 }
 // The host process (PyTorch) may leave a benign sticky error (e.g. hipErrorNotReady from an event query) in this
 // thread's HIP error slot: clear it before the launch so launch_status() reports only our own launch.

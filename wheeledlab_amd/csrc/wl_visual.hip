@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
             out.reward[e] = reward;
             out.terminated[e] = terminated ? 1 : 0;
             out.truncated[e] = truncated ? 1 : 0;
+            if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
         }
         float a0 = a.x, a1 = a.y;
         if (terminated || truncated) {
@@ -435,7 +436,7 @@ int wl_visual_rollout(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
     if (rc != WL_OK) return rc;
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
-    const bool quad = use_quad(b->n_envs);
+    const bool quad = use_quad(b);
     clear_error();
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = *out;
@@ -443,6 +444,7 @@ int wl_visual_rollout(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
         o.reward += k * vec_step_stride;
         o.terminated += k * vec_step_stride;
         o.truncated += k * vec_step_stride;
+        if (o.dones) o.dones += k * vec_step_stride;
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
         if (quad)
             visual_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, a, o, seed, step0 + (uint64_t)k, vd);

@@ -147,28 +147,35 @@ class ObservationManager:
         return {"policy": self._env._batch.observe()}
 
 
+def episode_log_keys(reward_slots, term_names):
+    """key -> (kind, metric index) table of an env's extras["log"] (built once per env)"""
+    keys = {f"Episode_Reward/{n}": ("r", s) for n, s in reward_slots.items()}
+    if "time_out" in term_names:
+        keys[f"Episode_Termination/{term_names['time_out']}"] = ("c", A.M_TIMEOUTS)
+    for k in range(4):
+        if k in term_names:
+            keys[f"Episode_Termination/{term_names[k]}"] = ("c", A.M_TERM0 + k)
+    keys["Metrics/resets"] = ("c", A.M_RESETS)
+    keys["Metrics/nonfinite_envs"] = ("c", A.M_NONFINITE)
+    return keys
+
+
 class EpisodeLog(dict):
     """extras["log"]: IsaacLab's per-reset statistics (`Episode_Reward/<term>` = mean over the envs that were reset of
     episode_sum / episode_length_s; `Episode_Termination/<term>` = count), evaluated LAZILY from one slot of the
-    device-side metric ring so that stepping never synchronises with the host.  Values are 0-dim device tensors;
-    with no reset in the step the means are NaN (IsaacLab would omit the keys: use nanmean, or cfg.sync_episode_log)."""
+    device-side metric ring so that stepping never synchronises with the host (and costs no torch launch unless a
+    value is read).  Values are 0-dim device tensors; with no reset in the step the means are NaN (IsaacLab would
+    omit the keys: use nanmean, or cfg.sync_episode_log)."""
+    __slots__ = ("_metrics", "_idx", "_len_s", "_keys")
 
-    def __init__(self, slot, reward_slots, term_names, episode_length_s):
+    def __init__(self, metrics, idx, keys, episode_length_s):
         super().__init__()
-        self._slot, self._len_s = slot, episode_length_s
-        self._keys = {f"Episode_Reward/{n}": ("r", s) for n, s in reward_slots.items()}
-        if "time_out" in term_names:
-            self._keys[f"Episode_Termination/{term_names['time_out']}"] = ("c", A.M_TIMEOUTS)
-        for k in range(4):
-            if k in term_names:
-                self._keys[f"Episode_Termination/{term_names[k]}"] = ("c", A.M_TERM0 + k)
-        self._keys["Metrics/resets"] = ("c", A.M_RESETS)
-        self._keys["Metrics/nonfinite_envs"] = ("c", A.M_NONFINITE)
+        self._metrics, self._idx, self._keys, self._len_s = metrics, idx, keys, episode_length_s
 
     def __missing__(self, key):
-        kind, idx = self._keys[key]
-        m = self._slot
-        v = m[idx] if kind == "c" else m[A.M_EPSUM0 + idx] / m[A.M_RESETS] / self._len_s
+        kind, i = self._keys[key]
+        m = self._metrics if self._idx is None else self._metrics[self._idx]
+        v = m[i] if kind == "c" else m[A.M_EPSUM0 + i] / m[A.M_RESETS] / self._len_s
         self[key] = v
         return v
 
@@ -236,6 +243,9 @@ class ManagerBasedRLEnv:
         self.observation_space = {"policy": Box(-math.inf, math.inf, (self.num_envs, self._batch.OBS_DIM))}
         self.extras = {}
         self.obs_buf = {}
+        self._log_keys = episode_log_keys(self.reward_manager._slots, flat.termination_names)
+        self._has_custom_rewards = bool(flat.custom_rewards)
+        self._has_curriculum = bool(flat.curriculum)
         self._clip_actions = False
         self._sim_step_counter = 0
 
@@ -282,20 +292,20 @@ class ManagerBasedRLEnv:
     def step(self, action: torch.Tensor):
         b = self._batch
         self.action_manager.prev_action = action
-        slot = b.metrics[b.step_count % b.metrics_slots] if b.metrics_slots > 1 else b.metrics
+        slot = b.step_count % b.metrics_slots if b.metrics_slots > 1 else None   # this step's slot of the metric ring
         if self._task == "visual" and self._flat.extra.get("augment"):
             b.sample_augmentation()       # one ColorJitter / GaussianBlur draw per call, as torchvision does for a batch
         obs, rew, terminated, truncated = b.step(action)
         self.common_step_counter += 1
         self._sim_step_counter += self.cfg.decimation
         # custom (non-fused) reward terms: user torch code on the device, RewardManager semantics
-        for name, term in self._flat.custom_rewards:
-            if term.weight != 0.0:
-                f = term.func
-                rew += f(self, **term.params) * term.weight * self.step_dt
+        if self._has_custom_rewards:
+            for name, term in self._flat.custom_rewards:
+                if term.weight != 0.0:
+                    rew += term.func(self, **term.params) * term.weight * self.step_dt
         # curriculum: evaluated inside _reset_idx in IsaacLab, i.e. on steps where >= 1 env resets; every built-in
         # term is a no-op off episode boundaries, so the (synchronising) any() runs once per max_episode_length steps
-        if self._flat.curriculum and self.common_step_counter % self.max_episode_length == 0:
+        if self._has_curriculum and self.common_step_counter % self.max_episode_length == 0:
             if bool((terminated | truncated).any()):
                 for name, term in self._flat.curriculum:
                     term.func(self, None, **term.params)
@@ -310,7 +320,7 @@ class ManagerBasedRLEnv:
         return self.obs_buf, rew, terminated, truncated, self.extras
 
     def _episode_log(self, slot):
-        return EpisodeLog(slot, self.reward_manager._slots, self._flat.termination_names, self.max_episode_length_s)
+        return EpisodeLog(self._batch.metrics, slot, self._log_keys, self.max_episode_length_s)
 
     def episode_metrics(self, window: int | None = None, reduce_ranks: bool = True):
         """aggregate of the last `window` per-step metric slots as one [WL_M_COUNT] vector; across ranks it is ONE

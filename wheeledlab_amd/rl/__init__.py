@@ -81,7 +81,7 @@ class RslRlVecEnvWrapper:
 
     def step(self, actions):
         obs, rew, terminated, truncated, extras = self.env.step(actions)
-        dones = (terminated | truncated).to(torch.long)
+        dones = self.unwrapped._batch.dones   # int64 terminated | truncated, written by the step kernel
         extras["observations"] = obs
         if not self.unwrapped.cfg.is_finite_horizon:
             extras["time_outs"] = truncated
