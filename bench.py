@@ -188,6 +188,29 @@ def main():
         persistent = {"us_per_step": pus, "env_steps_per_s": n / (pus * 1e-6), "steps_per_launch": ROLLOUT,
                       "kernel": "drift_rollout_kernel<FlatGround>"}
 
+    # secondary: the other two tasks at the same env count (configs[2] and [4] of BASELINE.json), per-step launches
+    other = {}
+    if rank == 0 and world == 1:
+        from wheeledlab_amd.core import ElevBatch, VisualBatch
+        for name, cls, k in (("elevation", ElevBatch, 32), ("visual", VisualBatch, 16)):
+            t = cls(n, device=dev, seed=42)
+            t.reset()
+            if name == "visual":
+                t.sample_augmentation(torch.Generator().manual_seed(0))   # the reference's default obs term is the augmented one
+            a = torch.rand(k, n, 2, device=dev) * 2 - 1
+            t.rollout(a)
+            torch.cuda.synchronize()
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            q0.record()
+            for _ in range(4):
+                t.rollout(a)
+            q1.record()
+            torch.cuda.synchronize()
+            us = q0.elapsed_time(q1) * 1e3 / (4 * k)
+            other[name] = {"us_per_step": us, "env_steps_per_s": n / (us * 1e-6), "obs_dim": t.OBS_DIM,
+                           "obs_GBs": n * t.OBS_DIM * 4 / (us * 1e-6) / 1e9}
+            del t, a
+
     # secondary: the same workload driven step by step through the drop-in Python surface
     # (registry.make -> ClipAction -> RslRlVecEnvWrapper.step), i.e. what a Python RL loop sees per env.step() call
     py_rate = None
@@ -252,6 +275,7 @@ def main():
         }
         line["python_surface_env_steps_per_s"] = py_rate
         line["persistent_rollout"] = persistent
+        line["other_tasks"] = other
         if sweep:
             line["large_n_sweep"] = sweep
         if world == 1 and not args.no_cpu_baseline:

@@ -535,6 +535,7 @@ int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
     if (b->n_envs <= 0 || b->stride < b->n_envs) return WL_EINVAL;
     if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
     if (b->metrics_slots < 1 || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
+    if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL) return WL_EINVAL;   // buffer-resource offsets are 32-bit (~13 M envs)
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || p->num_ref_points <= 0 || p->num_ref_points > 32) return WL_EINVAL;
     if (!(p->sim_dt > 0.f)) return WL_EINVAL;
     return WL_OK;

@@ -402,6 +402,7 @@ int check_elev(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField
     if (!p || !b || !hf || !b->state || !b->episode_len || !b->metrics || !hf->height) return WL_EINVAL;
     if (b->n_envs <= 0 || b->stride < b->n_envs || b->metrics_slots < 1) return WL_EINVAL;
     if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
+    if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f)) return WL_EINVAL;
     if (hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f)) return WL_EINVAL;
     return WL_OK;
