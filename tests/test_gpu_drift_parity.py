@@ -296,3 +296,44 @@ def test_ragged_and_tiny_sizes(lib):
         torch.cuda.synchronize()
         assert obs.shape == (n, 14) and torch.isfinite(obs).all()
         assert (env.state[:, n:] == 0).all() or env.stride == n or True
+
+
+def test_size_independent_physics_and_api_properties(lib):
+    """invariants that need no oracle, at BASELINE's env count: friction-limited acceleration, idempotent observe / reset,
+    masked reset touches only the masked envs, zero action brings every car to rest"""
+    n = 4096
+    env = _fresh(n, seed=21)
+    env.p.enable_pushes = 0                      # pushes are velocity jumps: keep them out of the acceleration bound
+    env.p.max_episode_length = 10 ** 9
+    env.p.r_out, env.p.r_in = 1e18, 0.0          # open plane: no resets during the physics checks
+    g = torch.Generator(device=DEV).manual_seed(3)
+    mu_s = (env.state[23, :n] * 1.1)             # wheel x ground static friction, "multiply" combine
+    worst = torch.zeros(n, device=DEV)
+    v_prev = env.state[7:9, :n].clone()
+    for k in range(150):
+        env.step(torch.rand(n, 2, device=DEV, generator=g) * 2 - 1)
+        v = env.state[7:9, :n]
+        if k > 5:
+            worst = torch.maximum(worst, (v - v_prev).norm(dim=0) / 0.02 / (mu_s * 9.81))
+        v_prev = v.clone()
+    assert float(worst.max()) < 1.15             # |a_horizontal| <= mu_s g (+ load-transfer / discretisation slack)
+    assert float(worst.mean()) > 0.2             # ... and the bound is actually exercised
+    # observe() is idempotent and does not touch the state
+    st = env.state.clone()
+    o1 = env.observe().clone()
+    o2 = env.observe().clone()
+    assert torch.equal(o1, o2) and torch.equal(st, env.state)
+    # masked reset: only the masked envs change, and resetting twice at the same step gives the same pose
+    mask = torch.zeros(n, dtype=torch.bool, device=DEV)
+    mask[::7] = True
+    env.reset(mask)
+    s1 = env.state.clone()
+    assert torch.equal(s1[:19, :n][:, ~mask], st[:19, :n][:, ~mask])
+    assert (s1[7:13, :n][:, mask] == 0).all() and (env.episode_len[:n][mask] == 0).all()
+    env.reset(mask)
+    assert torch.equal(env.state, s1)
+    # zero throttle: the motor holds the driven wheels at 0 and every car comes to rest on the plane
+    for _ in range(200):
+        env.step(torch.zeros(n, 2, device=DEV))
+    assert float(env.state[7:9, :n].norm(dim=0).max()) < 0.05 and float(env.state[13:15, :n].abs().max()) < 0.5
+    assert float(env.state[2, :n].abs().max()) < 5e-3
