@@ -47,9 +47,30 @@ WL_DEV ResetDraw draw_reset(const WlDriftParams& p, const float* __restrict__ re
 }
 
 // BlindObsCfg.PolicyCfg (wheeledlab_tasks/common/observations.py:24-54) into this wave's LDS tile
+// quad form: the 14 observation values are replicated on the four lanes of the env's quad, so each lane stores its
+// quarter as 8-byte words -- a wavefront (16 envs) writes one contiguous 896-byte run, no LDS transpose needed
+WL_DEV void store_obs_quad(float* __restrict__ row /* obs + e * 14 */, int wid, const float o[14]) {
+    float2* r2 = reinterpret_cast<float2*>(row);   // 56 B per env: 8-byte aligned
+    const float2 a = wid == 0 ? make_float2(o[0], o[1]) : wid == 1 ? make_float2(o[4], o[5]) : wid == 2 ? make_float2(o[8], o[9])
+                                                                                                       : make_float2(o[12], o[13]);
+    r2[wid * 2] = a;
+    if (wid < 3) {
+        const float2 c = wid == 0 ? make_float2(o[2], o[3]) : wid == 1 ? make_float2(o[6], o[7]) : make_float2(o[10], o[11]);
+        r2[wid * 2 + 1] = c;
+    }
+}
+
 struct Noise12 {
     float z[12];
 };
+
+WL_DEV void obs_values(float o14[14], const WlDriftParams& p, V3 pos, V3 e, V3 vb, V3 wb, float a0, float a1, const Noise12& nz) {
+    const float o[12] = {pos.x, pos.y, pos.z, e.x, e.y, e.z, vb.x, vb.y, vb.z, wb.x, wb.y, wb.z};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o14[k] = fmaf(p.noise_std[k / 3], nz.z[k], o[k]);
+    o14[12] = clampf(a0, -1.f, 1.f);
+    o14[13] = clampf(a1, -1.f, 1.f);
+}
 
 WL_DEV void write_obs_row(float* row, const WlDriftParams& p, V3 pos, V3 e /* euler xyz, wrapped */, V3 vb, V3 wb, float a0,
                           float a1, const Noise12& nz /* 12 standard normals (zeros when corruption is off) */) {
@@ -177,6 +198,19 @@ WL_DEV void load_env_const(const Rows& S, const WlVehicleParams& vp, const VehDe
     ec.damp = S.ld(WL_S_DAMP, e);
 }
 
+// Episode-metric accumulation.  Lane form: LDS atomics per block, <= 16 global atomics per block at the end (many
+// resets per block at large n).  Quad form: resets are rare per wavefront (16 envs), so the few lead lanes that reset go
+// straight to the global accumulators and the kernel needs no LDS and no block barrier at all.
+template <int LANES>
+struct MetricSink {
+    float* lds;     // block accumulators (lane form)
+    float* glob;    // this step's slot of the metric ring
+    WL_DEV void add(int idx, float v) const {
+        if constexpr (LANES == 4) atomicAdd(glob + idx, v);
+        else atomicAdd(lds + idx, v);
+    }
+};
+
 // ONE env.step() on the register image `r` (shared by the per-step kernel and the persistent rollout kernel): action
 // term -> physics -> terminations -> rewards -> reset -> pushes -> observation row into the block's LDS tile.
 // Writes reward / flags to `out` (already offset to this step); accumulates episode metrics into `blk_metrics` (LDS).
@@ -184,7 +218,7 @@ template <int LANES, class Ground>
 WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const VehDerived& vd, const Ground& ground,
                            const Rows& S, EnvConst& ec, DriftRows& r, float2 a, const float* __restrict__ noise,
                            const WlStepOut& out, int e, int le, int wid, bool lead, uint32_t gid, uint64_t seed, uint64_t step,
-                           float* tile, float* blk_metrics) {
+                           float* tile, const MetricSink<LANES>& ms) {
     const WlVehicleParams& vp = p.vehicle;
     // ---- action manager: ClipAction + process_actions + joint targets (once per env-step) ----
     float v_t, delta;
@@ -259,12 +293,12 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     if (terminated || truncated) {
         if (lead) {
 #pragma unroll
-            for (int i = 0; i < WL_DR_NTERMS; ++i) atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
-            atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
-            if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
-            if (terminated) atomicAdd(&blk_metrics[WL_M_TERM0], 1.f);
-            if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
-            atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
+            for (int i = 0; i < WL_DR_NTERMS; ++i) ms.add(WL_M_EPSUM0 + i, epsum[i]);
+            ms.add(WL_M_RESETS, 1.f);
+            if (truncated) ms.add(WL_M_TIMEOUTS, 1.f);
+            if (terminated) ms.add(WL_M_TERM0, 1.f);
+            if (!finite) ms.add(WL_M_NONFINITE, 1.f);
+            ms.add(WL_M_EPLEN, (float)ep_len);
         }
 #pragma unroll
         for (int i = 0; i < WL_DR_NTERMS; ++i) epsum[i] = 0.f;
@@ -330,7 +364,13 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     const V3 wb2 = mul_t(R2, ww);
     const Noise12 nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // all lanes of the quad
     if constexpr (LANES == 1) euler = euler_xyz_from_quat(s.q);
-    if (lead) write_obs_row(&tile[le * kObsPad], p, pos, euler, vb, wb2, a0, a1, nz);
+    if constexpr (LANES == 4) {
+        float o[14];
+        obs_values(o, p, pos, euler, vb, wb2, a0, a1, nz);
+        store_obs_quad(out.obs + (int64_t)e * kObsDim, wid, o);
+    } else {
+        write_obs_row(&tile[le * kObsPad], p, pos, euler, vb, wb2, a0, a1, nz);
+    }
 }
 
 // LANES = 1: lane per env (throughput form).  LANES = 4: quad per env, one wheel per lane (latency form, small n).
@@ -341,18 +381,21 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
                                                             const uint64_t seed, const uint64_t step, const Ground ground,
                                                             const VehDerived vd) {
     constexpr int kEnvs = kBlock / LANES;   // envs per block
-    __shared__ float tile[kEnvs * kObsPad];
-    __shared__ float blk_metrics[WL_M_COUNT];
+    __shared__ float tile[LANES == 1 ? kEnvs * kObsPad : 1];      // lane form only: obs transposing tile
+    __shared__ float blk_metrics[WL_M_COUNT];                      // lane form only
     const int le = threadIdx.x / LANES;             // env slot within the block
     const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);   // this lane's wheel (quad form)
     const bool lead = LANES == 1 || wid == 0;       // the lane that writes the env's shared rows / outputs
     const int e = blockIdx.x * kEnvs + le;
-    if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
     // per-step metric ring: accumulate into slot step % R, clear the slot the NEXT launch will use
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
     if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
         b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
-    __syncthreads();
+    const MetricSink<LANES> ms{blk_metrics, b.metrics + m_slot * WL_M_COUNT};
+    if constexpr (LANES == 1) {
+        if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
+        __syncthreads();
+    }
     if (e < b.n_envs) {
         const Rows S = make_rows(b.state, b.stride);
         EnvConst ec;
@@ -361,14 +404,16 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         load_env_const(S, p.vehicle, vd, e, ec);
         load_rows<LANES>(S, b, p, e, wid, r);
         drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, le, wid, lead, (uint32_t)(b.env_offset + e), seed,
-                              step, tile, blk_metrics);
+                              step, tile, ms);
         store_rows<LANES>(S, b, p, e, wid, lead, r);
     }
-    __syncthreads();
-    flush_obs(tile, out.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
-    if (threadIdx.x < WL_M_COUNT) {
-        const float m = blk_metrics[threadIdx.x];
-        if (m != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], m);
+    if constexpr (LANES == 1) {
+        __syncthreads();
+        flush_obs(tile, out.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
+        if (threadIdx.x < WL_M_COUNT) {
+            const float m = blk_metrics[threadIdx.x];
+            if (m != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], m);
+        }
     }
 }
 
@@ -383,26 +428,20 @@ __global__ void __launch_bounds__(kBlock) drift_rollout_kernel(const WlDriftPara
                                                                const int n_steps, const uint64_t seed, const uint64_t step0,
                                                                const Ground ground, const VehDerived vd) {
     constexpr int LANES = 4, kEnvs = kBlock / LANES;
-    __shared__ float tile[kEnvs * kObsPad];
-    __shared__ float blk_metrics[WL_M_COUNT];
     const int le = threadIdx.x / LANES, wid = threadIdx.x & 3;
     const bool lead = wid == 0;
     const int e = blockIdx.x * kEnvs + le;
-    const bool active = e < b.n_envs;
-    if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
     const int m_slot = b.metrics_slots > 1 ? (int)(step0 % (uint64_t)b.metrics_slots) : 0;
     if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
         b.metrics[(int)((step0 + (uint64_t)n_steps) % (uint64_t)b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
-    __syncthreads();
+    if (e >= b.n_envs) return;     // the quad form has no block-level barrier: whole quads may leave
+    const MetricSink<LANES> ms{nullptr, b.metrics + m_slot * WL_M_COUNT};
     const Rows S = make_rows(b.state, b.stride);
     EnvConst ec;
     DriftRows r;
-    float2 a_next = make_float2(0.f, 0.f);
-    if (active) {
-        load_env_const(S, p.vehicle, vd, e, ec);
-        load_rows<LANES>(S, b, p, e, wid, r);
-        if (n_steps > 0) a_next = actions[e];
-    }
+    load_env_const(S, p.vehicle, vd, e, ec);
+    load_rows<LANES>(S, b, p, e, wid, r);
+    float2 a_next = n_steps > 0 ? actions[e] : make_float2(0.f, 0.f);
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = out;
         o.obs += k * obs_step_stride;
@@ -410,21 +449,12 @@ __global__ void __launch_bounds__(kBlock) drift_rollout_kernel(const WlDriftPara
         o.terminated += k * vec_step_stride;
         o.truncated += k * vec_step_stride;
         if (o.dones) o.dones += k * vec_step_stride;
-        if (active) {
-            const float2 a = a_next;
-            if (k + 1 < n_steps) a_next = actions[(int64_t)(k + 1) * b.n_envs + e];   // prefetch: hidden behind the physics
-            drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, nullptr, o, e, le, wid, lead, (uint32_t)(b.env_offset + e), seed,
-                                  step0 + (uint64_t)k, tile, blk_metrics);
-        }
-        __syncthreads();
-        flush_obs(tile, o.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
-        __syncthreads();   // the tile is rewritten by the next step
+        const float2 a = a_next;
+        if (k + 1 < n_steps) a_next = actions[(int64_t)(k + 1) * b.n_envs + e];   // prefetch: hidden behind the physics
+        drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, nullptr, o, e, le, wid, lead, (uint32_t)(b.env_offset + e), seed,
+                              step0 + (uint64_t)k, nullptr, ms);
     }
-    if (active) store_rows<LANES>(S, b, p, e, wid, lead, r);
-    if (threadIdx.x < WL_M_COUNT) {
-        const float m = blk_metrics[threadIdx.x];
-        if (m != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], m);
-    }
+    store_rows<LANES>(S, b, p, e, wid, lead, r);
 }
 
 // ---- terms only, on caller-supplied state tensors (parity entry point) -----------------------------------
