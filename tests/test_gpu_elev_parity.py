@@ -6,7 +6,6 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import elev_mdp as OE
 from oracle import elev_step as OS
 from oracle import heightfield as OH
 

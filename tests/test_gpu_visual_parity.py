@@ -28,7 +28,6 @@ def _batch(n, trav, seed=3):
 
 
 def test_visual_mdp_kernel_matches_reference_golden(golden, trav):
-    from wheeledlab_amd import _abi as A
     env = _batch(64, trav)
     for name, key_pos in (("visual_mdp", "pos"), ("visual_trav", "xy")):
         g = golden(name)

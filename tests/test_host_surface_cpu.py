@@ -1,7 +1,5 @@
 """Host logic of the drop-in surface that needs no GPU: configclass semantics, the task registry, cfg -> kernel
 parameter flattening, curriculum scalar logic against the reference's golden trajectory."""
-import ctypes as C
-
 import numpy as np
 import pytest
 

@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import _abi as A
-from .params import MUSHR_CHASSIS_MASS, drift_params
+from .params import drift_params
 
 
 def stadium_reference_poses(u: torch.Tensor, track_radius: float = 0.8, straight: float = 0.8) -> torch.Tensor:

@@ -4,7 +4,6 @@
 from __future__ import annotations
 
 import copy
-import inspect
 import types
 
 MISSING = type("MISSING", (), {"__repr__": lambda s: "MISSING", "__deepcopy__": lambda s, m: s, "__copy__": lambda s: s})()

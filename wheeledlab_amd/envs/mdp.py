@@ -7,7 +7,6 @@ struct, so the hot path never calls it.  Called directly (user code, tests), it 
 entry point `wl_drift_mdp` on the env's current state -- there is one implementation of the arithmetic, in csrc/."""
 from __future__ import annotations
 
-import ctypes as C
 import math
 
 import torch
@@ -256,12 +255,8 @@ def is_falling_penalty(env, max_body_z_vel: float = 0.10):      # :251-254 (the 
     return _elev(env)["terms"][2] > 0.5
 
 
-def forward_vel(env):                                           # elevation :155-157 clamps at 1.2; visual :370-371 does not
-    v = base_lin_vel(env)[:, 0]
-    return torch.clamp(v, max=1.2) if getattr(env, "_task", "") == "elevation" else v
-
-
-forward_vel.wl_kind, forward_vel.wl_slot, forward_vel.wl_params = "reward", 1, {}   # visual reward slot
+def forward_vel_capped(env, cap: float = 1.2):                  # elevation :155-157 (used inside `stuck`)
+    return torch.clamp(base_lin_vel(env)[:, 0], max=cap)
 
 
 @_kernel_term("termination", 0, {"minimum_height": "min_height"})
@@ -310,6 +305,11 @@ def reset_root_state_uniform(env, env_ids, pose_range, velocity_range, asset_cfg
 @_kernel_term("reward", 0)
 def traversable_reward(env):                                    # :309-312
     return env._eval_visual_terms()["terms"][0]
+
+
+@_kernel_term("reward", 1)
+def forward_vel(env):                                           # visual :370-371: body-frame forward speed
+    return base_lin_vel(env)[:, 0]
 
 
 def is_traversable(env):                                        # :304-307
