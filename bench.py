@@ -188,6 +188,46 @@ def main():
         persistent = {"us_per_step": pus, "env_steps_per_s": n / (pus * 1e-6), "steps_per_launch": ROLLOUT,
                       "kernel": "drift_rollout_kernel<FlatGround>"}
 
+    # secondary: the reference runner's whole collection loop (actor MLP -> sample -> env.step, 128 steps per env,
+    # rsl_rl_ppo_cfg.py:6) as ONE launch with the actor on the f32 matrix pipe + the critic over the stored observations;
+    # next to it the same loop with per-step launches and the actor in torch (what a rsl_rl user runs today)
+    policy = None
+    if rank == 0 and world == 1 and n <= 32768:
+        from wheeledlab_amd.policy import ActorCritic, RolloutStorage
+        ac = ActorCritic(device=dev, seed=0)
+        store = RolloutStorage(ROLLOUT, n, device=dev)
+        env.observe()
+        env.rollout_policy(ac, store)
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(reps):
+            env.rollout_policy(ac, store)
+        c1.record()
+        torch.cuda.synchronize()
+        cus = c0.elapsed_time(c1) * 1e3 / (reps * ROLLOUT)
+        lin = [torch.nn.Linear(14, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 2)]
+        actor_t = torch.nn.Sequential(lin[0], torch.nn.ELU(), lin[1], torch.nn.ELU(), lin[2]).to(dev)
+        obs_t = env.obs
+        with torch.inference_mode():
+            for timed in (False, True):
+                if timed:
+                    torch.cuda.synchronize()
+                    c0.record()
+                for _ in range(ROLLOUT):
+                    mu = actor_t(obs_t)
+                    a_t = mu + ac.std * torch.randn_like(mu)
+                    obs_t, _, _, _ = env.step(a_t)
+            c1.record()
+            torch.cuda.synchronize()
+        tus = c0.elapsed_time(c1) * 1e3 / ROLLOUT
+        policy = {"us_per_step": cus, "env_steps_per_s": n / (cus * 1e-6), "steps_per_launch": ROLLOUT,
+                  "includes": "actor 14-64-64-2 ELU (fp32 MFMA), Gaussian sampling, log-prob, env.step, storage rows, "
+                              "critic over K+1 observations",
+                  "kernel": "drift_policy_rollout_kernel<ELU, FlatGround> + mlp_forward_kernel<ELU>",
+                  "per_step_launch_torch_actor_us_per_step": tus,
+                  "per_step_launch_torch_actor_env_steps_per_s": n / (tus * 1e-6)}
+
     # secondary: the other two tasks at the same env count (configs[2] and [4] of BASELINE.json), per-step launches
     other = {}
     if rank == 0 and world == 1:
@@ -275,6 +315,7 @@ def main():
         }
         line["python_surface_env_steps_per_s"] = py_rate
         line["persistent_rollout"] = persistent
+        line["policy_rollout"] = policy
         line["other_tasks"] = other
         if sweep:
             line["large_n_sweep"] = sweep

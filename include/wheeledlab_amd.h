@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 9
+#define WL_ABI_VERSION 10
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -195,11 +195,60 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
  * across the K steps; per step only the action is read and obs / reward / flags are written.  Results are identical to
  * K calls of wl_drift_step.  Episode metrics of all K steps accumulate into ring slot (step0 % R) and slot
  * ((step0 + K) % R) is cleared for the next launch (K % R must not be 0 when R > 1).  For pre-staged action sequences
- * (open-loop evaluation, sampling-based MPC); a policy in the loop needs wl_drift_step.
+ * (open-loop evaluation, sampling-based MPC); a policy in the loop needs wl_drift_step or wl_drift_rollout_policy.
  */
 int wl_drift_rollout_persistent(const WlDriftParams* p, const WlEnvBuffers* b, const float* actions,
                                 const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps,
                                 uint64_t seed, uint64_t step0, void* stream);
+
+/* ---- policy in the loop (the rollout loop of modified_rsl_rl_runner.py:70-80) ------------- */
+enum WlActivation { WL_ACT_RELU = 0, WL_ACT_ELU = 1 };
+
+/*
+ * One MLP of RSL-RL's ActorCritic as the drift agents configure it (rsl_rl_ppo_cfg.py:12-17: hidden dims [64, 64],
+ * activation "elu"): y = W3 act(W2 act(W1 x + b1) + b2) + b3.  Device pointers, fp32, torch nn.Linear layout
+ * (weight [out][in] row-major).
+ */
+typedef struct WlMlp {
+    const float* w1; const float* b1;   /* [64][in_dim], [64] */
+    const float* w2; const float* b2;   /* [64][64], [64] */
+    const float* w3; const float* b3;   /* [out_dim][64], [out_dim] */
+    int32_t in_dim;      /* 1..15 (drift observation: 14) */
+    int32_t out_dim;     /* 1..4  (actor: 2 action means; critic: 1 value) */
+    int32_t hidden;      /* must be 64 */
+    int32_t activation;  /* WlActivation */
+} WlMlp;
+
+/*
+ * y[n_rows][out_dim] = mlp(x[n_rows][in_dim]) on the f32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 products and
+ * sums, i.e. a plain fp32 MLP up to summation order).  Used for the critic over a collected rollout and as the parity
+ * entry point of the in-loop actor.
+ */
+int wl_mlp_forward(const WlMlp* net, int32_t n_rows, const float* x, float* y, void* stream);
+
+/* Rows of RSL-RL's RolloutStorage that the collection loop fills, K = n_steps, all device pointers, [step][env] major. */
+typedef struct WlPolicyRollout {
+    float* obs;            /* [K + 1][n][14]: row 0 = the current observation (INPUT), rows 1..K are written */
+    float* actions;        /* [K][n][2] sampled actions a = mu + sigma * N(0, 1), before ClipAction */
+    float* mu;             /* [K][n][2] actor output */
+    float* log_prob;       /* [K][n] sum over the 2 action dims of log N(a; mu, sigma) */
+    float* reward;         /* [K][n] */
+    uint8_t* terminated;   /* [K][n] */
+    uint8_t* truncated;    /* [K][n] ("time_outs": the caller bootstraps rewards with gamma * V on these) */
+    int64_t* dones;        /* [K][n] terminated | truncated, or NULL */
+} WlPolicyRollout;
+
+/*
+ * The rollout loop of the reference's runner (modified_rsl_rl_runner.py:70-80: `actions = alg.act(obs)`;
+ * `obs, rewards, dones, infos = env.step(actions)`) for K steps as ONE persistent launch: per step the actor MLP runs on
+ * the matrix pipe on the observation the env step just produced (still in registers), the action is sampled
+ * (Philox stream 7, keyed like every other draw by (seed, global env id, step)), the env is stepped exactly as
+ * wl_drift_step does, and the transition is written to the storage rows.  `action_std` is a device pointer to the 2
+ * standard deviations (RSL-RL's `ActorCritic.std`).  The critic is not on the loop's dependency chain: evaluate it
+ * over obs[0..K] afterwards with wl_mlp_forward.  Episode metrics as in wl_drift_rollout_persistent.
+ */
+int wl_drift_rollout_policy(const WlDriftParams* p, const WlEnvBuffers* b, const WlMlp* actor, const float* action_std,
+                            const WlPolicyRollout* io, int32_t n_steps, uint64_t seed, uint64_t step0, void* stream);
 
 /*
  * Drift mdp terms only, on caller-supplied state tensors (the parity entry point: "outputs match the reference

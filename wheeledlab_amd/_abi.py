@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 9
+WL_ABI_VERSION = 10
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -120,6 +120,20 @@ class WlStepOut(C.Structure):
                 ("dones", C.c_void_p)]
 
 
+ACT_RELU, ACT_ELU = 0, 1
+
+
+class WlMlp(C.Structure):
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p),
+                ("b3", C.c_void_p), ("in_dim", C.c_int32), ("out_dim", C.c_int32), ("hidden", C.c_int32),
+                ("activation", C.c_int32)]
+
+
+class WlPolicyRollout(C.Structure):
+    _fields_ = [("obs", C.c_void_p), ("actions", C.c_void_p), ("mu", C.c_void_p), ("log_prob", C.c_void_p),
+                ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("dones", C.c_void_p)]
+
+
 _P = C.POINTER
 _vp, _u64, _i32, _i64 = C.c_void_p, C.c_uint64, C.c_int32, C.c_int64
 
@@ -133,6 +147,9 @@ SIGNATURES = {
                                    _u64, _vp]),
     "wl_drift_rollout_persistent": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _P(WlStepOut), _i64, _i64, _i32,
                                               _u64, _u64, _vp]),
+    "wl_mlp_forward": (C.c_int, [_P(WlMlp), _i32, _vp, _vp, _vp]),
+    "wl_drift_rollout_policy": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _P(WlMlp), _vp, _P(WlPolicyRollout), _i32,
+                                          _u64, _u64, _vp]),
     "wl_drift_mdp": (C.c_int, [_P(WlDriftParams), _i32, _i64] + [_vp] * 12),
     "wl_action_map": (C.c_int, [_P(WlActionParams), _i32, _vp, _vp, _vp, _vp, _vp]),
     "wl_drift_reset": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _u64, _u64, _vp]),

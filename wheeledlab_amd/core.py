@@ -152,6 +152,29 @@ class DriftBatch:
                    self.step_count, self._stream()), "wl_drift_rollout")
         self.step_count += K
 
+    def rollout_policy(self, actor_critic, storage, evaluate_critic: bool = True):
+        """The runner's collection loop (modified_rsl_rl_runner.py:70-80) as one launch: storage.n_steps times
+        { actor(obs) on the matrix pipe -> sample -> env.step } with the env state and the observation in registers
+        (wl_drift_rollout_policy); then the critic over all K + 1 observations in one wl_mlp_forward.
+        storage.observations[0] is seeded with the current observation; self.obs ends as the last one."""
+        K = storage.n_steps
+        assert storage.n_envs == self.n and actor_critic.actor.in_dim == self.OBS_DIM
+        storage.observations[0].copy_(self.obs)
+        actor, io = actor_critic.actor.struct(), storage.struct()
+        A.check(self.lib.wl_drift_rollout_policy(C.byref(self.p), C.byref(self._bufs), C.byref(actor),
+                                                 actor_critic.std.data_ptr(), C.byref(io), K, self.seed, self.step_count,
+                                                 self._stream()), "wl_drift_rollout_policy")
+        self.step_count += K
+        if K > 0:
+            self.obs.copy_(storage.observations[K])
+            self.reward.copy_(storage.rewards[K - 1])
+            self.terminated.copy_(storage.terminated[K - 1])
+            self.truncated.copy_(storage.time_outs[K - 1])
+            self.dones.copy_(storage.dones[K - 1])
+        if evaluate_critic:
+            storage.values.copy_(actor_critic.critic(storage.observations).squeeze(-1))
+        return storage
+
     def read_metrics(self, zero: bool = True) -> torch.Tensor:
         m = self.metrics.clone()
         if zero:

@@ -1,0 +1,389 @@
+// wl_drift_env.h -- device code of ONE drift-task env.step() on a register image of the env's state rows: reset draw,
+// observation noise / layout, row load / store, episode-metric sink and drift_env_step<LANES, Ground> itself.  Shared by
+// the step / rollout kernels (wl_drift.hip) and the policy-in-the-loop rollout kernel (wl_policy.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/wheeledlab_amd.h"
+#include "wl_kernel_common.h"
+#include "wl_drift_terms.h"
+#include "wl_rng.h"
+#include "wl_vehicle.h"
+
+namespace {
+
+#ifndef WL_MIN_WAVES
+#define WL_MIN_WAVES 2   // __launch_bounds__ 2nd argument = waves per SIMD the register allocator must leave room for
+#endif
+constexpr int kObsDim = 14;
+constexpr int kObsPad = 15;  // odd LDS row pitch: the transposing writes are bank-conflict free
+
+struct ResetDraw {
+    V3 pos;
+    Quat q;
+    float yaw;   // the drawn yaw (rad, unwrapped): roll = pitch = 0, so the reset pose's Euler angles are (0, 0, yaw)
+    float timer_hf, timer_lf;
+};
+
+// reset_root_state_along_track.__call__ (drifting/mdp/events.py:119-133) + EventManager.reset interval re-arm
+WL_DEV ResetDraw draw_reset(const WlDriftParams& p, const float* __restrict__ ref, uint32_t gid, uint64_t step,
+                            uint64_t seed) {
+    const F4 u = philox_uniform4(gid, step, WL_RS_RESET, seed);
+    const int idx = min((int)(u.x * (float)p.num_ref_points), p.num_ref_points - 1);
+    ResetDraw r;
+    r.pos = v3(fmaf(2.f * u.y - 1.f, p.pos_noise, ref[idx]), fmaf(2.f * u.z - 1.f, p.pos_noise, ref[32 + idx]), 0.f);
+    const float yaw = fmaf(2.f * u.w - 1.f, p.yaw_noise, ref[64 + idx]);
+    float s, c;
+    sincos_fast(0.5f * yaw, s, c);
+    r.q = Quat{c, 0.f, 0.f, s};
+    r.yaw = yaw;
+    const F4 t = philox_uniform4(gid, step, WL_RS_TIMERS, seed);
+    r.timer_hf = fmaf(t.x, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
+    r.timer_lf = fmaf(t.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
+    return r;
+}
+
+// BlindObsCfg.PolicyCfg (wheeledlab_tasks/common/observations.py:24-54) into this wave's LDS tile
+// quad form: the 14 observation values are replicated on the four lanes of the env's quad, so each lane stores its
+// quarter as 8-byte words -- a wavefront (16 envs) writes one contiguous 896-byte run, no LDS transpose needed
+// by-value pick of this lane's element: the operands are SSA values, so the selection is three v_cndmask.  (Written as
+// a ternary chain over array elements the compiler folds it into a wid-indexed load of the array, which then lives in
+// scratch memory -- a store -> load round trip on the critical tail of the step.)
+WL_DEV float quad_pick(int wid, float a, float b, float c, float d) { return wid == 0 ? a : wid == 1 ? b : wid == 2 ? c : d; }
+
+WL_DEV void store_obs_quad(float* __restrict__ row /* obs + e * 14 */, int wid, const float o[14]) {
+    float2* r2 = reinterpret_cast<float2*>(row);   // 56 B per env: 8-byte aligned
+    r2[wid * 2] = make_float2(quad_pick(wid, o[0], o[4], o[8], o[12]), quad_pick(wid, o[1], o[5], o[9], o[13]));
+    const float2 c = make_float2(quad_pick(wid, o[2], o[6], o[10], 0.f), quad_pick(wid, o[3], o[7], o[11], 0.f));
+    if (wid < 3) r2[wid * 2 + 1] = c;
+}
+
+struct Noise12 {
+    float z[12];
+};
+
+WL_DEV void obs_values(float o14[14], const WlDriftParams& p, V3 pos, V3 e, V3 vb, V3 wb, float a0, float a1, const Noise12& nz) {
+    const float o[12] = {pos.x, pos.y, pos.z, e.x, e.y, e.z, vb.x, vb.y, vb.z, wb.x, wb.y, wb.z};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o14[k] = fmaf(p.noise_std[k / 3], nz.z[k], o[k]);
+    o14[12] = clampf(a0, -1.f, 1.f);
+    o14[13] = clampf(a1, -1.f, 1.f);
+}
+
+WL_DEV void write_obs_row(float* row, const WlDriftParams& p, V3 pos, V3 e /* euler xyz, wrapped */, V3 vb, V3 wb, float a0,
+                          float a1, const Noise12& nz /* 12 standard normals (zeros when corruption is off) */) {
+    const float o[12] = {pos.x, pos.y, pos.z, e.x, e.y, e.z, vb.x, vb.y, vb.z, wb.x, wb.y, wb.z};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) row[k] = fmaf(p.noise_std[k / 3], nz.z[k], o[k]);
+    row[12] = clampf(a0, -1.f, 1.f);
+    row[13] = clampf(a1, -1.f, 1.f);
+}
+
+// LANES == 4: lanes 0..2 of the quad each draw ONE Philox block (4 normals) and the 12 values are gathered with DPP
+// quad broadcasts -- one Philox + two Box-Muller on the critical path instead of three + six.  Must be called by all
+// four lanes of the quad.
+template <int LANES>
+WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise, int64_t stride, int e, uint32_t gid,
+                         uint64_t step, uint64_t seed, int wid = 0) {
+    Noise12 nz;
+    if (!p.enable_corruption) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) nz.z[k] = 0.f;
+    } else if (noise) {   // parity mode: caller-supplied standard normals [12][stride]
+#pragma unroll
+        for (int k = 0; k < 12; ++k) nz.z[k] = noise[k * stride + e];
+    } else if constexpr (LANES == 4) {
+        const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + (uint32_t)min(wid, 2), seed);
+        float z0, z1, z2, z3;
+        box_muller(u.x, u.y, z0, z1);
+        box_muller(u.z, u.w, z2, z3);
+        nz.z[0] = quad_bcast<0>(z0); nz.z[1] = quad_bcast<0>(z1); nz.z[2] = quad_bcast<0>(z2); nz.z[3] = quad_bcast<0>(z3);
+        nz.z[4] = quad_bcast<1>(z0); nz.z[5] = quad_bcast<1>(z1); nz.z[6] = quad_bcast<1>(z2); nz.z[7] = quad_bcast<1>(z3);
+        nz.z[8] = quad_bcast<2>(z0); nz.z[9] = quad_bcast<2>(z1); nz.z[10] = quad_bcast<2>(z2); nz.z[11] = quad_bcast<2>(z3);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + s, seed);
+            box_muller(u.x, u.y, nz.z[4 * s + 0], nz.z[4 * s + 1]);
+            box_muller(u.z, u.w, nz.z[4 * s + 2], nz.z[4 * s + 3]);
+        }
+    }
+    return nz;
+}
+
+// flush this block's LDS obs tile ([kBlock][kObsPad]) to obs[n][14]: contiguous dword stores per wavefront
+WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0, int n, int envs_per_block = kBlock) {
+    const int n_valid = min(envs_per_block, n - block_env0);
+    const int total = n_valid * kObsDim;
+    float* dst = obs + (int64_t)block_env0 * kObsDim;
+    for (int f = threadIdx.x; f < total; f += kBlock) {
+        const int e = f / kObsDim, k = f - e * kObsDim;
+        dst[f] = tile[e * kObsPad + k];
+    }
+}
+
+// Register image of one env's rows of the state matrix (memory form: root-link position, world-frame velocities).
+struct DriftRows {
+    V3 pos;
+    Quat q;
+    V3 v, ww;
+    float wheel[4];   // quad form: wheel[0] is this lane's wheel
+    float th, om;
+    float a0, a1;     // last raw action
+    float timer_hf, timer_lf;
+    float epsum[WL_DR_NTERMS];   // quad form only (the lane form streams these rows late to save registers)
+    int ep_len;
+};
+
+template <int LANES>
+WL_DEV void load_rows(const Rows& S, const WlEnvBuffers& b, const WlDriftParams& p, int e, int wid, DriftRows& r) {
+    r.pos = ld3(S, WL_S_PX, e);
+    r.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+    r.v = ld3(S, WL_S_VX, e);
+    r.ww = ld3(S, WL_S_WX, e);
+    if constexpr (LANES == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
+    } else {
+        r.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
+#pragma unroll
+        for (int i = 0; i < WL_DR_NTERMS; ++i) r.epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) : 0.f;
+    }
+    r.th = S.ld(WL_S_STEER_POS, e);
+    r.om = S.ld(WL_S_STEER_VEL, e);
+    r.timer_hf = S.ld(WL_S_TIMER_HF, e);
+    r.timer_lf = S.ld(WL_S_TIMER_LF, e);
+    r.ep_len = b.episode_len[e];
+}
+
+template <int LANES>
+WL_DEV void store_rows(const Rows& S, const WlEnvBuffers& b, const WlDriftParams& p, int e, int wid, bool lead,
+                       const DriftRows& r) {
+    if constexpr (LANES == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, r.wheel[i]);
+    } else {
+        S.st(WL_S_WHEEL_BL + wid, e, r.wheel[0]);
+    }
+    if (!lead) return;
+    st3(S, WL_S_PX, e, r.pos);
+    S.st(WL_S_QW, e, r.q.w);
+    S.st(WL_S_QX, e, r.q.x);
+    S.st(WL_S_QY, e, r.q.y);
+    S.st(WL_S_QZ, e, r.q.z);
+    st3(S, WL_S_VX, e, r.v);
+    st3(S, WL_S_WX, e, r.ww);
+    S.st(WL_S_STEER_POS, e, r.th);
+    S.st(WL_S_STEER_VEL, e, r.om);
+    S.st(WL_S_ACT0, e, r.a0);
+    S.st(WL_S_ACT1, e, r.a1);
+    S.st(WL_S_TIMER_HF, e, r.timer_hf);
+    S.st(WL_S_TIMER_LF, e, r.timer_lf);
+    if constexpr (LANES == 4) {
+        if (p.log_episode_sums) {
+#pragma unroll
+            for (int i = 0; i < WL_DR_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, r.epsum[i]);
+        }
+    }
+    b.episode_len[e] = r.ep_len;
+}
+
+// per-env constants that do not change during a rollout
+WL_DEV void load_env_const(const Rows& S, const WlVehicleParams& vp, const VehDerived& vd, int e, EnvConst& ec) {
+    env_const_mass(ec, vp, vd, S.ld(WL_S_MASS, e));
+    ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
+    ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
+    ec.damp = S.ld(WL_S_DAMP, e);
+}
+
+// Episode-metric accumulation.  Lane form: LDS atomics per block, <= 16 global atomics per block at the end (many
+// resets per block at large n).  Quad form: resets are rare per wavefront (16 envs), so the few lead lanes that reset go
+// straight to the global accumulators and the kernel needs no LDS and no block barrier at all.
+template <int LANES>
+struct MetricSink {
+    float* lds;     // block accumulators (lane form)
+    float* glob;    // this step's slot of the metric ring
+    WL_DEV void add(int idx, float v) const {
+        if constexpr (LANES == 4) atomicAdd(glob + idx, v);
+        else atomicAdd(lds + idx, v);
+    }
+};
+
+// ONE env.step() on the register image `r` (shared by the per-step kernel and the persistent rollout kernels): action
+// term -> physics -> terminations -> rewards -> reset -> pushes -> observation row into the block's LDS tile.
+// Writes reward / flags to `out` (already offset to this step); accumulates episode metrics into `blk_metrics` (LDS).
+template <int LANES, class Ground>
+WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const VehDerived& vd, const Ground& ground,
+                           const Rows& S, EnvConst& ec, DriftRows& r, float2 a, const float* __restrict__ noise,
+                           const WlStepOut& out, int e, int le, int wid, bool lead, uint32_t gid, uint64_t seed, uint64_t step,
+                           float* tile, const MetricSink<LANES>& ms, float* obs_keep = nullptr) {
+    const WlVehicleParams& vp = p.vehicle;
+    // ---- action manager: ClipAction + process_actions + joint targets (once per env-step) ----
+    float v_t, delta;
+    process_action(p.action, a.x, a.y, v_t, delta);
+    joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
+    // ---- memory form -> integrator form (CoM position, body-frame angular velocity) ----
+    VehState s;
+    s.q = r.q;
+    s.v = r.v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.wheel[i] = r.wheel[i];
+    s.th = r.th;
+    s.om = r.om;
+    {
+        const Mat3 R = mat_from_quat(s.q);
+        s.x = r.pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);  // CoM = link origin + R (0,0,cg_z)
+        s.wb = mul_t(R, r.ww);
+    }
+    // ---- physics: decimation x substeps, everything in registers ----
+    for (int k = 0; k < vd.n_sub; ++k) vehicle_substep<LANES>(vp, vd, ec, s, ground, wid);
+    const Mat3 R = mat_from_quat(s.q);
+    V3 ww = mul(R, s.wb);
+    V3 pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
+    // ---- terminations (time_out, cart_off_track) + non-finite guard ----
+    int ep_len = r.ep_len + 1;
+    const bool truncated = ep_len >= p.max_episode_length;
+    float wheel_sum;
+    if constexpr (LANES == 1) wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
+    else wheel_sum = quad_sum(s.wheel[0]);
+    const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y + ww.z +
+                      wheel_sum + s.th + s.om;
+    const bool finite = __builtin_isfinite(chk);
+    const bool terminated = !finite || cart_off_track(pos.x, pos.y, p.straight, p.r_in, p.r_out);
+    // ---- rewards on the post-physics state ----
+    V3 vb = mul_t(R, s.v);
+    // side-slip angle and the three Euler angles are four atan2s (asin(x) == atan2(x, sqrt(1 - x^2))): the quad form
+    // evaluates them as ONE atan2 with per-lane arguments and DPP-broadcasts the results
+    float slip_angle;
+    V3 euler;
+    if constexpr (LANES == 4) {
+        const Quat q = s.q;
+        const float sp = 2.f * (q.w * q.y - q.z * q.x);
+        const float ay = wid == 0 ? vb.y : wid == 1 ? 2.f * (q.w * q.x + q.y * q.z) : wid == 2 ? sp : 2.f * (q.w * q.z + q.x * q.y);
+        const float ax = wid == 0 ? vb.x : wid == 1 ? 1.f - 2.f * (q.x * q.x + q.y * q.y)
+                       : wid == 2 ? fsqrt(fmaxf(1.f - sp * sp, 0.f)) : 1.f - 2.f * (q.y * q.y + q.z * q.z);
+        const float ang = atan2f(ay, ax);
+        slip_angle = quad_bcast<0>(ang);
+        euler = v3(wrap_2pi(quad_bcast<1>(ang)), wrap_2pi(quad_bcast<2>(ang)), wrap_2pi(quad_bcast<3>(ang)));
+    } else {
+        slip_angle = atan2f(vb.y, vb.x);
+    }
+    DriftTerms tm = drift_terms(p, pos, vb, s.wb, ww.z, s.th, terminated, truncated, slip_angle);
+    const float step_dt = p.sim_dt * (float)p.decimation;
+    float reward = 0.f;
+    float epsum[WL_DR_NTERMS];
+#pragma unroll
+    for (int i = 0; i < WL_DR_NTERMS; ++i) {
+        const float w = p.weight[i];
+        const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;  // RewardManager skips w == 0
+        reward += c;
+        if constexpr (LANES == 4) epsum[i] = r.epsum[i] + c;
+        else epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;   // lane form: streamed late
+    }
+    if (lead) {
+        out.reward[e] = reward;
+        out.terminated[e] = terminated ? 1 : 0;
+        out.truncated[e] = truncated ? 1 : 0;
+        if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
+    }
+    // ---- reset (done envs) ----
+    float a0 = a.x, a1 = a.y, timer_hf = r.timer_hf, timer_lf = r.timer_lf;
+    if (terminated || truncated) {
+        if (lead) {
+#pragma unroll
+            for (int i = 0; i < WL_DR_NTERMS; ++i) ms.add(WL_M_EPSUM0 + i, epsum[i]);
+            ms.add(WL_M_RESETS, 1.f);
+            if (truncated) ms.add(WL_M_TIMEOUTS, 1.f);
+            if (terminated) ms.add(WL_M_TERM0, 1.f);
+            if (!finite) ms.add(WL_M_NONFINITE, 1.f);
+            ms.add(WL_M_EPLEN, (float)ep_len);
+        }
+#pragma unroll
+        for (int i = 0; i < WL_DR_NTERMS; ++i) epsum[i] = 0.f;
+        if (!finite) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
+            s.th = s.om = 0.f;
+        }
+        const ResetDraw rd = draw_reset(p, b.ref_poses, gid, step, seed);
+        pos = rd.pos;
+        s.q = rd.q;
+        if constexpr (LANES == 4) euler = v3(0.f, 0.f, rd.yaw - WL_TWO_PI * floorf(rd.yaw * WL_INV_TWO_PI));
+        s.v = v3(0.f, 0.f, 0.f);
+        ww = v3(0.f, 0.f, 0.f);
+        timer_hf = rd.timer_hf;
+        timer_lf = rd.timer_lf;
+        ep_len = 0;
+        a0 = a1 = 0.f;  // ActionManager.reset zeroes `action` (last_action) of reset envs
+    }
+    // ---- interval events: push_by_setting_velocity (mushr_drift_env_cfg.py:121-143) ----
+    if (p.enable_pushes) {
+        timer_hf -= step_dt;
+        if (timer_hf < 1e-6f) {
+            const F4 u = philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
+            s.v.x = fmaf(2.f * u.x - 1.f, p.hf_vel_x, s.v.x);
+            s.v.y = fmaf(2.f * u.y - 1.f, p.hf_vel_y, s.v.y);
+            ww.z = fmaf(2.f * u.z - 1.f, p.hf_vel_yaw, ww.z);
+            timer_hf = fmaf(u.w, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
+        }
+        timer_lf -= step_dt;
+        if (timer_lf < 1e-6f) {
+            const F4 u = philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
+            ww.z = fmaf(2.f * u.x - 1.f, p.lf_vel_yaw, ww.z);
+            timer_lf = fmaf(u.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
+        }
+    }
+    // ---- back to memory form ----
+    r.pos = pos;
+    r.q = s.q;
+    r.v = s.v;
+    r.ww = ww;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.wheel[i] = s.wheel[i];
+    r.th = s.th;
+    r.om = s.om;
+    r.a0 = a0;
+    r.a1 = a1;
+    r.timer_hf = timer_hf;
+    r.timer_lf = timer_lf;
+    r.ep_len = ep_len;
+    if constexpr (LANES == 4) {
+#pragma unroll
+        for (int i = 0; i < WL_DR_NTERMS; ++i) r.epsum[i] = epsum[i];
+    } else {
+        if (p.log_episode_sums) {
+#pragma unroll
+            for (int i = 0; i < WL_DR_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
+        }
+    }
+    // ---- observation of the post-reset state ----
+    const Mat3 R2 = mat_from_quat(s.q);
+    vb = mul_t(R2, s.v);
+    const V3 wb2 = mul_t(R2, ww);
+    const Noise12 nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // all lanes of the quad
+    if constexpr (LANES == 1) euler = euler_xyz_from_quat(s.q);
+    if constexpr (LANES == 4) {
+        // quad form: the 14 values are replicated on the quad's lanes; a caller that feeds them to a policy in the
+        // same launch (wl_policy.hip) keeps them in registers and stores the row itself
+        float o_local[14];
+        float* o = obs_keep ? obs_keep : o_local;
+        obs_values(o, p, pos, euler, vb, wb2, a0, a1, nz);
+        if (!obs_keep) store_obs_quad(out.obs + (int64_t)e * kObsDim, wid, o);
+    } else {
+        write_obs_row(&tile[le * kObsPad], p, pos, euler, vb, wb2, a0, a1, nz);
+    }
+}
+
+// host-side validation shared by every drift entry point
+inline int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
+    if (!p || !b || !b->state || !b->episode_len || !b->ref_poses || !b->metrics) return WL_EINVAL;
+    if (b->n_envs <= 0 || b->stride < b->n_envs) return WL_EINVAL;
+    if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
+    if (b->metrics_slots < 1 || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
+    if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL) return WL_EINVAL;   // buffer-resource offsets are 32-bit (~13 M envs)
+    if (p->decimation <= 0 || p->vehicle.substeps <= 0 || p->num_ref_points <= 0 || p->num_ref_points > 32) return WL_EINVAL;
+    if (!(p->sim_dt > 0.f)) return WL_EINVAL;
+    return WL_OK;
+}
+
+}  // namespace

@@ -1,0 +1,116 @@
+"""Policy in the loop: the RSL-RL ActorCritic MLPs of the drift agents and the rollout storage the fused collection
+kernel fills (reference: rsl_rl ActorCritic / RolloutStorage as driven by
+wheeledlab_rl/utils/modified_rsl_rl_runner.py:70-80 with wheeledlab_tasks/drifting/config/agents/mushr/rsl_rl_ppo_cfg.py).
+
+Everything that computes runs in the HIP library (`wl_mlp_forward`, `wl_drift_rollout_policy`); this module only owns
+the tensors and mirrors the names a rsl_rl user expects (`actor`, `critic`, `std`, `observations`, `actions`, `mu`,
+`actions_log_prob`, `values`, `rewards`, `dones`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _abi as A
+
+ACTIVATIONS = {"relu": A.ACT_RELU, "elu": A.ACT_ELU}
+
+
+class Mlp:
+    """in -> 64 -> 64 -> out with torch nn.Linear weight layout; evaluated on the f32 matrix pipe."""
+
+    def __init__(self, in_dim: int, out_dim: int, activation: str = "elu", device="cuda:0", hidden: int = 64,
+                 generator: torch.Generator | None = None):
+        if hidden != 64:
+            raise ValueError("the matrix-pipe MLP is specialised for hidden dims [64, 64] (rsl_rl_ppo_cfg.py:14-15)")
+        self.in_dim, self.out_dim, self.hidden, self.activation = int(in_dim), int(out_dim), 64, activation
+        self.device = torch.device(device)
+
+        def init(o, i):   # torch.nn.Linear default init: U(-1/sqrt(in), 1/sqrt(in)) for weight and bias
+            k = 1.0 / (i ** 0.5)
+            w = (torch.rand(o, i, generator=generator) * 2 - 1) * k
+            b = (torch.rand(o, generator=generator) * 2 - 1) * k
+            return w.to(self.device).contiguous(), b.to(self.device).contiguous()
+
+        self.w1, self.b1 = init(64, self.in_dim)
+        self.w2, self.b2 = init(64, 64)
+        self.w3, self.b3 = init(self.out_dim, 64)
+
+    @classmethod
+    def from_sequential(cls, seq, activation: str, device="cuda:0"):
+        """adopt the three nn.Linear layers of a torch Sequential (rsl_rl's `actor_critic.actor` / `.critic`)"""
+        lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+        if len(lin) != 3 or lin[0].out_features != 64 or lin[1].out_features != 64:
+            raise ValueError("expected Linear(in,64) / Linear(64,64) / Linear(64,out)")
+        self = cls.__new__(cls)
+        self.in_dim, self.out_dim, self.hidden, self.activation = lin[0].in_features, lin[2].out_features, 64, activation
+        self.device = torch.device(device)
+        for i, m in enumerate(lin, 1):
+            setattr(self, f"w{i}", m.weight.detach().to(self.device, torch.float32).contiguous())
+            setattr(self, f"b{i}", m.bias.detach().to(self.device, torch.float32).contiguous())
+        return self
+
+    def struct(self) -> A.WlMlp:
+        return A.WlMlp(self.w1.data_ptr(), self.b1.data_ptr(), self.w2.data_ptr(), self.b2.data_ptr(),
+                       self.w3.data_ptr(), self.b3.data_ptr(), self.in_dim, self.out_dim, self.hidden,
+                       ACTIVATIONS[self.activation])
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        """y[..., out_dim] = mlp(x[..., in_dim]) (wl_mlp_forward)"""
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == self.in_dim and x.device == self.device
+        y = torch.empty(*x.shape[:-1], self.out_dim, dtype=torch.float32, device=self.device)
+        s = self.struct()
+        A.check(A.load().wl_mlp_forward(C.byref(s), x.numel() // self.in_dim, x.data_ptr(), y.data_ptr(),
+                                        C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "wl_mlp_forward")
+        return y
+
+
+class ActorCritic:
+    """`actor`, `critic`, `std` as in rsl_rl's ActorCritic (init_noise_std 1.0, rsl_rl_ppo_cfg.py:13)"""
+
+    def __init__(self, num_obs: int = 14, num_actions: int = 2, activation: str = "elu", init_noise_std: float = 1.0,
+                 device="cuda:0", seed: int = 0):
+        g = torch.Generator().manual_seed(seed)
+        self.actor = Mlp(num_obs, num_actions, activation, device, generator=g)
+        self.critic = Mlp(num_obs, 1, activation, device, generator=g)
+        self.std = torch.full((num_actions,), float(init_noise_std), dtype=torch.float32, device=device)
+
+
+class RolloutStorage:
+    """[K(+1), n, ...] transition rows, named as rsl_rl's RolloutStorage"""
+
+    def __init__(self, n_steps: int, n_envs: int, obs_dim: int = 14, num_actions: int = 2, device="cuda:0"):
+        K, n, dev = int(n_steps), int(n_envs), torch.device(device)
+        self.n_steps, self.n_envs = K, n
+        self.observations = torch.zeros(K + 1, n, obs_dim, dtype=torch.float32, device=dev)   # row K = last obs
+        self.actions = torch.zeros(K, n, num_actions, dtype=torch.float32, device=dev)
+        self.mu = torch.zeros(K, n, num_actions, dtype=torch.float32, device=dev)
+        self.actions_log_prob = torch.zeros(K, n, dtype=torch.float32, device=dev)
+        self.rewards = torch.zeros(K, n, dtype=torch.float32, device=dev)
+        self.terminated = torch.zeros(K, n, dtype=torch.bool, device=dev)
+        self.time_outs = torch.zeros(K, n, dtype=torch.bool, device=dev)
+        self.dones = torch.zeros(K, n, dtype=torch.long, device=dev)
+        self.values = torch.zeros(K + 1, n, dtype=torch.float32, device=dev)                 # row K = bootstrap value
+
+    def struct(self) -> A.WlPolicyRollout:
+        return A.WlPolicyRollout(self.observations.data_ptr(), self.actions.data_ptr(), self.mu.data_ptr(),
+                                 self.actions_log_prob.data_ptr(), self.rewards.data_ptr(), self.terminated.data_ptr(),
+                                 self.time_outs.data_ptr(), self.dones.data_ptr())
+
+    def bootstrap_time_outs(self, gamma: float):
+        """rsl_rl PPO.process_env_step: rewards += gamma * V(obs_t) * time_outs (in place, once per collection)"""
+        self.rewards += gamma * self.values[:-1] * self.time_outs
+
+    def compute_returns(self, gamma: float = 0.99, lam: float = 0.95):
+        """GAE exactly as rsl_rl RolloutStorage.compute_returns; returns (returns, advantages) [K, n]"""
+        K = self.n_steps
+        adv = torch.zeros_like(self.rewards)
+        last = torch.zeros(self.n_envs, dtype=torch.float32, device=self.rewards.device)
+        not_done = 1.0 - self.dones.to(torch.float32)
+        for t in reversed(range(K)):
+            delta = self.rewards[t] + not_done[t] * gamma * self.values[t + 1] - self.values[t]
+            last = delta + not_done[t] * gamma * lam * last
+            adv[t] = last
+        returns = adv + self.values[:-1]
+        return returns, (adv - adv.mean()) / (adv.std() + 1e-8)
