@@ -43,3 +43,29 @@ for _ in range(200):
     y = x * 2 + 1
 torch.cuda.synchronize()
 rate("after elementwise torch ops")
+
+# the bench's policy section: fused collection launch, then the per-step loop with a torch actor in inference mode
+from wheeledlab_amd.core import DriftBatch  # noqa: E402
+from wheeledlab_amd.policy import ActorCritic, RolloutStorage  # noqa: E402
+
+b = DriftBatch(n, device=dev, seed=1)
+b.reset()
+b.observe()
+ac, store = ActorCritic(device=dev), RolloutStorage(128, n, device=dev)
+b.rollout_policy(ac, store)
+torch.cuda.synchronize()
+rate("after wl_drift_rollout_policy + wl_mlp_forward")
+lin3 = torch.nn.Sequential(torch.nn.Linear(14, 64), torch.nn.ELU(), torch.nn.Linear(64, 64), torch.nn.ELU(),
+                           torch.nn.Linear(64, 2)).to(dev)
+obs_t = b.obs
+with torch.inference_mode():
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(128):
+            mu = lin3(obs_t)
+            a_t = mu + ac.std * torch.randn_like(mu)
+            obs_t, _, _, _ = b.step(a_t)
+        torch.cuda.synchronize()
+        print(f"torch-actor loop rep {rep}: {(time.perf_counter() - t) / 128 * 1e6:.1f} us/step", flush=True)
+rate("after the torch-actor loop")
