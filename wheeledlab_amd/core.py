@@ -152,25 +152,32 @@ class DriftBatch:
                    self.step_count, self._stream()), "wl_drift_rollout")
         self.step_count += K
 
-    def rollout_policy(self, actor_critic, storage, evaluate_critic: bool = True):
-        """The runner's collection loop (modified_rsl_rl_runner.py:70-80) as one launch: storage.n_steps times
+    def rollout_policy(self, actor_critic, storage, evaluate_critic: bool = True, start: int = 0, count: int | None = None):
+        """The runner's collection loop (modified_rsl_rl_runner.py:70-80) as one launch: `count` times
         { actor(obs) on the matrix pipe -> sample -> env.step } with the env state and the observation in registers
-        (wl_drift_rollout_policy); then the critic over all K + 1 observations in one wl_mlp_forward.
-        storage.observations[0] is seeded with the current observation; self.obs ends as the last one."""
-        K = storage.n_steps
-        assert storage.n_envs == self.n and actor_critic.actor.in_dim == self.OBS_DIM
-        storage.observations[0].copy_(self.obs)
-        actor, io = actor_critic.actor.struct(), storage.struct()
+        (wl_drift_rollout_policy), filling storage rows start .. start + count; then (optionally) the critic over ALL
+        observation rows of the storage in one wl_mlp_forward.  Row `start` of storage.observations is seeded with the
+        current observation; self.obs ends as the last one."""
+        K = storage.n_steps - start if count is None else int(count)
+        assert storage.n_envs == self.n and actor_critic.actor.in_dim == self.OBS_DIM and 0 <= start and start + K <= storage.n_steps
+        storage.observations[start].copy_(self.obs)
+        if self.metrics_slots > 1 and K > 1:
+            # the launch folds all K steps into ring slot step0 % R and clears slot (step0 + K) % R; the slots it skips
+            # would otherwise keep counts from R steps ago
+            R = self.metrics_slots
+            self.metrics[[(self.step_count + i) % R for i in range(1, K)]] = 0
+        actor, io = actor_critic.actor.struct(), storage.struct(start)
         A.check(self.lib.wl_drift_rollout_policy(C.byref(self.p), C.byref(self._bufs), C.byref(actor),
                                                  actor_critic.std.data_ptr(), C.byref(io), K, self.seed, self.step_count,
                                                  self._stream()), "wl_drift_rollout_policy")
         self.step_count += K
         if K > 0:
-            self.obs.copy_(storage.observations[K])
-            self.reward.copy_(storage.rewards[K - 1])
-            self.terminated.copy_(storage.terminated[K - 1])
-            self.truncated.copy_(storage.time_outs[K - 1])
-            self.dones.copy_(storage.dones[K - 1])
+            e = start + K
+            self.obs.copy_(storage.observations[e])
+            self.reward.copy_(storage.rewards[e - 1])
+            self.terminated.copy_(storage.terminated[e - 1])
+            self.truncated.copy_(storage.time_outs[e - 1])
+            self.dones.copy_(storage.dones[e - 1])
         if evaluate_critic:
             storage.values.copy_(actor_critic.critic(storage.observations).squeeze(-1))
         return storage

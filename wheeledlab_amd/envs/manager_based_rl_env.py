@@ -319,6 +319,44 @@ class ManagerBasedRLEnv:
         self.obs_buf = {"policy": obs}
         return self.obs_buf, rew, terminated, truncated, self.extras
 
+    def rollout_policy(self, actor_critic, storage):
+        """storage.n_steps x { actor -> sample -> env.step } in fused launches (drift task): the collection loop of the
+        reference's runner (modified_rsl_rl_runner.py:70-80).  `actor_critic` exposes `.actor`, `.critic` (policy.Mlp)
+        and `.std`.  The rollout is cut at curriculum boundaries (common_step_counter % max_episode_length == 0), where
+        IsaacLab's _reset_idx would evaluate the curriculum terms, so reward weights change on the same step as they
+        do when stepping."""
+        if self._task != "drift":
+            raise NotImplementedError("fused policy rollouts exist for the drift task (14-dim observation)")
+        if self._has_custom_rewards:
+            raise ValueError("custom (torch) reward terms run between steps; use step()")
+        b, K, k = self._batch, storage.n_steps, 0
+        while k < K:
+            seg = K - k
+            if self._has_curriculum:
+                seg = min(seg, self.max_episode_length - self.common_step_counter % self.max_episode_length)
+            b.rollout_policy(actor_critic, storage, evaluate_critic=False, start=k, count=seg)
+            k += seg
+            self.common_step_counter += seg
+            self._sim_step_counter += seg * self.cfg.decimation
+            if self._has_curriculum and self.common_step_counter % self.max_episode_length == 0:
+                if bool(storage.dones[k - 1].any()):
+                    for name, term in self._flat.curriculum:
+                        term.func(self, None, **term.params)
+        storage.values.copy_(actor_critic.critic(storage.observations).squeeze(-1))
+        self.obs_buf = {"policy": b.obs}
+        self.extras["log"] = self._episode_log(None) if b.metrics_slots == 1 else EpisodeLog(
+            self.episode_metrics(window=K, reduce_ranks=False), None, self._log_keys, self.max_episode_length_s)
+        return storage
+
+    def episode_log_summary(self, window: int) -> dict:
+        """host floats of the episode log over the last `window` steps (one device->host copy; the runner's logging)"""
+        m = self.episode_metrics(window=window, reduce_ranks=False).tolist()
+        resets = max(m[A.M_RESETS], 1.0)
+        out = {}
+        for key, (kind, i) in self._log_keys.items():
+            out[key] = m[i] if kind == "c" else m[A.M_EPSUM0 + i] / resets / self.max_episode_length_s
+        return out
+
     def _episode_log(self, slot):
         return EpisodeLog(self._batch.metrics, slot, self._log_keys, self.max_episode_length_s)
 

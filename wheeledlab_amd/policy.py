@@ -93,10 +93,12 @@ class RolloutStorage:
         self.dones = torch.zeros(K, n, dtype=torch.long, device=dev)
         self.values = torch.zeros(K + 1, n, dtype=torch.float32, device=dev)                 # row K = bootstrap value
 
-    def struct(self) -> A.WlPolicyRollout:
-        return A.WlPolicyRollout(self.observations.data_ptr(), self.actions.data_ptr(), self.mu.data_ptr(),
-                                 self.actions_log_prob.data_ptr(), self.rewards.data_ptr(), self.terminated.data_ptr(),
-                                 self.time_outs.data_ptr(), self.dones.data_ptr())
+    def struct(self, start: int = 0) -> A.WlPolicyRollout:
+        """the rows from step `start` on ([step][env] major, so a suffix of every tensor is itself a valid storage)"""
+        return A.WlPolicyRollout(self.observations[start:].data_ptr(), self.actions[start:].data_ptr(),
+                                 self.mu[start:].data_ptr(), self.actions_log_prob[start:].data_ptr(),
+                                 self.rewards[start:].data_ptr(), self.terminated[start:].data_ptr(),
+                                 self.time_outs[start:].data_ptr(), self.dones[start:].data_ptr())
 
     def bootstrap_time_outs(self, gamma: float):
         """rsl_rl PPO.process_env_step: rewards += gamma * V(obs_t) * time_outs (in place, once per collection)"""

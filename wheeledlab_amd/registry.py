@@ -51,9 +51,11 @@ def load_cfg_from_registry(task: str, entry_key: str = "env_cfg_entry_point"):
     return entry() if isinstance(entry, type) else entry
 
 
-def parse_env_cfg(task: str, device: str = "cuda:0", num_envs: int | None = None):
-    """isaaclab_tasks.utils.parse_env_cfg work-alike (reference: wheeledlab_tasks/test/create_and_step_env.py:26)"""
-    cfg = load_cfg_from_registry(task)
+def parse_env_cfg(task: str, device: str = "cuda:0", num_envs: int | None = None, play: bool = False):
+    """isaaclab_tasks.utils.parse_env_cfg work-alike (reference: wheeledlab_tasks/test/create_and_step_env.py:26);
+    play=True picks the task's `play_env_cfg_entry_point` when it registers one (scripts/play_policy.py)"""
+    key = "play_env_cfg_entry_point" if play and "play_env_cfg_entry_point" in spec(task).kwargs else "env_cfg_entry_point"
+    cfg = load_cfg_from_registry(task, key)
     cfg.sim.device = device
     if num_envs is not None:
         cfg.num_envs = num_envs

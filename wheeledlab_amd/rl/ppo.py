@@ -1,0 +1,295 @@
+"""PPO learner + on-policy runner for the registered tasks.
+
+Host-side mirror of what the reference drives through rsl-rl-lib (wheeledlab_rl/utils/modified_rsl_rl_runner.py:24-128
+with the agent cfgs under wheeledlab_tasks/*/config/agents): same class / method names (`ActorCritic`, `PPO.update`,
+`OnPolicyRunner.learn / save / load / get_inference_policy`), same hyper-parameter fields, same checkpoint keys
+(`model_state_dict`, `optimizer_state_dict`, `iter`, `infos`).  rsl-rl-lib is not vendored in the reference tree; the
+algorithm follows its published definition (clipped surrogate, clipped value loss, entropy bonus, adaptive-KL learning
+rate, GAE) and is restated independently for the tests in oracle/policy.py (GAE) -- parity with rsl_rl itself is unpinned.
+
+What is MI355X-specific: collection.  For the drift task the whole `num_steps_per_env` rollout (actor on the f32 matrix
+pipe -> sample -> env.step -> storage rows) is ONE launch (`wl_drift_rollout_policy`) plus one `wl_mlp_forward` for
+the critic; the actor / critic parameters the kernels read ARE the torch Parameters the optimiser updates in place.
+The gradient step itself is ordinary torch autograd on [K * n, 14] batches (plumbing: three small GEMMs per net).
+"""
+from __future__ import annotations
+
+import os
+import time
+from collections import deque
+
+import torch
+from torch import nn
+
+from ..policy import Mlp, RolloutStorage
+
+_ACT = {"elu": nn.ELU, "relu": nn.ReLU, "tanh": nn.Tanh}
+
+
+def _mlp(i, hidden, o, activation):
+    layers, d = [], i
+    for h in hidden:
+        layers += [nn.Linear(d, h), _ACT[activation]()]
+        d = h
+    return nn.Sequential(*layers, nn.Linear(d, o))
+
+
+class ActorCritic(nn.Module):
+    """rsl_rl.modules.ActorCritic work-alike: `actor`, `critic`, `std`, act / evaluate / get_actions_log_prob"""
+
+    def __init__(self, num_actor_obs, num_critic_obs, num_actions, actor_hidden_dims=(64, 64), critic_hidden_dims=(64, 64),
+                 activation="elu", init_noise_std=1.0, **_unused):
+        super().__init__()
+        self.activation = activation
+        self.actor = _mlp(num_actor_obs, list(actor_hidden_dims), num_actions, activation)
+        self.critic = _mlp(num_critic_obs, list(critic_hidden_dims), 1, activation)
+        self.std = nn.Parameter(init_noise_std * torch.ones(num_actions))
+        self.distribution = None
+        self._fused = None
+
+    # -- torch path (gradient step, tasks without a fused collector) --
+    def update_distribution(self, obs):
+        self.distribution = torch.distributions.Normal(self.actor(obs), self.std.expand(obs.shape[0], -1))
+
+    def act(self, obs):
+        self.update_distribution(obs)
+        return self.distribution.sample()
+
+    def act_inference(self, obs):
+        return self.actor(obs)
+
+    def evaluate(self, critic_obs):
+        return self.critic(critic_obs)
+
+    def get_actions_log_prob(self, actions):
+        return self.distribution.log_prob(actions).sum(-1)
+
+    @property
+    def action_mean(self):
+        return self.distribution.mean
+
+    @property
+    def action_std(self):
+        return self.distribution.stddev
+
+    @property
+    def entropy(self):
+        return self.distribution.entropy().sum(-1)
+
+    # -- kernel view: the SAME storage, as the structs wl_drift_rollout_policy / wl_mlp_forward read --
+    def fusable(self) -> bool:
+        def ok(seq):
+            lin = [m for m in seq if isinstance(m, nn.Linear)]
+            return len(lin) == 3 and lin[0].out_features == 64 and lin[1].out_features == 64 and lin[0].in_features <= 15
+        return self.activation in ("elu", "relu") and ok(self.actor) and ok(self.critic) and self.std.is_cuda
+
+    def fused(self):
+        if self._fused is None:
+            class _View:
+                pass
+            v = _View()
+            v.actor = Mlp.from_sequential(self.actor, self.activation, self.std.device)
+            v.critic = Mlp.from_sequential(self.critic, self.activation, self.std.device)
+            v.std = self.std.detach()
+            for m, seq in ((v.actor, self.actor), (v.critic, self.critic)):   # the view must alias, never copy
+                lin = [x for x in seq if isinstance(x, nn.Linear)]
+                assert all(getattr(m, f"w{i + 1}").data_ptr() == lin[i].weight.data_ptr() for i in range(3))
+            self._fused = v
+        return self._fused
+
+
+class PPO:
+    """rsl_rl.algorithms.PPO.update on a filled RolloutStorage (fields: rsl_rl_ppo_cfg.py:18-31)"""
+
+    def __init__(self, actor_critic: ActorCritic, value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2,
+                 entropy_coef=0.005, num_learning_epochs=5, num_mini_batches=4, learning_rate=1e-3, schedule="adaptive",
+                 gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0, **_unused):
+        self.actor_critic = actor_critic
+        self.value_loss_coef, self.use_clipped_value_loss, self.clip_param = value_loss_coef, use_clipped_value_loss, clip_param
+        self.entropy_coef, self.num_learning_epochs, self.num_mini_batches = entropy_coef, num_learning_epochs, num_mini_batches
+        self.learning_rate, self.schedule, self.gamma, self.lam = learning_rate, schedule, gamma, lam
+        self.desired_kl, self.max_grad_norm = desired_kl, max_grad_norm
+        self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=learning_rate)
+
+    def update(self, storage: RolloutStorage, generator: torch.Generator | None = None):
+        K, n = storage.n_steps, storage.n_envs
+        returns, advantages = storage.compute_returns(self.gamma, self.lam)
+        sigma_old = self.actor_critic.std.detach().clone()
+        flat = dict(obs=storage.observations[:K].reshape(K * n, -1), actions=storage.actions.reshape(K * n, -1),
+                    values=storage.values[:K].reshape(K * n), returns=returns.reshape(K * n),
+                    adv=advantages.reshape(K * n), logp=storage.actions_log_prob.reshape(K * n),
+                    mu=storage.mu.reshape(K * n, -1))
+        batch = K * n
+        mb = batch // self.num_mini_batches
+        mean_value_loss = mean_surrogate_loss = mean_kl = 0.0
+        ac = self.actor_critic
+        for _ in range(self.num_learning_epochs):
+            perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator)
+            for i in range(self.num_mini_batches):
+                idx = perm[i * mb:(i + 1) * mb]
+                obs, actions = flat["obs"][idx], flat["actions"][idx]
+                ac.update_distribution(obs)
+                logp = ac.get_actions_log_prob(actions)
+                value = ac.evaluate(obs).squeeze(-1)
+                mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+                if self.desired_kl is not None and self.schedule == "adaptive":
+                    with torch.no_grad():
+                        kl = torch.sum(torch.log(sigma / sigma_old + 1e-5)
+                                       + (sigma_old.square() + (flat["mu"][idx] - mu).square()) / (2.0 * sigma.square()) - 0.5, -1)
+                        kl_mean = float(kl.mean())
+                    if kl_mean > self.desired_kl * 2.0:
+                        self.learning_rate = max(1e-5, self.learning_rate / 1.5)
+                    elif 0.0 < kl_mean < self.desired_kl / 2.0:
+                        self.learning_rate = min(1e-2, self.learning_rate * 1.5)
+                    for g in self.optimizer.param_groups:
+                        g["lr"] = self.learning_rate
+                    mean_kl += kl_mean
+                adv = flat["adv"][idx]
+                ratio = torch.exp(logp - flat["logp"][idx])
+                surrogate = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+                ret, v_old = flat["returns"][idx], flat["values"][idx]
+                if self.use_clipped_value_loss:
+                    v_clip = v_old + (value - v_old).clamp(-self.clip_param, self.clip_param)
+                    value_loss = torch.max((value - ret).square(), (v_clip - ret).square()).mean()
+                else:
+                    value_loss = (ret - value).square().mean()
+                loss = surrogate + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
+                self.optimizer.zero_grad()
+                loss.backward()
+                nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+                self.optimizer.step()
+                mean_value_loss += float(value_loss.detach())
+                mean_surrogate_loss += float(surrogate.detach())
+        u = self.num_learning_epochs * self.num_mini_batches
+        return dict(value_function=mean_value_loss / u, surrogate=mean_surrogate_loss / u, kl=mean_kl / u,
+                    learning_rate=self.learning_rate)
+
+
+class OnPolicyRunner:
+    """rsl_rl OnPolicyRunner / the reference's ModifiedRslRunner work-alike around a RslRlVecEnvWrapper"""
+
+    def __init__(self, env, train_cfg, log_dir: str | None = None, device=None, fused: bool | None = None):
+        cfg = train_cfg.to_dict() if hasattr(train_cfg, "to_dict") else dict(train_cfg)
+        self.cfg, self.env, self.log_dir = cfg, env, log_dir
+        self.device = torch.device(device or env.device)
+        self.num_steps_per_env = int(cfg.get("num_steps_per_env", 128))
+        self.save_interval = int(cfg.get("save_interval", 50))
+        pol = cfg.get("policy", {})
+        pol = pol.to_dict() if hasattr(pol, "to_dict") else dict(pol)
+        alg = cfg.get("algorithm", {})
+        alg = alg.to_dict() if hasattr(alg, "to_dict") else dict(alg)
+        pol.pop("class_name", None), alg.pop("class_name", None)
+        self.actor_critic = ActorCritic(env.num_obs, env.num_obs, env.num_actions, **pol).to(self.device)
+        self.alg = PPO(self.actor_critic, **alg)
+        base = env.unwrapped
+        can_fuse = (getattr(base, "_task", None) == "drift" and self.actor_critic.fusable()
+                    and not getattr(base, "_has_custom_rewards", False))
+        if fused and not can_fuse:
+            raise ValueError("fused collection needs the drift task, [64, 64] elu/relu MLPs and only built-in reward terms")
+        self.fused = can_fuse if fused is None else bool(fused)
+        self.storage = RolloutStorage(self.num_steps_per_env, env.num_envs, env.num_obs, env.num_actions, self.device)
+        self.current_learning_iteration = 0
+        self.tot_timesteps, self.tot_time = 0, 0.0
+        self.history: list[dict] = []
+
+    # ---- collection --------------------------------------------------------------------------------------
+    def _collect_fused(self):
+        self.env.unwrapped.rollout_policy(self.actor_critic.fused(), self.storage)
+
+    def _collect_stepwise(self, obs):
+        st, ac = self.storage, self.actor_critic
+        with torch.inference_mode():
+            for k in range(self.num_steps_per_env):
+                st.observations[k].copy_(obs)
+                a = ac.act(obs)
+                st.actions[k].copy_(a)
+                st.mu[k].copy_(ac.action_mean)
+                st.actions_log_prob[k].copy_(ac.get_actions_log_prob(a))
+                obs, rew, dones, infos = self.env.step(a)
+                st.rewards[k].copy_(rew)
+                st.dones[k].copy_(dones)
+                st.time_outs[k].copy_(infos.get("time_outs", torch.zeros_like(dones, dtype=torch.bool)))
+                st.terminated[k].copy_((dones != 0) & ~st.time_outs[k])
+            st.observations[self.num_steps_per_env].copy_(obs)
+            K, n = st.n_steps, st.n_envs
+            st.values.copy_(ac.evaluate(st.observations.reshape((K + 1) * n, -1)).reshape(K + 1, n))
+        return obs
+
+    # ---- the learning loop (modified_rsl_rl_runner.py:34-128) ----------------------------------------------
+    def learn(self, num_learning_iterations: int, init_at_random_ep_len: bool = False, verbose: bool = True):
+        env = self.env
+        if init_at_random_ep_len:
+            env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+        obs, _ = env.get_observations()
+        n = env.num_envs
+        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        cur_reward_sum = torch.zeros(n, device=self.device)
+        cur_episode_length = torch.zeros(n, device=self.device)
+        start_iter = self.current_learning_iteration
+        for it in range(start_iter, start_iter + num_learning_iterations):
+            t0 = time.time()
+            if self.fused:
+                self._collect_fused()
+            else:
+                obs = self._collect_stepwise(obs)
+            st = self.storage
+            # book keeping of finished episodes, vectorised over the rollout (runner :88-98 does it per step)
+            with torch.no_grad():
+                done = st.dones != 0
+                for k in range(st.n_steps):
+                    cur_reward_sum += st.rewards[k]
+                    cur_episode_length += 1
+                    if bool(done[k].any()):
+                        ids = done[k].nonzero().flatten()
+                        rewbuffer.extend(cur_reward_sum[ids].tolist())
+                        lenbuffer.extend(cur_episode_length[ids].tolist())
+                        cur_reward_sum[ids] = 0
+                        cur_episode_length[ids] = 0
+                st.bootstrap_time_outs(self.alg.gamma)
+            torch.cuda.synchronize() if self.device.type == "cuda" else None
+            t1 = time.time()
+            losses = self.alg.update(st)
+            torch.cuda.synchronize() if self.device.type == "cuda" else None
+            t2 = time.time()
+            self.current_learning_iteration = it + 1
+            steps = st.n_steps * n
+            self.tot_timesteps += steps
+            self.tot_time += t2 - t0
+            log = dict(iteration=it, collection_time=t1 - t0, learn_time=t2 - t1, fps=steps / (t2 - t0),
+                       collection_fps=steps / max(t1 - t0, 1e-9), mean_reward=_mean(rewbuffer), mean_episode_length=_mean(lenbuffer),
+                       mean_step_reward=float(st.rewards.mean()), mean_noise_std=float(self.actor_critic.std.mean()), **losses)
+            base = env.unwrapped
+            if hasattr(base, "episode_log_summary"):
+                log.update(base.episode_log_summary(st.n_steps))
+            self.history.append(log)
+            if verbose:
+                print(f"[it {it:4d}] fps {log['fps']:.3e} (collect {log['collection_fps']:.3e})  mean_reward {log['mean_reward']:.2f}"
+                      f"  ep_len {log['mean_episode_length']:.1f}  step_rew {log['mean_step_reward']:.3f}"
+                      f"  std {log['mean_noise_std']:.3f}  kl {losses['kl']:.4f}  lr {losses['learning_rate']:.2e}", flush=True)
+            if self.log_dir and (it % self.save_interval == 0 or it == start_iter + num_learning_iterations - 1):
+                self.save(os.path.join(self.log_dir, "models", f"model_{it}.pt"))
+        return self.history
+
+    # ---- checkpoints: rsl_rl's keys (train_rl.py:96-106 resumes from `model_*.pt`) --------------------------
+    def save(self, path: str, infos=None):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save({"model_state_dict": self.actor_critic.state_dict(), "optimizer_state_dict": self.alg.optimizer.state_dict(),
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path: str, load_optimizer: bool = True):
+        d = torch.load(path, map_location=self.device, weights_only=False)
+        self.actor_critic.load_state_dict(d["model_state_dict"])    # copies in place: the kernel view stays valid
+        if load_optimizer:
+            self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+        self.current_learning_iteration = d["iter"]
+        return d.get("infos")
+
+    def get_inference_policy(self, device=None):
+        self.actor_critic.eval()
+        if device is not None:
+            self.actor_critic.to(device)
+        return self.actor_critic.act_inference
+
+
+def _mean(buf):
+    return float(sum(buf) / len(buf)) if len(buf) else 0.0

@@ -21,17 +21,17 @@ register(
 register(
     id="Isaac-MushrVisualRL-v0", entry_point=_ENV, disable_env_checker=True,
     kwargs={"env_cfg_entry_point": MushrVisualRLEnvCfg,
-            "rsl_rl_cfg_entry_point": "wheeledlab_amd.tasks.drifting.agents:MushrPPORunnerCfg",
+            "rsl_rl_cfg_entry_point": "wheeledlab_amd.tasks.visual.agents:MushrPPORunnerCfg",
             "play_env_cfg_entry_point": MushrVisualPlayEnvCfg},
 )
 register(
     id="Isaac-MushrElevationRL-v0", entry_point=_ENV, disable_env_checker=True,
     kwargs={"env_cfg_entry_point": MushrElevationRLEnvCfg,
-            "rsl_rl_cfg_entry_point": "wheeledlab_amd.tasks.drifting.agents:MushrPPORunnerCfg",
+            "rsl_rl_cfg_entry_point": "wheeledlab_amd.tasks.elevation.agents:MushrPPORunnerCfg",
             "play_env_cfg_entry_point": MushrElevationPlayEnvCfg},
 )
 register(
     id="Isaac-F1TenthDriftRL-v0", entry_point=_ENV, disable_env_checker=True,
     kwargs={"env_cfg_entry_point": F1TenthDriftRLEnvCfg,
-            "rsl_rl_cfg_entry_point": "wheeledlab_amd.tasks.drifting.agents:MushrPPORunnerCfg"},
+            "rsl_rl_cfg_entry_point": "wheeledlab_amd.tasks.drifting.agents:F1TenthPPORunnerCfg"},
 )

@@ -1,6 +1,5 @@
-"""PPO hyper-parameters of the drift task as plain data (reference:
-wheeledlab_tasks/drifting/config/agents/mushr/rsl_rl_ppo_cfg.py:5-31).  The learner itself is out of scope; these
-values fix the rollout length (128 steps / env) the throughput harness reproduces."""
+"""PPO hyper-parameters of the drift agents as plain data (reference:
+wheeledlab_tasks/drifting/config/agents/{mushr,f1tenth}/rsl_rl_ppo_cfg.py).  Consumed by wheeledlab_amd.rl.ppo."""
 from ...envs.configclass import configclass
 
 
@@ -30,10 +29,17 @@ class AlgorithmCfg:
 
 @configclass
 class MushrPPORunnerCfg:
+    seed: int = 42
     num_steps_per_env: int = 128
-    max_iterations: int = 5000
-    save_interval: int = 100
-    experiment_name: str = "mushr_drift"
+    max_iterations: int = 150
+    save_interval: int = 50
+    experiment_name: str = "ppo_mushr"
     empirical_normalization: bool = False
     policy: PolicyCfg = PolicyCfg()
     algorithm: AlgorithmCfg = AlgorithmCfg()
+
+
+@configclass
+class F1TenthPPORunnerCfg(MushrPPORunnerCfg):
+    max_iterations: int = 1500
+    experiment_name: str = "ppo_f1tenth"
