@@ -39,15 +39,20 @@ def main():
     policy = runner.get_inference_policy(device=env.unwrapped.device)
     data = {"observations": [], "actions": []}
     obs, _ = env.get_observations()
-    total = 0.0
+    total, speed, yaw_rate = 0.0, 0.0, 0.0
     for _ in range(args.steps):
         with torch.inference_mode():
             actions = policy(obs)
             obs, rew, _, _ = env.step(actions)
         total += float(rew.mean())
+        if obs.shape[1] == 14:           # drift observation: body-frame velocity at [6:9], angular velocity at [9:12]
+            speed += float(obs[:, 6:8].norm(dim=-1).mean())
+            yaw_rate += float(obs[:, 11].mean())
         data["observations"].append(obs.clone())
         data["actions"].append(actions.clone())
-    print(f"mean reward / step over {args.steps} steps x {args.num_envs} envs: {total / args.steps:.4f}")
+    # the play cfgs carry no reward terms (as the reference's: mushr_drift_env_cfg.py:425-427), so the reward is 0 there
+    print(f"{args.steps} steps x {args.num_envs} envs: mean reward / step {total / args.steps:.4f}, "
+          f"mean planar speed {speed / args.steps:.3f} m/s, mean yaw rate {yaw_rate / args.steps:.3f} rad/s")
     if args.save_data:
         os.makedirs(os.path.dirname(os.path.abspath(args.save_data)), exist_ok=True)
         torch.save({k: torch.stack(v, 0) for k, v in data.items()}, args.save_data)

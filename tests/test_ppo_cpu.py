@@ -96,3 +96,28 @@ def test_agent_cfgs_follow_the_reference_per_task():
         d = registry.load_cfg_from_registry(task, "rsl_rl_cfg_entry_point").to_dict()
         assert (d["experiment_name"], d["max_iterations"], d["policy"]["activation"]) == (name, iters, act)
         assert d["num_steps_per_env"] == 128 and d["save_interval"] == 50 and d["algorithm"]["num_mini_batches"] == 4
+
+
+def test_vectorised_episode_bookkeeping_equals_the_runners_per_step_loop():
+    from wheeledlab_amd.rl.ppo import _finished_episodes
+    g = torch.Generator().manual_seed(5)
+    K, n = 37, 11
+    cr, cl = torch.rand(n, generator=g), torch.randint(0, 9, (n,), generator=g).float()
+    want_r, want_l, r0, l0 = [], [], cr.clone(), cl.clone()
+    got_r, got_l = [], []
+    for _ in range(3):                                   # carries across three rollouts
+        rew = torch.randn(K, n, generator=g)
+        done = torch.rand(K, n, generator=g) < 0.08
+        for k in range(K):                               # modified_rsl_rl_runner.py:88-98
+            r0 += rew[k]
+            l0 += 1
+            ids = done[k].nonzero().flatten()
+            want_r += r0[ids].tolist()
+            want_l += l0[ids].tolist()
+            r0[ids] = 0
+            l0[ids] = 0
+        a, b, cr, cl = _finished_episodes(rew, done, cr, cl)
+        got_r += a.tolist()
+        got_l += b.tolist()
+    assert torch.allclose(torch.tensor(got_r), torch.tensor(want_r), atol=1e-5) and got_l == want_l
+    assert torch.allclose(cr, r0, atol=1e-5) and torch.equal(cl, l0)

@@ -109,7 +109,8 @@ class PPO:
         self.entropy_coef, self.num_learning_epochs, self.num_mini_batches = entropy_coef, num_learning_epochs, num_mini_batches
         self.learning_rate, self.schedule, self.gamma, self.lam = learning_rate, schedule, gamma, lam
         self.desired_kl, self.max_grad_norm = desired_kl, max_grad_norm
-        self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=learning_rate)
+        on_gpu = next(actor_critic.parameters()).is_cuda
+        self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=learning_rate, fused=True if on_gpu else None)
 
     def update(self, storage: RolloutStorage, generator: torch.Generator | None = None):
         K, n = storage.n_steps, storage.n_envs
@@ -121,13 +122,15 @@ class PPO:
                     mu=storage.mu.reshape(K * n, -1))
         batch = K * n
         mb = batch // self.num_mini_batches
-        mean_value_loss = mean_surrogate_loss = mean_kl = 0.0
+        stats = torch.zeros(2, device=flat["obs"].device)
+        mean_kl = 0.0
         ac = self.actor_critic
         for _ in range(self.num_learning_epochs):
             perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator)
+            shuffled = {k: v[perm] for k, v in flat.items()}        # one gather per field and epoch
             for i in range(self.num_mini_batches):
-                idx = perm[i * mb:(i + 1) * mb]
-                obs, actions = flat["obs"][idx], flat["actions"][idx]
+                sl = slice(i * mb, (i + 1) * mb)
+                obs, actions = shuffled["obs"][sl], shuffled["actions"][sl]
                 ac.update_distribution(obs)
                 logp = ac.get_actions_log_prob(actions)
                 value = ac.evaluate(obs).squeeze(-1)
@@ -135,8 +138,8 @@ class PPO:
                 if self.desired_kl is not None and self.schedule == "adaptive":
                     with torch.no_grad():
                         kl = torch.sum(torch.log(sigma / sigma_old + 1e-5)
-                                       + (sigma_old.square() + (flat["mu"][idx] - mu).square()) / (2.0 * sigma.square()) - 0.5, -1)
-                        kl_mean = float(kl.mean())
+                                       + (sigma_old.square() + (shuffled["mu"][sl] - mu).square()) / (2.0 * sigma.square()) - 0.5, -1)
+                        kl_mean = float(kl.mean())                  # the schedule needs it on the host
                     if kl_mean > self.desired_kl * 2.0:
                         self.learning_rate = max(1e-5, self.learning_rate / 1.5)
                     elif 0.0 < kl_mean < self.desired_kl / 2.0:
@@ -144,10 +147,10 @@ class PPO:
                     for g in self.optimizer.param_groups:
                         g["lr"] = self.learning_rate
                     mean_kl += kl_mean
-                adv = flat["adv"][idx]
-                ratio = torch.exp(logp - flat["logp"][idx])
+                adv = shuffled["adv"][sl]
+                ratio = torch.exp(logp - shuffled["logp"][sl])
                 surrogate = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
-                ret, v_old = flat["returns"][idx], flat["values"][idx]
+                ret, v_old = shuffled["returns"][sl], shuffled["values"][sl]
                 if self.use_clipped_value_loss:
                     v_clip = v_old + (value - v_old).clamp(-self.clip_param, self.clip_param)
                     value_loss = torch.max((value - ret).square(), (v_clip - ret).square()).mean()
@@ -158,8 +161,8 @@ class PPO:
                 loss.backward()
                 nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
                 self.optimizer.step()
-                mean_value_loss += float(value_loss.detach())
-                mean_surrogate_loss += float(surrogate.detach())
+                stats += torch.stack([value_loss.detach(), surrogate.detach()])
+        mean_value_loss, mean_surrogate_loss = stats.tolist()
         u = self.num_learning_epochs * self.num_mini_batches
         return dict(value_function=mean_value_loss / u, surrogate=mean_surrogate_loss / u, kl=mean_kl / u,
                     learning_rate=self.learning_rate)
@@ -233,18 +236,13 @@ class OnPolicyRunner:
             else:
                 obs = self._collect_stepwise(obs)
             st = self.storage
-            # book keeping of finished episodes, vectorised over the rollout (runner :88-98 does it per step)
+            # book keeping of finished episodes (runner :88-98 does it per step with a host sync each): here the whole
+            # rollout at once with cumulative sums, one device->host copy of the finished episodes' returns / lengths
             with torch.no_grad():
-                done = st.dones != 0
-                for k in range(st.n_steps):
-                    cur_reward_sum += st.rewards[k]
-                    cur_episode_length += 1
-                    if bool(done[k].any()):
-                        ids = done[k].nonzero().flatten()
-                        rewbuffer.extend(cur_reward_sum[ids].tolist())
-                        lenbuffer.extend(cur_episode_length[ids].tolist())
-                        cur_reward_sum[ids] = 0
-                        cur_episode_length[ids] = 0
+                ret, length, cur_reward_sum, cur_episode_length = _finished_episodes(st.rewards, st.dones != 0, cur_reward_sum,
+                                                                                     cur_episode_length)
+                rewbuffer.extend(ret[-100:].tolist())
+                lenbuffer.extend(length[-100:].tolist())
                 st.bootstrap_time_outs(self.alg.gamma)
             torch.cuda.synchronize() if self.device.type == "cuda" else None
             t1 = time.time()
@@ -257,7 +255,7 @@ class OnPolicyRunner:
             self.tot_time += t2 - t0
             log = dict(iteration=it, collection_time=t1 - t0, learn_time=t2 - t1, fps=steps / (t2 - t0),
                        collection_fps=steps / max(t1 - t0, 1e-9), mean_reward=_mean(rewbuffer), mean_episode_length=_mean(lenbuffer),
-                       mean_step_reward=float(st.rewards.mean()), mean_noise_std=float(self.actor_critic.std.mean()), **losses)
+                       mean_step_reward=float(st.rewards.mean()), mean_noise_std=float(self.actor_critic.std.detach().mean()), **losses)
             base = env.unwrapped
             if hasattr(base, "episode_log_summary"):
                 log.update(base.episode_log_summary(st.n_steps))
@@ -289,6 +287,27 @@ class OnPolicyRunner:
         if device is not None:
             self.actor_critic.to(device)
         return self.actor_critic.act_inference
+
+
+def _finished_episodes(rewards, done, carry_ret, carry_len):
+    """returns / lengths of the episodes that end inside a [K, n] rollout, in time order, plus the updated carries of
+    the episodes still running -- the vectorised form of the runner's per-step cur_reward_sum bookkeeping"""
+    K, n = rewards.shape
+    dev = rewards.device
+    C = rewards.cumsum(0)
+    t = torch.arange(K, device=dev)[:, None].expand(K, n)
+    last_done = torch.cummax(torch.where(done, t, torch.full_like(t, -1)), 0).values        # last done index <= k
+    prev = torch.cat([torch.full((1, n), -1, device=dev, dtype=t.dtype), last_done[:-1]])   # last done index <  k
+    started_here = prev >= 0
+    C_prev = torch.where(started_here, C.gather(0, prev.clamp(min=0)), torch.zeros_like(C))
+    ep_ret = C - C_prev + torch.where(started_here, torch.zeros_like(C), carry_ret[None].expand(K, n))
+    ep_len = (t - prev).to(rewards.dtype) + torch.where(started_here, torch.zeros_like(C), carry_len[None].expand(K, n))
+    last = last_done[-1]
+    any_done = last >= 0
+    C_last = C.gather(0, last.clamp(min=0)[None])[0]
+    new_ret = torch.where(any_done, C[-1] - C_last, carry_ret + C[-1])
+    new_len = torch.where(any_done, (K - 1 - last).to(rewards.dtype), carry_len + K)
+    return ep_ret[done], ep_len[done], new_ret, new_len
 
 
 def _mean(buf):
