@@ -58,12 +58,15 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
 // launch boundary, the state round trip through L2 and its address arithmetic are paid once per rollout.  Episode
 // metrics of all K steps accumulate into ring slot (step0 % R); slot ((step0 + K) % R) is cleared for the next launch.
 template <class Ground>
-__global__ void __launch_bounds__(kBlock) drift_rollout_kernel(const WlDriftParams p, const WlEnvBuffers b,
+__global__ void __launch_bounds__(kBlock) drift_rollout_kernel(const WlDriftParams p_arg, const WlEnvBuffers b,
                                                                const float2* __restrict__ actions, const WlStepOut out,
                                                                const int64_t obs_step_stride, const int64_t vec_step_stride,
                                                                const int n_steps, const uint64_t seed, const uint64_t step0,
-                                                               const Ground ground, const VehDerived vd) {
+                                                               const Ground ground, const VehDerived vd_arg) {
     constexpr int LANES = 4, kEnvs = kBlock / LANES;
+    WlDriftParams p = p_arg;
+    VehDerived vd = vd_arg;
+    pin_params_vgpr(p, vd);
     const int le = threadIdx.x / LANES, wid = threadIdx.x & 3;
     const bool lead = wid == 0;
     const int e = blockIdx.x * kEnvs + le;

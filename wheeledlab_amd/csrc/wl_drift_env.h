@@ -374,6 +374,40 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     }
 }
 
+// Persistent kernels keep every parameter live across the whole rollout loop: ~130 uniform dwords against 102 SGPRs, so
+// the compiler parks the overflow in lanes of a VGPR and pays a v_readlane (+ hazard nops) per use -- ~600 extra
+// instructions per env-step.  gfx950 has no scalar float ALU, so float parameters are only ever VALU operands anyway:
+// pinning them into VGPRs (one v_mov each, once per launch) frees the SGPR file for addresses and loop control, and the
+// wavefront (alone on its SIMD in these kernels) has hundreds of VGPRs to spare.
+WL_DEV void pin_vgpr(float& x) { asm volatile("" : "+v"(x)); }
+template <int N>
+WL_DEV void pin_vgpr(float (&a)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) pin_vgpr(a[i]);
+}
+WL_DEV void pin_params_vgpr(WlDriftParams& p, VehDerived& d) {
+    pin_vgpr(p.sim_dt);
+    WlActionParams& a = p.action;
+    pin_vgpr(a.scale), pin_vgpr(a.offset), pin_vgpr(a.base_length), pin_vgpr(a.base_width), pin_vgpr(a.wheel_radius);
+    WlVehicleParams& v = p.vehicle;
+    float* vf[] = {&v.gravity, &v.half_wheelbase_f, &v.half_wheelbase_r, &v.half_track, &v.wheel_radius, &v.wheel_z, &v.cg_z,
+                   &v.gyr_x, &v.gyr_y, &v.gyr_z, &v.wheel_inertia, &v.wheel_damping, &v.susp_k, &v.susp_c, &v.ground_mu_s,
+                   &v.ground_mu_d, &v.slip_peak, &v.v_min, &v.motor_sat, &v.motor_limit, &v.motor_vel_limit, &v.steer_kp,
+                   &v.steer_kd, &v.steer_effort, &v.steer_vel_limit, &v.steer_inertia};
+#pragma unroll
+    for (float* f : vf) pin_vgpr(*f);
+    float* pf[] = {&p.straight, &p.r_in, &p.r_out, &p.r_line, &p.slip_min, &p.slip_max, &p.slip_min_vx, &p.speed_target,
+                   &p.speed_offset, &p.tlgr_thresh, &p.ctd_offset, &p.ctd_p, &p.pos_noise, &p.yaw_noise, &p.hf_vel_x,
+                   &p.hf_vel_y, &p.hf_vel_yaw, &p.lf_vel_yaw};
+#pragma unroll
+    for (float* f : pf) pin_vgpr(*f);
+    pin_vgpr(p.weight), pin_vgpr(p.noise_std), pin_vgpr(p.hf_interval), pin_vgpr(p.lf_interval);
+    float* df[] = {&d.h, &d.inv_h, &d.half_h, &d.steer_a, &d.steer_b, &d.steer_J_h, &d.steer_h_J, &d.zrel, &d.Iw_h, &d.A0,
+                   &d.inv_wlim, &d.r2};
+#pragma unroll
+    for (float* f : df) pin_vgpr(*f);
+}
+
 // host-side validation shared by every drift entry point
 inline int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
     if (!p || !b || !b->state || !b->episode_len || !b->ref_poses || !b->metrics) return WL_EINVAL;

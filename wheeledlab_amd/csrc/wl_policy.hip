@@ -50,12 +50,15 @@ __global__ void __launch_bounds__(kBlock) mlp_forward_kernel(const WlMlp net, co
 // K steps of { actor -> sample -> env.step } in one launch (quad form).  Lanes whose env index is past n_envs mirror
 // the last env (the matrix pipe and the cross-lane pulls want whole wavefronts) and never store.
 template <int ACT, class Ground>
-__global__ void __launch_bounds__(kBlock) drift_policy_rollout_kernel(const WlDriftParams p, const WlEnvBuffers b, const WlMlp actor,
+__global__ void __launch_bounds__(kBlock) drift_policy_rollout_kernel(const WlDriftParams p_arg, const WlEnvBuffers b, const WlMlp actor,
                                                                       const float* __restrict__ action_std,
                                                                       const WlPolicyRollout io, const int n_steps,
                                                                       const uint64_t seed, const uint64_t step0,
-                                                                      const Ground ground, const VehDerived vd) {
+                                                                      const Ground ground, const VehDerived vd_arg) {
     constexpr int LANES = 4, kEnvs = kBlock / LANES;
+    WlDriftParams p = p_arg;
+    VehDerived vd = vd_arg;
+    pin_params_vgpr(p, vd);
     const int lane = threadIdx.x & 63;
     const int le = threadIdx.x / LANES, wid = threadIdx.x & 3;
     const int e_raw = blockIdx.x * kEnvs + le;
