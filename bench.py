@@ -132,8 +132,7 @@ def main():
             env.rollout(actions[:k], obs_buf, rew_buf, term_buf, trunc_buf)
             done += k
             if k == ROLLOUT:  # episode-metric reduction at the logging cadence
-                m = env.metrics.clone()
-                env.metrics.zero_()
+                m = env.read_metrics(zero=True)
                 if dist is not None:
                     dist.all_reduce(m)
                 metric_sum.add_(m)

@@ -232,7 +232,7 @@ def test_persistent_rollout_matches_stepping(lib, n, ring):
     msum = torch.zeros(16, device=DEV)
     same = torch.ones(n, dtype=torch.bool, device=DEV)            # envs whose discrete events agreed so far
     for k in range(K):
-        slot = e2.metrics[e2.step_count % ring] if ring > 1 else None
+        slot_idx = e2.step_count % ring
         obs, rew, term, trunc = e2.step(a[k])
         assert torch.equal(trunc, tr[k]), k
         same &= term == te[k]
@@ -241,7 +241,7 @@ def test_persistent_rollout_matches_stepping(lib, n, ring):
         tol = 2e-5 if k < 3 else 5e-3                              # rounding first, then (bounded) divergence
         assert d[same].max() < tol, (k, float(d[same].max()))
         if ring > 1:
-            msum += slot
+            msum += e2.metrics[slot_idx]
     assert same.float().mean() > 0.99
     ds = (e1.state[:23, :n] - e2.state[:23, :n]).abs()[:, same]
     assert ds[:13].max() < 5e-3 and torch.equal(e1.episode_len[:n][same], e2.episode_len[:n][same])

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 10
+WL_ABI_VERSION = 11
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -24,6 +24,7 @@ ELEV_TERM_NAMES = ("vel_towards_goal", "height_z", "falling_penalty", "terminati
 ELEV_DONE_NAMES = ("cart_out_of_bounds", "stuck", "rollover", "at_goal")
 # WlMetric
 M_EPSUM0, M_RESETS, M_TIMEOUTS, M_TERM0, M_NONFINITE, M_EPLEN, M_COUNT = 0, 8, 9, 10, 14, 15, 16
+M_SHARDS = 32   # WL_M_SHARDS: an accumulator vector is [M_SHARDS][M_COUNT], its value the sum over shards
 # WlDriftRewTerm
 DRIFT_TERM_NAMES = ("side_slip", "vel", "progress", "tlgr", "turn_energy", "cross_track", "term_pens")
 

@@ -57,7 +57,17 @@ def apply_startup_events(state: torch.Tensor, su, g: torch.Generator, randomize:
     state[A.S_MASS] = (su.chassis_mass + u(su.mass_add, n)).to(dev)
 
 
-class DriftBatch:
+class _MetricsView:
+    """`metrics_raw` is what the kernels add into: [slots][WL_M_SHARDS][WL_M_COUNT].  `metrics` is the logical value
+    (sum over the shards): [WL_M_COUNT] for one accumulator, [slots][WL_M_COUNT] for a ring; a fresh tensor per read."""
+
+    @property
+    def metrics(self) -> torch.Tensor:
+        m = self.metrics_raw.sum(1)
+        return m[0] if self.metrics_slots == 1 else m
+
+
+class DriftBatch(_MetricsView):
     """n drift envs resident on one GPU as a SoA state matrix [S_COUNT, stride] (fp32)."""
 
     OBS_DIM = 14
@@ -78,9 +88,7 @@ class DriftBatch:
         self.state = torch.zeros(A.S_COUNT, self.stride, dtype=torch.float32, device=dev)
         self.episode_len = torch.zeros(self.stride, dtype=torch.int32, device=dev)
         self.metrics_slots = int(metrics_slots)
-        self.metrics = torch.zeros(self.metrics_slots, A.M_COUNT, dtype=torch.float32, device=dev)
-        if self.metrics_slots == 1:
-            self.metrics = self.metrics[0]
+        self.metrics_raw = torch.zeros(self.metrics_slots, A.M_SHARDS, A.M_COUNT, dtype=torch.float32, device=dev)
         self.obs = torch.zeros(self.n, self.OBS_DIM, dtype=torch.float32, device=dev)
         self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
         # torch.bool is one byte holding 0 / 1: the kernel's uint8 outputs land in it directly
@@ -95,7 +103,7 @@ class DriftBatch:
         self.ref_table = self.ref_table.to(dev)
         self._startup_events(g, randomize, startup)
         self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), self.ref_table.data_ptr(),
-                                    self.metrics.data_ptr(), self.stride, self.n, self.env_offset, self.metrics_slots, 0, 0)
+                                    self.metrics_raw.data_ptr(), self.stride, self.n, self.env_offset, self.metrics_slots, 0, 0)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
                                 self.truncated.data_ptr(), self.dones.data_ptr())
 
@@ -165,7 +173,7 @@ class DriftBatch:
             # the launch folds all K steps into ring slot step0 % R and clears slot (step0 + K) % R; the slots it skips
             # would otherwise keep counts from R steps ago
             R = self.metrics_slots
-            self.metrics[[(self.step_count + i) % R for i in range(1, K)]] = 0
+            self.metrics_raw[[(self.step_count + i) % R for i in range(1, K)]] = 0
         actor, io = actor_critic.actor.struct(), storage.struct(start)
         A.check(self.lib.wl_drift_rollout_policy(C.byref(self.p), C.byref(self._bufs), C.byref(actor),
                                                  actor_critic.std.data_ptr(), C.byref(io), K, self.seed, self.step_count,
@@ -183,13 +191,13 @@ class DriftBatch:
         return storage
 
     def read_metrics(self, zero: bool = True) -> torch.Tensor:
-        m = self.metrics.clone()
+        m = self.metrics
         if zero:
-            self.metrics.zero_()
+            self.metrics_raw.zero_()
         return m
 
 
-class ElevBatch:
+class ElevBatch(_MetricsView):
     """n elevation-task envs on one GPU (same SoA state matrix; rows WL_S_CMD_* carry the goal command)."""
 
     OBS_DIM = A.ELEV_OBS_DIM
@@ -209,9 +217,7 @@ class ElevBatch:
         self.state = torch.zeros(A.S_COUNT, self.stride, dtype=torch.float32, device=dev)
         self.episode_len = torch.zeros(self.stride, dtype=torch.int32, device=dev)
         self.metrics_slots = int(metrics_slots)
-        self.metrics = torch.zeros(self.metrics_slots, A.M_COUNT, dtype=torch.float32, device=dev)
-        if self.metrics_slots == 1:
-            self.metrics = self.metrics[0]
+        self.metrics_raw = torch.zeros(self.metrics_slots, A.M_SHARDS, A.M_COUNT, dtype=torch.float32, device=dev)
         self.obs = torch.zeros(self.n, self.OBS_DIM, dtype=torch.float32, device=dev)
         self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.terminated = torch.zeros(self.n, dtype=torch.bool, device=dev)
@@ -227,7 +233,7 @@ class ElevBatch:
             startup = StartupSpec(wheel_mu_s=(2.0, 2.0), wheel_mu_d=(1.0, 1.0), mu_buckets=5, mu_consistent=False,
                                   damping=(1000.0, 1000.0), mass_add=(0.2, 0.5))
         apply_startup_events(self.state, startup, torch.Generator().manual_seed(self.seed))
-        self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics.data_ptr(),
+        self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics_raw.data_ptr(),
                                     self.stride, self.n, self.env_offset, self.metrics_slots, 0, 0)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
                                 self.truncated.data_ptr(), self.dones.data_ptr())
@@ -273,7 +279,7 @@ class ElevBatch:
         self.step_count += K
 
 
-class VisualBatch:
+class VisualBatch(_MetricsView):
     """n visual-task envs on one GPU: flat black/white traversability plane + ray-cast grey camera."""
 
     OBS_DIM = A.VIS_OBS_DIM
@@ -295,9 +301,7 @@ class VisualBatch:
         self.state = torch.zeros(A.S_COUNT, self.stride, dtype=torch.float32, device=dev)
         self.episode_len = torch.zeros(self.stride, dtype=torch.int32, device=dev)
         self.metrics_slots = int(metrics_slots)
-        self.metrics = torch.zeros(self.metrics_slots, A.M_COUNT, dtype=torch.float32, device=dev)
-        if self.metrics_slots == 1:
-            self.metrics = self.metrics[0]
+        self.metrics_raw = torch.zeros(self.metrics_slots, A.M_SHARDS, A.M_COUNT, dtype=torch.float32, device=dev)
         self.obs = torch.zeros(self.n, self.OBS_DIM, dtype=torch.float32, device=dev)
         self.reward = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.terminated = torch.zeros(self.n, dtype=torch.bool, device=dev)
@@ -314,7 +318,7 @@ class VisualBatch:
             from .envs.flatten import StartupSpec
             startup = StartupSpec(wheel_mu_s=(0.5, 0.5), wheel_mu_d=(0.5, 0.5), damping=(1000.0, 1000.0), mass_add=(0.0, 0.0))
         apply_startup_events(self.state, startup, torch.Generator().manual_seed(self.seed))
-        self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics.data_ptr(),
+        self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics_raw.data_ptr(),
                                     self.stride, self.n, self.env_offset, self.metrics_slots, 0, 0)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
                                 self.truncated.data_ptr(), self.dones.data_ptr())

@@ -25,9 +25,8 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
     const int e = blockIdx.x * kEnvs + le;
     // per-step metric ring: accumulate into slot step % R, clear the slot the NEXT launch will use
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
-    if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
-        b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
-    const MetricSink<LANES> ms{blk_metrics, b.metrics + m_slot * WL_M_COUNT};
+    if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
+    const MetricSink<LANES> ms{blk_metrics, metric_shard(b, m_slot)};
     if constexpr (LANES == 1) {
         if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
         __syncthreads();
@@ -39,8 +38,15 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         const float2 a = actions[e];
         load_env_const(S, p.vehicle, vd, e, ec);
         load_rows<LANES>(S, b, p, e, wid, r);
-        drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, le, wid, lead, (uint32_t)(b.env_offset + e), seed,
-                              step, tile, ms);
+        const uint32_t gid = (uint32_t)(b.env_offset + e);
+        if constexpr (LANES == 4) {
+            // the step's random draws need only (seed, gid, step): computed while the state loads above are in flight
+            const StepDraws pre = draw_step(p, b.ref_poses, gid, step, seed, wid);
+            drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, le, wid, lead, gid, seed, step, tile, ms, nullptr,
+                                  &pre);
+        } else {
+            drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, le, wid, lead, gid, seed, step, tile, ms);
+        }
         store_rows<LANES>(S, b, p, e, wid, lead, r);
     }
     if constexpr (LANES == 1) {
@@ -48,7 +54,7 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         flush_obs(tile, out.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
         if (threadIdx.x < WL_M_COUNT) {
             const float m = blk_metrics[threadIdx.x];
-            if (m != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], m);
+            if (m != 0.f) atomicAdd(metric_shard(b, m_slot) + threadIdx.x, m);   // threads 0..15 = wavefront 0 of the block
         }
     }
 }
@@ -71,10 +77,9 @@ __global__ void __launch_bounds__(kBlock) drift_rollout_kernel(const WlDriftPara
     const bool lead = wid == 0;
     const int e = blockIdx.x * kEnvs + le;
     const int m_slot = b.metrics_slots > 1 ? (int)(step0 % (uint64_t)b.metrics_slots) : 0;
-    if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
-        b.metrics[(int)((step0 + (uint64_t)n_steps) % (uint64_t)b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
+    if (b.metrics_slots > 1) clear_metric_slot(b, (int)((step0 + (uint64_t)n_steps) % (uint64_t)b.metrics_slots));
     if (e >= b.n_envs) return;     // the quad form has no block-level barrier: whole quads may leave
-    const MetricSink<LANES> ms{nullptr, b.metrics + m_slot * WL_M_COUNT};
+    const MetricSink<LANES> ms{nullptr, metric_shard(b, m_slot)};
     const Rows S = make_rows(b.state, b.stride);
     EnvConst ec;
     DriftRows r;

@@ -79,6 +79,15 @@ WL_DEV void write_obs_row(float* row, const WlDriftParams& p, V3 pos, V3 e /* eu
     row[13] = clampf(a1, -1.f, 1.f);
 }
 
+// quad form: lane w < 3 holds normals 4w .. 4w+3; every lane of the quad gets all twelve via DPP quad broadcasts
+WL_DEV Noise12 gather_quad_noise(const float z[4]) {
+    Noise12 nz;
+    nz.z[0] = quad_bcast<0>(z[0]); nz.z[1] = quad_bcast<0>(z[1]); nz.z[2] = quad_bcast<0>(z[2]); nz.z[3] = quad_bcast<0>(z[3]);
+    nz.z[4] = quad_bcast<1>(z[0]); nz.z[5] = quad_bcast<1>(z[1]); nz.z[6] = quad_bcast<1>(z[2]); nz.z[7] = quad_bcast<1>(z[3]);
+    nz.z[8] = quad_bcast<2>(z[0]); nz.z[9] = quad_bcast<2>(z[1]); nz.z[10] = quad_bcast<2>(z[2]); nz.z[11] = quad_bcast<2>(z[3]);
+    return nz;
+}
+
 // LANES == 4: lanes 0..2 of the quad each draw ONE Philox block (4 normals) and the 12 values are gathered with DPP
 // quad broadcasts -- one Philox + two Box-Muller on the critical path instead of three + six.  Must be called by all
 // four lanes of the quad.
@@ -94,12 +103,10 @@ WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise
         for (int k = 0; k < 12; ++k) nz.z[k] = noise[k * stride + e];
     } else if constexpr (LANES == 4) {
         const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + (uint32_t)min(wid, 2), seed);
-        float z0, z1, z2, z3;
-        box_muller(u.x, u.y, z0, z1);
-        box_muller(u.z, u.w, z2, z3);
-        nz.z[0] = quad_bcast<0>(z0); nz.z[1] = quad_bcast<0>(z1); nz.z[2] = quad_bcast<0>(z2); nz.z[3] = quad_bcast<0>(z3);
-        nz.z[4] = quad_bcast<1>(z0); nz.z[5] = quad_bcast<1>(z1); nz.z[6] = quad_bcast<1>(z2); nz.z[7] = quad_bcast<1>(z3);
-        nz.z[8] = quad_bcast<2>(z0); nz.z[9] = quad_bcast<2>(z1); nz.z[10] = quad_bcast<2>(z2); nz.z[11] = quad_bcast<2>(z3);
+        float z[4];
+        box_muller(u.x, u.y, z[0], z[1]);
+        box_muller(u.z, u.w, z[2], z[3]);
+        nz = gather_quad_noise(z);
     } else {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -109,6 +116,30 @@ WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise
         }
     }
     return nz;
+}
+
+// Everything random about one env-step that does not depend on the env's state: (seed, global env id, step) key it all.
+// The per-step kernel (quad form) draws it BEFORE it first touches the state rows, i.e. in the shadow of the cold-L2
+// load of the state matrix, instead of on the tail of the step where each draw is a dependent chain of ~100
+// instructions (and the reset's reference-pose lookup a dependent memory round trip) on the kernel's critical path:
+// the kernel ends with its slowest wavefront, and with 16 envs per wavefront nearly every step some wavefront resets
+// and most have a push.  Persistent kernels have no load shadow and draw in place.
+struct StepDraws {
+    ResetDraw reset;
+    F4 push_hf, push_lf;
+    float z[4];        // this lane's four observation-noise normals (lanes 0..2 of the quad; see obs_noise)
+};
+
+WL_DEV StepDraws draw_step(const WlDriftParams& p, const float* __restrict__ ref, uint32_t gid, uint64_t step, uint64_t seed,
+                           int wid) {
+    StepDraws d;
+    d.reset = draw_reset(p, ref, gid, step, seed);
+    d.push_hf = philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
+    d.push_lf = philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
+    const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + (uint32_t)min(wid, 2), seed);
+    box_muller(u.x, u.y, d.z[0], d.z[1]);
+    box_muller(u.z, u.w, d.z[2], d.z[3]);
+    return d;
 }
 
 // flush this block's LDS obs tile ([kBlock][kObsPad]) to obs[n][14]: contiguous dword stores per wavefront
@@ -202,7 +233,7 @@ WL_DEV void load_env_const(const Rows& S, const WlVehicleParams& vp, const VehDe
 template <int LANES>
 struct MetricSink {
     float* lds;     // block accumulators (lane form)
-    float* glob;    // this step's slot of the metric ring
+    float* glob;    // this wavefront's shard of this step's slot of the metric ring
     WL_DEV void add(int idx, float v) const {
         if constexpr (LANES == 4) atomicAdd(glob + idx, v);
         else atomicAdd(lds + idx, v);
@@ -216,7 +247,8 @@ template <int LANES, class Ground>
 WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const VehDerived& vd, const Ground& ground,
                            const Rows& S, EnvConst& ec, DriftRows& r, float2 a, const float* __restrict__ noise,
                            const WlStepOut& out, int e, int le, int wid, bool lead, uint32_t gid, uint64_t seed, uint64_t step,
-                           float* tile, const MetricSink<LANES>& ms, float* obs_keep = nullptr) {
+                           float* tile, const MetricSink<LANES>& ms, float* obs_keep = nullptr,
+                           const StepDraws* pre = nullptr) {
     const WlVehicleParams& vp = p.vehicle;
     // ---- action manager: ClipAction + process_actions + joint targets (once per env-step) ----
     float v_t, delta;
@@ -305,7 +337,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
             for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
             s.th = s.om = 0.f;
         }
-        const ResetDraw rd = draw_reset(p, b.ref_poses, gid, step, seed);
+        const ResetDraw rd = pre ? pre->reset : draw_reset(p, b.ref_poses, gid, step, seed);
         pos = rd.pos;
         s.q = rd.q;
         if constexpr (LANES == 4) euler = v3(0.f, 0.f, rd.yaw - WL_TWO_PI * floorf(rd.yaw * WL_INV_TWO_PI));
@@ -320,7 +352,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     if (p.enable_pushes) {
         timer_hf -= step_dt;
         if (timer_hf < 1e-6f) {
-            const F4 u = philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
+            const F4 u = pre ? pre->push_hf : philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
             s.v.x = fmaf(2.f * u.x - 1.f, p.hf_vel_x, s.v.x);
             s.v.y = fmaf(2.f * u.y - 1.f, p.hf_vel_y, s.v.y);
             ww.z = fmaf(2.f * u.z - 1.f, p.hf_vel_yaw, ww.z);
@@ -328,7 +360,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         }
         timer_lf -= step_dt;
         if (timer_lf < 1e-6f) {
-            const F4 u = philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
+            const F4 u = pre ? pre->push_lf : philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
             ww.z = fmaf(2.f * u.x - 1.f, p.lf_vel_yaw, ww.z);
             timer_lf = fmaf(u.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
         }
@@ -360,7 +392,9 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     const Mat3 R2 = mat_from_quat(s.q);
     vb = mul_t(R2, s.v);
     const V3 wb2 = mul_t(R2, ww);
-    const Noise12 nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // all lanes of the quad
+    Noise12 nz;
+    if (LANES == 4 && pre && p.enable_corruption && !noise) nz = gather_quad_noise(pre->z);
+    else nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // all lanes of the quad
     if constexpr (LANES == 1) euler = euler_xyz_from_quat(s.q);
     if constexpr (LANES == 4) {
         // quad form: the 14 values are replicated on the quad's lanes; a caller that feeds them to a policy in the

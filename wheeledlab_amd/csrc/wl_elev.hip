@@ -124,8 +124,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
     const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
     if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
-    if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
-        b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
+    if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
     __syncthreads();
     const Rows S = make_rows(b.state, b.stride);
     const WlVehicleParams& vp = p.vehicle;
@@ -279,7 +278,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p,
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
         const float m = blk_metrics[threadIdx.x];
-        if (m != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], m);
+        if (m != 0.f) atomicAdd(metric_shard(b, m_slot) + threadIdx.x, m);   // threads 0..15 = wavefront 0 of the block
     }
 }
 

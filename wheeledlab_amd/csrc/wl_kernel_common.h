@@ -35,6 +35,17 @@ WL_DEV void st3(const Rows& s, int row, int e, V3 v) {
     s.st(row + 2, e, v.z);
 }
 
+// Metric accumulators: [slot][WL_M_SHARDS][WL_M_COUNT] (include/wheeledlab_amd.h).
+constexpr int kMetricSlotFloats = WL_M_SHARDS * WL_M_COUNT;
+WL_DEV float* metric_shard(const WlEnvBuffers& b, int slot) {   // this wavefront's shard of `slot`
+    const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    return b.metrics + (int64_t)slot * kMetricSlotFloats + (wave & (WL_M_SHARDS - 1)) * WL_M_COUNT;
+}
+WL_DEV void clear_metric_slot(const WlEnvBuffers& b, int slot) {   // block 0 zeroes all shards of `slot`
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < kMetricSlotFloats; i += kBlock) b.metrics[(int64_t)slot * kMetricSlotFloats + i] = 0.f;
+}
+
 inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 // Step kernels come in two forms (wl_vehicle.h): lane-per-env (no redundant work: best when the chip is full) and
 // quad-per-env (one wheel per lane: shorter critical path, 4x the waves: best while the chip is under-filled).

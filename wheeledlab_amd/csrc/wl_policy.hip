@@ -63,13 +63,12 @@ __global__ void __launch_bounds__(kBlock) drift_policy_rollout_kernel(const WlDr
     const int le = threadIdx.x / LANES, wid = threadIdx.x & 3;
     const int e_raw = blockIdx.x * kEnvs + le;
     const int m_slot = b.metrics_slots > 1 ? (int)(step0 % (uint64_t)b.metrics_slots) : 0;
-    if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
-        b.metrics[(int)((step0 + (uint64_t)n_steps) % (uint64_t)b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
+    if (b.metrics_slots > 1) clear_metric_slot(b, (int)((step0 + (uint64_t)n_steps) % (uint64_t)b.metrics_slots));
     if (e_raw - (lane >> 2) >= b.n_envs) return;   // the whole wavefront is past the end (wave-uniform)
     const bool valid = e_raw < b.n_envs;
     const int e = valid ? e_raw : b.n_envs - 1;
     const bool lead = valid && wid == 0;
-    const MetricSink<LANES> ms{nullptr, b.metrics + m_slot * WL_M_COUNT};
+    const MetricSink<LANES> ms{nullptr, metric_shard(b, m_slot)};
     const Rows S = make_rows(b.state, b.stride);
     const int64_t n = b.n_envs;
 

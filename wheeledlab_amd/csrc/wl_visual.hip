@@ -84,8 +84,7 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
     const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
     if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
-    if (b.metrics_slots > 1 && blockIdx.x == 0 && threadIdx.x < WL_M_COUNT)
-        b.metrics[((m_slot + 1) % b.metrics_slots) * WL_M_COUNT + threadIdx.x] = 0.f;
+    if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
     __syncthreads();
     const Rows S = make_rows(b.state, b.stride);
     const WlVehicleParams& vp = p.vehicle;
@@ -208,7 +207,7 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
         const float v = blk_metrics[threadIdx.x];
-        if (v != 0.f) atomicAdd(&b.metrics[m_slot * WL_M_COUNT + threadIdx.x], v);
+        if (v != 0.f) atomicAdd(metric_shard(b, m_slot) + threadIdx.x, v);   // threads 0..15 = wavefront 0 of the block
     }
 }
 

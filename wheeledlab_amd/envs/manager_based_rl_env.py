@@ -175,6 +175,9 @@ class EpisodeLog(dict):
     def __missing__(self, key):
         kind, i = self._keys[key]
         m = self._metrics if self._idx is None else self._metrics[self._idx]
+        if m.dim() == 2:                       # raw accumulator [WL_M_SHARDS][WL_M_COUNT]: fold the shards once
+            m = m.sum(0)
+            self._metrics, self._idx = m, None
         v = m[i] if kind == "c" else m[A.M_EPSUM0 + i] / m[A.M_RESETS] / self._len_s
         self[key] = v
         return v
@@ -358,7 +361,7 @@ class ManagerBasedRLEnv:
         return out
 
     def _episode_log(self, slot):
-        return EpisodeLog(self._batch.metrics, slot, self._log_keys, self.max_episode_length_s)
+        return EpisodeLog(self._batch.metrics_raw, 0 if slot is None else slot, self._log_keys, self.max_episode_length_s)
 
     def episode_metrics(self, window: int | None = None, reduce_ranks: bool = True):
         """aggregate of the last `window` per-step metric slots as one [WL_M_COUNT] vector; across ranks it is ONE
@@ -368,9 +371,9 @@ class ManagerBasedRLEnv:
             R = b.metrics_slots
             w = min(window or R - 1, R - 1, b.step_count)
             idx = [(b.step_count - 1 - i) % R for i in range(w)]
-            m = b.metrics[idx].sum(0) if idx else torch.zeros(A.M_COUNT, device=self.device)
+            m = b.metrics_raw[idx].sum((0, 1)) if idx else torch.zeros(A.M_COUNT, device=self.device)
         else:
-            m = b.metrics.clone()
+            m = b.metrics
         if reduce_ranks and torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.all_reduce(m)
         return m
