@@ -36,6 +36,21 @@ __global__ void __launch_bounds__(256) k_bigargs(const BigArgs a, float* __restr
     if ((threadIdx.x & 3) == 0) base[e] = s;
 }
 
+// (G) as F but the pointers come FIRST (preloadable into SGPRs with -mllvm -amdgpu-kernarg-preload-count=N) and the
+// kernel does its 34 row loads before it needs the struct: can the struct's fetch overlap the row loads?
+__global__ void __launch_bounds__(256) k_bigargs_ptr_first(float* __restrict__ base, long stride, int n, const BigArgs a) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) >> 2;
+    if (e >= n) return;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(stride * 4 * 41), 0x00020000);
+    const int voff = e * 4, rowb = (int)(stride * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 34; ++r) s += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, r * rowb, 0));
+#pragma unroll
+    for (int i = 0; i < 160; ++i) s += a.f[i];
+    if ((threadIdx.x & 3) == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s), rs, voff, 0, 0);
+}
+
 template <class K>
 float run(K kern, float* buf, long stride, int n, int chain, int grid) {
     hipEvent_t a, b;
@@ -76,6 +91,13 @@ int main() {
         float ms;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         printf("F 640-byte kernarg, all read  : %.2f\n", ms);
+        for (int i = 0; i < 20; ++i) k_bigargs_ptr_first<<<grid, 256>>>(buf, stride, n, a);
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 1000; ++i) k_bigargs_ptr_first<<<grid, 256>>>(buf, stride, n, a);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("G pointers first + 34 loads + 640-byte struct : %.2f\n", ms);
     }
     return 0;
 }
