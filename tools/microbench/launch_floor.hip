@@ -51,6 +51,35 @@ __global__ void __launch_bounds__(256) k_bigargs_ptr_first(float* __restrict__ b
     if ((threadIdx.x & 3) == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s), rs, voff, 0, 0);
 }
 
+// (H) as F but the 640 bytes live in an ordinary (cached) device buffer and are read with scalar loads through a
+// constant-address-space pointer: kernarg memory is written by the host for every launch and read uncached
+__global__ void __launch_bounds__(256) k_devargs(const BigArgs* __restrict__ a_dev, float* __restrict__ base, long stride, int n) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) >> 2;
+    if (e >= n) return;
+    const __attribute__((address_space(4))) float* f = (const __attribute__((address_space(4))) float*)a_dev;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 160; ++i) s += f[i];
+    if ((threadIdx.x & 3) == 0) base[e] = s;
+}
+
+// (I) the candidate design: parameters in a device buffer, fetched with VECTOR loads at a lane-uniform address (into
+// VGPRs, where float parameters are consumed anyway) in the same batch as the 34 state-row loads
+__global__ void __launch_bounds__(256) k_vecargs(const float* __restrict__ a_dev, float* __restrict__ base, long stride, int n) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) >> 2;
+    if (e >= n) return;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(stride * 4 * 41), 0x00020000);
+    const int voff = e * 4, rowb = (int)(stride * 4);
+    int z = 0;
+    asm volatile("" : "+v"(z));          // a VGPR zero the compiler cannot see through: keeps the loads on the vector path
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 34; ++r) s += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, r * rowb, 0));
+#pragma unroll
+    for (int i = 0; i < 160; ++i) s += a_dev[i + z];
+    if ((threadIdx.x & 3) == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s), rs, voff, 0, 0);
+}
+
 template <class K>
 float run(K kern, float* buf, long stride, int n, int chain, int grid) {
     hipEvent_t a, b;
@@ -97,6 +126,21 @@ int main() {
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         CHECK(hipEventElapsedTime(&ms, e0, e1));
+        BigArgs* a_dev;
+        CHECK(hipMalloc(&a_dev, sizeof(BigArgs)));
+        CHECK(hipMemcpy(a_dev, &a, sizeof(BigArgs), hipMemcpyHostToDevice));
+        for (int i = 0; i < 20; ++i) k_devargs<<<grid, 256>>>(a_dev, buf, stride, n);
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 1000; ++i) k_devargs<<<grid, 256>>>(a_dev, buf, stride, n);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        { float ms2; CHECK(hipEventElapsedTime(&ms2, e0, e1)); printf("H 640 bytes from a device buffer (s_load) : %.2f\n", ms2); }
+        for (int i = 0; i < 20; ++i) k_vecargs<<<grid, 256>>>((const float*)a_dev, buf, stride, n);
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 1000; ++i) k_vecargs<<<grid, 256>>>((const float*)a_dev, buf, stride, n);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        { float ms2; CHECK(hipEventElapsedTime(&ms2, e0, e1)); printf("I 34 row loads + 640 bytes by vector loads from a device buffer : %.2f\n", ms2); }
         printf("G pointers first + 34 loads + 640-byte struct : %.2f\n", ms);
     }
     return 0;

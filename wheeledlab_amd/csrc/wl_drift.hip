@@ -11,12 +11,22 @@ namespace {
 
 // LANES = 1: lane per env (throughput form).  LANES = 4: quad per env, one wheel per lane (latency form, small n).
 template <int LANES, class Ground>
-__global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const WlDriftParams p, const WlEnvBuffers b,
-                                                            const float2* __restrict__ actions,
+__global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const WlDriftParams p_arg, const VehDerived vd_arg,
+                                                            const WlEnvBuffers b, const float2* __restrict__ actions,
                                                             const float* __restrict__ noise, const WlStepOut out,
-                                                            const uint64_t seed, const uint64_t step, const Ground ground,
-                                                            const VehDerived vd) {
+                                                            const uint64_t seed, const uint64_t step, const Ground ground) {
     constexpr int kEnvs = kBlock / LANES;   // envs per block
+    // quad (latency) form: parameters by one batch of vector loads from the kernarg segment (p_arg at byte 0, vd_arg
+    // right behind it); lane (throughput) form: the compiler's scalar loads -- latency is hidden by occupancy there and
+    // the VGPRs are needed for the env
+    WlDriftParams p = p_arg;
+    VehDerived vd = vd_arg;
+    if constexpr (LANES == 4) {
+        p = kernarg_vector_copy<WlDriftParams>(0);
+        keep_scalar_fields(p, p_arg);
+        vd = kernarg_vector_copy<VehDerived>((int)sizeof(WlDriftParams));
+        vd.n_sub = vd_arg.n_sub;
+    }
     __shared__ float tile[LANES == 1 ? kEnvs * kObsPad : 1];      // lane form only: obs transposing tile
     __shared__ float blk_metrics[WL_M_COUNT];                      // lane form only
     const int le = threadIdx.x / LANES;             // env slot within the block
@@ -236,10 +246,10 @@ int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* ac
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
     if (use_quad(b))
         drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
-            *p, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{}, vd);
+            *p, vd, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{});
     else
         drift_step_kernel<1, FlatGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
-            *p, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{}, vd);
+            *p, vd, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{});
     return launch_status();
 }
 
@@ -263,10 +273,10 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
         if (quad)
             drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
-                *p, *b, a, nullptr, o, seed, step0 + (uint64_t)k, FlatGround{}, vd);
+                *p, vd, *b, a, nullptr, o, seed, step0 + (uint64_t)k, FlatGround{});
         else
             drift_step_kernel<1, FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-                *p, *b, a, nullptr, o, seed, step0 + (uint64_t)k, FlatGround{}, vd);
+                *p, vd, *b, a, nullptr, o, seed, step0 + (uint64_t)k, FlatGround{});
     }
     return launch_status();
 }
