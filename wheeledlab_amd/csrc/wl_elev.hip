@@ -114,10 +114,18 @@ WL_DEV ElevReset draw_elev_reset(const WlElevParams& p, const HeightFieldGround&
 }
 
 template <int LANES>
-__global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
-                                                           const float2* __restrict__ actions, const WlStepOut out,
-                                                           const uint64_t seed, const uint64_t step, const VehDerived vd) {
+__global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b,
+                                                           const HeightFieldGround ground, const float2* __restrict__ actions,
+                                                           const WlStepOut out, const uint64_t seed, const uint64_t step) {
     __shared__ float blk_metrics[WL_M_COUNT];
+    WlElevParams p = p_arg;
+    VehDerived vd = vd_arg;
+    if constexpr (LANES == 4) {   // latency form: one batch of vector loads instead of dependent scalar-load round trips
+        p = kernarg_vector_copy<WlElevParams>(0);
+        keep_scalar_common(p, p_arg);
+        vd = kernarg_vector_copy<VehDerived>((int)sizeof(WlElevParams));
+        vd.n_sub = vd_arg.n_sub;
+    }
     constexpr int kEnvs = kBlock / LANES;
     const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);
     const bool lead = LANES == 1 || wid == 0;
@@ -436,9 +444,9 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
         if (o.dones) o.dones += k * vec_step_stride;
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
         if (quad)
-            elev_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, a, o, seed, step0 + (uint64_t)k, vd);
+            elev_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, g, a, o, seed, step0 + (uint64_t)k);
         else
-            elev_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, a, o, seed, step0 + (uint64_t)k, vd);
+            elev_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, g, a, o, seed, step0 + (uint64_t)k);
         elev_scan_kernel<<<(b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
     }
     return launch_status();

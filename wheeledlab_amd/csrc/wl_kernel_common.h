@@ -35,6 +35,41 @@ WL_DEV void st3(const Rows& s, int row, int e, V3 v) {
     s.st(row + 2, e, v.z);
 }
 
+// Kernel arguments live in memory the host rewrites for every launch and the GPU reads uncached; the compiler fetches
+// them with scalar loads in as many dependent batches as the 102-entry SGPR file forces (six `s_load ... s_waitcnt`
+// round trips in the step kernel's prologue, each a trip to HBM).  The latency-bound form instead copies the whole
+// parameter block with VECTOR loads at a lane-uniform address: one batch, issued from the kernarg pointer the wavefront
+// is born with, straight into VGPRs (where float parameters are consumed anyway).  Integer fields that steer scalar
+// control flow are then taken from the scalar copy again so that branches and loop bounds stay uniform.
+template <class T>
+WL_DEV T kernarg_vector_copy(int byte_offset) {
+    static_assert(sizeof(T) % 4 == 0, "dword POD");
+    constexpr int N = sizeof(T) / 4;
+    using KArg = const __attribute__((address_space(4))) uint32_t;
+    KArg* ka = (KArg*)__builtin_amdgcn_kernarg_segment_ptr();
+    int z = 0;
+    asm volatile("" : "+v"(z));   // a VGPR zero the compiler cannot fold: keeps these loads on the vector path
+    uint32_t w[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = ka[byte_offset / 4 + i + z];
+    T t;
+    __builtin_memcpy(&t, w, sizeof(T));
+    return t;
+}
+// the integer fields every task's parameter struct has (WlDriftParams / WlElevParams / WlVisualParams)
+template <class P>
+WL_DEV void keep_scalar_common(P& v, const P& s) {
+    v.decimation = s.decimation;
+    v.max_episode_length = s.max_episode_length;
+    v.action.bounding = s.action.bounding;
+    v.action.no_reverse = s.action.no_reverse;
+    v.action.clip_wrapper = s.action.clip_wrapper;
+    v.action.map = s.action.map;
+    v.vehicle.drive = s.vehicle.drive;
+    v.vehicle.substeps = s.vehicle.substeps;
+    v.log_episode_sums = s.log_episode_sums;
+}
+
 // Metric accumulators: [slot][WL_M_SHARDS][WL_M_COUNT] (include/wheeledlab_amd.h).
 constexpr int kMetricSlotFloats = WL_M_SHARDS * WL_M_COUNT;
 WL_DEV float* metric_shard(const WlEnvBuffers& b, int slot) {   // this wavefront's shard of `slot`

@@ -74,10 +74,18 @@ WL_DEV VisReset draw_visual_reset(const WlVisualParams& p, const WlTravMap& m, u
 }
 
 template <int LANES>
-__global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
-                                                             const float2* __restrict__ actions, const WlStepOut out,
-                                                             const uint64_t seed, const uint64_t step, const VehDerived vd) {
+__global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b,
+                                                             const WlTravMap m, const float2* __restrict__ actions,
+                                                             const WlStepOut out, const uint64_t seed, const uint64_t step) {
     __shared__ float blk_metrics[WL_M_COUNT];
+    WlVisualParams p = p_arg;
+    VehDerived vd = vd_arg;
+    if constexpr (LANES == 4) {   // latency form: one batch of vector loads instead of dependent scalar-load round trips
+        p = kernarg_vector_copy<WlVisualParams>(0);
+        keep_scalar_common(p, p_arg);
+        vd = kernarg_vector_copy<VehDerived>((int)sizeof(WlVisualParams));
+        vd.n_sub = vd_arg.n_sub;
+    }
     constexpr int kEnvs = kBlock / LANES;
     const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);
     const bool lead = LANES == 1 || wid == 0;
@@ -447,9 +455,9 @@ int wl_visual_rollout(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
         if (o.dones) o.dones += k * vec_step_stride;
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
         if (quad)
-            visual_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, a, o, seed, step0 + (uint64_t)k, vd);
+            visual_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
         else
-            visual_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, a, o, seed, step0 + (uint64_t)k, vd);
+            visual_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
         visual_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, o.obs);
     }
     return launch_status();
