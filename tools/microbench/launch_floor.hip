@@ -80,6 +80,23 @@ __global__ void __launch_bounds__(256) k_vecargs(const float* __restrict__ a_dev
     if ((threadIdx.x & 3) == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s), rs, voff, 0, 0);
 }
 
+// (J) as I but the 640 bytes are the kernel's own by-value argument, read with vector loads from the kernarg segment
+__global__ void __launch_bounds__(256) k_vec_kernarg(const BigArgs a, float* __restrict__ base, long stride, int n) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) >> 2;
+    if (e >= n) return;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(stride * 4 * 41), 0x00020000);
+    const int voff = e * 4, rowb = (int)(stride * 4);
+    const __attribute__((address_space(4))) float* ka = (const __attribute__((address_space(4))) float*)__builtin_amdgcn_kernarg_segment_ptr();
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 34; ++r) s += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, r * rowb, 0));
+#pragma unroll
+    for (int i = 0; i < 160; ++i) s += ka[i + z];
+    if ((threadIdx.x & 3) == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s), rs, voff, 0, 0);
+}
+
 template <class K>
 float run(K kern, float* buf, long stride, int n, int chain, int grid) {
     hipEvent_t a, b;
@@ -141,6 +158,12 @@ int main() {
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         { float ms2; CHECK(hipEventElapsedTime(&ms2, e0, e1)); printf("I 34 row loads + 640 bytes by vector loads from a device buffer : %.2f\n", ms2); }
+        for (int i = 0; i < 20; ++i) k_vec_kernarg<<<grid, 256>>>(a, buf, stride, n);
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 1000; ++i) k_vec_kernarg<<<grid, 256>>>(a, buf, stride, n);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        { float ms2; CHECK(hipEventElapsedTime(&ms2, e0, e1)); printf("J 34 row loads + 640 bytes by vector loads from the kernarg segment : %.2f\n", ms2); }
         printf("G pointers first + 34 loads + 640-byte struct : %.2f\n", ms);
     }
     return 0;

@@ -9,34 +9,44 @@
 
 namespace {
 
+// The first eight arguments (13 dwords) repeat what the state loads and the random draws need -- pointers, sizes, seed,
+// step: built with -amdgpu-kernarg-preload-count they arrive in SGPRs WITH the wavefront, so the state-row loads
+// are issued at once, next to the vector loads of the parameter block, instead of after a first kernarg round trip.
+constexpr int kHotArgBytes = 56;   // state 0, episode_len 8, actions 16, stride 24, n_envs 28, env_offset 32, seed 40, step 48
+
 // LANES = 1: lane per env (throughput form).  LANES = 4: quad per env, one wheel per lane (latency form, small n).
 template <int LANES, class Ground>
-__global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const WlDriftParams p_arg, const VehDerived vd_arg,
-                                                            const WlEnvBuffers b, const float2* __restrict__ actions,
+__global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(float* __restrict__ state, int32_t* __restrict__ episode_len,
+                                                            const float2* __restrict__ actions, const int stride,
+                                                            const int n_envs, const int env_offset, const uint64_t seed,
+                                                            const uint64_t step, const WlDriftParams p_arg,
+                                                            const VehDerived vd_arg, const WlEnvBuffers b_arg,
                                                             const float* __restrict__ noise, const WlStepOut out,
-                                                            const uint64_t seed, const uint64_t step, const Ground ground) {
+                                                            const Ground ground) {
     constexpr int kEnvs = kBlock / LANES;   // envs per block
-    // quad (latency) form: parameters by one batch of vector loads from the kernarg segment (p_arg at byte 0, vd_arg
-    // right behind it); lane (throughput) form: the compiler's scalar loads -- latency is hidden by occupancy there and
-    // the VGPRs are needed for the env
+    // quad (latency) form: parameters by one batch of vector loads from the kernarg segment (p_arg right behind the
+    // hot arguments, vd_arg behind it); lane (throughput) form: the compiler's scalar loads -- latency is hidden by
+    // occupancy there and the VGPRs are needed for the env
     WlDriftParams p = p_arg;
     VehDerived vd = vd_arg;
     if constexpr (LANES == 4) {
-        p = kernarg_vector_copy<WlDriftParams>(0);
+        p = kernarg_vector_copy<WlDriftParams>(kHotArgBytes);
         keep_scalar_fields(p, p_arg);
-        vd = kernarg_vector_copy<VehDerived>((int)sizeof(WlDriftParams));
+        vd = kernarg_vector_copy<VehDerived>(kHotArgBytes + (int)sizeof(WlDriftParams));
         vd.n_sub = vd_arg.n_sub;
     }
+    WlEnvBuffers b = b_arg;          // the hot fields from the preloaded arguments, the rest when the kernarg block lands
+    b.state = state;
+    b.episode_len = episode_len;
+    b.stride = stride;
+    b.n_envs = n_envs;
+    b.env_offset = env_offset;
     __shared__ float tile[LANES == 1 ? kEnvs * kObsPad : 1];      // lane form only: obs transposing tile
     __shared__ float blk_metrics[WL_M_COUNT];                      // lane form only
     const int le = threadIdx.x / LANES;             // env slot within the block
     const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);   // this lane's wheel (quad form)
     const bool lead = LANES == 1 || wid == 0;       // the lane that writes the env's shared rows / outputs
     const int e = blockIdx.x * kEnvs + le;
-    // per-step metric ring: accumulate into slot step % R, clear the slot the NEXT launch will use
-    const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
-    if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
-    const MetricSink<LANES> ms{blk_metrics, metric_shard(b, m_slot)};
     if constexpr (LANES == 1) {
         if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
         __syncthreads();
@@ -49,6 +59,10 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         load_env_const(S, p.vehicle, vd, e, ec);
         load_rows<LANES>(S, b, p, e, wid, r);
         const uint32_t gid = (uint32_t)(b.env_offset + e);
+        // per-step metric ring: accumulate into slot step % R (first use of the non-preloaded kernarg fields: after
+        // the loads above are in flight)
+        const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
+        const MetricSink<LANES> ms{blk_metrics, metric_shard(b, m_slot)};
         if constexpr (LANES == 4) {
             // the step's random draws need only (seed, gid, step): computed while the state loads above are in flight
             const StepDraws pre = draw_step(p, b.ref_poses, gid, step, seed, wid);
@@ -59,6 +73,8 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(const 
         }
         store_rows<LANES>(S, b, p, e, wid, lead, r);
     }
+    const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
+    if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);   // the slot the NEXT launch will use
     if constexpr (LANES == 1) {
         __syncthreads();
         flush_obs(tile, out.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
@@ -246,10 +262,12 @@ int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* ac
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
     if (use_quad(b))
         drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
-            *p, vd, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{});
+            b->state, b->episode_len, (const float2*)actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b,
+            noise, *out, FlatGround{});
     else
         drift_step_kernel<1, FlatGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
-            *p, vd, *b, (const float2*)actions, noise, *out, seed, step, FlatGround{});
+            b->state, b->episode_len, (const float2*)actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b,
+            noise, *out, FlatGround{});
     return launch_status();
 }
 
@@ -273,10 +291,12 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
         if (quad)
             drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
-                *p, vd, *b, a, nullptr, o, seed, step0 + (uint64_t)k, FlatGround{});
+                b->state, b->episode_len, a, (int)b->stride, b->n_envs, b->env_offset, seed, step0 + (uint64_t)k, *p, vd, *b,
+                nullptr, o, FlatGround{});
         else
             drift_step_kernel<1, FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-                *p, vd, *b, a, nullptr, o, seed, step0 + (uint64_t)k, FlatGround{});
+                b->state, b->episode_len, a, (int)b->stride, b->n_envs, b->env_offset, seed, step0 + (uint64_t)k, *p, vd, *b,
+                nullptr, o, FlatGround{});
     }
     return launch_status();
 }
