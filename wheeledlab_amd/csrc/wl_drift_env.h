@@ -225,6 +225,8 @@ WL_DEV void load_env_const(const Rows& S, const WlVehicleParams& vp, const VehDe
     ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
     ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
     ec.damp = S.ld(WL_S_DAMP, e);
+    ec.inv_A0 = rcp(vd.A0);
+    ec.inv_A0_damp = rcp(vd.A0 + ec.damp);
 }
 
 // Episode-metric accumulation.  Lane form: LDS atomics per block, <= 16 global atomics per block at the end (many
@@ -268,7 +270,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         s.wb = mul_t(R, r.ww);
     }
     // ---- physics: decimation x substeps, everything in registers ----
-    for (int k = 0; k < vd.n_sub; ++k) vehicle_substep<LANES>(vp, vd, ec, s, ground, wid);
+    vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
     const Mat3 R = mat_from_quat(s.q);
     V3 ww = mul(R, s.wb);
     V3 pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);

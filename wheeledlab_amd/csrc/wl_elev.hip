@@ -147,6 +147,8 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
         ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
         ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
         ec.damp = S.ld(WL_S_DAMP, e);
+        ec.inv_A0 = rcp(vd.A0);
+        ec.inv_A0_damp = rcp(vd.A0 + ec.damp);
         VehState s;
         V3 pos = ld3(S, WL_S_PX, e);
         s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
             s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
             s.wb = mul_t(R, ww);
         }
-        for (int k = 0; k < vd.n_sub; ++k) vehicle_substep<LANES>(vp, vd, ec, s, ground, wid);
+        vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
         asm volatile("" ::: "memory");   // bookkeeping rows are fetched after the physics loop (register pressure)
         const Mat3 R = mat_from_quat(s.q);
         ww = mul(R, s.wb);

@@ -19,6 +19,7 @@ struct EnvConst {   // per-env constants hoisted out of the sub-step loop
     float K_cap;               // 0.125 m / h
     float mu_s, mu_d;          // combined (wheel x ground) friction
     float damp;                // throttle damping of driven wheels
+    float inv_A0, inv_A0_damp; // 1 / (Iw/h + bearing damping) and 1 / (that + damp): the saturated-branch wheel solve
     V3 Ib, h_inv_Ib;           // body inertia diag ; h / I
     float steer_target;
     float wheel_target[4];
@@ -128,12 +129,11 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const E
         const float scale = Fmax * rsq(fmaxf(mag2, 1e-30f));
         Fx *= scale;
         Fy *= scale;
-        const float A2 = vd.A0;
         const float rhs2 = fmaf(Iw_h, w_i, -r * Fx);
-        const float w_u2 = fmaf(d, wt, rhs2) * rcp(A2 + d);
+        const float w_u2 = fmaf(d, wt, rhs2) * (driven ? ec.inv_A0_damp : ec.inv_A0);   // 1 / (A0 + d), per-env constants
         const float tau_u2 = d * (wt - w_u2);
         const float tau2 = clampf(tau_u2, tau_lo, tau_hi);
-        w_n = (tau2 == tau_u2) ? w_u2 : (rhs2 + tau2) * rcp(A2);
+        w_n = (tau2 == tau_u2) ? w_u2 : (rhs2 + tau2) * ec.inv_A0;
     }
     w_spin = w_n;
     Fi = fma3(Fz, n, fma3(Fx, tx, Fy * ty));
@@ -196,12 +196,9 @@ WL_DEV V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)
 //               the critical path per sub-step drops from 4 wheels to 1.
 template <int LANES, class Ground>
 WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
-                            const Ground& ground, int wid = 0) {
-    steer_update(vp, vd, ec, s);
+                            const Ground& ground, int wid, float sn, float cs /* sin / cos of the steer angle in force */) {
     const Mat3 R = mat_from_quat(s.q);
     const V3 ww = mul(R, s.wb);
-    float sn, cs;
-    sincos_fast(s.th, sn, cs);   // |th| <= tan(0.488) rad: hardware sin/cos, ~1e-6 abs
     V3 F = v3(0.f, 0.f, 0.f), T = v3(0.f, 0.f, 0.f);
     if constexpr (LANES == 1) {
 #ifndef WL_UNROLLED_WHEELS
@@ -255,4 +252,18 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
         T = quad_sum(Ti);
     }
     body_integrate(vd, ec, s, R, F, T);
+}
+
+// decimation x substeps integrator sub-steps (everything in registers).  A variant that software-pipelined the steering
+// joint one sub-step ahead measured no gain: these kernels are bound by instruction issue (4 cycles per wave64 VALU
+// instruction), not by the dependent chain, so only fewer instructions help.
+template <int LANES, class Ground>
+WL_DEV void vehicle_integrate(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
+                              const Ground& ground, int wid = 0) {
+    for (int k = 0; k < vd.n_sub; ++k) {
+        steer_update(vp, vd, ec, s);
+        float sn, cs;
+        sincos_fast(s.th, sn, cs);   // |th| <= tan(0.488) rad: hardware sin/cos, ~1e-6 abs
+        vehicle_substep<LANES>(vp, vd, ec, s, ground, wid, sn, cs);
+    }
 }

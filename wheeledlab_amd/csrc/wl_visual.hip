@@ -107,6 +107,8 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
         ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
         ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
         ec.damp = S.ld(WL_S_DAMP, e);
+        ec.inv_A0 = rcp(vd.A0);
+        ec.inv_A0_damp = rcp(vd.A0 + ec.damp);
         VehState s;
         V3 pos = ld3(S, WL_S_PX, e);
         s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
             s.wb = mul_t(R, ww);
         }
         const FlatGround ground{};
-        for (int k = 0; k < vd.n_sub; ++k) vehicle_substep<LANES>(vp, vd, ec, s, ground, wid);
+        vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
         asm volatile("" ::: "memory");
         const Mat3 R = mat_from_quat(s.q);
         ww = mul(R, s.wb);
