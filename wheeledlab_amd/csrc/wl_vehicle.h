@@ -140,6 +140,113 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const E
     Ti = cross(arm, Fi);
 }
 
+// ---- packed axle form (lane-per-env kernels) ---------------------------------------------------------------------------
+// tools/microbench/valu_issue.hip: a wavefront that is alone on its SIMD issues one VALU instruction every ~4.5 cycles
+// (8 when it depends on the previous one) whether it is v_fma_f32 or v_pk_fma_f32 -- the packed one is free there; with
+// >= 2 wavefronts per SIMD the pipe takes 2 cycles for v_fma_f32 and 4 for v_pk_fma_f32 (same flops either way).  So
+// packing pays exactly while the lane form runs at ~1 wavefront per SIMD (32 K .. ~130 K envs: 17.1 -> 13.8 us at
+// 65 536) and is neutral beyond (1 M: 113 vs 114 us).  The two wheels of an axle run the same arithmetic on different
+// data: held as float2 (.x = left, .y = right) their mul / add / fma become packed instructions; max / min / select /
+// rcp / rsq / sqrt have no packed form and are issued per element.  wheel_force_axle is wheel_force, line by line,
+// on pairs.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct V3p {
+    f2 x, y, z;
+};
+WL_DEV f2 splat(float a) { return f2{a, a}; }
+WL_DEV f2 pfma(f2 a, f2 b, f2 c) { return a * b + c; }     // contracts to v_pk_fma_f32
+WL_DEV f2 pmax(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+WL_DEV f2 pmin(f2 a, f2 b) { return f2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
+WL_DEV f2 pabs(f2 a) { return f2{fabsf(a.x), fabsf(a.y)}; }
+WL_DEV f2 prcp(f2 a) { return f2{rcp(a.x), rcp(a.y)}; }
+WL_DEV f2 prsq(f2 a) { return f2{rsq(a.x), rsq(a.y)}; }
+WL_DEV f2 psqrt(f2 a) { return f2{fsqrt(a.x), fsqrt(a.y)}; }
+WL_DEV f2 pclamp(f2 a, f2 lo, f2 hi) { return pmin(pmax(a, lo), hi); }
+WL_DEV f2 psel(bool c0, bool c1, f2 a, f2 b) { return f2{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
+WL_DEV f2 pdot(const V3p& a, const V3p& b) { return pfma(a.x, b.x, pfma(a.y, b.y, a.z * b.z)); }
+WL_DEV f2 pdot(V3 a, const V3p& b) { return pfma(splat(a.x), b.x, pfma(splat(a.y), b.y, splat(a.z) * b.z)); }
+WL_DEV V3p pcross(const V3p& a, const V3p& b) { return V3p{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+WL_DEV V3p pcross(V3 a, const V3p& b) {
+    return V3p{splat(a.y) * b.z - splat(a.z) * b.y, splat(a.z) * b.x - splat(a.x) * b.z, splat(a.x) * b.y - splat(a.y) * b.x};
+}
+
+// the two wheels of one axle (front: steered).  F / T: their summed contact force / torque about the CoM (world).
+WL_DEV void wheel_force_axle(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Mat3& R, V3 x, V3 v,
+                             V3 ww, float cs, float sn, f2 zg, const V3p& n, bool front, f2 wt, f2& w_spin, V3& F, V3& T) {
+    const f2 r = splat(vp.wheel_radius);
+    const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r;
+    const f2 by = f2{vp.half_track, -vp.half_track};
+    // arm_c = R pb with pb = (bx, +-half_track, zrel): the x / z parts are shared by the two wheels
+    const V3p arm_c{pfma(splat(R.r0.y), by, splat(fmaf(R.r0.x, bx, R.r0.z * vd.zrel))),
+                    pfma(splat(R.r1.y), by, splat(fmaf(R.r1.x, bx, R.r1.z * vd.zrel))),
+                    pfma(splat(R.r2.y), by, splat(fmaf(R.r2.x, bx, R.r2.z * vd.zrel)))};
+    const f2 cz = splat(x.z) + arm_c.z;
+    const f2 pen = r - (cz - zg) * n.z;
+    const V3p arm{arm_c.x - r * n.x, arm_c.y - r * n.y, arm_c.z - r * n.z};
+    const V3p wxa = pcross(ww, arm);
+    const V3p vcp{splat(v.x) + wxa.x, splat(v.y) + wxa.y, splat(v.z) + wxa.z};
+    const f2 vn = pdot(vcp, n);
+    const f2 fz_raw = pmax(pfma(splat(vp.susp_k), pen, -splat(vp.susp_c) * vn), splat(0.f));
+    const f2 Fz = psel(pen.x > 0.f, pen.y > 0.f, fz_raw, splat(0.f));
+    // wheel heading (shared by the axle) projected into each wheel's contact plane
+    const float hc = front ? cs : 1.f, hs = front ? sn : 0.f;
+    const V3 hw = v3(fmaf(R.r0.x, hc, R.r0.y * hs), fmaf(R.r1.x, hc, R.r1.y * hs), fmaf(R.r2.x, hc, R.r2.y * hs));
+    const f2 hn = pdot(hw, n);
+    const V3p t{splat(hw.x) - hn * n.x, splat(hw.y) - hn * n.y, splat(hw.z) - hn * n.z};
+    const f2 inv_t = prsq(pdot(t, t));
+    const V3p tx{inv_t * t.x, inv_t * t.y, inv_t * t.z};
+    const V3p ty = pcross(n, tx);
+    const f2 vcx = pdot(vcp, tx), vcy = pdot(vcp, ty);
+    const f2 w_i = w_spin;
+    const f2 vden = pmax(splat(vp.v_min), splat(vp.slip_peak) * pmax(pabs(vcx), pabs(w_i * r)));
+    const f2 inv_vden = prcp(vden);
+    const f2 sx = (w_i * r - vcx) * inv_vden, sy = -vcy * inv_vden;
+    const f2 sig = psqrt(pfma(sx, sx, sy * sy));
+    const f2 inv_sig = prcp(pmax(sig, splat(1.f)));
+    const f2 g_lo = splat(ec.mu_s) * (splat(2.f) - sig);
+    const f2 g_hi = pfma(splat(ec.mu_s - ec.mu_d), inv_sig, splat(ec.mu_d)) * inv_sig;
+    const f2 gq = psel(sig.x <= 1.f, sig.y <= 1.f, g_lo, g_hi);
+    const f2 K = pmin(Fz * gq * inv_vden, splat(ec.K_cap));
+    const bool driven = (vp.drive == 1) || !front;
+    const f2 d = splat(driven ? ec.damp : 0.f);
+    const f2 rel = w_i * splat(vd.inv_wlim);
+    const f2 tau_hi = pclamp(splat(vp.motor_sat) * (splat(1.f) - rel), splat(0.f), splat(vp.motor_limit));
+    const f2 tau_lo = pclamp(splat(vp.motor_sat) * (splat(-1.f) - rel), splat(-vp.motor_limit), splat(0.f));
+    const f2 Iw_h = splat(vd.Iw_h);
+    const f2 A = pfma(K, splat(vd.r2), splat(vd.A0));
+    const f2 rhs0 = pfma(Iw_h, w_i, r * K * vcx);
+    const f2 w_u = pfma(d, wt, rhs0) * prcp(A + d);
+    const f2 tau_u = d * (wt - w_u);
+    const f2 tau = pclamp(tau_u, tau_lo, tau_hi);
+    const f2 w_c = (rhs0 + tau) * prcp(A);
+    f2 w_n = psel(tau.x == tau_u.x, tau.y == tau_u.y, w_u, w_c);
+    f2 Fx = K * pfma(w_n, r, -vcx);
+    f2 Fy = -K * vcy;
+    const f2 Fmax = splat(ec.mu_s) * Fz;
+    const f2 mag2 = pfma(Fx, Fx, Fy * Fy);
+    const f2 fm2 = Fmax * Fmax;
+    const bool sat0 = mag2.x > fm2.x, sat1 = mag2.y > fm2.y;
+    if (sat0 || sat1) {   // friction-circle saturation: re-solve the wheel against the force actually applied
+        const f2 scale = psel(sat0, sat1, Fmax * prsq(pmax(mag2, splat(1e-30f))), splat(1.f));
+        Fx *= scale;
+        Fy *= scale;
+        const f2 inv_A2d = splat(driven ? ec.inv_A0_damp : ec.inv_A0);
+        const f2 rhs2 = pfma(Iw_h, w_i, -r * Fx);
+        const f2 w_u2 = pfma(d, wt, rhs2) * inv_A2d;
+        const f2 tau_u2 = d * (wt - w_u2);
+        const f2 tau2 = pclamp(tau_u2, tau_lo, tau_hi);
+        const f2 w_c2 = (rhs2 + tau2) * splat(ec.inv_A0);
+        const f2 w_s = psel(tau2.x == tau_u2.x, tau2.y == tau_u2.y, w_u2, w_c2);
+        w_n = psel(sat0, sat1, w_s, w_n);
+    }
+    w_spin = w_n;
+    const V3p Fi{pfma(Fz, n.x, pfma(Fx, tx.x, Fy * ty.x)), pfma(Fz, n.y, pfma(Fx, tx.y, Fy * ty.y)),
+                 pfma(Fz, n.z, pfma(Fx, tx.z, Fy * ty.z))};
+    const V3p Ti = pcross(arm, Fi);
+    F = v3(Fi.x.x + Fi.x.y, Fi.y.x + Fi.y.y, Fi.z.x + Fi.z.y);
+    T = v3(Ti.x.x + Ti.x.y, Ti.y.x + Ti.y.y, Ti.z.x + Ti.z.y);
+}
+
 // steering: implicit PD drive, effort- and rate-limited (hound.py:5-12)
 WL_DEV void steer_update(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s) {
     const float e = ec.steer_target - s.th;
@@ -201,7 +308,31 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
     const V3 ww = mul(R, s.wb);
     V3 F = v3(0.f, 0.f, 0.f), T = v3(0.f, 0.f, 0.f);
     if constexpr (LANES == 1) {
-#ifndef WL_UNROLLED_WHEELS
+#if !defined(WL_SCALAR_WHEELS)
+        // two iterations (rear, front axle), the two wheels of an axle as packed pairs
+#pragma unroll 1
+        for (int ax = 0; ax < 2; ++ax) {
+            const bool front = ax == 1;
+            const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r;
+            const float sx_ = fmaf(R.r0.x, bx, R.r0.z * vd.zrel), sy_ = fmaf(R.r1.x, bx, R.r1.z * vd.zrel);
+            const float cxl = s.x.x + fmaf(R.r0.y, vp.half_track, sx_), cxr = s.x.x + fmaf(R.r0.y, -vp.half_track, sx_);
+            const float cyl = s.x.y + fmaf(R.r1.y, vp.half_track, sy_), cyr = s.x.y + fmaf(R.r1.y, -vp.half_track, sy_);
+            float zl, zr;
+            V3 nl, nr, Fa, Ta;
+            ground.sample(cxl, cyl, zl, nl);
+            ground.sample(cxr, cyr, zr, nr);
+            const V3p n{f2{nl.x, nr.x}, f2{nl.y, nr.y}, f2{nl.z, nr.z}};
+            f2 w = front ? f2{s.wheel[2], s.wheel[3]} : f2{s.wheel[0], s.wheel[1]};
+            const f2 wt = front ? f2{ec.wheel_target[2], ec.wheel_target[3]} : f2{ec.wheel_target[0], ec.wheel_target[1]};
+            wheel_force_axle(vp, vd, ec, R, s.x, s.v, ww, cs, sn, f2{zl, zr}, n, front, wt, w, Fa, Ta);
+            s.wheel[0] = front ? s.wheel[0] : w.x;
+            s.wheel[1] = front ? s.wheel[1] : w.y;
+            s.wheel[2] = front ? w.x : s.wheel[2];
+            s.wheel[3] = front ? w.y : s.wheel[3];
+            F = F + Fa;
+            T = T + Ta;
+        }
+#elif !defined(WL_UNROLLED_WHEELS)   // A/B builds: -DWL_SCALAR_WHEELS (rolled loop over 4 wheels), + -DWL_UNROLLED_WHEELS
         // rolled wheel loop (default; -DWL_UNROLLED_WHEELS restores the 4x inlined form: 140 vs 121 VGPRs, 3 vs 4 waves/SIMD): one wheel's temporaries live at a time and the loop body is a quarter of the code; the
         // loop counter is scalar, so picking the wheel's spin / target is a handful of s_cselect-driven moves
 #pragma unroll 1
