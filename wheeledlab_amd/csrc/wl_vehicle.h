@@ -386,8 +386,8 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
 }
 
 // decimation x substeps integrator sub-steps (everything in registers).  A variant that software-pipelined the steering
-// joint one sub-step ahead measured no gain: these kernels are bound by instruction issue (4 cycles per wave64 VALU
-// instruction), not by the dependent chain, so only fewer instructions help.
+// joint one sub-step ahead measured no gain: a wavefront alone on its SIMD pays ~3 ns per instruction whatever the
+// chain looks like (tools/microbench/valu_issue.hip), so only fewer instructions on the critical lane help.
 template <int LANES, class Ground>
 WL_DEV void vehicle_integrate(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
                               const Ground& ground, int wid = 0) {
