@@ -46,11 +46,6 @@ WL_DEV ResetDraw draw_reset(const WlDriftParams& p, const float* __restrict__ re
 // BlindObsCfg.PolicyCfg (wheeledlab_tasks/common/observations.py:24-54) into this wave's LDS tile
 // quad form: the 14 observation values are replicated on the four lanes of the env's quad, so each lane stores its
 // quarter as 8-byte words -- a wavefront (16 envs) writes one contiguous 896-byte run, no LDS transpose needed
-// by-value pick of this lane's element: the operands are SSA values, so the selection is three v_cndmask.  (Written as
-// a ternary chain over array elements the compiler folds it into a wid-indexed load of the array, which then lives in
-// scratch memory -- a store -> load round trip on the critical tail of the step.)
-WL_DEV float quad_pick(int wid, float a, float b, float c, float d) { return wid == 0 ? a : wid == 1 ? b : wid == 2 ? c : d; }
-
 WL_DEV void store_obs_quad(float* __restrict__ row /* obs + e * 14 */, int wid, const float o[14]) {
     float2* r2 = reinterpret_cast<float2*>(row);   // 56 B per env: 8-byte aligned
     r2[wid * 2] = make_float2(quad_pick(wid, o[0], o[4], o[8], o[12]), quad_pick(wid, o[1], o[5], o[9], o[13]));
@@ -256,6 +251,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     float v_t, delta;
     process_action(p.action, a.x, a.y, v_t, delta);
     joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
+    ec.wt_lane = LANES == 4 ? quad_pick(wid, ec.wheel_target[0], ec.wheel_target[1], ec.wheel_target[2], ec.wheel_target[3]) : 0.f;
     // ---- memory form -> integrator form (CoM position, body-frame angular velocity) ----
     VehState s;
     s.q = r.q;

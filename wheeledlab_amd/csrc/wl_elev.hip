@@ -143,6 +143,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
         process_action(p.action, a.x, a.y, v_t, delta);
         EnvConst ec;
         joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
+        ec.wt_lane = LANES == 4 ? quad_pick(wid, ec.wheel_target[0], ec.wheel_target[1], ec.wheel_target[2], ec.wheel_target[3]) : 0.f;
         env_const_mass(ec, vp, vd, S.ld(WL_S_MASS, e));
         ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
         ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);

@@ -11,6 +11,7 @@ typedef float wl_float2_u __attribute__((ext_vector_type(2), aligned(4)));
 
 // bilinear heightfield sampler (spec: oracle/heightfield.py::sample)
 struct HeightFieldGround {
+    static constexpr bool kFlat = false;
     WlHeightField f;
     float inv_cell;
     WL_DEV bool sample_full(float x, float y, float& z, V3& n) const {

@@ -23,6 +23,7 @@ struct EnvConst {   // per-env constants hoisted out of the sub-step loop
     V3 Ib, h_inv_Ib;           // body inertia diag ; h / I
     float steer_target;
     float wheel_target[4];
+    float wt_lane;             // quad form: the target of THIS lane's wheel (picked once per env-step, not per sub-step)
 };
 
 
@@ -68,15 +69,24 @@ WL_DEV void env_const_mass(EnvConst& ec, const WlVehicleParams& vp, const VehDer
 }
 
 struct FlatGround {
+    static constexpr bool kFlat = true;   // n == (0, 0, 1), zg == 0 everywhere: wheel_force drops the terms that vanish
     WL_DEV void sample(float, float, float& zg, V3& n) const {
         zg = 0.f;
         n = v3(0.f, 0.f, 1.f);
     }
 };
 
+// by-value pick of this lane's element: the operands are SSA values, so the selection is three v_cndmask.  (Written as
+// a ternary chain over array elements the compiler folds it into a wid-indexed load of the array, which then lives in
+// scratch memory -- a store -> load round trip on the critical tail of the step.)
+WL_DEV float quad_pick(int wid, float a, float b, float c, float d) { return wid == 0 ? a : wid == 1 ? b : wid == 2 ? c : d; }
+
 // Contact + tyre + wheel-spin solve of ONE wheel.  `front` / `left` are compile-time constants in the lane-per-env
 // kernels (the call is inlined per wheel) and per-lane values in the quad kernels (one wheel per lane).
 // Returns the contact force on the body (world) and its torque about the CoM; updates the wheel spin.
+// FLAT (plane z = 0, n = +z): the products with the zero components of n are spelled out as absent -- the compiler must
+// keep `x * 0` (x could be inf / NaN) and would issue a dozen of them per wheel and sub-step.
+template <bool FLAT>
 WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Mat3& R, V3 x, V3 v,
                         V3 ww, float cs, float sn, float zg, V3 n, bool front, bool left, float wt, float& w_spin,
                         V3& Fi, V3& Ti) {
@@ -84,18 +94,36 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const E
     const V3 pb = v3(front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, left ? vp.half_track : -vp.half_track, vd.zrel);
     const V3 arm_c = mul(R, pb);
     const float cz = x.z + arm_c.z;
-    const float pen = r - (cz - zg) * n.z;
-    const V3 arm = fma3(-r, n, arm_c);
-    const V3 vcp = v + cross(ww, arm);
-    const float vn = dot(vcp, n);
+    float pen, vn, vcx, vcy;
+    V3 arm, vcp, tx, ty;
+    if constexpr (FLAT) {
+        pen = r - cz;
+        arm = v3(arm_c.x, arm_c.y, arm_c.z - r);
+        vcp = v + cross(ww, arm);
+        vn = vcp.z;
+    } else {
+        pen = r - (cz - zg) * n.z;
+        arm = fma3(-r, n, arm_c);
+        vcp = v + cross(ww, arm);
+        vn = dot(vcp, n);
+    }
     const float Fz = pen > 0.f ? fmaxf(fmaf(vp.susp_k, pen, -vp.susp_c * vn), 0.f) : 0.f;
     // wheel heading projected into the contact plane (front wheels are rotated by the steer angle)
     const float hc = front ? cs : 1.f, hs = front ? sn : 0.f;
     const V3 hw = v3(fmaf(R.r0.x, hc, R.r0.y * hs), fmaf(R.r1.x, hc, R.r1.y * hs), fmaf(R.r2.x, hc, R.r2.y * hs));
-    const V3 t = fma3(-dot(hw, n), n, hw);
-    const V3 tx = rsq(dot(t, t)) * t;
-    const V3 ty = cross(n, tx);
-    const float vcx = dot(vcp, tx), vcy = dot(vcp, ty);
+    if constexpr (FLAT) {
+        const float inv = rsq(fmaf(hw.x, hw.x, hw.y * hw.y));
+        tx = v3(inv * hw.x, inv * hw.y, 0.f);
+        ty = v3(-tx.y, tx.x, 0.f);
+        vcx = fmaf(vcp.x, tx.x, vcp.y * tx.y);
+        vcy = fmaf(vcp.y, tx.x, -vcp.x * tx.y);
+    } else {
+        const V3 t = fma3(-dot(hw, n), n, hw);
+        tx = rsq(dot(t, t)) * t;
+        ty = cross(n, tx);
+        vcx = dot(vcp, tx);
+        vcy = dot(vcp, ty);
+    }
     const float w_i = w_spin;
     const float vden = fmaxf(vp.v_min, vp.slip_peak * fmaxf(fabsf(vcx), fabsf(w_i * r)));
     const float inv_vden = rcp(vden);
@@ -136,7 +164,8 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const E
         w_n = (tau2 == tau_u2) ? w_u2 : (rhs2 + tau2) * ec.inv_A0;
     }
     w_spin = w_n;
-    Fi = fma3(Fz, n, fma3(Fx, tx, Fy * ty));
+    if constexpr (FLAT) Fi = v3(fmaf(Fx, tx.x, -Fy * tx.y), fmaf(Fx, tx.y, Fy * tx.x), Fz);
+    else Fi = fma3(Fz, n, fma3(Fx, tx, Fy * ty));
     Ti = cross(arm, Fi);
 }
 
@@ -171,6 +200,7 @@ WL_DEV V3p pcross(V3 a, const V3p& b) {
 }
 
 // the two wheels of one axle (front: steered).  F / T: their summed contact force / torque about the CoM (world).
+template <bool FLAT>
 WL_DEV void wheel_force_axle(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Mat3& R, V3 x, V3 v,
                              V3 ww, float cs, float sn, f2 zg, const V3p& n, bool front, f2 wt, f2& w_spin, V3& F, V3& T) {
     const f2 r = splat(vp.wheel_radius);
@@ -181,22 +211,40 @@ WL_DEV void wheel_force_axle(const WlVehicleParams& vp, const VehDerived& vd, co
                     pfma(splat(R.r1.y), by, splat(fmaf(R.r1.x, bx, R.r1.z * vd.zrel))),
                     pfma(splat(R.r2.y), by, splat(fmaf(R.r2.x, bx, R.r2.z * vd.zrel)))};
     const f2 cz = splat(x.z) + arm_c.z;
-    const f2 pen = r - (cz - zg) * n.z;
-    const V3p arm{arm_c.x - r * n.x, arm_c.y - r * n.y, arm_c.z - r * n.z};
+    f2 pen, vn, vcx, vcy;
+    V3p arm, tx, ty;
+    if constexpr (FLAT) {
+        pen = r - cz;
+        arm = V3p{arm_c.x, arm_c.y, arm_c.z - r};
+    } else {
+        pen = r - (cz - zg) * n.z;
+        arm = V3p{arm_c.x - r * n.x, arm_c.y - r * n.y, arm_c.z - r * n.z};
+    }
     const V3p wxa = pcross(ww, arm);
     const V3p vcp{splat(v.x) + wxa.x, splat(v.y) + wxa.y, splat(v.z) + wxa.z};
-    const f2 vn = pdot(vcp, n);
+    if constexpr (FLAT) vn = vcp.z;
+    else vn = pdot(vcp, n);
     const f2 fz_raw = pmax(pfma(splat(vp.susp_k), pen, -splat(vp.susp_c) * vn), splat(0.f));
     const f2 Fz = psel(pen.x > 0.f, pen.y > 0.f, fz_raw, splat(0.f));
     // wheel heading (shared by the axle) projected into each wheel's contact plane
     const float hc = front ? cs : 1.f, hs = front ? sn : 0.f;
     const V3 hw = v3(fmaf(R.r0.x, hc, R.r0.y * hs), fmaf(R.r1.x, hc, R.r1.y * hs), fmaf(R.r2.x, hc, R.r2.y * hs));
-    const f2 hn = pdot(hw, n);
-    const V3p t{splat(hw.x) - hn * n.x, splat(hw.y) - hn * n.y, splat(hw.z) - hn * n.z};
-    const f2 inv_t = prsq(pdot(t, t));
-    const V3p tx{inv_t * t.x, inv_t * t.y, inv_t * t.z};
-    const V3p ty = pcross(n, tx);
-    const f2 vcx = pdot(vcp, tx), vcy = pdot(vcp, ty);
+    if constexpr (FLAT) {   // one tangent frame for the axle
+        const float inv = rsq(fmaf(hw.x, hw.x, hw.y * hw.y));
+        const float tx_x = inv * hw.x, tx_y = inv * hw.y;
+        tx = V3p{splat(tx_x), splat(tx_y), splat(0.f)};
+        ty = V3p{splat(-tx_y), splat(tx_x), splat(0.f)};
+        vcx = pfma(vcp.x, tx.x, vcp.y * tx.y);
+        vcy = pfma(vcp.y, tx.x, -vcp.x * tx.y);
+    } else {
+        const f2 hn = pdot(hw, n);
+        const V3p t{splat(hw.x) - hn * n.x, splat(hw.y) - hn * n.y, splat(hw.z) - hn * n.z};
+        const f2 inv_t = prsq(pdot(t, t));
+        tx = V3p{inv_t * t.x, inv_t * t.y, inv_t * t.z};
+        ty = pcross(n, tx);
+        vcx = pdot(vcp, tx);
+        vcy = pdot(vcp, ty);
+    }
     const f2 w_i = w_spin;
     const f2 vden = pmax(splat(vp.v_min), splat(vp.slip_peak) * pmax(pabs(vcx), pabs(w_i * r)));
     const f2 inv_vden = prcp(vden);
@@ -240,8 +288,10 @@ WL_DEV void wheel_force_axle(const WlVehicleParams& vp, const VehDerived& vd, co
         w_n = psel(sat0, sat1, w_s, w_n);
     }
     w_spin = w_n;
-    const V3p Fi{pfma(Fz, n.x, pfma(Fx, tx.x, Fy * ty.x)), pfma(Fz, n.y, pfma(Fx, tx.y, Fy * ty.y)),
-                 pfma(Fz, n.z, pfma(Fx, tx.z, Fy * ty.z))};
+    V3p Fi;
+    if constexpr (FLAT) Fi = V3p{pfma(Fx, tx.x, -Fy * tx.y), pfma(Fx, tx.y, Fy * tx.x), Fz};
+    else Fi = V3p{pfma(Fz, n.x, pfma(Fx, tx.x, Fy * ty.x)), pfma(Fz, n.y, pfma(Fx, tx.y, Fy * ty.y)),
+                  pfma(Fz, n.z, pfma(Fx, tx.z, Fy * ty.z))};
     const V3p Ti = pcross(arm, Fi);
     F = v3(Fi.x.x + Fi.x.y, Fi.y.x + Fi.y.y, Fi.z.x + Fi.z.y);
     T = v3(Ti.x.x + Ti.x.y, Ti.y.x + Ti.y.y, Ti.z.x + Ti.z.y);
@@ -324,7 +374,7 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
             const V3p n{f2{nl.x, nr.x}, f2{nl.y, nr.y}, f2{nl.z, nr.z}};
             f2 w = front ? f2{s.wheel[2], s.wheel[3]} : f2{s.wheel[0], s.wheel[1]};
             const f2 wt = front ? f2{ec.wheel_target[2], ec.wheel_target[3]} : f2{ec.wheel_target[0], ec.wheel_target[1]};
-            wheel_force_axle(vp, vd, ec, R, s.x, s.v, ww, cs, sn, f2{zl, zr}, n, front, wt, w, Fa, Ta);
+            wheel_force_axle<Ground::kFlat>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, f2{zl, zr}, n, front, wt, w, Fa, Ta);
             s.wheel[0] = front ? s.wheel[0] : w.x;
             s.wheel[1] = front ? s.wheel[1] : w.y;
             s.wheel[2] = front ? w.x : s.wheel[2];
@@ -346,7 +396,7 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
             ground.sample(cx, cy, zg, n);
             float w = i == 0 ? s.wheel[0] : i == 1 ? s.wheel[1] : i == 2 ? s.wheel[2] : s.wheel[3];
             const float wt = i == 0 ? ec.wheel_target[0] : i == 1 ? ec.wheel_target[1] : i == 2 ? ec.wheel_target[2] : ec.wheel_target[3];
-            wheel_force(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, wt, w, Fi, Ti);
+            wheel_force<Ground::kFlat>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, wt, w, Fi, Ti);
             s.wheel[0] = i == 0 ? w : s.wheel[0];
             s.wheel[1] = i == 1 ? w : s.wheel[1];
             s.wheel[2] = i == 2 ? w : s.wheel[2];
@@ -364,7 +414,7 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
             float zg;
             V3 n, Fi, Ti;
             ground.sample(cx, cy, zg, n);
-            wheel_force(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, ec.wheel_target[i], s.wheel[i], Fi, Ti);
+            wheel_force<Ground::kFlat>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, ec.wheel_target[i], s.wheel[i], Fi, Ti);
             F = F + Fi;
             T = T + Ti;
         }
@@ -377,8 +427,7 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
         float zg;
         V3 n, Fi, Ti;
         ground.sample(cx, cy, zg, n);
-        const float wt = wid == 0 ? ec.wheel_target[0] : wid == 1 ? ec.wheel_target[1] : wid == 2 ? ec.wheel_target[2] : ec.wheel_target[3];
-        wheel_force(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, wt, s.wheel[0], Fi, Ti);
+        wheel_force<Ground::kFlat>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, ec.wt_lane, s.wheel[0], Fi, Ti);
         F = quad_sum(Fi);
         T = quad_sum(Ti);
     }
