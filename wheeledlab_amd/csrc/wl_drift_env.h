@@ -289,9 +289,11 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     if constexpr (LANES == 4) {
         const Quat q = s.q;
         const float sp = 2.f * (q.w * q.y - q.z * q.x);
-        const float ay = wid == 0 ? vb.y : wid == 1 ? 2.f * (q.w * q.x + q.y * q.z) : wid == 2 ? sp : 2.f * (q.w * q.z + q.x * q.y);
-        const float ax = wid == 0 ? vb.x : wid == 1 ? 1.f - 2.f * (q.x * q.x + q.y * q.y)
-                       : wid == 2 ? fsqrt(fmaxf(1.f - sp * sp, 0.f)) : 1.f - 2.f * (q.y * q.y + q.z * q.z);
+        // all four argument pairs are computed by every lane and picked by value (three v_cndmask each): written as a
+        // ternary chain over expressions the selection becomes divergent control flow
+        const float ay = quad_pick(wid, vb.y, 2.f * (q.w * q.x + q.y * q.z), sp, 2.f * (q.w * q.z + q.x * q.y));
+        const float ax = quad_pick(wid, vb.x, 1.f - 2.f * (q.x * q.x + q.y * q.y), fsqrt(fmaxf(1.f - sp * sp, 0.f)),
+                                   1.f - 2.f * (q.y * q.y + q.z * q.z));
         const float ang = atan2f(ay, ax);
         slip_angle = quad_bcast<0>(ang);
         euler = v3(wrap_2pi(quad_bcast<1>(ang)), wrap_2pi(quad_bcast<2>(ang)), wrap_2pi(quad_bcast<3>(ang)));

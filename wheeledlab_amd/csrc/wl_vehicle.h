@@ -129,8 +129,11 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const E
     const float inv_vden = rcp(vden);
     const float sx = (w_i * r - vcx) * inv_vden, sy = -vcy * inv_vden;
     const float sig = fsqrt(fmaf(sx, sx, sy * sy));
+    // g(sig) / sig, branch-free: below the peak (sig <= 1, inv_sig == 1) the first term is mu_s and the second adds
+    // mu_s (1 - sig) -> mu_s (2 - sig); above it the second term vanishes.  (As a ?: the two short arms become
+    // divergent control flow: five exec-mask instructions around six arithmetic ones, every wheel, every sub-step.)
     const float inv_sig = rcp(fmaxf(sig, 1.f));
-    const float gq = sig <= 1.f ? ec.mu_s * (2.f - sig) : fmaf(ec.mu_s - ec.mu_d, inv_sig, ec.mu_d) * inv_sig;
+    const float gq = fmaf(ec.mu_s, fmaxf(1.f - sig, 0.f), fmaf(ec.mu_s - ec.mu_d, inv_sig, ec.mu_d) * inv_sig);
     // explicit-stepping stability cap: at most half of this wheel's share of the body momentum per sub-step
     const float K = fminf(Fz * gq * inv_vden, ec.K_cap);
     const bool driven = (vp.drive == 1) || !front;
@@ -251,9 +254,8 @@ WL_DEV void wheel_force_axle(const WlVehicleParams& vp, const VehDerived& vd, co
     const f2 sx = (w_i * r - vcx) * inv_vden, sy = -vcy * inv_vden;
     const f2 sig = psqrt(pfma(sx, sx, sy * sy));
     const f2 inv_sig = prcp(pmax(sig, splat(1.f)));
-    const f2 g_lo = splat(ec.mu_s) * (splat(2.f) - sig);
-    const f2 g_hi = pfma(splat(ec.mu_s - ec.mu_d), inv_sig, splat(ec.mu_d)) * inv_sig;
-    const f2 gq = psel(sig.x <= 1.f, sig.y <= 1.f, g_lo, g_hi);
+    const f2 gq = pfma(splat(ec.mu_s), pmax(splat(1.f) - sig, splat(0.f)),
+                       pfma(splat(ec.mu_s - ec.mu_d), inv_sig, splat(ec.mu_d)) * inv_sig);
     const f2 K = pmin(Fz * gq * inv_vden, splat(ec.K_cap));
     const bool driven = (vp.drive == 1) || !front;
     const f2 d = splat(driven ? ec.damp : 0.f);
