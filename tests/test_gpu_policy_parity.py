@@ -5,7 +5,6 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import drift_step as OS
 from oracle import params as OP
 from oracle import policy as OPOL
 
