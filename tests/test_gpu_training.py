@@ -69,3 +69,46 @@ def test_short_ppo_run_improves_the_drift_policy():
     last = np.mean([h["mean_step_reward"] for h in hist[-3:]])
     assert last > first + 0.05 * abs(first), (first, last)
     assert all(np.isfinite(h["value_function"]) and np.isfinite(h["surrogate"]) for h in hist)
+
+
+def test_graph_captured_ppo_step_equals_the_eager_step():
+    """the HIP-graph replay of a minibatch step must do exactly what the eager step does: same parameters after an update
+    on the same storage with the same permutations (fp32 tolerance: kernels are the same, fusion order may differ), the
+    same adaptive learning rate, and a checkpoint resumed into a graph runner keeps its Adam state"""
+    import copy
+    from wheeledlab_amd.policy import RolloutStorage
+    from wheeledlab_amd.rl.ppo import ActorCritic, PPO
+    torch.manual_seed(3)
+    n, K = 512, 16
+    ac_g = ActorCritic(14, 14, 2).to(DEV)
+    ac_e = copy.deepcopy(ac_g)
+    st = RolloutStorage(K, n, device=DEV)
+    st.observations.normal_()
+    with torch.no_grad():
+        ac_e.update_distribution(st.observations[:K].reshape(K * n, 14))
+        a = ac_e.distribution.sample()
+        st.actions.copy_(a.reshape(K, n, 2))
+        st.mu.copy_(ac_e.action_mean.reshape(K, n, 2))
+        st.actions_log_prob.copy_(ac_e.get_actions_log_prob(a).reshape(K, n))
+        st.values.copy_(ac_e.evaluate(st.observations.reshape((K + 1) * n, 14)).reshape(K + 1, n))
+    st.rewards.normal_()
+    st.dones.copy_((torch.rand(K, n, device=DEV) < 0.05).long())
+    pg, pe = PPO(ac_g, use_graph=True), PPO(ac_e, use_graph=False)
+    for it in range(3):
+        gg = torch.Generator(device=DEV).manual_seed(10 + it)
+        ge = torch.Generator(device=DEV).manual_seed(10 + it)
+        lg, le = pg.update(st, generator=gg), pe.update(st, generator=ge)
+        for a_, b_ in zip(ac_g.parameters(), ac_e.parameters()):
+            assert torch.allclose(a_, b_, rtol=2e-4, atol=2e-5), (it, float((a_ - b_).abs().max()))
+        assert abs(lg["learning_rate"] - le["learning_rate"]) < 1e-9 and abs(lg["kl"] - le["kl"]) < 1e-4
+        assert abs(lg["surrogate"] - le["surrogate"]) < 1e-4 and abs(lg["value_function"] - le["value_function"]) < 1e-3
+    # resume: optimizer state loaded into a fresh graph-mode learner survives the (re)capture
+    sd = copy.deepcopy(pg.optimizer.state_dict())
+    ac_r = copy.deepcopy(ac_g)
+    pr = PPO(ac_r, use_graph=True)
+    pr.load_optimizer_state(sd)
+    g1, g2 = torch.Generator(device=DEV).manual_seed(99), torch.Generator(device=DEV).manual_seed(99)
+    pg.update(st, generator=g1)
+    pr.update(st, generator=g2)
+    for a_, b_ in zip(ac_g.parameters(), ac_r.parameters()):
+        assert torch.allclose(a_, b_, rtol=2e-4, atol=2e-5)

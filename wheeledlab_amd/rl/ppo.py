@@ -49,7 +49,9 @@ class ActorCritic(nn.Module):
 
     # -- torch path (gradient step, tasks without a fused collector) --
     def update_distribution(self, obs):
-        self.distribution = torch.distributions.Normal(self.actor(obs), self.std.expand(obs.shape[0], -1))
+        # validate_args=False: the argument checks call .all() -> a host sync per minibatch (and are illegal while a HIP
+        # graph is being captured)
+        self.distribution = torch.distributions.Normal(self.actor(obs), self.std.expand(obs.shape[0], -1), validate_args=False)
 
     def act(self, obs):
         self.update_distribution(obs)
@@ -99,18 +101,114 @@ class ActorCritic(nn.Module):
 
 
 class PPO:
-    """rsl_rl.algorithms.PPO.update on a filled RolloutStorage (fields: rsl_rl_ppo_cfg.py:18-31)"""
+    """rsl_rl.algorithms.PPO.update on a filled RolloutStorage (fields: rsl_rl_ppo_cfg.py:18-31).
+
+    On a GPU one minibatch step (forward of both MLPs, losses, backward, gradient clipping, Adam, the adaptive-KL
+    learning-rate rule) is captured ONCE into a HIP graph and replayed for the 20 steps of every update: the step is ~100
+    tiny kernels, i.e. pure launch overhead when issued one by one from Python (3.9 ms per step eagerly), and the
+    learning-rate rule is the only thing that ever needed the host -- here it is a device-side `where` on an lr tensor
+    the (capturable) Adam reads.  `use_graph=False` (and every CPU run) takes the eager path with identical arithmetic."""
 
     def __init__(self, actor_critic: ActorCritic, value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2,
                  entropy_coef=0.005, num_learning_epochs=5, num_mini_batches=4, learning_rate=1e-3, schedule="adaptive",
-                 gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0, **_unused):
+                 gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0, use_graph: bool | None = None, **_unused):
         self.actor_critic = actor_critic
         self.value_loss_coef, self.use_clipped_value_loss, self.clip_param = value_loss_coef, use_clipped_value_loss, clip_param
         self.entropy_coef, self.num_learning_epochs, self.num_mini_batches = entropy_coef, num_learning_epochs, num_mini_batches
-        self.learning_rate, self.schedule, self.gamma, self.lam = learning_rate, schedule, gamma, lam
+        self.schedule, self.gamma, self.lam = schedule, gamma, lam
         self.desired_kl, self.max_grad_norm = desired_kl, max_grad_norm
-        on_gpu = next(actor_critic.parameters()).is_cuda
-        self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=learning_rate, fused=True if on_gpu else None)
+        dev = next(actor_critic.parameters()).device
+        self.use_graph = dev.type == "cuda" if use_graph is None else bool(use_graph)
+        if self.use_graph and dev.type != "cuda":
+            raise ValueError("HIP-graph capture of the PPO step needs a GPU")
+        # the learning rate lives in a tensor so that the adaptive rule can run on the device
+        self._lr = torch.tensor(float(learning_rate), dtype=torch.float32, device=dev)
+        if self.use_graph:
+            self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=self._lr, capturable=True, foreach=True)
+        else:
+            self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=float(learning_rate))
+        self._graph = None
+        self._static = None
+
+    @property
+    def learning_rate(self) -> float:
+        return float(self._lr)
+
+    # ---- one minibatch step on the tensors of `b` (all arithmetic; no host round trip) ---------------------------------
+    def _step(self, b, sigma_old):
+        ac = self.actor_critic
+        ac.update_distribution(b["obs"])
+        logp = ac.get_actions_log_prob(b["actions"])
+        value = ac.evaluate(b["obs"]).squeeze(-1)
+        mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+        kl_mean = torch.zeros((), device=mu.device)
+        if self.desired_kl is not None and self.schedule == "adaptive":
+            with torch.no_grad():
+                kl = torch.sum(torch.log(sigma / sigma_old + 1e-5)
+                               + (sigma_old.square() + (b["mu"] - mu).square()) / (2.0 * sigma.square()) - 0.5, -1)
+                kl_mean = kl.mean()
+                lr = self._lr
+                up = (kl_mean > 0.0) & (kl_mean < self.desired_kl / 2.0)
+                new_lr = torch.where(kl_mean > self.desired_kl * 2.0, (lr / 1.5).clamp_min(1e-5),
+                                     torch.where(up, (lr * 1.5).clamp_max(1e-2), lr))
+                self._lr.copy_(new_lr)
+                if not self.use_graph:
+                    for g in self.optimizer.param_groups:
+                        g["lr"] = float(new_lr)
+        adv = b["adv"]
+        ratio = torch.exp(logp - b["logp"])
+        surrogate = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+        ret, v_old = b["returns"], b["values"]
+        if self.use_clipped_value_loss:
+            v_clip = v_old + (value - v_old).clamp(-self.clip_param, self.clip_param)
+            value_loss = torch.max((value - ret).square(), (v_clip - ret).square()).mean()
+        else:
+            value_loss = (ret - value).square().mean()
+        loss = surrogate + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+        return torch.stack([value_loss.detach(), surrogate.detach(), kl_mean.detach()])
+
+    def _capture(self, example, sigma_old):
+        """capture _step on static buffers shaped like `example`; parameters, Adam state and lr are restored afterwards"""
+        params = list(self.actor_critic.parameters())
+        saved = [p.detach().clone() for p in params]
+        saved_state = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.optimizer.state.items()}
+        lr0 = self._lr.clone()
+        self._static = {k: torch.empty_like(v) for k, v in example.items()}
+        for k, v in example.items():
+            self._static[k].copy_(v)
+        self._sigma_old = sigma_old.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):                      # warm-up: allocator, lazy Adam state, autograd caches
+                self._step(self._static, self._sigma_old)
+        torch.cuda.current_stream().wait_stream(side)
+        self.optimizer.zero_grad(set_to_none=True)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._out = self._step(self._static, self._sigma_old)
+        with torch.no_grad():
+            for p, q in zip(params, saved):
+                p.copy_(q)
+            for p, st in self.optimizer.state.items():     # in place: the graph holds these tensors
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(saved_state[p][k]) if p in saved_state else v.zero_()
+            self._lr.copy_(lr0)
+
+    def load_optimizer_state(self, state_dict):
+        """checkpoint resume: load_state_dict replaces the state tensors, so the lr tensor is re-bound and a captured
+        graph is dropped (it is re-captured, around the loaded state, at the next update)"""
+        self.optimizer.load_state_dict(state_dict)
+        with torch.no_grad():
+            self._lr.copy_(torch.as_tensor(self.optimizer.param_groups[0]["lr"], dtype=torch.float32))
+        for g in self.optimizer.param_groups:
+            g["lr"] = self._lr if self.use_graph else float(self._lr)
+        self._graph = None
 
     def update(self, storage: RolloutStorage, generator: torch.Generator | None = None):
         K, n = storage.n_steps, storage.n_envs
@@ -122,50 +220,26 @@ class PPO:
                     mu=storage.mu.reshape(K * n, -1))
         batch = K * n
         mb = batch // self.num_mini_batches
-        stats = torch.zeros(2, device=flat["obs"].device)
-        mean_kl = 0.0
-        ac = self.actor_critic
+        stats = torch.zeros(3, device=flat["obs"].device)
+        if self.use_graph:
+            if self._graph is None or self._static["obs"].shape[0] != mb:
+                self._capture({k: v[:mb] for k, v in flat.items()}, sigma_old)
+            self._sigma_old.copy_(sigma_old)
         for _ in range(self.num_learning_epochs):
             perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator)
             shuffled = {k: v[perm] for k, v in flat.items()}        # one gather per field and epoch
             for i in range(self.num_mini_batches):
                 sl = slice(i * mb, (i + 1) * mb)
-                obs, actions = shuffled["obs"][sl], shuffled["actions"][sl]
-                ac.update_distribution(obs)
-                logp = ac.get_actions_log_prob(actions)
-                value = ac.evaluate(obs).squeeze(-1)
-                mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
-                if self.desired_kl is not None and self.schedule == "adaptive":
-                    with torch.no_grad():
-                        kl = torch.sum(torch.log(sigma / sigma_old + 1e-5)
-                                       + (sigma_old.square() + (shuffled["mu"][sl] - mu).square()) / (2.0 * sigma.square()) - 0.5, -1)
-                        kl_mean = float(kl.mean())                  # the schedule needs it on the host
-                    if kl_mean > self.desired_kl * 2.0:
-                        self.learning_rate = max(1e-5, self.learning_rate / 1.5)
-                    elif 0.0 < kl_mean < self.desired_kl / 2.0:
-                        self.learning_rate = min(1e-2, self.learning_rate * 1.5)
-                    for g in self.optimizer.param_groups:
-                        g["lr"] = self.learning_rate
-                    mean_kl += kl_mean
-                adv = shuffled["adv"][sl]
-                ratio = torch.exp(logp - shuffled["logp"][sl])
-                surrogate = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
-                ret, v_old = shuffled["returns"][sl], shuffled["values"][sl]
-                if self.use_clipped_value_loss:
-                    v_clip = v_old + (value - v_old).clamp(-self.clip_param, self.clip_param)
-                    value_loss = torch.max((value - ret).square(), (v_clip - ret).square()).mean()
+                if self.use_graph:
+                    for k, v in shuffled.items():
+                        self._static[k].copy_(v[sl])
+                    self._graph.replay()
+                    stats += self._out
                 else:
-                    value_loss = (ret - value).square().mean()
-                loss = surrogate + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
-                self.optimizer.zero_grad()
-                loss.backward()
-                nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
-                self.optimizer.step()
-                stats += torch.stack([value_loss.detach(), surrogate.detach()])
-        mean_value_loss, mean_surrogate_loss = stats.tolist()
+                    stats += self._step({k: v[sl] for k, v in shuffled.items()}, sigma_old)
         u = self.num_learning_epochs * self.num_mini_batches
-        return dict(value_function=mean_value_loss / u, surrogate=mean_surrogate_loss / u, kl=mean_kl / u,
-                    learning_rate=self.learning_rate)
+        mean_value_loss, mean_surrogate_loss, mean_kl = (stats / u).tolist()
+        return dict(value_function=mean_value_loss, surrogate=mean_surrogate_loss, kl=mean_kl, learning_rate=self.learning_rate)
 
 
 class OnPolicyRunner:
@@ -278,7 +352,7 @@ class OnPolicyRunner:
         d = torch.load(path, map_location=self.device, weights_only=False)
         self.actor_critic.load_state_dict(d["model_state_dict"])    # copies in place: the kernel view stays valid
         if load_optimizer:
-            self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
+            self.alg.load_optimizer_state(d["optimizer_state_dict"])
         self.current_learning_iteration = d["iter"]
         return d.get("infos")
 
