@@ -152,7 +152,8 @@ typedef struct WlEnvBuffers {
     int32_t env_offset;       /* global id of env 0 of this shard (rank * n_envs): keys the RNG streams            */
     int32_t metrics_slots;    /* 1: one accumulator the caller zeroes; R > 1: ring of per-step slots, the step    */
                               /* kernel accumulates into slot (step % R) and clears slot ((step + 1) % R)         */
-    int32_t lanes;            /* step-kernel form: 0 = choose by env count, 1 = lane per env, 4 = quad per env    */
+    int32_t lanes;            /* step-kernel form: 0 = choose by env count, 1 = lane per env (packed axles),       */
+                              /* 2 = lane per env (scalar wheel loop, 5 waves / SIMD), 4 = quad per env            */
     int32_t reserved;
 } WlEnvBuffers;
 

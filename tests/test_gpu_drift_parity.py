@@ -140,7 +140,7 @@ def test_reset_kernel_matches_oracle(lib):
     assert d.max() <= 0.5 * np.sqrt(2) + 1e-5
 
 
-@pytest.mark.parametrize("lanes", [4, 1])
+@pytest.mark.parametrize("lanes", [4, 1, 2])
 @pytest.mark.parametrize("mode", ["philox", "noise_tensor", "no_corruption"])
 def test_fused_step_matches_oracle_single_steps(lib, mode, lanes):
     """Each step starts from the device state (copied to the host), so differences do not accumulate:
@@ -148,7 +148,8 @@ def test_fused_step_matches_oracle_single_steps(lib, mode, lanes):
     (weights up to 5000 * dt amplify), observation 1e-3."""
     n = 1024
     env = _fresh(n, seed=5)
-    env.set_lanes(lanes)      # both forms of the step kernel: quad-per-env (latency) and lane-per-env (throughput)
+    env.set_lanes(lanes)      # every form of the step kernel: quad-per-env (latency), lane-per-env with packed axles,
+                              # lane-per-env with the scalar wheel loop (throughput)
     p = OP.drift_params()
     if mode == "no_corruption":
         env.p.enable_corruption = 0

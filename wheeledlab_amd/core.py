@@ -120,7 +120,7 @@ class DriftBatch(_MetricsView):
 
     def set_lanes(self, lanes: int = 0):
         """step-kernel form: 0 = by env count (quad up to 32768 envs), 1 = lane per env, 4 = quad per env"""
-        assert lanes in (0, 1, 4)
+        assert lanes in (0, 1, 2, 4)   # 2: lane form with the scalar wheel loop (drift only; treated as 1 elsewhere)
         self._bufs.lanes = lanes
 
     def reset(self, mask: torch.Tensor | None = None):

@@ -15,8 +15,12 @@ namespace {
 constexpr int kHotArgBytes = 56;   // state 0, episode_len 8, actions 16, stride 24, n_envs 28, env_offset 32, seed 40, step 48
 
 // LANES = 1: lane per env (throughput form).  LANES = 4: quad per env, one wheel per lane (latency form, small n).
-template <int LANES, class Ground>
-__global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(float* __restrict__ state, int32_t* __restrict__ episode_len,
+// PACKED (lane form only): the two wheels of an axle as packed float2 -- faster while the SIMDs hold ~1 wavefront each;
+// !PACKED: rolled scalar wheel loop in 93 VGPRs -> 5 wavefronts per SIMD, faster once every SIMD is filled several times
+// (same-box A/B, us per step, packed / scalar-5: 65 536 envs 13.5 / 16.1, 262 144 32.8 / 33.1, 1 M 103.8 / 99.7,
+// 4 M 398 / 368).
+template <int LANES, class Ground, bool PACKED = true>
+__global__ void __launch_bounds__(kBlock, PACKED ? WL_MIN_WAVES : 5) drift_step_kernel(float* __restrict__ state, int32_t* __restrict__ episode_len,
                                                             const float2* __restrict__ actions, const int stride,
                                                             const int n_envs, const int env_offset, const uint64_t seed,
                                                             const uint64_t step, const WlDriftParams p_arg,
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(kBlock, WL_MIN_WAVES) drift_step_kernel(float*
             drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, le, wid, lead, gid, seed, step, tile, ms, nullptr,
                                   &pre);
         } else {
-            drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, le, wid, lead, gid, seed, step, tile, ms);
+            drift_env_step<LANES, PACKED>(p, b, vd, ground, S, ec, r, a, noise, out, e, le, wid, lead, gid, seed, step, tile, ms);
         }
         store_rows<LANES>(S, b, p, e, wid, lead, r);
     }
@@ -264,8 +268,12 @@ int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* ac
         drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
             b->state, b->episode_len, (const float2*)actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b,
             noise, *out, FlatGround{});
+    else if (use_packed(b))
+        drift_step_kernel<1, FlatGround, true><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
+            b->state, b->episode_len, (const float2*)actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b,
+            noise, *out, FlatGround{});
     else
-        drift_step_kernel<1, FlatGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
+        drift_step_kernel<1, FlatGround, false><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
             b->state, b->episode_len, (const float2*)actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b,
             noise, *out, FlatGround{});
     return launch_status();
@@ -293,8 +301,12 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
             drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
                 b->state, b->episode_len, a, (int)b->stride, b->n_envs, b->env_offset, seed, step0 + (uint64_t)k, *p, vd, *b,
                 nullptr, o, FlatGround{});
+        else if (use_packed(b))
+            drift_step_kernel<1, FlatGround, true><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+                b->state, b->episode_len, a, (int)b->stride, b->n_envs, b->env_offset, seed, step0 + (uint64_t)k, *p, vd, *b,
+                nullptr, o, FlatGround{});
         else
-            drift_step_kernel<1, FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+            drift_step_kernel<1, FlatGround, false><<<grid, kBlock, 0, (hipStream_t)stream>>>(
                 b->state, b->episode_len, a, (int)b->stride, b->n_envs, b->env_offset, seed, step0 + (uint64_t)k, *p, vd, *b,
                 nullptr, o, FlatGround{});
     }

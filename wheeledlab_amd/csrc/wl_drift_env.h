@@ -240,7 +240,7 @@ struct MetricSink {
 // ONE env.step() on the register image `r` (shared by the per-step kernel and the persistent rollout kernels): action
 // term -> physics -> terminations -> rewards -> reset -> pushes -> observation row into the block's LDS tile.
 // Writes reward / flags to `out` (already offset to this step); accumulates episode metrics into `blk_metrics` (LDS).
-template <int LANES, class Ground>
+template <int LANES, bool PACKED = true, class Ground>
 WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const VehDerived& vd, const Ground& ground,
                            const Rows& S, EnvConst& ec, DriftRows& r, float2 a, const float* __restrict__ noise,
                            const WlStepOut& out, int e, int le, int wid, bool lead, uint32_t gid, uint64_t seed, uint64_t step,
@@ -266,7 +266,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         s.wb = mul_t(R, r.ww);
     }
     // ---- physics: decimation x substeps, everything in registers ----
-    vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
+    vehicle_integrate<LANES, Ground, PACKED>(vp, vd, ec, s, ground, wid);
     const Mat3 R = mat_from_quat(s.q);
     V3 ww = mul(R, s.wb);
     V3 pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
@@ -454,7 +454,7 @@ inline int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
     if (!p || !b || !b->state || !b->episode_len || !b->ref_poses || !b->metrics) return WL_EINVAL;
     if (b->n_envs <= 0 || b->stride < b->n_envs) return WL_EINVAL;
     if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
-    if (b->metrics_slots < 1 || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
+    if (b->metrics_slots < 1 || (b->lanes != 0 && b->lanes != 1 && b->lanes != 2 && b->lanes != 4)) return WL_EINVAL;
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL) return WL_EINVAL;   // buffer-resource offsets are 32-bit (~13 M envs)
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || p->num_ref_points <= 0 || p->num_ref_points > 32) return WL_EINVAL;
     if (!(p->sim_dt > 0.f)) return WL_EINVAL;

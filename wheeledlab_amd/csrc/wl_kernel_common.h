@@ -88,8 +88,17 @@ inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 #ifndef WL_QUAD_MAX_ENVS
 #define WL_QUAD_MAX_ENVS 32768
 #endif
+// lane form: packed axles up to here, the low-register scalar wheel loop beyond (crossover measured at ~260 K envs)
+#ifndef WL_PACKED_MAX_ENVS
+#define WL_PACKED_MAX_ENVS 262144
+#endif
+inline bool use_packed(const WlEnvBuffers* b) {   // lane form only
+    if (b->lanes == 1) return true;
+    if (b->lanes == 2) return false;
+    return b->n_envs <= WL_PACKED_MAX_ENVS;
+}
 inline bool use_quad(const WlEnvBuffers* b) {
-    if (b->lanes == 1) return false;
+    if (b->lanes == 1 || b->lanes == 2) return false;
     if (b->lanes == 4) return true;
     return b->n_envs <= WL_QUAD_MAX_ENVS;
 }

@@ -353,14 +353,13 @@ WL_DEV V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)
 //   LANES == 4: a quad of lanes owns the env, lane `wid` owns wheel `wid` (s.wheel[0] is ITS spin); the body state is
 //               replicated, the wheel forces are summed across the quad with DPP.  Latency form for small env counts:
 //               the critical path per sub-step drops from 4 wheels to 1.
-template <int LANES, class Ground>
+template <int LANES, class Ground, bool PACKED = true>
 WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
                             const Ground& ground, int wid, float sn, float cs /* sin / cos of the steer angle in force */) {
     const Mat3 R = mat_from_quat(s.q);
     const V3 ww = mul(R, s.wb);
     V3 F = v3(0.f, 0.f, 0.f), T = v3(0.f, 0.f, 0.f);
-    if constexpr (LANES == 1) {
-#if !defined(WL_SCALAR_WHEELS)
+    if constexpr (LANES == 1 && PACKED) {
         // two iterations (rear, front axle), the two wheels of an axle as packed pairs
 #pragma unroll 1
         for (int ax = 0; ax < 2; ++ax) {
@@ -384,9 +383,9 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
             F = F + Fa;
             T = T + Ta;
         }
-#elif !defined(WL_UNROLLED_WHEELS)   // A/B builds: -DWL_SCALAR_WHEELS (rolled loop over 4 wheels), + -DWL_UNROLLED_WHEELS
-        // rolled wheel loop (default; -DWL_UNROLLED_WHEELS restores the 4x inlined form: 140 vs 121 VGPRs, 3 vs 4 waves/SIMD): one wheel's temporaries live at a time and the loop body is a quarter of the code; the
-        // loop counter is scalar, so picking the wheel's spin / target is a handful of s_cselect-driven moves
+    } else if constexpr (LANES == 1) {
+        // rolled loop over the four wheels, one wheel's temporaries live at a time: the low-register variant (93 VGPRs -> 5
+        // wavefronts per SIMD) for batches large enough to fill every SIMD several times over
 #pragma unroll 1
         for (int i = 0; i < 4; ++i) {
             const bool front = i >= 2, left = (i & 1) == 0;
@@ -406,21 +405,6 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
             F = F + Fi;
             T = T + Ti;
         }
-#else
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool front = i >= 2, left = (i & 1) == 0;
-            const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;
-            const float cx = s.x.x + fmaf(R.r0.x, bx, fmaf(R.r0.y, by, R.r0.z * vd.zrel));
-            const float cy = s.x.y + fmaf(R.r1.x, bx, fmaf(R.r1.y, by, R.r1.z * vd.zrel));
-            float zg;
-            V3 n, Fi, Ti;
-            ground.sample(cx, cy, zg, n);
-            wheel_force<Ground::kFlat>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, ec.wheel_target[i], s.wheel[i], Fi, Ti);
-            F = F + Fi;
-            T = T + Ti;
-        }
-#endif
     } else {
         const bool front = wid >= 2, left = (wid & 1) == 0;
         const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;
@@ -439,13 +423,13 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
 // decimation x substeps integrator sub-steps (everything in registers).  A variant that software-pipelined the steering
 // joint one sub-step ahead measured no gain: a wavefront alone on its SIMD pays ~3 ns per instruction whatever the
 // chain looks like (tools/microbench/valu_issue.hip), so only fewer instructions on the critical lane help.
-template <int LANES, class Ground>
+template <int LANES, class Ground, bool PACKED = true>
 WL_DEV void vehicle_integrate(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
                               const Ground& ground, int wid = 0) {
     for (int k = 0; k < vd.n_sub; ++k) {
         steer_update(vp, vd, ec, s);
         float sn, cs;
         sincos_fast(s.th, sn, cs);   // |th| <= tan(0.488) rad: hardware sin/cos, ~1e-6 abs
-        vehicle_substep<LANES>(vp, vd, ec, s, ground, wid, sn, cs);
+        vehicle_substep<LANES, Ground, PACKED>(vp, vd, ec, s, ground, wid, sn, cs);
     }
 }
