@@ -103,32 +103,27 @@ class ActorCritic(nn.Module):
 class PPO:
     """rsl_rl.algorithms.PPO.update on a filled RolloutStorage (fields: rsl_rl_ppo_cfg.py:18-31).
 
-    On a GPU one minibatch step (forward of both MLPs, losses, backward, gradient clipping, Adam, the adaptive-KL
-    learning-rate rule) is captured ONCE into a HIP graph and replayed for the 20 steps of every update: the step is ~100
-    tiny kernels, i.e. pure launch overhead when issued one by one from Python (3.9 ms per step eagerly), and the
-    learning-rate rule is the only thing that ever needed the host -- here it is a device-side `where` on an lr tensor
-    the (capturable) Adam reads.  `use_graph=False` (and every CPU run) takes the eager path with identical arithmetic."""
+    On a GPU nothing in the update touches the host: the learning rate lives in a device tensor that the (capturable)
+    Adam reads, and the adaptive-KL rule -- the one step of rsl_rl's update that needs `kl_mean` on the host -- is a
+    `torch.where` on that tensor.  (Replaying the minibatch step as a captured HIP graph was tried on top of this: it
+    saved 15 % of the update and its bias gradients drifted from the eager step's after the first update, with either
+    BLAS backend, so it is not used.)"""
 
     def __init__(self, actor_critic: ActorCritic, value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2,
                  entropy_coef=0.005, num_learning_epochs=5, num_mini_batches=4, learning_rate=1e-3, schedule="adaptive",
-                 gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0, use_graph: bool | None = None, **_unused):
+                 gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0, **_unused):
         self.actor_critic = actor_critic
         self.value_loss_coef, self.use_clipped_value_loss, self.clip_param = value_loss_coef, use_clipped_value_loss, clip_param
         self.entropy_coef, self.num_learning_epochs, self.num_mini_batches = entropy_coef, num_learning_epochs, num_mini_batches
         self.schedule, self.gamma, self.lam = schedule, gamma, lam
         self.desired_kl, self.max_grad_norm = desired_kl, max_grad_norm
         dev = next(actor_critic.parameters()).device
-        self.use_graph = dev.type == "cuda" if use_graph is None else bool(use_graph)
-        if self.use_graph and dev.type != "cuda":
-            raise ValueError("HIP-graph capture of the PPO step needs a GPU")
-        # the learning rate lives in a tensor so that the adaptive rule can run on the device
         self._lr = torch.tensor(float(learning_rate), dtype=torch.float32, device=dev)
-        if self.use_graph:
+        self._lr_on_device = dev.type == "cuda"
+        if self._lr_on_device:   # the optimiser reads the lr tensor: the adaptive rule never needs the host
             self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=self._lr, capturable=True, foreach=True)
         else:
             self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=float(learning_rate))
-        self._graph = None
-        self._static = None
 
     @property
     def learning_rate(self) -> float:
@@ -152,7 +147,7 @@ class PPO:
                 new_lr = torch.where(kl_mean > self.desired_kl * 2.0, (lr / 1.5).clamp_min(1e-5),
                                      torch.where(up, (lr * 1.5).clamp_max(1e-2), lr))
                 self._lr.copy_(new_lr)
-                if not self.use_graph:
+                if not self._lr_on_device:
                     for g in self.optimizer.param_groups:
                         g["lr"] = float(new_lr)
         adv = b["adv"]
@@ -171,44 +166,13 @@ class PPO:
         self.optimizer.step()
         return torch.stack([value_loss.detach(), surrogate.detach(), kl_mean.detach()])
 
-    def _capture(self, example, sigma_old):
-        """capture _step on static buffers shaped like `example`; parameters, Adam state and lr are restored afterwards"""
-        params = list(self.actor_critic.parameters())
-        saved = [p.detach().clone() for p in params]
-        saved_state = {p: {k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for p, st in self.optimizer.state.items()}
-        lr0 = self._lr.clone()
-        self._static = {k: torch.empty_like(v) for k, v in example.items()}
-        for k, v in example.items():
-            self._static[k].copy_(v)
-        self._sigma_old = sigma_old.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):                      # warm-up: allocator, lazy Adam state, autograd caches
-                self._step(self._static, self._sigma_old)
-        torch.cuda.current_stream().wait_stream(side)
-        self.optimizer.zero_grad(set_to_none=True)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._out = self._step(self._static, self._sigma_old)
-        with torch.no_grad():
-            for p, q in zip(params, saved):
-                p.copy_(q)
-            for p, st in self.optimizer.state.items():     # in place: the graph holds these tensors
-                for k, v in st.items():
-                    if torch.is_tensor(v):
-                        v.copy_(saved_state[p][k]) if p in saved_state else v.zero_()
-            self._lr.copy_(lr0)
-
     def load_optimizer_state(self, state_dict):
-        """checkpoint resume: load_state_dict replaces the state tensors, so the lr tensor is re-bound and a captured
-        graph is dropped (it is re-captured, around the loaded state, at the next update)"""
+        """checkpoint resume: load_state_dict replaces the param-group lr, so the device lr tensor is re-bound"""
         self.optimizer.load_state_dict(state_dict)
         with torch.no_grad():
             self._lr.copy_(torch.as_tensor(self.optimizer.param_groups[0]["lr"], dtype=torch.float32))
         for g in self.optimizer.param_groups:
-            g["lr"] = self._lr if self.use_graph else float(self._lr)
-        self._graph = None
+            g["lr"] = self._lr if self._lr_on_device else float(self._lr)
 
     def update(self, storage: RolloutStorage, generator: torch.Generator | None = None):
         K, n = storage.n_steps, storage.n_envs
@@ -221,22 +185,12 @@ class PPO:
         batch = K * n
         mb = batch // self.num_mini_batches
         stats = torch.zeros(3, device=flat["obs"].device)
-        if self.use_graph:
-            if self._graph is None or self._static["obs"].shape[0] != mb:
-                self._capture({k: v[:mb] for k, v in flat.items()}, sigma_old)
-            self._sigma_old.copy_(sigma_old)
         for _ in range(self.num_learning_epochs):
             perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator)
             shuffled = {k: v[perm] for k, v in flat.items()}        # one gather per field and epoch
             for i in range(self.num_mini_batches):
                 sl = slice(i * mb, (i + 1) * mb)
-                if self.use_graph:
-                    for k, v in shuffled.items():
-                        self._static[k].copy_(v[sl])
-                    self._graph.replay()
-                    stats += self._out
-                else:
-                    stats += self._step({k: v[sl] for k, v in shuffled.items()}, sigma_old)
+                stats += self._step({k: v[sl] for k, v in shuffled.items()}, sigma_old)
         u = self.num_learning_epochs * self.num_mini_batches
         mean_value_loss, mean_surrogate_loss, mean_kl = (stats / u).tolist()
         return dict(value_function=mean_value_loss, surrogate=mean_surrogate_loss, kl=mean_kl, learning_rate=self.learning_rate)
