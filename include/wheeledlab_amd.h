@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 11
+#define WL_ABI_VERSION 12
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -256,6 +256,59 @@ typedef struct WlPolicyRollout {
  */
 int wl_drift_rollout_policy(const WlDriftParams* p, const WlEnvBuffers* b, const WlMlp* actor, const float* action_std,
                             const WlPolicyRollout* io, int32_t n_steps, uint64_t seed, uint64_t step0, void* stream);
+
+/* ---- PPO learner step of the drift agents ("on-device PPO for the 64-64 MLP") ------------
+ * One minibatch step of rsl_rl's PPO.update (modified_rsl_rl_runner.py:104-109; rsl_rl_ppo_cfg.py:18-31) for the
+ * 14-64-64-2 actor / 14-64-64-1 critic pair: forward, clipped surrogate + clipped value loss + entropy bonus, backward,
+ * gradient-norm clipping, the adaptive-KL learning-rate rule and Adam, entirely on the device.
+ * Flat parameter / gradient order (WL_PPO_NUM_PARAMS floats) = torch named_parameters() of the ActorCritic:
+ * std[2], actor w1[64][14] b1[64] w2[64][64] b2[64] w3[2][64] b3[2], critic w1 b1 w2 b2 w3[1][64] b3[1]. */
+#define WL_PPO_NUM_PARAMS 10437
+#define WL_PPO_PARTIAL_STRIDE 10440   /* + value-loss, surrogate and KL sums of the minibatch */
+#define WL_PPO_BLOCKS 256             /* rows of WlPpoState.partials */
+/* WlPpoState.ctrl (16 floats, zero-initialised by the caller once): */
+#define WL_PPO_CTRL_LR 0      /* [2] learning rate, ping-pong by `parity` (the caller seeds BOTH with the initial lr) */
+#define WL_PPO_CTRL_NORM2 2   /* [2] squared gradient norm accumulator, ping-pong */
+#define WL_PPO_CTRL_STATS 4   /* [3] running sums of mean value loss / surrogate / KL over the calls (caller zeroes) */
+
+typedef struct WlPpoBatch {          /* a flattened rollout, B = K * n samples; all device pointers */
+    const float* obs;                /* [B][14] */
+    const float* actions;            /* [B][2] */
+    const float* mu_old;             /* [B][2] */
+    const float* logp_old;           /* [B] */
+    const float* adv;                /* [B] advantages as the loss uses them (normalised) */
+    const float* returns;            /* [B] */
+    const float* values_old;         /* [B] */
+    const int32_t* perm;             /* [>= mb_start + mb_size] sample order of this epoch */
+    const float* sigma_old;          /* [2] action std at collection time */
+} WlPpoBatch;
+
+typedef struct WlPpoParams {
+    float clip, value_loss_coef, entropy_coef, desired_kl, max_grad_norm;
+    float beta1, beta2, eps;         /* Adam (0.9, 0.999, 1e-8) */
+    float lr_min, lr_max;            /* bounds of the adaptive rule (1e-5, 1e-2) */
+    int32_t use_clipped_value_loss;
+    int32_t adaptive;                /* schedule == "adaptive" && desired_kl set */
+} WlPpoParams;
+
+typedef struct WlPpoState {          /* caller-owned device scratch */
+    float* partials;                 /* [WL_PPO_BLOCKS][WL_PPO_PARTIAL_STRIDE] */
+    float* grad;                     /* [WL_PPO_PARTIAL_STRIDE] */
+    float* adam_m;                   /* [WL_PPO_NUM_PARAMS] */
+    float* adam_v;                   /* [WL_PPO_NUM_PARAMS] */
+    float* ctrl;                     /* [16], see WL_PPO_CTRL_* */
+} WlPpoState;
+
+/* gradients only (parity entry point): state->grad = d loss / d params (entropy term and clipping NOT applied) + the
+ * three sums; accumulates the squared norm into ctrl[WL_PPO_CTRL_NORM2 + parity]. */
+int wl_ppo_gradients(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* batch, int32_t mb_start,
+                     int32_t mb_size, const WlPpoParams* hp, const WlPpoState* state, int32_t parity, void* stream);
+
+/* the whole step: parameters (`actor`, `critic`, `std`) are updated in place.  `parity` alternates 0 / 1 between
+ * consecutive calls; `adam_step` counts the calls from 1. */
+int wl_ppo_minibatch(const WlMlp* actor, const WlMlp* critic, float* std, const WlPpoBatch* batch, int32_t mb_start,
+                     int32_t mb_size, const WlPpoParams* hp, const WlPpoState* state, int32_t parity, int32_t adam_step,
+                     void* stream);
 
 /*
  * Drift mdp terms only, on caller-supplied state tensors (the parity entry point: "outputs match the reference

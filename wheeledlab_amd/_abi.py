@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 11
+WL_ABI_VERSION = 12
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -135,6 +135,25 @@ class WlPolicyRollout(C.Structure):
                 ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("dones", C.c_void_p)]
 
 
+PPO_NUM_PARAMS, PPO_PARTIAL_STRIDE, PPO_BLOCKS = 10437, 10440, 256
+PPO_CTRL_LR, PPO_CTRL_NORM2, PPO_CTRL_STATS = 0, 2, 4
+
+
+class WlPpoBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "actions", "mu_old", "logp_old", "adv", "returns", "values_old", "perm",
+                                          "sigma_old")]
+
+
+class WlPpoParams(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("clip", "value_loss_coef", "entropy_coef", "desired_kl", "max_grad_norm", "beta1",
+                                         "beta2", "eps", "lr_min", "lr_max")] + [("use_clipped_value_loss", C.c_int32),
+                                                                                 ("adaptive", C.c_int32)]
+
+
+class WlPpoState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("partials", "grad", "adam_m", "adam_v", "ctrl")]
+
+
 _P = C.POINTER
 _vp, _u64, _i32, _i64 = C.c_void_p, C.c_uint64, C.c_int32, C.c_int64
 
@@ -151,6 +170,10 @@ SIGNATURES = {
     "wl_mlp_forward": (C.c_int, [_P(WlMlp), _i32, _vp, _vp, _vp]),
     "wl_drift_rollout_policy": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _P(WlMlp), _vp, _P(WlPolicyRollout), _i32,
                                           _u64, _u64, _vp]),
+    "wl_ppo_gradients": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _P(WlPpoBatch), _i32, _i32, _P(WlPpoParams), _P(WlPpoState), _i32,
+                                   _vp]),
+    "wl_ppo_minibatch": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _P(WlPpoBatch), _i32, _i32, _P(WlPpoParams), _P(WlPpoState), _i32,
+                                   _i32, _vp]),
     "wl_drift_mdp": (C.c_int, [_P(WlDriftParams), _i32, _i64] + [_vp] * 12),
     "wl_action_map": (C.c_int, [_P(WlActionParams), _i32, _vp, _vp, _vp, _vp, _vp]),
     "wl_drift_reset": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _u64, _u64, _vp]),

@@ -1,0 +1,503 @@
+// wl_ppo.hip -- one PPO minibatch step of the drift agents (14-64-64-2 actor, 14-64-64-1 critic; rsl_rl PPO.update as the
+// reference drives it: wheeledlab_rl/utils/modified_rsl_rl_runner.py:104-109, hyper-parameters rsl_rl_ppo_cfg.py:18-31)
+// as three launches: forward + losses + backward + weight gradients fused on the f32 matrix pipe, a partial-sum
+// reduction, and gradient clipping + Adam + the adaptive-KL learning-rate rule.
+//
+// Gradient kernel, one wavefront per 16-sample tile (v_mfma_f32_16x16x4_f32 throughout, lane l: g = l >> 4, n = l & 15):
+//   * forward in the transposed formulation of wl_mlp.h: H^T[unit][sample] = W . X^T, so a layer's accumulator (lane
+//     (g, n): units 16 t + 4 g + r of sample n) is the next layer's B operand when k is walked as (tile t', register r);
+//   * the output layer is ONE accumulator for both nets with its rows spread so that lane group g ends up holding
+//     output g of sample n in register 0: g = 0 mu_0, g = 1 mu_1, g = 2 value.  The loss derivatives are computed right
+//     there, and that register IS the B operand (k = g) of the backward product delta2^T = W3^T . delta3^T;
+//   * delta1^T = W2^T . delta2^T uses the same layout trick as the forward pass (delta2's accumulator is its B operand);
+//   * weight gradients dW = delta^T . H contract over the SAMPLES, which the accumulator layout keeps in l & 15 while
+//     both MFMA operands want their k index in l >> 4: delta and H are transposed through a per-wavefront LDS buffer
+//     ([unit][sample], 16 ds_write + 16 ds_read per lane and matrix) and then feed A and B with the same read pattern;
+//     dW1 takes the observation rows straight from memory in B layout, its padded feature 14 (= 1) yields db1 for free;
+//   * every weight operand is read from LDS, where the block has laid the nets out in MFMA operand order once
+//     (86 KB: forward L1 / L2, backward W2^T / W3^T per net, the joint output layer); gradient accumulators (228 VGPRs)
+//     stay in registers across all tiles of the wavefront and leave through an LDS reduction over the block's four
+//     wavefronts as one [G] partial per block.
+#include <hip/hip_runtime.h>
+
+#include "../../include/wheeledlab_amd.h"
+#include "wl_kernel_common.h"
+#include "wl_mlp.h"
+
+namespace {
+
+constexpr int kIn = 14, kHid = 64, kTiles = 4;
+constexpr int G = WL_PPO_NUM_PARAMS, kRow = WL_PPO_PARTIAL_STRIDE, kPpoBlocks = WL_PPO_BLOCKS;
+// flat parameter order = torch named_parameters() of rl/ppo.py ActorCritic: std, actor.{0,2,4}.{weight,bias}, critic...
+constexpr int O_STD = 0, O_AW1 = 2, O_AB1 = O_AW1 + kHid * kIn, O_AW2 = O_AB1 + kHid, O_AB2 = O_AW2 + kHid * kHid,
+              O_AW3 = O_AB2 + kHid, O_AB3 = O_AW3 + 2 * kHid, O_CW1 = O_AB3 + 2, O_CB1 = O_CW1 + kHid * kIn, O_CW2 = O_CB1 + kHid,
+              O_CB2 = O_CW2 + kHid * kHid, O_CW3 = O_CB2 + kHid, O_CB3 = O_CW3 + kHid;
+static_assert(O_CB3 + 1 == G, "parameter layout");
+constexpr int S_VLOSS = G, S_SURR = G + 1, S_KL = G + 2;
+
+// LDS operand tables (floats); every operand is 64 consecutive floats (one per lane)
+constexpr int T_F1 = 0, T_F2 = T_F1 + 4 * 4 * 64, T_B2 = T_F2 + 4 * 17 * 64, T_B3 = T_B2 + 4 * 16 * 64, kNetTab = T_B3 + 4 * 64;
+constexpr int T_F3 = 2 * kNetTab, kTabFloats = T_F3 + 33 * 64;
+constexpr int kTStride = 20, kTBuf = kHid * kTStride;          // transposition buffer [unit][sample], padded rows
+constexpr int kLdsFloats = kTabFloats + 4 * 2 * kTBuf;          // + two buffers per wavefront
+static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
+static_assert(kTabFloats >= kRow, "the operand tables are reused as the block's gradient accumulator");
+
+struct PpoNets {
+    WlMlp actor, critic;
+    const float* std;
+};
+
+// value of slot `idx` of the operand tables (run once per block; lane = idx & 63: i = row of the A tile, g = k index)
+WL_DEV float operand_value(const PpoNets& N, int idx) {
+    const int lane = idx & 63, i = lane & 15, g = lane >> 4;
+    int op = idx >> 6;
+    if (op < 2 * (kNetTab / 64)) {
+        const WlMlp& net = op < kNetTab / 64 ? N.actor : N.critic;
+        if (op >= kNetTab / 64) op -= kNetTab / 64;
+        if (op < T_F2 / 64) {                                   // forward layer 1: [t][s]
+            const int t = op >> 2, s = op & 3, f = 4 * s + g, unit = 16 * t + i;
+            return f < kIn ? net.w1[unit * kIn + f] : f == kIn ? net.b1[unit] : 0.f;
+        }
+        op -= T_F2 / 64;
+        if (op < 4 * 17) {                                      // forward layer 2: [t][ks], ks = 4 t' + r | bias
+            const int t = op / 17, ks = op % 17, unit = 16 * t + i;
+            if (ks == 16) return g == 0 ? net.b2[unit] : 0.f;
+            return net.w2[unit * kHid + 16 * (ks >> 2) + 4 * g + (ks & 3)];
+        }
+        op -= 4 * 17;
+        if (op < 4 * 16) {                                      // backward W2^T: [t (input tile)][ks = 4 t' + r]
+            const int t = op >> 4, ks = op & 15;
+            return net.w2[(16 * (ks >> 2) + 4 * g + (ks & 3)) * kHid + 16 * t + i];
+        }
+        op -= 4 * 16;                                           // backward W3^T: [t]; k = g = output index of the joint layer
+        const int unit = 16 * op + i;
+        if (&net == &N.actor) return g < 2 ? net.w3[g * kHid + unit] : 0.f;
+        return g == 2 ? net.w3[unit] : 0.f;
+    }
+    op -= 2 * (kNetTab / 64);                                   // joint output layer: rows 0 / 4 / 8 = mu_0 / mu_1 / value
+    if (op < 16) return i == 0 ? N.actor.w3[16 * (op >> 2) + 4 * g + (op & 3)]
+                      : i == 4 ? N.actor.w3[kHid + 16 * (op >> 2) + 4 * g + (op & 3)] : 0.f;
+    if (op < 32) return i == 8 ? N.critic.w3[16 * ((op - 16) >> 2) + 4 * g + ((op - 16) & 3)] : 0.f;
+    return g != 0 ? 0.f : i == 0 ? N.actor.b3[0] : i == 4 ? N.actor.b3[1] : i == 8 ? N.critic.b3[0] : 0.f;
+}
+
+template <int ACT>
+WL_DEV float act_grad_from_output(float h) {   // d act / d z expressed through h = act(z)
+    if constexpr (ACT == WL_ACT_RELU) return h > 0.f ? 1.f : 0.f;
+    else return h > 0.f ? 1.f : h + 1.f;       // ELU: e^z = h + 1 for z <= 0
+}
+
+WL_DEV float lane_xor16(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __float_as_int(v)));
+}
+
+// accumulator layout -> [unit][sample] in the wavefront's LDS buffer
+WL_DEV void put_transposed(float* T, const f32x4 X[kTiles], int g, int n) {
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(16 * t + 4 * g + r) * kTStride + n] = X[t][r];
+}
+// operand (A or B alike) of k-step s for unit tile t: element [unit 16 t + n][sample 4 s + g]
+WL_DEV float get_transposed(const float* T, int t, int s, int g, int n) { return T[(16 * t + n) * kTStride + 4 * s + g]; }
+
+template <int ACT>
+WL_DEV void forward_hidden(const float* tab, const float xs[4], float one_g0, int lane, f32x4 h1[kTiles], f32x4 h2[kTiles]) {
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) h1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) h1[t] = mfma4(tab[T_F1 + (4 * t + s) * 64 + lane], xs[s], h1[t]);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[t][r] = mlp_act<ACT>(h1[t][r]);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) h2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < kTiles; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) h2[t] = mfma4(tab[T_F2 + (17 * t + 4 * tp + r) * 64 + lane], h1[tp][r], h2[t]);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) h2[t] = mfma4(tab[T_F2 + (17 * t + 16) * 64 + lane], one_g0, h2[t]);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[t][r] = mlp_act<ACT>(h2[t][r]);
+}
+
+// gradient accumulators of one net, in MFMA accumulator layout (rows 4 g + r, column n of each 16 x 16 tile)
+struct NetGrads {
+    f32x4 w2[kTiles][kTiles];   // [out tile][in tile]
+    f32x4 w1[kTiles];           // columns = input features (14 = bias, 15 unused)
+    f32x4 w3[kTiles];           // rows 0 / 4 (actor) or 8 (critic) of the joint output layer, columns = units of tile t'
+    f32x4 b2[kTiles];           // this lane's partial sums over its sample column
+    WL_DEV void zero() {
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            w1[t] = w3[t] = b2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < kTiles; ++u) w2[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+};
+
+// backward of one net from delta3 (B operand of the joint layer) + weight-gradient accumulation for this tile
+template <int ACT>
+WL_DEV void backward_net(const float* tab, float* Td, float* Th, const f32x4 h1[kTiles], const f32x4 h2[kTiles], float d3,
+                         const float xb[4] /* obs rows in B layout: sample 4 s + g, feature n */, int lane, NetGrads& A) {
+    const int g = lane >> 4, n = lane & 15;
+    // dW3 += delta3^T . H2 : A operand = delta3 of row i's output at sample 4 s + g (rows 0 / 4 / 8), via Td
+    put_transposed(Th, h2, g, n);
+    if (n < 16) Td[g * kTStride + n] = d3;                       // [output g][sample n]
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float a = (n & 3) == 0 && n < 12 ? Td[(n >> 2) * kTStride + 4 * s + g] : 0.f;
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) A.w3[t] = mfma4(a, get_transposed(Th, t, s, g, n), A.w3[t]);
+    }
+    // delta2 = (W3^T delta3) * act'(h2)
+    f32x4 d2[kTiles], d1[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) {
+        d2[t] = mfma4(tab[T_B3 + t * 64 + lane], d3, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d2[t][r] *= act_grad_from_output<ACT>(h2[t][r]);
+    }
+    // delta1 = (W2^T delta2) * act'(h1)
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) d1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < kTiles; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) d1[t] = mfma4(tab[T_B2 + (16 * t + 4 * tp + r) * 64 + lane], d2[tp][r], d1[t]);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            d1[t][r] *= act_grad_from_output<ACT>(h1[t][r]);
+            A.b2[t][r] += d2[t][r];
+        }
+    // dW2 += delta2^T . H1
+    __builtin_amdgcn_wave_barrier();
+    put_transposed(Td, d2, g, n);
+    put_transposed(Th, h1, g, n);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float hb[kTiles];
+#pragma unroll
+        for (int u = 0; u < kTiles; ++u) hb[u] = get_transposed(Th, u, s, g, n);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            const float a = get_transposed(Td, t, s, g, n);
+#pragma unroll
+            for (int u = 0; u < kTiles; ++u) A.w2[t][u] = mfma4(a, hb[u], A.w2[t][u]);
+        }
+    }
+    // dW1 (+ db1 in column 14) += delta1^T . X
+    __builtin_amdgcn_wave_barrier();
+    put_transposed(Td, d1, g, n);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) A.w1[t] = mfma4(get_transposed(Td, t, s, g, n), xb[s], A.w1[t]);
+    __builtin_amdgcn_wave_barrier();
+}
+
+WL_DEV void flush_net(float* acc, const NetGrads& A, int lane, bool actor) {
+    const int g = lane >> 4, n = lane & 15;
+    const int o_w1 = actor ? O_AW1 : O_CW1, o_b1 = actor ? O_AB1 : O_CB1, o_w2 = actor ? O_AW2 : O_CW2,
+              o_b2 = actor ? O_AB2 : O_CB2, o_w3 = actor ? O_AW3 : O_CW3;
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int uo = 16 * t + 4 * g + r;
+#pragma unroll
+            for (int u = 0; u < kTiles; ++u) atomicAdd(&acc[o_w2 + uo * kHid + 16 * u + n], A.w2[t][u][r]);
+            if (n < kIn) atomicAdd(&acc[o_w1 + uo * kIn + n], A.w1[t][r]);
+            else if (n == kIn) atomicAdd(&acc[o_b1 + uo], A.w1[t][r]);
+            atomicAdd(&acc[o_b2 + uo], A.b2[t][r]);
+        }
+    // joint output layer: accumulator row 4 g + r; rows 0 / 4 are the actor's outputs 0 / 1, row 8 the critic's
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) {
+        if (actor && g < 2) atomicAdd(&acc[o_w3 + g * kHid + 16 * t + n], A.w3[t][0]);
+        if (!actor && g == 2) atomicAdd(&acc[o_w3 + 16 * t + n], A.w3[t][0]);
+    }
+}
+
+struct PpoHyper {
+    float clip, value_loss_coef, inv_batch;
+    int use_clipped_value_loss;
+};
+
+template <int ACT>
+__global__ void __launch_bounds__(256) ppo_grad_kernel(const PpoNets N, const WlPpoBatch bt, const int mb_start, const int mb_size,
+                                                       const PpoHyper hp, float* __restrict__ partials) {
+    extern __shared__ float lds[];
+    float* tab = lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, n = lane & 15;
+    float* Td = lds + kTabFloats + wave * 2 * kTBuf;
+    float* Th = Td + kTBuf;
+    for (int i = threadIdx.x; i < kTabFloats; i += 256) tab[i] = operand_value(N, i);
+    __syncthreads();
+    const float one_g0 = g == 0 ? 1.f : 0.f;
+    const float sig = N.std[g & 1], sig_other = N.std[(g & 1) ^ 1];
+    const float inv_sig = 1.f / sig, log_sig_sum = logf(sig) + logf(sig_other);
+
+    NetGrads GA, GC;
+    GA.zero();
+    GC.zero();
+    float d_sigma = 0.f, d_b3 = 0.f, s_vloss = 0.f, s_surr = 0.f, s_kl = 0.f;
+
+    const int n_tiles = (mb_size + 15) >> 4;
+    const int n_waves = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += n_waves) {
+        const int k_n = tile * 16 + n;                       // position in the minibatch of "my" sample (column n)
+        const bool valid = k_n < mb_size;
+        const int smp = bt.perm[mb_start + (valid ? k_n : 0)];
+        // observation of sample n in forward-B layout (feature 4 s + g) ...
+        float xs[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int f = 4 * s + g;
+            xs[s] = f == kIn ? 1.f : f < kIn ? bt.obs[(int64_t)smp * kIn + f] : 0.f;
+        }
+        // ... and of sample 4 s + g in weight-gradient-B layout (feature n)
+        float xb[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k_s = tile * 16 + 4 * s + g;
+            const int smp_s = bt.perm[mb_start + (k_s < mb_size ? k_s : 0)];
+            xb[s] = (k_s >= mb_size) ? 0.f : n == kIn ? 1.f : n < kIn ? bt.obs[(int64_t)smp_s * kIn + n] : 0.f;
+        }
+        const float adv = bt.adv[smp], ret = bt.returns[smp], v_old = bt.values_old[smp], logp_old = bt.logp_old[smp];
+        const float act_g = bt.actions[smp * 2 + (g & 1)], mu_old_g = bt.mu_old[smp * 2 + (g & 1)];
+
+        f32x4 h1a[kTiles], h2a[kTiles], h1c[kTiles], h2c[kTiles];
+        forward_hidden<ACT>(tab, xs, one_g0, lane, h1a, h2a);
+        forward_hidden<ACT>(tab + kNetTab, xs, one_g0, lane, h1c, h2c);
+        f32x4 out = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < kTiles; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out = mfma4(tab[T_F3 + (4 * tp + r) * 64 + lane], h2a[tp][r], out);
+#pragma unroll
+        for (int tp = 0; tp < kTiles; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out = mfma4(tab[T_F3 + (16 + 4 * tp + r) * 64 + lane], h2c[tp][r], out);
+        out = mfma4(tab[T_F3 + 32 * 64 + lane], one_g0, out);
+        const float y = out[0];                               // g = 0: mu_0, 1: mu_1, 2: value (3: nothing)
+
+        // ---- losses and their derivatives w.r.t. the three outputs -----------------------------------------------------
+        const float z = (act_g - y) * inv_sig;                // meaningful on g < 2
+        const float zz_other = lane_xor16(z * z, lane);
+        const float logp = -0.5f * (z * z + zz_other) - log_sig_sum - 1.8378770664093453f;
+        const float ratio = __expf(logp - logp_old);
+        const float s1 = -adv * ratio, s2 = -adv * fminf(fmaxf(ratio, 1.f - hp.clip), 1.f + hp.clip);
+        const float dl_dlogp = (s1 >= s2 ? -adv : 0.f) * ratio * hp.inv_batch;
+        // value loss on g == 2
+        const float e1 = y - ret, dvo = y - v_old;
+        const float e2 = v_old + fminf(fmaxf(dvo, -hp.clip), hp.clip) - ret;
+        const float l1 = e1 * e1, l2 = e2 * e2;
+        float vloss = l1, dvl = 2.f * e1;
+        if (hp.use_clipped_value_loss && l2 > l1) {
+            vloss = l2;
+            dvl = fabsf(dvo) <= hp.clip ? 2.f * e2 : 0.f;
+        }
+        float d3 = 0.f;
+        if (valid) {
+            if (g < 2) {
+                d3 = dl_dlogp * z * inv_sig;
+                d_sigma += dl_dlogp * (z * z - 1.f) * inv_sig;
+                if (g == 0) s_surr += fmaxf(s1, s2);
+            } else if (g == 2) {
+                d3 = hp.value_loss_coef * dvl * hp.inv_batch;
+                s_vloss += vloss;
+            }
+            d_b3 += d3;
+        }
+        // KL term: sum over the two action dims of log(sigma / sigma_old + 1e-5) + (sigma_old^2 + (mu_old - mu)^2) / (2 sigma^2) - 1/2
+        {
+            const float so = bt.sigma_old[g & 1];
+            const float kl_g = logf(sig / so + 1e-5f) + (so * so + (mu_old_g - y) * (mu_old_g - y)) * (0.5f * inv_sig * inv_sig) - 0.5f;
+            const float kl_o = lane_xor16(kl_g, lane);
+            if (valid && g == 0) s_kl += kl_g + kl_o;
+        }
+
+        backward_net<ACT>(tab, Td, Th, h1a, h2a, g < 2 ? d3 : 0.f, xb, lane, GA);
+        backward_net<ACT>(tab + kNetTab, Td, Th, h1c, h2c, g == 2 ? d3 : 0.f, xb, lane, GC);
+    }
+
+    // ---- block reduction: the operand tables become the [G + stats] accumulator ------------------------------------------
+    __syncthreads();
+    float* acc = lds;
+    for (int i = threadIdx.x; i < kRow; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    flush_net(acc, GA, lane, true);
+    flush_net(acc, GC, lane, false);
+    if (g < 2) {
+        atomicAdd(&acc[O_STD + g], d_sigma);
+        atomicAdd(&acc[O_AB3 + g], d_b3);
+    } else if (g == 2) {
+        atomicAdd(&acc[O_CB3], d_b3);
+        atomicAdd(&acc[S_VLOSS], s_vloss);
+    }
+    if (g == 0) {
+        atomicAdd(&acc[S_SURR], s_surr);
+        atomicAdd(&acc[S_KL], s_kl);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kRow; i += 256) partials[(int64_t)blockIdx.x * kRow + i] = acc[i];
+}
+
+// grad[i] = sum over blocks of partials[b][i]; norm2 += sum of squares of the parameter gradients (stats excluded)
+__global__ void __launch_bounds__(256) ppo_reduce_kernel(const float* __restrict__ partials, int n_blocks, float* __restrict__ grad,
+                                                         float* __restrict__ norm2) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    if (i < kRow)
+        for (int b = 0; b < n_blocks; ++b) s += partials[(int64_t)b * kRow + i];
+    if (i < kRow) grad[i] = s;
+    float q = i < G ? s * s : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(norm2, red[0] + red[1] + red[2] + red[3]);
+}
+
+WL_DEV float* param_ptr(const PpoNets& N, float* std, int i) {
+    if (i < O_AW1) return std + i;
+    const bool a = i < O_CW1;
+    const WlMlp& net = a ? N.actor : N.critic;
+    const int j = i - (a ? O_AW1 : O_CW1);
+    const int nw3 = a ? 2 * kHid : kHid;
+    if (j < kHid * kIn) return const_cast<float*>(net.w1) + j;
+    if (j < kHid * kIn + kHid) return const_cast<float*>(net.b1) + (j - kHid * kIn);
+    const int k = j - kHid * kIn - kHid;
+    if (k < kHid * kHid) return const_cast<float*>(net.w2) + k;
+    if (k < kHid * kHid + kHid) return const_cast<float*>(net.b2) + (k - kHid * kHid);
+    const int m = k - kHid * kHid - kHid;
+    if (m < nw3) return const_cast<float*>(net.w3) + m;
+    return const_cast<float*>(net.b3) + (m - nw3);
+}
+
+// entropy term, gradient clipping, the adaptive-KL learning-rate rule and Adam (torch.optim.Adam's arithmetic)
+__global__ void __launch_bounds__(256) ppo_apply_kernel(const PpoNets N, float* std, const WlPpoParams hp, const float inv_batch,
+                                                        const float* __restrict__ grad, float* __restrict__ adam_m,
+                                                        float* __restrict__ adam_v, float* __restrict__ ctrl, const int parity,
+                                                        const int step /* 1-based */) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float lr_old = ctrl[WL_PPO_CTRL_LR + parity];
+    float lr = lr_old;
+    if (hp.adaptive) {
+        const float kl = grad[S_KL] * inv_batch;
+        if (kl > hp.desired_kl * 2.f) lr = fmaxf(hp.lr_min, lr_old / 1.5f);
+        else if (kl > 0.f && kl < hp.desired_kl * 0.5f) lr = fminf(hp.lr_max, lr_old * 1.5f);
+    }
+    // the entropy bonus -c_e * sum_j log sigma_j enters the std gradient before the norm; its square is added on the fly
+    float n2 = ctrl[WL_PPO_CTRL_NORM2 + parity];
+    const float gs0 = grad[O_STD], gs1 = grad[O_STD + 1];
+    const float es0 = -hp.entropy_coef / std[0], es1 = -hp.entropy_coef / std[1];
+    n2 += (gs0 + es0) * (gs0 + es0) - gs0 * gs0 + (gs1 + es1) * (gs1 + es1) - gs1 * gs1;
+    const float coef = fminf(1.f, hp.max_grad_norm / (sqrtf(fmaxf(n2, 0.f)) + 1e-6f));
+    if (i < G) {
+        float gr = grad[i];
+        if (i == O_STD) gr += es0;
+        if (i == O_STD + 1) gr += es1;
+        gr *= coef;
+        const float m = hp.beta1 * adam_m[i] + (1.f - hp.beta1) * gr;
+        const float v = hp.beta2 * adam_v[i] + (1.f - hp.beta2) * gr * gr;
+        adam_m[i] = m;
+        adam_v[i] = v;
+        const float bc1 = 1.f - powf(hp.beta1, (float)step), bc2 = 1.f - powf(hp.beta2, (float)step);
+        const float denom = sqrtf(v) / sqrtf(bc2) + hp.eps;
+        float* p = param_ptr(N, std, i);
+        *p -= (lr / bc1) * (m / denom);
+    }
+    if (i == 0) {   // hand the learning rate to the next call, clear its norm accumulator, book the statistics
+        ctrl[WL_PPO_CTRL_LR + (parity ^ 1)] = lr;
+        ctrl[WL_PPO_CTRL_NORM2 + (parity ^ 1)] = 0.f;
+        ctrl[WL_PPO_CTRL_STATS + 0] += grad[S_VLOSS] * inv_batch;
+        ctrl[WL_PPO_CTRL_STATS + 1] += grad[S_SURR] * inv_batch;
+        ctrl[WL_PPO_CTRL_STATS + 2] += grad[S_KL] * inv_batch;
+    }
+}
+
+int check_ppo(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
+              const WlPpoState* st) {
+    int rc = check_mlp(actor);
+    if (rc != WL_OK) return rc;
+    rc = check_mlp(critic);
+    if (rc != WL_OK) return rc;
+    if (actor->in_dim != kIn || critic->in_dim != kIn || actor->out_dim != 2 || critic->out_dim != 1 ||
+        actor->activation != critic->activation)
+        return WL_EINVAL;
+    if (!std || !bt || !bt->obs || !bt->actions || !bt->mu_old || !bt->logp_old || !bt->adv || !bt->returns || !bt->values_old ||
+        !bt->perm || !bt->sigma_old || mb_start < 0 || mb_size <= 0)
+        return WL_EINVAL;
+    if (!st || !st->partials || !st->grad || !st->ctrl) return WL_EINVAL;
+    return WL_OK;
+}
+
+int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
+                const WlPpoParams* hp, const WlPpoState* st, int parity, hipStream_t stream) {
+    const PpoNets N{*actor, *critic, std};
+    const PpoHyper h{hp->clip, hp->value_loss_coef, 1.f / (float)mb_size, hp->use_clipped_value_loss};
+    const int n_tiles = (mb_size + 15) / 16;
+    const int blocks = min(kPpoBlocks, (n_tiles + 3) / 4);
+    const size_t lds_bytes = (size_t)kLdsFloats * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ppo_grad_kernel<WL_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)ppo_grad_kernel<WL_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    clear_error();
+    if (actor->activation == WL_ACT_ELU)
+        ppo_grad_kernel<WL_ACT_ELU><<<blocks, 256, lds_bytes, stream>>>(N, *bt, mb_start, mb_size, h, st->partials);
+    else
+        ppo_grad_kernel<WL_ACT_RELU><<<blocks, 256, lds_bytes, stream>>>(N, *bt, mb_start, mb_size, h, st->partials);
+    ppo_reduce_kernel<<<(kRow + 255) / 256, 256, 0, stream>>>(st->partials, blocks, st->grad, st->ctrl + WL_PPO_CTRL_NORM2 + parity);
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int wl_ppo_gradients(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* batch, int32_t mb_start,
+                     int32_t mb_size, const WlPpoParams* hp, const WlPpoState* state, int32_t parity, void* stream) {
+    int rc = check_ppo(actor, critic, std, batch, mb_start, mb_size, state);
+    if (rc != WL_OK) return rc;
+    if (!hp || (parity != 0 && parity != 1)) return WL_EINVAL;
+    return launch_grad(actor, critic, std, batch, mb_start, mb_size, hp, state, parity, (hipStream_t)stream);
+}
+
+int wl_ppo_minibatch(const WlMlp* actor, const WlMlp* critic, float* std, const WlPpoBatch* batch, int32_t mb_start,
+                     int32_t mb_size, const WlPpoParams* hp, const WlPpoState* state, int32_t parity, int32_t adam_step,
+                     void* stream) {
+    int rc = check_ppo(actor, critic, std, batch, mb_start, mb_size, state);
+    if (rc != WL_OK) return rc;
+    if (!hp || !state->adam_m || !state->adam_v || (parity != 0 && parity != 1) || adam_step < 1) return WL_EINVAL;
+    rc = launch_grad(actor, critic, std, batch, mb_start, mb_size, hp, state, parity, (hipStream_t)stream);
+    if (rc != WL_OK) return rc;
+    const PpoNets N{*actor, *critic, std};
+    ppo_apply_kernel<<<(G + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, std, *hp, 1.f / (float)mb_size, state->grad, state->adam_m,
+                                                                       state->adam_v, state->ctrl, parity, adam_step);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -340,3 +340,69 @@ def _finished_episodes(rewards, done, carry_ret, carry_len):
 
 def _mean(buf):
     return float(sum(buf) / len(buf)) if len(buf) else 0.0
+
+
+class FusedPpoStep:
+    """The PPO minibatch step as three HIP launches (csrc/wl_ppo.hip: fused MFMA forward / backward / weight gradients,
+    partial-sum reduction, clip + adaptive-KL learning rate + Adam) on the torch Parameters of `actor_critic` in place.
+    Owns the device scratch the C ABI asks the caller for."""
+
+    def __init__(self, actor_critic: ActorCritic, ppo: "PPO"):
+        import ctypes as C
+
+        from .. import _abi as A
+        if not actor_critic.fusable() or actor_critic.actor[0].in_features != 14 or actor_critic.actor[4].out_features != 2:
+            raise ValueError("the fused PPO step is specialised for the drift agents' 14-64-64-2 / 14-64-64-1 MLPs")
+        self._C, self._A, self.lib = C, A, A.load()
+        self.ac, self.view = actor_critic, actor_critic.fused()
+        dev = actor_critic.std.device
+        self.dev = dev
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        self.partials, self.grad = z(A.PPO_BLOCKS, A.PPO_PARTIAL_STRIDE), z(A.PPO_PARTIAL_STRIDE)
+        self.adam_m, self.adam_v, self.ctrl = z(A.PPO_NUM_PARAMS), z(A.PPO_NUM_PARAMS), z(16)
+        self.ctrl[A.PPO_CTRL_LR:A.PPO_CTRL_LR + 2] = float(ppo.learning_rate)
+        self.state = A.WlPpoState(self.partials.data_ptr(), self.grad.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+                                  self.ctrl.data_ptr())
+        adaptive = int(ppo.desired_kl is not None and ppo.schedule == "adaptive")
+        self.hp = A.WlPpoParams(ppo.clip_param, ppo.value_loss_coef, ppo.entropy_coef, float(ppo.desired_kl or 0.0),
+                                ppo.max_grad_norm, 0.9, 0.999, 1e-8, 1e-5, 1e-2, int(ppo.use_clipped_value_loss), adaptive)
+        self.parity, self.adam_step = 0, 0
+        self._actor, self._critic = self.view.actor.struct(), self.view.critic.struct()
+
+    def _batch(self, flat, perm, sigma_old):
+        A = self._A
+        for k in ("obs", "actions", "mu", "logp", "adv", "returns", "values"):
+            t = flat[k]
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.dev, k
+        assert perm.dtype == torch.int32 and perm.is_contiguous()
+        self._keep = (flat, perm, sigma_old)     # the launch is asynchronous: keep the tensors alive
+        return A.WlPpoBatch(flat["obs"].data_ptr(), flat["actions"].data_ptr(), flat["mu"].data_ptr(), flat["logp"].data_ptr(),
+                            flat["adv"].data_ptr(), flat["returns"].data_ptr(), flat["values"].data_ptr(), perm.data_ptr(),
+                            sigma_old.data_ptr())
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    @property
+    def learning_rate(self) -> float:
+        return float(self.ctrl[self._A.PPO_CTRL_LR + self.parity])
+
+    def gradients(self, flat, perm, mb_start, mb_size, sigma_old):
+        """d loss / d parameters of one minibatch in the flat order of named_parameters() (no entropy term, no clipping)
+        plus [value-loss sum, surrogate sum, KL sum] -- the parity entry point"""
+        C, A = self._C, self._A
+        bt = self._batch(flat, perm, sigma_old)
+        self.ctrl[A.PPO_CTRL_NORM2:A.PPO_CTRL_NORM2 + 2] = 0.0
+        A.check(self.lib.wl_ppo_gradients(C.byref(self._actor), C.byref(self._critic), self.ac.std.data_ptr(), C.byref(bt),
+                                          int(mb_start), int(mb_size), C.byref(self.hp), C.byref(self.state), self.parity,
+                                          self._stream()), "wl_ppo_gradients")
+        return self.grad
+
+    def minibatch(self, flat, perm, mb_start, mb_size, sigma_old):
+        C, A = self._C, self._A
+        bt = self._batch(flat, perm, sigma_old)
+        self.adam_step += 1
+        A.check(self.lib.wl_ppo_minibatch(C.byref(self._actor), C.byref(self._critic), self.ac.std.data_ptr(), C.byref(bt),
+                                          int(mb_start), int(mb_size), C.byref(self.hp), C.byref(self.state), self.parity,
+                                          self.adam_step, self._stream()), "wl_ppo_minibatch")
+        self.parity ^= 1
