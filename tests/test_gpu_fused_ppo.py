@@ -79,3 +79,71 @@ def test_fused_gradients_match_autograd(activation, B, mb_start, mb_size):
     assert abs(float(stats[0]) - float(value_loss)) < 1e-4 * (1 + abs(float(value_loss)))
     assert abs(float(stats[1]) - float(surrogate)) < 1e-4 * (1 + abs(float(surrogate)))
     assert abs(float(stats[2]) - float(kl)) < 1e-4 * (1 + abs(float(kl)))
+
+
+def test_fused_step_tracks_the_torch_step():
+    """12 consecutive minibatch steps (gradients -> entropy term -> norm clipping -> adaptive-KL learning rate -> Adam) by
+    the fused kernels and by the torch implementation on copies of the same nets and the same minibatches: parameters
+    stay equal to accumulated fp32 rounding, the learning-rate trajectory is identical"""
+    from wheeledlab_amd.rl.ppo import FusedPpoStep, PPO
+    B, mb = 8192, 2048
+    ac_f, flat, sigma_old = _problem(B, "elu", seed=3)
+    ac_t = copy.deepcopy(ac_f)
+    pf, pt = PPO(ac_f, desired_kl=0.002), PPO(ac_t, desired_kl=0.002)   # the synthetic KL (~0.01) is far above 2 x target
+    fused = FusedPpoStep(ac_f, pf)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    lrs_f, lrs_t = [], []
+    for step in range(12):
+        if step % 4 == 0:
+            perm = torch.randperm(B, device=DEV, generator=g).to(torch.int32)
+        start = (step % 4) * mb
+        fused.minibatch(flat, perm, start, mb, sigma_old)
+        idx = perm[start:start + mb].long()
+        pt._step({k: v[idx] for k, v in flat.items()}, sigma_old)
+        lrs_f.append(fused.learning_rate)
+        lrs_t.append(pt.learning_rate)
+        for (name, a), b in zip(ac_f.named_parameters(), ac_t.parameters()):
+            d = float((a - b).abs().max())
+            assert d < 2e-5 * (step + 1) + 2e-3 * lrs_t[-1] * (step + 1), (step, name, d)
+    assert np.allclose(lrs_f, lrs_t, rtol=1e-6), (lrs_f, lrs_t)
+    assert len(set(lrs_t)) > 1                                     # the adaptive rule actually moved the learning rate
+
+
+def test_update_with_the_fused_step_equals_the_torch_update_and_checkpoints_round_trip(tmp_path):
+    """PPO.update(fused_update=True) vs PPO.update(fused_update=False) on one storage with the same permutations; the
+    optimizer state written by the fused learner loads into the torch learner (rsl_rl's checkpoint format) and back"""
+    from wheeledlab_amd.policy import RolloutStorage
+    from wheeledlab_amd.rl.ppo import ActorCritic, PPO
+    torch.manual_seed(4)
+    n, K = 1024, 16
+    ac_f = ActorCritic(14, 14, 2).to(DEV)
+    ac_t = copy.deepcopy(ac_f)
+    st = RolloutStorage(K, n, device=DEV)
+    st.observations.normal_()
+    with torch.no_grad():
+        ac_t.update_distribution(st.observations[:K].reshape(K * n, 14))
+        a = ac_t.distribution.sample()
+        st.actions.copy_(a.reshape(K, n, 2))
+        st.mu.copy_(ac_t.action_mean.reshape(K, n, 2))
+        st.actions_log_prob.copy_(ac_t.get_actions_log_prob(a).reshape(K, n))
+        st.values.copy_(ac_t.evaluate(st.observations.reshape((K + 1) * n, 14)).reshape(K + 1, n))
+    st.rewards.normal_()
+    st.dones.copy_((torch.rand(K, n, device=DEV) < 0.05).long())
+    pf, pt = PPO(ac_f, fused_update=True), PPO(ac_t, fused_update=False)
+    for it in range(2):
+        lf = pf.update(st, generator=torch.Generator(device=DEV).manual_seed(20 + it))
+        lt = pt.update(st, generator=torch.Generator(device=DEV).manual_seed(20 + it))
+        for (name, p), q in zip(ac_f.named_parameters(), ac_t.parameters()):
+            assert torch.allclose(p, q, rtol=1e-3, atol=2e-4), (it, name, float((p - q).abs().max()))
+        assert abs(lf["learning_rate"] - lt["learning_rate"]) < 1e-9
+        assert abs(lf["kl"] - lt["kl"]) < 1e-4 and abs(lf["surrogate"] - lt["surrogate"]) < 1e-4
+        assert abs(lf["value_function"] - lt["value_function"]) < 1e-3 * (1 + abs(lt["value_function"]))
+    # fused -> checkpoint format -> torch learner: the next torch update continues from the fused moments
+    sd = copy.deepcopy(pf.optimizer_state_dict())
+    ac_r = copy.deepcopy(ac_f)
+    pr = PPO(ac_r, fused_update=False)
+    pr.load_optimizer_state(sd)
+    pf.update(st, generator=torch.Generator(device=DEV).manual_seed(77))
+    pr.update(st, generator=torch.Generator(device=DEV).manual_seed(77))
+    for (name, p), q in zip(ac_f.named_parameters(), ac_r.parameters()):
+        assert torch.allclose(p, q, rtol=1e-3, atol=2e-4), (name, float((p - q).abs().max()))

@@ -111,7 +111,7 @@ class PPO:
 
     def __init__(self, actor_critic: ActorCritic, value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2,
                  entropy_coef=0.005, num_learning_epochs=5, num_mini_batches=4, learning_rate=1e-3, schedule="adaptive",
-                 gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0, **_unused):
+                 gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0, fused_update: bool | None = None, **_unused):
         self.actor_critic = actor_critic
         self.value_loss_coef, self.use_clipped_value_loss, self.clip_param = value_loss_coef, use_clipped_value_loss, clip_param
         self.entropy_coef, self.num_learning_epochs, self.num_mini_batches = entropy_coef, num_learning_epochs, num_mini_batches
@@ -125,9 +125,17 @@ class PPO:
         else:
             self.optimizer = torch.optim.Adam(actor_critic.parameters(), lr=float(learning_rate))
 
+        # the drift agents' nets on a GPU: the whole minibatch step runs in the HIP library (FusedPpoStep below)
+        can_fuse = (dev.type == "cuda" and actor_critic.fusable() and actor_critic.actor[0].in_features == 14
+                    and actor_critic.actor[4].out_features == 2)
+        if fused_update and not can_fuse:
+            raise ValueError("fused_update needs the 14-64-64-2 / 14-64-64-1 elu / relu nets on a GPU")
+        self.fused_update = can_fuse if fused_update is None else bool(fused_update)
+        self._fused = None
+
     @property
     def learning_rate(self) -> float:
-        return float(self._lr)
+        return self._fused.learning_rate if self._fused is not None else float(self._lr)
 
     # ---- one minibatch step on the tensors of `b` (all arithmetic; no host round trip) ---------------------------------
     def _step(self, b, sigma_old):
@@ -166,6 +174,12 @@ class PPO:
         self.optimizer.step()
         return torch.stack([value_loss.detach(), surrogate.detach(), kl_mean.detach()])
 
+    def optimizer_state_dict(self):
+        """torch.optim.Adam's state_dict (rsl_rl's checkpoint key), also when the fused step owns the moments"""
+        if self._fused is not None:
+            self._fused.state_to_optimizer(self.optimizer)
+        return self.optimizer.state_dict()
+
     def load_optimizer_state(self, state_dict):
         """checkpoint resume: load_state_dict replaces the param-group lr, so the device lr tensor is re-bound"""
         self.optimizer.load_state_dict(state_dict)
@@ -173,6 +187,8 @@ class PPO:
             self._lr.copy_(torch.as_tensor(self.optimizer.param_groups[0]["lr"], dtype=torch.float32))
         for g in self.optimizer.param_groups:
             g["lr"] = self._lr if self._lr_on_device else float(self._lr)
+        if self._fused is not None:
+            self._fused.state_from_optimizer(self.optimizer, float(self._lr))
 
     def update(self, storage: RolloutStorage, generator: torch.Generator | None = None):
         K, n = storage.n_steps, storage.n_envs
@@ -185,12 +201,25 @@ class PPO:
         batch = K * n
         mb = batch // self.num_mini_batches
         stats = torch.zeros(3, device=flat["obs"].device)
-        for _ in range(self.num_learning_epochs):
-            perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator)
-            shuffled = {k: v[perm] for k, v in flat.items()}        # one gather per field and epoch
-            for i in range(self.num_mini_batches):
-                sl = slice(i * mb, (i + 1) * mb)
-                stats += self._step({k: v[sl] for k, v in shuffled.items()}, sigma_old)
+        if self.fused_update:
+            if self._fused is None:
+                self._fused = FusedPpoStep(self.actor_critic, self)
+                self._fused.state_from_optimizer(self.optimizer, float(self._lr))
+            fz = self._fused
+            fz.ctrl[4:7] = 0.0
+            flat = {k: v.contiguous() for k, v in flat.items()}
+            for _ in range(self.num_learning_epochs):
+                perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator).to(torch.int32)
+                for i in range(self.num_mini_batches):    # the kernel gathers through `perm`: no shuffled copies
+                    fz.minibatch(flat, perm, i * mb, mb, sigma_old)
+            stats = fz.ctrl[4:7].clone()
+        else:
+            for _ in range(self.num_learning_epochs):
+                perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator)
+                shuffled = {k: v[perm] for k, v in flat.items()}        # one gather per field and epoch
+                for i in range(self.num_mini_batches):
+                    sl = slice(i * mb, (i + 1) * mb)
+                    stats += self._step({k: v[sl] for k, v in shuffled.items()}, sigma_old)
         u = self.num_learning_epochs * self.num_mini_batches
         mean_value_loss, mean_surrogate_loss, mean_kl = (stats / u).tolist()
         return dict(value_function=mean_value_loss, surrogate=mean_surrogate_loss, kl=mean_kl, learning_rate=self.learning_rate)
@@ -299,7 +328,7 @@ class OnPolicyRunner:
     # ---- checkpoints: rsl_rl's keys (train_rl.py:96-106 resumes from `model_*.pt`) --------------------------
     def save(self, path: str, infos=None):
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        torch.save({"model_state_dict": self.actor_critic.state_dict(), "optimizer_state_dict": self.alg.optimizer.state_dict(),
+        torch.save({"model_state_dict": self.actor_critic.state_dict(), "optimizer_state_dict": self.alg.optimizer_state_dict(),
                     "iter": self.current_learning_iteration, "infos": infos}, path)
 
     def load(self, path: str, load_optimizer: bool = True):
@@ -406,3 +435,33 @@ class FusedPpoStep:
                                           int(mb_start), int(mb_size), C.byref(self.hp), C.byref(self.state), self.parity,
                                           self.adam_step, self._stream()), "wl_ppo_minibatch")
         self.parity ^= 1
+
+    # ---- Adam state <-> torch.optim.Adam (checkpoints keep rsl_rl's format) ---------------------------------------------
+    def state_to_optimizer(self, optimizer):
+        off = 0
+        for p in self.ac.parameters():
+            k = p.numel()
+            st = optimizer.state[p]
+            st["step"] = torch.tensor(float(self.adam_step), dtype=torch.float32, device=self.dev)
+            st["exp_avg"] = self.adam_m[off:off + k].view_as(p).clone()
+            st["exp_avg_sq"] = self.adam_v[off:off + k].view_as(p).clone()
+            off += k
+        lr = self.learning_rate
+        for g in optimizer.param_groups:
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
+
+    def state_from_optimizer(self, optimizer, lr: float):
+        off, step = 0, 0
+        for p in self.ac.parameters():
+            k = p.numel()
+            st = optimizer.state.get(p, {})
+            if "exp_avg" in st:
+                self.adam_m[off:off + k] = st["exp_avg"].reshape(-1)
+                self.adam_v[off:off + k] = st["exp_avg_sq"].reshape(-1)
+                step = int(float(st["step"]))
+            off += k
+        self.adam_step = step
+        self.ctrl[self._A.PPO_CTRL_LR:self._A.PPO_CTRL_LR + 2] = float(lr)
