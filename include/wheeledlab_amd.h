@@ -299,6 +299,11 @@ typedef struct WlPpoState {          /* caller-owned device scratch */
     float* ctrl;                     /* [16], see WL_PPO_CTRL_* */
 } WlPpoState;
 
+/* Generalised advantage estimation exactly as rsl_rl's RolloutStorage.compute_returns: rewards / dones [K][n], values
+ * [K + 1][n] (row K = bootstrap value of the last observation); writes returns and (un-normalised) advantages [K][n]. */
+int wl_gae(int32_t n_steps, int32_t n_envs, const float* rewards, const float* values, const int64_t* dones, float gamma,
+           float lam, float* returns, float* advantages, void* stream);
+
 /* gradients only (parity entry point): state->grad = d loss / d params (entropy term and clipping NOT applied) + the
  * three sums; accumulates the squared norm into ctrl[WL_PPO_CTRL_NORM2 + parity]. */
 int wl_ppo_gradients(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* batch, int32_t mb_start,

@@ -147,3 +147,18 @@ def test_update_with_the_fused_step_equals_the_torch_update_and_checkpoints_roun
     pr.update(st, generator=torch.Generator(device=DEV).manual_seed(77))
     for (name, p), q in zip(ac_f.named_parameters(), ac_r.parameters()):
         assert torch.allclose(p, q, rtol=1e-3, atol=2e-4), (name, float((p - q).abs().max()))
+
+
+def test_gae_kernel_matches_the_oracle():
+    from oracle import policy as OPOL
+    from wheeledlab_amd.policy import RolloutStorage
+    rng = np.random.default_rng(2)
+    K, n = 37, 1000
+    st = RolloutStorage(K, n, device=DEV)
+    st.rewards.copy_(torch.from_numpy(rng.normal(size=(K, n)).astype(np.float32)))
+    st.values.copy_(torch.from_numpy(rng.normal(size=(K + 1, n)).astype(np.float32)))
+    st.dones.copy_(torch.from_numpy((rng.random((K, n)) < 0.1).astype(np.int64)))
+    ret, adv_n = st.compute_returns(0.99, 0.95)
+    ret_o, adv_o = OPOL.compute_returns(st.rewards.cpu().numpy(), st.values.cpu().numpy(), st.dones.cpu().numpy(), 0.99, 0.95)
+    np.testing.assert_allclose(ret.cpu().numpy(), ret_o, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(adv_n.cpu().numpy(), (adv_o - adv_o.mean()) / (adv_o.std(ddof=1) + 1e-8), rtol=1e-4, atol=1e-4)

@@ -436,6 +436,25 @@ __global__ void __launch_bounds__(256) ppo_apply_kernel(const PpoNets N, float* 
     }
 }
 
+// rsl_rl RolloutStorage.compute_returns: one lane per env walks its K transitions backwards ([step][env] rows: coalesced)
+__global__ void __launch_bounds__(256) gae_kernel(const int K, const int n, const float* __restrict__ rewards,
+                                                   const float* __restrict__ values, const int64_t* __restrict__ dones,
+                                                   const float gamma, const float lam, float* __restrict__ returns,
+                                                   float* __restrict__ advantages) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float adv = 0.f, v_next = values[(int64_t)K * n + e];
+    for (int t = K - 1; t >= 0; --t) {
+        const int64_t at = (int64_t)t * n + e;
+        const float nd = dones[at] != 0 ? 0.f : 1.f, v = values[at];
+        const float delta = rewards[at] + nd * gamma * v_next - v;
+        adv = delta + nd * gamma * lam * adv;
+        advantages[at] = adv;
+        returns[at] = adv + v;
+        v_next = v;
+    }
+}
+
 int check_ppo(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
               const WlPpoState* st) {
     int rc = check_mlp(actor);
@@ -477,6 +496,15 @@ int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const
 }  // namespace
 
 extern "C" {
+
+int wl_gae(int32_t n_steps, int32_t n_envs, const float* rewards, const float* values, const int64_t* dones, float gamma,
+           float lam, float* returns, float* advantages, void* stream) {
+    if (n_steps <= 0 || n_envs <= 0 || !rewards || !values || !dones || !returns || !advantages) return WL_EINVAL;
+    clear_error();
+    gae_kernel<<<(n_envs + 255) / 256, 256, 0, (hipStream_t)stream>>>(n_steps, n_envs, rewards, values, dones, gamma, lam, returns,
+                                                                      advantages);
+    return launch_status();
+}
 
 int wl_ppo_gradients(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* batch, int32_t mb_start,
                      int32_t mb_size, const WlPpoParams* hp, const WlPpoState* state, int32_t parity, void* stream) {

@@ -105,14 +105,21 @@ class RolloutStorage:
         self.rewards += gamma * self.values[:-1] * self.time_outs
 
     def compute_returns(self, gamma: float = 0.99, lam: float = 0.95):
-        """GAE exactly as rsl_rl RolloutStorage.compute_returns; returns (returns, advantages) [K, n]"""
+        """GAE exactly as rsl_rl RolloutStorage.compute_returns; returns (returns, normalised advantages) [K, n].
+        On a GPU the backward recursion is one launch (wl_gae: one lane per env); on the CPU it is the torch loop."""
         K = self.n_steps
-        adv = torch.zeros_like(self.rewards)
-        last = torch.zeros(self.n_envs, dtype=torch.float32, device=self.rewards.device)
-        not_done = 1.0 - self.dones.to(torch.float32)
-        for t in reversed(range(K)):
-            delta = self.rewards[t] + not_done[t] * gamma * self.values[t + 1] - self.values[t]
-            last = delta + not_done[t] * gamma * lam * last
-            adv[t] = last
-        returns = adv + self.values[:-1]
+        adv = torch.empty_like(self.rewards)
+        if self.rewards.is_cuda:
+            returns = torch.empty_like(self.rewards)
+            A.check(A.load().wl_gae(K, self.n_envs, self.rewards.data_ptr(), self.values.data_ptr(), self.dones.data_ptr(),
+                                    float(gamma), float(lam), returns.data_ptr(), adv.data_ptr(),
+                                    C.c_void_p(torch.cuda.current_stream(self.rewards.device).cuda_stream)), "wl_gae")
+        else:
+            last = torch.zeros(self.n_envs, dtype=torch.float32, device=self.rewards.device)
+            not_done = 1.0 - self.dones.to(torch.float32)
+            for t in reversed(range(K)):
+                delta = self.rewards[t] + not_done[t] * gamma * self.values[t + 1] - self.values[t]
+                last = delta + not_done[t] * gamma * lam * last
+                adv[t] = last
+            returns = adv + self.values[:-1]
         return returns, (adv - adv.mean()) / (adv.std() + 1e-8)
