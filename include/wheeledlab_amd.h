@@ -266,6 +266,7 @@ int wl_drift_rollout_policy(const WlDriftParams* p, const WlEnvBuffers* b, const
 #define WL_PPO_NUM_PARAMS 10437
 #define WL_PPO_PARTIAL_STRIDE 10440   /* + value-loss, surrogate and KL sums of the minibatch */
 #define WL_PPO_BLOCKS 256             /* rows of WlPpoState.partials */
+#define WL_PPO_OPERAND_FLOATS 21760   /* both nets laid out in MFMA operand order (rebuilt by every step) */
 /* WlPpoState.ctrl (16 floats, zero-initialised by the caller once): */
 #define WL_PPO_CTRL_LR 0      /* [2] learning rate, ping-pong by `parity` (the caller seeds BOTH with the initial lr) */
 #define WL_PPO_CTRL_NORM2 2   /* [2] squared gradient norm accumulator, ping-pong */
@@ -297,6 +298,7 @@ typedef struct WlPpoState {          /* caller-owned device scratch */
     float* adam_m;                   /* [WL_PPO_NUM_PARAMS] */
     float* adam_v;                   /* [WL_PPO_NUM_PARAMS] */
     float* ctrl;                     /* [16], see WL_PPO_CTRL_* */
+    float* operands;                 /* [WL_PPO_OPERAND_FLOATS], 16-byte aligned */
 } WlPpoState;
 
 /* Generalised advantage estimation exactly as rsl_rl's RolloutStorage.compute_returns: rewards / dones [K][n], values

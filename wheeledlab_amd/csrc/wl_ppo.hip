@@ -35,9 +35,17 @@ constexpr int O_STD = 0, O_AW1 = 2, O_AB1 = O_AW1 + kHid * kIn, O_AW2 = O_AB1 + 
 static_assert(O_CB3 + 1 == G, "parameter layout");
 constexpr int S_VLOSS = G, S_SURR = G + 1, S_KL = G + 2;
 
-// LDS operand tables (floats); every operand is 64 consecutive floats (one per lane)
-constexpr int T_F1 = 0, T_F2 = T_F1 + 4 * 4 * 64, T_B2 = T_F2 + 4 * 17 * 64, T_B3 = T_B2 + 4 * 16 * 64, kNetTab = T_B3 + 4 * 64;
-constexpr int T_F3 = 2 * kNetTab, kTabFloats = T_F3 + 33 * 64;
+// LDS operand tables (floats).  Operands are stored in QUADS in the order the MFMA loops consume them -- slot
+// ((quad * 64 + lane) * 4 + j) -- so that one ds_read_b128 per lane fetches the A operands of four consecutive MFMAs
+// (with one ds_read_b32 per MFMA the kernel waited on LDS latency for every matrix instruction: 210 us per minibatch).
+//   F1 quad s        : the four output tiles t = j of layer-1 k-step s
+//   F2 quad ks       : the four output tiles t = j of layer-2 k-step ks (ks = 4 t' + r, 16 = bias)
+//   B2 quad ks       : the four input tiles t = j of the W2^T k-step ks
+//   B3 quad 0        : the four unit tiles t = j of W3^T
+//   F3 quad q        : k-steps 4 q + j of the joint output layer (0..15 actor units, 16..31 critic units, 32 bias, pad)
+constexpr int T_F1 = 0, T_F2 = T_F1 + 4 * 256, T_B2 = T_F2 + 17 * 256, T_B3 = T_B2 + 16 * 256, kNetTab = T_B3 + 256;
+constexpr int T_F3 = 2 * kNetTab, kTabFloats = T_F3 + 9 * 256;
+static_assert(kTabFloats == WL_PPO_OPERAND_FLOATS, "header constant");
 constexpr int kTStride = 20, kTBuf = kHid * kTStride;          // transposition buffer [unit][sample], padded rows
 constexpr int kLdsFloats = kTabFloats + 4 * 2 * kTBuf;          // + two buffers per wavefront
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
@@ -48,39 +56,40 @@ struct PpoNets {
     const float* std;
 };
 
-// value of slot `idx` of the operand tables (run once per block; lane = idx & 63: i = row of the A tile, g = k index)
+// value of slot `idx` of the operand tables (run once per block): i = row of the A tile, g = its k index
 WL_DEV float operand_value(const PpoNets& N, int idx) {
-    const int lane = idx & 63, i = lane & 15, g = lane >> 4;
-    int op = idx >> 6;
-    if (op < 2 * (kNetTab / 64)) {
-        const WlMlp& net = op < kNetTab / 64 ? N.actor : N.critic;
-        if (op >= kNetTab / 64) op -= kNetTab / 64;
-        if (op < T_F2 / 64) {                                   // forward layer 1: [t][s]
-            const int t = op >> 2, s = op & 3, f = 4 * s + g, unit = 16 * t + i;
+    const int j = idx & 3, lane = (idx >> 2) & 63, i = lane & 15, g = lane >> 4;
+    int q = idx >> 8;
+    if (q < 2 * (kNetTab / 256)) {
+        const bool is_actor = q < kNetTab / 256;
+        const WlMlp& net = is_actor ? N.actor : N.critic;
+        if (!is_actor) q -= kNetTab / 256;
+        if (q < 4) {                                            // forward layer 1: k-step s = q, tile t = j
+            const int f = 4 * q + g, unit = 16 * j + i;
             return f < kIn ? net.w1[unit * kIn + f] : f == kIn ? net.b1[unit] : 0.f;
         }
-        op -= T_F2 / 64;
-        if (op < 4 * 17) {                                      // forward layer 2: [t][ks], ks = 4 t' + r | bias
-            const int t = op / 17, ks = op % 17, unit = 16 * t + i;
-            if (ks == 16) return g == 0 ? net.b2[unit] : 0.f;
-            return net.w2[unit * kHid + 16 * (ks >> 2) + 4 * g + (ks & 3)];
+        q -= 4;
+        if (q < 17) {                                           // forward layer 2: k-step ks = q, tile t = j
+            const int unit = 16 * j + i;
+            if (q == 16) return g == 0 ? net.b2[unit] : 0.f;
+            return net.w2[unit * kHid + 16 * (q >> 2) + 4 * g + (q & 3)];
         }
-        op -= 4 * 17;
-        if (op < 4 * 16) {                                      // backward W2^T: [t (input tile)][ks = 4 t' + r]
-            const int t = op >> 4, ks = op & 15;
-            return net.w2[(16 * (ks >> 2) + 4 * g + (ks & 3)) * kHid + 16 * t + i];
-        }
-        op -= 4 * 16;                                           // backward W3^T: [t]; k = g = output index of the joint layer
-        const int unit = 16 * op + i;
-        if (&net == &N.actor) return g < 2 ? net.w3[g * kHid + unit] : 0.f;
+        q -= 17;
+        if (q < 16)                                             // backward W2^T: k-step ks = q (output unit), input tile t = j
+            return net.w2[(16 * (q >> 2) + 4 * g + (q & 3)) * kHid + 16 * j + i];
+        const int unit = 16 * j + i;                            // backward W3^T: k = g = output index of the joint layer
+        if (is_actor) return g < 2 ? net.w3[g * kHid + unit] : 0.f;
         return g == 2 ? net.w3[unit] : 0.f;
     }
-    op -= 2 * (kNetTab / 64);                                   // joint output layer: rows 0 / 4 / 8 = mu_0 / mu_1 / value
-    if (op < 16) return i == 0 ? N.actor.w3[16 * (op >> 2) + 4 * g + (op & 3)]
-                      : i == 4 ? N.actor.w3[kHid + 16 * (op >> 2) + 4 * g + (op & 3)] : 0.f;
-    if (op < 32) return i == 8 ? N.critic.w3[16 * ((op - 16) >> 2) + 4 * g + ((op - 16) & 3)] : 0.f;
+    q -= 2 * (kNetTab / 256);                                   // joint output layer: rows 0 / 4 / 8 = mu_0 / mu_1 / value
+    const int ks = 4 * q + j;
+    if (ks < 16) return i == 0 ? N.actor.w3[16 * (ks >> 2) + 4 * g + (ks & 3)]
+                      : i == 4 ? N.actor.w3[kHid + 16 * (ks >> 2) + 4 * g + (ks & 3)] : 0.f;
+    if (ks < 32) return i == 8 ? N.critic.w3[16 * ((ks - 16) >> 2) + 4 * g + ((ks - 16) & 3)] : 0.f;
+    if (ks > 32) return 0.f;
     return g != 0 ? 0.f : i == 0 ? N.actor.b3[0] : i == 4 ? N.actor.b3[1] : i == 8 ? N.critic.b3[0] : 0.f;
 }
+WL_DEV f32x4 quad(const float* tab, int q, int lane) { return *reinterpret_cast<const f32x4*>(tab + (q * 64 + lane) * 4); }
 
 template <int ACT>
 WL_DEV float act_grad_from_output(float h) {   // d act / d z expressed through h = act(z)
@@ -92,24 +101,30 @@ WL_DEV float lane_xor16(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __float_as_int(v)));
 }
 
-// accumulator layout -> [unit][sample] in the wavefront's LDS buffer
+// accumulator layout -> [unit][sample] in the wavefront's LDS buffer.  Sample 4 s + g' sits at column 4 g' + s, so the four
+// k-steps s = 0..3 of an operand (same lane group g' = g) are one 16-byte read.
 WL_DEV void put_transposed(float* T, const f32x4 X[kTiles], int g, int n) {
+    const int col = 4 * (n & 3) + (n >> 2);
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T[(16 * t + 4 * g + r) * kTStride + n] = X[t][r];
+        for (int r = 0; r < 4; ++r) T[(16 * t + 4 * g + r) * kTStride + col] = X[t][r];
 }
-// operand (A or B alike) of k-step s for unit tile t: element [unit 16 t + n][sample 4 s + g]
-WL_DEV float get_transposed(const float* T, int t, int s, int g, int n) { return T[(16 * t + n) * kTStride + 4 * s + g]; }
+// operands (A or B alike) of k-steps s = 0..3 for unit tile t: elements [unit 16 t + n][sample 4 s + g]
+WL_DEV f32x4 get_transposed4(const float* T, int t, int g, int n) {
+    return *reinterpret_cast<const f32x4*>(T + (16 * t + n) * kTStride + 4 * g);
+}
 
 template <int ACT>
 WL_DEV void forward_hidden(const float* tab, const float xs[4], float one_g0, int lane, f32x4 h1[kTiles], f32x4 h2[kTiles]) {
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) h1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s) {
+        const f32x4 a = quad(tab + T_F1, s, lane);
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) h1[t] = mfma4(tab[T_F1 + (4 * t + s) * 64 + lane], xs[s], h1[t]);
+        for (int t = 0; t < kTiles; ++t) h1[t] = mfma4(a[t], xs[s], h1[t]);
+    }
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
@@ -117,13 +132,12 @@ WL_DEV void forward_hidden(const float* tab, const float xs[4], float one_g0, in
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) h2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tp = 0; tp < kTiles; ++tp)
+    for (int ks = 0; ks < 17; ++ks) {
+        const f32x4 a = quad(tab + T_F2, ks, lane);
+        const float b = ks < 16 ? h1[ks >> 2][ks & 3] : one_g0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int t = 0; t < kTiles; ++t) h2[t] = mfma4(tab[T_F2 + (17 * t + 4 * tp + r) * 64 + lane], h1[tp][r], h2[t]);
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) h2[t] = mfma4(tab[T_F2 + (17 * t + 16) * 64 + lane], one_g0, h2[t]);
+        for (int t = 0; t < kTiles; ++t) h2[t] = mfma4(a[t], b, h2[t]);
+    }
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
@@ -153,31 +167,38 @@ WL_DEV void backward_net(const float* tab, float* Td, float* Th, const f32x4 h1[
     const int g = lane >> 4, n = lane & 15;
     // dW3 += delta3^T . H2 : A operand = delta3 of row i's output at sample 4 s + g (rows 0 / 4 / 8), via Td
     put_transposed(Th, h2, g, n);
-    if (n < 16) Td[g * kTStride + n] = d3;                       // [output g][sample n]
+    Td[g * kTStride + 4 * (n & 3) + (n >> 2)] = d3;             // [output g][sample n]
     __builtin_amdgcn_wave_barrier();
+    {
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 a4 = (n & 3) == 0 && n < 12 ? *reinterpret_cast<const f32x4*>(Td + (n >> 2) * kTStride + 4 * g) : zero4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const float a = (n & 3) == 0 && n < 12 ? Td[(n >> 2) * kTStride + 4 * s + g] : 0.f;
+        for (int t = 0; t < kTiles; ++t) {
+            const f32x4 b4 = get_transposed4(Th, t, g, n);
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) A.w3[t] = mfma4(a, get_transposed(Th, t, s, g, n), A.w3[t]);
+            for (int s = 0; s < 4; ++s) A.w3[t] = mfma4(a4[s], b4[s], A.w3[t]);
+        }
     }
     // delta2 = (W3^T delta3) * act'(h2)
     f32x4 d2[kTiles], d1[kTiles];
+    {
+        const f32x4 a = quad(tab + T_B3, 0, lane);
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) {
-        d2[t] = mfma4(tab[T_B3 + t * 64 + lane], d3, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int t = 0; t < kTiles; ++t) {
+            d2[t] = mfma4(a[t], d3, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d2[t][r] *= act_grad_from_output<ACT>(h2[t][r]);
+            for (int r = 0; r < 4; ++r) d2[t][r] *= act_grad_from_output<ACT>(h2[t][r]);
+        }
     }
     // delta1 = (W2^T delta2) * act'(h1)
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) d1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tp = 0; tp < kTiles; ++tp)
+    for (int ks = 0; ks < 16; ++ks) {
+        const f32x4 a = quad(tab + T_B2, ks, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int t = 0; t < kTiles; ++t) d1[t] = mfma4(tab[T_B2 + (16 * t + 4 * tp + r) * 64 + lane], d2[tp][r], d1[t]);
+        for (int t = 0; t < kTiles; ++t) d1[t] = mfma4(a[t], d2[ks >> 2][ks & 3], d1[t]);
+    }
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
@@ -190,16 +211,17 @@ WL_DEV void backward_net(const float* tab, float* Td, float* Th, const f32x4 h1[
     put_transposed(Td, d2, g, n);
     put_transposed(Th, h1, g, n);
     __builtin_amdgcn_wave_barrier();
+    {
+        f32x4 hb[kTiles];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        float hb[kTiles];
-#pragma unroll
-        for (int u = 0; u < kTiles; ++u) hb[u] = get_transposed(Th, u, s, g, n);
+        for (int u = 0; u < kTiles; ++u) hb[u] = get_transposed4(Th, u, g, n);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) {
-            const float a = get_transposed(Td, t, s, g, n);
+            const f32x4 a4 = get_transposed4(Td, t, g, n);
 #pragma unroll
-            for (int u = 0; u < kTiles; ++u) A.w2[t][u] = mfma4(a, hb[u], A.w2[t][u]);
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int u = 0; u < kTiles; ++u) A.w2[t][u] = mfma4(a4[s], hb[u][s], A.w2[t][u]);
         }
     }
     // dW1 (+ db1 in column 14) += delta1^T . X
@@ -207,32 +229,70 @@ WL_DEV void backward_net(const float* tab, float* Td, float* Th, const f32x4 h1[
     put_transposed(Td, d1, g, n);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int t = 0; t < kTiles; ++t) {
+        const f32x4 a4 = get_transposed4(Td, t, g, n);
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) A.w1[t] = mfma4(get_transposed(Td, t, s, g, n), xb[s], A.w1[t]);
+        for (int s = 0; s < 4; ++s) A.w1[t] = mfma4(a4[s], xb[s], A.w1[t]);
+    }
     __builtin_amdgcn_wave_barrier();
 }
 
+// sum over the 16 sample-lanes (n = 0..15) of a lane group
+WL_DEV float sum_over_n(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// one wavefront adds its accumulators into the block's [G] buffer.  The caller serialises the four wavefronts (barriers
+// in between), so these are plain read-modify-writes to addresses no other lane touches: LDS float atomics from four
+// wavefronts at once made this epilogue ~40 us of the kernel.
 WL_DEV void flush_net(float* acc, const NetGrads& A, int lane, bool actor) {
     const int g = lane >> 4, n = lane & 15;
     const int o_w1 = actor ? O_AW1 : O_CW1, o_b1 = actor ? O_AB1 : O_CB1, o_w2 = actor ? O_AW2 : O_CW2,
               o_b2 = actor ? O_AB2 : O_CB2, o_w3 = actor ? O_AW3 : O_CW3;
+    // reads first, writes after, tile by tile: written as `acc[i] += v` every element is a dependent LDS round trip
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t)
+    for (int t = 0; t < kTiles; ++t) {
+        float o2[4][kTiles], o1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int uo = 16 * t + 4 * g + r;
 #pragma unroll
-            for (int u = 0; u < kTiles; ++u) atomicAdd(&acc[o_w2 + uo * kHid + 16 * u + n], A.w2[t][u][r]);
-            if (n < kIn) atomicAdd(&acc[o_w1 + uo * kIn + n], A.w1[t][r]);
-            else if (n == kIn) atomicAdd(&acc[o_b1 + uo], A.w1[t][r]);
-            atomicAdd(&acc[o_b2 + uo], A.b2[t][r]);
+            for (int u = 0; u < kTiles; ++u) o2[r][u] = acc[o_w2 + uo * kHid + 16 * u + n];
+            o1[r] = n < kIn ? acc[o_w1 + uo * kIn + n] : n == kIn ? acc[o_b1 + uo] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int uo = 16 * t + 4 * g + r;
+#pragma unroll
+            for (int u = 0; u < kTiles; ++u) acc[o_w2 + uo * kHid + 16 * u + n] = o2[r][u] + A.w2[t][u][r];
+            if (n < kIn) acc[o_w1 + uo * kIn + n] = o1[r] + A.w1[t][r];
+            else if (n == kIn) acc[o_b1 + uo] = o1[r] + A.w1[t][r];
+        }
+    }
+    float b2[kTiles][4], ob[kTiles][4];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            b2[t][r] = sum_over_n(A.b2[t][r]);
+            ob[t][r] = acc[o_b2 + 16 * t + 4 * g + r];
         }
     // joint output layer: accumulator row 4 g + r; rows 0 / 4 are the actor's outputs 0 / 1, row 8 the critic's
+    const bool mine = actor ? g < 2 : g == 2;
+    const int w3_row = actor ? g * kHid : 0;
+    float o3[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) o3[t] = mine ? acc[o_w3 + w3_row + 16 * t + n] : 0.f;
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) {
-        if (actor && g < 2) atomicAdd(&acc[o_w3 + g * kHid + 16 * t + n], A.w3[t][0]);
-        if (!actor && g == 2) atomicAdd(&acc[o_w3 + 16 * t + n], A.w3[t][0]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n == 0) acc[o_b2 + 16 * t + 4 * g + r] = ob[t][r] + b2[t][r];
+        if (mine) acc[o_w3 + w3_row + 16 * t + n] = o3[t] + A.w3[t][0];
     }
 }
 
@@ -241,15 +301,35 @@ struct PpoHyper {
     int use_clipped_value_loss;
 };
 
+// the nets in MFMA operand order, built once per minibatch step (each slot is a dependent gather from the weight tensors:
+// done by every block of the gradient kernel it cost more than the matrix work)
+__global__ void __launch_bounds__(256) ppo_operands_kernel(const PpoNets N, float* __restrict__ operands) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < kTabFloats) operands[i] = operand_value(N, i);
+}
+
 template <int ACT>
-__global__ void __launch_bounds__(256) ppo_grad_kernel(const PpoNets N, const WlPpoBatch bt, const int mb_start, const int mb_size,
-                                                       const PpoHyper hp, float* __restrict__ partials) {
+__global__ void __launch_bounds__(256) ppo_grad_kernel(const PpoNets N, const float* __restrict__ operands, const WlPpoBatch bt,
+                                                       const int mb_start, const int mb_size, const PpoHyper hp,
+                                                       float* __restrict__ partials) {
     extern __shared__ float lds[];
     float* tab = lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, n = lane & 15;
     float* Td = lds + kTabFloats + wave * 2 * kTBuf;
     float* Th = Td + kTBuf;
-    for (int i = threadIdx.x; i < kTabFloats; i += 256) tab[i] = operand_value(N, i);
+    {   // 87 KB of operands -> LDS, the loads issued in batches of eight (one by one they are 21 dependent round trips)
+        constexpr int kVec = kTabFloats / 4;
+        const f32x4* src = reinterpret_cast<const f32x4*>(operands);
+        f32x4* dst = reinterpret_cast<f32x4*>(tab);
+        for (int base = threadIdx.x; base < kVec; base += 8 * 256) {
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = base + k * 256 < kVec ? src[base + k * 256] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (base + k * 256 < kVec) dst[base + k * 256] = v[k];
+        }
+    }
     __syncthreads();
     const float one_g0 = g == 0 ? 1.f : 0.f;
     const float sig = N.std[g & 1], sig_other = N.std[(g & 1) ^ 1];
@@ -287,16 +367,17 @@ __global__ void __launch_bounds__(256) ppo_grad_kernel(const PpoNets N, const Wl
         f32x4 h1a[kTiles], h2a[kTiles], h1c[kTiles], h2c[kTiles];
         forward_hidden<ACT>(tab, xs, one_g0, lane, h1a, h2a);
         forward_hidden<ACT>(tab + kNetTab, xs, one_g0, lane, h1c, h2c);
-        f32x4 out = {0.f, 0.f, 0.f, 0.f};
+        f32x4 out = {0.f, 0.f, 0.f, 0.f}, out_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tp = 0; tp < kTiles; ++tp)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out = mfma4(tab[T_F3 + (4 * tp + r) * 64 + lane], h2a[tp][r], out);
-#pragma unroll
-        for (int tp = 0; tp < kTiles; ++tp)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out = mfma4(tab[T_F3 + (16 + 4 * tp + r) * 64 + lane], h2c[tp][r], out);
-        out = mfma4(tab[T_F3 + 32 * 64 + lane], one_g0, out);
+        for (int q = 0; q < 8; ++q) {                          // k-steps 4 q + j: actor units (q < 4), critic units (q >= 4)
+            const f32x4 a = quad(tab + T_F3, q, lane);
+            const f32x4 b = q < 4 ? h2a[q] : h2c[q - 4];
+            out = mfma4(a[0], b[0], out);
+            out_b = mfma4(a[1], b[1], out_b);
+            out = mfma4(a[2], b[2], out);
+            out_b = mfma4(a[3], b[3], out_b);
+        }
+        out = mfma4(quad(tab + T_F3, 8, lane)[0], one_g0, out) + out_b;
         const float y = out[0];                               // g = 0: mu_0, 1: mu_1, 2: value (3: nothing)
 
         // ---- losses and their derivatives w.r.t. the three outputs -----------------------------------------------------
@@ -344,38 +425,62 @@ __global__ void __launch_bounds__(256) ppo_grad_kernel(const PpoNets N, const Wl
     float* acc = lds;
     for (int i = threadIdx.x; i < kRow; i += 256) acc[i] = 0.f;
     __syncthreads();
-    flush_net(acc, GA, lane, true);
-    flush_net(acc, GC, lane, false);
-    if (g < 2) {
-        atomicAdd(&acc[O_STD + g], d_sigma);
-        atomicAdd(&acc[O_AB3 + g], d_b3);
-    } else if (g == 2) {
-        atomicAdd(&acc[O_CB3], d_b3);
-        atomicAdd(&acc[S_VLOSS], s_vloss);
+    d_sigma = sum_over_n(d_sigma);
+    d_b3 = sum_over_n(d_b3);
+    s_vloss = sum_over_n(s_vloss);
+    s_surr = sum_over_n(s_surr);
+    s_kl = sum_over_n(s_kl);
+    for (int w = 0; w < 4; ++w) {      // one wavefront at a time
+        if (wave == w) {
+            flush_net(acc, GA, lane, true);
+            flush_net(acc, GC, lane, false);
+            if (n == 0) {
+                if (g < 2) {
+                    acc[O_STD + g] += d_sigma;
+                    acc[O_AB3 + g] += d_b3;
+                } else if (g == 2) {
+                    acc[O_CB3] += d_b3;
+                    acc[S_VLOSS] += s_vloss;
+                }
+                if (g == 0) {
+                    acc[S_SURR] += s_surr;
+                    acc[S_KL] += s_kl;
+                }
+            }
+        }
+        __syncthreads();
     }
-    if (g == 0) {
-        atomicAdd(&acc[S_SURR], s_surr);
-        atomicAdd(&acc[S_KL], s_kl);
-    }
-    __syncthreads();
     for (int i = threadIdx.x; i < kRow; i += 256) partials[(int64_t)blockIdx.x * kRow + i] = acc[i];
 }
 
-// grad[i] = sum over blocks of partials[b][i]; norm2 += sum of squares of the parameter gradients (stats excluded)
+// grad[i] = sum over blocks of partials[b][i]; norm2 += sum of squares of the parameter gradients (stats excluded).
+// 64 columns per block, four row groups of threads: 64 independent coalesced loads per thread instead of one thread
+// walking all 256 rows (61 us -> a few).
 __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float* __restrict__ partials, int n_blocks, float* __restrict__ grad,
                                                          float* __restrict__ norm2) {
-    __shared__ float red[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    float s = 0.f;
-    if (i < kRow)
-        for (int b = 0; b < n_blocks; ++b) s += partials[(int64_t)b * kRow + i];
-    if (i < kRow) grad[i] = s;
-    float q = i < G ? s * s : 0.f;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < kRow) {
+        int b = rg;
+        for (; b + 12 < n_blocks; b += 16) {
+            s0 += partials[(int64_t)b * kRow + c];
+            s1 += partials[(int64_t)(b + 4) * kRow + c];
+            s2 += partials[(int64_t)(b + 8) * kRow + c];
+            s3 += partials[(int64_t)(b + 12) * kRow + c];
+        }
+        for (; b < n_blocks; b += 4) s0 += partials[(int64_t)b * kRow + c];
+    }
+    part[rg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(norm2, red[0] + red[1] + red[2] + red[3]);
+    if (rg == 0) {
+        const float s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (c < kRow) grad[c] = s;
+        float q = c < G ? s * s : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+        if (threadIdx.x == 0) atomicAdd(norm2, q);
+    }
 }
 
 WL_DEV float* param_ptr(const PpoNets& N, float* std, int i) {
@@ -467,7 +572,7 @@ int check_ppo(const WlMlp* actor, const WlMlp* critic, const float* std, const W
     if (!std || !bt || !bt->obs || !bt->actions || !bt->mu_old || !bt->logp_old || !bt->adv || !bt->returns || !bt->values_old ||
         !bt->perm || !bt->sigma_old || mb_start < 0 || mb_size <= 0)
         return WL_EINVAL;
-    if (!st || !st->partials || !st->grad || !st->ctrl) return WL_EINVAL;
+    if (!st || !st->partials || !st->grad || !st->ctrl || !st->operands || ((uintptr_t)st->operands & 15u)) return WL_EINVAL;
     return WL_OK;
 }
 
@@ -485,11 +590,12 @@ int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const
         attr_set = true;
     }
     clear_error();
+    ppo_operands_kernel<<<(kTabFloats + 255) / 256, 256, 0, stream>>>(N, st->operands);
     if (actor->activation == WL_ACT_ELU)
-        ppo_grad_kernel<WL_ACT_ELU><<<blocks, 256, lds_bytes, stream>>>(N, *bt, mb_start, mb_size, h, st->partials);
+        ppo_grad_kernel<WL_ACT_ELU><<<blocks, 256, lds_bytes, stream>>>(N, st->operands, *bt, mb_start, mb_size, h, st->partials);
     else
-        ppo_grad_kernel<WL_ACT_RELU><<<blocks, 256, lds_bytes, stream>>>(N, *bt, mb_start, mb_size, h, st->partials);
-    ppo_reduce_kernel<<<(kRow + 255) / 256, 256, 0, stream>>>(st->partials, blocks, st->grad, st->ctrl + WL_PPO_CTRL_NORM2 + parity);
+        ppo_grad_kernel<WL_ACT_RELU><<<blocks, 256, lds_bytes, stream>>>(N, st->operands, *bt, mb_start, mb_size, h, st->partials);
+    ppo_reduce_kernel<<<(kRow + 63) / 64, 256, 0, stream>>>(st->partials, blocks, st->grad, st->ctrl + WL_PPO_CTRL_NORM2 + parity);
     return launch_status();
 }
 

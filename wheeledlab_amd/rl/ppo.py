@@ -389,9 +389,10 @@ class FusedPpoStep:
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         self.partials, self.grad = z(A.PPO_BLOCKS, A.PPO_PARTIAL_STRIDE), z(A.PPO_PARTIAL_STRIDE)
         self.adam_m, self.adam_v, self.ctrl = z(A.PPO_NUM_PARAMS), z(A.PPO_NUM_PARAMS), z(16)
+        self.operands = z(A.PPO_OPERAND_FLOATS)
         self.ctrl[A.PPO_CTRL_LR:A.PPO_CTRL_LR + 2] = float(ppo.learning_rate)
         self.state = A.WlPpoState(self.partials.data_ptr(), self.grad.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
-                                  self.ctrl.data_ptr())
+                                  self.ctrl.data_ptr(), self.operands.data_ptr())
         adaptive = int(ppo.desired_kl is not None and ppo.schedule == "adaptive")
         self.hp = A.WlPpoParams(ppo.clip_param, ppo.value_loss_coef, ppo.entropy_coef, float(ppo.desired_kl or 0.0),
                                 ppo.max_grad_norm, 0.9, 0.999, 1e-8, 1e-5, 1e-2, int(ppo.use_clipped_value_loss), adaptive)
