@@ -172,7 +172,7 @@ def main():
     traffic, traffic_src = pmc_traffic(n)
 
     # secondary: the same K-step rollouts as ONE persistent launch each (state in registers across steps; only possible
-    # with pre-staged actions, so it is NOT the headline: a policy in the loop needs one launch per env.step())
+    # with pre-staged actions, so it is NOT the headline; the policy-in-the-loop form follows)
     persistent = None
     if rank == 0 and world == 1 and n <= 32768:
         env.rollout(actions, obs_buf, rew_buf, term_buf, trunc_buf, persistent=True)
@@ -226,6 +226,30 @@ def main():
                   "kernel": "drift_policy_rollout_kernel<ELU, FlatGround> + mlp_forward_kernel<ELU>",
                   "per_step_launch_torch_actor_us_per_step": tus,
                   "per_step_launch_torch_actor_env_steps_per_s": n / (tus * 1e-6)}
+
+    # secondary: whole training iterations (fused collection + GAE + 20 fused PPO minibatch steps), env-steps/s end to end
+    train = None
+    if rank == 0 and world == 1 and n <= 32768:
+        import wheeledlab_amd.tasks  # noqa: F401
+        from wheeledlab_amd import registry
+        from wheeledlab_amd.rl import ClipAction, RslRlVecEnvWrapper
+        from wheeledlab_amd.rl.ppo import OnPolicyRunner
+        tcfg = registry.parse_env_cfg("Isaac-MushrDriftRL-v0", device=str(dev), num_envs=n)
+        te = registry.make("Isaac-MushrDriftRL-v0", cfg=tcfg)
+        te.action_space.low, te.action_space.high = -1.0, 1.0
+        runner = OnPolicyRunner(RslRlVecEnvWrapper(ClipAction(te)),
+                                registry.load_cfg_from_registry("Isaac-MushrDriftRL-v0", "rsl_rl_cfg_entry_point"), device=str(dev))
+        runner.learn(3, verbose=False)
+        torch.cuda.synchronize()
+        tt = time.perf_counter()
+        hist = runner.learn(12, verbose=False)
+        torch.cuda.synchronize()
+        tt = time.perf_counter() - tt
+        train = {"env_steps_per_s": 12 * runner.num_steps_per_env * n / tt, "ms_per_iteration": tt / 12 * 1e3,
+                 "collection_ms": 1e3 * sum(h["collection_time"] for h in hist[-12:]) / 12,
+                 "learn_ms": 1e3 * sum(h["learn_time"] for h in hist[-12:]) / 12, "fused_collection": runner.fused,
+                 "fused_learner": runner.alg.fused_update, "steps_per_env": runner.num_steps_per_env}
+        del runner, te
 
     # secondary: the other two tasks at the same env count (configs[2] and [4] of BASELINE.json), per-step launches
     other = {}
@@ -318,6 +342,7 @@ def main():
         line["python_surface_env_steps_per_s"] = py_rate
         line["persistent_rollout"] = persistent
         line["policy_rollout"] = policy
+        line["training_iteration"] = train
         line["other_tasks"] = other
         if sweep:
             line["large_n_sweep"] = sweep
