@@ -110,3 +110,44 @@ def test_policy_structs_match_header_and_misuse_is_refused(tmp_path):
     assert lib.wl_drift_rollout_policy(C.byref(p), C.byref(bufs), C.byref(good), base, None, 4, 0, 0, None) == -1
     io_misaligned = A.WlPolicyRollout(base + 4, base, base, base, base, base, base, None)
     assert lib.wl_drift_rollout_policy(C.byref(p), C.byref(bufs), C.byref(good), base, C.byref(io_misaligned), 4, 0, 0, None) == -3
+
+
+def test_ppo_structs_match_header_and_misuse_is_refused(tmp_path):
+    probe = tmp_path / "probe4.c"
+    probe.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "wheeledlab_amd.h"\n'
+        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %d %d %d %d %d %d %d\\n\", sizeof(WlPpoBatch), sizeof(WlPpoParams),"
+        " sizeof(WlPpoState), offsetof(WlPpoBatch, sigma_old), offsetof(WlPpoParams, use_clipped_value_loss),"
+        " offsetof(WlPpoState, operands), (int)WL_PPO_NUM_PARAMS, (int)WL_PPO_PARTIAL_STRIDE, (int)WL_PPO_BLOCKS,"
+        " (int)WL_PPO_OPERAND_FLOATS, (int)WL_PPO_CTRL_LR, (int)WL_PPO_CTRL_NORM2, (int)WL_PPO_CTRL_STATS);return 0;}\n")
+    exe = tmp_path / "probe4"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == [C.sizeof(A.WlPpoBatch), C.sizeof(A.WlPpoParams), C.sizeof(A.WlPpoState), A.WlPpoBatch.sigma_old.offset,
+                   A.WlPpoParams.use_clipped_value_loss.offset, A.WlPpoState.operands.offset, A.PPO_NUM_PARAMS,
+                   A.PPO_PARTIAL_STRIDE, A.PPO_BLOCKS, A.PPO_OPERAND_FLOATS, A.PPO_CTRL_LR, A.PPO_CTRL_NORM2, A.PPO_CTRL_STATS]
+    # the flat parameter count is the ActorCritic's
+    from wheeledlab_amd.rl.ppo import ActorCritic
+    assert sum(p.numel() for p in ActorCritic(14, 14, 2).parameters()) == A.PPO_NUM_PARAMS
+    assert [n for n, _ in ActorCritic(14, 14, 2).named_parameters()][:3] == ["std", "actor.0.weight", "actor.0.bias"]
+    import __graft_entry__ as g
+    g.build()
+    lib = A.load()
+    buf = (C.c_float * 4096)()
+    base = C.addressof(buf)
+    ok = dict(w1=base, b1=base, w2=base, b2=base, w3=base, b3=base)
+    actor = A.WlMlp(in_dim=14, out_dim=2, hidden=64, activation=A.ACT_ELU, **ok)
+    critic = A.WlMlp(in_dim=14, out_dim=1, hidden=64, activation=A.ACT_ELU, **ok)
+    bt = A.WlPpoBatch(*([base] * 9))
+    hp = A.WlPpoParams()
+    st = A.WlPpoState(base, base, base, base, base, base)
+    args = lambda a, c, b, s, par=0: (C.byref(a), C.byref(c), base, C.byref(b), 0, 16, C.byref(hp), C.byref(s), par)
+    assert lib.wl_ppo_gradients(*args(critic, critic, bt, st), None) == -1            # actor must have 2 outputs
+    relu_critic = A.WlMlp(in_dim=14, out_dim=1, hidden=64, activation=A.ACT_RELU, **ok)
+    assert lib.wl_ppo_gradients(*args(actor, relu_critic, bt, st), None) == -1       # one activation for both nets
+    assert lib.wl_ppo_gradients(*args(actor, critic, A.WlPpoBatch(), st), None) == -1
+    assert lib.wl_ppo_gradients(*args(actor, critic, bt, A.WlPpoState(base, base, base, base, base, None)), None) == -1
+    assert lib.wl_ppo_gradients(*args(actor, critic, bt, st, par=2), None) == -1
+    assert lib.wl_ppo_minibatch(*args(actor, critic, bt, st), 0, None) == -1          # adam_step counts from 1
+    assert lib.wl_gae(0, 16, base, base, base, 0.99, 0.95, base, base, None) == -1
+    assert lib.wl_gae(4, 16, base, base, None, 0.99, 0.95, base, base, None) == -1
