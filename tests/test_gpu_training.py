@@ -114,3 +114,37 @@ def test_gpu_ppo_update_equals_the_cpu_update():
     for a_, b_ in zip(ac_c.parameters(), ac_g.parameters()):
         assert torch.allclose(a_, b_.cpu(), rtol=2e-3, atol=2e-4), float((a_ - b_.cpu()).abs().max())
     assert abs(pc.learning_rate - pg.learning_rate) < 1e-7
+
+
+def test_checkpoint_resume_and_stepwise_collection(tmp_path):
+    """save -> load into a fresh runner -> the next iteration is the same as without the round trip (fused learner state
+    travels through rsl_rl's optimizer format); the step-wise collector (torch actor, one launch per env.step) feeds
+    the same learner"""
+    import wheeledlab_amd.tasks  # noqa: F401
+    from wheeledlab_amd import registry
+    from wheeledlab_amd.rl.ppo import OnPolicyRunner
+    cfg = registry.load_cfg_from_registry("Isaac-MushrDriftRL-v0", "rsl_rl_cfg_entry_point")
+    torch.manual_seed(1)
+    a = OnPolicyRunner(_make(512, seed=5), cfg, log_dir=str(tmp_path), device=DEV)
+    a.learn(3, verbose=False)
+    path = str(tmp_path / "models" / "model_2.pt")
+    ck = torch.load(path, weights_only=False)
+    assert ck["iter"] == 3 and len(ck["optimizer_state_dict"]["state"]) == 13      # std + 6 actor + 6 critic tensors
+    b = OnPolicyRunner(_make(512, seed=5), cfg, device=DEV)
+    b.load(path)
+    assert b.current_learning_iteration == 3 and abs(b.alg.learning_rate - a.alg.learning_rate) < 1e-9
+    for p, q in zip(a.actor_critic.parameters(), b.actor_critic.parameters()):
+        assert torch.equal(p, q)
+    st_a = a.alg.optimizer_state_dict()["state"]
+    b.alg.update(_filled_storage(b))                                                # creates the fused step from the loaded state
+    st_b = b.alg.optimizer_state_dict()["state"]
+    assert float(st_b[0]["step"]) == float(st_a[0]["step"]) + 20                    # 5 epochs x 4 minibatches more
+    c = OnPolicyRunner(_make(256, seed=6), cfg, device=DEV, fused=False)
+    assert not c.fused and c.alg.fused_update
+    hist = c.learn(2, verbose=False)
+    assert len(hist) == 2 and np.isfinite(hist[-1]["value_function"])
+
+
+def _filled_storage(runner):
+    runner.env.unwrapped.rollout_policy(runner.actor_critic.fused(), runner.storage)
+    return runner.storage
