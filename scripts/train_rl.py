@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""Train a registered task with PPO on one MI355X -- the counterpart of the reference's
-source/wheeledlab_rl/scripts/train_rl.py (env creation :70-93, runner :95, checkpoints :96-106, learn :114).
+"""Train a registered run config with PPO on one MI355X -- the counterpart of the reference's
+source/wheeledlab_rl/scripts/train_rl.py (run config :8,:34, env creation :70-93, runner :95, checkpoints :96-106,
+learn :114), with the same command line:
 
-    python scripts/train_rl.py --task Isaac-MushrDriftRL-v0 --num_envs 4096 --max_iterations 100 --log_dir logs/drift
+    python scripts/train_rl.py -r RSS_DRIFT_CONFIG env_setup.num_envs=4096 train.num_iterations=150 \\
+        env.rewards.side_slip.weight=20 agent.algorithm.learning_rate=3e-4 train.log.run_name=drift-a
 
-For the drift task the rollout of every iteration is one fused launch (actor MLP on the matrix pipe + env.step, see
-wheeledlab_amd/csrc/wl_policy.hip); `--stepwise` forces the generic one-launch-per-env.step() path (the only path for
-the elevation / visual tasks, whose observations are 689 / 3208 wide)."""
+`-r` names a run config (wheeledlab_amd/configs/runs: RSS_DRIFT_CONFIG, RSS_ELEV_CONFIG, RSS_VISUAL_CONFIG,
+F1TENTH_DRIFT_CONFIG); the remaining arguments are Hydra-style `key=value` overrides of `env_setup`, `train`, `env`
+(the task's env cfg) and `agent` (its rsl_rl cfg).  For the drift tasks the rollout of every iteration is one fused launch
+(actor MLP on the matrix pipe + env.step, csrc/wl_policy.hip) and the PPO update runs in csrc/wl_ppo.hip;
+`--stepwise` forces the generic one-launch-per-env.step() collector (the only one for the elevation / visual tasks,
+whose observations are 689 / 3208 wide)."""
 import argparse
 import json
 import os
@@ -17,47 +22,51 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--task", default="Isaac-MushrDriftRL-v0")
-    ap.add_argument("--num_envs", type=int, default=4096)
-    ap.add_argument("--max_iterations", type=int, default=100)
-    ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--device", default="cuda:0")
-    ap.add_argument("--log_dir", default=None)
-    ap.add_argument("--load_run", default=None, help="checkpoint (model_*.pt) to resume from")
-    ap.add_argument("--set_env_step", type=int, default=0, help="common_step_counter to continue curriculums from")
+    ap = argparse.ArgumentParser(description="Train an RL agent on the MI355X-native WheeledLab envs.")
+    ap.add_argument("-r", "--run-config-name", default="RSS_DRIFT_CONFIG")
     ap.add_argument("--stepwise", action="store_true", help="one launch per env.step() with a torch actor")
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("overrides", nargs="*", help="Hydra-style key=value overrides")
     args = ap.parse_args()
 
     import torch
+    import yaml
 
-    import wheeledlab_amd.tasks  # noqa: F401  (registers the task ids)
     from wheeledlab_amd import registry
+    from wheeledlab_amd.configs.runs import resolve_run
     from wheeledlab_amd.rl import ClipAction, RslRlVecEnvWrapper
     from wheeledlab_amd.rl.ppo import OnPolicyRunner
 
-    torch.manual_seed(args.seed)
-    env_cfg = registry.parse_env_cfg(args.task, device=args.device, num_envs=args.num_envs)
-    env_cfg.seed = args.seed
-    agent_cfg = registry.load_cfg_from_registry(args.task, "rsl_rl_cfg_entry_point")
-    env = registry.make(args.task, cfg=env_cfg)
+    run_cfg = resolve_run(args.run_config_name, args.overrides)
+    env_cfg, agent_cfg, train_cfg, log_cfg, env_setup = run_cfg.env, run_cfg.agent, run_cfg.train, run_cfg.train.log, run_cfg.env_setup
+    log_dir = None if log_cfg.no_log else log_cfg.run_log_dir
+    if log_dir:
+        os.makedirs(log_cfg.model_save_path, exist_ok=True)
+        with open(os.path.join(log_dir, "run_config.yaml"), "w") as f:     # train_rl.py:62-64
+            yaml.safe_dump(json.loads(json.dumps(run_cfg.to_dict(), default=str)), f)
+
+    torch.manual_seed(train_cfg.seed)
+    env = registry.make(env_setup.task_name, cfg=env_cfg)
     env.action_space.low, env.action_space.high = -1.0, 1.0
     env = RslRlVecEnvWrapper(ClipAction(env))
-    runner = OnPolicyRunner(env, agent_cfg, log_dir=args.log_dir, device=args.device, fused=False if args.stepwise else None)
-    if args.load_run:
-        runner.load(args.load_run)
-    env.seed(args.seed)
-    env.unwrapped.common_step_counter = args.set_env_step
-    hist = runner.learn(args.max_iterations, verbose=not args.quiet)
-    if args.log_dir:
-        with open(os.path.join(args.log_dir, "history.json"), "w") as f:
+    if not log_cfg.no_checkpoints:
+        agent_cfg.save_interval = min(agent_cfg.save_interval, log_cfg.checkpoint_every)
+    runner = OnPolicyRunner(env, agent_cfg, log_dir=None if log_cfg.no_checkpoints else log_dir, device=train_cfg.device,
+                            fused=False if args.stepwise else None)
+    if train_cfg.load_run is not None:
+        runner.load(train_cfg.load_run)
+    env.seed(agent_cfg.seed)
+    env.unwrapped.common_step_counter = train_cfg.set_env_step       # for continuing curriculums (train_rl.py:113)
+    hist = runner.learn(train_cfg.num_iterations, verbose=not args.quiet)
+    if log_dir:
+        with open(os.path.join(log_dir, "history.json"), "w") as f:
             json.dump(hist, f)
     first, last = hist[0], hist[-1]
-    print(json.dumps({"task": args.task, "fused_collection": runner.fused, "iterations": len(hist),
+    print(json.dumps({"run_config": args.run_config_name, "task": env_setup.task_name, "num_envs": env_setup.num_envs,
+                      "fused_collection": runner.fused, "fused_learner": runner.alg.fused_update, "iterations": len(hist),
                       "mean_step_reward_first": first["mean_step_reward"], "mean_step_reward_last": last["mean_step_reward"],
                       "mean_reward_last": last["mean_reward"], "mean_episode_length_last": last["mean_episode_length"],
-                      "fps_last": last["fps"], "collection_fps_last": last["collection_fps"]}))
+                      "fps_last": last["fps"], "collection_fps_last": last["collection_fps"], "log_dir": log_dir}))
     env.close()
 
 
