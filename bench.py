@@ -94,7 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sweep", action="store_true", help="also print a large-N sweep (extra JSON lines on stderr)")
+    ap.add_argument("--sweep", action="store_true", help="(default at N=1) large-N sweep of the same kernel: the HBM-bound regime")
+    ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -297,8 +298,10 @@ def main():
         py_rate = n * 2048 / (time.perf_counter() - t1)
         del w, e
 
+    # secondary: the SAME fused step at env counts where it is bandwidth- rather than launch-bound (SURVEY 8(d) config 2:
+    # "also sweep N ... to expose the bandwidth-bound regime"); these launches also write the int64 `dones` row (+8 B)
     sweep = []
-    if args.sweep and rank == 0:
+    if rank == 0 and world == 1 and not args.no_sweep:
         for big in (65536, 1048576, 4194304):
             e2 = DriftBatch(big, device=dev, seed=42)
             e2.reset()
@@ -313,8 +316,9 @@ def main():
             s1.record()
             torch.cuda.synchronize()
             us = s0.elapsed_time(s1) * 1e3 / 48
+            gbs = (BYTES_PER_ENV_STEP + 8) * big / (us * 1e-6) / 1e9
             sweep.append({"n_envs": big, "us_per_step": round(us, 2), "env_steps_per_s": big / (us * 1e-6),
-                          "achieved_GBs": BYTES_PER_ENV_STEP * big / (us * 1e-6) / 1e9})
+                          "achieved_GBs": gbs, "frac_of_8TBs": gbs / 8000.0, "bytes_per_env_step": BYTES_PER_ENV_STEP + 8})
             del e2, a2
 
     if rank == 0:
