@@ -14,10 +14,10 @@
 //     both MFMA operands want their k index in l >> 4: delta and H are transposed through a per-wavefront LDS buffer
 //     ([unit][sample], 16 ds_write + 16 ds_read per lane and matrix) and then feed A and B with the same read pattern;
 //     dW1 takes the observation rows straight from memory in B layout, its padded feature 14 (= 1) yields db1 for free;
-//   * every weight operand is read from LDS, where the block has laid the nets out in MFMA operand order once
-//     (86 KB: forward L1 / L2, backward W2^T / W3^T per net, the joint output layer); gradient accumulators (228 VGPRs)
-//     stay in registers across all tiles of the wavefront and leave through an LDS reduction over the block's four
-//     wavefronts as one [G] partial per block.
+//   * every weight operand is read from LDS (86 KB of operand-ordered quads: forward L1 / L2, backward W2^T / W3^T per net,
+//     the joint output layer), copied in by the block from a table the step builds once;
+//   * a block is four actor + four critic wavefronts working pairwise on the same tiles: 114 gradient accumulators per
+//     wavefront stay in registers across all its tiles and leave through a batched LDS reduction as one [G] partial per block.
 #include <hip/hip_runtime.h>
 
 #include "../../include/wheeledlab_amd.h"
@@ -47,7 +47,8 @@ constexpr int T_F1 = 0, T_F2 = T_F1 + 4 * 256, T_B2 = T_F2 + 17 * 256, T_B3 = T_
 constexpr int T_F3 = 2 * kNetTab, kTabFloats = T_F3 + 9 * 256;
 static_assert(kTabFloats == WL_PPO_OPERAND_FLOATS, "header constant");
 constexpr int kTStride = 20, kTBuf = kHid * kTStride;          // transposition buffer [unit][sample], padded rows
-constexpr int kLdsFloats = kTabFloats + 4 * 2 * kTBuf;          // + two buffers per wavefront
+constexpr int kPpoWaves = 8;                                   // per block: four actor wavefronts + four critic wavefronts
+constexpr int kLdsFloats = kTabFloats + kPpoWaves * kTBuf;     // + one buffer per wavefront
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
 static_assert(kTabFloats >= kRow, "the operand tables are reused as the block's gradient accumulator");
 
@@ -160,24 +161,28 @@ struct NetGrads {
     }
 };
 
-// backward of one net from delta3 (B operand of the joint layer) + weight-gradient accumulation for this tile
+// backward of one net from delta3 (B operand of the joint layer) + weight-gradient accumulation for this tile.  One LDS
+// buffer per wavefront: a matrix is written, the operands it feeds are read into registers, then the next one is written.
 template <int ACT>
-WL_DEV void backward_net(const float* tab, float* Td, float* Th, const f32x4 h1[kTiles], const f32x4 h2[kTiles], float d3,
+WL_DEV void backward_net(const float* tab, float* T, const f32x4 h1[kTiles], const f32x4 h2[kTiles], float d3,
                          const float xb[4] /* obs rows in B layout: sample 4 s + g, feature n */, int lane, NetGrads& A) {
     const int g = lane >> 4, n = lane & 15;
-    // dW3 += delta3^T . H2 : A operand = delta3 of row i's output at sample 4 s + g (rows 0 / 4 / 8), via Td
-    put_transposed(Th, h2, g, n);
-    Td[g * kTStride + 4 * (n & 3) + (n >> 2)] = d3;             // [output g][sample n]
-    __builtin_amdgcn_wave_barrier();
+    // dW3 += delta3^T . H2 : A operand = delta3 of row i's output at sample 4 s + g (rows 0 / 4 / 8)
     {
+        put_transposed(T, h2, g, n);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 b4[kTiles];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) b4[t] = get_transposed4(T, t, g, n);
+        __builtin_amdgcn_wave_barrier();
+        T[g * kTStride + 4 * (n & 3) + (n >> 2)] = d3;          // [output g][sample n], over rows 0..3 (already consumed)
+        __builtin_amdgcn_wave_barrier();
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 a4 = (n & 3) == 0 && n < 12 ? *reinterpret_cast<const f32x4*>(Td + (n >> 2) * kTStride + 4 * g) : zero4;
+        const f32x4 a4 = (n & 3) == 0 && n < 12 ? *reinterpret_cast<const f32x4*>(T + (n >> 2) * kTStride + 4 * g) : zero4;
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) {
-            const f32x4 b4 = get_transposed4(Th, t, g, n);
+        for (int t = 0; t < kTiles; ++t)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) A.w3[t] = mfma4(a4[s], b4[s], A.w3[t]);
-        }
+            for (int s = 0; s < 4; ++s) A.w3[t] = mfma4(a4[s], b4[t][s], A.w3[t]);
     }
     // delta2 = (W3^T delta3) * act'(h2)
     f32x4 d2[kTiles], d1[kTiles];
@@ -207,17 +212,19 @@ WL_DEV void backward_net(const float* tab, float* Td, float* Th, const f32x4 h1[
             A.b2[t][r] += d2[t][r];
         }
     // dW2 += delta2^T . H1
-    __builtin_amdgcn_wave_barrier();
-    put_transposed(Td, d2, g, n);
-    put_transposed(Th, h1, g, n);
-    __builtin_amdgcn_wave_barrier();
     {
+        __builtin_amdgcn_wave_barrier();
+        put_transposed(T, h1, g, n);
+        __builtin_amdgcn_wave_barrier();
         f32x4 hb[kTiles];
 #pragma unroll
-        for (int u = 0; u < kTiles; ++u) hb[u] = get_transposed4(Th, u, g, n);
+        for (int u = 0; u < kTiles; ++u) hb[u] = get_transposed4(T, u, g, n);
+        __builtin_amdgcn_wave_barrier();
+        put_transposed(T, d2, g, n);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) {
-            const f32x4 a4 = get_transposed4(Td, t, g, n);
+            const f32x4 a4 = get_transposed4(T, t, g, n);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -226,11 +233,11 @@ WL_DEV void backward_net(const float* tab, float* Td, float* Th, const f32x4 h1[
     }
     // dW1 (+ db1 in column 14) += delta1^T . X
     __builtin_amdgcn_wave_barrier();
-    put_transposed(Td, d1, g, n);
+    put_transposed(T, d1, g, n);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) {
-        const f32x4 a4 = get_transposed4(Td, t, g, n);
+        const f32x4 a4 = get_transposed4(T, t, g, n);
 #pragma unroll
         for (int s = 0; s < 4; ++s) A.w1[t] = mfma4(a4[s], xb[s], A.w1[t]);
     }
@@ -308,41 +315,46 @@ __global__ void __launch_bounds__(256) ppo_operands_kernel(const PpoNets N, floa
     if (i < kTabFloats) operands[i] = operand_value(N, i);
 }
 
+// Eight wavefronts per block: wavefronts 0..3 differentiate the ACTOR, 4..7 the CRITIC, pairwise on the same tiles (the
+// surrogate / KL / std terms need only the actor's outputs, the value loss only the critic's, so the two never talk).
+// Each half needs ~250 registers, which puts one actor and one critic wavefront on every SIMD: while one is in its
+// activation / transpose (VALU, LDS) phases the other keeps the matrix pipe busy.
 template <int ACT>
-__global__ void __launch_bounds__(256) ppo_grad_kernel(const PpoNets N, const float* __restrict__ operands, const WlPpoBatch bt,
-                                                       const int mb_start, const int mb_size, const PpoHyper hp,
-                                                       float* __restrict__ partials) {
+__global__ void __launch_bounds__(64 * kPpoWaves) ppo_grad_kernel(const PpoNets N, const float* __restrict__ operands,
+                                                                  const WlPpoBatch bt, const int mb_start, const int mb_size,
+                                                                  const PpoHyper hp, float* __restrict__ partials) {
+    constexpr int kThreads = 64 * kPpoWaves;
     extern __shared__ float lds[];
     float* tab = lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, n = lane & 15;
-    float* Td = lds + kTabFloats + wave * 2 * kTBuf;
-    float* Th = Td + kTBuf;
-    {   // 87 KB of operands -> LDS, the loads issued in batches of eight (one by one they are 21 dependent round trips)
+    const bool actor_wave = wave < 4;
+    float* T = lds + kTabFloats + wave * kTBuf;
+    {   // 87 KB of operands -> LDS, the loads issued in batches (one by one they are dependent round trips)
         constexpr int kVec = kTabFloats / 4;
         const f32x4* src = reinterpret_cast<const f32x4*>(operands);
         f32x4* dst = reinterpret_cast<f32x4*>(tab);
-        for (int base = threadIdx.x; base < kVec; base += 8 * 256) {
-            f32x4 v[8];
+        for (int base = threadIdx.x; base < kVec; base += 4 * kThreads) {
+            f32x4 v[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = base + k * 256 < kVec ? src[base + k * 256] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < 4; ++k) v[k] = base + k * kThreads < kVec ? src[base + k * kThreads] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (base + k * 256 < kVec) dst[base + k * 256] = v[k];
+            for (int k = 0; k < 4; ++k)
+                if (base + k * kThreads < kVec) dst[base + k * kThreads] = v[k];
         }
     }
     __syncthreads();
+    const float* net_tab = tab + (actor_wave ? 0 : kNetTab);
     const float one_g0 = g == 0 ? 1.f : 0.f;
     const float sig = N.std[g & 1], sig_other = N.std[(g & 1) ^ 1];
     const float inv_sig = 1.f / sig, log_sig_sum = logf(sig) + logf(sig_other);
 
-    NetGrads GA, GC;
-    GA.zero();
-    GC.zero();
+    NetGrads GN;
+    GN.zero();
     float d_sigma = 0.f, d_b3 = 0.f, s_vloss = 0.f, s_surr = 0.f, s_kl = 0.f;
 
     const int n_tiles = (mb_size + 15) >> 4;
-    const int n_waves = gridDim.x * 4;
-    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += n_waves) {
+    const int n_pairs = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + (wave & 3); tile < n_tiles; tile += n_pairs) {
         const int k_n = tile * 16 + n;                       // position in the minibatch of "my" sample (column n)
         const bool valid = k_n < mb_size;
         const int smp = bt.perm[mb_start + (valid ? k_n : 0)];
@@ -361,96 +373,94 @@ __global__ void __launch_bounds__(256) ppo_grad_kernel(const PpoNets N, const fl
             const int smp_s = bt.perm[mb_start + (k_s < mb_size ? k_s : 0)];
             xb[s] = (k_s >= mb_size) ? 0.f : n == kIn ? 1.f : n < kIn ? bt.obs[(int64_t)smp_s * kIn + n] : 0.f;
         }
-        const float adv = bt.adv[smp], ret = bt.returns[smp], v_old = bt.values_old[smp], logp_old = bt.logp_old[smp];
-        const float act_g = bt.actions[smp * 2 + (g & 1)], mu_old_g = bt.mu_old[smp * 2 + (g & 1)];
 
-        f32x4 h1a[kTiles], h2a[kTiles], h1c[kTiles], h2c[kTiles];
-        forward_hidden<ACT>(tab, xs, one_g0, lane, h1a, h2a);
-        forward_hidden<ACT>(tab + kNetTab, xs, one_g0, lane, h1c, h2c);
+        f32x4 h1[kTiles], h2[kTiles];
+        forward_hidden<ACT>(net_tab, xs, one_g0, lane, h1, h2);
+        // this net's rows of the joint output layer: k-steps 0..15 (actor units) or 16..31 (critic units), then the biases
         f32x4 out = {0.f, 0.f, 0.f, 0.f}, out_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {                          // k-steps 4 q + j: actor units (q < 4), critic units (q >= 4)
-            const f32x4 a = quad(tab + T_F3, q, lane);
-            const f32x4 b = q < 4 ? h2a[q] : h2c[q - 4];
-            out = mfma4(a[0], b[0], out);
-            out_b = mfma4(a[1], b[1], out_b);
-            out = mfma4(a[2], b[2], out);
-            out_b = mfma4(a[3], b[3], out_b);
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = quad(tab + T_F3, actor_wave ? q : q + 4, lane);
+            out = mfma4(a[0], h2[q][0], out);
+            out_b = mfma4(a[1], h2[q][1], out_b);
+            out = mfma4(a[2], h2[q][2], out);
+            out_b = mfma4(a[3], h2[q][3], out_b);
         }
         out = mfma4(quad(tab + T_F3, 8, lane)[0], one_g0, out) + out_b;
-        const float y = out[0];                               // g = 0: mu_0, 1: mu_1, 2: value (3: nothing)
+        const float y = out[0];                               // g = 0: mu_0, 1: mu_1 (actor waves); g = 2: value (critic waves)
 
-        // ---- losses and their derivatives w.r.t. the three outputs -----------------------------------------------------
-        const float z = (act_g - y) * inv_sig;                // meaningful on g < 2
-        const float zz_other = lane_xor16(z * z, lane);
-        const float logp = -0.5f * (z * z + zz_other) - log_sig_sum - 1.8378770664093453f;
-        const float ratio = __expf(logp - logp_old);
-        const float s1 = -adv * ratio, s2 = -adv * fminf(fmaxf(ratio, 1.f - hp.clip), 1.f + hp.clip);
-        const float dl_dlogp = (s1 >= s2 ? -adv : 0.f) * ratio * hp.inv_batch;
-        // value loss on g == 2
-        const float e1 = y - ret, dvo = y - v_old;
-        const float e2 = v_old + fminf(fmaxf(dvo, -hp.clip), hp.clip) - ret;
-        const float l1 = e1 * e1, l2 = e2 * e2;
-        float vloss = l1, dvl = 2.f * e1;
-        if (hp.use_clipped_value_loss && l2 > l1) {
-            vloss = l2;
-            dvl = fabsf(dvo) <= hp.clip ? 2.f * e2 : 0.f;
-        }
         float d3 = 0.f;
-        if (valid) {
-            if (g < 2) {
-                d3 = dl_dlogp * z * inv_sig;
-                d_sigma += dl_dlogp * (z * z - 1.f) * inv_sig;
-                if (g == 0) s_surr += fmaxf(s1, s2);
-            } else if (g == 2) {
-                d3 = hp.value_loss_coef * dvl * hp.inv_batch;
-                s_vloss += vloss;
-            }
-            d_b3 += d3;
-        }
-        // KL term: sum over the two action dims of log(sigma / sigma_old + 1e-5) + (sigma_old^2 + (mu_old - mu)^2) / (2 sigma^2) - 1/2
-        {
+        if (actor_wave) {   // ---- clipped surrogate, KL statistic, std gradient ------------------------------------------
+            const float adv = bt.adv[smp], logp_old = bt.logp_old[smp];
+            const float act_g = bt.actions[smp * 2 + (g & 1)], mu_old_g = bt.mu_old[smp * 2 + (g & 1)];
+            const float z = (act_g - y) * inv_sig;            // meaningful on g < 2
+            const float zz_other = lane_xor16(z * z, lane);
+            const float logp = -0.5f * (z * z + zz_other) - log_sig_sum - 1.8378770664093453f;
+            const float ratio = __expf(logp - logp_old);
+            const float s1 = -adv * ratio, s2 = -adv * fminf(fmaxf(ratio, 1.f - hp.clip), 1.f + hp.clip);
+            const float dl_dlogp = (s1 >= s2 ? -adv : 0.f) * ratio * hp.inv_batch;
+            // KL(old || new) per action dim: log(sigma / sigma_old + 1e-5) + (sigma_old^2 + (mu_old - mu)^2) / (2 sigma^2) - 1/2
             const float so = bt.sigma_old[g & 1];
             const float kl_g = logf(sig / so + 1e-5f) + (so * so + (mu_old_g - y) * (mu_old_g - y)) * (0.5f * inv_sig * inv_sig) - 0.5f;
             const float kl_o = lane_xor16(kl_g, lane);
-            if (valid && g == 0) s_kl += kl_g + kl_o;
+            if (valid && g < 2) {
+                d3 = dl_dlogp * z * inv_sig;
+                d_sigma += dl_dlogp * (z * z - 1.f) * inv_sig;
+                d_b3 += d3;
+                if (g == 0) {
+                    s_surr += fmaxf(s1, s2);
+                    s_kl += kl_g + kl_o;
+                }
+            }
+        } else {            // ---- (clipped) value loss on lane group 2 -----------------------------------------------------
+            const float ret = bt.returns[smp], v_old = bt.values_old[smp];
+            const float e1 = y - ret, dvo = y - v_old;
+            const float e2 = v_old + fminf(fmaxf(dvo, -hp.clip), hp.clip) - ret;
+            const float l1 = e1 * e1, l2 = e2 * e2;
+            float vloss = l1, dvl = 2.f * e1;
+            if (hp.use_clipped_value_loss && l2 > l1) {
+                vloss = l2;
+                dvl = fabsf(dvo) <= hp.clip ? 2.f * e2 : 0.f;
+            }
+            if (valid && g == 2) {
+                d3 = hp.value_loss_coef * dvl * hp.inv_batch;
+                d_b3 += d3;
+                s_vloss += vloss;
+            }
         }
-
-        backward_net<ACT>(tab, Td, Th, h1a, h2a, g < 2 ? d3 : 0.f, xb, lane, GA);
-        backward_net<ACT>(tab + kNetTab, Td, Th, h1c, h2c, g == 2 ? d3 : 0.f, xb, lane, GC);
+        backward_net<ACT>(net_tab, T, h1, h2, d3, xb, lane, GN);
     }
 
     // ---- block reduction: the operand tables become the [G + stats] accumulator ------------------------------------------
     __syncthreads();
     float* acc = lds;
-    for (int i = threadIdx.x; i < kRow; i += 256) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < kRow; i += kThreads) acc[i] = 0.f;
     __syncthreads();
     d_sigma = sum_over_n(d_sigma);
     d_b3 = sum_over_n(d_b3);
     s_vloss = sum_over_n(s_vloss);
     s_surr = sum_over_n(s_surr);
     s_kl = sum_over_n(s_kl);
-    for (int w = 0; w < 4; ++w) {      // one wavefront at a time
-        if (wave == w) {
-            flush_net(acc, GA, lane, true);
-            flush_net(acc, GC, lane, false);
+    for (int w = 0; w < 4; ++w) {      // one actor and one critic wavefront at a time (their parameter ranges are disjoint)
+        if ((wave & 3) == w) {
+            flush_net(acc, GN, lane, actor_wave);
             if (n == 0) {
-                if (g < 2) {
+                if (actor_wave && g < 2) {
                     acc[O_STD + g] += d_sigma;
                     acc[O_AB3 + g] += d_b3;
-                } else if (g == 2) {
+                    if (g == 0) {
+                        acc[S_SURR] += s_surr;
+                        acc[S_KL] += s_kl;
+                    }
+                } else if (!actor_wave && g == 2) {
                     acc[O_CB3] += d_b3;
                     acc[S_VLOSS] += s_vloss;
-                }
-                if (g == 0) {
-                    acc[S_SURR] += s_surr;
-                    acc[S_KL] += s_kl;
                 }
             }
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < kRow; i += 256) partials[(int64_t)blockIdx.x * kRow + i] = acc[i];
+    for (int i = threadIdx.x; i < kRow; i += kThreads) partials[(int64_t)blockIdx.x * kRow + i] = acc[i];
 }
 
 // grad[i] = sum over blocks of partials[b][i]; norm2 += sum of squares of the parameter gradients (stats excluded).
@@ -592,9 +602,9 @@ int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const
     clear_error();
     ppo_operands_kernel<<<(kTabFloats + 255) / 256, 256, 0, stream>>>(N, st->operands);
     if (actor->activation == WL_ACT_ELU)
-        ppo_grad_kernel<WL_ACT_ELU><<<blocks, 256, lds_bytes, stream>>>(N, st->operands, *bt, mb_start, mb_size, h, st->partials);
+        ppo_grad_kernel<WL_ACT_ELU><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, st->operands, *bt, mb_start, mb_size, h, st->partials);
     else
-        ppo_grad_kernel<WL_ACT_RELU><<<blocks, 256, lds_bytes, stream>>>(N, st->operands, *bt, mb_start, mb_size, h, st->partials);
+        ppo_grad_kernel<WL_ACT_RELU><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, st->operands, *bt, mb_start, mb_size, h, st->partials);
     ppo_reduce_kernel<<<(kRow + 63) / 64, 256, 0, stream>>>(st->partials, blocks, st->grad, st->ctrl + WL_PPO_CTRL_NORM2 + parity);
     return launch_status();
 }
