@@ -208,15 +208,16 @@ class PPO:
             fz = self._fused
             fz.ctrl[4:7] = 0.0
             flat = {k: v.contiguous() for k, v in flat.items()}
+            # rsl_rl's mini_batch_generator draws ONE permutation per update and walks it in every epoch
+            perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator).to(torch.int32)
             for _ in range(self.num_learning_epochs):
-                perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator).to(torch.int32)
                 for i in range(self.num_mini_batches):    # the kernel gathers through `perm`: no shuffled copies
                     fz.minibatch(flat, perm, i * mb, mb, sigma_old)
             stats = fz.ctrl[4:7].clone()
         else:
+            perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator)
+            shuffled = {k: v[perm] for k, v in flat.items()}            # one gather per field and update
             for _ in range(self.num_learning_epochs):
-                perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator)
-                shuffled = {k: v[perm] for k, v in flat.items()}        # one gather per field and epoch
                 for i in range(self.num_mini_batches):
                     sl = slice(i * mb, (i + 1) * mb)
                     stats += self._step({k: v[sl] for k, v in shuffled.items()}, sigma_old)
