@@ -119,7 +119,8 @@ class DriftBatch(_MetricsView):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def set_lanes(self, lanes: int = 0):
-        """step-kernel form: 0 = by env count (quad up to 32768 envs), 1 = lane per env, 4 = quad per env"""
+        """step-kernel form: 0 = by env count (quad up to 32 768 envs, lane form with packed axles up to 262 144, with the
+        scalar wheel loop beyond), 1 = lane per env / packed axles, 2 = lane per env / scalar wheel loop, 4 = quad per env"""
         assert lanes in (0, 1, 2, 4)   # 2: lane form with the scalar wheel loop (drift only; treated as 1 elsewhere)
         self._bufs.lanes = lanes
 
