@@ -105,13 +105,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    # WL_BENCH_BACKEND=gloo is a debugging aid only (lets the N>1 code path run with several ranks sharing one GPU)
+    backend = os.environ.get("WL_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from wheeledlab_amd.core import DriftBatch
 
@@ -127,7 +134,15 @@ def main():
     metric_sum = torch.zeros_like(env.metrics)
 
     def run(k_steps):
-        done = 0
+        # the episode-metric all-reduce (the path's only collective) is issued async on RCCL's own stream and joined one
+        # logging interval later, so the next 128 launches overlap it instead of queueing behind it
+        done, pending = 0, None
+
+        def join(p):
+            if p is not None:
+                p[0].wait()
+                metric_sum.add_(p[1])
+
         while done < k_steps:
             k = min(ROLLOUT, k_steps - done)
             env.rollout(actions[:k], obs_buf, rew_buf, term_buf, trunc_buf)
@@ -135,8 +150,11 @@ def main():
             if k == ROLLOUT:  # episode-metric reduction at the logging cadence
                 m = env.read_metrics(zero=True)
                 if dist is not None:
-                    dist.all_reduce(m)
-                metric_sum.add_(m)
+                    join(pending)
+                    pending = (dist.all_reduce(m, async_op=True), m)
+                else:
+                    metric_sum.add_(m)
+        join(pending)
 
     def barrier():
         if dist is not None:
