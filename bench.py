@@ -48,11 +48,45 @@ def pmc_traffic(n_envs: int):
     return None, None
 
 
-def cpu_baseline(n_envs: int, budget_s: float = 12.0):
+def cpu_baseline(n_envs: int, budget_s: float = 14.0):
+    """The same workload on the host cores: the numpy oracle's FULL drift env.step (oracle/drift_step.py: action term ->
+    4 integrator sub-steps of the vehicle model -> terminations -> rewards -> in-step reset -> noisy obs) on n_envs envs.
+    Beside it (`mdp_only`) the torch-CPU port of just the reference's mdp path (oracle/torch_mdp.py) -- the only part of
+    the step the reference itself computes outside PhysX."""
+    import numpy as np
+
+    from oracle import drift_reset as DR
+    from oracle import drift_step as OS
+    from oracle import params as OP
+
+    host_cores = os.cpu_count() or 1
+    torch.set_num_threads(1)
+    p = OP.drift_params()
+    rng = np.random.RandomState(0)
+    st = OS.init_state(p, n_envs, seed=0)
+    ep = np.zeros(st.shape[1], np.int32)
+    ref = DR.ref_pose_table(DR.reference_poses(rng.rand(int(p.num_ref_points)).astype(np.float32)))
+    OS.reset_envs(p, st, ep, ref, np.arange(n_envs), 42, 0)
+    acts = (rng.rand(8, n_envs, 2) * 2 - 1).astype(np.float32)
+    OS.step(p, st, ep, ref, acts[0], 42, 0)
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < budget_s * 0.6:
+        OS.step(p, st, ep, ref, acts[k % 8], 42, k + 1)
+        k += 1
+    full_dt = time.perf_counter() - t0
+    full = {"value": n_envs * k / full_dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{k} full drift env.steps (4 sub-steps of the vehicle model + mdp terms + in-step reset + noisy "
+                      f"obs) of the numpy oracle on {n_envs} envs, numpy {np.__version__}, 1 thread of a {host_cores}-core "
+                      f"host, {full_dt:.1f} s"}
+    full["mdp_only"] = _cpu_mdp_only(n_envs, budget_s * 0.4, host_cores)
+    return full
+
+
+def _cpu_mdp_only(n_envs: int, budget_s: float, host_cores: int):
     """torch-CPU port of the reference's drift mdp path (oracle/torch_mdp.py) on the host cores."""
     from oracle import torch_mdp as T
 
-    host_cores = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
     r = lambda *s: torch.rand(*s, generator=g)
     pos = torch.cat([r(n_envs, 2) * 4 - 2, torch.zeros(n_envs, 1)], -1)
@@ -82,9 +116,9 @@ def cpu_baseline(n_envs: int, budget_s: float = 12.0):
             best = (cores, iters, dt)
     cores, iters, dt = best
     return {"value": n_envs * iters / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} passes of the drift mdp path (action term + 2 terminations + 7 rewards + noisy 14-dim "
-                      f"obs; no physics exists on the reference's CPU side) on {n_envs} envs, torch {torch.__version__} "
-                      f"CPU, best of 1 / {min(8, host_cores)} intra-op threads on a {host_cores}-core host, {dt:.1f} s"}
+            "sample": f"{iters} passes of the drift mdp path only (action term + 2 terminations + 7 rewards + noisy 14-dim "
+                      f"obs; no physics) on {n_envs} envs, torch {torch.__version__} CPU, best of 1 / "
+                      f"{min(8, host_cores)} intra-op threads, {dt:.1f} s"}
 
 
 def main():
