@@ -8,6 +8,8 @@ n, K = int(sys.argv[1]), int(sys.argv[2])
 dev = "cuda:0"
 env = DriftBatch(n, device=dev, seed=42)
 env.reset()
+if len(sys.argv) > 3:
+    env.set_lanes(int(sys.argv[3]))   # force a step-kernel form (WlEnvBuffers.lanes)
 a = torch.rand(K, n, 2, device=dev) * 2 - 1
 obs = torch.zeros(K, n, 14, device=dev)
 rew = torch.zeros(K, n, device=dev)
