@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 12
+#define WL_ABI_VERSION 13
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -316,6 +316,15 @@ int wl_ppo_gradients(const WlMlp* actor, const WlMlp* critic, const float* std, 
 int wl_ppo_minibatch(const WlMlp* actor, const WlMlp* critic, float* std, const WlPpoBatch* batch, int32_t mb_start,
                      int32_t mb_size, const WlPpoParams* hp, const WlPpoState* state, int32_t parity, int32_t adam_step,
                      void* stream);
+
+/* The second half of wl_ppo_minibatch on a gradient row the caller has already reduced: entropy term, norm clipping
+ * (with ctrl[WL_PPO_CTRL_NORM2 + parity] = squared norm of state->grad's parameter part), adaptive-KL learning rate, Adam.
+ * Data-parallel learner: every rank calls wl_ppo_gradients on its shard of the minibatch, the ranks average state->grad
+ * (all WL_PPO_PARTIAL_STRIDE floats: parameter gradients are means, the three statistics are sums over `mb_size` samples)
+ * with ONE all-reduce, set the squared norm, and call this -- identical inputs on every rank, hence identical parameters
+ * and learning rates without a broadcast. */
+int wl_ppo_apply(const WlMlp* actor, const WlMlp* critic, float* std, int32_t mb_size, const WlPpoParams* hp,
+                 const WlPpoState* state, int32_t parity, int32_t adam_step, void* stream);
 
 /*
  * Drift mdp terms only, on caller-supplied state tensors (the parity entry point: "outputs match the reference

@@ -37,9 +37,17 @@ def main():
     from wheeledlab_amd.rl import ClipAction, RslRlVecEnvWrapper
     from wheeledlab_amd.rl.ppo import OnPolicyRunner
 
+    from wheeledlab_amd import dist as D
+
     run_cfg = resolve_run(args.run_config_name, args.overrides)
     env_cfg, agent_cfg, train_cfg, log_cfg, env_setup = run_cfg.env, run_cfg.agent, run_cfg.train, run_cfg.train.log, run_cfg.env_setup
-    log_dir = None if log_cfg.no_log else log_cfg.run_log_dir
+    # one process per GPU (python -m torch.distributed.run --nproc-per-node N scripts/train_rl.py ...): every rank trains on
+    # its own num_envs envs (global ids rank * num_envs ...), gradients are averaged per minibatch step, rank 0 logs
+    rank, local_rank, world = D.init_from_env()
+    if world > 1:
+        dev = f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu"
+        env_cfg.sim.device, train_cfg.device = dev, dev
+    log_dir = None if (log_cfg.no_log or rank != 0) else log_cfg.run_log_dir
     if log_dir:
         os.makedirs(log_cfg.model_save_path, exist_ok=True)
         with open(os.path.join(log_dir, "run_config.yaml"), "w") as f:     # train_rl.py:62-64
@@ -62,12 +70,20 @@ def main():
         with open(os.path.join(log_dir, "history.json"), "w") as f:
             json.dump(hist, f)
     first, last = hist[0], hist[-1]
-    print(json.dumps({"run_config": args.run_config_name, "task": env_setup.task_name, "num_envs": env_setup.num_envs,
-                      "fused_collection": runner.fused, "fused_learner": runner.alg.fused_update, "iterations": len(hist),
-                      "mean_step_reward_first": first["mean_step_reward"], "mean_step_reward_last": last["mean_step_reward"],
-                      "mean_reward_last": last["mean_reward"], "mean_episode_length_last": last["mean_episode_length"],
-                      "fps_last": last["fps"], "collection_fps_last": last["collection_fps"], "log_dir": log_dir}))
+    # replicated state must not have drifted apart (identical averaged gradients -> identical steps on every rank)
+    flat_params = torch.cat([p.detach().reshape(-1) for p in runner.actor_critic.parameters()])
+    in_sync = D.ranks_agree(flat_params)
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        print(json.dumps({"run_config": args.run_config_name, "task": env_setup.task_name, "num_envs": env_setup.num_envs,
+                          "fused_collection": runner.fused, "fused_learner": runner.alg.fused_update, "iterations": len(hist),
+                          "mean_step_reward_first": first["mean_step_reward"], "mean_step_reward_last": last["mean_step_reward"],
+                          "mean_reward_last": last["mean_reward"], "mean_episode_length_last": last["mean_episode_length"],
+                          "n_gpus": world, "ranks_in_sync": in_sync, "fps_last": last["fps"], "collection_fps_last": last["collection_fps"], "log_dir": log_dir}))
     env.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

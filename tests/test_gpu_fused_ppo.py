@@ -109,6 +109,28 @@ def test_fused_step_tracks_the_torch_step():
     assert len(set(lrs_t)) > 1                                     # the adaptive rule actually moved the learning rate
 
 
+def test_split_step_for_the_data_parallel_learner_equals_the_fused_step():
+    """wl_ppo_gradients -> (all-reduce of the gradient row; a no-op with one rank) -> squared norm -> wl_ppo_apply is the
+    same step as wl_ppo_minibatch: 8 steps on copies of the same nets; the only difference is the summation order of the
+    squared norm (torch reduction vs the reduce kernel's atomics), i.e. the clipping coefficient to fp32 rounding"""
+    from wheeledlab_amd.rl.ppo import FusedPpoStep, PPO
+    B, mb = 8192, 2048
+    ac_a, flat, sigma_old = _problem(B, "elu", seed=5)
+    ac_b = copy.deepcopy(ac_a)
+    fa, fb = FusedPpoStep(ac_a, PPO(ac_a, desired_kl=0.002)), FusedPpoStep(ac_b, PPO(ac_b, desired_kl=0.002))
+    perm = torch.randperm(B, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2)).to(torch.int32)
+    for step in range(8):
+        start = (step % 4) * mb
+        fa.minibatch(flat, perm, start, mb, sigma_old)
+        fb.minibatch(flat, perm, start, mb, sigma_old, split=True)
+        assert fa.learning_rate == fb.learning_rate
+        for (name, a), b in zip(ac_a.named_parameters(), ac_b.parameters()):
+            torch.testing.assert_close(b, a, rtol=0, atol=2e-6 * (step + 1), msg=f"step {step} {name}")
+    torch.testing.assert_close(fb.adam_m, fa.adam_m, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(fb.ctrl[4:7], fa.ctrl[4:7], rtol=1e-6, atol=0)
+    assert fa.adam_step == fb.adam_step == 8 and fa.parity == fb.parity
+
+
 def test_update_with_the_fused_step_equals_the_torch_update_and_checkpoints_round_trip(tmp_path):
     """PPO.update(fused_update=True) vs PPO.update(fused_update=False) on one storage with the same permutations; the
     optimizer state written by the fused learner loads into the torch learner (rsl_rl's checkpoint format) and back"""

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 12
+WL_ABI_VERSION = 13
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -175,6 +175,7 @@ SIGNATURES = {
                                    _vp]),
     "wl_ppo_minibatch": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _P(WlPpoBatch), _i32, _i32, _P(WlPpoParams), _P(WlPpoState), _i32,
                                    _i32, _vp]),
+    "wl_ppo_apply": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _i32, _P(WlPpoParams), _P(WlPpoState), _i32, _i32, _vp]),
     "wl_drift_mdp": (C.c_int, [_P(WlDriftParams), _i32, _i64] + [_vp] * 12),
     "wl_action_map": (C.c_int, [_P(WlActionParams), _i32, _vp, _vp, _vp, _vp, _vp]),
     "wl_drift_reset": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _u64, _u64, _vp]),

@@ -644,4 +644,20 @@ int wl_ppo_minibatch(const WlMlp* actor, const WlMlp* critic, float* std, const 
     return launch_status();
 }
 
+int wl_ppo_apply(const WlMlp* actor, const WlMlp* critic, float* std, int32_t mb_size, const WlPpoParams* hp,
+                 const WlPpoState* state, int32_t parity, int32_t adam_step, void* stream) {
+    int rc = check_mlp(actor);
+    if (rc == WL_OK) rc = check_mlp(critic);
+    if (rc != WL_OK) return rc;
+    if (actor->in_dim != kIn || critic->in_dim != kIn || actor->out_dim != 2 || critic->out_dim != 1) return WL_EINVAL;
+    if (!std || !hp || !state || !state->grad || !state->adam_m || !state->adam_v || !state->ctrl || mb_size <= 0 ||
+        (parity != 0 && parity != 1) || adam_step < 1)
+        return WL_EINVAL;
+    clear_error();
+    const PpoNets N{*actor, *critic, std};
+    ppo_apply_kernel<<<(G + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, std, *hp, 1.f / (float)mb_size, state->grad, state->adam_m,
+                                                                       state->adam_v, state->ctrl, parity, adam_step);
+    return launch_status();
+}
+
 }  // extern "C"

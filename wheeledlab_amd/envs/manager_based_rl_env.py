@@ -351,9 +351,10 @@ class ManagerBasedRLEnv:
             self.episode_metrics(window=K, reduce_ranks=False), None, self._log_keys, self.max_episode_length_s)
         return storage
 
-    def episode_log_summary(self, window: int) -> dict:
-        """host floats of the episode log over the last `window` steps (one device->host copy; the runner's logging)"""
-        m = self.episode_metrics(window=window, reduce_ranks=False).tolist()
+    def episode_log_summary(self, window: int, reduce_ranks: bool = False) -> dict:
+        """host floats of the episode log over the last `window` steps (one device->host copy; the runner's logging);
+        reduce_ranks: over all ranks' envs (every rank must call it: one all-reduce)"""
+        m = self.episode_metrics(window=window, reduce_ranks=reduce_ranks).tolist()
         resets = max(m[A.M_RESETS], 1.0)
         out = {}
         for key, (kind, i) in self._log_keys.items():

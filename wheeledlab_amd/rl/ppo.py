@@ -21,6 +21,7 @@ from collections import deque
 import torch
 from torch import nn
 
+from .. import dist as D
 from ..policy import Mlp, RolloutStorage
 
 _ACT = {"elu": nn.ELU, "relu": nn.ReLU, "tanh": nn.Tanh}
@@ -111,7 +112,8 @@ class PPO:
 
     def __init__(self, actor_critic: ActorCritic, value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2,
                  entropy_coef=0.005, num_learning_epochs=5, num_mini_batches=4, learning_rate=1e-3, schedule="adaptive",
-                 gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0, fused_update: bool | None = None, **_unused):
+                 gamma=0.99, lam=0.95, desired_kl=0.01, max_grad_norm=1.0, fused_update: bool | None = None,
+                 distributed: bool | None = None, **_unused):
         self.actor_critic = actor_critic
         self.value_loss_coef, self.use_clipped_value_loss, self.clip_param = value_loss_coef, use_clipped_value_loss, clip_param
         self.entropy_coef, self.num_learning_epochs, self.num_mini_batches = entropy_coef, num_learning_epochs, num_mini_batches
@@ -132,6 +134,9 @@ class PPO:
             raise ValueError("fused_update needs the 14-64-64-2 / 14-64-64-1 elu / relu nets on a GPU")
         self.fused_update = can_fuse if fused_update is None else bool(fused_update)
         self._fused = None
+        # data-parallel learner: ranks hold identical parameters (same seed), step their own env shards, and average the
+        # gradient (and the KL statistic of the adaptive rule) once per minibatch step
+        self.world = D.world_size() if distributed is None else (D.world_size() if distributed else 1)
 
     @property
     def learning_rate(self) -> float:
@@ -150,6 +155,8 @@ class PPO:
                 kl = torch.sum(torch.log(sigma / sigma_old + 1e-5)
                                + (sigma_old.square() + (b["mu"] - mu).square()) / (2.0 * sigma.square()) - 0.5, -1)
                 kl_mean = kl.mean()
+                if self.world > 1:
+                    D.average_(kl_mean)     # every rank takes the same learning-rate decision
                 lr = self._lr
                 up = (kl_mean > 0.0) & (kl_mean < self.desired_kl / 2.0)
                 new_lr = torch.where(kl_mean > self.desired_kl * 2.0, (lr / 1.5).clamp_min(1e-5),
@@ -170,6 +177,8 @@ class PPO:
         loss = surrogate + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if self.world > 1:
+            D.average_gradients_(list(ac.parameters()))
         nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
         self.optimizer.step()
         return torch.stack([value_loss.detach(), surrogate.detach(), kl_mean.detach()])
@@ -212,7 +221,7 @@ class PPO:
             perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator).to(torch.int32)
             for _ in range(self.num_learning_epochs):
                 for i in range(self.num_mini_batches):    # the kernel gathers through `perm`: no shuffled copies
-                    fz.minibatch(flat, perm, i * mb, mb, sigma_old)
+                    fz.minibatch(flat, perm, i * mb, mb, sigma_old, split=self.world > 1)
             stats = fz.ctrl[4:7].clone()
         else:
             perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator)
@@ -250,6 +259,10 @@ class OnPolicyRunner:
         self.fused = can_fuse if fused is None else bool(fused)
         self.storage = RolloutStorage(self.num_steps_per_env, env.num_envs, env.num_obs, env.num_actions, self.device)
         self.current_learning_iteration = 0
+        # one process per GPU: every rank runs this loop on its own env shard with identical parameters (same seed, gradient
+        # averaged per minibatch step in PPO); rank 0 prints and writes checkpoints, throughput is the whole job's
+        self.world = self.alg.world
+        self.rank = torch.distributed.get_rank() if self.world > 1 else 0
         self.tot_timesteps, self.tot_time = 0, 0.0
         self.history: list[dict] = []
 
@@ -308,7 +321,7 @@ class OnPolicyRunner:
             torch.cuda.synchronize() if self.device.type == "cuda" else None
             t2 = time.time()
             self.current_learning_iteration = it + 1
-            steps = st.n_steps * n
+            steps = st.n_steps * n * self.world
             self.tot_timesteps += steps
             self.tot_time += t2 - t0
             log = dict(iteration=it, collection_time=t1 - t0, learn_time=t2 - t1, fps=steps / (t2 - t0),
@@ -316,13 +329,13 @@ class OnPolicyRunner:
                        mean_step_reward=float(st.rewards.mean()), mean_noise_std=float(self.actor_critic.std.detach().mean()), **losses)
             base = env.unwrapped
             if hasattr(base, "episode_log_summary"):
-                log.update(base.episode_log_summary(st.n_steps))
+                log.update(base.episode_log_summary(st.n_steps, reduce_ranks=self.world > 1))
             self.history.append(log)
-            if verbose:
+            if verbose and self.rank == 0:
                 print(f"[it {it:4d}] fps {log['fps']:.3e} (collect {log['collection_fps']:.3e})  mean_reward {log['mean_reward']:.2f}"
                       f"  ep_len {log['mean_episode_length']:.1f}  step_rew {log['mean_step_reward']:.3f}"
                       f"  std {log['mean_noise_std']:.3f}  kl {losses['kl']:.4f}  lr {losses['learning_rate']:.2e}", flush=True)
-            if self.log_dir and (it % self.save_interval == 0 or it == start_iter + num_learning_iterations - 1):
+            if self.log_dir and self.rank == 0 and (it % self.save_interval == 0 or it == start_iter + num_learning_iterations - 1):
                 self.save(os.path.join(self.log_dir, "models", f"model_{it}.pt"))
         return self.history
 
@@ -429,8 +442,24 @@ class FusedPpoStep:
                                           self._stream()), "wl_ppo_gradients")
         return self.grad
 
-    def minibatch(self, flat, perm, mb_start, mb_size, sigma_old):
+    def minibatch(self, flat, perm, mb_start, mb_size, sigma_old, split: bool = False):
+        """one PPO step in place.  split=True is the data-parallel form: gradients of this rank's minibatch, ONE all-reduce
+        of the gradient row (parameter gradients + the three statistics), then the update on the averaged row"""
         C, A = self._C, self._A
+        if split:
+            self.ctrl[A.PPO_CTRL_NORM2 + self.parity] = 0.0
+            bt = self._batch(flat, perm, sigma_old)
+            A.check(self.lib.wl_ppo_gradients(C.byref(self._actor), C.byref(self._critic), self.ac.std.data_ptr(), C.byref(bt),
+                                              int(mb_start), int(mb_size), C.byref(self.hp), C.byref(self.state), self.parity,
+                                              self._stream()), "wl_ppo_gradients")
+            D.average_(self.grad)
+            self.ctrl[A.PPO_CTRL_NORM2 + self.parity] = self.grad[:A.PPO_NUM_PARAMS].square().sum()
+            self.adam_step += 1
+            A.check(self.lib.wl_ppo_apply(C.byref(self._actor), C.byref(self._critic), self.ac.std.data_ptr(), int(mb_size),
+                                          C.byref(self.hp), C.byref(self.state), self.parity, self.adam_step, self._stream()),
+                    "wl_ppo_apply")
+            self.parity ^= 1
+            return
         bt = self._batch(flat, perm, sigma_old)
         self.adam_step += 1
         A.check(self.lib.wl_ppo_minibatch(C.byref(self._actor), C.byref(self._critic), self.ac.std.data_ptr(), C.byref(bt),
