@@ -17,6 +17,7 @@ this box's host cores on a bounded sample; baseline, not target).
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -121,6 +122,35 @@ def _cpu_mdp_only(n_envs: int, budget_s: float, host_cores: int):
                       f"{min(8, host_cores)} intra-op threads, {dt:.1f} s"}
 
 
+def large_n_sweep(dev):
+    """us per fused drift env.step() at 65 536 / 1 M / 4 M envs (outputs overwritten in place; these launches also write
+    the int64 `dones` row: + 8 B per env-step)"""
+    from wheeledlab_amd.core import DriftBatch
+
+    sweep = []
+    for big in (65536, 1048576, 4194304):
+        e2 = DriftBatch(big, device=dev, seed=42)
+        e2.reset()
+        a2 = torch.rand(8, big, 2, device=dev) * 2 - 1
+        for _ in range(3):
+            e2.rollout(a2)
+        torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(2):
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(6):
+                e2.rollout(a2)
+            s1.record()
+            torch.cuda.synchronize()
+            best = min(best, s0.elapsed_time(s1) * 1e3 / 48)
+        gbs = (BYTES_PER_ENV_STEP + 8) * big / (best * 1e-6) / 1e9
+        sweep.append({"n_envs": big, "us_per_step": round(best, 2), "env_steps_per_s": big / (best * 1e-6),
+                      "achieved_GBs": gbs, "frac_of_8TBs": gbs / 8000.0, "bytes_per_env_step": BYTES_PER_ENV_STEP + 8})
+        del e2, a2
+    return sweep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,7 +160,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="(default at N=1) large-N sweep of the same kernel: the HBM-bound regime")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--sweep-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.sweep_child:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+        print(json.dumps(large_n_sweep(torch.device("cuda", 0))), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -350,28 +385,18 @@ def main():
         py_rate = n * 2048 / (time.perf_counter() - t1)
         del w, e
 
-    # secondary: the SAME fused step at env counts where it is bandwidth- rather than launch-bound (SURVEY 8(d) config 2:
-    # "also sweep N ... to expose the bandwidth-bound regime"); these launches also write the int64 `dones` row (+8 B)
+    # secondary: the SAME fused step at env counts where it is throughput- rather than launch-bound (SURVEY 8(d) config 2:
+    # "also sweep N ... to expose the bandwidth-bound regime").  Run in a fresh process: with the GB-sized buffers carved
+    # out of this process's caching-allocator leftovers the same launches measured 12-15 % slower (tools/lanes_probe.py)
     sweep = []
     if rank == 0 and world == 1 and not args.no_sweep:
-        for big in (65536, 1048576, 4194304):
-            e2 = DriftBatch(big, device=dev, seed=42)
-            e2.reset()
-            a2 = torch.rand(8, big, 2, device=dev) * 2 - 1
-            for _ in range(3):
-                e2.rollout(a2)
-            torch.cuda.synchronize()
-            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s0.record()
-            for _ in range(6):
-                e2.rollout(a2)
-            s1.record()
-            torch.cuda.synchronize()
-            us = s0.elapsed_time(s1) * 1e3 / 48
-            gbs = (BYTES_PER_ENV_STEP + 8) * big / (us * 1e-6) / 1e9
-            sweep.append({"n_envs": big, "us_per_step": round(us, 2), "env_steps_per_s": big / (us * 1e-6),
-                          "achieved_GBs": gbs, "frac_of_8TBs": gbs / 8000.0, "bytes_per_env_step": BYTES_PER_ENV_STEP + 8})
-            del e2, a2
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--sweep-child"], capture_output=True, text=True,
+                                 timeout=600, check=True).stdout.strip().splitlines()[-1]
+            sweep = json.loads(out)
+        except Exception as ex:   # noqa: BLE001 -- the sweep is a secondary figure: never lose the headline line over it
+            print(f"[bench] sweep subprocess failed ({ex!r}); measuring in-process", file=sys.stderr, flush=True)
+            sweep = large_n_sweep(dev)
 
     if rank == 0:
         total_envs = n * world
