@@ -360,7 +360,26 @@ def main():
             us = q0.elapsed_time(q1) * 1e3 / (4 * k)
             other[name] = {"us_per_step": us, "env_steps_per_s": n / (us * 1e-6), "obs_dim": t.OBS_DIM,
                            "obs_GBs": n * t.OBS_DIM * 4 / (us * 1e-6) / 1e9}
-            del t, a
+            # the agent's policy step on this observation width (actor -> sample -> log-prob + critic value) as ONE launch
+            # (wl_actor_critic_act: the first layers as skinny fp32 GEMMs on the matrix pipe)
+            from wheeledlab_amd.policy import ActorCritic as KernelAC
+            kac = KernelAC(t.OBS_DIM, 2, "relu" if name == "elevation" else "elu", device=dev, seed=0)
+            ob = torch.randn(n, t.OBS_DIM, device=dev)
+            pa, pm = torch.empty(n, 2, device=dev), torch.empty(n, 2, device=dev)
+            pl, pv = torch.empty(n, device=dev), torch.empty(n, device=dev)
+            for i in range(10):
+                kac.act(ob, pa, pm, pl, pv, 42, i)
+            torch.cuda.synchronize()
+            q0.record()
+            for i in range(100):
+                kac.act(ob, pa, pm, pl, pv, 42, i)
+            q1.record()
+            torch.cuda.synchronize()
+            pus = q0.elapsed_time(q1) * 1e3 / 100
+            flop = 2.0 * n * (2 * t.OBS_DIM * 64 + 2 * 64 * 64 + 3 * 64)
+            other[name]["policy_step_us"] = pus
+            other[name]["policy_step_TFLOPs"] = flop / (pus * 1e-6) / 1e12
+            del t, a, kac, ob
 
     # secondary: the same workload driven step by step through the drop-in Python surface
     # (registry.make -> ClipAction -> RslRlVecEnvWrapper.step), i.e. what a Python RL loop sees per env.step() call

@@ -220,7 +220,7 @@ typedef struct WlMlp {
     const float* w1; const float* b1;   /* [64][in_dim], [64] */
     const float* w2; const float* b2;   /* [64][64], [64] */
     const float* w3; const float* b3;   /* [out_dim][64], [out_dim] */
-    int32_t in_dim;      /* 1..15 (drift observation: 14) */
+    int32_t in_dim;      /* 1..15 (drift observation: 14); wl_actor_critic_act: any (elevation 689, visual 3208) */
     int32_t out_dim;     /* 1..4  (actor: 2 action means; critic: 1 value) */
     int32_t hidden;      /* must be 64 */
     int32_t activation;  /* WlActivation */
@@ -256,6 +256,18 @@ typedef struct WlPolicyRollout {
  */
 int wl_drift_rollout_policy(const WlDriftParams* p, const WlEnvBuffers* b, const WlMlp* actor, const float* action_std,
                             const WlPolicyRollout* io, int32_t n_steps, uint64_t seed, uint64_t step0, void* stream);
+
+/*
+ * One policy step on WIDE observations (the elevation / visual agents: rsl_rl ActorCritic.act + evaluate of
+ * modified_rsl_rl_runner.py:70-76 on 689 / 3208 features) in ONE launch: mu = actor(obs), a = mu + std * N(0, 1),
+ * log_prob, value = critic(obs).  obs is [n_rows][obs_stride] (obs_stride >= in_dim floats, rows 4-byte aligned); the
+ * first layers run as skinny GEMMs on the f32 matrix pipe (exact fp32 products and sums), the draw is keyed by
+ * (seed, env_offset + row, step) on the policy stream -- the draw of wl_drift_rollout_policy -- or skipped
+ * (deterministic != 0: a = mu, the play policy).  actions / mu are [n_rows][2] (8-byte aligned), log_prob / values [n_rows].
+ */
+int wl_actor_critic_act(const WlMlp* actor, const WlMlp* critic, const float* std, int32_t n_rows, const float* obs,
+                        int64_t obs_stride, float* actions, float* mu, float* log_prob, float* values, int32_t env_offset,
+                        uint64_t seed, uint64_t step, int32_t deterministic, void* stream);
 
 /* ---- PPO learner step of the drift agents ("on-device PPO for the 64-64 MLP") ------------
  * One minibatch step of rsl_rl's PPO.update (modified_rsl_rl_runner.py:104-109; rsl_rl_ppo_cfg.py:18-31) for the

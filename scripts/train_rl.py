@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser(description="Train an RL agent on the MI355X-native WheeledLab envs.")
     ap.add_argument("-r", "--run-config-name", default="RSS_DRIFT_CONFIG")
     ap.add_argument("--stepwise", action="store_true", help="one launch per env.step() with a torch actor")
+    ap.add_argument("--torch-policy", action="store_true", help="per-step collection with the policy step in torch eager")
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("overrides", nargs="*", help="Hydra-style key=value overrides")
     args = ap.parse_args()
@@ -60,7 +61,7 @@ def main():
     if not log_cfg.no_checkpoints:
         agent_cfg.save_interval = min(agent_cfg.save_interval, log_cfg.checkpoint_every)
     runner = OnPolicyRunner(env, agent_cfg, log_dir=None if log_cfg.no_checkpoints else log_dir, device=train_cfg.device,
-                            fused=False if args.stepwise else None)
+                            fused=False if args.stepwise else None, kernel_policy=False if args.torch_policy else None)
     if train_cfg.load_run is not None:
         runner.load(train_cfg.load_run)
     env.seed(agent_cfg.seed)
@@ -77,7 +78,7 @@ def main():
         torch.distributed.barrier()
     if rank == 0:
         print(json.dumps({"run_config": args.run_config_name, "task": env_setup.task_name, "num_envs": env_setup.num_envs,
-                          "fused_collection": runner.fused, "fused_learner": runner.alg.fused_update, "iterations": len(hist),
+                          "fused_collection": runner.fused, "fused_learner": runner.alg.fused_update, "kernel_policy": runner.kernel_policy, "iterations": len(hist),
                           "mean_step_reward_first": first["mean_step_reward"], "mean_step_reward_last": last["mean_step_reward"],
                           "mean_reward_last": last["mean_reward"], "mean_episode_length_last": last["mean_episode_length"],
                           "n_gpus": world, "ranks_in_sync": in_sync, "fps_last": last["fps"], "collection_fps_last": last["collection_fps"], "log_dir": log_dir}))

@@ -1,0 +1,99 @@
+"""GPU parity of the one-launch policy step for wide observations (csrc/wl_actor.hip: wl_actor_critic_act) against the
+numpy oracle of the same ActorCritic (oracle/policy.py: fp32 MLPs + the Philox / Box-Muller draw of the policy stream).
+Tolerance: 3e-4 abs on means / values (fp32 dot products of up to 3208 terms in a different summation order), the draw
+itself to 2e-5 (hardware log / sin / cos), log-prob 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import policy as OPOL
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _nets(D, activation, seed):
+    from wheeledlab_amd.policy import ActorCritic
+    ac = ActorCritic(D, 2, activation, init_noise_std=1.0, device=DEV, seed=seed)
+    ac.std.copy_(torch.tensor([0.7, 1.3], device=DEV))
+    as_np = lambda m: dict(w1=m.w1.cpu().numpy(), b1=m.b1.cpu().numpy(), w2=m.w2.cpu().numpy(), b2=m.b2.cpu().numpy(),
+                           w3=m.w3.cpu().numpy(), b3=m.b3.cpu().numpy(), activation=activation)
+    return ac, as_np(ac.actor), as_np(ac.critic)
+
+
+@pytest.mark.parametrize("activation", ["elu", "relu"])
+@pytest.mark.parametrize("D,n", [(689, 4096), (3208, 512), (689, 100), (3208, 4096), (14, 300), (16, 64), (33, 17), (1, 5)])
+def test_policy_step_matches_oracle(D, n, activation):
+    ac, actor_np, critic_np = _nets(D, activation, seed=D + n)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    obs = torch.randn(n, D, device=DEV, generator=g)
+    a, mu = torch.empty(n, 2, device=DEV), torch.empty(n, 2, device=DEV)
+    logp, val = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    seed, step, off = 42, 1234567, 8192
+    ac.act(obs, a, mu, logp, val, seed, step, env_offset=off)
+    torch.cuda.synchronize()
+    o_a, o_mu, o_logp = OPOL.act(actor_np, ac.std.cpu().numpy(), obs.cpu().numpy(), np.arange(n) + off, step, seed)
+    o_val = OPOL.mlp(critic_np, obs.cpu().numpy())[:, 0]
+    np.testing.assert_allclose(mu.cpu().numpy(), o_mu, rtol=0, atol=3e-4)
+    np.testing.assert_allclose(val.cpu().numpy(), o_val, rtol=0, atol=3e-4)
+    std = ac.std.cpu().numpy()
+    np.testing.assert_allclose((a - mu).cpu().numpy() / std, (o_a - o_mu) / std, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), o_logp, rtol=0, atol=1e-3)
+    # and against torch's own Normal on the kernel's numbers (what rsl_rl would compute for these actions)
+    ref = torch.distributions.Normal(mu, ac.std).log_prob(a).sum(-1)
+    torch.testing.assert_close(logp, ref, rtol=0, atol=1e-4)
+
+
+def test_deterministic_step_and_strided_rows():
+    """play policy (a = mu) on observation rows that are a column slice of a wider matrix (obs_stride > in_dim)"""
+    D, n = 689, 1000
+    ac, actor_np, _ = _nets(D, "relu", seed=5)
+    wide = torch.randn(n, D + 7, device=DEV)
+    obs = wide[:, 3:3 + D]
+    a, mu = torch.empty(n, 2, device=DEV), torch.empty(n, 2, device=DEV)
+    logp, val = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    ac.act(obs, a, mu, logp, val, 1, 2, deterministic=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, mu)
+    np.testing.assert_allclose(mu.cpu().numpy(), OPOL.mlp(actor_np, obs.cpu().numpy()), rtol=0, atol=3e-4)
+
+
+def test_matches_the_drift_rollout_draw():
+    """for the 14-wide drift observation the step equals the first step of wl_drift_rollout_policy: same nets, same
+    (seed, env, step) key -> same actions"""
+    from wheeledlab_amd.core import DriftBatch
+    from wheeledlab_amd.policy import ActorCritic, RolloutStorage
+    n = 512
+    env = DriftBatch(n, device=DEV, seed=9)
+    env.reset()
+    env.observe()
+    ac = ActorCritic(device=DEV, seed=2)
+    st = RolloutStorage(1, n, device=DEV)
+    obs0 = env.obs.clone()
+    a, mu = torch.empty(n, 2, device=DEV), torch.empty(n, 2, device=DEV)
+    logp, val = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    ac.act(obs0, a, mu, logp, val, env.seed, env.step_count, env.env_offset)
+    env.rollout_policy(ac, st)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(st.mu[0], mu, rtol=0, atol=2e-5)
+    torch.testing.assert_close(st.actions[0], a, rtol=0, atol=2e-5)
+    torch.testing.assert_close(st.actions_log_prob[0], logp, rtol=0, atol=1e-5)
+    torch.testing.assert_close(st.values[0], val, rtol=0, atol=2e-5)
+
+
+def test_rejects_bad_arguments():
+    import ctypes as C
+
+    from wheeledlab_amd import _abi as A
+    ac, _, _ = _nets(20, "elu", seed=0)
+    lib = A.load()
+    a, c = ac.actor.struct(), ac.critic.struct()
+    obs = torch.zeros(4, 20, device=DEV)
+    out2, out1 = torch.zeros(4, 2, device=DEV), torch.zeros(4, device=DEV)
+    call = lambda n, stride, ap=a: lib.wl_actor_critic_act(C.byref(ap), C.byref(c), ac.std.data_ptr(), n, obs.data_ptr(), stride,
+                                                          out2.data_ptr(), out2.data_ptr(), out1.data_ptr(), out1.data_ptr(), 0, 0, 0,
+                                                          0, None)
+    assert call(4, 20) == 0
+    assert call(0, 20) == -1 and call(4, 19) == -1      # WL_EINVAL
+    bad = ac.critic.struct()       # an "actor" with one output
+    assert call(4, 20, bad) == -1

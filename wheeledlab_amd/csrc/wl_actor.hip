@@ -1,0 +1,288 @@
+// wl_actor.hip -- one policy step for WIDE observations (elevation: 689 features, visual: 3208): actor mean -> Gaussian
+// sample -> log-prob, and the critic's value, in ONE launch (rsl_rl ActorCritic.act + evaluate,
+// modified_rsl_rl_runner.py:70-76 with the agents of elevation/config/agents/mushr/rsl_rl_ppo_cfg.py: [64, 64] MLPs).
+//
+// The first layer is a skinny GEMM H1^T[64 x rows] = W1[64 x D] * X^T[D x rows] on v_mfma_f32_16x16x4_f32 (exact fp32).
+// A wavefront owns ONE net (actor or critic) and ONE 16-row tile, i.e. four 16-unit accumulators; the contraction index
+// is walked in chunks of 16 features with the k-step <-> feature mapping f = k0 + 4 g + s (lane group g, k-step s), so
+// that every lane fetches its A operands (weights) and its B operand (observation) as ONE 16-byte load per chunk and
+// tile -- a dot product does not care about the order of its terms.  A wavefront keeps RT row tiles on the same weight
+// operands; KS wavefronts split the feature range of one net and one row block between them (a 4096-env batch is only
+// 128 row blocks of 32: 2 nets x KS = 4 puts a wavefront on every SIMD) and fold their partial accumulators through LDS;
+// wavefront 0 then finishes the 64-64-out tail with the register-resident layout of wl_mlp.h (the layer-1 accumulator IS
+// the B operand of layer 2).
+#include <hip/hip_runtime.h>
+
+#include "../../include/wheeledlab_amd.h"
+#include "wl_kernel_common.h"
+#include "wl_mlp.h"
+#include "wl_rng.h"
+
+namespace {
+
+constexpr float kLog2PiA = 1.8378770664093453f;
+typedef float wl_f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (rows of odd length)
+
+struct MlpTail {   // A operands of layers 2 and 3 (this lane's element of each 16 x 4 weight tile), as in MlpWeights
+    float w2[kMlpTiles][kMlpHidSteps];
+    float w3[kMlpHidSteps];
+};
+
+WL_DEV void load_tail(const WlMlp& net, int lane, MlpTail& W) {
+    const int m = lane & 15, g = (lane >> 4) & 3;
+#pragma unroll
+    for (int t = 0; t < kMlpTiles; ++t) {
+        const int unit = 16 * t + m;
+#pragma unroll
+        for (int tp = 0; tp < kMlpTiles; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W.w2[t][4 * tp + r] = net.w2[unit * kMlpHidden + 16 * tp + 4 * g + r];
+        W.w2[t][kMlpHidSteps - 1] = g == 0 ? net.b2[unit] : 0.f;
+    }
+#pragma unroll
+    for (int tp = 0; tp < kMlpTiles; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W.w3[4 * tp + r] = m < net.out_dim ? net.w3[m * kMlpHidden + 16 * tp + 4 * g + r] : 0.f;
+    W.w3[kMlpHidSteps - 1] = (g == 0 && m < net.out_dim) ? net.b3[m] : 0.f;
+}
+
+// layers 2 and 3 on the (pre-activation, bias included) layer-1 accumulators; lanes 0..15 return outputs 0..3 of row l
+template <int ACT>
+WL_DEV f32x4 eval_tail(const MlpTail& W, f32x4 h1[kMlpTiles], int lane) {
+    const float one_g0 = ((lane >> 4) & 3) == 0 ? 1.f : 0.f;
+    f32x4 h2[kMlpTiles];
+#pragma unroll
+    for (int t = 0; t < kMlpTiles; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[t][r] = mlp_act<ACT>(h1[t][r]);
+        h2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int tp = 0; tp < kMlpTiles; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < kMlpTiles; ++t) h2[t] = mfma4(W.w2[t][4 * tp + r], h1[tp][r], h2[t]);
+#pragma unroll
+    for (int t = 0; t < kMlpTiles; ++t) h2[t] = mfma4(W.w2[t][kMlpHidSteps - 1], one_g0, h2[t]);
+#pragma unroll
+    for (int t = 0; t < kMlpTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h2[t][r] = mlp_act<ACT>(h2[t][r]);
+    f32x4 out = {0.f, 0.f, 0.f, 0.f}, out_b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < kMlpTiles; tp += 2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            out = mfma4(W.w3[4 * tp + r], h2[tp][r], out);
+            out_b = mfma4(W.w3[4 * (tp + 1) + r], h2[tp + 1][r], out_b);
+        }
+    out = mfma4(W.w3[kMlpHidSteps - 1], one_g0, out);
+    return out + out_b;
+}
+
+constexpr int kRing = 4;   // chunks of operands in flight per wavefront (deeper rings measured no different: the
+                           // kernel is bound by L2 -> L1 operand traffic, not by its latency)
+
+// operands of one 16-feature chunk: A (weights) for the four unit tiles, B (observations) for the RT row tiles
+template <int RT>
+struct Chunk {
+    wl_f4u a[kMlpTiles];
+    wl_f4u b[RT];
+};
+
+// 16-byte operand loads of chunk k0 (all 16 features inside [0, D))
+template <int RT>
+WL_DEV void load_chunk(const float* __restrict__ w_lane, const float* const (&x_lane)[RT], int D, int k0, Chunk<RT>& c) {
+#pragma unroll
+    for (int t = 0; t < kMlpTiles; ++t) c.a[t] = *reinterpret_cast<const wl_f4u*>(w_lane + (int64_t)16 * t * D + k0);
+#pragma unroll
+    for (int q = 0; q < RT; ++q) c.b[q] = *reinterpret_cast<const wl_f4u*>(x_lane[q] + k0);
+}
+// the last, partial chunk: element-wise with the features past D read as zero (never touches memory past a row's end)
+template <int RT>
+WL_DEV void load_chunk_tail(const float* __restrict__ w_lane, const float* const (&x_lane)[RT], int D, int k0, int g, Chunk<RT>& c) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bool in = k0 + 4 * g + s < D;
+#pragma unroll
+        for (int t = 0; t < kMlpTiles; ++t) c.a[t][s] = in ? w_lane[(int64_t)16 * t * D + k0 + s] : 0.f;
+#pragma unroll
+        for (int q = 0; q < RT; ++q) c.b[q][s] = in ? x_lane[q][k0 + s] : 0.f;
+    }
+}
+template <int RT>
+WL_DEV void mma_chunk(const Chunk<RT>& c, f32x4 (&h)[RT][kMlpTiles]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int q = 0; q < RT; ++q)
+#pragma unroll
+            for (int t = 0; t < kMlpTiles; ++t) h[q][t] = mfma4(c.a[t][s], c.b[q][s], h[q][t]);
+}
+
+// block = KS wavefronts on RT 16-row tiles of ONE net (blockIdx.y: 0 actor, 1 critic).  Every weight operand a wavefront
+// fetches feeds RT row tiles: at RT = 1 the launch was bound by L2 -> L1 operand traffic (each of the 256 tiles of a
+// 4096-row batch streamed the whole first-layer matrix), not by the matrix pipe.
+template <int ACT, int KS, int RT>
+__global__ void __launch_bounds__(64 * KS) actor_critic_act_kernel(const WlMlp actor, const WlMlp critic,
+                                                                   const float* __restrict__ std, const int n_rows,
+                                                                   const float* __restrict__ obs, const int64_t obs_stride,
+                                                                   float* __restrict__ actions, float* __restrict__ mu_out,
+                                                                   float* __restrict__ log_prob, float* __restrict__ values,
+                                                                   const int env_offset, const uint64_t seed, const uint64_t step,
+                                                                   const int deterministic) {
+    __shared__ float part[KS > 1 ? KS - 1 : 1][RT * kMlpTiles * 4][64];
+    const int lane = threadIdx.x & 63, kpart = threadIdx.x >> 6;   // this wavefront's share of the features
+    const int which = blockIdx.y;
+    const WlMlp& net = which == 0 ? actor : critic;
+    const int D = net.in_dim;
+    const int m = lane & 15, g = lane >> 4;
+    const int row0 = (int)blockIdx.x * (16 * RT);
+    // this lane's operand streams: weights of unit m (+ 16 t) and the observations of rows m (+ 16 q), at feature offset 4 g
+    const float* w_lane = net.w1 + (int64_t)m * D + 4 * g;
+    const float* x_lane[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q)   // spare lanes of the last tile(s) mirror the last row
+        x_lane[q] = obs + (int64_t)min(row0 + 16 * q + m, n_rows - 1) * obs_stride + 4 * g;
+
+    f32x4 h[RT][kMlpTiles];
+#pragma unroll
+    for (int t = 0; t < kMlpTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float bias = kpart == 0 ? net.b1[16 * t + 4 * g + r] : 0.f;   // the bias seeds the accumulators
+#pragma unroll
+            for (int q = 0; q < RT; ++q) h[q][t][r] = bias;
+        }
+
+    // chunks [c0, c1) of 16 features for this wavefront; the partial last chunk (if any) belongs to the last share
+    const int n_full = D >> 4, per = (n_full + KS - 1) / KS;
+    const int c0 = min(kpart * per, n_full), c1 = min(c0 + per, n_full);
+    Chunk<RT> ring[kRing];
+#pragma unroll
+    for (int j = 0; j < kRing; ++j)
+        if (c0 + j < c1) load_chunk<RT>(w_lane, x_lane, D, (c0 + j) << 4, ring[j]);
+    Chunk<RT> last;   // the partial last chunk, requested up front as well
+    const bool has_last = kpart == KS - 1 && (D & 15);
+    if (has_last) load_chunk_tail<RT>(w_lane, x_lane, D, n_full << 4, g, last);
+    // independent of layer 1 and needed right after it: the tail's weights and the action draws, requested / computed in
+    // the shadow of the first operand loads instead of as a dependent round trip at the end
+    MlpTail W;
+    float z0[RT], z1[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) z0[q] = z1[q] = 0.f;
+    if (kpart == 0) {
+        load_tail(net, lane, W);
+        if (which == 0 && !deterministic) {
+#pragma unroll
+            for (int q = 0; q < RT; ++q) {
+                const F4 u = philox_uniform4((uint32_t)(env_offset + row0 + 16 * q + m), step, WL_RS_POLICY, seed);
+                box_muller(u.x, u.y, z0[q], z1[q]);
+            }
+        }
+    }
+    for (int c = c0; c < c1; c += kRing) {
+#pragma unroll
+        for (int j = 0; j < kRing; ++j) {
+            if (c + j < c1) {
+                mma_chunk<RT>(ring[j], h);
+                if (c + j + kRing < c1) load_chunk<RT>(w_lane, x_lane, D, (c + j + kRing) << 4, ring[j]);
+            }
+        }
+    }
+    if (has_last) mma_chunk<RT>(last, h);
+    if constexpr (KS > 1) {
+        if (kpart > 0) {
+#pragma unroll
+            for (int q = 0; q < RT; ++q)
+#pragma unroll
+                for (int t = 0; t < kMlpTiles; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[kpart - 1][(q * kMlpTiles + t) * 4 + r][lane] = h[q][t][r];
+        }
+        __syncthreads();
+        if (kpart > 0) return;
+#pragma unroll
+        for (int k = 0; k < KS - 1; ++k)
+#pragma unroll
+            for (int q = 0; q < RT; ++q)
+#pragma unroll
+                for (int t = 0; t < kMlpTiles; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[q][t][r] += part[k][(q * kMlpTiles + t) * 4 + r][lane];
+    }
+    const float std0 = std[0], std1 = std[1];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        const f32x4 out = eval_tail<ACT>(W, h[q], lane);
+        const int r_out = row0 + 16 * q + m;
+        if (g != 0 || r_out >= n_rows) continue;
+        if (which == 1) {
+            values[r_out] = out[0];
+            continue;
+        }
+        // a ~ N(mu, diag(std^2)) keyed by (seed, global env, step) on the policy stream: the draw of wl_drift_rollout_policy
+        reinterpret_cast<float2*>(actions)[r_out] = make_float2(fmaf(std0, z0[q], out[0]), fmaf(std1, z1[q], out[1]));
+        reinterpret_cast<float2*>(mu_out)[r_out] = make_float2(out[0], out[1]);
+        log_prob[r_out] = fmaf(-0.5f, fmaf(z0[q], z0[q], z1[q] * z1[q]), -(log_fast(std0) + log_fast(std1)) - kLog2PiA);
+    }
+}
+
+int check_wide(const WlMlp* net, int out_dim) {
+    if (!net || !net->w1 || !net->b1 || !net->w2 || !net->b2 || !net->w3 || !net->b3) return WL_EINVAL;
+    if (net->hidden != kMlpHidden || net->in_dim < 1 || net->in_dim > (1 << 20) || net->out_dim != out_dim) return WL_EINVAL;
+    if (net->activation != WL_ACT_RELU && net->activation != WL_ACT_ELU) return WL_EINVAL;
+    return WL_OK;
+}
+
+template <int ACT, int RT>
+void launch_act(int ks, int row_blocks, hipStream_t s, const WlMlp& a, const WlMlp& c, const float* std, int n_rows,
+                const float* obs, int64_t obs_stride, float* actions, float* mu, float* log_prob, float* values, int env_offset,
+                uint64_t seed, uint64_t step, int deterministic) {
+    const dim3 grid(row_blocks, 2);
+#define WL_LAUNCH_ACT(KS)                                                                                                      \
+    actor_critic_act_kernel<ACT, KS, RT><<<grid, 64 * KS, 0, s>>>(a, c, std, n_rows, obs, obs_stride, actions, mu, log_prob,    \
+                                                                   values, env_offset, seed, step, deterministic)
+    if (ks >= 4) WL_LAUNCH_ACT(4);
+    else if (ks == 2) WL_LAUNCH_ACT(2);
+    else WL_LAUNCH_ACT(1);
+#undef WL_LAUNCH_ACT
+}
+
+}  // namespace
+
+extern "C" {
+
+int wl_actor_critic_act(const WlMlp* actor, const WlMlp* critic, const float* std, int32_t n_rows, const float* obs,
+                        int64_t obs_stride, float* actions, float* mu, float* log_prob, float* values, int32_t env_offset,
+                        uint64_t seed, uint64_t step, int32_t deterministic, void* stream) {
+    int rc = check_wide(actor, 2);
+    if (rc == WL_OK) rc = check_wide(critic, 1);
+    if (rc != WL_OK) return rc;
+    if (actor->in_dim != critic->in_dim || actor->activation != critic->activation) return WL_EINVAL;
+    if (!std || n_rows <= 0 || !obs || obs_stride < actor->in_dim || !actions || !mu || !log_prob || !values) return WL_EINVAL;
+    if (((uintptr_t)actions & 7u) || ((uintptr_t)mu & 7u) || ((uintptr_t)obs & 3u)) return WL_EALIGN;
+    clear_error();
+    const int tiles = (n_rows + 15) / 16;
+    // two row tiles per wavefront once there are enough tiles; then split the features over up to 4 wavefronts as long as
+    // that adds wavefronts the 1024 SIMDs can use and leaves each at least ~8 chunks of 16 features
+    const int rt = tiles >= 128 ? 2 : 1;
+    const int row_blocks = (tiles + rt - 1) / rt;
+    int ks = 1;
+    while (ks < 4 && row_blocks * 2 * ks < 1024 && (actor->in_dim >> 4) / (ks * 2) >= 8) ks *= 2;
+    const bool elu = actor->activation == WL_ACT_ELU;
+#define WL_ACT_ARGS ks, row_blocks, (hipStream_t)stream, *actor, *critic, std, n_rows, obs, obs_stride, actions, mu, log_prob, values, \
+                    env_offset, seed, step, deterministic
+    if (rt == 2) {
+        if (elu) launch_act<WL_ACT_ELU, 2>(WL_ACT_ARGS);
+        else launch_act<WL_ACT_RELU, 2>(WL_ACT_ARGS);
+    } else {
+        if (elu) launch_act<WL_ACT_ELU, 1>(WL_ACT_ARGS);
+        else launch_act<WL_ACT_RELU, 1>(WL_ACT_ARGS);
+    }
+#undef WL_ACT_ARGS
+    return launch_status();
+}
+
+}  // extern "C"

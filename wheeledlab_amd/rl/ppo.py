@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from .. import dist as D
+from ..policy import ActorCritic as _KernelActorCritic
 from ..policy import Mlp, RolloutStorage
 
 _ACT = {"elu": nn.ELU, "relu": nn.ReLU, "tanh": nn.Tanh}
@@ -86,11 +87,16 @@ class ActorCritic(nn.Module):
             return len(lin) == 3 and lin[0].out_features == 64 and lin[1].out_features == 64 and lin[0].in_features <= 15
         return self.activation in ("elu", "relu") and ok(self.actor) and ok(self.critic) and self.std.is_cuda
 
+    def act_fusable(self) -> bool:
+        """the policy step as ONE launch (wl_actor_critic_act): [64, 64] elu / relu MLPs of any input width on a GPU"""
+        def ok(seq, out):
+            lin = [m for m in seq if isinstance(m, nn.Linear)]
+            return len(lin) == 3 and lin[0].out_features == 64 and lin[1].out_features == 64 and lin[2].out_features == out
+        return self.activation in ("elu", "relu") and ok(self.actor, 2) and ok(self.critic, 1) and self.std.is_cuda
+
     def fused(self):
         if self._fused is None:
-            class _View:
-                pass
-            v = _View()
+            v = _KernelActorCritic.__new__(_KernelActorCritic)   # a kernel-side view: aliases the Parameters, owns nothing
             v.actor = Mlp.from_sequential(self.actor, self.activation, self.std.device)
             v.critic = Mlp.from_sequential(self.critic, self.activation, self.std.device)
             v.std = self.std.detach()
@@ -238,7 +244,8 @@ class PPO:
 class OnPolicyRunner:
     """rsl_rl OnPolicyRunner / the reference's ModifiedRslRunner work-alike around a RslRlVecEnvWrapper"""
 
-    def __init__(self, env, train_cfg, log_dir: str | None = None, device=None, fused: bool | None = None):
+    def __init__(self, env, train_cfg, log_dir: str | None = None, device=None, fused: bool | None = None,
+                 kernel_policy: bool | None = None):
         cfg = train_cfg.to_dict() if hasattr(train_cfg, "to_dict") else dict(train_cfg)
         self.cfg, self.env, self.log_dir = cfg, env, log_dir
         self.device = torch.device(device or env.device)
@@ -257,6 +264,11 @@ class OnPolicyRunner:
         if fused and not can_fuse:
             raise ValueError("fused collection needs the drift task, [64, 64] elu/relu MLPs and only built-in reward terms")
         self.fused = can_fuse if fused is None else bool(fused)
+        # per-step collection (every task, any observation width): the policy step as one launch (wl_actor_critic_act)
+        can_act = self.device.type == "cuda" and self.actor_critic.act_fusable() and hasattr(base, "_batch")
+        if kernel_policy and not can_act:
+            raise ValueError("kernel_policy needs [64, 64] elu / relu MLPs with 2 actions on a GPU")
+        self.kernel_policy = can_act if kernel_policy is None else bool(kernel_policy)
         self.storage = RolloutStorage(self.num_steps_per_env, env.num_envs, env.num_obs, env.num_actions, self.device)
         self.current_learning_iteration = 0
         # one process per GPU: every rank runs this loop on its own env shard with identical parameters (same seed, gradient
@@ -272,13 +284,23 @@ class OnPolicyRunner:
 
     def _collect_stepwise(self, obs):
         st, ac = self.storage, self.actor_critic
+        # the policy step as one launch for any observation width (elevation 689, visual 3208): actor, sampling, log-prob
+        # and the critic's value straight into the storage rows
+        one_launch = self.kernel_policy
+        view = ac.fused() if one_launch else None
+        batch = getattr(self.env.unwrapped, "_batch", None)
         with torch.inference_mode():
             for k in range(self.num_steps_per_env):
                 st.observations[k].copy_(obs)
-                a = ac.act(obs)
-                st.actions[k].copy_(a)
-                st.mu[k].copy_(ac.action_mean)
-                st.actions_log_prob[k].copy_(ac.get_actions_log_prob(a))
+                if one_launch:
+                    view.act(st.observations[k], st.actions[k], st.mu[k], st.actions_log_prob[k], st.values[k], batch.seed,
+                             batch.step_count, batch.env_offset)
+                    a = st.actions[k]
+                else:
+                    a = ac.act(obs)
+                    st.actions[k].copy_(a)
+                    st.mu[k].copy_(ac.action_mean)
+                    st.actions_log_prob[k].copy_(ac.get_actions_log_prob(a))
                 obs, rew, dones, infos = self.env.step(a)
                 st.rewards[k].copy_(rew)
                 st.dones[k].copy_(dones)
@@ -286,7 +308,10 @@ class OnPolicyRunner:
                 st.terminated[k].copy_((dones != 0) & ~st.time_outs[k])
             st.observations[self.num_steps_per_env].copy_(obs)
             K, n = st.n_steps, st.n_envs
-            st.values.copy_(ac.evaluate(st.observations.reshape((K + 1) * n, -1)).reshape(K + 1, n))
+            if one_launch:
+                st.values[K].copy_(ac.evaluate(obs).reshape(n))
+            else:
+                st.values.copy_(ac.evaluate(st.observations.reshape((K + 1) * n, -1)).reshape(K + 1, n))
         return obs
 
     # ---- the learning loop (modified_rsl_rl_runner.py:34-128) ----------------------------------------------
