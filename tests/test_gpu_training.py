@@ -148,3 +148,62 @@ def test_checkpoint_resume_and_stepwise_collection(tmp_path):
 def _filled_storage(runner):
     runner.env.unwrapped.rollout_policy(runner.actor_critic.fused(), runner.storage)
     return runner.storage
+
+
+@pytest.mark.parametrize("task,n,K", [("Isaac-MushrElevationRL-v0", 192, 12), ("Isaac-MushrVisualRL-v0", 96, 6),
+                                      ("Isaac-MushrDriftRL-v0", 320, 260)])
+def test_in_place_collection_equals_stepping_through_the_wrapper(task, n, K):
+    """env.collect_step (policy kernel + fused step writing straight into the storage rows) against the same loop driven
+    through RslRlVecEnvWrapper.step with copies: identical storage (same kernels, same (seed, env, step) keys), identical
+    counters and curriculum state"""
+    import wheeledlab_amd.tasks  # noqa: F401
+    from wheeledlab_amd import registry
+    from wheeledlab_amd.policy import RolloutStorage
+    from wheeledlab_amd.rl import ClipAction, RslRlVecEnvWrapper
+    from wheeledlab_amd.rl.ppo import ActorCritic
+
+    def make():
+        cfg = registry.parse_env_cfg(task, device=DEV, num_envs=n)
+        cfg.seed = 7
+        env = registry.make(task, cfg=cfg)
+        env.action_space.low, env.action_space.high = -1.0, 1.0
+        return RslRlVecEnvWrapper(ClipAction(env))
+
+    ea, eb = make(), make()
+    D = ea.num_obs
+    torch.manual_seed(1)
+    ac = ActorCritic(D, D, 2, activation="relu").to(DEV)
+    view = ac.fused()
+    sa, sb = RolloutStorage(K, n, D, 2, DEV), RolloutStorage(K, n, D, 2, DEV)
+    obs_a, _ = ea.get_observations()
+    obs_b, _ = eb.get_observations()
+    assert torch.equal(obs_a, obs_b)
+    base = ea.unwrapped
+    sa.observations[0].copy_(obs_a)
+    torch.manual_seed(99)     # the visual task draws its per-step augmentation from the host generator
+    for k in range(K):
+        base.collect_step(view, sa, k)
+    base.finish_collection(sa)
+    bb = eb.unwrapped._batch
+    obs = obs_b
+    torch.manual_seed(99)
+    for k in range(K):
+        sb.observations[k].copy_(obs)
+        view.act(sb.observations[k], sb.actions[k], sb.mu[k], sb.actions_log_prob[k], sb.values[k], bb.seed, bb.step_count,
+                 bb.env_offset)
+        obs, rew, dones, infos = eb.step(sb.actions[k])
+        sb.rewards[k].copy_(rew)
+        sb.dones[k].copy_(dones)
+        sb.time_outs[k].copy_(infos["time_outs"])
+    sb.observations[K].copy_(obs)
+    torch.cuda.synchronize()
+    for name in ("observations", "actions", "mu", "actions_log_prob", "rewards", "dones", "time_outs"):
+        assert torch.equal(getattr(sa, name), getattr(sb, name)), name
+    assert torch.equal(sa.values[:K], sb.values[:K])
+    # the kernel's `terminated` is the raw flag (an env may run out of bounds on its time-out step)
+    assert torch.equal(sa.terminated | sa.time_outs, sb.dones != 0) and bool((sa.terminated >= ((sb.dones != 0) & ~sb.time_outs)).all())
+    assert ea.unwrapped.common_step_counter == eb.unwrapped.common_step_counter == K
+    assert torch.equal(ea.get_observations()[0], eb.get_observations()[0])
+    if task == "Isaac-MushrDriftRL-v0":   # the curriculum fired at the 250-step boundary in both
+        wa = ea.unwrapped.reward_manager.get_term_cfg("side_slip").weight
+        assert wa == eb.unwrapped.reward_manager.get_term_cfg("side_slip").weight

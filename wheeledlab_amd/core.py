@@ -146,13 +146,15 @@ class DriftBatch(_MetricsView):
         return self.obs, self.reward, self.terminated, self.truncated
 
     def rollout(self, actions: torch.Tensor, obs_out: torch.Tensor | None = None, rew_out: torch.Tensor | None = None,
-                term_out: torch.Tensor | None = None, trunc_out: torch.Tensor | None = None, persistent: bool = False):
+                term_out: torch.Tensor | None = None, trunc_out: torch.Tensor | None = None, persistent: bool = False,
+                dones_out: torch.Tensor | None = None):
         """K fused steps with pre-staged actions [K,n,2]; optional [K,...] output storage (else overwrite).
         persistent=True runs them as ONE launch with the state held in registers (wl_drift_rollout_persistent)."""
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
         if obs_out is not None:
-            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(), None)
+            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(),
+                              None if dones_out is None else dones_out.data_ptr())
             os_, vs_ = self.n * self.OBS_DIM, self.n
         else:
             out, os_, vs_ = self._out, 0, 0
@@ -266,11 +268,12 @@ class ElevBatch(_MetricsView):
         self.step_count += 1
         return self.obs, self.reward, self.terminated, self.truncated
 
-    def rollout(self, actions: torch.Tensor, obs_out=None, rew_out=None, term_out=None, trunc_out=None):
+    def rollout(self, actions: torch.Tensor, obs_out=None, rew_out=None, term_out=None, trunc_out=None, dones_out=None):
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
         if obs_out is not None:
-            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(), None)
+            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(),
+                              None if dones_out is None else dones_out.data_ptr())
             os_, vs_ = self.n * self.OBS_DIM, self.n
         else:
             out, os_, vs_ = self._out, 0, 0
@@ -359,11 +362,12 @@ class VisualBatch(_MetricsView):
         self.step_count += 1
         return self.obs, self.reward, self.terminated, self.truncated
 
-    def rollout(self, actions: torch.Tensor, obs_out=None, rew_out=None, term_out=None, trunc_out=None):
+    def rollout(self, actions: torch.Tensor, obs_out=None, rew_out=None, term_out=None, trunc_out=None, dones_out=None):
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
         if obs_out is not None:
-            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(), None)
+            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(),
+                              None if dones_out is None else dones_out.data_ptr())
             os_, vs_ = self.n * self.OBS_DIM, self.n
         else:
             out, os_, vs_ = self._out, 0, 0

@@ -322,6 +322,38 @@ class ManagerBasedRLEnv:
         self.obs_buf = {"policy": obs}
         return self.obs_buf, rew, terminated, truncated, self.extras
 
+    def collect_step(self, actor_critic, storage, k: int):
+        """One { policy step -> env.step } of the runner's collection loop (modified_rsl_rl_runner.py:70-80) with every
+        output written IN PLACE into the storage: actions / mu / log-prob / value of row k from observation row k
+        (wl_actor_critic_act, any observation width), then the fused step's observation into row k + 1 and reward / flags /
+        dones into row k -- two or three launches per step, no copies.  Counters, curriculum and the episode log behave as
+        in step(); call finish_collection() after the last step."""
+        if self._has_custom_rewards:
+            raise ValueError("custom (torch) reward terms run between steps; use step()")
+        b = self._batch
+        a = storage.actions[k]
+        actor_critic.act(storage.observations[k], a, storage.mu[k], storage.actions_log_prob[k], storage.values[k], b.seed,
+                         b.step_count, b.env_offset)
+        self.action_manager.prev_action = a
+        if self._task == "visual" and self._flat.extra.get("augment"):
+            b.sample_augmentation()
+        b.rollout(storage.actions[k:k + 1], storage.observations[k + 1:k + 2], storage.rewards[k:k + 1],
+                  storage.terminated[k:k + 1], storage.time_outs[k:k + 1], dones_out=storage.dones[k:k + 1])
+        self.common_step_counter += 1
+        self._sim_step_counter += self.cfg.decimation
+        if self._has_curriculum and self.common_step_counter % self.max_episode_length == 0:
+            if bool(storage.dones[k].any()):
+                for name, term in self._flat.curriculum:
+                    term.func(self, None, **term.params)
+
+    def finish_collection(self, storage, n_steps: int | None = None):
+        """after the last collect_step(): the env's own observation buffer and episode log catch up with the storage"""
+        b, K = self._batch, storage.n_steps if n_steps is None else n_steps
+        b.obs.copy_(storage.observations[K])
+        self.obs_buf = {"policy": b.obs}
+        self.extras["log"] = self._episode_log(None) if b.metrics_slots == 1 else EpisodeLog(
+            self.episode_metrics(window=K, reduce_ranks=False), None, self._log_keys, self.max_episode_length_s)
+
     def rollout_policy(self, actor_critic, storage):
         """storage.n_steps x { actor -> sample -> env.step } in fused launches (drift task): the collection loop of the
         reference's runner (modified_rsl_rl_runner.py:70-80).  `actor_critic` exposes `.actor`, `.critic` (policy.Mlp)

@@ -288,7 +288,18 @@ class OnPolicyRunner:
         # and the critic's value straight into the storage rows
         one_launch = self.kernel_policy
         view = ac.fused() if one_launch else None
-        batch = getattr(self.env.unwrapped, "_batch", None)
+        base = self.env.unwrapped
+        batch = getattr(base, "_batch", None)
+        if one_launch and hasattr(base, "collect_step") and not getattr(base, "_has_custom_rewards", False):
+            # every output straight into the storage rows: per step one policy launch + the env's own launches, no copies
+            with torch.inference_mode():
+                st.observations[0].copy_(obs)
+                for k in range(self.num_steps_per_env):
+                    base.collect_step(view, st, k)
+                base.finish_collection(st)
+                obs = st.observations[self.num_steps_per_env]
+                st.values[self.num_steps_per_env].copy_(ac.evaluate(obs).reshape(st.n_envs))
+            return obs
         with torch.inference_mode():
             for k in range(self.num_steps_per_env):
                 st.observations[k].copy_(obs)
