@@ -207,3 +207,25 @@ def test_in_place_collection_equals_stepping_through_the_wrapper(task, n, K):
     if task == "Isaac-MushrDriftRL-v0":   # the curriculum fired at the 250-step boundary in both
         wa = ea.unwrapped.reward_manager.get_term_cfg("side_slip").weight
         assert wa == eb.unwrapped.reward_manager.get_term_cfg("side_slip").weight
+
+
+def test_chunked_weight_gradients_equal_the_blas_ones():
+    """_TallLinear (dW as one batched GEMM over 64 row chunks + a sum) against plain nn.Linear autograd on the same
+    minibatch: same loss, gradients equal to fp32 summation order (1e-5 of each tensor's scale)"""
+    from wheeledlab_amd.rl.ppo import ActorCritic
+    B, D = 32768, 689
+    torch.manual_seed(0)
+    ac = ActorCritic(D, D, 2, activation="relu").to(DEV)
+    obs = torch.randn(B, D, device=DEV)
+    act = torch.randn(B, 2, device=DEV)
+    grads = []
+    for tall in (True, False):
+        ac.tall_linear = tall
+        ac.zero_grad(set_to_none=True)
+        ac.update_distribution(obs)
+        loss = -ac.get_actions_log_prob(act).mean() + ac.evaluate(obs).square().mean()
+        loss.backward()
+        grads.append((float(loss), [p.grad.clone() for p in ac.parameters()]))
+    assert abs(grads[0][0] - grads[1][0]) < 1e-6 * abs(grads[1][0])
+    for a, b in zip(grads[0][1], grads[1][1]):
+        torch.testing.assert_close(a, b, rtol=0, atol=1e-5 * float(b.abs().max()) + 1e-9)
