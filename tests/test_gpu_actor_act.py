@@ -22,7 +22,7 @@ def _nets(D, activation, seed):
 
 
 @pytest.mark.parametrize("activation", ["elu", "relu"])
-@pytest.mark.parametrize("D,n", [(689, 4096), (3208, 512), (689, 100), (3208, 4096), (14, 300), (16, 64), (33, 17), (1, 5)])
+@pytest.mark.parametrize("D,n", [(689, 4096), (3208, 512), (689, 100), (3208, 4096), (689, 16401), (14, 300), (16, 64), (33, 17), (1, 5)])
 def test_policy_step_matches_oracle(D, n, activation):
     ac, actor_np, critic_np = _nets(D, activation, seed=D + n)
     g = torch.Generator(device=DEV).manual_seed(1)

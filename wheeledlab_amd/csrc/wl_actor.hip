@@ -265,16 +265,19 @@ int wl_actor_critic_act(const WlMlp* actor, const WlMlp* critic, const float* st
     if (((uintptr_t)actions & 7u) || ((uintptr_t)mu & 7u) || ((uintptr_t)obs & 3u)) return WL_EALIGN;
     clear_error();
     const int tiles = (n_rows + 15) / 16;
-    // two row tiles per wavefront once there are enough tiles; then split the features over up to 4 wavefronts as long as
+    // two (four) row tiles per wavefront once there are enough tiles; then split the features over up to 4 wavefronts as long as
     // that adds wavefronts the 1024 SIMDs can use and leaves each at least ~8 chunks of 16 features
-    const int rt = tiles >= 128 ? 2 : 1;
+    const int rt = tiles >= 1024 ? 4 : tiles >= 128 ? 2 : 1;
     const int row_blocks = (tiles + rt - 1) / rt;
     int ks = 1;
     while (ks < 4 && row_blocks * 2 * ks < 1024 && (actor->in_dim >> 4) / (ks * 2) >= 8) ks *= 2;
     const bool elu = actor->activation == WL_ACT_ELU;
 #define WL_ACT_ARGS ks, row_blocks, (hipStream_t)stream, *actor, *critic, std, n_rows, obs, obs_stride, actions, mu, log_prob, values, \
                     env_offset, seed, step, deterministic
-    if (rt == 2) {
+    if (rt == 4) {
+        if (elu) launch_act<WL_ACT_ELU, 4>(WL_ACT_ARGS);
+        else launch_act<WL_ACT_RELU, 4>(WL_ACT_ARGS);
+    } else if (rt == 2) {
         if (elu) launch_act<WL_ACT_ELU, 2>(WL_ACT_ARGS);
         else launch_act<WL_ACT_RELU, 2>(WL_ACT_ARGS);
     } else {
