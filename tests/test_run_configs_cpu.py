@@ -42,3 +42,17 @@ def test_unknown_keys_and_malformed_overrides_fail_loudly():
         resolve_run("RSS_DRIFT_CONFIG", ["train.num_iterations"])
     with pytest.raises(KeyError):
         apply_override(resolve_run("RSS_DRIFT_CONFIG"), "train.nope", 1)
+
+
+def test_every_registered_run_dumps_to_yaml():
+    """train_rl.py writes run_config.yaml for every logged run (train_rl.py:62-64 of the reference): to_dict() must cope with
+    class- and function-valued fields (term functions, action classes, nested config classes held as types)"""
+    import json
+
+    import yaml
+
+    from wheeledlab_amd.configs.runs import resolve_run
+    for name in ("RSS_DRIFT_CONFIG", "RSS_ELEV_CONFIG", "RSS_VISUAL_CONFIG", "F1TENTH_DRIFT_CONFIG"):
+        d = resolve_run(name, []).to_dict()
+        text = yaml.safe_dump(json.loads(json.dumps(d, default=str)))
+        assert "num_envs" in text and "learning_rate" in text, name

@@ -57,17 +57,17 @@ def configclass(cls):
         return new
 
     def to_dict(self):
-        out = {}
-        for k, v in self.__dict__.items():
+        def plain(v):
+            if isinstance(v, type) or (callable(v) and not hasattr(v, "to_dict")):   # a class / function held as a value
+                return f"{getattr(v, '__module__', '')}:{getattr(v, '__qualname__', repr(v))}"
             if hasattr(v, "to_dict"):
-                out[k] = v.to_dict()
-            elif callable(v) and not isinstance(v, type):
-                out[k] = f"{getattr(v, '__module__', '')}:{getattr(v, '__qualname__', repr(v))}"
-            elif isinstance(v, dict):
-                out[k] = {kk: (vv.to_dict() if hasattr(vv, "to_dict") else vv) for kk, vv in v.items()}
-            else:
-                out[k] = v
-        return out
+                return v.to_dict()
+            if isinstance(v, dict):
+                return {kk: plain(vv) for kk, vv in v.items()}
+            if isinstance(v, (list, tuple)):
+                return type(v)(plain(x) for x in v)
+            return v
+        return {k: plain(v) for k, v in self.__dict__.items()}
 
     def __repr__(self):
         body = ", ".join(f"{k}={v!r}" for k, v in self.__dict__.items())
