@@ -121,3 +121,13 @@ def test_vectorised_episode_bookkeeping_equals_the_runners_per_step_loop():
         got_l += b.tolist()
     assert torch.allclose(torch.tensor(got_r), torch.tensor(want_r), atol=1e-5) and got_l == want_l
     assert torch.allclose(cr, r0, atol=1e-5) and torch.equal(cl, l0)
+
+
+def test_runner_raises_on_non_finite_actions():
+    """the reference runner's only runtime guard (modified_rsl_rl_runner.py:74-75)"""
+    import pytest
+    runner = OnPolicyRunner(_ToyEnv(seed=0), CFG, device="cpu")
+    with torch.no_grad():
+        runner.actor_critic.actor[-1].bias.fill_(float("nan"))
+    with pytest.raises(ValueError, match="non-finite"):
+        runner.learn(1, verbose=False)

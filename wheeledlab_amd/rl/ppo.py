@@ -383,6 +383,10 @@ class OnPolicyRunner:
             # book keeping of finished episodes (runner :88-98 does it per step with a host sync each): here the whole
             # rollout at once with cumulative sums, one device->host copy of the finished episodes' returns / lengths
             with torch.no_grad():
+                # the runner's runtime guard (modified_rsl_rl_runner.py:74-75: "NaN in actions"), once per rollout instead
+                # of a host round trip per step
+                if not bool(torch.isfinite(st.actions).all()):
+                    raise ValueError(f"non-finite values in the actions of iteration {it} (diverged policy?)")
                 ret, length, cur_reward_sum, cur_episode_length = _finished_episodes(st.rewards, st.dones != 0, cur_reward_sum,
                                                                                      cur_episode_length)
                 rewbuffer.extend(ret[-100:].tolist())
