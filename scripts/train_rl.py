@@ -21,6 +21,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def checkpoint_path(logs_dir: str, load_run: str, load_run_checkpoint: int = 0) -> str:
+    """train_rl.py:99-106 of the reference (IsaacLab get_checkpoint_path): `load_run` names a run directory under the logs
+    directory (a regex, the last match in sorted order wins), the checkpoint is models/model_<load_run_checkpoint>.pt or,
+    for 0, the highest-numbered model_*.pt; a path to a checkpoint file is taken as it is."""
+    import re
+    if os.path.isfile(load_run):
+        return load_run
+    runs = sorted(d for d in (os.listdir(logs_dir) if os.path.isdir(logs_dir) else []) if re.fullmatch(load_run, d)
+                  and os.path.isdir(os.path.join(logs_dir, d)))
+    if not runs:
+        raise FileNotFoundError(f"no run matching '{load_run}' under {logs_dir}")
+    models = os.path.join(logs_dir, runs[-1], "models")
+    number = str(load_run_checkpoint) if load_run_checkpoint > 0 else r"\d+"
+    pat = re.compile(r"model_(" + number + r")\.pt")
+    files = [(int(m.group(1)), f) for f in (os.listdir(models) if os.path.isdir(models) else []) if (m := pat.fullmatch(f))]
+    if not files:
+        raise FileNotFoundError(f"no checkpoint matching '{pat.pattern}' in {models}")
+    return os.path.join(models, max(files)[1])
+
+
 def main():
     ap = argparse.ArgumentParser(description="Train an RL agent on the MI355X-native WheeledLab envs.")
     ap.add_argument("-r", "--run-config-name", default="RSS_DRIFT_CONFIG")
@@ -63,7 +83,10 @@ def main():
     runner = OnPolicyRunner(env, agent_cfg, log_dir=None if log_cfg.no_checkpoints else log_dir, device=train_cfg.device,
                             fused=False if args.stepwise else None, kernel_policy=False if args.torch_policy else None)
     if train_cfg.load_run is not None:
-        runner.load(train_cfg.load_run)
+        resume_path = checkpoint_path(log_cfg.logs_dir, train_cfg.load_run, train_cfg.load_run_checkpoint)
+        if rank == 0 and not args.quiet:
+            print(f"[INFO]: Loading model checkpoint from: {resume_path}")
+        runner.load(resume_path)
     env.seed(agent_cfg.seed)
     env.unwrapped.common_step_counter = train_cfg.set_env_step       # for continuing curriculums (train_rl.py:113)
     hist = runner.learn(train_cfg.num_iterations, verbose=not args.quiet)

@@ -56,3 +56,28 @@ def test_every_registered_run_dumps_to_yaml():
         d = resolve_run(name, []).to_dict()
         text = yaml.safe_dump(json.loads(json.dumps(d, default=str)))
         assert "num_envs" in text and "learning_rate" in text, name
+
+
+def test_resume_checkpoint_is_found_by_run_name(tmp_path):
+    """train.load_run / train.load_run_checkpoint as in the reference (train_rl.py:99-106): run directory by (regex) name
+    under the logs directory, highest-numbered or the requested model_*.pt; a file path is taken as it is"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("train_rl", os.path.join(os.path.dirname(__file__), "..", "scripts", "train_rl.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for run, its in (("run-1", [0, 50]), ("run-2", [0, 100, 1000, 99])):
+        os.makedirs(tmp_path / run / "models")
+        for i in its:
+            (tmp_path / run / "models" / f"model_{i}.pt").touch()
+    d = str(tmp_path)
+    assert mod.checkpoint_path(d, "run-2").endswith("run-2/models/model_1000.pt")
+    assert mod.checkpoint_path(d, "run-.*", 100).endswith("run-2/models/model_100.pt")
+    assert mod.checkpoint_path(d, "run-1").endswith("run-1/models/model_50.pt")
+    f = str(tmp_path / "run-1" / "models" / "model_0.pt")
+    assert mod.checkpoint_path(d, f) == f
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        mod.checkpoint_path(d, "nope")
+    with pytest.raises(FileNotFoundError):
+        mod.checkpoint_path(d, "run-1", 7)
