@@ -46,6 +46,8 @@ def _worker(rank, world, port, out_dir):
     same, lr_same, w = _update(11, None)            # both ranks see rollout 11
     assert w == world
     diff, lr_diff, _ = _update(20 + rank, None)     # rollouts 20 / 21
+    # the end-of-run sync check of scripts/train_rl.py
+    assert D.ranks_agree(same) and D.ranks_agree(diff) and not D.ranks_agree(torch.full((3,), float(rank)))
     torch.save({"same": same, "lr_same": lr_same, "diff": diff, "lr_diff": lr_diff}, os.path.join(out_dir, f"r{rank}.pt"))
     torch.distributed.destroy_process_group()
 
