@@ -75,6 +75,23 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.wl_drift_step(C.byref(p), C.byref(b), None, None, C.byref(out), 0, 0, None) == -1
     assert lib.wl_action_map(C.byref(p.action), 0, None, None, None, None, None) == -1
     assert lib.wl_philox_uniform(0, 0, 0, 0, None, None) == -1
+    # rollout-side entry points: null nets / wrong shapes are refused before any launch
+    buf = (C.c_float * 8192)()
+    base = C.addressof(buf)
+    net = lambda i, o: A.WlMlp(base, base, base, base, base, base, i, o, 64, A.ACT_ELU)
+    actor, critic, null = net(689, 2), net(689, 1), A.WlMlp()
+    act = lib.wl_actor_critic_act
+    assert act(C.byref(null), C.byref(critic), base, 4, base, 689, base, base, base, base, 0, 0, 0, 0, None) == -1
+    assert act(C.byref(actor), C.byref(net(700, 1)), base, 4, base, 700, base, base, base, base, 0, 0, 0, 0, None) == -1   # widths differ
+    assert act(C.byref(actor), C.byref(critic), base, 4, base, 688, base, base, base, base, 0, 0, 0, 0, None) == -1          # stride < in_dim
+    assert act(C.byref(actor), C.byref(critic), base, 4, base, 689, base + 4, base, base, base, 0, 0, 0, 0, None) == -3      # actions not 8-byte aligned
+    hp, st = A.WlPpoParams(), A.WlPpoState()
+    small_a, small_c = net(14, 2), net(14, 1)
+    assert lib.wl_ppo_apply(C.byref(small_a), C.byref(small_c), base, 64, C.byref(hp), C.byref(st), 0, 1, None) == -1          # null state
+    st = A.WlPpoState(base, base, base, base, base, base)
+    assert lib.wl_ppo_apply(C.byref(small_a), C.byref(small_c), base, 64, C.byref(hp), C.byref(st), 2, 1, None) == -1          # parity
+    assert lib.wl_ppo_apply(C.byref(small_a), C.byref(small_c), base, 0, C.byref(hp), C.byref(st), 0, 1, None) == -1           # empty batch
+    assert lib.wl_ppo_apply(C.byref(actor), C.byref(critic), base, 64, C.byref(hp), C.byref(st), 0, 1, None) == -1             # not the 14-wide nets
 
 
 def test_layout_of_task_structs_and_misuse_codes(tmp_path):
