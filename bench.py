@@ -50,17 +50,23 @@ def pmc_traffic(n_envs: int):
 
 
 def cpu_baseline(n_envs: int, budget_s: float = 14.0):
-    """The same workload on the host cores: the numpy oracle's FULL drift env.step (oracle/drift_step.py: action term ->
-    4 integrator sub-steps of the vehicle model -> terminations -> rewards -> in-step reset -> noisy obs) on n_envs envs.
-    Beside it (`mdp_only`) the torch-CPU port of just the reference's mdp path (oracle/torch_mdp.py) -- the only part of
-    the step the reference itself computes outside PhysX."""
+    """The baseline BASELINE.json's north_star and SURVEY 8(d) name: the torch-CPU port of the reference's drift mdp path
+    (oracle/torch_mdp.py -- action term, terminations, rewards, noisy observation: what the reference itself computes
+    outside PhysX) on the GPU box's host cores.  Beside it (`full_step_oracle`) the numpy oracle's FULL env.step (the same
+    workload as the fused kernel: + 4 integrator sub-steps of the vehicle model + in-step reset) on one thread."""
+    host_cores = os.cpu_count() or 1
+    out = _cpu_mdp_only(n_envs, budget_s * 0.5, host_cores)
+    out["full_step_oracle"] = _cpu_full_step(n_envs, budget_s * 0.5, host_cores)
+    return out
+
+
+def _cpu_full_step(n_envs: int, budget_s: float, host_cores: int):
     import numpy as np
 
     from oracle import drift_reset as DR
     from oracle import drift_step as OS
     from oracle import params as OP
 
-    host_cores = os.cpu_count() or 1
     torch.set_num_threads(1)
     p = OP.drift_params()
     rng = np.random.RandomState(0)
@@ -72,16 +78,14 @@ def cpu_baseline(n_envs: int, budget_s: float = 14.0):
     OS.step(p, st, ep, ref, acts[0], 42, 0)
     t0 = time.perf_counter()
     k = 0
-    while time.perf_counter() - t0 < budget_s * 0.6:
+    while time.perf_counter() - t0 < budget_s:
         OS.step(p, st, ep, ref, acts[k % 8], 42, k + 1)
         k += 1
-    full_dt = time.perf_counter() - t0
-    full = {"value": n_envs * k / full_dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    dt = time.perf_counter() - t0
+    return {"value": n_envs * k / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": f"{k} full drift env.steps (4 sub-steps of the vehicle model + mdp terms + in-step reset + noisy "
                       f"obs) of the numpy oracle on {n_envs} envs, numpy {np.__version__}, 1 thread of a {host_cores}-core "
-                      f"host, {full_dt:.1f} s"}
-    full["mdp_only"] = _cpu_mdp_only(n_envs, budget_s * 0.4, host_cores)
-    return full
+                      f"host, {dt:.1f} s"}
 
 
 def _cpu_mdp_only(n_envs: int, budget_s: float, host_cores: int):
