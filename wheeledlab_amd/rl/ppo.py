@@ -7,10 +7,16 @@ with the agent cfgs under wheeledlab_tasks/*/config/agents): same class / method
 algorithm follows its published definition (clipped surrogate, clipped value loss, entropy bonus, adaptive-KL learning
 rate, GAE) and is restated independently for the tests in oracle/policy.py (GAE) -- parity with rsl_rl itself is unpinned.
 
-What is MI355X-specific: collection.  For the drift task the whole `num_steps_per_env` rollout (actor on the f32 matrix
-pipe -> sample -> env.step -> storage rows) is ONE launch (`wl_drift_rollout_policy`) plus one `wl_mlp_forward` for
-the critic; the actor / critic parameters the kernels read ARE the torch Parameters the optimiser updates in place.
-The gradient step itself is ordinary torch autograd on [K * n, 14] batches (plumbing: three small GEMMs per net).
+What is MI355X-specific:
+* collection, drift tasks: the whole `num_steps_per_env` rollout (actor on the f32 matrix pipe -> sample -> env.step ->
+  storage rows) is ONE launch (`wl_drift_rollout_policy`) plus one `wl_mlp_forward` for the critic;
+* collection, any task / observation width: per step one policy launch (`wl_actor_critic_act`) and the env's own launches,
+  every output written in place into the storage rows (`env.collect_step`);
+* the update, drift agents: the minibatch step (forward, losses, backward, clipping, adaptive-KL rule, Adam) in the HIP
+  library (`FusedPpoStep`: `wl_ppo_minibatch`, or `wl_ppo_gradients` -> all-reduce -> `wl_ppo_apply` when data-parallel);
+  other widths: torch autograd with the weight gradients of the tall minibatches as chunked batched GEMMs (`_TallLinear`);
+* the actor / critic parameters the kernels read ARE the torch Parameters (updated in place, rsl_rl's checkpoint keys).
+On a CPU (tests, gloo world-2) everything here runs as plain torch.
 """
 from __future__ import annotations
 
