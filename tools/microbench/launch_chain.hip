@@ -59,7 +59,15 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&s[1]));
     hipEvent_t e0, e1, fork, join;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&fork)); CK(hipEventCreate(&join));
-    for (int mode = 0; mode < 2; ++mode) {
+    // (C) the serial chain captured once into a hipGraph and replayed: does the graph executor close the gap between
+    // dependent kernel nodes?
+    hipGraph_t graph;
+    hipGraphExec_t gexec;
+    CK(hipStreamBeginCapture(s[0], hipStreamCaptureModeThreadLocal));
+    for (int k = 0; k < K; ++k) step_kernel<<<kBlocks, kThreads, 0, s[0]>>>(rows, flags, err, (unsigned)k, 0, chain_len);
+    CK(hipStreamEndCapture(s[0], &graph));
+    CK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    for (int mode = 0; mode < 3; ++mode) {
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipMemsetAsync(rows, 0, sizeof(float) * kRows * kN, s[0]));
             CK(hipMemsetAsync(flags, 0, sizeof(unsigned) * kBlocks, s[0]));
@@ -67,6 +75,8 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(e0, s[0]));
             if (mode == 0) {
                 for (int k = 0; k < K; ++k) step_kernel<<<kBlocks, kThreads, 0, s[0]>>>(rows, flags, err, (unsigned)k, 0, chain_len);
+            } else if (mode == 2) {
+                CK(hipGraphLaunch(gexec, s[0]));
             } else {
                 CK(hipEventRecord(fork, s[0]));
                 CK(hipStreamWaitEvent(s[1], fork, 0));
@@ -86,7 +96,8 @@ int main(int argc, char** argv) {
             long bad = 0;
             for (int r = 0; r < kRows; ++r)
                 for (int i = 0; i < kN; ++i) bad += h[r * kN + i] != (float)(K * (r + 1));
-            printf("%s rep %d: %.2f us per step, %ld wrong values, %u spin time-outs\n", mode ? "chained 2-stream" : "serial 1-stream", rep,
+            printf("%s rep %d: %.2f us per step, %ld wrong values, %u spin time-outs\n",
+                   mode == 0 ? "serial 1-stream" : mode == 1 ? "chained 2-stream" : "hipGraph replay ", rep,
                    ms * 1e3 / K, bad, herr);
         }
     }
