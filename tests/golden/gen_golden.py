@@ -14,7 +14,8 @@ therefore "parity unpinned" -- see DESIGN.md).  Every arithmetic line that the r
 (reward / termination / observation / action-term / reset / curriculum / traversability functions) is
 executed from the reference's files.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py      (WL_GOLDEN_OUT=<dir> writes there instead;
+tests/test_oracle_golden_drift.py::test_committed_vectors_regenerate_from_the_reference does that and compares)
 """
 import sys
 
@@ -30,7 +31,7 @@ import numpy as np
 import torch
 
 REF = "/root/reference/source"
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("WL_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))   # WL_GOLDEN_OUT: regenerate elsewhere
 
 # --------------------------------------------------------------------------------------------------
 # 1. stub namespace

@@ -1,6 +1,8 @@
 """Pin the oracle (numpy restatement) to the golden vectors produced by the reference's own functions
 (tests/golden/gen_golden.py).  CPU only.  Tolerances: float outputs 1e-6 abs + 1e-6 rel (both sides fp32,
 different libm paths for atan2/sqrt); boolean / integer outputs bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -104,3 +106,21 @@ def test_math_self_consistency():
     # identity -> zero angles; small negative yaw wraps to just below 2pi (reference quirk)
     _, _, yw = ml.euler_xyz_from_quat(ml.quat_from_euler_xyz(0.0, 0.0, -0.01)[None])
     assert abs(yw[0] - (2 * np.pi - 0.01)) < 1e-5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/source"), reason="the reference tree exists only in the authoring container")
+def test_committed_vectors_regenerate_from_the_reference(tmp_path):
+    """provenance of tests/golden/*.npz: running gen_golden.py (which imports the reference's own functions) again
+    reproduces every committed array exactly"""
+    import subprocess
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    env = dict(os.environ, WL_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    subprocess.run([sys.executable, os.path.join(here, "gen_golden.py")], check=True, env=env, capture_output=True, timeout=600)
+    names = sorted(f for f in os.listdir(here) if f.endswith(".npz"))
+    assert names == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) and len(names) == 8
+    for f in names:
+        a, b = np.load(os.path.join(here, f)), np.load(tmp_path / f)
+        assert set(a.files) == set(b.files), f
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), (f, k)
