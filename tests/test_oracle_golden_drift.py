@@ -124,3 +124,20 @@ def test_committed_vectors_regenerate_from_the_reference(tmp_path):
         assert set(a.files) == set(b.files), f
         for k in a.files:
             assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), (f, k)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/source"), reason="the reference tree exists only in the authoring container")
+@pytest.mark.parametrize("offset", [1000, 2024])
+def test_oracle_matches_the_reference_on_fresh_seeds(tmp_path, offset):
+    """beyond the committed vectors: new states / actions / query points (every input seed shifted), pushed through the
+    reference's own functions by gen_golden.py, and the whole oracle-vs-golden suite run against those files"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, WL_GOLDEN_OUT=str(tmp_path), WL_GOLDEN_SEED_OFFSET=str(offset), PYTHONDONTWRITEBYTECODE="1")
+    subprocess.run([sys.executable, os.path.join(here, "golden", "gen_golden.py")], check=True, env=env, capture_output=True, timeout=600)
+    env = dict(os.environ, WL_GOLDEN_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(here, "test_oracle_golden_drift.py"),
+                        os.path.join(here, "test_oracle_golden_elev_visual.py"), "-k", "not regenerate and not fresh_seeds"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
