@@ -108,6 +108,30 @@ def test_math_self_consistency():
     assert abs(yw[0] - (2 * np.pi - 0.01)) < 1e-5
 
 
+def test_math_helpers_match_scipy_rotation():
+    """the IsaacLab helpers the reference relies on (quat_from_euler_xyz, matrix_from_quat, euler_xyz_from_quat,
+    quat_rotate / quat_rotate_inverse -- IsaacLab v2.0.2 is not vendored, so the oracle restates their published
+    definitions) against an independent implementation of the same convention: scipy's Rotation, extrinsic x-y-z
+    Euler angles, quaternion (w, x, y, z); fp32 rounding (2e-6), angles on the circle"""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.RandomState(0)
+    rpy = np.stack([rng.uniform(-1.4, 1.4, 1000), rng.uniform(-1.4, 1.4, 1000), rng.uniform(-3.1, 3.1, 1000)], -1)
+    ref = Rotation.from_euler("xyz", rpy)
+    q = ml.quat_from_euler_xyz(rpy[:, 0], rpy[:, 1], rpy[:, 2])
+    sq = ref.as_quat()                                   # scipy: (x, y, z, w)
+    sq = np.concatenate([sq[:, 3:4], sq[:, :3]], 1)
+    sign = np.sign((q * sq).sum(1))[:, None]             # q and -q are the same rotation
+    np.testing.assert_allclose(q, sign * sq, atol=2e-6)
+    np.testing.assert_allclose(ml.matrix_from_quat(q), ref.as_matrix(), atol=2e-6)
+    r, p, y = ml.euler_xyz_from_quat(q)
+    want = np.mod(Rotation.from_quat(np.concatenate([q[:, 1:], q[:, :1]], 1)).as_euler("xyz"), 2 * np.pi)
+    d = np.abs(np.stack([r, p, y], 1) - want)
+    assert np.minimum(d, 2 * np.pi - d).max() < 5e-6
+    v = rng.normal(size=(1000, 3))
+    np.testing.assert_allclose(ml.rotate(q, v), ref.apply(v), atol=5e-6)
+    np.testing.assert_allclose(ml.rotate_inverse(q, v), ref.inv().apply(v), atol=5e-6)
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/source"), reason="the reference tree exists only in the authoring container")
 def test_committed_vectors_regenerate_from_the_reference(tmp_path):
     """provenance of tests/golden/*.npz: running gen_golden.py (which imports the reference's own functions) again
