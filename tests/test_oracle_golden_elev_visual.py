@@ -52,3 +52,32 @@ def test_visual_terms_match_reference(golden):
     np.testing.assert_array_equal(V.forward_vel(g["lin_vel_b"]), g["forward_vel"])
     np.testing.assert_array_equal(V.out_of_map(g["pos"]), g["out_of_map"])
     np.testing.assert_array_equal(g["weights"], np.array([5.0, 7.0], np.float32))
+
+
+def test_camera_blur_matches_scipy_correlation():
+    """the GaussianBlur(5, sigma) restated from torchvision's published definition (torchvision is not installed; kernel
+    exp(-x^2 / 2 sigma^2) on x = -2..2, normalised; separable; reflect padding that does not repeat the edge) against an
+    independent implementation: scipy.ndimage.correlate1d in 'mirror' mode, on rendered camera images"""
+    import scipy.ndimage as ndi
+
+    from oracle import visual_step as VS
+    rng = np.random.RandomState(3)
+    trav = rng.rand(500, 500) < 0.5
+    n = 6
+    p = VS.visual_params()
+    st = VS.init_state(p, n)
+    st[VS.PX, :n], st[VS.PX + 1, :n], st[VS.PX + 2, :n] = rng.uniform(-50, 50, n), rng.uniform(-50, 50, n), 0.1
+    yaw = rng.uniform(0, 6.28, n)
+    st[VS.QW, :n], st[VS.QW + 3, :n] = np.cos(yaw / 2), np.sin(yaw / 2)
+    p.brightness = 0.9
+    plain = VS.camera(p, st[:, :n], trav)
+    img = ((plain * 0.5 + 0.5) / 0.9999).reshape(n, VS.IMG_H - VS.CROP, VS.IMG_W).astype(np.float64)
+    assert 0.2 < img.mean() < 0.8 and img.std() > 0.2          # a real image: road / off-road / sky
+    for sigma in (0.1, 0.7, 2.0, 5.0):
+        p.blur_sigma = sigma
+        got = VS.camera(p, st[:, :n], trav).reshape(n, VS.IMG_H - VS.CROP, VS.IMG_W)
+        x = np.arange(-2, 3, dtype=np.float64)
+        k = np.exp(-0.5 * (x / sigma) ** 2)
+        k /= k.sum()
+        want = ndi.correlate1d(ndi.correlate1d(img, k, axis=2, mode="mirror"), k, axis=1, mode="mirror")
+        np.testing.assert_allclose(got, (want * 0.9999 - 0.5) / 0.5, atol=3e-6)
