@@ -123,6 +123,24 @@ def test_philox_known_answers():
                                                                                              0x24126EA1]
 
 
+def test_noise_draws_are_uniform_and_standard_normal():
+    """what the observation-noise model (IsaacLab GaussianNoiseCfg, un-vendored: N(0, std)) needs from the generator:
+    u01 of the Philox words is U[0, 1) and the Box-Muller pairs are N(0, 1) -- Kolmogorov-Smirnov against scipy's
+    distributions on 2 x 10^5 draws, independent across envs / steps / streams (lag correlations)"""
+    from scipy import stats
+
+    from oracle import philox as PH
+    u = PH.uniform4(np.arange(50000), 5, 0, 42).reshape(-1)
+    assert u.min() >= 0.0 and u.max() < 1.0 and stats.kstest(u, "uniform").pvalue > 1e-3
+    z = PH.normal12(np.arange(20000), 7, 42)                       # [12, n]: the 12 observation-noise normals per env
+    assert stats.kstest(z.reshape(-1), "norm").pvalue > 1e-3
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
+    c = np.corrcoef(z)                                             # the 12 values of an env are mutually uncorrelated ...
+    assert np.abs(c - np.eye(12)).max() < 0.03
+    z2 = PH.normal12(np.arange(20000), 8, 42)                      # ... and so are consecutive steps and neighbouring envs
+    assert abs(np.corrcoef(z[0], z2[0])[0, 1]) < 0.03 and abs(np.corrcoef(z[0, :-1], z[0, 1:])[0, 1]) < 0.03
+
+
 def test_math_helpers_match_scipy_rotation():
     """the IsaacLab helpers the reference relies on (quat_from_euler_xyz, matrix_from_quat, euler_xyz_from_quat,
     quat_rotate / quat_rotate_inverse -- IsaacLab v2.0.2 is not vendored, so the oracle restates their published
