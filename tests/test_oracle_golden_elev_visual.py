@@ -81,3 +81,33 @@ def test_camera_blur_matches_scipy_correlation():
         k /= k.sum()
         want = ndi.correlate1d(ndi.correlate1d(img, k, axis=2, mode="mirror"), k, axis=1, mode="mirror")
         np.testing.assert_allclose(got, (want * 0.9999 - 0.5) / 0.5, atol=3e-6)
+
+
+def test_heightfield_sampling_matches_scipy_interpolation():
+    """the bilinear terrain sampler (designed: the reference's terrain mesh is missing) against scipy's independent
+    RegularGridInterpolator on the synthetic terrain: heights to fp32 rounding, normals against central differences of the
+    interpolant, outside-the-grid behaviour"""
+    from scipy.interpolate import RegularGridInterpolator
+
+    from oracle import heightfield as HF
+    hf, x0, y0, cell = HF.make_terrain()
+    n = hf.shape[0]
+    axis = np.float64(x0) + np.arange(n) * np.float64(cell)
+    interp = RegularGridInterpolator((axis, axis), hf.astype(np.float64), method="linear")      # indexed [iy, ix]
+    rng = np.random.RandomState(4)
+    x, y = rng.uniform(-19.9, 19.8, 5000), rng.uniform(-19.9, 19.8, 5000)
+    z, nrm, inside = HF.sample(hf, x0, y0, cell, x, y)
+    assert inside.all()
+    np.testing.assert_allclose(z, interp(np.stack([y, x], -1)), atol=5e-5)
+    # the normal is (-dz/dx, -dz/dy, 1) normalised: compare the slopes with differences taken inside one cell
+    u = (x - np.float64(x0)) / np.float64(cell)
+    v = (y - np.float64(y0)) / np.float64(cell)
+    mid = (np.abs(u - np.floor(u) - 0.5) < 0.3) & (np.abs(v - np.floor(v) - 0.5) < 0.3)
+    eps = 0.1 * np.float64(cell)
+    dzdx = (interp(np.stack([y, x + eps], -1)) - interp(np.stack([y, x - eps], -1))) / (2 * eps)
+    dzdy = (interp(np.stack([y + eps, x], -1)) - interp(np.stack([y - eps, x], -1))) / (2 * eps)
+    np.testing.assert_allclose((-nrm[:, 0] / nrm[:, 2])[mid], dzdx[mid], atol=2e-3)
+    np.testing.assert_allclose((-nrm[:, 1] / nrm[:, 2])[mid], dzdy[mid], atol=2e-3)
+    np.testing.assert_allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-6)
+    zo, no, ins = HF.sample(hf, x0, y0, cell, np.array([25.0, -21.0, 0.0]), np.array([0.0, 0.0, 30.0]), outside=0.19)
+    assert not ins.any() and np.allclose(zo, 0.19) and np.allclose(no, [0, 0, 1])
