@@ -101,3 +101,51 @@ def test_braking_is_friction_limited():
 def test_more_grip_more_acceleration():
     a = lambda mu: np.diff(np.hypot(*_run([1.0, 0.0], 40, mu=mu)[:, 7:9].T)).max() / 0.02
     assert a(0.5) > a(0.4) > a(0.3)
+
+
+def test_free_flight_converges_to_the_rigid_body_equations():
+    """airborne (no contact), the integrator must solve Euler's rigid-body equations + quaternion kinematics + gravity:
+    against scipy's solve_ivp (RK45, rtol 1e-10) of the same equations the state after 0.1 s agrees to the integrator's
+    first-order error, and that error halves when the step is halved"""
+    from scipy.integrate import solve_ivp
+
+    from oracle import vehicle as V
+    vp = P.drift_params().vehicle
+    n, T = 8, 0.1
+    rng = np.random.RandomState(1)
+    mass = np.full(n, 3.4, np.float32)
+    x0 = np.tile(np.array([0.0, 0.0, 5.0], np.float32), (n, 1))
+    q0 = rng.normal(size=(n, 4)).astype(np.float32)
+    q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+    v0 = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    w0 = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    I = 3.4 * np.array([vp.gyr_x ** 2, vp.gyr_y ** 2, vp.gyr_z ** 2])
+
+    def rhs(t, y):
+        q, wb = y[6:10], y[10:13]
+        qw, qx, qy, qz = q
+        R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                      [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                      [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+        ww = R @ wb
+        dq = 0.5 * np.array([-ww[0] * qx - ww[1] * qy - ww[2] * qz, ww[0] * qw + ww[1] * qz - ww[2] * qy,
+                             -ww[0] * qz + ww[1] * qw + ww[2] * qx, ww[0] * qy - ww[1] * qx + ww[2] * qw])
+        return np.concatenate([y[3:6], [0.0, 0.0, -vp.gravity], dq, -np.cross(wb, I * wb) / I])
+
+    exact = np.array([solve_ivp(rhs, (0, T), np.concatenate([x0[i], v0[i], q0[i], w0[i]]).astype(np.float64), rtol=1e-10,
+                                atol=1e-12).y[:, -1] for i in range(n)])
+
+    def integrate(h):
+        x, q, v, wb = x0.copy(), q0.copy(), v0.copy(), w0.copy()
+        wheel, th, om = np.zeros((n, 4), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        z = np.zeros(n, np.float32)
+        for _ in range(int(round(T / h))):
+            x, q, v, wb, wheel, th, om = V.substep(x, q, v, wb, wheel, th, om, z, np.zeros((n, 4), np.float32), mass,
+                                                   np.full(n, 0.4, np.float32), np.full(n, 0.4, np.float32), z + 30, vp, h)
+        sign = np.sign((q * exact[:, 6:10]).sum(1))[:, None]
+        return (np.abs(x - exact[:, 0:3]).max(), np.abs(v - exact[:, 3:6]).max(), np.abs(sign * q - exact[:, 6:10]).max(),
+                np.abs(wb - exact[:, 10:13]).max())
+
+    e1, e2 = integrate(0.005), integrate(0.0025)
+    assert max(e1) < 2e-2, e1                                  # first-order error of the 5 ms step over 0.1 s
+    assert e1[3] > 1e-4 and all(b < 0.62 * a + 2e-5 for a, b in zip(e1, e2)), (e1, e2)   # ~ halves with the step
