@@ -149,3 +149,29 @@ def test_free_flight_converges_to_the_rigid_body_equations():
     e1, e2 = integrate(0.005), integrate(0.0025)
     assert max(e1) < 2e-2, e1                                  # first-order error of the 5 ms step over 0.1 s
     assert e1[3] > 1e-4 and all(b < 0.62 * a + 2e-5 for a, b in zip(e1, e2)), (e1, e2)   # ~ halves with the step
+
+
+def test_steering_drive_converges_to_the_pd_joint_equation():
+    """the implicit PD steering drive (J theta'' = kp (target - theta) - kd theta', hound.py:5-12; very stiff: kd / J =
+    5e4 1/s) in its linear regime against scipy's stiff solver: a small step response agrees to first order in the step
+    length and the error halves with it; a step far beyond the steering range rides the 10 rad/s rate limit"""
+    from scipy.integrate import solve_ivp
+
+    from oracle import vehicle as V
+    vp = P.drift_params().vehicle
+    J, kp, kd = vp.steer_inertia, vp.steer_kp, vp.steer_kd
+    target, T = 0.02, 0.1
+    exact = solve_ivp(lambda t, y: [y[1], (kp * (target - y[0]) - kd * y[1]) / J], (0, T), [0.0, 0.0], method="Radau", rtol=1e-10,
+                      atol=1e-13).y[0, -1]
+
+    def run(h, tgt, t_end):
+        th, om = np.zeros(1, np.float32), np.zeros(1, np.float32)
+        for _ in range(int(round(t_end / h))):
+            th, om = V.steer_update(th, om, np.float32(tgt), vp, np.float32(h))
+        return float(th[0]), float(om[0])
+
+    e1, e2 = abs(run(0.005, target, T)[0] - exact), abs(run(0.0025, target, T)[0] - exact)
+    assert abs(exact - target * (1 - np.exp(-kp / kd * T))) < 2e-4 * target          # the slow pole kp / kd dominates
+    assert e1 < 0.03 * target and 0.4 * e1 < e2 < 0.62 * e1, (e1, e2, exact)
+    th, om = run(0.005, 2.0, 0.02)                       # a step far beyond the steering range: rides the rate limit
+    assert abs(om - vp.steer_vel_limit) < 1e-4 and abs(th - 0.02 * vp.steer_vel_limit) < 0.051
