@@ -264,10 +264,12 @@ int wl_drift_rollout_policy(const WlDriftParams* p, const WlEnvBuffers* b, const
  * first layers run as skinny GEMMs on the f32 matrix pipe (exact fp32 products and sums), the draw is keyed by
  * (seed, env_offset + row, step) on the policy stream -- the draw of wl_drift_rollout_policy -- or skipped
  * (deterministic != 0: a = mu, the play policy).  actions / mu are [n_rows][2] (8-byte aligned), log_prob / values [n_rows].
+ * `nets`: 3 = both, 1 = actor only (values may be NULL: the play policy), 2 = critic only (std / actions / mu / log_prob may
+ * be NULL: values of stored observations); the results do not depend on how the two halves are launched.
  */
 int wl_actor_critic_act(const WlMlp* actor, const WlMlp* critic, const float* std, int32_t n_rows, const float* obs,
                         int64_t obs_stride, float* actions, float* mu, float* log_prob, float* values, int32_t env_offset,
-                        uint64_t seed, uint64_t step, int32_t deterministic, void* stream);
+                        uint64_t seed, uint64_t step, int32_t deterministic, int32_t nets, void* stream);
 
 /* ---- PPO learner step of the drift agents ("on-device PPO for the 64-64 MLP") ------------
  * One minibatch step of rsl_rl's PPO.update (modified_rsl_rl_runner.py:104-109; rsl_rl_ppo_cfg.py:18-31) for the

@@ -81,10 +81,12 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     net = lambda i, o: A.WlMlp(base, base, base, base, base, base, i, o, 64, A.ACT_ELU)
     actor, critic, null = net(689, 2), net(689, 1), A.WlMlp()
     act = lib.wl_actor_critic_act
-    assert act(C.byref(null), C.byref(critic), base, 4, base, 689, base, base, base, base, 0, 0, 0, 0, None) == -1
-    assert act(C.byref(actor), C.byref(net(700, 1)), base, 4, base, 700, base, base, base, base, 0, 0, 0, 0, None) == -1   # widths differ
-    assert act(C.byref(actor), C.byref(critic), base, 4, base, 688, base, base, base, base, 0, 0, 0, 0, None) == -1          # stride < in_dim
-    assert act(C.byref(actor), C.byref(critic), base, 4, base, 689, base + 4, base, base, base, 0, 0, 0, 0, None) == -3      # actions not 8-byte aligned
+    assert act(C.byref(null), C.byref(critic), base, 4, base, 689, base, base, base, base, 0, 0, 0, 0, 3, None) == -1
+    assert act(C.byref(actor), C.byref(net(700, 1)), base, 4, base, 700, base, base, base, base, 0, 0, 0, 0, 3, None) == -1   # widths differ
+    assert act(C.byref(actor), C.byref(critic), base, 4, base, 688, base, base, base, base, 0, 0, 0, 0, 3, None) == -1          # stride < in_dim
+    assert act(C.byref(actor), C.byref(critic), base, 4, base, 689, base + 4, base, base, base, 0, 0, 0, 0, 3, None) == -3      # actions not 8-byte aligned
+    assert act(C.byref(actor), C.byref(critic), base, 4, base, 689, base, base, base, base, 0, 0, 0, 0, 4, None) == -1          # nets not in 1..3
+    assert act(C.byref(actor), C.byref(critic), base, 4, base, 689, base, base, base, None, 0, 0, 0, 0, 2, None) == -1          # critic half without values
     hp, st = A.WlPpoParams(), A.WlPpoState()
     small_a, small_c = net(14, 2), net(14, 1)
     assert lib.wl_ppo_apply(C.byref(small_a), C.byref(small_c), base, 64, C.byref(hp), C.byref(st), 0, 1, None) == -1          # null state

@@ -92,8 +92,30 @@ def test_rejects_bad_arguments():
     out2, out1 = torch.zeros(4, 2, device=DEV), torch.zeros(4, device=DEV)
     call = lambda n, stride, ap=a: lib.wl_actor_critic_act(C.byref(ap), C.byref(c), ac.std.data_ptr(), n, obs.data_ptr(), stride,
                                                           out2.data_ptr(), out2.data_ptr(), out1.data_ptr(), out1.data_ptr(), 0, 0, 0,
-                                                          0, None)
+                                                          0, 3, None)
     assert call(4, 20) == 0
     assert call(0, 20) == -1 and call(4, 19) == -1      # WL_EINVAL
     bad = ac.critic.struct()       # an "actor" with one output
     assert call(4, 20, bad) == -1
+
+
+def test_actor_and_critic_halves_equal_the_joint_launch():
+    """nets = 1 (actor only) and nets = 2 (critic only, on a second stream) fill the same rows as the joint launch, bit for bit"""
+    D, n = 689, 3000
+    ac, _, _ = _nets(D, "relu", seed=11)
+    obs = torch.randn(n, D, device=DEV)
+    out = lambda: (torch.zeros(n, 2, device=DEV), torch.zeros(n, 2, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV))
+    a0, m0, l0, v0 = out()
+    ac.act(obs, a0, m0, l0, v0, 5, 77, env_offset=4096)
+    a1, m1, l1, v1 = out()
+    ac.act(obs, a1, m1, l1, v1, 5, 77, env_offset=4096, nets=1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ac.act(obs, a1, m1, l1, v1, 5, 77, env_offset=4096, nets=2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(a0, a1) and torch.equal(m0, m1) and torch.equal(l0, l1) and torch.equal(v0, v1)
+    assert float(v1.abs().max()) > 0 and float(a1.abs().max()) > 0
+    v2 = torch.zeros(n, device=DEV)
+    assert torch.equal(ac.values(obs, v2), v0)                       # the critic alone, no other outputs

@@ -170,7 +170,8 @@ SIGNATURES = {
     "wl_mlp_forward": (C.c_int, [_P(WlMlp), _i32, _vp, _vp, _vp]),
     "wl_drift_rollout_policy": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _P(WlMlp), _vp, _P(WlPolicyRollout), _i32,
                                           _u64, _u64, _vp]),
-    "wl_actor_critic_act": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _u64, _u64, _i32, _vp]),
+    "wl_actor_critic_act": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _u64, _u64, _i32, _i32,
+                                      _vp]),
     "wl_gae": (C.c_int, [_i32, _i32, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp]),
     "wl_ppo_gradients": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _P(WlPpoBatch), _i32, _i32, _P(WlPpoParams), _P(WlPpoState), _i32,
                                    _vp]),

@@ -131,10 +131,10 @@ __global__ void __launch_bounds__(64 * KS) actor_critic_act_kernel(const WlMlp a
                                                                    float* __restrict__ actions, float* __restrict__ mu_out,
                                                                    float* __restrict__ log_prob, float* __restrict__ values,
                                                                    const int env_offset, const uint64_t seed, const uint64_t step,
-                                                                   const int deterministic) {
+                                                                   const int deterministic, const int first_net) {
     __shared__ float part[KS > 1 ? KS - 1 : 1][RT * kMlpTiles * 4][64];
     const int lane = threadIdx.x & 63, kpart = threadIdx.x >> 6;   // this wavefront's share of the features
-    const int which = blockIdx.y;
+    const int which = (int)blockIdx.y + first_net;   // 0 actor, 1 critic (grid.y = 1: only `first_net`)
     const WlMlp& net = which == 0 ? actor : critic;
     const int D = net.in_dim;
     const int m = lane & 15, g = lane >> 4;
@@ -239,11 +239,12 @@ int check_wide(const WlMlp* net, int out_dim) {
 template <int ACT, int RT>
 void launch_act(int ks, int row_blocks, hipStream_t s, const WlMlp& a, const WlMlp& c, const float* std, int n_rows,
                 const float* obs, int64_t obs_stride, float* actions, float* mu, float* log_prob, float* values, int env_offset,
-                uint64_t seed, uint64_t step, int deterministic) {
-    const dim3 grid(row_blocks, 2);
+                uint64_t seed, uint64_t step, int deterministic, int nets) {
+    const dim3 grid(row_blocks, nets == 3 ? 2 : 1);
+    const int first_net = nets == 2 ? 1 : 0;
 #define WL_LAUNCH_ACT(KS)                                                                                                      \
     actor_critic_act_kernel<ACT, KS, RT><<<grid, 64 * KS, 0, s>>>(a, c, std, n_rows, obs, obs_stride, actions, mu, log_prob,    \
-                                                                   values, env_offset, seed, step, deterministic)
+                                                                   values, env_offset, seed, step, deterministic, first_net)
     if (ks >= 4) WL_LAUNCH_ACT(4);
     else if (ks == 2) WL_LAUNCH_ACT(2);
     else WL_LAUNCH_ACT(1);
@@ -256,24 +257,32 @@ extern "C" {
 
 int wl_actor_critic_act(const WlMlp* actor, const WlMlp* critic, const float* std, int32_t n_rows, const float* obs,
                         int64_t obs_stride, float* actions, float* mu, float* log_prob, float* values, int32_t env_offset,
-                        uint64_t seed, uint64_t step, int32_t deterministic, void* stream) {
+                        uint64_t seed, uint64_t step, int32_t deterministic, int32_t nets, void* stream) {
     int rc = check_wide(actor, 2);
     if (rc == WL_OK) rc = check_wide(critic, 1);
     if (rc != WL_OK) return rc;
     if (actor->in_dim != critic->in_dim || actor->activation != critic->activation) return WL_EINVAL;
-    if (!std || n_rows <= 0 || !obs || obs_stride < actor->in_dim || !actions || !mu || !log_prob || !values) return WL_EINVAL;
-    if (((uintptr_t)actions & 7u) || ((uintptr_t)mu & 7u) || ((uintptr_t)obs & 3u)) return WL_EALIGN;
+    if (nets < 1 || nets > 3 || n_rows <= 0 || !obs || obs_stride < actor->in_dim) return WL_EINVAL;
+    if ((nets & 1) && (!std || !actions || !mu || !log_prob)) return WL_EINVAL;
+    if ((nets & 2) && !values) return WL_EINVAL;
+    if ((nets & 1) && (((uintptr_t)actions & 7u) || ((uintptr_t)mu & 7u))) return WL_EALIGN;
+    if ((uintptr_t)obs & 3u) return WL_EALIGN;
     clear_error();
     const int tiles = (n_rows + 15) / 16;
-    // two (four) row tiles per wavefront once there are enough tiles; then split the features over up to 4 wavefronts as long as
-    // that adds wavefronts the 1024 SIMDs can use and leaves each at least ~8 chunks of 16 features
-    const int rt = tiles >= 1024 ? 4 : tiles >= 128 ? 2 : 1;
+    // Row tiles per wavefront by the number of (tile, net) pairs: one while a wavefront per pair does not yet fill the 1024
+    // SIMDs four times over with the feature split, two / four beyond (each weight operand then feeds more rows).  The
+    // feature split KS is chosen from the row count alone (as for a joint launch), so the arithmetic -- the order of the
+    // partial sums -- and hence the result does not depend on `nets`.
+    const int n_nets = nets == 3 ? 2 : 1;
+    const int rt = tiles * n_nets >= 2048 ? 4 : tiles * n_nets >= 512 ? 2 : 1;
     const int row_blocks = (tiles + rt - 1) / rt;
+    const int rt_joint = tiles * 2 >= 2048 ? 4 : tiles * 2 >= 512 ? 2 : 1;
+    const int row_blocks_joint = (tiles + rt_joint - 1) / rt_joint;
     int ks = 1;
-    while (ks < 4 && row_blocks * 2 * ks < 1024 && (actor->in_dim >> 4) / (ks * 2) >= 8) ks *= 2;
+    while (ks < 4 && row_blocks_joint * 2 * ks < 1024 && (actor->in_dim >> 4) / (ks * 2) >= 8) ks *= 2;
     const bool elu = actor->activation == WL_ACT_ELU;
 #define WL_ACT_ARGS ks, row_blocks, (hipStream_t)stream, *actor, *critic, std, n_rows, obs, obs_stride, actions, mu, log_prob, values, \
-                    env_offset, seed, step, deterministic
+                    env_offset, seed, step, deterministic, nets
     if (rt == 4) {
         if (elu) launch_act<WL_ACT_ELU, 4>(WL_ACT_ARGS);
         else launch_act<WL_ACT_RELU, 4>(WL_ACT_ARGS);

@@ -77,22 +77,31 @@ class ActorCritic:
         self.std = torch.full((num_actions,), float(init_noise_std), dtype=torch.float32, device=device)
 
     def act(self, obs: torch.Tensor, actions: torch.Tensor, mu: torch.Tensor, log_prob: torch.Tensor, values: torch.Tensor,
-            seed: int, step: int, env_offset: int = 0, deterministic: bool = False):
+            seed: int, step: int, env_offset: int = 0, deterministic: bool = False, nets: int = 3):
         """One policy step for observations of ANY width in one launch (wl_actor_critic_act): fills `actions`, `mu` [n, 2],
-        `log_prob`, `values` [n] (rows of a RolloutStorage) from obs [n, D]; the draw is keyed by (seed, env_offset + row, step)."""
+        `log_prob`, `values` [n] (rows of a RolloutStorage) from obs [n, D]; the draw is keyed by (seed, env_offset + row, step).
+        nets = 1: only the actor's half (actions / mu / log_prob; `values` may be None), nets = 2: only the critic's
+        (`values`; the other outputs may be None)."""
         n, D = obs.shape
         assert D == self.actor.in_dim == self.critic.in_dim and obs.dtype == torch.float32 and obs.stride(1) == 1
-        for t, shape in ((actions, (n, 2)), (mu, (n, 2)), (log_prob, (n,)), (values, (n,))):
+        needed = (((actions, (n, 2)), (mu, (n, 2)), (log_prob, (n,))) if nets & 1 else ()) + (((values, (n,)),) if nets & 2 else ())
+        for t, shape in needed:
             assert t.shape == shape and t.dtype == torch.float32 and t.is_contiguous() and t.device == obs.device
+        ptr = lambda t: None if t is None else t.data_ptr()
         key = (self.actor.w1.data_ptr(), self.critic.w1.data_ptr(), self.std.data_ptr())
         if getattr(self, "_act_key", None) != key:   # the structs only hold pointers: rebuilt when the tensors are replaced
             self._act_key, self._act_structs, self._act_fn = key, (self.actor.struct(), self.critic.struct()), A.load().wl_actor_critic_act
         a, c = self._act_structs
         A.check(self._act_fn(C.byref(a), C.byref(c), self.std.data_ptr(), n, obs.data_ptr(), obs.stride(0),
-                                             actions.data_ptr(), mu.data_ptr(), log_prob.data_ptr(), values.data_ptr(),
-                                             int(env_offset), int(seed), int(step), int(bool(deterministic)),
+                                             ptr(actions), ptr(mu), ptr(log_prob), ptr(values),
+                                             int(env_offset), int(seed), int(step), int(bool(deterministic)), int(nets),
                                              C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)),
                 "wl_actor_critic_act")
+
+    def values(self, obs: torch.Tensor, out: torch.Tensor):
+        """critic(obs) -> out [n] for observations of any width (the critic's half of wl_actor_critic_act)"""
+        self.act(obs, None, None, None, out, 0, 0, nets=2)
+        return out
 
 
 class RolloutStorage:

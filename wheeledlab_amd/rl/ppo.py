@@ -341,7 +341,7 @@ class OnPolicyRunner:
                     base.collect_step(view, st, k)
                 base.finish_collection(st)
                 obs = st.observations[self.num_steps_per_env]
-                st.values[self.num_steps_per_env].copy_(ac.evaluate(obs).reshape(st.n_envs))
+                view.values(obs, st.values[self.num_steps_per_env])      # bootstrap value of the last observation
             return obs
         with torch.inference_mode():
             for k in range(self.num_steps_per_env):
