@@ -1,0 +1,55 @@
+// TEST INFRASTRUCTURE ONLY: the device physics of wheeledlab_amd/csrc/wl_vehicle.h compiled for the host (through the
+// stand-in hip_runtime.h next to this file) and driven over arrays, so that tests/test_host_sim_cpu.py can hold the
+// lane-per-env form against oracle/vehicle.py without a GPU.  Built by the test into a scratch directory.
+#include <hip/hip_runtime.h>
+
+#include "wl_vehicle.h"
+#include "wl_heightfield.h"
+
+namespace {
+template <class Ground, bool UNROLL>
+void run(const WlVehicleParams& vp, float sim_dt, int decimation, int n, float* x, float* q, float* v, float* wb, float* wheel,
+         float* steer, const float* steer_target, const float* wheel_target, const float* mass, const float* mu_s,
+         const float* mu_d, const float* damp, const Ground& ground) {
+    const VehDerived vd = derive_vehicle(vp, sim_dt, decimation);
+    for (int e = 0; e < n; ++e) {
+        EnvConst ec;
+        env_const_rows(ec, vp, vd, mass[e], mu_s[e], mu_d[e], damp[e]);
+        ec.steer_target = steer_target[e];
+        for (int i = 0; i < 4; ++i) ec.wheel_target[i] = wheel_target[4 * e + i];
+        VehState s;
+        s.x = v3(x[3 * e], x[3 * e + 1], x[3 * e + 2]);
+        s.q = Quat{q[4 * e], q[4 * e + 1], q[4 * e + 2], q[4 * e + 3]};
+        s.v = v3(v[3 * e], v[3 * e + 1], v[3 * e + 2]);
+        s.wb = v3(wb[3 * e], wb[3 * e + 1], wb[3 * e + 2]);
+        for (int i = 0; i < 4; ++i) s.wheel[i] = wheel[4 * e + i];
+        s.th = steer[2 * e];
+        s.om = steer[2 * e + 1];
+        vehicle_integrate<1, Ground, UNROLL>(vp, vd, ec, s, ground, 0);
+        x[3 * e] = s.x.x, x[3 * e + 1] = s.x.y, x[3 * e + 2] = s.x.z;
+        q[4 * e] = s.q.w, q[4 * e + 1] = s.q.x, q[4 * e + 2] = s.q.y, q[4 * e + 3] = s.q.z;
+        v[3 * e] = s.v.x, v[3 * e + 1] = s.v.y, v[3 * e + 2] = s.v.z;
+        wb[3 * e] = s.wb.x, wb[3 * e + 1] = s.wb.y, wb[3 * e + 2] = s.wb.z;
+        for (int i = 0; i < 4; ++i) wheel[4 * e + i] = s.wheel[i];
+        steer[2 * e] = s.th;
+        steer[2 * e + 1] = s.om;
+    }
+}
+}  // namespace
+
+extern "C" {
+// decimation x substeps integrator sub-steps of n envs, in place; arrays are [n][k] row-major float32.
+// hf == NULL: flat ground (the drift / visual tasks); else the bilinear heightfield (elevation task).
+void hs_vehicle_integrate(const WlVehicleParams* vp, float sim_dt, int decimation, int n, float* x, float* q, float* v, float* wb,
+                          float* wheel, float* steer, const float* steer_target, const float* wheel_target, const float* mass,
+                          const float* mu_s, const float* mu_d, const float* damp, const WlHeightField* hf, int unroll) {
+    if (hf) {
+        const HeightFieldGround g = make_ground(hf);
+        if (unroll) run<HeightFieldGround, true>(*vp, sim_dt, decimation, n, x, q, v, wb, wheel, steer, steer_target, wheel_target, mass, mu_s, mu_d, damp, g);
+        else run<HeightFieldGround, false>(*vp, sim_dt, decimation, n, x, q, v, wb, wheel, steer, steer_target, wheel_target, mass, mu_s, mu_d, damp, g);
+    } else {
+        if (unroll) run<FlatGround, true>(*vp, sim_dt, decimation, n, x, q, v, wb, wheel, steer, steer_target, wheel_target, mass, mu_s, mu_d, damp, FlatGround{});
+        else run<FlatGround, false>(*vp, sim_dt, decimation, n, x, q, v, wb, wheel, steer, steer_target, wheel_target, mass, mu_s, mu_d, damp, FlatGround{});
+    }
+}
+}

@@ -216,12 +216,7 @@ WL_DEV void store_rows(const Rows& S, const WlEnvBuffers& b, const WlDriftParams
 
 // per-env constants that do not change during a rollout
 WL_DEV void load_env_const(const Rows& S, const WlVehicleParams& vp, const VehDerived& vd, int e, EnvConst& ec) {
-    env_const_mass(ec, vp, vd, S.ld(WL_S_MASS, e));
-    ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
-    ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
-    ec.damp = S.ld(WL_S_DAMP, e);
-    ec.inv_A0 = rcp(vd.A0);
-    ec.inv_A0_damp = rcp(vd.A0 + ec.damp);
+    env_const_rows(ec, vp, vd, S.ld(WL_S_MASS, e), S.ld(WL_S_MU_S, e), S.ld(WL_S_MU_D, e), S.ld(WL_S_DAMP, e));
 }
 
 // Episode-metric accumulation.  Lane form: LDS atomics per block, <= 16 global atomics per block at the end (many
@@ -251,7 +246,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     float v_t, delta;
     process_action(p.action, a.x, a.y, v_t, delta);
     joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-    ec.wt_lane = LANES == 4 ? quad_pick(wid, ec.wheel_target[0], ec.wheel_target[1], ec.wheel_target[2], ec.wheel_target[3]) : 0.f;
+    if constexpr (LANES == 4) env_const_lane(ec, vp, wid);
     // ---- memory form -> integrator form (CoM position, body-frame angular velocity) ----
     VehState s;
     s.q = r.q;
@@ -437,7 +432,7 @@ WL_DEV void pin_params_vgpr(WlDriftParams& p, VehDerived& d) {
     for (float* f : pf) pin_vgpr(*f);
     pin_vgpr(p.weight), pin_vgpr(p.noise_std), pin_vgpr(p.hf_interval), pin_vgpr(p.lf_interval);
     float* df[] = {&d.h, &d.inv_h, &d.half_h, &d.steer_a, &d.steer_b, &d.steer_J_h, &d.steer_h_J, &d.zrel, &d.Iw_h, &d.A0,
-                   &d.inv_wlim, &d.r2};
+                   &d.inv_wlim, &d.mot_b, &d.r2};
 #pragma unroll
     for (float* f : df) pin_vgpr(*f);
 }

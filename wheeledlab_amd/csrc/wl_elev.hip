@@ -143,13 +143,8 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
         process_action(p.action, a.x, a.y, v_t, delta);
         EnvConst ec;
         joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-        ec.wt_lane = LANES == 4 ? quad_pick(wid, ec.wheel_target[0], ec.wheel_target[1], ec.wheel_target[2], ec.wheel_target[3]) : 0.f;
-        env_const_mass(ec, vp, vd, S.ld(WL_S_MASS, e));
-        ec.mu_s = S.ld(WL_S_MU_S, e) * vp.ground_mu_s;
-        ec.mu_d = fminf(S.ld(WL_S_MU_D, e) * vp.ground_mu_d, ec.mu_s);
-        ec.damp = S.ld(WL_S_DAMP, e);
-        ec.inv_A0 = rcp(vd.A0);
-        ec.inv_A0_damp = rcp(vd.A0 + ec.damp);
+        if constexpr (LANES == 4) env_const_lane(ec, vp, wid);
+        env_const_rows(ec, vp, vd, S.ld(WL_S_MASS, e), S.ld(WL_S_MU_S, e), S.ld(WL_S_MU_D, e), S.ld(WL_S_DAMP, e));
         VehState s;
         V3 pos = ld3(S, WL_S_PX, e);
         s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};

@@ -17,13 +17,15 @@ struct VehState {
 struct EnvConst {   // per-env constants hoisted out of the sub-step loop
     float weight, h_inv_mass;  // m g ; h / m
     float K_cap;               // 0.125 m / h
-    float mu_s, mu_d;          // combined (wheel x ground) friction
+    float mu_s, mu_d, mu_sd;   // combined (wheel x ground) friction: static, dynamic, static - dynamic
     float damp;                // throttle damping of driven wheels
     float inv_A0, inv_A0_damp; // 1 / (Iw/h + bearing damping) and 1 / (that + damp): the saturated-branch wheel solve
     V3 Ib, h_inv_Ib;           // body inertia diag ; h / I
     float steer_target;
     float wheel_target[4];
-    float wt_lane;             // quad form: the target of THIS lane's wheel (picked once per env-step, not per sub-step)
+    // quad form: THIS lane's wheel (picked once per env-step, not per sub-step): velocity target, body position,
+    // throttle damping (0: undriven), 1 / (A0 + that damping)
+    float wt_lane, bx_lane, by_lane, d_lane, inv_A0d_lane;
 };
 
 
@@ -36,7 +38,7 @@ struct VehDerived {
     float steer_J_h, steer_h_J;             // J / h ; h / J
     float zrel;                             // wheel centre z relative to the CoM (body frame)
     float Iw_h, A0;                         // wheel inertia / h ; Iw_h + bearing damping
-    float inv_wlim;                         // 1 / motor_vel_limit
+    float inv_wlim, mot_b;                  // 1 / motor_vel_limit ; motor_sat / motor_vel_limit
     float r2;                               // wheel radius squared
     int32_t n_sub;                          // decimation * substeps
 };
@@ -55,21 +57,30 @@ inline VehDerived derive_vehicle(const WlVehicleParams& vp, float sim_dt, int de
     d.Iw_h = vp.wheel_inertia * d.inv_h;
     d.A0 = d.Iw_h + vp.wheel_damping;
     d.inv_wlim = 1.f / vp.motor_vel_limit;
+    d.mot_b = vp.motor_sat / vp.motor_vel_limit;
     d.r2 = vp.wheel_radius * vp.wheel_radius;
     d.n_sub = decimation * vp.substeps;
     return d;
 }
 
-WL_DEV void env_const_mass(EnvConst& ec, const WlVehicleParams& vp, const VehDerived& vd, float mass) {
+// per-env constants from the env's randomisation rows (wheel friction, throttle damping, mass)
+WL_DEV void env_const_rows(EnvConst& ec, const WlVehicleParams& vp, const VehDerived& vd, float mass, float mu_s_wheel,
+                           float mu_d_wheel, float damp) {
     ec.weight = mass * vp.gravity;
     ec.h_inv_mass = vd.h * rcp(mass);
     ec.K_cap = 0.125f * mass * vd.inv_h;
     ec.Ib = v3(mass * (vp.gyr_x * vp.gyr_x), mass * (vp.gyr_y * vp.gyr_y), mass * (vp.gyr_z * vp.gyr_z));
     ec.h_inv_Ib = v3(vd.h * rcp(ec.Ib.x), vd.h * rcp(ec.Ib.y), vd.h * rcp(ec.Ib.z));
+    ec.mu_s = mu_s_wheel * vp.ground_mu_s;
+    ec.mu_d = fminf(mu_d_wheel * vp.ground_mu_d, ec.mu_s);
+    ec.mu_sd = ec.mu_s - ec.mu_d;
+    ec.damp = damp;
+    ec.inv_A0 = rcp(vd.A0);
+    ec.inv_A0_damp = rcp(vd.A0 + damp);
 }
 
 struct FlatGround {
-    static constexpr bool kFlat = true;   // n == (0, 0, 1), zg == 0 everywhere: wheel_force drops the terms that vanish
+    static constexpr bool kFlat = true;   // n == (0, 0, 1), zg == 0 everywhere
     WL_DEV void sample(float, float, float& zg, V3& n) const {
         zg = 0.f;
         n = v3(0.f, 0.f, 1.f);
@@ -81,78 +92,84 @@ struct FlatGround {
 // scratch memory -- a store -> load round trip on the critical tail of the step.)
 WL_DEV float quad_pick(int wid, float a, float b, float c, float d) { return wid == 0 ? a : wid == 1 ? b : wid == 2 ? c : d; }
 
-// Contact + tyre + wheel-spin solve of ONE wheel.  `front` / `left` are compile-time constants in the lane-per-env
-// kernels (the call is inlined per wheel) and per-lane values in the quad kernels (one wheel per lane).
-// Returns the contact force on the body (world) and its torque about the CoM; updates the wheel spin.
-// FLAT (plane z = 0, n = +z): the products with the zero components of n are spelled out as absent -- the compiler must
-// keep `x * 0` (x could be inf / NaN) and would issue a dozen of them per wheel and sub-step.
-template <bool FLAT>
-WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Mat3& R, V3 x, V3 v,
-                        V3 ww, float cs, float sn, float zg, V3 n, bool front, bool left, float wt, float& w_spin,
-                        V3& Fi, V3& Ti) {
+// per-lane constants of the quad form (lane `wid` owns wheel `wid`): picked once per env-step, not per sub-step
+WL_DEV void env_const_lane(EnvConst& ec, const WlVehicleParams& vp, int wid) {
+    const bool front = wid >= 2, left = (wid & 1) == 0;
+    const bool driven = (vp.drive == 1) || !front;
+    ec.wt_lane = quad_pick(wid, ec.wheel_target[0], ec.wheel_target[1], ec.wheel_target[2], ec.wheel_target[3]);
+    ec.bx_lane = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r;
+    ec.by_lane = left ? vp.half_track : -vp.half_track;
+    ec.d_lane = driven ? ec.damp : 0.f;
+    ec.inv_A0d_lane = driven ? ec.inv_A0_damp : ec.inv_A0;
+}
+
+// ---- one wheel: contact + tyre + wheel-spin solve, everything in the BODY frame ------------------------------------------
+// Round 1 worked in the world frame: per wheel and sub-step R pb, ww x arm, a tangent frame rebuilt from R h, arm x F and
+// finally R^T T -- 3 559 VALU instructions per env-step, which (not HBM) bound the lane form (profiles/r01_pmc_sq).  In
+// the body frame the arm of wheel i is pb_i - r n with n the ground normal in body coordinates (on flat ground: the
+// third ROW of R, shared by all wheels), the heading of an axle is h = (cos th, sin th, 0), and
+//     tx = (h - g n) / |h - g n|,  ty = n x tx = (n x h) / |h - g n|,   g = n . h,  |h - g n|^2 = 1 - g^2
+// so that the slip velocities need no frame at all:
+//     v_cx = (h . vc - g vn) it,   v_cy = ((n x h) . vc) it,   it = rsq(1 - g^2),   vn = n . vc
+// and the force comes back as F = fx h + fy (n x h) + (Fz - fx g) n with fx = Fx it, fy = Fy it.  Torques are summed in
+// the body frame (no R^T T), the quaternion is advanced with the body rate (q (0, w_b) == (0, R w_b) q: no R w_b), and
+// on flat ground the world z force is the plain sum of the normal loads.  Same model, same numbers to rounding
+// (spec: oracle/vehicle.py::substep, which keeps the world-frame form), ~40 % fewer instructions per sub-step.
+//   n: ground normal at the wheel (body frame); vc: contact-point velocity (body frame); pen: penetration along n_w
+//   STEER: the wheel's heading in the body frame is (hc, hs, 0) = (cos th, sin th, 0); !STEER: (1, 0, 0) with every
+//          product by the constant components spelled out as absent (the compiler must keep `x * 0`: x could be inf)
+//   MOTOR: the wheel may be driven: d = throttle damping (0: undriven), inv_A0d = 1 / (A0 + d);
+//          !MOTOR: known to be undriven (d == 0): tau == 0 and the DC-motor window drops out
+struct WheelOut {
+    V3 F;       // contact force on the body, body frame
+    float Fz;   // normal load
+};
+template <bool STEER, bool MOTOR>
+WL_DEV WheelOut wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, V3 n, V3 vc, float pen, float hc,
+                           float hs, float d, float inv_A0d, float wt, float& w_spin) {
     const float r = vp.wheel_radius;
-    const V3 pb = v3(front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, left ? vp.half_track : -vp.half_track, vd.zrel);
-    const V3 arm_c = mul(R, pb);
-    const float cz = x.z + arm_c.z;
-    float pen, vn, vcx, vcy;
-    V3 arm, vcp, tx, ty;
-    if constexpr (FLAT) {
-        pen = r - cz;
-        arm = v3(arm_c.x, arm_c.y, arm_c.z - r);
-        vcp = v + cross(ww, arm);
-        vn = vcp.z;
-    } else {
-        pen = r - (cz - zg) * n.z;
-        arm = fma3(-r, n, arm_c);
-        vcp = v + cross(ww, arm);
-        vn = dot(vcp, n);
-    }
+    const float vn = dot(n, vc);
     const float Fz = pen > 0.f ? fmaxf(fmaf(vp.susp_k, pen, -vp.susp_c * vn), 0.f) : 0.f;
-    // wheel heading projected into the contact plane (front wheels are rotated by the steer angle)
-    const float hc = front ? cs : 1.f, hs = front ? sn : 0.f;
-    const V3 hw = v3(fmaf(R.r0.x, hc, R.r0.y * hs), fmaf(R.r1.x, hc, R.r1.y * hs), fmaf(R.r2.x, hc, R.r2.y * hs));
-    if constexpr (FLAT) {
-        const float inv = rsq(fmaf(hw.x, hw.x, hw.y * hw.y));
-        tx = v3(inv * hw.x, inv * hw.y, 0.f);
-        ty = v3(-tx.y, tx.x, 0.f);
-        vcx = fmaf(vcp.x, tx.x, vcp.y * tx.y);
-        vcy = fmaf(vcp.y, tx.x, -vcp.x * tx.y);
-    } else {
-        const V3 t = fma3(-dot(hw, n), n, hw);
-        tx = rsq(dot(t, t)) * t;
-        ty = cross(n, tx);
-        vcx = dot(vcp, tx);
-        vcy = dot(vcp, ty);
-    }
+    // g = n . h ; m = (n x h).z ; lx = h . vc ; ly = (hc vc.y - hs vc.x)  [(n x h).xy = n.z (-hs, hc)]
+    const float g = STEER ? fmaf(n.x, hc, n.y * hs) : n.x;
+    const float m = STEER ? fmaf(n.x, hs, -n.y * hc) : -n.y;
+    const float lx = STEER ? fmaf(hc, vc.x, hs * vc.y) : vc.x;
+    const float ly = STEER ? fmaf(hc, vc.y, -hs * vc.x) : vc.y;
+    const float it = rsq(fmaf(-g, g, 1.f));
+    const float vcx = it * fmaf(-g, vn, lx);
+    const float vcy = it * fmaf(n.z, ly, m * vc.z);
     const float w_i = w_spin;
-    const float vden = fmaxf(vp.v_min, vp.slip_peak * fmaxf(fabsf(vcx), fabsf(w_i * r)));
+    const float wr = w_i * r;
+    const float vden = fmaxf(vp.v_min, vp.slip_peak * fmaxf(fabsf(vcx), fabsf(wr)));
     const float inv_vden = rcp(vden);
-    const float sx = (w_i * r - vcx) * inv_vden, sy = -vcy * inv_vden;
+    const float sx = (wr - vcx) * inv_vden, sy = vcy * inv_vden;   // (sy's sign is immaterial: only sy^2 is used)
     const float sig = fsqrt(fmaf(sx, sx, sy * sy));
     // g(sig) / sig, branch-free: below the peak (sig <= 1, inv_sig == 1) the first term is mu_s and the second adds
     // mu_s (1 - sig) -> mu_s (2 - sig); above it the second term vanishes.  (As a ?: the two short arms become
     // divergent control flow: five exec-mask instructions around six arithmetic ones, every wheel, every sub-step.)
     const float inv_sig = rcp(fmaxf(sig, 1.f));
-    const float gq = fmaf(ec.mu_s, fmaxf(1.f - sig, 0.f), fmaf(ec.mu_s - ec.mu_d, inv_sig, ec.mu_d) * inv_sig);
+    const float gq = fmaf(ec.mu_s, fmaxf(1.f - sig, 0.f), fmaf(ec.mu_sd, inv_sig, ec.mu_d) * inv_sig);
     // explicit-stepping stability cap: at most half of this wheel's share of the body momentum per sub-step
     const float K = fminf(Fz * gq * inv_vden, ec.K_cap);
-    const bool driven = (vp.drive == 1) || !front;
-    const float d = driven ? ec.damp : 0.f;
-    // DC-motor torque window at the current spin (IsaacLab DCMotor, hound.py:13-21)
-    const float rel = w_i * vd.inv_wlim;
-    const float tau_hi = clampf(vp.motor_sat * (1.f - rel), 0.f, vp.motor_limit);
-    const float tau_lo = clampf(vp.motor_sat * (-1.f - rel), -vp.motor_limit, 0.f);
-    const float Iw_h = vd.Iw_h;
-    // implicit spin update with the tyre's secant stiffness (unconditionally stable)
+    // implicit spin update with the tyre's secant stiffness (unconditionally stable): A w = rhs0 + tau(w) with the
+    // DC-motor torque tau = clamp(d (wt - w), lo, hi), window [lo, hi] taken at the current spin (IsaacLab DCMotor,
+    // hound.py:13-21).  tau is non-increasing in w, so the solution is the unclipped root w_u = (rhs0 + d wt) / (A + d)
+    // clamped to the roots of the two constant-torque equations: ONE median instead of torque -> clamp -> compare ->
+    // select (and never the cancelling difference d (wt - w_u), whose rounding d / A ~ 3e3 amplifies).
     const float A = fmaf(K, vd.r2, vd.A0);
-    const float rhs0 = fmaf(Iw_h, w_i, r * K * vcx);
-    const float w_u = fmaf(d, wt, rhs0) * rcp(A + d);
-    // tau = d (wt - w_u) cancels catastrophically near the target (d / A ~ 3e3 amplifies the rounding of w_u), so
-    // the unclipped branch takes w_u itself and only a clipped (constant) torque is pushed through the wheel equation
-    const float tau_u = d * (wt - w_u);
-    const float tau = clampf(tau_u, tau_lo, tau_hi);
-    float w_n = (tau == tau_u) ? w_u : (rhs0 + tau) * rcp(A);
-    float Fx = K * fmaf(w_n, r, -vcx);
+    const float rK = r * K;
+    const float rhs0 = fmaf(vd.Iw_h, w_i, rK * vcx);
+    const float inv_A = rcp(A);
+    float w_n, tau_lo = 0.f, tau_hi = 0.f;
+    if constexpr (MOTOR) {
+        tau_hi = clampf(fmaf(-vd.mot_b, w_i, vp.motor_sat), 0.f, vp.motor_limit);     // sat (1 - w / w_lim)
+        tau_lo = clampf(fmaf(-vd.mot_b, w_i, -vp.motor_sat), -vp.motor_limit, 0.f);   // sat (-1 - w / w_lim)
+        const float w_u = fmaf(d, wt, rhs0) * rcp(A + d);
+        w_n = clampf(w_u, (rhs0 + tau_lo) * inv_A, (rhs0 + tau_hi) * inv_A);
+    } else {
+        w_n = rhs0 * inv_A;
+    }
+    float Fx = fmaf(w_n, rK, -K * vcx);
     float Fy = -K * vcy;
     const float Fmax = ec.mu_s * Fz;
     const float mag2 = fmaf(Fx, Fx, Fy * Fy);
@@ -160,143 +177,85 @@ WL_DEV void wheel_force(const WlVehicleParams& vp, const VehDerived& vd, const E
         const float scale = Fmax * rsq(fmaxf(mag2, 1e-30f));
         Fx *= scale;
         Fy *= scale;
-        const float rhs2 = fmaf(Iw_h, w_i, -r * Fx);
-        const float w_u2 = fmaf(d, wt, rhs2) * (driven ? ec.inv_A0_damp : ec.inv_A0);   // 1 / (A0 + d), per-env constants
-        const float tau_u2 = d * (wt - w_u2);
-        const float tau2 = clampf(tau_u2, tau_lo, tau_hi);
-        w_n = (tau2 == tau_u2) ? w_u2 : (rhs2 + tau2) * ec.inv_A0;
+        const float rhs2 = fmaf(vd.Iw_h, w_i, -r * Fx);
+        if constexpr (MOTOR) {
+            const float w_u2 = fmaf(d, wt, rhs2) * inv_A0d;   // 1 / (A0 + d): per-env constant
+            w_n = clampf(w_u2, (rhs2 + tau_lo) * ec.inv_A0, (rhs2 + tau_hi) * ec.inv_A0);
+        } else {
+            w_n = rhs2 * ec.inv_A0;
+        }
     }
     w_spin = w_n;
-    if constexpr (FLAT) Fi = v3(fmaf(Fx, tx.x, -Fy * tx.y), fmaf(Fx, tx.y, Fy * tx.x), Fz);
-    else Fi = fma3(Fz, n, fma3(Fx, tx, Fy * ty));
-    Ti = cross(arm, Fi);
+    // F = fx h + fy (n x h) + (Fz - fx g) n  with fx = Fx it, fy = Fy it
+    const float fx = Fx * it, fy = Fy * it;
+    const float kz = fmaf(-fx, g, Fz);
+    const float fyz = fy * n.z;
+    WheelOut o;
+    if constexpr (STEER) o.F = v3(fmaf(kz, n.x, fmaf(fx, hc, -fyz * hs)), fmaf(kz, n.y, fmaf(fx, hs, fyz * hc)), fmaf(kz, n.z, fy * m));
+    else o.F = v3(fmaf(kz, n.x, fx), fmaf(kz, n.y, fyz), fmaf(kz, n.z, fy * m));
+    o.Fz = Fz;
+    return o;
 }
 
-// ---- packed axle form (lane-per-env kernels) ---------------------------------------------------------------------------
-// tools/microbench/valu_issue.hip: a wavefront that is alone on its SIMD issues one VALU instruction every ~4.5 cycles
-// (8 when it depends on the previous one) whether it is v_fma_f32 or v_pk_fma_f32 -- the packed one is free there; with
-// >= 2 wavefronts per SIMD the pipe takes 2 cycles for v_fma_f32 and 4 for v_pk_fma_f32 (same flops either way).  So
-// packing pays exactly while the lane form runs at ~1 wavefront per SIMD (32 K .. ~130 K envs: 17.1 -> 13.8 us at
-// 65 536) and is neutral beyond (1 M: 113 vs 114 us).  The two wheels of an axle run the same arithmetic on different
-// data: held as float2 (.x = left, .y = right) their mul / add / fma become packed instructions; max / min / select /
-// rcp / rsq / sqrt have no packed form and are issued per element.  wheel_force_axle is wheel_force, line by line,
-// on pairs.
-typedef float f2 __attribute__((ext_vector_type(2)));
-struct V3p {
-    f2 x, y, z;
+// contact kinematics of one wheel at body position (bx, by, zrel)
+struct Contact {
+    V3 n;       // ground normal, body frame
+    V3 arm;     // CoM -> contact point, body frame
+    V3 vc;      // velocity of the contact point, body frame
+    float pen;
 };
-WL_DEV f2 splat(float a) { return f2{a, a}; }
-WL_DEV f2 pfma(f2 a, f2 b, f2 c) { return a * b + c; }     // contracts to v_pk_fma_f32
-WL_DEV f2 pmax(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
-WL_DEV f2 pmin(f2 a, f2 b) { return f2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
-WL_DEV f2 pabs(f2 a) { return f2{fabsf(a.x), fabsf(a.y)}; }
-WL_DEV f2 prcp(f2 a) { return f2{rcp(a.x), rcp(a.y)}; }
-WL_DEV f2 prsq(f2 a) { return f2{rsq(a.x), rsq(a.y)}; }
-WL_DEV f2 psqrt(f2 a) { return f2{fsqrt(a.x), fsqrt(a.y)}; }
-WL_DEV f2 pclamp(f2 a, f2 lo, f2 hi) { return pmin(pmax(a, lo), hi); }
-WL_DEV f2 psel(bool c0, bool c1, f2 a, f2 b) { return f2{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
-WL_DEV f2 pdot(const V3p& a, const V3p& b) { return pfma(a.x, b.x, pfma(a.y, b.y, a.z * b.z)); }
-WL_DEV f2 pdot(V3 a, const V3p& b) { return pfma(splat(a.x), b.x, pfma(splat(a.y), b.y, splat(a.z) * b.z)); }
-WL_DEV V3p pcross(const V3p& a, const V3p& b) { return V3p{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-WL_DEV V3p pcross(V3 a, const V3p& b) {
-    return V3p{splat(a.y) * b.z - splat(a.z) * b.y, splat(a.z) * b.x - splat(a.x) * b.z, splat(a.x) * b.y - splat(a.y) * b.x};
+// On flat ground the sub-expressions shared by the wheels of an axle / a side (arm components, the partial sums of
+// vb + w_b x arm, the penetration) are written so that the compiler's CSE merges them across the inlined calls.
+template <class Ground>
+WL_DEV Contact wheel_contact(const WlVehicleParams& vp, const VehDerived& vd, const Ground& ground, const Mat3& R, const VehState& s,
+                             V3 vb, float bx, float by) {
+    const float r = vp.wheel_radius;
+    Contact c;
+    if constexpr (Ground::kFlat) {
+        c.n = R.r2;   // world +z in body coordinates
+        c.pen = fmaf(-c.n.y, by, fmaf(-c.n.x, bx, fmaf(-c.n.z, vd.zrel, r - s.x.z)));   // r - (x.z + r2 . pb)
+    } else {
+        const float cx = s.x.x + fmaf(R.r0.x, bx, fmaf(R.r0.y, by, R.r0.z * vd.zrel));
+        const float cy = s.x.y + fmaf(R.r1.x, bx, fmaf(R.r1.y, by, R.r1.z * vd.zrel));
+        const float cz = s.x.z + fmaf(R.r2.x, bx, fmaf(R.r2.y, by, R.r2.z * vd.zrel));
+        float zg;
+        V3 nw;
+        ground.sample(cx, cy, zg, nw);
+        c.pen = r - (cz - zg) * nw.z;
+        c.n = mul_t(R, nw);
+    }
+    c.arm = v3(fmaf(-r, c.n.x, bx), fmaf(-r, c.n.y, by), fmaf(-r, c.n.z, vd.zrel));
+    c.vc = v3(fmaf(-s.wb.z, c.arm.y, fmaf(s.wb.y, c.arm.z, vb.x)), fmaf(s.wb.z, c.arm.x, fmaf(-s.wb.x, c.arm.z, vb.y)),
+              fmaf(-s.wb.y, c.arm.x, fmaf(s.wb.x, c.arm.y, vb.z)));
+    return c;
 }
 
-// the two wheels of one axle (front: steered).  F / T: their summed contact force / torque about the CoM (world).
-template <bool FLAT>
-WL_DEV void wheel_force_axle(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Mat3& R, V3 x, V3 v,
-                             V3 ww, float cs, float sn, f2 zg, const V3p& n, bool front, f2 wt, f2& w_spin, V3& F, V3& T) {
-    const f2 r = splat(vp.wheel_radius);
-    const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r;
-    const f2 by = f2{vp.half_track, -vp.half_track};
-    // arm_c = R pb with pb = (bx, +-half_track, zrel): the x / z parts are shared by the two wheels
-    const V3p arm_c{pfma(splat(R.r0.y), by, splat(fmaf(R.r0.x, bx, R.r0.z * vd.zrel))),
-                    pfma(splat(R.r1.y), by, splat(fmaf(R.r1.x, bx, R.r1.z * vd.zrel))),
-                    pfma(splat(R.r2.y), by, splat(fmaf(R.r2.x, bx, R.r2.z * vd.zrel)))};
-    const f2 cz = splat(x.z) + arm_c.z;
-    f2 pen, vn, vcx, vcy;
-    V3p arm, tx, ty;
-    if constexpr (FLAT) {
-        pen = r - cz;
-        arm = V3p{arm_c.x, arm_c.y, arm_c.z - r};
+// force / torque / load accumulators of one sub-step (body frame)
+struct Wrench {
+    V3 F, T;
+    float Fz;
+};
+template <bool FIRST>
+WL_DEV void wrench_add(Wrench& w, const Contact& c, const WheelOut& o) {
+    const V3 t = cross(c.arm, o.F);
+    if constexpr (FIRST) {   // plain assignment: `0 + x` cannot be folded (-0), it would cost an instruction per component
+        w.F = o.F;
+        w.T = t;
+        w.Fz = o.Fz;
     } else {
-        pen = r - (cz - zg) * n.z;
-        arm = V3p{arm_c.x - r * n.x, arm_c.y - r * n.y, arm_c.z - r * n.z};
+        w.F = w.F + o.F;
+        w.T = w.T + t;
+        w.Fz += o.Fz;
     }
-    const V3p wxa = pcross(ww, arm);
-    const V3p vcp{splat(v.x) + wxa.x, splat(v.y) + wxa.y, splat(v.z) + wxa.z};
-    if constexpr (FLAT) vn = vcp.z;
-    else vn = pdot(vcp, n);
-    const f2 fz_raw = pmax(pfma(splat(vp.susp_k), pen, -splat(vp.susp_c) * vn), splat(0.f));
-    const f2 Fz = psel(pen.x > 0.f, pen.y > 0.f, fz_raw, splat(0.f));
-    // wheel heading (shared by the axle) projected into each wheel's contact plane
-    const float hc = front ? cs : 1.f, hs = front ? sn : 0.f;
-    const V3 hw = v3(fmaf(R.r0.x, hc, R.r0.y * hs), fmaf(R.r1.x, hc, R.r1.y * hs), fmaf(R.r2.x, hc, R.r2.y * hs));
-    if constexpr (FLAT) {   // one tangent frame for the axle
-        const float inv = rsq(fmaf(hw.x, hw.x, hw.y * hw.y));
-        const float tx_x = inv * hw.x, tx_y = inv * hw.y;
-        tx = V3p{splat(tx_x), splat(tx_y), splat(0.f)};
-        ty = V3p{splat(-tx_y), splat(tx_x), splat(0.f)};
-        vcx = pfma(vcp.x, tx.x, vcp.y * tx.y);
-        vcy = pfma(vcp.y, tx.x, -vcp.x * tx.y);
-    } else {
-        const f2 hn = pdot(hw, n);
-        const V3p t{splat(hw.x) - hn * n.x, splat(hw.y) - hn * n.y, splat(hw.z) - hn * n.z};
-        const f2 inv_t = prsq(pdot(t, t));
-        tx = V3p{inv_t * t.x, inv_t * t.y, inv_t * t.z};
-        ty = pcross(n, tx);
-        vcx = pdot(vcp, tx);
-        vcy = pdot(vcp, ty);
-    }
-    const f2 w_i = w_spin;
-    const f2 vden = pmax(splat(vp.v_min), splat(vp.slip_peak) * pmax(pabs(vcx), pabs(w_i * r)));
-    const f2 inv_vden = prcp(vden);
-    const f2 sx = (w_i * r - vcx) * inv_vden, sy = -vcy * inv_vden;
-    const f2 sig = psqrt(pfma(sx, sx, sy * sy));
-    const f2 inv_sig = prcp(pmax(sig, splat(1.f)));
-    const f2 gq = pfma(splat(ec.mu_s), pmax(splat(1.f) - sig, splat(0.f)),
-                       pfma(splat(ec.mu_s - ec.mu_d), inv_sig, splat(ec.mu_d)) * inv_sig);
-    const f2 K = pmin(Fz * gq * inv_vden, splat(ec.K_cap));
-    const bool driven = (vp.drive == 1) || !front;
-    const f2 d = splat(driven ? ec.damp : 0.f);
-    const f2 rel = w_i * splat(vd.inv_wlim);
-    const f2 tau_hi = pclamp(splat(vp.motor_sat) * (splat(1.f) - rel), splat(0.f), splat(vp.motor_limit));
-    const f2 tau_lo = pclamp(splat(vp.motor_sat) * (splat(-1.f) - rel), splat(-vp.motor_limit), splat(0.f));
-    const f2 Iw_h = splat(vd.Iw_h);
-    const f2 A = pfma(K, splat(vd.r2), splat(vd.A0));
-    const f2 rhs0 = pfma(Iw_h, w_i, r * K * vcx);
-    const f2 w_u = pfma(d, wt, rhs0) * prcp(A + d);
-    const f2 tau_u = d * (wt - w_u);
-    const f2 tau = pclamp(tau_u, tau_lo, tau_hi);
-    const f2 w_c = (rhs0 + tau) * prcp(A);
-    f2 w_n = psel(tau.x == tau_u.x, tau.y == tau_u.y, w_u, w_c);
-    f2 Fx = K * pfma(w_n, r, -vcx);
-    f2 Fy = -K * vcy;
-    const f2 Fmax = splat(ec.mu_s) * Fz;
-    const f2 mag2 = pfma(Fx, Fx, Fy * Fy);
-    const f2 fm2 = Fmax * Fmax;
-    const bool sat0 = mag2.x > fm2.x, sat1 = mag2.y > fm2.y;
-    if (sat0 || sat1) {   // friction-circle saturation: re-solve the wheel against the force actually applied
-        const f2 scale = psel(sat0, sat1, Fmax * prsq(pmax(mag2, splat(1e-30f))), splat(1.f));
-        Fx *= scale;
-        Fy *= scale;
-        const f2 inv_A2d = splat(driven ? ec.inv_A0_damp : ec.inv_A0);
-        const f2 rhs2 = pfma(Iw_h, w_i, -r * Fx);
-        const f2 w_u2 = pfma(d, wt, rhs2) * inv_A2d;
-        const f2 tau_u2 = d * (wt - w_u2);
-        const f2 tau2 = pclamp(tau_u2, tau_lo, tau_hi);
-        const f2 w_c2 = (rhs2 + tau2) * splat(ec.inv_A0);
-        const f2 w_s = psel(tau2.x == tau_u2.x, tau2.y == tau_u2.y, w_u2, w_c2);
-        w_n = psel(sat0, sat1, w_s, w_n);
-    }
-    w_spin = w_n;
-    V3p Fi;
-    if constexpr (FLAT) Fi = V3p{pfma(Fx, tx.x, -Fy * tx.y), pfma(Fx, tx.y, Fy * tx.x), Fz};
-    else Fi = V3p{pfma(Fz, n.x, pfma(Fx, tx.x, Fy * ty.x)), pfma(Fz, n.y, pfma(Fx, tx.y, Fy * ty.y)),
-                  pfma(Fz, n.z, pfma(Fx, tx.z, Fy * ty.z))};
-    const V3p Ti = pcross(arm, Fi);
-    F = v3(Fi.x.x + Fi.x.y, Fi.y.x + Fi.y.y, Fi.z.x + Fi.z.y);
-    T = v3(Ti.x.x + Ti.x.y, Ti.y.x + Ti.y.y, Ti.z.x + Ti.z.y);
+}
+
+template <class Ground, bool STEER, bool MOTOR, bool FIRST>
+WL_DEV void wheel_step(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Ground& ground, const Mat3& R,
+                       const VehState& s, V3 vb, float bx, float by, float hc, float hs, float d, float inv_A0d, float wt,
+                       float& w_spin, Wrench& w) {
+    const Contact c = wheel_contact(vp, vd, ground, R, s, vb, bx, by);
+    const WheelOut o = wheel_tyre<STEER, MOTOR>(vp, vd, ec, c.n, c.vc, c.pen, hc, hs, d, inv_A0d, wt, w_spin);
+    wrench_add<FIRST>(w, c, o);
 }
 
 // steering: implicit PD drive, effort- and rate-limited (hound.py:5-12)
@@ -309,30 +268,26 @@ WL_DEV void steer_update(const WlVehicleParams& vp, const VehDerived& vd, const 
     s.om = om_n;
 }
 
-// semi-implicit Euler of the rigid body under the summed contact force F / torque T (world, about the CoM)
-WL_DEV void body_integrate(const VehDerived& vd, const EnvConst& ec, VehState& s, const Mat3& R, V3 F, V3 T) {
-    F.z -= ec.weight;
+// semi-implicit Euler of the rigid body under the summed contact force Fb / torque Tb about the CoM (BODY frame);
+// Fz_w: world z component of the contact force where the caller knows it without R (flat ground: the sum of the loads)
+template <bool FLAT>
+WL_DEV void body_integrate(const VehDerived& vd, const EnvConst& ec, VehState& s, const Mat3& R, V3 Fb, V3 Tb, float Fz_w) {
+    const V3 F = v3(dot(R.r0, Fb), dot(R.r1, Fb), (FLAT ? Fz_w : dot(R.r2, Fb)) - ec.weight);
     s.v = fma3(ec.h_inv_mass, F, s.v);
-    const V3 Tb = mul_t(R, T);
     const V3 Iw = v3(ec.Ib.x * s.wb.x, ec.Ib.y * s.wb.y, ec.Ib.z * s.wb.z);
     const V3 gyro = cross(s.wb, Iw);
     s.wb = v3(fmaf(ec.h_inv_Ib.x, Tb.x - gyro.x, s.wb.x), fmaf(ec.h_inv_Ib.y, Tb.y - gyro.y, s.wb.y),
               fmaf(ec.h_inv_Ib.z, Tb.z - gyro.z, s.wb.z));
-    const V3 w2 = mul(R, s.wb);
     s.x = fma3(vd.h, s.v, s.x);
-    const float hh = vd.half_h;
+    // q <- q + (h / 2) q (0, w_b)   [== (h / 2) (0, R w_b) q, the world-rate form of the spec], then renormalise
+    const V3 u = vd.half_h * s.wb;
     Quat q = s.q;
-    Quat dq;
-    dq.w = -w2.x * q.x - w2.y * q.y - w2.z * q.z;
-    dq.x = w2.x * q.w + w2.y * q.z - w2.z * q.y;
-    dq.y = -w2.x * q.z + w2.y * q.w + w2.z * q.x;
-    dq.z = w2.x * q.y - w2.y * q.x + w2.z * q.w;
-    q.w = fmaf(hh, dq.w, q.w);
-    q.x = fmaf(hh, dq.x, q.x);
-    q.y = fmaf(hh, dq.y, q.y);
-    q.z = fmaf(hh, dq.z, q.z);
-    const float inv_n = rsq(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-    s.q = Quat{q.w * inv_n, q.x * inv_n, q.y * inv_n, q.z * inv_n};
+    const float nw = fmaf(-q.x, u.x, fmaf(-q.y, u.y, fmaf(-q.z, u.z, q.w)));
+    const float nx = fmaf(q.w, u.x, fmaf(q.y, u.z, fmaf(-q.z, u.y, q.x)));
+    const float ny = fmaf(q.w, u.y, fmaf(q.z, u.x, fmaf(-q.x, u.z, q.y)));
+    const float nz = fmaf(q.w, u.z, fmaf(q.x, u.y, fmaf(-q.y, u.x, q.z)));
+    const float inv_n = rsq(fmaf(nw, nw, fmaf(nx, nx, fmaf(ny, ny, nz * nz))));
+    s.q = Quat{nw * inv_n, nx * inv_n, ny * inv_n, nz * inv_n};
 }
 
 // sum over the 4 lanes of a quad with DPP quad_perm swaps (no LDS traffic); every lane gets the SAME bits
@@ -349,87 +304,62 @@ WL_DEV float quad_bcast(float v) {
 WL_DEV V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
 
 // One integrator sub-step.
-//   LANES == 1: one lane owns the env and loops over its 4 wheels (throughput form: no redundant work).
+//   LANES == 1: one lane owns the env and visits its 4 wheels (throughput form: no redundant work).  UNROLL: all four
+//               wheels inlined (sub-expressions shared across axles and sides, more registers) or a rolled loop over
+//               the two axles (fewer registers -> more wavefronts per SIMD).
 //   LANES == 4: a quad of lanes owns the env, lane `wid` owns wheel `wid` (s.wheel[0] is ITS spin); the body state is
 //               replicated, the wheel forces are summed across the quad with DPP.  Latency form for small env counts:
 //               the critical path per sub-step drops from 4 wheels to 1.
-template <int LANES, class Ground, bool PACKED = true>
+template <int LANES, class Ground, bool UNROLL = true>
 WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
                             const Ground& ground, int wid, float sn, float cs /* sin / cos of the steer angle in force */) {
     const Mat3 R = mat_from_quat(s.q);
-    const V3 ww = mul(R, s.wb);
-    V3 F = v3(0.f, 0.f, 0.f), T = v3(0.f, 0.f, 0.f);
-    if constexpr (LANES == 1 && PACKED) {
-        // two iterations (rear, front axle), the two wheels of an axle as packed pairs
-#pragma unroll 1
-        for (int ax = 0; ax < 2; ++ax) {
-            const bool front = ax == 1;
-            const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r;
-            const float sx_ = fmaf(R.r0.x, bx, R.r0.z * vd.zrel), sy_ = fmaf(R.r1.x, bx, R.r1.z * vd.zrel);
-            const float cxl = s.x.x + fmaf(R.r0.y, vp.half_track, sx_), cxr = s.x.x + fmaf(R.r0.y, -vp.half_track, sx_);
-            const float cyl = s.x.y + fmaf(R.r1.y, vp.half_track, sy_), cyr = s.x.y + fmaf(R.r1.y, -vp.half_track, sy_);
-            float zl, zr;
-            V3 nl, nr, Fa, Ta;
-            ground.sample(cxl, cyl, zl, nl);
-            ground.sample(cxr, cyr, zr, nr);
-            const V3p n{f2{nl.x, nr.x}, f2{nl.y, nr.y}, f2{nl.z, nr.z}};
-            f2 w = front ? f2{s.wheel[2], s.wheel[3]} : f2{s.wheel[0], s.wheel[1]};
-            const f2 wt = front ? f2{ec.wheel_target[2], ec.wheel_target[3]} : f2{ec.wheel_target[0], ec.wheel_target[1]};
-            wheel_force_axle<Ground::kFlat>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, f2{zl, zr}, n, front, wt, w, Fa, Ta);
-            s.wheel[0] = front ? s.wheel[0] : w.x;
-            s.wheel[1] = front ? s.wheel[1] : w.y;
-            s.wheel[2] = front ? w.x : s.wheel[2];
-            s.wheel[3] = front ? w.y : s.wheel[3];
-            F = F + Fa;
-            T = T + Ta;
-        }
-    } else if constexpr (LANES == 1) {
-        // rolled loop over the four wheels, one wheel's temporaries live at a time: the low-register variant (93 VGPRs -> 5
-        // wavefronts per SIMD) for batches large enough to fill every SIMD several times over
-#pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
-            const bool front = i >= 2, left = (i & 1) == 0;
-            const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;
-            const float cx = s.x.x + fmaf(R.r0.x, bx, fmaf(R.r0.y, by, R.r0.z * vd.zrel));
-            const float cy = s.x.y + fmaf(R.r1.x, bx, fmaf(R.r1.y, by, R.r1.z * vd.zrel));
-            float zg;
-            V3 n, Fi, Ti;
-            ground.sample(cx, cy, zg, n);
-            float w = i == 0 ? s.wheel[0] : i == 1 ? s.wheel[1] : i == 2 ? s.wheel[2] : s.wheel[3];
-            const float wt = i == 0 ? ec.wheel_target[0] : i == 1 ? ec.wheel_target[1] : i == 2 ? ec.wheel_target[2] : ec.wheel_target[3];
-            wheel_force<Ground::kFlat>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, wt, w, Fi, Ti);
-            s.wheel[0] = i == 0 ? w : s.wheel[0];
-            s.wheel[1] = i == 1 ? w : s.wheel[1];
-            s.wheel[2] = i == 2 ? w : s.wheel[2];
-            s.wheel[3] = i == 3 ? w : s.wheel[3];
-            F = F + Fi;
-            T = T + Ti;
+    const V3 vb = mul_t(R, s.v);
+    Wrench w;
+    if constexpr (LANES == 1) {
+        const float ht = vp.half_track, bxr = -vp.half_wheelbase_r, bxf = vp.half_wheelbase_f;
+        // rear axle: always driven, never steered
+        wheel_step<Ground, false, true, true>(vp, vd, ec, ground, R, s, vb, bxr, ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
+                                              ec.wheel_target[0], s.wheel[0], w);
+        if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
+        wheel_step<Ground, false, true, false>(vp, vd, ec, ground, R, s, vb, bxr, -ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
+                                               ec.wheel_target[1], s.wheel[1], w);
+        if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
+        // front axle: steered; driven only with 4WD (uniform branch: the undriven wheel has no motor arithmetic at all)
+        if (vp.drive == 1) {
+            wheel_step<Ground, true, true, false>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, ec.damp, ec.inv_A0_damp,
+                                                  ec.wheel_target[2], s.wheel[2], w);
+            if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
+            wheel_step<Ground, true, true, false>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, ec.damp, ec.inv_A0_damp,
+                                                  ec.wheel_target[3], s.wheel[3], w);
+        } else {
+            wheel_step<Ground, true, false, false>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, 0.f, ec.inv_A0, 0.f, s.wheel[2], w);
+            if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
+            wheel_step<Ground, true, false, false>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, 0.f, ec.inv_A0, 0.f, s.wheel[3], w);
         }
     } else {
-        const bool front = wid >= 2, left = (wid & 1) == 0;
-        const float bx = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r, by = left ? vp.half_track : -vp.half_track;
-        const float cx = s.x.x + fmaf(R.r0.x, bx, fmaf(R.r0.y, by, R.r0.z * vd.zrel));
-        const float cy = s.x.y + fmaf(R.r1.x, bx, fmaf(R.r1.y, by, R.r1.z * vd.zrel));
-        float zg;
-        V3 n, Fi, Ti;
-        ground.sample(cx, cy, zg, n);
-        wheel_force<Ground::kFlat>(vp, vd, ec, R, s.x, s.v, ww, cs, sn, zg, n, front, left, ec.wt_lane, s.wheel[0], Fi, Ti);
-        F = quad_sum(Fi);
-        T = quad_sum(Ti);
+        const bool front = wid >= 2;
+        const float hc = front ? cs : 1.f, hs = front ? sn : 0.f;
+        wheel_step<Ground, true, true, true>(vp, vd, ec, ground, R, s, vb, ec.bx_lane, ec.by_lane, hc, hs, ec.d_lane, ec.inv_A0d_lane,
+                                             ec.wt_lane, s.wheel[0], w);
+        w.F = quad_sum(w.F);
+        w.T = quad_sum(w.T);
+        if constexpr (Ground::kFlat) w.Fz = quad_sum(w.Fz);
     }
-    body_integrate(vd, ec, s, R, F, T);
+    if constexpr (LANES == 1 && !UNROLL) __builtin_amdgcn_sched_barrier(0);
+    body_integrate<Ground::kFlat>(vd, ec, s, R, w.F, w.T, w.Fz);
 }
 
 // decimation x substeps integrator sub-steps (everything in registers).  A variant that software-pipelined the steering
 // joint one sub-step ahead measured no gain: a wavefront alone on its SIMD pays ~3 ns per instruction whatever the
 // chain looks like (tools/microbench/valu_issue.hip), so only fewer instructions on the critical lane help.
-template <int LANES, class Ground, bool PACKED = true>
+template <int LANES, class Ground, bool UNROLL = true>
 WL_DEV void vehicle_integrate(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
                               const Ground& ground, int wid = 0) {
     for (int k = 0; k < vd.n_sub; ++k) {
         steer_update(vp, vd, ec, s);
         float sn, cs;
         sincos_fast(s.th, sn, cs);   // |th| <= tan(0.488) rad: hardware sin/cos, ~1e-6 abs
-        vehicle_substep<LANES, Ground, PACKED>(vp, vd, ec, s, ground, wid, sn, cs);
+        vehicle_substep<LANES, Ground, UNROLL>(vp, vd, ec, s, ground, wid, sn, cs);
     }
 }
