@@ -15,18 +15,17 @@ namespace {
 constexpr int kHotArgBytes = 56;   // state 0, episode_len 8, actions 16, stride 24, n_envs 28, env_offset 32, seed 40, step 48
 
 // LANES = 1: lane per env (throughput form).  LANES = 4: quad per env, one wheel per lane (latency form, small n).
-// PACKED (lane form only): the two wheels of an axle as packed float2 -- faster while the SIMDs hold ~1 wavefront each;
-// !PACKED: rolled scalar wheel loop in 93 VGPRs -> 5 wavefronts per SIMD, faster once every SIMD is filled several times
-// (same-box A/B, us per step, packed / scalar-5: 65 536 envs 13.5 / 16.1, 262 144 32.8 / 33.1, 1 M 103.8 / 99.7,
-// 4 M 398 / 368).
-template <int LANES, class Ground, bool PACKED = true>
-__global__ void __launch_bounds__(kBlock, PACKED ? WL_MIN_WAVES : 5) drift_step_kernel(float* __restrict__ state, int32_t* __restrict__ episode_len,
+// UNROLL (lane form only): the four wheels inlined and interleaved by the scheduler (more registers, more ILP: better
+// while the SIMDs hold few wavefronts) or fenced one after the other (fewer registers -> one more wavefront per SIMD).
+// DRIVE (lane form): the drive train compiled in (wl_vehicle.h); -1: the quad form decides per lane at run time.
+template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1>
+__global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? WL_LANE_WAVES : WL_LOWREG_WAVES)) drift_step_kernel(float* __restrict__ state, int32_t* __restrict__ episode_len,
                                                             const float2* __restrict__ actions, const int stride,
                                                             const int n_envs, const int env_offset, const uint64_t seed,
                                                             const uint64_t step, const WlDriftParams p_arg,
                                                             const VehDerived vd_arg, const WlEnvBuffers b_arg,
                                                             const float* __restrict__ noise, const WlStepOut out,
-                                                            const Ground ground) {
+                                                            const Ground ground, const MetricSlots slots) {
     constexpr int kEnvs = kBlock / LANES;   // envs per block
     // quad (latency) form: parameters by one batch of vector loads from the kernarg segment (p_arg right behind the
     // hot arguments, vd_arg behind it); lane (throughput) form: the compiler's scalar loads -- latency is hidden by
@@ -45,16 +44,15 @@ __global__ void __launch_bounds__(kBlock, PACKED ? WL_MIN_WAVES : 5) drift_step_
     b.stride = stride;
     b.n_envs = n_envs;
     b.env_offset = env_offset;
-    __shared__ float tile[LANES == 1 ? kEnvs * kObsPad : 1];      // lane form only: obs transposing tile
-    __shared__ float blk_metrics[WL_M_COUNT];                      // lane form only
-    const int le = threadIdx.x / LANES;             // env slot within the block
+    // lane form only: per-WAVEFRONT obs transposing tile and metric accumulators (no block barrier anywhere)
+    __shared__ float tile[LANES == 1 ? kEnvs * kObsPad : 1];
+    __shared__ float wave_metrics[LANES == 1 ? (kBlock / 64) * WL_M_COUNT : 1];
+    const int wave = threadIdx.x >> 6;
     const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);   // this lane's wheel (quad form)
     const bool lead = LANES == 1 || wid == 0;       // the lane that writes the env's shared rows / outputs
-    const int e = blockIdx.x * kEnvs + le;
-    if constexpr (LANES == 1) {
-        if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
-        __syncthreads();
-    }
+    const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
+    const MetricSink<LANES> ms{wave_metrics + (LANES == 1 ? wave * WL_M_COUNT : 0), metric_shard(b, slots.cur)};
+    ms.open();
     if (e < b.n_envs) {
         const Rows S = make_rows(b.state, b.stride);
         EnvConst ec;
@@ -63,29 +61,21 @@ __global__ void __launch_bounds__(kBlock, PACKED ? WL_MIN_WAVES : 5) drift_step_
         load_env_const(S, p.vehicle, vd, e, ec);
         load_rows<LANES>(S, b, p, e, wid, r);
         const uint32_t gid = (uint32_t)(b.env_offset + e);
-        // per-step metric ring: accumulate into slot step % R (first use of the non-preloaded kernarg fields: after
-        // the loads above are in flight)
-        const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
-        const MetricSink<LANES> ms{blk_metrics, metric_shard(b, m_slot)};
+        float* tile_w = tile + (LANES == 1 ? wave * 64 * kObsPad : 0);
         if constexpr (LANES == 4) {
             // the step's random draws need only (seed, gid, step): computed while the state loads above are in flight
             const StepDraws pre = draw_step(p, b.ref_poses, gid, step, seed, wid);
-            drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, le, wid, lead, gid, seed, step, tile, ms, nullptr,
-                                  &pre);
+            drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, wid, lead, gid, seed, step, tile_w, ms, nullptr, &pre);
         } else {
-            drift_env_step<LANES, PACKED>(p, b, vd, ground, S, ec, r, a, noise, out, e, le, wid, lead, gid, seed, step, tile, ms);
+            drift_env_step<LANES, UNROLL, DRIVE>(p, b, vd, ground, S, ec, r, a, noise, out, e, wid, lead, gid, seed, step, tile_w, ms);
         }
         store_rows<LANES>(S, b, p, e, wid, lead, r);
     }
-    const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
-    if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);   // the slot the NEXT launch will use
+    if (b.metrics_slots > 1) clear_metric_slot(b, slots.next);   // the slot the NEXT launch will use
     if constexpr (LANES == 1) {
-        __syncthreads();
-        flush_obs(tile, out.obs, blockIdx.x * kEnvs, b.n_envs, kEnvs);
-        if (threadIdx.x < WL_M_COUNT) {
-            const float m = blk_metrics[threadIdx.x];
-            if (m != 0.f) atomicAdd(metric_shard(b, m_slot) + threadIdx.x, m);   // threads 0..15 = wavefront 0 of the block
-        }
+        const int wave_env0 = blockIdx.x * kEnvs + wave * 64;
+        if (wave_env0 < b.n_envs) flush_obs_wave(tile + wave * 64 * kObsPad, out.obs, wave_env0, b.n_envs);
+        ms.close();
     }
 }
 
@@ -98,23 +88,23 @@ __global__ void __launch_bounds__(kBlock) drift_rollout_kernel(const WlDriftPara
                                                                const float2* __restrict__ actions, const WlStepOut out,
                                                                const int64_t obs_step_stride, const int64_t vec_step_stride,
                                                                const int n_steps, const uint64_t seed, const uint64_t step0,
-                                                               const Ground ground, const VehDerived vd_arg) {
+                                                               const Ground ground, const VehDerived vd_arg, const MetricSlots slots) {
     constexpr int LANES = 4, kEnvs = kBlock / LANES;
     WlDriftParams p = p_arg;
     VehDerived vd = vd_arg;
     pin_params_vgpr(p, vd);
-    const int le = threadIdx.x / LANES, wid = threadIdx.x & 3;
+    const int wid = threadIdx.x & 3;
     const bool lead = wid == 0;
-    const int e = blockIdx.x * kEnvs + le;
-    const int m_slot = b.metrics_slots > 1 ? (int)(step0 % (uint64_t)b.metrics_slots) : 0;
-    if (b.metrics_slots > 1) clear_metric_slot(b, (int)((step0 + (uint64_t)n_steps) % (uint64_t)b.metrics_slots));
+    const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
+    if (b.metrics_slots > 1) clear_metric_slot(b, slots.next);
     if (e >= b.n_envs) return;     // the quad form has no block-level barrier: whole quads may leave
-    const MetricSink<LANES> ms{nullptr, metric_shard(b, m_slot)};
+    const MetricSink<LANES> ms{nullptr, metric_shard(b, slots.cur)};
     const Rows S = make_rows(b.state, b.stride);
     EnvConst ec;
     DriftRows r;
     load_env_const(S, p.vehicle, vd, e, ec);
     load_rows<LANES>(S, b, p, e, wid, r);
+    const uint32_t gid = (uint32_t)(b.env_offset + e);
     float2 a_next = n_steps > 0 ? actions[e] : make_float2(0.f, 0.f);
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = out;
@@ -125,8 +115,9 @@ __global__ void __launch_bounds__(kBlock) drift_rollout_kernel(const WlDriftPara
         if (o.dones) o.dones += k * vec_step_stride;
         const float2 a = a_next;
         if (k + 1 < n_steps) a_next = actions[(int64_t)(k + 1) * b.n_envs + e];   // prefetch: hidden behind the physics
-        drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, nullptr, o, e, le, wid, lead, (uint32_t)(b.env_offset + e), seed,
-                              step0 + (uint64_t)k, nullptr, ms);
+        const StepDraws pre = draw_step(p, b.ref_poses, gid, step0 + (uint64_t)k, seed, wid);
+        drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, nullptr, o, e, wid, lead, gid, seed, step0 + (uint64_t)k, nullptr, ms,
+                              nullptr, &pre);
     }
     store_rows<LANES>(S, b, p, e, wid, lead, r);
 }
@@ -150,7 +141,7 @@ __global__ void __launch_bounds__(kBlock) drift_mdp_kernel(const WlDriftParams p
         const float sm = 0.5f * (steer[e] + steer[stride + e]);
         const bool to = timed_out ? timed_out[e] != 0 : false;
         const bool term = cart_off_track(P.x, P.y, p.straight, p.r_in, p.r_out);
-        const DriftTerms tm = drift_terms(p, P, vb, wb, wwz, sm, term, to, atan2f(vb.y, vb.x));
+        const DriftTerms tm = drift_terms(p, P, vb, wb, wwz, sm, term, to, atan2_fast(vb.y, vb.x));
         const float step_dt = p.sim_dt * (float)p.decimation;
         float r = 0.f;
 #pragma unroll
@@ -257,6 +248,24 @@ const char* wl_strerror(int code) {
     }
 }
 
+// one fused env.step() launch in the form the batch size (or WlEnvBuffers.lanes) selects
+static void launch_step(const WlDriftParams* p, const WlEnvBuffers* b, const VehDerived& vd, const float2* actions, const float* noise,
+                        const WlStepOut& out, uint64_t seed, uint64_t step, hipStream_t stream) {
+    const MetricSlots slots = metric_slots(b, step);
+#define WL_STEP_ARGS b->state, b->episode_len, actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b, noise, out, FlatGround{}, slots
+    const int grid = grid_for(b->n_envs);
+    const bool awd = p->vehicle.drive == 1;
+    if (use_quad(b)) drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, stream>>>(WL_STEP_ARGS);
+    else if (use_unrolled(b)) {
+        if (awd) drift_step_kernel<1, FlatGround, true, 1><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
+        else drift_step_kernel<1, FlatGround, true, 0><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
+    } else {
+        if (awd) drift_step_kernel<1, FlatGround, false, 1><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
+        else drift_step_kernel<1, FlatGround, false, 0><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
+    }
+#undef WL_STEP_ARGS
+}
+
 int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* actions, const float* noise,
                   const WlStepOut* out, uint64_t seed, uint64_t step, void* stream) {
     int rc = check_buffers(p, b);
@@ -264,18 +273,7 @@ int wl_drift_step(const WlDriftParams* p, const WlEnvBuffers* b, const float* ac
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated) return WL_EINVAL;
     clear_error();
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
-    if (use_quad(b))
-        drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
-            b->state, b->episode_len, (const float2*)actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b,
-            noise, *out, FlatGround{});
-    else if (use_packed(b))
-        drift_step_kernel<1, FlatGround, true><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
-            b->state, b->episode_len, (const float2*)actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b,
-            noise, *out, FlatGround{});
-    else
-        drift_step_kernel<1, FlatGround, false><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(
-            b->state, b->episode_len, (const float2*)actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b,
-            noise, *out, FlatGround{});
+    launch_step(p, b, vd, (const float2*)actions, noise, *out, seed, step, (hipStream_t)stream);
     return launch_status();
 }
 
@@ -286,9 +284,7 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
     if (rc != WL_OK) return rc;
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
     clear_error();
-    const int grid = grid_for(b->n_envs);
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
-    const bool quad = use_quad(b);
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = *out;
         o.obs += k * obs_step_stride;
@@ -296,19 +292,7 @@ int wl_drift_rollout(const WlDriftParams* p, const WlEnvBuffers* b, const float*
         o.terminated += k * vec_step_stride;
         o.truncated += k * vec_step_stride;
         if (o.dones) o.dones += k * vec_step_stride;
-        const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
-        if (quad)
-            drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
-                b->state, b->episode_len, a, (int)b->stride, b->n_envs, b->env_offset, seed, step0 + (uint64_t)k, *p, vd, *b,
-                nullptr, o, FlatGround{});
-        else if (use_packed(b))
-            drift_step_kernel<1, FlatGround, true><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-                b->state, b->episode_len, a, (int)b->stride, b->n_envs, b->env_offset, seed, step0 + (uint64_t)k, *p, vd, *b,
-                nullptr, o, FlatGround{});
-        else
-            drift_step_kernel<1, FlatGround, false><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-                b->state, b->episode_len, a, (int)b->stride, b->n_envs, b->env_offset, seed, step0 + (uint64_t)k, *p, vd, *b,
-                nullptr, o, FlatGround{});
+        launch_step(p, b, vd, (const float2*)(actions + (int64_t)k * b->n_envs * 2), nullptr, o, seed, step0 + (uint64_t)k, (hipStream_t)stream);
     }
     return launch_status();
 }
@@ -323,7 +307,7 @@ int wl_drift_rollout_persistent(const WlDriftParams* p, const WlEnvBuffers* b, c
     clear_error();
     drift_rollout_kernel<FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
         *p, *b, (const float2*)actions, *out, obs_step_stride, vec_step_stride, n_steps, seed, step0, FlatGround{},
-        derive_vehicle(p->vehicle, p->sim_dt, p->decimation));
+        derive_vehicle(p->vehicle, p->sim_dt, p->decimation), metric_slots(b, step0, (uint64_t)n_steps));
     return launch_status();
 }
 

@@ -83,9 +83,8 @@ WL_DEV Noise12 gather_quad_noise(const float z[4]) {
     return nz;
 }
 
-// LANES == 4: lanes 0..2 of the quad each draw ONE Philox block (4 normals) and the 12 values are gathered with DPP
-// quad broadcasts -- one Philox + two Box-Muller on the critical path instead of three + six.  Must be called by all
-// four lanes of the quad.
+// observation noise: off, the caller's parity tensor, or (lane form) three Philox blocks -> 12 normals.  The quad form
+// draws its normals in draw_step (one block per lane) and gathers them with gather_quad_noise.
 template <int LANES>
 WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise, int64_t stride, int e, uint32_t gid,
                          uint64_t step, uint64_t seed, int wid = 0) {
@@ -96,12 +95,6 @@ WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise
     } else if (noise) {   // parity mode: caller-supplied standard normals [12][stride]
 #pragma unroll
         for (int k = 0; k < 12; ++k) nz.z[k] = noise[k * stride + e];
-    } else if constexpr (LANES == 4) {
-        const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + (uint32_t)min(wid, 2), seed);
-        float z[4];
-        box_muller(u.x, u.y, z[0], z[1]);
-        box_muller(u.z, u.w, z[2], z[3]);
-        nz = gather_quad_noise(z);
     } else {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
@@ -114,30 +107,59 @@ WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise
 }
 
 // Everything random about one env-step that does not depend on the env's state: (seed, global env id, step) key it all.
-// The per-step kernel (quad form) draws it BEFORE it first touches the state rows, i.e. in the shadow of the cold-L2
-// load of the state matrix, instead of on the tail of the step where each draw is a dependent chain of ~100
-// instructions (and the reset's reference-pose lookup a dependent memory round trip) on the kernel's critical path:
-// the kernel ends with its slowest wavefront, and with 16 envs per wavefront nearly every step some wavefront resets
-// and most have a push.  Persistent kernels have no load shadow and draw in place.
+// Quad form: drawn at the top of the step -- in the per-step kernel that is the shadow of the cold-L2 load of the state
+// matrix -- instead of lazily in the reset / push branches on the tail, where each draw is a dependent chain of ~100
+// instructions on the kernel's critical path (the kernel ends with its slowest wavefront, and with 16 envs per
+// wavefront nearly every step some wavefront resets and most have a push).  The draws are SPREAD over the quad: lane w
+// computes ONE event block, Philox stream w (WL_RS_RESET, WL_RS_TIMERS, WL_RS_PUSH_HF, WL_RS_PUSH_LF == 0 .. 3), and
+// one observation-noise block (stream 4 + min(w, 2)) -- two Philox blocks per lane where round 1 had five -- and the
+// branch that needs an event pulls it from its lane with DPP quad broadcasts (the branch conditions are functions of
+// the replicated env state, so a quad is always wholly inside or outside a branch).
 struct StepDraws {
-    ResetDraw reset;
-    F4 push_hf, push_lf;
-    float z[4];        // this lane's four observation-noise normals (lanes 0..2 of the quad; see obs_noise)
+    F4 ev;        // lane 0: reset pose (x, y, yaw) ; lane 1: re-armed timers (hf, lf) ; lane 2: hf-push u ; lane 3: lf-push u
+    float z[4];   // this lane's four observation-noise normals (lanes 0..2 of the quad; see gather_quad_noise)
 };
 
 WL_DEV StepDraws draw_step(const WlDriftParams& p, const float* __restrict__ ref, uint32_t gid, uint64_t step, uint64_t seed,
                            int wid) {
     StepDraws d;
-    d.reset = draw_reset(p, ref, gid, step, seed);
-    d.push_hf = philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
-    d.push_lf = philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
-    const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + (uint32_t)min(wid, 2), seed);
-    box_muller(u.x, u.y, d.z[0], d.z[1]);
-    box_muller(u.z, u.w, d.z[2], d.z[3]);
+    const F4 u = philox_uniform4(gid, step, (uint32_t)wid, seed);
+    // both reset streams are post-processed by every lane on ITS block, branch-free (only lane 0's pose and lane 1's
+    // timers are ever read): the reference-pose lookup is a dependent memory round trip that belongs up here too
+    const int idx = min((int)(u.x * (float)p.num_ref_points), p.num_ref_points - 1);
+    const float rx = fmaf(2.f * u.y - 1.f, p.pos_noise, ref[idx]), ry = fmaf(2.f * u.z - 1.f, p.pos_noise, ref[32 + idx]);
+    const float ryaw = fmaf(2.f * u.w - 1.f, p.yaw_noise, ref[64 + idx]);
+    const float thf = fmaf(u.x, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
+    const float tlf = fmaf(u.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
+    d.ev.x = opaque(wid == 0 ? rx : wid == 1 ? thf : u.x);
+    d.ev.y = opaque(wid == 0 ? ry : wid == 1 ? tlf : u.y);
+    d.ev.z = opaque(wid == 0 ? ryaw : u.z);
+    d.ev.w = opaque(u.w);
+    const F4 n = philox_uniform4(gid, step, WL_RS_NOISE0 + (uint32_t)min(wid, 2), seed);
+    box_muller(n.x, n.y, d.z[0], d.z[1]);
+    box_muller(n.z, n.w, d.z[2], d.z[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d.z[k] = opaque(d.z[k]);   // computed HERE, not sunk to the observation code on the tail
     return d;
 }
+// the events of the quad, pulled from the lanes that drew them
+WL_DEV ResetDraw quad_reset_draw(const StepDraws& d) {
+    ResetDraw r;
+    r.pos = v3(quad_bcast<0>(d.ev.x), quad_bcast<0>(d.ev.y), 0.f);
+    r.yaw = quad_bcast<0>(d.ev.z);
+    float s, c;
+    sincos_fast(0.5f * r.yaw, s, c);
+    r.q = Quat{c, 0.f, 0.f, s};
+    r.timer_hf = quad_bcast<1>(d.ev.x);
+    r.timer_lf = quad_bcast<1>(d.ev.y);
+    return r;
+}
+template <int K>
+WL_DEV F4 quad_event(const StepDraws& d) {
+    return F4{quad_bcast<K>(d.ev.x), quad_bcast<K>(d.ev.y), quad_bcast<K>(d.ev.z), quad_bcast<K>(d.ev.w)};
+}
 
-// flush this block's LDS obs tile ([kBlock][kObsPad]) to obs[n][14]: contiguous dword stores per wavefront
+// flush a tile of `n_slots` obs rows ([slot][kObsPad], row-padded) to obs[n][14]: contiguous dword stores
 WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0, int n, int envs_per_block = kBlock) {
     const int n_valid = min(envs_per_block, n - block_env0);
     const int total = n_valid * kObsDim;
@@ -145,6 +167,26 @@ WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0
     for (int f = threadIdx.x; f < total; f += kBlock) {
         const int e = f / kObsDim, k = f - e * kObsDim;
         dst[f] = tile[e * kObsPad + k];
+    }
+}
+// Lane form: every WAVEFRONT owns a 64-row tile and flushes it itself -- LDS accesses of one wavefront execute in
+// order, so the transposition needs no block barrier (round 1: one tile per block behind __syncthreads, the
+// wavefronts of a block waiting for the slowest).  Element f = lane + 64 j of the wavefront's 896 contiguous output
+// floats sits at tile[f + f / 14].
+WL_DEV void flush_obs_wave(const float* tile_w, float* __restrict__ obs, int wave_env0, int n) {
+    const int lane = threadIdx.x & 63;
+    const int n_valid = min(64, n - wave_env0);
+    float* dst = obs + (int64_t)wave_env0 * kObsDim + lane;
+    if (n_valid == 64) {               // wave-uniform: every wavefront but the batch's last
+        const int m = lane * 4682;     // f / 14 == (f * 4682) >> 16 for f < 896
+#pragma unroll
+        for (int j = 0; j < kObsDim; ++j) {
+            const int e = (m + 64 * j * 4682) >> 16;
+            dst[64 * j] = tile_w[lane + 64 * j + e];
+        }
+    } else {
+        const int total = n_valid * kObsDim;
+        for (int f = lane; f < total; f += 64) dst[f - lane] = tile_w[f + f / kObsDim];
     }
 }
 
@@ -161,6 +203,13 @@ struct DriftRows {
     int ep_len;
 };
 
+// rows that only the tail of the step reads
+WL_DEV void load_bookkeeping_rows(const Rows& S, const WlEnvBuffers& b, int e, DriftRows& r) {
+    r.timer_hf = S.ld(WL_S_TIMER_HF, e);
+    r.timer_lf = S.ld(WL_S_TIMER_LF, e);
+    r.ep_len = b.episode_len[e];
+}
+
 template <int LANES>
 WL_DEV void load_rows(const Rows& S, const WlEnvBuffers& b, const WlDriftParams& p, int e, int wid, DriftRows& r) {
     r.pos = ld3(S, WL_S_PX, e);
@@ -171,15 +220,13 @@ WL_DEV void load_rows(const Rows& S, const WlEnvBuffers& b, const WlDriftParams&
 #pragma unroll
         for (int i = 0; i < 4; ++i) r.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
     } else {
-        r.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
+        r.wheel[0] = S.ld_lane_row(WL_S_WHEEL_BL + wid, e);
 #pragma unroll
         for (int i = 0; i < WL_DR_NTERMS; ++i) r.epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) : 0.f;
     }
     r.th = S.ld(WL_S_STEER_POS, e);
     r.om = S.ld(WL_S_STEER_VEL, e);
-    r.timer_hf = S.ld(WL_S_TIMER_HF, e);
-    r.timer_lf = S.ld(WL_S_TIMER_LF, e);
-    r.ep_len = b.episode_len[e];
+    if constexpr (LANES == 4) load_bookkeeping_rows(S, b, e, r);   // lane form: fetched after the physics loop (registers)
 }
 
 template <int LANES>
@@ -189,7 +236,7 @@ WL_DEV void store_rows(const Rows& S, const WlEnvBuffers& b, const WlDriftParams
 #pragma unroll
         for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, r.wheel[i]);
     } else {
-        S.st(WL_S_WHEEL_BL + wid, e, r.wheel[0]);
+        S.st_lane_row(WL_S_WHEEL_BL + wid, e, r.wheel[0]);
     }
     if (!lead) return;
     st3(S, WL_S_PX, e, r.pos);
@@ -219,26 +266,50 @@ WL_DEV void load_env_const(const Rows& S, const WlVehicleParams& vp, const VehDe
     env_const_rows(ec, vp, vd, S.ld(WL_S_MASS, e), S.ld(WL_S_MU_S, e), S.ld(WL_S_MU_D, e), S.ld(WL_S_DAMP, e));
 }
 
-// Episode-metric accumulation.  Lane form: LDS atomics per block, <= 16 global atomics per block at the end (many
-// resets per block at large n).  Quad form: resets are rare per wavefront (16 envs), so the few lead lanes that reset go
-// straight to the global accumulators and the kernel needs no LDS and no block barrier at all.
+// Episode-metric accumulation.  Lane form: LDS atomics into the WAVEFRONT's own 16 accumulators (zeroed and flushed by
+// the wavefront itself: no block barrier), <= 16 global atomics per wavefront that had a reset.  Quad form: resets are
+// rare per wavefront (16 envs), so the few lead lanes that reset go straight to the global accumulators and the
+// kernel needs no LDS at all.
 template <int LANES>
 struct MetricSink {
-    float* lds;     // block accumulators (lane form)
+    float* lds;     // this wavefront's accumulators (lane form)
     float* glob;    // this wavefront's shard of this step's slot of the metric ring
     WL_DEV void add(int idx, float v) const {
         if constexpr (LANES == 4) atomicAdd(glob + idx, v);
         else atomicAdd(lds + idx, v);
     }
+    WL_DEV void open() const {    // lane form, before the first add
+        if constexpr (LANES == 1)
+            if ((threadIdx.x & 63) < WL_M_COUNT) lds[threadIdx.x & 63] = 0.f;
+    }
+    WL_DEV void close() const {   // lane form, after the last add (LDS operations of a wavefront complete in order)
+        if constexpr (LANES == 1) {
+            if ((threadIdx.x & 63) < WL_M_COUNT) {
+                const float m = lds[threadIdx.x & 63];
+                if (m != 0.f) atomicAdd(glob + (threadIdx.x & 63), m);
+            }
+        }
+    }
 };
 
+// sum of 16 values as a tree (depth 4): the non-finite guard is on the step's critical path and a chain of 15 dependent
+// adds is 15 x the dependent-issue latency of a wavefront that is alone on its SIMD
+WL_DEV float sum16(const float (&v)[16]) {
+    const float a0 = v[0] + v[1], a1 = v[2] + v[3], a2 = v[4] + v[5], a3 = v[6] + v[7];
+    const float a4 = v[8] + v[9], a5 = v[10] + v[11], a6 = v[12] + v[13], a7 = v[14] + v[15];
+    return ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+
 // ONE env.step() on the register image `r` (shared by the per-step kernel and the persistent rollout kernels): action
-// term -> physics -> terminations -> rewards -> reset -> pushes -> observation row into the block's LDS tile.
-// Writes reward / flags to `out` (already offset to this step); accumulates episode metrics into `blk_metrics` (LDS).
-template <int LANES, bool PACKED = true, class Ground>
+// term -> physics -> terminations -> rewards -> reset -> pushes -> observation row.
+// Writes reward / flags to `out` (already offset to this step); accumulates episode metrics into `ms`.
+//   tile: lane form: this WAVEFRONT's LDS obs tile (64 rows) -- the caller flushes it with flush_obs_wave
+//   obs_keep: quad form: the 14 values stay in the caller's registers (policy in the loop) instead of being stored
+//   pre: quad form: this step's draws (draw_step), made by the caller where they overlap a memory wait
+template <int LANES, bool UNROLL = true, int DRIVE = -1, class Ground>
 WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const VehDerived& vd, const Ground& ground,
                            const Rows& S, EnvConst& ec, DriftRows& r, float2 a, const float* __restrict__ noise,
-                           const WlStepOut& out, int e, int le, int wid, bool lead, uint32_t gid, uint64_t seed, uint64_t step,
+                           const WlStepOut& out, int e, int wid, bool lead, uint32_t gid, uint64_t seed, uint64_t step,
                            float* tile, const MetricSink<LANES>& ms, float* obs_keep = nullptr,
                            const StepDraws* pre = nullptr) {
     const WlVehicleParams& vp = p.vehicle;
@@ -246,7 +317,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     float v_t, delta;
     process_action(p.action, a.x, a.y, v_t, delta);
     joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-    if constexpr (LANES == 4) env_const_lane(ec, vp, wid);
+    if constexpr (LANES == 4) env_const_lane(ec, vp, vd, wid);
     // ---- memory form -> integrator form (CoM position, body-frame angular velocity) ----
     VehState s;
     s.q = r.q;
@@ -261,19 +332,28 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         s.wb = mul_t(R, r.ww);
     }
     // ---- physics: decimation x substeps, everything in registers ----
-    vehicle_integrate<LANES, Ground, PACKED>(vp, vd, ec, s, ground, wid);
+    vehicle_integrate<LANES, Ground, UNROLL, DRIVE>(vp, vd, ec, s, ground, wid);
+    // lane form: the rows only the tail reads are requested NOW, behind ~1000 instructions of cover (terminations,
+    // rewards, Euler angles, noise) and not up front, where they would sit in registers through the physics loop
+    float epsum[WL_DR_NTERMS];
+    if constexpr (LANES == 1) {
+        load_bookkeeping_rows(S, b, e, r);
+#pragma unroll
+        for (int i = 0; i < WL_DR_NTERMS; ++i) epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) : 0.f;
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests here: the scheduler would sink them to their first use
+    } else {
+#pragma unroll
+        for (int i = 0; i < WL_DR_NTERMS; ++i) epsum[i] = r.epsum[i];
+    }
     const Mat3 R = mat_from_quat(s.q);
     V3 ww = mul(R, s.wb);
     V3 pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
     // ---- terminations (time_out, cart_off_track) + non-finite guard ----
-    int ep_len = r.ep_len + 1;
-    const bool truncated = ep_len >= p.max_episode_length;
     float wheel_sum;
-    if constexpr (LANES == 1) wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
+    if constexpr (LANES == 1) wheel_sum = (s.wheel[0] + s.wheel[1]) + (s.wheel[2] + s.wheel[3]);
     else wheel_sum = quad_sum(s.wheel[0]);
-    const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y + ww.z +
-                      wheel_sum + s.th + s.om;
-    const bool finite = __builtin_isfinite(chk);
+    const float chk_in[16] = {pos.x, pos.y, pos.z, s.q.w, s.q.x, s.q.y, s.q.z, s.v.x, s.v.y, s.v.z, ww.x, ww.y, ww.z, wheel_sum, s.th, s.om};
+    const bool finite = __builtin_isfinite(sum16(chk_in));
     const bool terminated = !finite || cart_off_track(pos.x, pos.y, p.straight, p.r_in, p.r_out);
     // ---- rewards on the post-physics state ----
     V3 vb = mul_t(R, s.v);
@@ -284,28 +364,27 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     if constexpr (LANES == 4) {
         const Quat q = s.q;
         const float sp = 2.f * (q.w * q.y - q.z * q.x);
-        // all four argument pairs are computed by every lane and picked by value (three v_cndmask each): written as a
-        // ternary chain over expressions the selection becomes divergent control flow
-        const float ay = quad_pick(wid, vb.y, 2.f * (q.w * q.x + q.y * q.z), sp, 2.f * (q.w * q.z + q.x * q.y));
-        const float ax = quad_pick(wid, vb.x, 1.f - 2.f * (q.x * q.x + q.y * q.y), fsqrt(fmaxf(1.f - sp * sp, 0.f)),
-                                   1.f - 2.f * (q.y * q.y + q.z * q.z));
-        const float ang = atan2f(ay, ax);
+        // all four argument pairs are computed by every lane and picked by value (three v_cndmask each)
+        const float ay = quad_pick(wid, opaque(vb.y), opaque(2.f * (q.w * q.x + q.y * q.z)), opaque(sp), opaque(2.f * (q.w * q.z + q.x * q.y)));
+        const float ax = quad_pick(wid, opaque(vb.x), opaque(1.f - 2.f * (q.x * q.x + q.y * q.y)), opaque(fsqrt(fmaxf(fmaf(-sp, sp, 1.f), 0.f))),
+                                   opaque(1.f - 2.f * (q.y * q.y + q.z * q.z)));
+        const float ang = atan2_fast(ay, ax);
         slip_angle = quad_bcast<0>(ang);
         euler = v3(wrap_2pi(quad_bcast<1>(ang)), wrap_2pi(quad_bcast<2>(ang)), wrap_2pi(quad_bcast<3>(ang)));
     } else {
-        slip_angle = atan2f(vb.y, vb.x);
+        slip_angle = atan2_fast(vb.y, vb.x);
     }
+    int ep_len = r.ep_len + 1;
+    const bool truncated = ep_len >= p.max_episode_length;
     DriftTerms tm = drift_terms(p, pos, vb, s.wb, ww.z, s.th, terminated, truncated, slip_angle);
     const float step_dt = p.sim_dt * (float)p.decimation;
     float reward = 0.f;
-    float epsum[WL_DR_NTERMS];
 #pragma unroll
     for (int i = 0; i < WL_DR_NTERMS; ++i) {
         const float w = p.weight[i];
         const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;  // RewardManager skips w == 0
         reward += c;
-        if constexpr (LANES == 4) epsum[i] = r.epsum[i] + c;
-        else epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;   // lane form: streamed late
+        epsum[i] += c;
     }
     if (lead) {
         out.reward[e] = reward;
@@ -332,7 +411,9 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
             for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
             s.th = s.om = 0.f;
         }
-        const ResetDraw rd = pre ? pre->reset : draw_reset(p, b.ref_poses, gid, step, seed);
+        ResetDraw rd;
+        if constexpr (LANES == 4) rd = quad_reset_draw(*pre);
+        else rd = draw_reset(p, b.ref_poses, gid, step, seed);
         pos = rd.pos;
         s.q = rd.q;
         if constexpr (LANES == 4) euler = v3(0.f, 0.f, rd.yaw - WL_TWO_PI * floorf(rd.yaw * WL_INV_TWO_PI));
@@ -347,7 +428,9 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     if (p.enable_pushes) {
         timer_hf -= step_dt;
         if (timer_hf < 1e-6f) {
-            const F4 u = pre ? pre->push_hf : philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
+            F4 u;
+            if constexpr (LANES == 4) u = quad_event<2>(*pre);
+            else u = philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
             s.v.x = fmaf(2.f * u.x - 1.f, p.hf_vel_x, s.v.x);
             s.v.y = fmaf(2.f * u.y - 1.f, p.hf_vel_y, s.v.y);
             ww.z = fmaf(2.f * u.z - 1.f, p.hf_vel_yaw, ww.z);
@@ -355,7 +438,9 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         }
         timer_lf -= step_dt;
         if (timer_lf < 1e-6f) {
-            const F4 u = pre ? pre->push_lf : philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
+            F4 u;
+            if constexpr (LANES == 4) u = quad_event<3>(*pre);
+            else u = philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
             ww.z = fmaf(2.f * u.x - 1.f, p.lf_vel_yaw, ww.z);
             timer_lf = fmaf(u.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
         }
@@ -388,8 +473,14 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     vb = mul_t(R2, s.v);
     const V3 wb2 = mul_t(R2, ww);
     Noise12 nz;
-    if (LANES == 4 && pre && p.enable_corruption && !noise) nz = gather_quad_noise(pre->z);
-    else nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // all lanes of the quad
+    bool drawn = false;
+    if constexpr (LANES == 4) {
+        if (p.enable_corruption && !noise) {
+            nz = gather_quad_noise(pre->z);
+            drawn = true;
+        }
+    }
+    if (!drawn) nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // off / parity tensor / lane form
     if constexpr (LANES == 1) euler = euler_xyz_from_quat(s.q);
     if constexpr (LANES == 4) {
         // quad form: the 14 values are replicated on the quad's lanes; a caller that feeds them to a policy in the
@@ -399,7 +490,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         obs_values(o, p, pos, euler, vb, wb2, a0, a1, nz);
         if (!obs_keep) store_obs_quad(out.obs + (int64_t)e * kObsDim, wid, o);
     } else {
-        write_obs_row(&tile[le * kObsPad], p, pos, euler, vb, wb2, a0, a1, nz);
+        write_obs_row(&tile[(threadIdx.x & 63) * kObsPad], p, pos, euler, vb, wb2, a0, a1, nz);
     }
 }
 
@@ -432,7 +523,7 @@ WL_DEV void pin_params_vgpr(WlDriftParams& p, VehDerived& d) {
     for (float* f : pf) pin_vgpr(*f);
     pin_vgpr(p.weight), pin_vgpr(p.noise_std), pin_vgpr(p.hf_interval), pin_vgpr(p.lf_interval);
     float* df[] = {&d.h, &d.inv_h, &d.half_h, &d.steer_a, &d.steer_b, &d.steer_J_h, &d.steer_h_J, &d.zrel, &d.Iw_h, &d.A0,
-                   &d.inv_wlim, &d.mot_b, &d.r2};
+                   &d.inv_wlim, &d.mot_b, &d.r2, &d.inv_A0, &d.hg, &d.inv_g2x, &d.inv_g2y, &d.inv_g2z, &d.cgx, &d.cgy, &d.cgz};
 #pragma unroll
     for (float* f : df) pin_vgpr(*f);
 }

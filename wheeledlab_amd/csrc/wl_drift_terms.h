@@ -66,11 +66,11 @@ WL_DEV float side_slip_from_angle(float slip_angle, float vbx, float min_thresh,
     return ang < min_thresh ? 0.f : ang;
 }
 WL_DEV float side_slip(V3 vb, float min_thresh, float max_thresh, float min_vel_x) {
-    return side_slip_from_angle(atan2f(vb.y, vb.x), vb.x, min_thresh, max_thresh, min_vel_x);
+    return side_slip_from_angle(atan2_fast(vb.y, vb.x), vb.x, min_thresh, max_thresh, min_vel_x);
 }
 // vel_dist (:167-171)
 WL_DEV float vel_dist(V3 vb, float target, float offset) {
-    const float gs = sqrtf(fmaf(vb.x, vb.x, vb.y * vb.y));
+    const float gs = fsqrt(fmaf(vb.x, vb.x, vb.y * vb.y));   // v_sqrt_f32: 1 ulp
     return fmaf(gs - target, gs - target, offset);
 }
 // turn_left_go_right (:232-240); steer_mean = mean of the two steer joint positions
@@ -86,7 +86,7 @@ WL_DEV float cross_track_dist(float x, float y, float straight, float r, float o
         d = fabsf(x > 0.f ? x - r : x + r);
     } else {
         const float dy = y > 0.f ? y - straight : y + straight;
-        d = fabsf(sqrtf(fmaf(dy, dy, x * x)) - r);
+        d = fabsf(fsqrt(fmaf(dy, dy, x * x)) - r);
     }
     const float ctd = d + offset;
     return p == 1.f ? ctd : powf(ctd, p);

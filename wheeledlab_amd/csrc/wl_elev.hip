@@ -44,8 +44,9 @@ WL_DEV ElevTerms elev_terms(const WlElevParams& p, V3 pos, float up_dot, V3 vb, 
     r.flag[WL_ET_BELOW_MIN_HEIGHT] = pos.z < p.min_height;                                            // :356-359
     r.flag[WL_ET_STUCK] = fminf(vb.x, p.stuck_vel_cap) < p.stuck_min_vel && wheel_sum > p.stuck_wheel_spin;   // :342-347
     r.flag[WL_ET_ROLLOVER] = up_dot < p.upright_cos;                                                  // :217-222, 339-340
-    r.flag[WL_ET_AT_GOAL] = sqrtf(fmaf(gx, gx, gy * gy)) < p.goal_dist;                               // :268-273
-    r.t[WL_ER_GOAL_PROGRESS] = p.progress_offset + fmaf(vw.x, gx, vw.y * gy) / sqrtf(fmaf(gx, gx, gy * gy));   // :239-249
+    const float g2 = fmaf(gx, gx, gy * gy);
+    r.flag[WL_ET_AT_GOAL] = fsqrt(g2) < p.goal_dist;                               // :268-273
+    r.t[WL_ER_GOAL_PROGRESS] = p.progress_offset + fmaf(vw.x, gx, vw.y * gy) * rsq(g2);   // :239-249
     const float z = pos.z - p.elev_z0;
     r.t[WL_ER_HIGHER_ELEVATION] = clampf((z > p.elev_min && vb.x > p.elev_min_vel) ? z : 0.f, 0.f, 1.f);       // :166-173
     r.t[WL_ER_FALLING] = vb.z > p.fall_vel ? 1.f : 0.f;                                               // :251-254
@@ -64,7 +65,7 @@ WL_DEV void write_elev_prop(const WlElevParams& p, float* __restrict__ row, V3 p
         const float ay = wid == 1 ? 2.f * (q.w * q.x + q.y * q.z) : wid == 2 ? sp : 2.f * (q.w * q.z + q.x * q.y);
         const float ax = wid == 1 ? 1.f - 2.f * (q.x * q.x + q.y * q.y) : wid == 2 ? fsqrt(fmaxf(1.f - sp * sp, 0.f))
                                                                                   : 1.f - 2.f * (q.y * q.y + q.z * q.z);
-        const float ang = atan2f(ay, ax);
+        const float ang = atan2_fast(ay, ax);
         eu = v3(wrap_2pi(quad_bcast<1>(ang)), wrap_2pi(quad_bcast<2>(ang)), wrap_2pi(quad_bcast<3>(ang)));
     } else {
         eu = euler_xyz_from_quat(q);
@@ -143,8 +144,8 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
         process_action(p.action, a.x, a.y, v_t, delta);
         EnvConst ec;
         joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-        if constexpr (LANES == 4) env_const_lane(ec, vp, wid);
         env_const_rows(ec, vp, vd, S.ld(WL_S_MASS, e), S.ld(WL_S_MU_S, e), S.ld(WL_S_MU_D, e), S.ld(WL_S_DAMP, e));
+        if constexpr (LANES == 4) env_const_lane(ec, vp, vd, wid);
         VehState s;
         V3 pos = ld3(S, WL_S_PX, e);
         s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};

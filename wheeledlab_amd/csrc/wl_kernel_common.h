@@ -22,6 +22,15 @@ struct Rows {
     WL_DEV void st(int row, int env, float v) const {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, env * 4, row * row_bytes, 0);
     }
+    // row index that differs per LANE (quad form: lane `wid` owns wheel row WL_S_WHEEL_BL + wid): the row goes into the
+    // per-lane byte offset.  (Through ld / st the row would be the SCALAR offset, and a lane-varying scalar operand
+    // makes the compiler emit a readfirstlane "waterfall" loop: up to four serialised passes around one load.)
+    WL_DEV float ld_lane_row(int row_lane, int env) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, row_lane * row_bytes + env * 4, 0, 0));
+    }
+    WL_DEV void st_lane_row(int row_lane, int env, float v) const {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, row_lane * row_bytes + env * 4, 0, 0);
+    }
 };
 WL_DEV Rows make_rows(float* base, int64_t stride) {
     // dword3 0x00020000: raw 32-bit data format on gfx90a / gfx94x / gfx950; num_records bounds the whole matrix
@@ -81,6 +90,18 @@ WL_DEV void clear_metric_slot(const WlEnvBuffers& b, int slot) {   // block 0 ze
         for (int i = threadIdx.x; i < kMetricSlotFloats; i += kBlock) b.metrics[(int64_t)slot * kMetricSlotFloats + i] = 0.f;
 }
 
+// The slot of the metric ring a launch accumulates into and the slot it clears for its successor, computed by the
+// C-ABI wrapper: `step % slots` on a 64-bit step is ~110 scalar instructions in-kernel (no hardware divide), twice,
+// on the latency-critical head and tail of a 7 us launch.
+struct MetricSlots {
+    int32_t cur, next;
+};
+inline MetricSlots metric_slots(const WlEnvBuffers* b, uint64_t step0, uint64_t n_steps = 1) {
+    if (b->metrics_slots <= 1) return MetricSlots{0, 0};
+    const uint64_t R = (uint64_t)b->metrics_slots;
+    return MetricSlots{(int32_t)(step0 % R), (int32_t)((step0 + n_steps) % R)};
+}
+
 inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 // Step kernels come in two forms (wl_vehicle.h): lane-per-env (no redundant work: best when the chip is full) and
 // quad-per-env (one wheel per lane: shorter critical path, 4x the waves: best while the chip is under-filled).
@@ -88,14 +109,20 @@ inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 #ifndef WL_QUAD_MAX_ENVS
 #define WL_QUAD_MAX_ENVS 32768
 #endif
-// lane form: packed axles up to here, the low-register scalar wheel loop beyond (crossover measured at ~260 K envs)
-#ifndef WL_PACKED_MAX_ENVS
-#define WL_PACKED_MAX_ENVS 262144
+// lane form: the interleaved-wheels build up to here, the fenced low-register build beyond
+#ifndef WL_UNROLL_MAX_ENVS
+#define WL_UNROLL_MAX_ENVS 262144
 #endif
-inline bool use_packed(const WlEnvBuffers* b) {   // lane form only
+#ifndef WL_LANE_WAVES
+#define WL_LANE_WAVES 5     // wavefronts per SIMD the lane builds must leave room for (__launch_bounds__): interleaved ..
+#endif
+#ifndef WL_LOWREG_WAVES
+#define WL_LOWREG_WAVES 5   // .. and fenced
+#endif
+inline bool use_unrolled(const WlEnvBuffers* b) {   // lane form only
     if (b->lanes == 1) return true;
     if (b->lanes == 2) return false;
-    return b->n_envs <= WL_PACKED_MAX_ENVS;
+    return b->n_envs <= WL_UNROLL_MAX_ENVS;
 }
 inline bool use_quad(const WlEnvBuffers* b) {
     if (b->lanes == 1 || b->lanes == 2) return false;

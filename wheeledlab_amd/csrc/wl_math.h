@@ -70,11 +70,41 @@ WL_DEV float wrap_2pi(float a) {
     return a < 0.f ? a + WL_TWO_PI : a;  // == torch.remainder(a, 2pi) on this range (may round to 2pi itself)
 }
 
-// IsaacLab euler_xyz_from_quat (un-vendored; reference call site wheeledlab/envs/mdp/observations.py:11)
+// atan2 for finite arguments: octant reduction to t = min / max in [0, 1], atan t = t + t^3 P(t^2) (degree-7 least-squares
+// fit on Chebyshev nodes: 1.3e-7 abs in fp32 Horner form, rcp at 1 ulp), unfolded by value.  ~22 instructions against
+// ~50 for libm's atan2f (exact division through frexp / ldexp, inf / NaN / signed-zero cases); four of them per env-step.
+WL_DEV float atan2_fast(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * rcp(fmaxf(mx, 1e-37f));   // (0, 0) -> 0
+    const float u = t * t;
+    float q = fmaf(u, 0.003962155897170305f, -0.020364457741379738f);
+    q = fmaf(u, q, 0.04938491806387901f);
+    q = fmaf(u, q, -0.08042293787002563f);
+    q = fmaf(u, q, 0.10877407342195511f);
+    q = fmaf(u, q, -0.14259037375450134f);
+    q = fmaf(u, q, 0.19998809695243835f);
+    q = fmaf(u, q, -0.33333325386047363f);
+    float r = fmaf(t * u, q, t);
+    r = ay > ax ? 1.57079632679489661923f - r : r;
+    r = x < 0.f ? WL_PI - r : r;
+    return copysignf(r, y);
+}
+
+// IsaacLab euler_xyz_from_quat (un-vendored; reference call site wheeledlab/envs/mdp/observations.py:11).
+// asin x = atan2(x, sqrt(1 - x^2)), which is +-pi/2 at |x| >= 1 like the reference's clamp.
 WL_DEV V3 euler_xyz_from_quat(Quat q) {
-    float roll = atan2f(2.f * (q.w * q.x + q.y * q.z), 1.f - 2.f * (q.x * q.x + q.y * q.y));
-    float sp = 2.f * (q.w * q.y - q.z * q.x);
-    float pitch = fabsf(sp) >= 1.f ? copysignf(0.5f * WL_PI, sp) : asinf(sp);
-    float yaw = atan2f(2.f * (q.w * q.z + q.x * q.y), 1.f - 2.f * (q.y * q.y + q.z * q.z));
+    const float roll = atan2_fast(2.f * (q.w * q.x + q.y * q.z), 1.f - 2.f * (q.x * q.x + q.y * q.y));
+    const float sp = 2.f * (q.w * q.y - q.z * q.x);
+    const float pitch = atan2_fast(sp, fsqrt(fmaxf(fmaf(-sp, sp, 1.f), 0.f)));
+    const float yaw = atan2_fast(2.f * (q.w * q.z + q.x * q.y), 1.f - 2.f * (q.y * q.y + q.z * q.z));
     return v3(wrap_2pi(roll), wrap_2pi(pitch), wrap_2pi(yaw));
+}
+
+// a value the optimiser cannot look through or move into a branch: the operands of a by-value selection stay plain
+// VALU results and the selection a v_cndmask (LLVM otherwise sinks an expensive operand -- a sqrt, a chain of fmas --
+// into a divergent branch around the select: exec-mask save / restore plus a branch per selection)
+WL_DEV float opaque(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(kBlock) drift_policy_rollout_kernel(const WlDr
                                                                       const float* __restrict__ action_std,
                                                                       const WlPolicyRollout io, const int n_steps,
                                                                       const uint64_t seed, const uint64_t step0,
-                                                                      const Ground ground, const VehDerived vd_arg) {
+                                                                      const Ground ground, const VehDerived vd_arg, const MetricSlots slots) {
     constexpr int LANES = 4, kEnvs = kBlock / LANES;
     WlDriftParams p = p_arg;
     VehDerived vd = vd_arg;
@@ -62,13 +62,12 @@ __global__ void __launch_bounds__(kBlock) drift_policy_rollout_kernel(const WlDr
     const int lane = threadIdx.x & 63;
     const int le = threadIdx.x / LANES, wid = threadIdx.x & 3;
     const int e_raw = blockIdx.x * kEnvs + le;
-    const int m_slot = b.metrics_slots > 1 ? (int)(step0 % (uint64_t)b.metrics_slots) : 0;
-    if (b.metrics_slots > 1) clear_metric_slot(b, (int)((step0 + (uint64_t)n_steps) % (uint64_t)b.metrics_slots));
+    if (b.metrics_slots > 1) clear_metric_slot(b, slots.next);
     if (e_raw - (lane >> 2) >= b.n_envs) return;   // the whole wavefront is past the end (wave-uniform)
     const bool valid = e_raw < b.n_envs;
     const int e = valid ? e_raw : b.n_envs - 1;
     const bool lead = valid && wid == 0;
-    const MetricSink<LANES> ms{nullptr, metric_shard(b, m_slot)};
+    const MetricSink<LANES> ms{nullptr, metric_shard(b, slots.cur)};
     const Rows S = make_rows(b.state, b.stride);
     const int64_t n = b.n_envs;
 
@@ -125,7 +124,8 @@ __global__ void __launch_bounds__(kBlock) drift_policy_rollout_kernel(const WlDr
         so.terminated = io.terminated + (int64_t)k * n;
         so.truncated = io.truncated + (int64_t)k * n;
         so.dones = io.dones ? io.dones + (int64_t)k * n : nullptr;
-        drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, nullptr, so, e, le, wid, lead, gid, seed, step, nullptr, ms, o);
+        const StepDraws pre = draw_step(p, b.ref_poses, gid, step, seed, wid);
+        drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, nullptr, so, e, wid, lead, gid, seed, step, nullptr, ms, o, &pre);
         if (valid) store_obs_quad(io.obs + ((int64_t)(k + 1) * n + e) * kObsDim, wid, o);
     }
     if (valid) store_rows<LANES>(S, b, p, e, wid, lead, r);
@@ -165,10 +165,10 @@ int wl_drift_rollout_policy(const WlDriftParams* p, const WlEnvBuffers* b, const
     const int grid = grid_for(b->n_envs * 4);
     if (actor->activation == WL_ACT_ELU)
         drift_policy_rollout_kernel<WL_ACT_ELU, FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-            *p, *b, *actor, action_std, *io, n_steps, seed, step0, FlatGround{}, vd);
+            *p, *b, *actor, action_std, *io, n_steps, seed, step0, FlatGround{}, vd, metric_slots(b, step0, (uint64_t)n_steps));
     else
         drift_policy_rollout_kernel<WL_ACT_RELU, FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-            *p, *b, *actor, action_std, *io, n_steps, seed, step0, FlatGround{}, vd);
+            *p, *b, *actor, action_std, *io, n_steps, seed, step0, FlatGround{}, vd, metric_slots(b, step0, (uint64_t)n_steps));
     return launch_status();
 }
 

@@ -14,13 +14,12 @@ struct VehState {
     float th, om;    // steer angle / rate
 };
 
-struct EnvConst {   // per-env constants hoisted out of the sub-step loop
-    float weight, h_inv_mass;  // m g ; h / m
+struct EnvConst {   // per-env constants hoisted out of the sub-step loop (VGPRs that live through it: keep them few)
+    float h_inv_mass;          // h / m   (inertia = m * gyr^2: everything else about the mass is uniform, see VehDerived)
     float K_cap;               // 0.125 m / h
     float mu_s, mu_d, mu_sd;   // combined (wheel x ground) friction: static, dynamic, static - dynamic
     float damp;                // throttle damping of driven wheels
-    float inv_A0, inv_A0_damp; // 1 / (Iw/h + bearing damping) and 1 / (that + damp): the saturated-branch wheel solve
-    V3 Ib, h_inv_Ib;           // body inertia diag ; h / I
+    float inv_A0_damp;         // 1 / (Iw/h + bearing damping + damp): the saturated-branch wheel solve of a driven wheel
     float steer_target;
     float wheel_target[4];
     // quad form: THIS lane's wheel (picked once per env-step, not per sub-step): velocity target, body position,
@@ -37,7 +36,10 @@ struct VehDerived {
     float steer_a, steer_b;                 // h kp / J ;  1 / (1 + h kd / J + h^2 kp / J)
     float steer_J_h, steer_h_J;             // J / h ; h / J
     float zrel;                             // wheel centre z relative to the CoM (body frame)
-    float Iw_h, A0;                         // wheel inertia / h ; Iw_h + bearing damping
+    float Iw_h, A0, inv_A0;                 // wheel inertia / h ; Iw_h + bearing damping ; 1 / that
+    float hg;                               // h * gravity
+    float inv_g2x, inv_g2y, inv_g2z;        // 1 / gyr^2: h / I = (h / m) * inv_g2
+    float cgx, cgy, cgz;                    // gyroscopic coefficients h (Iz - Iy) / Ix, ... : the mass cancels
     float inv_wlim, mot_b;                  // 1 / motor_vel_limit ; motor_sat / motor_vel_limit
     float r2;                               // wheel radius squared
     int32_t n_sub;                          // decimation * substeps
@@ -56,6 +58,15 @@ inline VehDerived derive_vehicle(const WlVehicleParams& vp, float sim_dt, int de
     d.zrel = vp.wheel_z - vp.cg_z;
     d.Iw_h = vp.wheel_inertia * d.inv_h;
     d.A0 = d.Iw_h + vp.wheel_damping;
+    d.inv_A0 = 1.f / d.A0;
+    d.hg = d.h * vp.gravity;
+    const float gx2 = vp.gyr_x * vp.gyr_x, gy2 = vp.gyr_y * vp.gyr_y, gz2 = vp.gyr_z * vp.gyr_z;
+    d.inv_g2x = 1.f / gx2;
+    d.inv_g2y = 1.f / gy2;
+    d.inv_g2z = 1.f / gz2;
+    d.cgx = d.h * (gz2 - gy2) / gx2;
+    d.cgy = d.h * (gx2 - gz2) / gy2;
+    d.cgz = d.h * (gy2 - gx2) / gz2;
     d.inv_wlim = 1.f / vp.motor_vel_limit;
     d.mot_b = vp.motor_sat / vp.motor_vel_limit;
     d.r2 = vp.wheel_radius * vp.wheel_radius;
@@ -66,16 +77,12 @@ inline VehDerived derive_vehicle(const WlVehicleParams& vp, float sim_dt, int de
 // per-env constants from the env's randomisation rows (wheel friction, throttle damping, mass)
 WL_DEV void env_const_rows(EnvConst& ec, const WlVehicleParams& vp, const VehDerived& vd, float mass, float mu_s_wheel,
                            float mu_d_wheel, float damp) {
-    ec.weight = mass * vp.gravity;
     ec.h_inv_mass = vd.h * rcp(mass);
     ec.K_cap = 0.125f * mass * vd.inv_h;
-    ec.Ib = v3(mass * (vp.gyr_x * vp.gyr_x), mass * (vp.gyr_y * vp.gyr_y), mass * (vp.gyr_z * vp.gyr_z));
-    ec.h_inv_Ib = v3(vd.h * rcp(ec.Ib.x), vd.h * rcp(ec.Ib.y), vd.h * rcp(ec.Ib.z));
     ec.mu_s = mu_s_wheel * vp.ground_mu_s;
     ec.mu_d = fminf(mu_d_wheel * vp.ground_mu_d, ec.mu_s);
     ec.mu_sd = ec.mu_s - ec.mu_d;
     ec.damp = damp;
-    ec.inv_A0 = rcp(vd.A0);
     ec.inv_A0_damp = rcp(vd.A0 + damp);
 }
 
@@ -93,14 +100,14 @@ struct FlatGround {
 WL_DEV float quad_pick(int wid, float a, float b, float c, float d) { return wid == 0 ? a : wid == 1 ? b : wid == 2 ? c : d; }
 
 // per-lane constants of the quad form (lane `wid` owns wheel `wid`): picked once per env-step, not per sub-step
-WL_DEV void env_const_lane(EnvConst& ec, const WlVehicleParams& vp, int wid) {
+WL_DEV void env_const_lane(EnvConst& ec, const WlVehicleParams& vp, const VehDerived& vd, int wid) {
     const bool front = wid >= 2, left = (wid & 1) == 0;
     const bool driven = (vp.drive == 1) || !front;
     ec.wt_lane = quad_pick(wid, ec.wheel_target[0], ec.wheel_target[1], ec.wheel_target[2], ec.wheel_target[3]);
     ec.bx_lane = front ? vp.half_wheelbase_f : -vp.half_wheelbase_r;
     ec.by_lane = left ? vp.half_track : -vp.half_track;
     ec.d_lane = driven ? ec.damp : 0.f;
-    ec.inv_A0d_lane = driven ? ec.inv_A0_damp : ec.inv_A0;
+    ec.inv_A0d_lane = driven ? ec.inv_A0_damp : vd.inv_A0;
 }
 
 // ---- one wheel: contact + tyre + wheel-spin solve, everything in the BODY frame ------------------------------------------
@@ -120,12 +127,20 @@ WL_DEV void env_const_lane(EnvConst& ec, const WlVehicleParams& vp, int wid) {
 //          product by the constant components spelled out as absent (the compiler must keep `x * 0`: x could be inf)
 //   MOTOR: the wheel may be driven: d = throttle damping (0: undriven), inv_A0d = 1 / (A0 + d);
 //          !MOTOR: known to be undriven (d == 0): tau == 0 and the DC-motor window drops out
-struct WheelOut {
-    V3 F;       // contact force on the body, body frame
-    float Fz;   // normal load
+struct TyreCoef {   // the contact force on the body (body frame) is F = fx h + fy (n x h) + kz n
+    float fx, fy, kz;
+    float Fz;       // normal load
 };
+// F for coefficients c -- LINEAR in (fx, fy, kz): the axle form below maps the sum and the difference of its two wheels
+template <bool STEER>
+WL_DEV V3 tyre_force(float fx, float fy, float kz, V3 n, float hc, float hs) {
+    const float fyz = fy * n.z;   // (n x h) = (-n.z hs, n.z hc, n.x hs - n.y hc)
+    if constexpr (STEER) return v3(fmaf(kz, n.x, fmaf(fx, hc, -fyz * hs)), fmaf(kz, n.y, fmaf(fx, hs, fyz * hc)),
+                                   fmaf(kz, n.z, fy * fmaf(n.x, hs, -n.y * hc)));
+    else return v3(fmaf(kz, n.x, fx), fmaf(kz, n.y, fyz), fmaf(kz, n.z, -fy * n.y));
+}
 template <bool STEER, bool MOTOR>
-WL_DEV WheelOut wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, V3 n, V3 vc, float pen, float hc,
+WL_DEV TyreCoef wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, V3 n, V3 vc, float pen, float hc,
                            float hs, float d, float inv_A0d, float wt, float& w_spin) {
     const float r = vp.wheel_radius;
     const float vn = dot(n, vc);
@@ -143,11 +158,14 @@ WL_DEV WheelOut wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, cons
     const float vden = fmaxf(vp.v_min, vp.slip_peak * fmaxf(fabsf(vcx), fabsf(wr)));
     const float inv_vden = rcp(vden);
     const float sx = (wr - vcx) * inv_vden, sy = vcy * inv_vden;   // (sy's sign is immaterial: only sy^2 is used)
-    const float sig = fsqrt(fmaf(sx, sx, sy * sy));
+    // sig = |s| and 1 / max(sig, 1) from ONE rsq (sqrt + rcp were two quarter-rate instructions)
+    const float s2 = fmaxf(fmaf(sx, sx, sy * sy), 1e-30f);
+    const float rs = rsq(s2);
+    const float sig = s2 * rs;
     // g(sig) / sig, branch-free: below the peak (sig <= 1, inv_sig == 1) the first term is mu_s and the second adds
     // mu_s (1 - sig) -> mu_s (2 - sig); above it the second term vanishes.  (As a ?: the two short arms become
     // divergent control flow: five exec-mask instructions around six arithmetic ones, every wheel, every sub-step.)
-    const float inv_sig = rcp(fmaxf(sig, 1.f));
+    const float inv_sig = fminf(rs, 1.f);
     const float gq = fmaf(ec.mu_s, fmaxf(1.f - sig, 0.f), fmaf(ec.mu_sd, inv_sig, ec.mu_d) * inv_sig);
     // explicit-stepping stability cap: at most half of this wheel's share of the body momentum per sub-step
     const float K = fminf(Fz * gq * inv_vden, ec.K_cap);
@@ -180,21 +198,15 @@ WL_DEV WheelOut wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, cons
         const float rhs2 = fmaf(vd.Iw_h, w_i, -r * Fx);
         if constexpr (MOTOR) {
             const float w_u2 = fmaf(d, wt, rhs2) * inv_A0d;   // 1 / (A0 + d): per-env constant
-            w_n = clampf(w_u2, (rhs2 + tau_lo) * ec.inv_A0, (rhs2 + tau_hi) * ec.inv_A0);
+            w_n = clampf(w_u2, (rhs2 + tau_lo) * vd.inv_A0, (rhs2 + tau_hi) * vd.inv_A0);
         } else {
-            w_n = rhs2 * ec.inv_A0;
+            w_n = rhs2 * vd.inv_A0;
         }
     }
     w_spin = w_n;
     // F = fx h + fy (n x h) + (Fz - fx g) n  with fx = Fx it, fy = Fy it
-    const float fx = Fx * it, fy = Fy * it;
-    const float kz = fmaf(-fx, g, Fz);
-    const float fyz = fy * n.z;
-    WheelOut o;
-    if constexpr (STEER) o.F = v3(fmaf(kz, n.x, fmaf(fx, hc, -fyz * hs)), fmaf(kz, n.y, fmaf(fx, hs, fyz * hc)), fmaf(kz, n.z, fy * m));
-    else o.F = v3(fmaf(kz, n.x, fx), fmaf(kz, n.y, fyz), fmaf(kz, n.z, fy * m));
-    o.Fz = Fz;
-    return o;
+    const float fx = Fx * it;
+    return TyreCoef{fx, Fy * it, fmaf(-fx, g, Fz), Fz};
 }
 
 // contact kinematics of one wheel at body position (bx, by, zrel)
@@ -235,27 +247,50 @@ struct Wrench {
     V3 F, T;
     float Fz;
 };
-template <bool FIRST>
-WL_DEV void wrench_add(Wrench& w, const Contact& c, const WheelOut& o) {
-    const V3 t = cross(c.arm, o.F);
-    if constexpr (FIRST) {   // plain assignment: `0 + x` cannot be folded (-0), it would cost an instruction per component
-        w.F = o.F;
-        w.T = t;
-        w.Fz = o.Fz;
-    } else {
-        w.F = w.F + o.F;
-        w.T = w.T + t;
-        w.Fz += o.Fz;
-    }
-}
-
 template <class Ground, bool STEER, bool MOTOR, bool FIRST>
 WL_DEV void wheel_step(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Ground& ground, const Mat3& R,
                        const VehState& s, V3 vb, float bx, float by, float hc, float hs, float d, float inv_A0d, float wt,
                        float& w_spin, Wrench& w) {
     const Contact c = wheel_contact(vp, vd, ground, R, s, vb, bx, by);
-    const WheelOut o = wheel_tyre<STEER, MOTOR>(vp, vd, ec, c.n, c.vc, c.pen, hc, hs, d, inv_A0d, wt, w_spin);
-    wrench_add<FIRST>(w, c, o);
+    const TyreCoef o = wheel_tyre<STEER, MOTOR>(vp, vd, ec, c.n, c.vc, c.pen, hc, hs, d, inv_A0d, wt, w_spin);
+    const V3 F = tyre_force<STEER>(o.fx, o.fy, o.kz, c.n, hc, hs);
+    const V3 t = cross(c.arm, F);
+    if constexpr (FIRST) {   // plain assignment: `0 + x` cannot be folded (-0), it would cost an instruction per component
+        w.F = F;
+        w.T = t;
+        w.Fz = o.Fz;
+    } else {
+        w.F = w.F + F;
+        w.T = w.T + t;
+        w.Fz += o.Fz;
+    }
+}
+
+// The two wheels of an axle on FLAT ground (lane form): they share n, the heading and arm.x / arm.z, and F is linear
+// in the tyre coefficients -- so the axle's force is the map of the coefficient SUMS, and all the torque needs beyond
+// that is the map of their DIFFERENCES (x and z components): sum_i arm_i x F_i with arm.y = +-ht - r n.y.
+struct AxleOut {
+    V3 F;          // force of both wheels
+    float dX, dZ;  // F_left - F_right, x and z components
+    float ax;      // arm.x of the axle
+    float Fz;      // load of both wheels
+};
+template <bool STEER, bool MOTOR>
+WL_DEV AxleOut axle_step(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Mat3& R, const VehState& s, V3 vb,
+                         float bx, float hc, float hs, float d, float inv_A0d, float wt_l, float wt_r, float& w_l, float& w_r) {
+    const FlatGround flat{};
+    const Contact cl = wheel_contact(vp, vd, flat, R, s, vb, bx, vp.half_track);
+    const Contact cr = wheel_contact(vp, vd, flat, R, s, vb, bx, -vp.half_track);
+    const TyreCoef a = wheel_tyre<STEER, MOTOR>(vp, vd, ec, cl.n, cl.vc, cl.pen, hc, hs, d, inv_A0d, wt_l, w_l);
+    const TyreCoef b = wheel_tyre<STEER, MOTOR>(vp, vd, ec, cr.n, cr.vc, cr.pen, hc, hs, d, inv_A0d, wt_r, w_r);
+    AxleOut o;
+    o.F = tyre_force<STEER>(a.fx + b.fx, a.fy + b.fy, a.kz + b.kz, cl.n, hc, hs);
+    const V3 D = tyre_force<STEER>(a.fx - b.fx, a.fy - b.fy, a.kz - b.kz, cl.n, hc, hs);   // (the y component is dead code)
+    o.dX = D.x;
+    o.dZ = D.z;
+    o.ax = cl.arm.x;
+    o.Fz = a.Fz + b.Fz;
+    return o;
 }
 
 // steering: implicit PD drive, effort- and rate-limited (hound.py:5-12)
@@ -269,15 +304,18 @@ WL_DEV void steer_update(const WlVehicleParams& vp, const VehDerived& vd, const 
 }
 
 // semi-implicit Euler of the rigid body under the summed contact force Fb / torque Tb about the CoM (BODY frame);
-// Fz_w: world z component of the contact force where the caller knows it without R (flat ground: the sum of the loads)
+// Fz_w: world z component of the contact force where the caller knows it without R (flat ground: the sum of the loads).
+// The inertia tensor is m diag(gyr^2): h / I = (h / m) / gyr^2 and the gyroscopic term w x (I w) / I has the mass
+// cancelled -- per-env h / m and uniform constants, no per-env inertia vectors living in registers through the loop.
 template <bool FLAT>
 WL_DEV void body_integrate(const VehDerived& vd, const EnvConst& ec, VehState& s, const Mat3& R, V3 Fb, V3 Tb, float Fz_w) {
-    const V3 F = v3(dot(R.r0, Fb), dot(R.r1, Fb), (FLAT ? Fz_w : dot(R.r2, Fb)) - ec.weight);
-    s.v = fma3(ec.h_inv_mass, F, s.v);
-    const V3 Iw = v3(ec.Ib.x * s.wb.x, ec.Ib.y * s.wb.y, ec.Ib.z * s.wb.z);
-    const V3 gyro = cross(s.wb, Iw);
-    s.wb = v3(fmaf(ec.h_inv_Ib.x, Tb.x - gyro.x, s.wb.x), fmaf(ec.h_inv_Ib.y, Tb.y - gyro.y, s.wb.y),
-              fmaf(ec.h_inv_Ib.z, Tb.z - gyro.z, s.wb.z));
+    const float Fz = FLAT ? Fz_w : dot(R.r2, Fb);
+    s.v = v3(fmaf(ec.h_inv_mass, dot(R.r0, Fb), s.v.x), fmaf(ec.h_inv_mass, dot(R.r1, Fb), s.v.y),
+             fmaf(ec.h_inv_mass, Fz, s.v.z) - vd.hg);
+    const V3 t = ec.h_inv_mass * Tb;
+    const V3 w = s.wb;
+    s.wb = v3(fmaf(vd.inv_g2x, t.x, fmaf(-vd.cgx, w.y * w.z, w.x)), fmaf(vd.inv_g2y, t.y, fmaf(-vd.cgy, w.z * w.x, w.y)),
+              fmaf(vd.inv_g2z, t.z, fmaf(-vd.cgz, w.x * w.y, w.z)));
     s.x = fma3(vd.h, s.v, s.x);
     // q <- q + (h / 2) q (0, w_b)   [== (h / 2) (0, R w_b) q, the world-rate form of the spec], then renormalise
     const V3 u = vd.half_h * s.wb;
@@ -310,32 +348,48 @@ WL_DEV V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)
 //   LANES == 4: a quad of lanes owns the env, lane `wid` owns wheel `wid` (s.wheel[0] is ITS spin); the body state is
 //               replicated, the wheel forces are summed across the quad with DPP.  Latency form for small env counts:
 //               the critical path per sub-step drops from 4 wheels to 1.
-template <int LANES, class Ground, bool UNROLL = true>
+//   DRIVE (lane form): 0 rear-wheel drive, 1 four-wheel drive: compiled in -- the other drive's front-axle code, its
+//               branch and its live values (two wheel targets) leave the loop; -1: decided at run time (vp.drive)
+template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1>
 WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
                             const Ground& ground, int wid, float sn, float cs /* sin / cos of the steer angle in force */) {
     const Mat3 R = mat_from_quat(s.q);
     const V3 vb = mul_t(R, s.v);
     Wrench w;
-    if constexpr (LANES == 1) {
+    if constexpr (LANES == 1 && Ground::kFlat) {
+        const bool awd = DRIVE == 1 || (DRIVE < 0 && vp.drive == 1);
+        // rear axle: always driven, never steered; front axle: steered, driven only with 4WD (the undriven wheel has no
+        // motor arithmetic at all)
+        const AxleOut ar = axle_step<false, true>(vp, vd, ec, R, s, vb, -vp.half_wheelbase_r, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
+                                                  ec.wheel_target[0], ec.wheel_target[1], s.wheel[0], s.wheel[1]);
+        if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
+        AxleOut af;
+        if (awd) af = axle_step<true, true>(vp, vd, ec, R, s, vb, vp.half_wheelbase_f, cs, sn, ec.damp, ec.inv_A0_damp, ec.wheel_target[2],
+                                            ec.wheel_target[3], s.wheel[2], s.wheel[3]);
+        else af = axle_step<true, false>(vp, vd, ec, R, s, vb, vp.half_wheelbase_f, cs, sn, 0.f, vd.inv_A0, 0.f, 0.f, s.wheel[2], s.wheel[3]);
+        if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
+        const V3 n = R.r2;
+        const float r = vp.wheel_radius, ht = vp.half_track;
+        const float ayc = -r * n.y, az = fmaf(-r, n.z, vd.zrel);   // arm.y = +-ht + ayc ; arm.z
+        w.F = ar.F + af.F;
+        const float DX = ar.dX + af.dX, DZ = ar.dZ + af.dZ;
+        w.T = v3(fmaf(ht, DZ, fmaf(ayc, w.F.z, -az * w.F.y)), fmaf(az, w.F.x, -fmaf(ar.ax, ar.F.z, af.ax * af.F.z)),
+                 fmaf(ar.ax, ar.F.y, af.ax * af.F.y) - fmaf(ht, DX, ayc * w.F.x));
+        w.Fz = ar.Fz + af.Fz;
+    } else if constexpr (LANES == 1) {
         const float ht = vp.half_track, bxr = -vp.half_wheelbase_r, bxf = vp.half_wheelbase_f;
-        // rear axle: always driven, never steered
         wheel_step<Ground, false, true, true>(vp, vd, ec, ground, R, s, vb, bxr, ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
                                               ec.wheel_target[0], s.wheel[0], w);
-        if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
         wheel_step<Ground, false, true, false>(vp, vd, ec, ground, R, s, vb, bxr, -ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
                                                ec.wheel_target[1], s.wheel[1], w);
-        if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
-        // front axle: steered; driven only with 4WD (uniform branch: the undriven wheel has no motor arithmetic at all)
-        if (vp.drive == 1) {
+        if (DRIVE == 1 || (DRIVE < 0 && vp.drive == 1)) {
             wheel_step<Ground, true, true, false>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, ec.damp, ec.inv_A0_damp,
                                                   ec.wheel_target[2], s.wheel[2], w);
-            if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
             wheel_step<Ground, true, true, false>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, ec.damp, ec.inv_A0_damp,
                                                   ec.wheel_target[3], s.wheel[3], w);
         } else {
-            wheel_step<Ground, true, false, false>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, 0.f, ec.inv_A0, 0.f, s.wheel[2], w);
-            if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
-            wheel_step<Ground, true, false, false>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, 0.f, ec.inv_A0, 0.f, s.wheel[3], w);
+            wheel_step<Ground, true, false, false>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[2], w);
+            wheel_step<Ground, true, false, false>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[3], w);
         }
     } else {
         const bool front = wid >= 2;
@@ -353,13 +407,13 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
 // decimation x substeps integrator sub-steps (everything in registers).  A variant that software-pipelined the steering
 // joint one sub-step ahead measured no gain: a wavefront alone on its SIMD pays ~3 ns per instruction whatever the
 // chain looks like (tools/microbench/valu_issue.hip), so only fewer instructions on the critical lane help.
-template <int LANES, class Ground, bool UNROLL = true>
+template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1>
 WL_DEV void vehicle_integrate(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
                               const Ground& ground, int wid = 0) {
     for (int k = 0; k < vd.n_sub; ++k) {
         steer_update(vp, vd, ec, s);
         float sn, cs;
         sincos_fast(s.th, sn, cs);   // |th| <= tan(0.488) rad: hardware sin/cos, ~1e-6 abs
-        vehicle_substep<LANES, Ground, UNROLL>(vp, vd, ec, s, ground, wid, sn, cs);
+        vehicle_substep<LANES, Ground, UNROLL, DRIVE>(vp, vd, ec, s, ground, wid, sn, cs);
     }
 }

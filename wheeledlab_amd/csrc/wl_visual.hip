@@ -103,8 +103,8 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
         process_action(p.action, a.x, a.y, v_t, delta);
         EnvConst ec;
         joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-        if constexpr (LANES == 4) env_const_lane(ec, vp, wid);
         env_const_rows(ec, vp, vd, S.ld(WL_S_MASS, e), S.ld(WL_S_MU_S, e), S.ld(WL_S_MU_D, e), S.ld(WL_S_DAMP, e));
+        if constexpr (LANES == 4) env_const_lane(ec, vp, vd, wid);
         VehState s;
         V3 pos = ld3(S, WL_S_PX, e);
         s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
