@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 13
+#define WL_ABI_VERSION 14
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -511,6 +511,28 @@ int wl_visual_mdp(const WlVisualParams* p, const WlTravMap* m, int32_t n, int64_
  */
 int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, float max_depth,
                     float* depth, void* stream);
+
+/*
+ * Startup-mode events (domain randomisation applied ONCE per env, at construction): bucketed wheel friction
+ * (isaaclab randomize_rigid_body_material: `mu_buckets` materials per run, every env picks one; make_consistent:
+ * mu_d <= mu_s), throttle damping (randomize_actuator_gains, "abs") and base mass (randomize_rigid_body_mass, "add"
+ * onto the chassis mass).  Reference configs: mushr_drift_env_cfg.py:98-119,145-154; elevation cfg :387-407; visual
+ * cfg :264-299.  Writes rows WL_S_MU_S, WL_S_MU_D, WL_S_DAMP, WL_S_MASS of every env and sets WL_S_QW = 1.
+ * Keyed like every other draw: Philox counter (global env id = env_offset + e, 0, stream 8) for the env's bucket /
+ * damping / mass and (bucket id, 0, stream 9) for a bucket's friction pair -- so a W-rank run of n envs each holds the
+ * same W*n parameter sets as a 1-rank run of W*n envs (the reference draws per env, not per process).
+ * randomize == 0: every env gets the mid-points of the ranges.
+ */
+typedef struct WlStartupParams {
+    float wheel_mu_s[2], wheel_mu_d[2];   /* ranges of the wheel material's static / dynamic friction           */
+    int32_t mu_buckets;                   /* num_buckets (20 in the drift task)                                  */
+    int32_t mu_consistent;                /* make_consistent: mu_d = min(mu_d, mu_s)                             */
+    float damping[2];                     /* throttle damping range                                              */
+    float chassis_mass;                   /* base mass before the "add" operation                                */
+    float mass_add[2];                    /* added mass range                                                    */
+    int32_t randomize;
+} WlStartupParams;
+int wl_startup_randomize(const WlStartupParams* su, const WlEnvBuffers* b, uint64_t seed, void* stream);
 
 /* Raw Philox4x32-10 uniforms as used in-kernel: out[4][n] for counter (env, step, stream_id). Test hook. */
 int wl_philox_uniform(int32_t n, uint64_t seed, uint64_t step, uint32_t stream_id, float* out, void* stream);

@@ -145,18 +145,13 @@ def step(p, state, episode_len, ref_table, actions, seed, step_count, metrics=No
     return obs, reward, terminated, truncated, dict(terms=terms, done=done, finite=finite)
 
 
-def init_state(p, n, seed=0, stride=None):
+def init_state(p, n, seed=0, stride=None, env_offset=0):
     """startup events (mushr_drift_env_cfg.py:98-119,145-154): wheel friction U(0.3,0.5) in 20 buckets with
-    mu_d <= mu_s, rear throttle damping U(10,50), base mass += U(0.3,0.5) -> fresh state matrix (host RNG)."""
+    mu_d <= mu_s, rear throttle damping U(10,50), base mass += U(0.3,0.5) -> fresh state matrix.  Keyed by the global
+    env id (oracle/startup.py), like the product's wl_startup_randomize."""
+    from . import startup
     stride = stride or ((n + 63) // 64) * 64
-    rng = np.random.RandomState(seed)
     s = np.zeros((S_COUNT, stride), F)
     s[QW] = 1
-    lo, hi, nb = 0.3, 0.5, 20
-    buckets_s = rng.uniform(lo, hi, nb)
-    buckets_d = np.minimum(rng.uniform(lo, hi, nb), buckets_s)
-    b = rng.randint(0, nb, stride)
-    s[MU_S], s[MU_D] = buckets_s[b], buckets_d[b]
-    s[DAMP] = rng.uniform(10.0, 50.0, stride)
-    s[MASS] = 3.0 + rng.uniform(0.3, 0.5, stride)
+    s[MU_S, :n], s[MU_D, :n], s[DAMP, :n], s[MASS, :n], _ = startup.draw(n, seed, env_offset, **startup.DRIFT)
     return s

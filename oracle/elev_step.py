@@ -204,13 +204,12 @@ def step(p, state, episode_len, hf, actions, seed, step_count, metrics=None, env
                                                               finite=finite)
 
 
-def init_state(p, n, seed=0, stride=None):
+def init_state(p, n, seed=0, stride=None, env_offset=0):
     """startup events (:387-407): wheel friction (2.0, 1.0) fixed, base mass += U(0.2, 0.5); throttle damping 1000
-    (hound.py:19, not randomised in this task)"""
+    (hound.py:19, not randomised in this task).  Keyed by the global env id (oracle/startup.py)."""
+    from . import startup
     stride = stride or ((n + 63) // 64) * 64
-    rng = np.random.RandomState(seed)
     s = np.zeros((S_COUNT, stride), F)
     s[QW] = 1
-    s[MU_S], s[MU_D], s[DAMP] = 2.0, 1.0, 1000.0
-    s[MASS] = 3.0 + rng.uniform(0.2, 0.5, stride)
+    s[MU_S, :n], s[MU_D, :n], s[DAMP, :n], s[MASS, :n], _ = startup.draw(n, seed, env_offset, **startup.ELEV)
     return s

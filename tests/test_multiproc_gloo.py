@@ -18,7 +18,7 @@ def _free_port():
 
 def _run_shard(p, rank, world, n, steps, ref):
     from oracle import drift_step as OS
-    st = OS.init_state(p, n * world, seed=3)[:, rank * n:(rank + 1) * n].copy()  # slice of the GLOBAL startup draw
+    st = OS.init_state(p, n, seed=3, stride=n, env_offset=rank * n)   # startup draws are keyed by the global env id, like the kernel's
     ep = np.zeros(n, np.int32)
     OS.reset_envs(p, st, ep, ref, np.arange(n), 42, 0, env_offset=rank * n)
     met = np.zeros(16)

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 13
+WL_ABI_VERSION = 14
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -150,6 +150,12 @@ class WlPpoParams(C.Structure):
                                                                                  ("adaptive", C.c_int32)]
 
 
+class WlStartupParams(C.Structure):
+    _fields_ = [("wheel_mu_s", C.c_float * 2), ("wheel_mu_d", C.c_float * 2), ("mu_buckets", C.c_int32),
+                ("mu_consistent", C.c_int32), ("damping", C.c_float * 2), ("chassis_mass", C.c_float),
+                ("mass_add", C.c_float * 2), ("randomize", C.c_int32)]
+
+
 class WlPpoState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("partials", "grad", "adam_m", "adam_v", "ctrl", "operands")]
 
@@ -183,6 +189,7 @@ SIGNATURES = {
     "wl_drift_reset": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _u64, _u64, _vp]),
     "wl_drift_observe": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _vp, _u64, _u64, _vp]),
     "wl_philox_uniform": (C.c_int, [_i32, _u64, _u64, C.c_uint32, _vp, _vp]),
+    "wl_startup_randomize": (C.c_int, [_P(WlStartupParams), _P(WlEnvBuffers), _u64, _vp]),
     "wl_elev_step": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _P(WlStepOut), _u64, _u64, _vp]),
     "wl_elev_rollout": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _P(WlStepOut), _i64, _i64,
                                   _i32, _u64, _u64, _vp]),

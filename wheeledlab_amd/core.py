@@ -34,27 +34,16 @@ def stadium_reference_poses(u: torch.Tensor, track_radius: float = 0.8, straight
     return torch.stack([x, y, yaw]).float()
 
 
-def apply_startup_events(state: torch.Tensor, su, g: torch.Generator, randomize: bool = True):
+def apply_startup_events(lib, bufs: "A.WlEnvBuffers", su, seed: int, stream, randomize: bool = True):
     """startup-mode events (domain randomisation, applied once): bucketed wheel friction
     (isaaclab randomize_rigid_body_material), throttle damping (randomize_actuator_gains, "abs"), base mass
-    (randomize_rigid_body_mass, "add" onto / "abs" instead of the chassis mass).  Reference configs:
-    mushr_drift_env_cfg.py:98-119,145-154; elevation cfg :387-407; visual cfg :264-299."""
-    n, dev = state.shape[1], state.device
-    state[A.S_QW] = 1.0
-    if not randomize:
-        mid = lambda r: 0.5 * (r[0] + r[1])
-        state[A.S_MU_S], state[A.S_MU_D] = mid(su.wheel_mu_s), min(mid(su.wheel_mu_d), mid(su.wheel_mu_s))
-        state[A.S_DAMP], state[A.S_MASS] = mid(su.damping), su.chassis_mass + mid(su.mass_add)
-        return
-    u = lambda r, k: torch.rand(k, generator=g) * (r[1] - r[0]) + r[0]
-    nb = max(1, su.mu_buckets)
-    mu_s, mu_d = u(su.wheel_mu_s, nb), u(su.wheel_mu_d, nb)
-    if su.mu_consistent:
-        mu_d = torch.minimum(mu_d, mu_s)
-    b = torch.randint(0, nb, (n,), generator=g)
-    state[A.S_MU_S], state[A.S_MU_D] = mu_s[b].to(dev), mu_d[b].to(dev)
-    state[A.S_DAMP] = u(su.damping, n).to(dev)
-    state[A.S_MASS] = (su.chassis_mass + u(su.mass_add, n)).to(dev)
+    (randomize_rigid_body_mass, "add" onto the chassis mass).  Reference configs: mushr_drift_env_cfg.py:98-119,145-154;
+    elevation cfg :387-407; visual cfg :264-299.  One launch of wl_startup_randomize: the draws are keyed by the GLOBAL
+    env id (bufs.env_offset + e), so a sharded run holds the same parameter sets as the one big batch."""
+    sp = A.WlStartupParams((C.c_float * 2)(*su.wheel_mu_s), (C.c_float * 2)(*su.wheel_mu_d), int(su.mu_buckets),
+                           int(bool(su.mu_consistent)), (C.c_float * 2)(*su.damping), float(su.chassis_mass),
+                           (C.c_float * 2)(*su.mass_add), int(bool(randomize)))
+    A.check(lib.wl_startup_randomize(C.byref(sp), C.byref(bufs), int(seed), stream), "wl_startup_randomize")
 
 
 class _MetricsView:
@@ -101,19 +90,19 @@ class DriftBatch(_MetricsView):
         tr = (startup.track_radius, startup.track_straight) if startup is not None else (0.8, 0.8)
         self.ref_table[:, : self.p.num_ref_points] = stadium_reference_poses(torch.rand(self.p.num_ref_points, generator=g), *tr)
         self.ref_table = self.ref_table.to(dev)
-        self._startup_events(g, randomize, startup)
         self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), self.ref_table.data_ptr(),
                                     self.metrics_raw.data_ptr(), self.stride, self.n, self.env_offset, self.metrics_slots, 0, 0)
+        self._startup_events(randomize, startup)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
                                 self.truncated.data_ptr(), self.dones.data_ptr())
 
     # startup events (mushr_drift_env_cfg.py:98-119, 145-154)
-    def _startup_events(self, g: torch.Generator, randomize: bool, su=None):
+    def _startup_events(self, randomize: bool, su=None):
         if su is None:  # the RSS drift defaults
             from .envs.flatten import StartupSpec
             su = StartupSpec(wheel_mu_s=(0.3, 0.5), wheel_mu_d=(0.3, 0.5), mu_buckets=20, mu_consistent=True,
                              damping=(10.0, 50.0), mass_add=(0.3, 0.5))
-        apply_startup_events(self.state, su, g, randomize)
+        apply_startup_events(self.lib, self._bufs, su, self.seed, self._stream(), randomize)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -235,9 +224,9 @@ class ElevBatch(_MetricsView):
             from .envs.flatten import StartupSpec
             startup = StartupSpec(wheel_mu_s=(2.0, 2.0), wheel_mu_d=(1.0, 1.0), mu_buckets=5, mu_consistent=False,
                                   damping=(1000.0, 1000.0), mass_add=(0.2, 0.5))
-        apply_startup_events(self.state, startup, torch.Generator().manual_seed(self.seed))
         self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics_raw.data_ptr(),
                                     self.stride, self.n, self.env_offset, self.metrics_slots, 0, 0)
+        apply_startup_events(self.lib, self._bufs, startup, self.seed, self._stream())
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
                                 self.truncated.data_ptr(), self.dones.data_ptr())
 
@@ -321,9 +310,9 @@ class VisualBatch(_MetricsView):
         if startup is None:
             from .envs.flatten import StartupSpec
             startup = StartupSpec(wheel_mu_s=(0.5, 0.5), wheel_mu_d=(0.5, 0.5), damping=(1000.0, 1000.0), mass_add=(0.0, 0.0))
-        apply_startup_events(self.state, startup, torch.Generator().manual_seed(self.seed))
         self._bufs = A.WlEnvBuffers(self.state.data_ptr(), self.episode_len.data_ptr(), None, self.metrics_raw.data_ptr(),
                                     self.stride, self.n, self.env_offset, self.metrics_slots, 0, 0)
+        apply_startup_events(self.lib, self._bufs, startup, self.seed, self._stream())
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
                                 self.truncated.data_ptr(), self.dones.data_ptr())
 

@@ -3,7 +3,8 @@
 #pragma once
 #include "wl_math.h"
 
-enum WlRngStream : uint32_t { WL_RS_RESET = 0, WL_RS_TIMERS = 1, WL_RS_PUSH_HF = 2, WL_RS_PUSH_LF = 3, WL_RS_NOISE0 = 4 /* ..6 */, WL_RS_POLICY = 7 };
+enum WlRngStream : uint32_t { WL_RS_RESET = 0, WL_RS_TIMERS = 1, WL_RS_PUSH_HF = 2, WL_RS_PUSH_LF = 3, WL_RS_NOISE0 = 4 /* ..6 */, WL_RS_POLICY = 7,
+                            WL_RS_STARTUP = 8, WL_RS_STARTUP_BUCKET = 9 };
 
 struct U4 {
     uint32_t x, y, z, w;
