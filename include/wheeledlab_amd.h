@@ -285,6 +285,7 @@ int wl_actor_critic_act(const WlMlp* actor, const WlMlp* critic, const float* st
 #define WL_PPO_CTRL_LR 0      /* [2] learning rate, ping-pong by `parity` (the caller seeds BOTH with the initial lr) */
 #define WL_PPO_CTRL_NORM2 2   /* [2] squared gradient norm accumulator, ping-pong */
 #define WL_PPO_CTRL_STATS 4   /* [3] running sums of mean value loss / surrogate / KL over the calls (caller zeroes) */
+#define WL_PPO_CTRL_STD 8     /* [2] the action std the gradients were taken at (written by the gradient launches, read by apply) */
 
 typedef struct WlPpoBatch {          /* a flattened rollout, B = K * n samples; all device pointers */
     const float* obs;                /* [B][14] */

@@ -82,6 +82,10 @@ def main():
         agent_cfg.save_interval = min(agent_cfg.save_interval, log_cfg.checkpoint_every)
     runner = OnPolicyRunner(env, agent_cfg, log_dir=None if log_cfg.no_checkpoints else log_dir, device=train_cfg.device,
                             fused=False if args.stepwise else None, kernel_policy=False if args.torch_policy else None)
+    if world > 1:
+        # the parameters above were initialised from the SAME seed on every rank (they must start identical); whatever is
+        # sampled from torch's global RNG from here on (the torch policy path's exploration noise) must differ per shard
+        torch.manual_seed(train_cfg.seed + 1000003 * rank)
     if train_cfg.load_run is not None:
         resume_path = checkpoint_path(log_cfg.logs_dir, train_cfg.load_run, train_cfg.load_run_checkpoint)
         if rank == 0 and not args.quiet:

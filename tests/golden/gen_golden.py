@@ -619,6 +619,36 @@ def gen_elevation(El):
     res["weights"] = np.array([R.vel_towards_goal.weight, R.height_z.weight, R.falling_penalty.weight,
                                R.termination_penalty.weight], np.float32)
     np.savez_compressed(os.path.join(OUT, "elevation_mdp.npz"), **res)
+    gen_elevation_unwired(El, st, env)
+
+
+def gen_elevation_unwired(El, st, env):
+    """the reward functions the elevation cfg module DEFINES but does not register (SURVEY.md 8(a) row E12,
+    mushr_elevation_env_cfg.py:159-164,175-231,256-266): their outputs on the same 256 states, so that the build's
+    torch-fallback restatements (wheeledlab_amd/envs/mdp.py) are pinned too.  elevation_continuity keeps its previous
+    elevation in a function attribute: first call (-> zeros), then a second call on shifted heights."""
+    out = dict(pos=st["pos"], quat=st["quat"], lin_vel_b=st["lin_vel_b"], ang_vel_b=st["ang_vel_b"], lin_vel_w=st["lin_vel_w"],
+               joint_vel=st["joint_vel"])
+    out["forward_wheel_spin"] = npy(El.forward_wheel_spin(env))
+    out["change_in_elevation"] = npy(El.change_in_elevation(env))
+    out["steep_penalty"] = npy(El.steep_penalty(env, 0.2))
+    out["yaw_change_onElev"] = npy(El.yaw_change_onElev(env, 0.5, 0.1))
+    out["roll_on_elev"] = npy(El.roll_on_elev(env, 0.1, 0.1))
+    out["ascending"] = npy(El.ascending(env))
+    out["low_vel_penalty"] = npy(El.low_vel_penalty(env, 0.1))
+    out["upright_penalty_30"] = npy(El.upright_penalty(env, 30.0))
+    if hasattr(El.elevation_continuity, "prev_elevation"):
+        del El.elevation_continuity.prev_elevation
+    out["elevation_continuity_first"] = npy(El.elevation_continuity(env, 0.1))
+    rng = np.random.RandomState(9 + SEED_OFFSET)
+    dz = rng.normal(0, 0.05, st["pos"].shape[0]).astype(np.float32)
+    st2 = dict(st)
+    st2["pos"] = st["pos"].copy()
+    st2["pos"][:, 2] += dz
+    env2 = env_from_state(st2)
+    out["pos_second"] = st2["pos"]
+    out["elevation_continuity_second"] = npy(El.elevation_continuity(env2, 0.1))
+    np.savez_compressed(os.path.join(OUT, "elevation_unwired.npz"), **out)
 
 
 def gen_visual(VU, TU):

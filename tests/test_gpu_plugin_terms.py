@@ -1,0 +1,172 @@
+"""The term plugin API on the GPU: reward / termination / observation terms WITHOUT a HIP implementation
+-- any `f(env, **params) -> Tensor[N]` as the reference's configs allow (mushr_drift_env_cfg.py:219,343-362,
+elevation/mushr_elevation_env_cfg.py:44-48,155-231,349-376, common/observations.py:24-54) -- registered through the
+config run as torch on the state views behind the fused kernel: custom rewards are added (and logged), a custom
+termination ends the episode through a masked reset launch, custom observation terms are concatenated behind the fused
+block, and the elevation task's height scanner is readable through `env.scene.sensors`."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg(task, n):
+    from wheeledlab_amd import registry, tasks  # noqa: F401
+    return registry, registry.parse_env_cfg(task, device=DEV, num_envs=n)
+
+
+def test_drift_lambda_termination_observation_and_reward_run_behind_the_kernel():
+    from wheeledlab_amd.core import DriftBatch
+    from wheeledlab_amd.envs import mdp
+    from wheeledlab_amd.envs.managers_cfg import ObservationTermCfg as ObsTerm
+    from wheeledlab_amd.envs.managers_cfg import RewardTermCfg as RewTerm
+    from wheeledlab_amd.envs.managers_cfg import TerminationTermCfg as DoneTerm
+    n, K, X_MAX = 512, 40, 0.95
+    registry, cfg = _cfg("Isaac-MushrDriftRL-v0", n)
+    # plain callables, nothing kernel-backed about them
+    cfg.terminations.too_far_right = DoneTerm(func=lambda env, x_max: mdp.root_pos_w(env)[:, 0] > x_max, params=dict(x_max=X_MAX))
+    cfg.rewards.go_fast = RewTerm(func=lambda env: mdp.base_lin_vel(env)[:, 0].clamp(min=0.0), weight=2.5)
+    cfg.observations.policy.speed = ObsTerm(func=lambda env: mdp.base_lin_vel(env)[:, :2], clip=(-2.0, 2.0), scale=0.5)
+    cfg.observations.policy.enable_corruption = False
+    env = registry.make("Isaac-MushrDriftRL-v0", cfg=cfg)
+    assert env.observation_manager.group_obs_dim["policy"] == (16,) and env._has_custom_rewards
+    assert "too_far_right" in env.termination_manager.active_terms
+    # the twin: the same kernel without the custom terms, re-seated on the env's state before every step
+    twin = DriftBatch(n, device=DEV, seed=env._batch.seed, params=env._batch.p, startup=env._flat.startup)
+    obs, _ = env.reset()
+    assert obs["policy"].shape == (n, 16)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    fired = resets = 0
+    dt = cfg.sim.dt * cfg.decimation
+    for k in range(K):
+        twin.state.copy_(env._batch.state)
+        twin.episode_len.copy_(env._batch.episode_len)
+        twin.step_count = env._batch.step_count
+        a = torch.rand(n, 2, device=DEV, generator=g) * 2 - 1
+        a[:, 0] = a[:, 0].abs()
+        o, rew, term, trunc, extras = env.step(a)
+        o2, r2, t2, u2 = twin.step(a)
+        o, rew, term, trunc = o["policy"].clone(), rew.clone(), term.clone(), trunc.clone()
+        st = twin.state                                           # post-step state incl. the kernel's own resets
+        live = ~(t2 | u2)
+        q = st[3:7, :n]
+        vw = st[7:10, :n]
+        # body-frame velocity of the twin's state: R(q)^T v
+        w, x, y, z = q
+        r00, r10, r20 = 1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)
+        r01, r11, r21 = 2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)
+        vbx = r00 * vw[0] + r10 * vw[1] + r20 * vw[2]
+        vby = r01 * vw[0] + r11 * vw[1] + r21 * vw[2]
+        want_flag = (st[0, :n] > X_MAX) & live
+        assert torch.equal(term, t2 | want_flag) and torch.equal(trunc, u2), k
+        assert torch.equal(env.termination_manager.get_term("too_far_right"), want_flag)
+        want_rew = r2 + torch.where(live, vbx.clamp(min=0.0) * (2.5 * dt), torch.zeros_like(vbx))
+        torch.testing.assert_close(rew, want_rew, rtol=1e-5, atol=1e-5)
+        # envs ended by the custom term were reset by the masked launch: fresh episode, at rest, on the centre line
+        es = env._batch.state
+        if bool(want_flag.any()):
+            assert (env._batch.episode_len[:n][want_flag] == 0).all() and (es[7:13, :n][:, want_flag] == 0).all()
+            assert (es[0, :n][want_flag].abs() <= 0.8 + 0.5 + 1e-5).all()
+        keep = ~want_flag
+        assert torch.equal(es[:, :n][:, keep], st[:, :n][:, keep])         # everyone else: exactly the kernel's state
+        assert torch.equal(o[keep][:, :14], o2[keep])
+        # the custom observation columns: post-reset state, clip then scale
+        q = es[3:7, :n]
+        w, x, y, z = q
+        vw = es[7:10, :n]
+        vb = torch.stack([(1 - 2 * (y * y + z * z)) * vw[0] + 2 * (x * y + w * z) * vw[1] + 2 * (x * z - w * y) * vw[2],
+                          2 * (x * y - w * z) * vw[0] + (1 - 2 * (x * x + z * z)) * vw[1] + 2 * (y * z + w * x) * vw[2]], -1)
+        torch.testing.assert_close(o[:, 14:], vb.clamp(-2.0, 2.0) * 0.5, rtol=1e-5, atol=1e-5)
+        fired += int(want_flag.sum())
+        resets += int((term | trunc).sum())
+        log = extras["log"]
+        assert "Episode_Reward/go_fast" in log and "Episode_Termination/too_far_right" in log
+        assert int(log["Episode_Termination/too_far_right"]) == int(want_flag.sum())
+    assert fired > 0 and resets > fired
+    assert float(env.episode_metrics()[8]) == resets                # every episode end was booked, whoever ended it
+    env.close()
+
+
+def test_elevation_unwired_reward_custom_termination_and_the_height_scanner():
+    from oracle import elev_step as OE
+    from oracle import heightfield as OH
+    from wheeledlab_amd.envs import mdp
+    from wheeledlab_amd.envs.managers_cfg import ObservationTermCfg as ObsTerm
+    from wheeledlab_amd.envs.managers_cfg import RewardTermCfg as RewTerm
+    from wheeledlab_amd.envs.managers_cfg import SceneEntityCfg
+    from wheeledlab_amd.envs.managers_cfg import TerminationTermCfg as DoneTerm
+    n = 256
+    registry, cfg = _cfg("Isaac-MushrElevationRL-v0", n)
+    cfg.rewards.upright = RewTerm(func=mdp.upright_penalty, weight=-3.0, params=dict(thresh_deg=2.0))      # an E12 function
+    cfg.rewards.low_vel = RewTerm(func=mdp.low_vel_penalty, weight=-1.0, params=dict(min_vel=0.1))
+    cfg.terminations.tilted = DoneTerm(func=lambda env, deg: mdp.upright_penalty(env, deg) > 0, params=dict(deg=12.0))
+    cfg.observations.policy.scan_min = ObsTerm(
+        func=lambda env, sensor_cfg: mdp.height_scan(env, sensor_cfg, offset=0.0).amin(1, keepdim=True),
+        params=dict(sensor_cfg=SceneEntityCfg("height_scanner")))
+    env = registry.make("Isaac-MushrElevationRL-v0", cfg=cfg)
+    b = env._batch
+    assert env.observation_manager.group_obs_dim["policy"] == (690,) and "height_scanner" in env.scene.sensors
+    obs, _ = env.reset()
+    # the sensor view against the numpy restatement of the ray caster
+    p = OE.elev_params()
+    hf = OH.make_terrain()
+    st = b.state.cpu().numpy()
+    want_map = OE.height_map(p, st[:, :n], hf)
+    sensor = env.scene.sensors["height_scanner"]
+    hits = sensor.data.ray_hits_w
+    assert hits.shape == (n, 676, 3) and sensor.data.pos_w.shape == (n, 3)
+    inside = want_map < p.obs_clip
+    got_z = hits[..., 2].cpu().numpy()
+    np.testing.assert_allclose(got_z[inside], (want_map - np.float32(p.scan_offset) + np.float32(p.elev_z0))[inside], atol=2e-5)
+    assert np.isinf(got_z[~inside]).all()
+    torch.testing.assert_close(sensor.data.pos_w[:, 2], b.state[2, :n] + 20.0)
+    hs = mdp.height_scan(env, SceneEntityCfg("height_scanner"), offset=0.084)            # IsaacLab's definition
+    np.testing.assert_allclose(hs.cpu().numpy()[inside], (st[2, :n, None] + 20.0 - got_z - 0.084)[inside], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(obs["policy"][:, 689:], mdp.height_scan(env, SceneEntityCfg("height_scanner"), 0.0).amin(1, keepdim=True))
+    # steps: rewards of the two E12 terms + the custom termination, against the same formulas in numpy on the device state
+    g = torch.Generator(device=DEV).manual_seed(2)
+    ended = 0
+    for k in range(30):
+        a = torch.rand(n, 2, device=DEV, generator=g) * 2 - 1
+        base_w = [(nm, env.reward_manager.get_term_cfg(nm).weight) for nm in ("upright", "low_vel")]
+        o, rew, term, trunc, extras = env.step(a)
+        flag = env.termination_manager.get_term("tilted").clone()
+        s = b.state.cpu().numpy()[:, :n]
+        # envs that are still running (neither the kernel nor the custom term ended them) show their post-step state
+        running = ~(term | trunc).cpu().numpy()
+        q = s[3:7]
+        up = 1 - 2 * (q[1] ** 2 + q[2] ** 2)
+        tilt = np.degrees(np.arccos(np.clip(up, -1, 1)))
+        assert (tilt[running] <= 12.0 + 1e-3).all()                       # whoever tilted further was ended
+        ended += int(flag.sum())
+        assert (b.episode_len[:n][flag] == 0).all()
+        assert "Episode_Reward/upright" in extras["log"] and "Episode_Termination/tilted" in extras["log"]
+        assert base_w == [(nm, env.reward_manager.get_term_cfg(nm).weight) for nm in ("upright", "low_vel")]
+        assert o["policy"].shape == (n, 690) and torch.isfinite(o["policy"][:, :13]).all()
+    assert ended > 0
+    # one more step, checked term by term: reward = kernel reward + the two E12 terms on the running envs
+    from wheeledlab_amd.core import ElevBatch
+    twin = ElevBatch(n, device=DEV, seed=b.seed, params=b.p, startup=env._flat.startup)
+    twin.state.copy_(b.state)
+    twin.episode_len.copy_(b.episode_len)
+    twin.step_count = b.step_count
+    a = torch.rand(n, 2, device=DEV, generator=g) * 2 - 1
+    o, rew, term, trunc, _ = env.step(a)
+    o2, r2, t2, u2 = twin.step(a)
+    s = twin.state[:, :n]
+    live = ~(t2 | u2)
+    q = s[3:7]
+    up = 1 - 2 * (q[1] ** 2 + q[2] ** 2)
+    tilt = torch.rad2deg(torch.arccos(up))
+    pen = torch.where(tilt > 2.0, tilt - 2.0, torch.zeros_like(tilt))
+    w, x, y, z = q
+    vbx = (1 - 2 * (y * y + z * z)) * s[7] + 2 * (x * y + w * z) * s[8] + 2 * (x * z - w * y) * s[9]
+    dt = cfg.sim.dt * cfg.decimation
+    extra = torch.where(live, (-3.0 * pen - 1.0 * (vbx < 0.1).float()) * dt, torch.zeros_like(pen))
+    torch.testing.assert_close(rew, r2 + extra, rtol=1e-4, atol=1e-4)
+    assert torch.equal(term, t2 | ((pen > 10.0) & live))
+    env.close()

@@ -80,21 +80,29 @@ def test_flatten_overrides_and_play_cfg():
     assert play.params.r_out > 1e20 and play.params.pos_noise == 0.0 and play.params.yaw_noise == 0.0
 
 
-def test_flatten_rejects_what_the_kernel_cannot_express():
+def test_flatten_routes_unknown_terms_to_the_torch_fallback_and_rejects_what_cannot_be_expressed():
+    from wheeledlab_amd.envs.managers_cfg import ObservationTermCfg, TerminationTermCfg
     cfg = MushrDriftRLEnvCfg()
-    cfg.rewards.extra = RewardTermCfg(func=lambda env: None, weight=1.0)      # custom reward: allowed, evaluated after the kernel
-    type(cfg.rewards).__cfg_fields__ = {**type(cfg.rewards).__cfg_fields__, "extra": None}
-    try:
-        flat = flatten_drift_cfg(cfg)
-        assert [n for n, _ in flat.custom_rewards] == ["extra"]
-    finally:
-        type(cfg.rewards).__cfg_fields__.pop("extra")
+    cfg.rewards.extra = RewardTermCfg(func=lambda env: None, weight=1.0)      # set on the instance, as IsaacLab users do
+    cfg.terminations.mine = TerminationTermCfg(func=lambda env: None)
+    cfg.observations.policy.more = ObservationTermCfg(func=lambda env: None)
+    flat = flatten_drift_cfg(cfg)
+    assert [n for n, _ in flat.custom_rewards] == ["extra"]
+    assert [n for n, _ in flat.custom_terminations] == ["mine"] and [n for n, _ in flat.custom_obs] == ["more"]
+    assert flat.termination_names == {"time_out": "time_out", 0: "out_of_bounds"}     # the built-in ones stay fused
+    # replacing a built-in termination by a plain callable: that term moves to the fallback, the kernel's slot is disabled
+    cfg = MushrDriftRLEnvCfg()
+    cfg.terminations.out_of_bounds.func = lambda env: None
+    flat = flatten_drift_cfg(cfg)
+    assert [n for n, _ in flat.custom_terminations] == ["out_of_bounds"] and 0 not in flat.termination_names
+    assert flat.params.r_in == 0.0 and flat.params.r_out > 1e29
+    # what neither the kernel nor a torch term can express is still refused
     cfg = MushrDriftRLEnvCfg()
     cfg.scene.terrain.physics_material.friction_combine_mode = "average"
     with pytest.raises(NotImplementedError):
         flatten_drift_cfg(cfg)
     cfg = MushrDriftRLEnvCfg()
-    cfg.terminations.out_of_bounds.func = lambda env: None
+    cfg.observations.policy.base_lin_vel_term.func = lambda env: None     # the fused block's layout is fixed
     with pytest.raises(NotImplementedError):
         flatten_drift_cfg(cfg)
 

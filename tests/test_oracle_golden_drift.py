@@ -175,7 +175,7 @@ def test_committed_vectors_regenerate_from_the_reference(tmp_path):
     env = dict(os.environ, WL_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
     subprocess.run([sys.executable, os.path.join(here, "gen_golden.py")], check=True, env=env, capture_output=True, timeout=600)
     names = sorted(f for f in os.listdir(here) if f.endswith(".npz"))
-    assert names == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) and len(names) == 8
+    assert names == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) and len(names) == 9
     for f in names:
         a, b = np.load(os.path.join(here, f)), np.load(tmp_path / f)
         assert set(a.files) == set(b.files), f

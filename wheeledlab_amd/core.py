@@ -244,10 +244,12 @@ class ElevBatch(_MetricsView):
                                        None if m is None else m.data_ptr(), self.seed, self.step_count, self._stream()),
                 "wl_elev_reset")
 
-    def observe(self) -> torch.Tensor:
-        A.check(self.lib.wl_elev_observe(C.byref(self.p), C.byref(self._bufs), C.byref(self._hf), self.obs.data_ptr(),
+    def observe(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        """observation of the current state into self.obs (or a caller's [n, 689] buffer)"""
+        out = self.obs if out is None else out
+        A.check(self.lib.wl_elev_observe(C.byref(self.p), C.byref(self._bufs), C.byref(self._hf), out.data_ptr(),
                                          self._stream()), "wl_elev_observe")
-        return self.obs
+        return out
 
     def step(self, actions: torch.Tensor):
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.shape != (self.n, 2):

@@ -466,8 +466,13 @@ __global__ void __launch_bounds__(64 * kPpoWaves) ppo_grad_kernel(const PpoNets 
 // grad[i] = sum over blocks of partials[b][i]; norm2 += sum of squares of the parameter gradients (stats excluded).
 // 64 columns per block, four row groups of threads: 64 independent coalesced loads per thread instead of one thread
 // walking all 256 rows (61 us -> a few).
+// Also snapshots the action std into ctrl: the apply kernel updates std in place (threads 0 / 1 of its block 0) while every
+// one of its blocks needs the OLD std for the entropy gradient and the clip coefficient -- reading it from `std` there is a
+// cross-block race (a late block sees the new value: nondeterministic clip coefficient, ranks drifting apart bit by bit).
 __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float* __restrict__ partials, int n_blocks, float* __restrict__ grad,
-                                                         float* __restrict__ norm2) {
+                                                         float* __restrict__ norm2, const float* __restrict__ std,
+                                                         float* __restrict__ std_snapshot) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) std_snapshot[threadIdx.x] = std[threadIdx.x];
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -525,7 +530,7 @@ __global__ void __launch_bounds__(256) ppo_apply_kernel(const PpoNets N, float* 
     // the entropy bonus -c_e * sum_j log sigma_j enters the std gradient before the norm; its square is added on the fly
     float n2 = ctrl[WL_PPO_CTRL_NORM2 + parity];
     const float gs0 = grad[O_STD], gs1 = grad[O_STD + 1];
-    const float es0 = -hp.entropy_coef / std[0], es1 = -hp.entropy_coef / std[1];
+    const float es0 = -hp.entropy_coef / ctrl[WL_PPO_CTRL_STD], es1 = -hp.entropy_coef / ctrl[WL_PPO_CTRL_STD + 1];   // snapshot, see ppo_reduce_kernel
     n2 += (gs0 + es0) * (gs0 + es0) - gs0 * gs0 + (gs1 + es1) * (gs1 + es1) - gs1 * gs1;
     const float coef = fminf(1.f, hp.max_grad_norm / (sqrtf(fmaxf(n2, 0.f)) + 1e-6f));
     if (i < G) {
@@ -605,7 +610,8 @@ int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const
         ppo_grad_kernel<WL_ACT_ELU><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, st->operands, *bt, mb_start, mb_size, h, st->partials);
     else
         ppo_grad_kernel<WL_ACT_RELU><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, st->operands, *bt, mb_start, mb_size, h, st->partials);
-    ppo_reduce_kernel<<<(kRow + 63) / 64, 256, 0, stream>>>(st->partials, blocks, st->grad, st->ctrl + WL_PPO_CTRL_NORM2 + parity);
+    ppo_reduce_kernel<<<(kRow + 63) / 64, 256, 0, stream>>>(st->partials, blocks, st->grad, st->ctrl + WL_PPO_CTRL_NORM2 + parity, std,
+                                                             st->ctrl + WL_PPO_CTRL_STD);
     return launch_status();
 }
 

@@ -83,5 +83,8 @@ def configclass(cls):
 
 
 def fields_of(cfg):
-    """(name, value) pairs of a config instance in declaration order"""
-    return [(k, getattr(cfg, k)) for k in type(cfg).__cfg_fields__ if hasattr(cfg, k)]
+    """(name, value) pairs of a config instance in declaration order, then attributes set on the INSTANCE afterwards
+    (`cfg.rewards.my_term = RewTerm(...)`: IsaacLab's managers iterate the instance dict, so such terms count)"""
+    declared = type(cfg).__cfg_fields__
+    names = [k for k in declared if hasattr(cfg, k)] + [k for k in vars(cfg) if k not in declared and not k.startswith("_")]
+    return [(k, getattr(cfg, k)) for k in names]

@@ -35,6 +35,8 @@ class FlatDriftCfg:
     startup: StartupSpec
     reward_names: list = field(default_factory=list)        # [(cfg name, slot)]
     custom_rewards: list = field(default_factory=list)      # [(name, term_cfg)] evaluated with torch after the kernel
+    custom_terminations: list = field(default_factory=list) # [(name, term_cfg)] torch, on the post-step state views
+    custom_obs: list = field(default_factory=list)          # [(name, term_cfg)] torch, concatenated after the fused block
     termination_names: dict = field(default_factory=dict)   # {"time_out": name, 0: name}
     curriculum: list = field(default_factory=list)          # [(name, term_cfg)]
     obs_dim: int = 14
@@ -109,8 +111,9 @@ def flatten_drift_cfg(cfg) -> FlatDriftCfg:
     has_timeout = False
     for name, term in _terms(cfg.terminations):
         f = term.func
-        if getattr(f, "wl_kind", None) != "termination":
-            raise NotImplementedError(f"termination term '{name}': {getattr(f, '__name__', f)} has no HIP implementation")
+        if getattr(f, "wl_kind", None) != "termination":   # any f(env, **params) -> bool[N]: torch fallback on the state views
+            flat.custom_terminations.append((name, term))
+            continue
         if f.wl_slot == "time_out":
             if not term.time_out:
                 raise NotImplementedError("mdp.time_out must be registered with time_out=True")
@@ -126,8 +129,10 @@ def flatten_drift_cfg(cfg) -> FlatDriftCfg:
     obs_terms = _terms(pol)
     want = ["root_pos_w", "root_euler_xyz", "base_lin_vel", "base_ang_vel", "last_action"]
     got = [getattr(t.func, "__name__", str(t.func)) for _, t in obs_terms]
-    if got != want:
-        raise NotImplementedError(f"policy observation terms {got} != the fused kernel's layout {want}")
+    if got[:len(want)] != want:
+        raise NotImplementedError(f"the policy observation must start with the fused kernel's layout {want} (got {got}); "
+                                  "further terms are evaluated with torch and concatenated behind it")
+    flat.custom_obs = obs_terms[len(want):]
     p.enable_corruption = int(bool(pol.enable_corruption))
     for i, (_, t) in enumerate(obs_terms[:4]):
         n = t.noise
@@ -226,6 +231,8 @@ class FlatTaskCfg:
     startup: StartupSpec
     reward_names: list = field(default_factory=list)
     custom_rewards: list = field(default_factory=list)
+    custom_terminations: list = field(default_factory=list)
+    custom_obs: list = field(default_factory=list)
     termination_names: dict = field(default_factory=dict)
     curriculum: list = field(default_factory=list)
     obs_dim: int = 0
@@ -338,7 +345,8 @@ def flatten_elev_cfg(cfg) -> FlatTaskCfg:
             flat.termination_names["time_out"] = name
             continue
         if getattr(f, "wl_kind", None) != "termination" or f not in (mdp.root_height_below_minimum, mdp.stuck, mdp.upright_bool, mdp.close_to_goal):
-            raise NotImplementedError(f"termination term '{name}' has no HIP implementation")
+            flat.custom_terminations.append((name, term))     # torch fallback on the state views
+            continue
         for key, fld in f.wl_params.items():
             val = float(term.params[key])
             setattr(p, fld, math.cos(math.radians(val)) if fld == "upright_cos" else val)
@@ -349,8 +357,9 @@ def flatten_elev_cfg(cfg) -> FlatTaskCfg:
     want = ["goal_relative_xyz", "root_euler_xyz", "base_lin_vel", "base_ang_vel", "last_action", "world_height_map"]
     obs_terms = _terms(cfg.observations.policy)
     got = [getattr(t.func, "__name__", str(t.func)) for _, t in obs_terms]
-    if got != want or cfg.observations.policy.enable_corruption:
-        raise NotImplementedError(f"policy observation terms {got} != the fused kernel's layout {want} (no corruption)")
+    if got[:len(want)] != want or cfg.observations.policy.enable_corruption:
+        raise NotImplementedError(f"the policy observation must start with the fused kernel's layout {want} (no corruption); got {got}")
+    flat.custom_obs = obs_terms[len(want):]
     hm = obs_terms[5][1]
     p.scan_offset, p.elev_z0 = float(hm.params.get("offset", 0.084)), float(hm.params.get("plane_init_value", 0.19))
     p.obs_clip = float(hm.clip[1])
@@ -409,14 +418,16 @@ def flatten_visual_cfg(cfg) -> FlatTaskCfg:
             has_oom = True
             flat.termination_names[0] = name
         else:
-            raise NotImplementedError(f"termination term '{name}' has no HIP implementation")
+            flat.custom_terminations.append((name, term))     # torch fallback on the state views
     if not has_timeout:
         p.max_episode_length = INT_MAX
     flat.extra["out_of_map"] = has_oom
     want = ["camera_data_rgb_flattened_aug", "base_lin_vel", "base_ang_vel", "last_action"]
-    got = [getattr(t.func, "__name__", str(t.func)) for _, t in _terms(cfg.observations.policy)]
-    if got != want or cfg.observations.policy.enable_corruption:
-        raise NotImplementedError(f"policy observation terms {got} != the fused kernel's layout {want} (no corruption)")
+    vis_obs = _terms(cfg.observations.policy)
+    got = [getattr(t.func, "__name__", str(t.func)) for _, t in vis_obs]
+    if got[:len(want)] != want or cfg.observations.policy.enable_corruption:
+        raise NotImplementedError(f"the policy observation must start with the fused kernel's layout {want} (no corruption); got {got}")
+    flat.custom_obs = vis_obs[len(want):]
     cam = cfg.scene.camera
     if (cam.height, cam.width) != (60, 80):
         raise NotImplementedError("the fused camera is 60 x 80")

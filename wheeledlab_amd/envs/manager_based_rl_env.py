@@ -70,7 +70,7 @@ class TerminationManager:
 
     @property
     def active_terms(self):
-        return list(self._names.values())
+        return list(self._names.values()) + [n for n, _ in self._env._custom_term]
 
     @property
     def terminated(self):
@@ -85,6 +85,8 @@ class TerminationManager:
         return self.terminated | self.time_outs
 
     def get_term(self, name):
+        if name in self._env._custom_flags:          # a torch-fallback term: its value at the last step
+            return self._env._custom_flags[name]
         if name == self._names.get("time_out"):
             return self.time_outs
         slots = [k for k, v in self._names.items() if v == name and k != "time_out"]
@@ -140,11 +142,11 @@ class CommandManager:
 class ObservationManager:
     def __init__(self, env):
         self._env = env
-        self.group_obs_dim = {"policy": (env._batch.OBS_DIM,)}
+        self.group_obs_dim = {"policy": (env._batch.OBS_DIM,)}      # grown by the env once its custom terms are sized
         self.active_terms = {"policy": [k for k, v in fields_of(env.cfg.observations.policy) if hasattr(v, "func")]}
 
     def compute(self):
-        return {"policy": self._env._batch.observe()}
+        return {"policy": self._env._with_custom_obs(self._env._batch.observe())}
 
 
 def episode_log_keys(reward_slots, term_names):
@@ -168,12 +170,19 @@ class EpisodeLog(dict):
     omit the keys: use nanmean, or cfg.sync_episode_log)."""
     __slots__ = ("_metrics", "_idx", "_len_s", "_keys")
 
-    def __init__(self, metrics, idx, keys, episode_length_s):
+    def __init__(self, metrics, idx, keys, episode_length_s, extra=None):
         super().__init__()
         self._metrics, self._idx, self._keys, self._len_s = metrics, idx, keys, episode_length_s
+        if extra:       # torch-fallback terms: ready-made device scalars
+            self._keys = dict(keys)
+            for k, v in extra.items():
+                self._keys[k] = ("x", v)
 
     def __missing__(self, key):
         kind, i = self._keys[key]
+        if kind == "x":
+            self[key] = i
+            return i
         m = self._metrics if self._idx is None else self._metrics[self._idx]
         if m.dim() == 2:                       # raw accumulator [WL_M_SHARDS][WL_M_COUNT]: fold the shards once
             m = m.sum(0)
@@ -225,7 +234,12 @@ class ManagerBasedRLEnv:
                                                       sub_group_size=x["group"], num_walkers=x["walkers"]), **common)
         else:
             self._batch = DriftBatch(self.num_envs, **common)
-        self.scene = SceneView(self._batch, cfg.scene)
+        self.scene = SceneView(self._batch, cfg.scene, task=flat.task)
+        # plugin terms without a HIP implementation: any f(env, **params) evaluates with torch on the state views
+        self._custom_rew, self._custom_term, self._custom_obs = list(flat.custom_rewards), list(flat.custom_terminations), list(flat.custom_obs)
+        self._custom_flags = {n: torch.zeros(self.num_envs, dtype=torch.bool, device=self.device) for n, _ in self._custom_term}
+        self._custom_epsum = {n: torch.zeros(self.num_envs, device=self.device) for n, _ in self._custom_rew}
+        self._custom_log = {}
         self.common_step_counter = 0
         self.step_dt = cfg.sim.dt * cfg.decimation
         self.physics_dt = cfg.sim.dt
@@ -247,7 +261,15 @@ class ManagerBasedRLEnv:
         self.extras = {}
         self.obs_buf = {}
         self._log_keys = episode_log_keys(self.reward_manager._slots, flat.termination_names)
-        self._has_custom_rewards = bool(flat.custom_rewards)
+        # "torch terms run between the kernel launches": the fused collectors (one launch per rollout / writing straight
+        # into the runner's storage) are off whenever any kind of custom term is registered
+        self._has_custom_rewards = bool(self._custom_rew or self._custom_term or self._custom_obs)
+        self._obs_dim = self._batch.OBS_DIM
+        if self._custom_obs:
+            self._obs_dim += sum(self._eval_obs_term(t).shape[1] for _, t in self._custom_obs)
+            self.observation_manager.group_obs_dim["policy"] = (self._obs_dim,)
+            self.single_observation_space = {"policy": Box(-math.inf, math.inf, (self._obs_dim,))}
+            self.observation_space = {"policy": Box(-math.inf, math.inf, (self.num_envs, self._obs_dim))}
         self._has_curriculum = bool(flat.curriculum)
         self._clip_actions = False
         self._sim_step_counter = 0
@@ -289,7 +311,9 @@ class ManagerBasedRLEnv:
             self.seed(seed)
         self._batch.reset()
         self.extras = {}
-        self.obs_buf = {"policy": self._batch.observe()}
+        for t in self._custom_epsum.values():
+            t.zero_()
+        self.obs_buf = {"policy": self._with_custom_obs(self._batch.observe())}
         return self.obs_buf, self.extras
 
     def step(self, action: torch.Tensor):
@@ -301,11 +325,8 @@ class ManagerBasedRLEnv:
         obs, rew, terminated, truncated = b.step(action)
         self.common_step_counter += 1
         self._sim_step_counter += self.cfg.decimation
-        # custom (non-fused) reward terms: user torch code on the device, RewardManager semantics
         if self._has_custom_rewards:
-            for name, term in self._flat.custom_rewards:
-                if term.weight != 0.0:
-                    rew += term.func(self, **term.params) * term.weight * self.step_dt
+            obs, rew, terminated, truncated = self._apply_custom_terms(obs, rew, terminated, truncated, slot)
         # curriculum: evaluated inside _reset_idx in IsaacLab, i.e. on steps where >= 1 env resets; every built-in
         # term is a no-op off episode boundaries, so the (synchronising) any() runs once per max_episode_length steps
         if self._has_curriculum and self.common_step_counter % self.max_episode_length == 0:
@@ -396,7 +417,82 @@ class ManagerBasedRLEnv:
         return out
 
     def _episode_log(self, slot):
-        return EpisodeLog(self._batch.metrics_raw, 0 if slot is None else slot, self._log_keys, self.max_episode_length_s)
+        return EpisodeLog(self._batch.metrics_raw, 0 if slot is None else slot, self._log_keys, self.max_episode_length_s,
+                          self._custom_log)
+
+    # ---- torch fallback for terms without a HIP implementation (SURVEY.md 8(b) "term plugin API") -------------------
+    def _eval_obs_term(self, term) -> torch.Tensor:
+        """ObservationManager semantics for one term: f(env, **params) -> noise (if corruption is on) -> clip -> scale"""
+        v = term.func(self, **term.params).to(torch.float32)
+        if v.dim() == 1:
+            v = v.unsqueeze(-1)
+        v = v.reshape(self.num_envs, -1)
+        n = getattr(term, "noise", None)
+        if n is not None and getattr(self.cfg.observations.policy, "enable_corruption", False):
+            if hasattr(n, "std"):
+                v = v + n.mean + n.std * torch.randn_like(v)
+            else:
+                v = v + n.n_min + (n.n_max - n.n_min) * torch.rand_like(v)
+        if getattr(term, "clip", None) is not None:
+            v = v.clamp(term.clip[0], term.clip[1])
+        if getattr(term, "scale", None) is not None:
+            v = v * term.scale
+        return v
+
+    def _with_custom_obs(self, obs: torch.Tensor) -> torch.Tensor:
+        if not self._custom_obs:
+            return obs
+        return torch.cat([obs] + [self._eval_obs_term(t) for _, t in self._custom_obs], dim=-1)
+
+    def _apply_custom_terms(self, obs, rew, terminated, truncated, slot):
+        """The fused kernel has already stepped, rewarded, terminated and RESET the envs its built-in terms ended.  Custom
+        terms see the post-step state of every env that is still running (exactly what IsaacLab would show them); envs
+        that a built-in term ended this step are already at their reset pose, so custom rewards / terminations are
+        masked off for them (their last-step custom reward is the one approximation of this path).  A custom
+        termination ends the episode through a masked wl_*_reset launch; its episode sums go to the metric ring first.
+        Everything is device-side torch: no host synchronisation."""
+        b, n = self._batch, self.num_envs
+        live = ~(terminated | truncated)
+        zero = torch.zeros((), device=self.device)
+        for name, term in self._custom_rew:
+            if term.weight == 0.0:       # RewardManager skips zero-weight terms
+                continue
+            val = torch.where(live, term.func(self, **term.params).to(torch.float32) * (term.weight * self.step_dt), zero)
+            rew += val
+            self._custom_epsum[name] += val
+        newly = None
+        if self._custom_term:
+            c_term = torch.zeros(n, dtype=torch.bool, device=self.device)
+            c_to = torch.zeros_like(c_term)
+            for name, term in self._custom_term:
+                flag = term.func(self, **term.params).to(torch.bool) & live
+                self._custom_flags[name] = flag
+                if getattr(term, "time_out", False):
+                    c_to |= flag
+                else:
+                    c_term |= flag
+            newly = c_term | c_to
+            m = newly.to(torch.float32)
+            ring = b.metrics_raw[0 if slot is None else slot, 0]                 # shard 0 of this step's slot
+            ring[A.M_EPSUM0:A.M_EPSUM0 + A.WL_MAX_REW_TERMS] += (b.state[A.S_EPSUM0:A.S_EPSUM0 + A.WL_MAX_REW_TERMS, :n] * m).sum(1)
+            ring[A.M_RESETS] += m.sum()
+            ring[A.M_TIMEOUTS] += c_to.sum()
+            ring[A.M_EPLEN] += (b.episode_len[:n].to(torch.float32) * m).sum()
+            terminated |= c_term          # in place: the batch's own flag buffers (reset_buf, the RSL-RL wrapper's dones)
+            truncated |= c_to
+            b.dones |= newly.to(b.dones.dtype)
+            kept = obs.clone()
+            b.reset(newly)                                                        # masked launch (no-op without flags)
+            obs.copy_(torch.where(newly.unsqueeze(-1), b.observe().clone(), kept))   # fresh observation for those envs only
+        done = ~live if newly is None else (~live | newly)
+        cnt = done.sum().to(torch.float32)
+        self._custom_log = {}
+        for name, acc in self._custom_epsum.items():
+            self._custom_log[f"Episode_Reward/{name}"] = (acc * done).sum() / cnt / self.max_episode_length_s
+            acc *= ~done
+        for name, flag in self._custom_flags.items():
+            self._custom_log[f"Episode_Termination/{name}"] = flag.sum()
+        return self._with_custom_obs(obs), rew, terminated, truncated
 
     def episode_metrics(self, window: int | None = None, reduce_ranks: bool = True):
         """aggregate of the last `window` per-step metric slots as one [WL_M_COUNT] vector; across ranks it is ONE

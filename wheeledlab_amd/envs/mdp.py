@@ -288,7 +288,74 @@ def world_height_map(env, sensor_cfg=None, offset: float = 0.084, plane_init_val
 
 
 def height_scan(env, sensor_cfg=None, offset: float = 0.5):
-    raise NotImplementedError("mdp.height_scan is fused into world_height_map (elev_obs_kernel)")
+    """isaaclab mdp.height_scan: sensor height - hit height - offset, [N, rays] (un-vendored).  The
+    hits come from the scan kernel through the scene's sensor view (envs/scene.py::RayCasterData)."""
+    sensor = env.scene.sensors[sensor_cfg.name if sensor_cfg is not None else "height_scanner"]
+    return sensor.data.pos_w[:, 2].unsqueeze(1) - sensor.data.ray_hits_w[..., 2] - offset
+
+
+# ---- reward terms the reference DEFINES for this task but does not wire into its reward cfg (:159-164, 175-231, 256-266):
+# plain torch on the state views, so a config override that registers one runs through the custom-term path ----------
+
+def _elev_z(env, base: float = 0.19):
+    return root_pos_w(env)[:, 2] - base
+
+
+def forward_wheel_spin(env, asset_cfg=_ROBOT):                  # :159-164: summed throttle-joint speed, capped at 200
+    robot = env.scene[asset_cfg.name]
+    ids = robot.find_joints(".*_throttle")[0]
+    return robot.data.joint_vel[:, ids].sum(-1).clamp(max=200.0)
+
+
+def change_in_elevation(env):                                   # :175-178: upward world velocity only
+    return root_lin_vel_w(env)[:, 2].clamp(min=0.0)
+
+
+def steep_penalty(env, thresh_pitch):                           # :180-186: pitch (wrapped to [0, 2 pi)) above a threshold
+    return (euler_xyz_from_quat(root_quat_w(env))[1] - thresh_pitch).clamp(min=0.0)
+
+
+class _ElevationContinuity:
+    """:188-203: +-50 x the change of elevation since the previous call while above `threshold_elev`.  The reference keeps
+    the previous elevation in a function attribute (one global for the process); here it lives per env object."""
+    __name__ = "elevation_continuity"
+
+    def __call__(self, env, threshold_elev):
+        z = _elev_z(env)
+        prev = getattr(env, "_elev_continuity_prev", None)
+        if prev is None or prev.shape != z.shape:
+            prev = z.clone()
+        dz = z - prev
+        env._elev_continuity_prev = z.clone()
+        return torch.where(z > threshold_elev, 50.0 * dz.abs(), torch.zeros_like(z))
+
+
+elevation_continuity = _ElevationContinuity()
+
+
+def yaw_change_onElev(env, threshold_yaw, threshold_z):         # :206-212
+    wz = base_ang_vel(env)[:, 2].abs()
+    return torch.where((_elev_z(env) > threshold_z) & (wz > threshold_yaw), 2.0 * wz * wz, torch.zeros_like(wz))
+
+
+def upright_penalty(env, thresh_deg):                           # :217-222: tilt of the body z axis beyond thresh_deg [deg]
+    q = root_quat_w(env)
+    up = 1.0 - 2.0 * (q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2])   # R[2, 2]
+    tilt = torch.rad2deg(torch.arccos(up))
+    return torch.where(tilt > thresh_deg, tilt - thresh_deg, torch.zeros_like(tilt))
+
+
+def roll_on_elev(env, z_start, roll_rate_thresh):               # :224-231
+    wx = base_ang_vel(env)[:, 0].abs()
+    return torch.where((_elev_z(env) > z_start) & (wx > roll_rate_thresh), 2.0 * wx, torch.zeros_like(wx))
+
+
+def ascending(env):                                             # :256-259
+    return root_lin_vel_w(env)[:, 2].clamp(min=0.0)
+
+
+def low_vel_penalty(env, min_vel: float = 0.1):                 # :261-265
+    return (base_lin_vel(env)[:, 0] < min_vel).float()
 
 
 @_event("reset_uniform")

@@ -124,8 +124,47 @@ class ArticulationView:
         self._b.state[A.S_VX:A.S_VX + 6, ids] = vel.T.to(torch.float32)
 
 
+class RayCasterData:
+    """`sensor.data` of the elevation task's height scanner (isaaclab RayCaster, un-vendored): `pos_w` [N, 3] and
+    `ray_hits_w` [N, 676, 3], grid order "xy" (x fastest), yaw-aligned -- what `mdp.height_scan` and the reference's
+    `world_height_map` (elevation/mushr_elevation_env_cfg.py:44-48) read.  The hit heights come from the scan KERNEL
+    (elev_scan_kernel through wl_elev_observe: world_height_map = hit_z + offset - plane_init, +clip on a miss), the hit
+    x / y are the grid points themselves (vertical rays); rays that miss the terrain report +inf like Warp's ray caster."""
+
+    def __init__(self, batch, offset_pos):
+        self._b, self._off = batch, offset_pos
+
+    @property
+    def pos_w(self):
+        b = self._b
+        return b.state[A.S_PX:A.S_PX + 3, : b.n].T + torch.tensor(self._off, device=b.device, dtype=torch.float32)
+
+    @property
+    def ray_hits_w(self):
+        b, p = self._b, self._b.p
+        n, k = b.n, A.ELEV_SCAN_N
+        hmap = b.observe(torch.empty_like(b.obs))[:, 13:]     # scratch buffer: the env's own observation stays untouched
+        z = torch.where(hmap >= p.obs_clip, torch.full_like(hmap, float("inf")), hmap - p.scan_offset + p.elev_z0)
+        g = -0.5 * p.scan_size + p.scan_res * torch.arange(k, device=b.device, dtype=torch.float32)
+        lx, ly = g.repeat(k), g.repeat_interleave(k)
+        q = b.state[A.S_QW:A.S_QW + 4, :n]
+        ca, sa = 1.0 - 2.0 * (q[2] * q[2] + q[3] * q[3]), 2.0 * (q[0] * q[3] + q[1] * q[2])
+        inv = torch.rsqrt(ca * ca + sa * sa)
+        c, s_ = (ca * inv).unsqueeze(1), (sa * inv).unsqueeze(1)
+        x = b.state[A.S_PX, :n].unsqueeze(1) + c * lx - s_ * ly
+        y = b.state[A.S_PY, :n].unsqueeze(1) + s_ * lx + c * ly
+        return torch.stack([x, y, z], dim=-1)
+
+
+class RayCasterView:
+    def __init__(self, batch, cfg):
+        self.cfg = cfg
+        self.data = RayCasterData(batch, tuple(getattr(cfg, "offset_pos", (0.0, 0.0, 0.0))))
+        self.num_instances = batch.n
+
+
 class SceneView:
-    def __init__(self, batch, cfg=None):
+    def __init__(self, batch, cfg=None, task: str = "drift"):
         self._b = batch
         self.cfg = cfg
         self.num_envs = batch.n
@@ -133,6 +172,8 @@ class SceneView:
         names = getattr(getattr(cfg, "robot", None), "joint_names", None) or MUSHR_JOINT_NAMES
         self.articulations = {"robot": ArticulationView(batch, names)}
         self.sensors = {}
+        if task == "elevation" and getattr(cfg, "height_scanner", None) is not None:
+            self.sensors["height_scanner"] = RayCasterView(batch, cfg.height_scanner)
         self.terrain = getattr(cfg, "terrain", None)
 
     def __getitem__(self, key):

@@ -104,6 +104,19 @@ class ActorCritic:
         return out
 
 
+def _normalise_over_ranks(adv: torch.Tensor) -> torch.Tensor:
+    """(adv - mean) / (std + 1e-8) over the GLOBAL batch: with one process per GPU the moments are all-reduced (one
+    3-float collective), so an N-rank run normalises exactly like the one big batch (rsl_rl is single-process)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return (adv - adv.mean()) / (adv.std() + 1e-8)
+    m = torch.stack([adv.sum().double(), (adv.double() ** 2).sum(), torch.tensor(float(adv.numel()), device=adv.device, dtype=torch.float64)])
+    dist.all_reduce(m, op=dist.ReduceOp.SUM)
+    mean = m[0] / m[2]
+    var = (m[1] - m[2] * mean * mean) / (m[2] - 1.0)          # unbiased, like torch.std
+    return ((adv - mean.float()) / (var.clamp_min(0).sqrt().float() + 1e-8))
+
+
 class RolloutStorage:
     """[K(+1), n, ...] transition rows, named as rsl_rl's RolloutStorage"""
 
@@ -149,4 +162,4 @@ class RolloutStorage:
                 last = delta + not_done[t] * gamma * lam * last
                 adv[t] = last
             returns = adv + self.values[:-1]
-        return returns, (adv - adv.mean()) / (adv.std() + 1e-8)
+        return returns, _normalise_over_ranks(adv)

@@ -397,6 +397,9 @@ class OnPolicyRunner:
                                                                                      cur_episode_length)
                 rewbuffer.extend(ret[-100:].tolist())
                 lenbuffer.extend(length[-100:].tolist())
+                # the learning signal that is logged is the RAW env reward: bootstrap_time_outs adds gamma * V(obs) at
+                # time-out steps, which grows as the critic learns even when the policy does not
+                mean_step_reward = float(st.rewards.mean())
                 st.bootstrap_time_outs(self.alg.gamma)
             torch.cuda.synchronize() if self.device.type == "cuda" else None
             t1 = time.time()
@@ -409,7 +412,7 @@ class OnPolicyRunner:
             self.tot_time += t2 - t0
             log = dict(iteration=it, collection_time=t1 - t0, learn_time=t2 - t1, fps=steps / (t2 - t0),
                        collection_fps=steps / max(t1 - t0, 1e-9), mean_reward=_mean(rewbuffer), mean_episode_length=_mean(lenbuffer),
-                       mean_step_reward=float(st.rewards.mean()), mean_noise_std=float(self.actor_critic.std.detach().mean()), **losses)
+                       mean_step_reward=mean_step_reward, mean_noise_std=float(self.actor_critic.std.detach().mean()), **losses)
             base = env.unwrapped
             if hasattr(base, "episode_log_summary"):
                 log.update(base.episode_log_summary(st.n_steps, reduce_ranks=self.world > 1))
