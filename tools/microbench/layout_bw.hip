@@ -23,6 +23,35 @@ __global__ void __launch_bounds__(256) stream_kernel(float* __restrict__ base, l
     for (int w = 0; w < W; ++w) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s + (float)w), rs, voff, w * rowb, 0);
 }
 
+// (c) rows grouped in fours: [group][n] of float4 -- 16 B per lane per access, 1 KB contiguous per wavefront
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int GR, int GW>
+__global__ void __launch_bounds__(256) stream4_kernel(f4* __restrict__ base, long stride, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    f4 acc[GR];
+#pragma unroll
+    for (int g = 0; g < GR; ++g) acc[g] = base[(long)g * stride + e];
+    f4 s = acc[0];
+#pragma unroll
+    for (int g = 1; g < GR; ++g) s += acc[g];
+#pragma unroll
+    for (int g = 0; g < GW; ++g) base[(long)g * stride + e] = s + (float)g;
+}
+template <int GR, int GW>
+float run4(float* buf, long stride, int n) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) stream4_kernel<GR, GW><<<(n + 255) / 256, 256>>>((f4*)buf, stride, n);
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < 10; ++i) stream4_kernel<GR, GW><<<(n + 255) / 256, 256>>>((f4*)buf, stride, n);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms * 100.f;
+}
+
 template <bool TILED>
 float run(float* buf, long stride, int n) {
     hipEvent_t a, b;
@@ -37,16 +66,58 @@ float run(float* buf, long stride, int n) {
     return ms * 100.f;   // us per launch
 }
 
+template <int R, int W>
+float run_rw(float* buf, long stride, int n) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) stream_kernel<R, W, false><<<(n + 255) / 256, 256>>>(buf, stride, n);
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < 10; ++i) stream_kernel<R, W, false><<<(n + 255) / 256, 256>>>(buf, stride, n);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms * 100.f;
+}
+__global__ void __launch_bounds__(256) copy4_kernel(const f4* __restrict__ src, f4* __restrict__ dst, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
 int main() {
+    {   // reference points on this box: plain float4 copy (grid-stride, 16 B / lane), read-mostly and write-mostly SoA streams
+        const int n = 1 << 22;
+        float* buf;
+        CHECK(hipMalloc(&buf, (long)n * 4 * 44));
+        CHECK(hipMemset(buf, 0, (long)n * 4 * 44));
+        const long n4 = (long)n * 20 / 4;   // 20 rows -> 20 rows
+        hipEvent_t a, b;
+        CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+        for (int g : {4096, 16384, 65536}) {
+            for (int i = 0; i < 3; ++i) copy4_kernel<<<g, 256>>>((const f4*)buf, (f4*)buf + n4, n4);
+            CHECK(hipEventRecord(a));
+            for (int i = 0; i < 10; ++i) copy4_kernel<<<g, 256>>>((const f4*)buf, (f4*)buf + n4, n4);
+            CHECK(hipEventRecord(b));
+            CHECK(hipEventSynchronize(b));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, a, b));
+            printf("float4 copy 336 MB -> 336 MB, grid %d: %.1f us (%.2f TB/s)\n", g, ms * 100.f, 2.0 * n4 * 16 / (ms * 100.f) / 1e6);
+        }
+        const float r = run_rw<34, 1>(buf, n, n), w = run_rw<1, 30>(buf, n, n), h = run_rw<17, 15>(buf, n, n);
+        printf("SoA 34 in / 1 out %.1f us (%.2f TB/s)   1 in / 30 out %.1f us (%.2f TB/s)   17 in / 15 out %.1f us (%.2f TB/s)\n", r,
+               35.0 * 4 * n / r / 1e6, w, 31.0 * 4 * n / w / 1e6, h, 32.0 * 4 * n / h / 1e6);
+        CHECK(hipFree(buf));
+    }
     for (int n : {1 << 20, 1 << 22}) {
         const long stride = n;
         float* buf;
-        CHECK(hipMalloc(&buf, stride * 4 * 41));
-        CHECK(hipMemset(buf, 0, stride * 4 * 41));
+        CHECK(hipMalloc(&buf, stride * 4 * 44));
+        CHECK(hipMemset(buf, 0, stride * 4 * 44));
         const double bytes = (34.0 + 30.0) * 4 * n;
         const float us_soa = run<false>(buf, stride, n), us_tiled = run<true>(buf, stride, n);
-        printf("n=%d  SoA %.1f us (%.2f TB/s)   AoSoA64 %.1f us (%.2f TB/s)\n", n, us_soa, bytes / us_soa / 1e6, us_tiled,
-               bytes / us_tiled / 1e6);
+        const float us_g4 = run4<9, 8>(buf, stride, n);
+        const double bytes4 = (9.0 + 8.0) * 16 * n;
+        printf("n=%d  SoA %.1f us (%.2f TB/s)   AoSoA64 %.1f us (%.2f TB/s)   float4 groups 9 in / 8 out %.1f us (%.2f TB/s)\n", n,
+               us_soa, bytes / us_soa / 1e6, us_tiled, bytes / us_tiled / 1e6, us_g4, bytes4 / us_g4 / 1e6);
         CHECK(hipFree(buf));
     }
     return 0;

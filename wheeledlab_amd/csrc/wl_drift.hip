@@ -32,12 +32,6 @@ __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? 
     // occupancy there and the VGPRs are needed for the env
     WlDriftParams p = p_arg;
     VehDerived vd = vd_arg;
-    if constexpr (LANES == 4) {
-        p = kernarg_vector_copy<WlDriftParams>(kHotArgBytes);
-        keep_scalar_fields(p, p_arg);
-        vd = kernarg_vector_copy<VehDerived>(kHotArgBytes + (int)sizeof(WlDriftParams));
-        vd.n_sub = vd_arg.n_sub;
-    }
     WlEnvBuffers b = b_arg;          // the hot fields from the preloaded arguments, the rest when the kernarg block lands
     b.state = state;
     b.episode_len = episode_len;
@@ -58,15 +52,37 @@ __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? 
         EnvConst ec;
         DriftRows r;
         const float2 a = actions[e];
-        load_env_const(S, p.vehicle, vd, e, ec);
+        float dr_mass, dr_mu_s, dr_mu_d, dr_damp;
+        dr_mass = S.ld(WL_S_MASS, e), dr_mu_s = S.ld(WL_S_MU_S, e), dr_mu_d = S.ld(WL_S_MU_D, e), dr_damp = S.ld(WL_S_DAMP, e);
         load_rows<LANES>(S, b, p, e, wid, r);
         const uint32_t gid = (uint32_t)(b.env_offset + e);
         float* tile_w = tile + (LANES == 1 ? wave * 64 * kObsPad : 0);
         if constexpr (LANES == 4) {
-            // the step's random draws need only (seed, gid, step): computed while the state loads above are in flight
-            const StepDraws pre = draw_step(p, b.ref_poses, gid, step, seed, wid);
-            drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, wid, lead, gid, seed, step, tile_w, ms, nullptr, &pre);
+            // The state requests go out FIRST (they need only the preloaded arguments), the parameter block right behind
+            // them.  Everything that follows runs in their shadow -- and is kept there by a basic-block boundary: within
+            // one block the instruction selector, to shorten live ranges, put the ~200 instructions of the draws (which
+            // need no loaded value) IN FRONT of the state requests, so that the launch waited for the parameter block,
+            // drew, and only then asked for its state: two memory round trips in series.  The memory clobber keeps the
+            // loads from being sunk across the boundary, the always-true test of an opaque scalar cannot be folded.
+            uint32_t kw[(sizeof(WlDriftParams) + sizeof(VehDerived)) / 4];
+            kernarg_vector_words(kHotArgBytes, kw);
+            int go = 1;
+            asm volatile("" : "+s"(go) : : "memory");
+            if (go) {
+                // the step's random draws need only (seed, gid, step) -- preloaded arguments: two Philox blocks and two
+                // Box-Muller pairs per lane before the first instruction that waits for anything
+                StepDraws pre = draw_step_raw(gid, step, seed, wid);
+                kernarg_words_landed(kw);            // the first instruction that waits for the parameter block
+                __builtin_memcpy(&p, kw, sizeof(WlDriftParams));
+                __builtin_memcpy(&vd, kw + sizeof(WlDriftParams) / 4, sizeof(VehDerived));
+                keep_scalar_fields(p, p_arg);        // v_readfirstlane of the integer parameters
+                vd.n_sub = uniform_i32(vd.n_sub);
+                ref_pose_request(pre, b.ref_poses, p.num_ref_points);   // consumed only inside the (rare) reset branch: never waited for here
+                env_const_rows(ec, p.vehicle, vd, dr_mass, dr_mu_s, dr_mu_d, dr_damp);
+                drift_env_step<LANES>(p, b, vd, ground, S, ec, r, a, noise, out, e, wid, lead, gid, seed, step, tile_w, ms, nullptr, &pre);
+            }
         } else {
+            env_const_rows(ec, p.vehicle, vd, dr_mass, dr_mu_s, dr_mu_d, dr_damp);
             drift_env_step<LANES, UNROLL, DRIVE>(p, b, vd, ground, S, ec, r, a, noise, out, e, wid, lead, gid, seed, step, tile_w, ms);
         }
         store_rows<LANES>(S, b, p, e, wid, lead, r);

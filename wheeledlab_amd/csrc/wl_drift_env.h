@@ -116,42 +116,49 @@ WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise
 // branch that needs an event pulls it from its lane with DPP quad broadcasts (the branch conditions are functions of
 // the replicated env state, so a quad is always wholly inside or outside a branch).
 struct StepDraws {
-    F4 ev;        // lane 0: reset pose (x, y, yaw) ; lane 1: re-armed timers (hf, lf) ; lane 2: hf-push u ; lane 3: lf-push u
-    float z[4];   // this lane's four observation-noise normals (lanes 0..2 of the quad; see gather_quad_noise)
+    F4 ev;               // this lane's event block: lane 0 reset pose, lane 1 re-armed timers, lane 2 hf push, lane 3 lf push
+    float ref[3];        // the reference pose (x, y, yaw) lane 0's reset would start from (ref_pose_request)
+    float z[4];          // this lane's four observation-noise normals (lanes 0..2 of the quad; see gather_quad_noise)
 };
 
-WL_DEV StepDraws draw_step(const WlDriftParams& p, const float* __restrict__ ref, uint32_t gid, uint64_t step, uint64_t seed,
-                           int wid) {
+// first half: needs nothing but the key (preloaded kernel arguments): it runs while BOTH the state rows and the parameter
+// block are still in flight
+WL_DEV StepDraws draw_step_raw(uint32_t gid, uint64_t step, uint64_t seed, int wid) {
     StepDraws d;
-    const F4 u = philox_uniform4(gid, step, (uint32_t)wid, seed);
-    // both reset streams are post-processed by every lane on ITS block, branch-free (only lane 0's pose and lane 1's
-    // timers are ever read): the reference-pose lookup is a dependent memory round trip that belongs up here too
-    const int idx = min((int)(u.x * (float)p.num_ref_points), p.num_ref_points - 1);
-    const float rx = fmaf(2.f * u.y - 1.f, p.pos_noise, ref[idx]), ry = fmaf(2.f * u.z - 1.f, p.pos_noise, ref[32 + idx]);
-    const float ryaw = fmaf(2.f * u.w - 1.f, p.yaw_noise, ref[64 + idx]);
-    const float thf = fmaf(u.x, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
-    const float tlf = fmaf(u.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
-    d.ev.x = opaque(wid == 0 ? rx : wid == 1 ? thf : u.x);
-    d.ev.y = opaque(wid == 0 ? ry : wid == 1 ? tlf : u.y);
-    d.ev.z = opaque(wid == 0 ? ryaw : u.z);
-    d.ev.w = opaque(u.w);
+    d.ev = philox_uniform4(gid, step, (uint32_t)wid, seed);
     const F4 n = philox_uniform4(gid, step, WL_RS_NOISE0 + (uint32_t)min(wid, 2), seed);
     box_muller(n.x, n.y, d.z[0], d.z[1]);
     box_muller(n.z, n.w, d.z[2], d.z[3]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) d.z[k] = opaque(d.z[k]);   // computed HERE, not sunk to the observation code on the tail
+    d.ev.x = opaque(d.ev.x), d.ev.y = opaque(d.ev.y), d.ev.z = opaque(d.ev.z), d.ev.w = opaque(d.ev.w);
+    d.ref[0] = d.ref[1] = d.ref[2] = 0.f;
     return d;
 }
-// the events of the quad, pulled from the lanes that drew them
-WL_DEV ResetDraw quad_reset_draw(const StepDraws& d) {
+// the reference-pose lookup is a dependent memory round trip: requested as soon as the pose count is known, consumed
+// only inside the reset branch (every lane looks up ITS block's index; lane 0's is the one that counts)
+WL_DEV void ref_pose_request(StepDraws& d, const float* __restrict__ ref, int num_ref) {
+    const int idx = min((int)(d.ev.x * (float)num_ref), num_ref - 1);
+    d.ref[0] = ref[idx], d.ref[1] = ref[32 + idx], d.ref[2] = ref[64 + idx];
+}
+WL_DEV StepDraws draw_step(const WlDriftParams& p, const float* __restrict__ ref, uint32_t gid, uint64_t step, uint64_t seed,
+                           int wid) {
+    StepDraws d = draw_step_raw(gid, step, seed, wid);
+    ref_pose_request(d, ref, p.num_ref_points);
+    return d;
+}
+// the events of the quad, pulled from the lanes that drew them (called inside the reset branch: a quad is always wholly
+// inside or outside it, the branch conditions being functions of the replicated env state)
+WL_DEV ResetDraw quad_reset_draw(const WlDriftParams& p, const StepDraws& d) {
     ResetDraw r;
-    r.pos = v3(quad_bcast<0>(d.ev.x), quad_bcast<0>(d.ev.y), 0.f);
-    r.yaw = quad_bcast<0>(d.ev.z);
+    // reset_root_state_along_track.__call__ (drifting/mdp/events.py:119-133) on lane 0's block, timers on lane 1's
+    r.pos = v3(quad_bcast<0>(fmaf(2.f * d.ev.y - 1.f, p.pos_noise, d.ref[0])), quad_bcast<0>(fmaf(2.f * d.ev.z - 1.f, p.pos_noise, d.ref[1])), 0.f);
+    r.yaw = quad_bcast<0>(fmaf(2.f * d.ev.w - 1.f, p.yaw_noise, d.ref[2]));
     float s, c;
     sincos_fast(0.5f * r.yaw, s, c);
     r.q = Quat{c, 0.f, 0.f, s};
-    r.timer_hf = quad_bcast<1>(d.ev.x);
-    r.timer_lf = quad_bcast<1>(d.ev.y);
+    r.timer_hf = quad_bcast<1>(fmaf(d.ev.x, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]));
+    r.timer_lf = quad_bcast<1>(fmaf(d.ev.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]));
     return r;
 }
 template <int K>
@@ -212,21 +219,30 @@ WL_DEV void load_bookkeeping_rows(const Rows& S, const WlEnvBuffers& b, int e, D
 
 template <int LANES>
 WL_DEV void load_rows(const Rows& S, const WlEnvBuffers& b, const WlDriftParams& p, int e, int wid, DriftRows& r) {
-    r.pos = ld3(S, WL_S_PX, e);
-    r.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
-    r.v = ld3(S, WL_S_VX, e);
-    r.ww = ld3(S, WL_S_WX, e);
-    if constexpr (LANES == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
-    } else {
+    if constexpr (LANES == 4) {   // latency form: ordered requests, everything up front (see Rows::ld)
+        r.pos = v3(S.ld(WL_S_PX, e), S.ld(WL_S_PY, e), S.ld(WL_S_PZ, e));
+        r.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+        r.v = v3(S.ld(WL_S_VX, e), S.ld(WL_S_VY, e), S.ld(WL_S_VZ, e));
+        r.ww = v3(S.ld(WL_S_WX, e), S.ld(WL_S_WY, e), S.ld(WL_S_WZ, e));
         r.wheel[0] = S.ld_lane_row(WL_S_WHEEL_BL + wid, e);
 #pragma unroll
-        for (int i = 0; i < WL_DR_NTERMS; ++i) r.epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) : 0.f;
+        for (int i = 0; i < WL_DR_NTERMS; ++i) r.epsum[i] = S.ld(WL_S_EPSUM0 + i, e);   // unconditional: gating the REQUEST on
+        // log_episode_sums would make the load burst wait for the flag's own fetch; the flag gates the uses (metrics, store)
+        r.th = S.ld(WL_S_STEER_POS, e);
+        r.om = S.ld(WL_S_STEER_VEL, e);
+        r.timer_hf = S.ld(WL_S_TIMER_HF, e);
+        r.timer_lf = S.ld(WL_S_TIMER_LF, e);
+        r.ep_len = b.episode_len[e];
+    } else {                      // throughput form: the bookkeeping rows are fetched after the physics loop (registers)
+        r.pos = ld3(S, WL_S_PX, e);
+        r.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+        r.v = ld3(S, WL_S_VX, e);
+        r.ww = ld3(S, WL_S_WX, e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
+        r.th = S.ld(WL_S_STEER_POS, e);
+        r.om = S.ld(WL_S_STEER_VEL, e);
     }
-    r.th = S.ld(WL_S_STEER_POS, e);
-    r.om = S.ld(WL_S_STEER_VEL, e);
-    if constexpr (LANES == 4) load_bookkeeping_rows(S, b, e, r);   // lane form: fetched after the physics loop (registers)
 }
 
 template <int LANES>
@@ -343,7 +359,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         __builtin_amdgcn_sched_barrier(0);   // keep the requests here: the scheduler would sink them to their first use
     } else {
 #pragma unroll
-        for (int i = 0; i < WL_DR_NTERMS; ++i) epsum[i] = r.epsum[i];
+        for (int i = 0; i < WL_DR_NTERMS; ++i) epsum[i] = p.log_episode_sums ? r.epsum[i] : 0.f;
     }
     const Mat3 R = mat_from_quat(s.q);
     V3 ww = mul(R, s.wb);
@@ -393,6 +409,12 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
     }
     // ---- reset (done envs) ----
+    // The observation wants the body-frame velocities of the state AFTER reset and pushes.  Round 1 rebuilt the rotation
+    // matrix from the final quaternion and rotated both vectors again (43 instructions, every env, every step); but the
+    // common path changes neither, a reset leaves the env at rest, and a push adds a known world-frame increment: the
+    // body-frame values are carried along and corrected inside the (divergent, occasional) branches instead.
+    Mat3 Ro = R;
+    V3 wb_o = s.wb;
     float a0 = a.x, a1 = a.y, timer_hf = r.timer_hf, timer_lf = r.timer_lf;
     if (terminated || truncated) {
         if (lead) {
@@ -412,13 +434,18 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
             s.th = s.om = 0.f;
         }
         ResetDraw rd;
-        if constexpr (LANES == 4) rd = quad_reset_draw(*pre);
+        if constexpr (LANES == 4) rd = quad_reset_draw(p, *pre);
         else rd = draw_reset(p, b.ref_poses, gid, step, seed);
         pos = rd.pos;
         s.q = rd.q;
         if constexpr (LANES == 4) euler = v3(0.f, 0.f, rd.yaw - WL_TWO_PI * floorf(rd.yaw * WL_INV_TWO_PI));
         s.v = v3(0.f, 0.f, 0.f);
         ww = v3(0.f, 0.f, 0.f);
+        // the observation frame: at rest, rotated about z only (q = (c, 0, 0, s))
+        vb = v3(0.f, 0.f, 0.f);
+        wb_o = v3(0.f, 0.f, 0.f);
+        const float cy = fmaf(rd.q.w, rd.q.w, -rd.q.z * rd.q.z), sy = 2.f * rd.q.w * rd.q.z;
+        Ro = Mat3{v3(cy, -sy, 0.f), v3(sy, cy, 0.f), v3(0.f, 0.f, 1.f)};
         timer_hf = rd.timer_hf;
         timer_lf = rd.timer_lf;
         ep_len = 0;
@@ -431,9 +458,13 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
             F4 u;
             if constexpr (LANES == 4) u = quad_event<2>(*pre);
             else u = philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
-            s.v.x = fmaf(2.f * u.x - 1.f, p.hf_vel_x, s.v.x);
-            s.v.y = fmaf(2.f * u.y - 1.f, p.hf_vel_y, s.v.y);
-            ww.z = fmaf(2.f * u.z - 1.f, p.hf_vel_yaw, ww.z);
+            const float dvx = (2.f * u.x - 1.f) * p.hf_vel_x, dvy = (2.f * u.y - 1.f) * p.hf_vel_y, dwz = (2.f * u.z - 1.f) * p.hf_vel_yaw;
+            s.v.x += dvx;
+            s.v.y += dvy;
+            ww.z += dwz;
+            vb = v3(fmaf(Ro.r0.x, dvx, fmaf(Ro.r1.x, dvy, vb.x)), fmaf(Ro.r0.y, dvx, fmaf(Ro.r1.y, dvy, vb.y)),
+                    fmaf(Ro.r0.z, dvx, fmaf(Ro.r1.z, dvy, vb.z)));
+            wb_o = fma3(dwz, Ro.r2, wb_o);
             timer_hf = fmaf(u.w, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
         }
         timer_lf -= step_dt;
@@ -441,7 +472,9 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
             F4 u;
             if constexpr (LANES == 4) u = quad_event<3>(*pre);
             else u = philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
-            ww.z = fmaf(2.f * u.x - 1.f, p.lf_vel_yaw, ww.z);
+            const float dwz = (2.f * u.x - 1.f) * p.lf_vel_yaw;
+            ww.z += dwz;
+            wb_o = fma3(dwz, Ro.r2, wb_o);
             timer_lf = fmaf(u.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
         }
     }
@@ -468,10 +501,8 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
             for (int i = 0; i < WL_DR_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
         }
     }
-    // ---- observation of the post-reset state ----
-    const Mat3 R2 = mat_from_quat(s.q);
-    vb = mul_t(R2, s.v);
-    const V3 wb2 = mul_t(R2, ww);
+    // ---- observation of the post-reset state (vb, wb_o: carried along above) ----
+    const V3 wb2 = wb_o;
     Noise12 nz;
     bool drawn = false;
     if constexpr (LANES == 4) {
@@ -528,11 +559,11 @@ WL_DEV void pin_params_vgpr(WlDriftParams& p, VehDerived& d) {
     for (float* f : df) pin_vgpr(*f);
 }
 
-WL_DEV void keep_scalar_fields(WlDriftParams& v, const WlDriftParams& s) {
-    keep_scalar_common(v, s);
-    v.enable_corruption = s.enable_corruption;
-    v.num_ref_points = s.num_ref_points;
-    v.enable_pushes = s.enable_pushes;
+WL_DEV void keep_scalar_fields(WlDriftParams& v, const WlDriftParams&) {
+    uniform_scalar_common(v);
+    v.enable_corruption = uniform_i32(v.enable_corruption);
+    v.num_ref_points = uniform_i32(v.num_ref_points);
+    v.enable_pushes = uniform_i32(v.enable_pushes);
 }
 
 // host-side validation shared by every drift entry point

@@ -25,11 +25,16 @@ struct Rows {
     // row index that differs per LANE (quad form: lane `wid` owns wheel row WL_S_WHEEL_BL + wid): the row goes into the
     // per-lane byte offset.  (Through ld / st the row would be the SCALAR offset, and a lane-varying scalar operand
     // makes the compiler emit a readfirstlane "waterfall" loop: up to four serialised passes around one load.)
+    // The product is a 24-bit multiply (row < 64, row_bytes < 2^24: the C-ABI wrappers refuse the quad form beyond that):
+    // written as `row * row_bytes + env * 4` the compiler emits v_mad_u64_u32 with a 64-bit addend PAIR whose upper
+    // register it shares with a pending load's destination -- a false dependency that parked the wavefront on
+    // s_waitcnt vmcnt in the middle of its load burst (one extra memory round trip per launch).
+    WL_DEV int lane_row_offset(int row_lane, int env) const { return (int)__umul24((unsigned)row_lane, (unsigned)row_bytes) + env * 4; }
     WL_DEV float ld_lane_row(int row_lane, int env) const {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, row_lane * row_bytes + env * 4, 0, 0));
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_row_offset(row_lane, env), 0, 0));
     }
     WL_DEV void st_lane_row(int row_lane, int env, float v) const {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, row_lane * row_bytes + env * 4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, lane_row_offset(row_lane, env), 0, 0);
     }
 };
 WL_DEV Rows make_rows(float* base, int64_t stride) {
@@ -50,24 +55,77 @@ WL_DEV void st3(const Rows& s, int row, int e, V3 v) {
 // parameter block with VECTOR loads at a lane-uniform address: one batch, issued from the kernarg pointer the wavefront
 // is born with, straight into VGPRs (where float parameters are consumed anyway).  Integer fields that steer scalar
 // control flow are then taken from the scalar copy again so that branches and loop bounds stay uniform.
-template <class T>
-WL_DEV T kernarg_vector_copy(int byte_offset) {
-    static_assert(sizeof(T) % 4 == 0, "dword POD");
-    constexpr int N = sizeof(T) / 4;
-    using KArg = const __attribute__((address_space(4))) uint32_t;
+template <int N>
+WL_DEV void kernarg_vector_words(int byte_offset, uint32_t (&w)[N]) {
+    // volatile: the requests stay where they are written (constant-address-space loads are otherwise sunk to their
+    // first use, block by block -- each batch another kernarg round trip on the critical path).  On gfx950 a volatile load
+    // carries sc0 sc1; the argument block is written by the host for this launch and read once: nothing to lose.
+    using KArg = const volatile __attribute__((address_space(4))) uint32_t;
     KArg* ka = (KArg*)__builtin_amdgcn_kernarg_segment_ptr();
     int z = 0;
     asm volatile("" : "+v"(z));   // a VGPR zero the compiler cannot fold: keeps these loads on the vector path
-    uint32_t w[N];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+    using KArg4 = const volatile __attribute__((address_space(4))) u32x4;
+    constexpr int N4 = N / 4;   // 16-byte requests (a volatile access is never merged: dword by dword it would be N requests)
 #pragma unroll
-    for (int i = 0; i < N; ++i) w[i] = ka[byte_offset / 4 + i + z];
+    for (int i = 0; i < N4; ++i) {
+        const u32x4 q = *(KArg4*)(ka + byte_offset / 4 + 4 * i + z);
+        w[4 * i] = q.x, w[4 * i + 1] = q.y, w[4 * i + 2] = q.z, w[4 * i + 3] = q.w;
+    }
+#pragma unroll
+    for (int i = 4 * N4; i < N; ++i) w[i] = ka[byte_offset / 4 + i + z];
+}
+template <class T>
+WL_DEV T kernarg_vector_copy(int byte_offset) {
+    static_assert(sizeof(T) % 4 == 0, "dword POD");
+    uint32_t w[sizeof(T) / 4];
+    kernarg_vector_words(byte_offset, w);
     T t;
     __builtin_memcpy(&t, w, sizeof(T));
     return t;
 }
+// Volatile requests cannot be dropped, so fields nobody reads are fetched too -- and a destination register that is
+// dead on arrival is handed out again at once, which makes the NEXT writer of that register wait for the load to land
+// (write-after-write): the draws that should run in the shadow of the burst stalled on its first instruction.  Touching
+// every word where the block is first needed keeps all destinations allocated until then.
+template <int N>
+WL_DEV void kernarg_words_landed(uint32_t (&w)[N]) {
+#pragma unroll
+    for (int i = 0; i + 8 <= N; i += 8)
+        asm volatile("" : "+v"(w[i]), "+v"(w[i + 1]), "+v"(w[i + 2]), "+v"(w[i + 3]), "+v"(w[i + 4]), "+v"(w[i + 5]), "+v"(w[i + 6]), "+v"(w[i + 7]));
+#pragma unroll
+    for (int i = N - N % 8; i < N; ++i) asm volatile("" : "+v"(w[i]));
+}
+// two ADJACENT argument structs in one burst from one address register (two separate copies made the second one's
+// address registers collide with the first one's pending destinations: a wait in the middle of the burst)
+template <class A, class B>
+WL_DEV void kernarg_vector_copy2(int byte_offset, A& a, B& b) {
+    static_assert(sizeof(A) % 4 == 0 && sizeof(B) % 4 == 0, "dword PODs");
+    uint32_t w[(sizeof(A) + sizeof(B)) / 4];
+    kernarg_vector_words(byte_offset, w);
+    __builtin_memcpy(&a, w, sizeof(A));
+    __builtin_memcpy(&b, w + sizeof(A) / 4, sizeof(B));
+}
+// Integer fields steer scalar control flow (loop bounds, uniform branches): they must live in SGPRs.  They arrive with
+// the vector copy like everything else and are moved across with v_readfirstlane (the value is lane-uniform) -- NOT
+// re-read from the scalar copy of the argument: those s_loads were issued where first used, each batch a further
+// kernarg round trip (~1 us) on the launch's critical path.
+WL_DEV int32_t uniform_i32(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 // the integer fields every task's parameter struct has (WlDriftParams / WlElevParams / WlVisualParams)
 template <class P>
-WL_DEV void keep_scalar_common(P& v, const P& s) {
+WL_DEV void uniform_scalar_common(P& v) {   // from the vector copy, once it has landed
+    v.decimation = uniform_i32(v.decimation);
+    v.max_episode_length = uniform_i32(v.max_episode_length);
+    v.action.bounding = uniform_i32(v.action.bounding);
+    v.action.no_reverse = uniform_i32(v.action.no_reverse);
+    v.action.clip_wrapper = uniform_i32(v.action.clip_wrapper);
+    v.action.map = uniform_i32(v.action.map);
+    v.vehicle.drive = uniform_i32(v.vehicle.drive);
+    v.vehicle.substeps = uniform_i32(v.vehicle.substeps);
+    v.log_episode_sums = uniform_i32(v.log_episode_sums);
+}
+template <class P>
+WL_DEV void keep_scalar_common(P& v, const P& s) {   // from the scalar copy of the argument (s_load where first used)
     v.decimation = s.decimation;
     v.max_episode_length = s.max_episode_length;
     v.action.bounding = s.action.bounding;
@@ -126,6 +184,7 @@ inline bool use_unrolled(const WlEnvBuffers* b) {   // lane form only
 }
 inline bool use_quad(const WlEnvBuffers* b) {
     if (b->lanes == 1 || b->lanes == 2) return false;
+    if (b->stride * 4 >= (1 << 24)) return false;   // Rows::lane_row_offset is a 24-bit multiply (4 M envs: never the quad regime)
     if (b->lanes == 4) return true;
     return b->n_envs <= WL_QUAD_MAX_ENVS;
 }
