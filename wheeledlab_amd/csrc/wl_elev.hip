@@ -6,8 +6,10 @@
 //      reset -> goal-command update.  State is read once / written once; sub-steps stay in VGPRs.
 //      The step kernel also writes the 13 proprioceptive values of the observation row.
 //   2. elev_scan_kernel  (block = env): the 26 x 26 yaw-aligned height rays (4 L2-resident gathers each), written with
-//      contiguous dword stores -- this launch carries ~90 % of the task's HBM bytes (2.7 KB / env).  (Staging the patch
-//      in LDS was measured 2x slower: the patch has 5.9 k cells, the rays read only 2.7 k corners.)
+//      contiguous dword stores -- this launch carries ~90 % of the task's HBM bytes (2.7 KB / env).  (Staging the env's
+//      terrain patch in LDS -- its bounding box fetched row by row with coalesced 8-byte requests, corners read from
+//      the tile -- was measured slower in every form tried: block per env 15.8 us, persistent blocks with the next
+//      env's pose prefetched 18 us, against 11.3 us for the gathers; round 2)
 #include <hip/hip_runtime.h>
 
 #include "../../include/wheeledlab_amd.h"
