@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 14
+#define WL_ABI_VERSION 15
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -340,6 +340,55 @@ int wl_ppo_minibatch(const WlMlp* actor, const WlMlp* critic, float* std, const 
  * and learning rates without a broadcast. */
 int wl_ppo_apply(const WlMlp* actor, const WlMlp* critic, float* std, int32_t mb_size, const WlPpoParams* hp,
                  const WlPpoState* state, int32_t parity, int32_t adam_step, void* stream);
+
+/* ---- PPO learner step of the WIDE agents (SURVEY section 8(f) rank 3 remainder): D-64-64-2 actor / D-64-64-1 critic with
+ * D = 689 (elevation, config/agents/mushr/rsl_rl_ppo_cfg.py of that task) or 3208 (visual); any D >= 16 works.
+ * Same algorithm, same flat parameter order (with 14 -> D) and the same ctrl slots as the drift agents' step; what
+ * differs is where the first layer runs.  With B = 131 072 rows of 689 floats a minibatch is 361 MB, so the layer-1
+ * products are streaming contractions, done on the bf16 matrix pipe with every f32 operand split into two bf16 planes
+ * (x = hi + lo, 16 mantissa bits; three products hi.hi + lo.hi + hi.lo, f32 accumulation):
+ *   wl_ppo_wide_stage      once per update: rows of `obs` in the order of `perm` -> the planes X [row][Dp] and X^T [Dp][row]
+ *   wl_ppo_wide_gradients  per minibatch: H1 = act(X W1^T + b1) for both nets (one contraction, 128 units), the rest of
+ *                          the forward / loss / backward pass as in wl_ppo_gradients (same kernel, first layer cut off),
+ *                          delta1 out as bf16 planes, dW1 = delta1^T X as a split-K contraction over the samples, and the
+ *                          reduction of all partial sums into state->grad
+ *   wl_ppo_wide_apply      clipping + adaptive-KL rule + Adam on state->grad (after an all-reduce when data-parallel)
+ *   wl_ppo_wide_minibatch  = gradients + apply.
+ * Dp = D rounded up to 64.  Minibatch starts / sizes must be multiples of 64 (rsl_rl's sizes are). */
+typedef struct WlPpoWideState {      /* caller-owned device memory; the caller zero-fills ctrl, adam_m, adam_v once */
+    uint16_t *x_hi, *x_lo;           /* [capacity][dp]  staged observations, bf16 planes */
+    uint16_t *xt_hi, *xt_lo;         /* [capacity / 64][dp][64]  their transposes, blocked by 64 rows */
+    uint16_t *w_hi, *w_lo;           /* [128][dp]       layer-1 weights of both nets (rebuilt by every step) */
+    float* h1;                       /* [mb_capacity][128]  activated layer-1 outputs of the minibatch */
+    uint16_t *dt_hi, *dt_lo;         /* [mb_capacity / 64][128][64]  delta1^T planes, blocked likewise */
+    float* dw_partials;              /* [splits][dp][128]   split-K partial sums of dW1^T */
+    float* partials;                 /* [WL_PPO_BLOCKS][WL_PPO_PARTIAL_STRIDE]  per-block sums of the narrow part */
+    float* narrow;                   /* [WL_PPO_PARTIAL_STRIDE]  their reduction (first-layer weight slots unused) */
+    float* grad;                     /* [wl_ppo_wide_num_params(D) + 3]  flat gradient + value-loss / surrogate / KL sums */
+    float *adam_m, *adam_v;          /* [wl_ppo_wide_num_params(D)] */
+    float* ctrl;                     /* [16], WL_PPO_CTRL_* */
+    float* operands;                 /* [WL_PPO_OPERAND_FLOATS], 16-byte aligned */
+    int32_t in_dim, dp;              /* D and D rounded up to 64 */
+    int32_t capacity, mb_capacity;   /* rows staged per update (multiple of 64) / largest minibatch (multiple of 64) */
+    int32_t splits;                  /* split-K factor of the dW1 contraction: multiple of 8, minibatch size / splits a multiple of 64 */
+} WlPpoWideState;
+
+/* number of parameters of the D-64-64-2 / D-64-64-1 pair incl. the 2 std entries (10437 for D = 14) */
+int32_t wl_ppo_wide_num_params(int32_t in_dim);
+
+/* rows [0, n_rows) of the staged planes <- obs[perm[k]] ([*][D] f32, row stride D).  n_rows <= capacity, multiple of 64. */
+int wl_ppo_wide_stage(const float* obs, const int32_t* perm, int32_t n_rows, const WlPpoWideState* state, void* stream);
+
+/* WlPpoBatch.obs is not read (the staged planes are); the other fields are gathered through `perm` as in wl_ppo_gradients,
+ * and staged row k must be obs[perm[k]].  state->grad = d loss / d params (no entropy term, no clipping) + the three sums;
+ * ctrl[WL_PPO_CTRL_NORM2 + parity] accumulates its squared norm. */
+int wl_ppo_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* batch, int32_t mb_start,
+                          int32_t mb_size, const WlPpoParams* hp, const WlPpoWideState* state, int32_t parity, void* stream);
+int wl_ppo_wide_apply(const WlMlp* actor, const WlMlp* critic, float* std, int32_t mb_size, const WlPpoParams* hp,
+                      const WlPpoWideState* state, int32_t parity, int32_t adam_step, void* stream);
+int wl_ppo_wide_minibatch(const WlMlp* actor, const WlMlp* critic, float* std, const WlPpoBatch* batch, int32_t mb_start,
+                          int32_t mb_size, const WlPpoParams* hp, const WlPpoWideState* state, int32_t parity, int32_t adam_step,
+                          void* stream);
 
 /*
  * Drift mdp terms only, on caller-supplied state tensors (the parity entry point: "outputs match the reference

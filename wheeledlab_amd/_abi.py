@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 14
+WL_ABI_VERSION = 15
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -160,6 +160,12 @@ class WlPpoState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("partials", "grad", "adam_m", "adam_v", "ctrl", "operands")]
 
 
+class WlPpoWideState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x_hi", "x_lo", "xt_hi", "xt_lo", "w_hi", "w_lo", "h1", "dt_hi", "dt_lo", "dw_partials",
+                                          "partials", "narrow", "grad", "adam_m", "adam_v", "ctrl", "operands")] + [
+        (n, C.c_int32) for n in ("in_dim", "dp", "capacity", "mb_capacity", "splits")]
+
+
 _P = C.POINTER
 _vp, _u64, _i32, _i64 = C.c_void_p, C.c_uint64, C.c_int32, C.c_int64
 
@@ -184,6 +190,13 @@ SIGNATURES = {
     "wl_ppo_minibatch": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _P(WlPpoBatch), _i32, _i32, _P(WlPpoParams), _P(WlPpoState), _i32,
                                    _i32, _vp]),
     "wl_ppo_apply": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _i32, _P(WlPpoParams), _P(WlPpoState), _i32, _i32, _vp]),
+    "wl_ppo_wide_num_params": (C.c_int32, [_i32]),
+    "wl_ppo_wide_stage": (C.c_int, [_vp, _vp, _i32, _P(WlPpoWideState), _vp]),
+    "wl_ppo_wide_gradients": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _P(WlPpoBatch), _i32, _i32, _P(WlPpoParams),
+                                        _P(WlPpoWideState), _i32, _vp]),
+    "wl_ppo_wide_apply": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _i32, _P(WlPpoParams), _P(WlPpoWideState), _i32, _i32, _vp]),
+    "wl_ppo_wide_minibatch": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _P(WlPpoBatch), _i32, _i32, _P(WlPpoParams),
+                                        _P(WlPpoWideState), _i32, _i32, _vp]),
     "wl_drift_mdp": (C.c_int, [_P(WlDriftParams), _i32, _i64] + [_vp] * 12),
     "wl_action_map": (C.c_int, [_P(WlActionParams), _i32, _vp, _vp, _vp, _vp, _vp]),
     "wl_drift_reset": (C.c_int, [_P(WlDriftParams), _P(WlEnvBuffers), _vp, _u64, _u64, _vp]),

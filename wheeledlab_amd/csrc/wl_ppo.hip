@@ -23,6 +23,7 @@
 #include "../../include/wheeledlab_amd.h"
 #include "wl_kernel_common.h"
 #include "wl_mlp.h"
+#include "wl_ppo_internal.h"
 
 namespace {
 
@@ -117,19 +118,7 @@ WL_DEV f32x4 get_transposed4(const float* T, int t, int g, int n) {
 }
 
 template <int ACT>
-WL_DEV void forward_hidden(const float* tab, const float xs[4], float one_g0, int lane, f32x4 h1[kTiles], f32x4 h2[kTiles]) {
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) h1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const f32x4 a = quad(tab + T_F1, s, lane);
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) h1[t] = mfma4(a[t], xs[s], h1[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h1[t][r] = mlp_act<ACT>(h1[t][r]);
+WL_DEV void forward_layer2(const float* tab, float one_g0, int lane, const f32x4 h1[kTiles], f32x4 h2[kTiles]) {
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) h2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -145,10 +134,27 @@ WL_DEV void forward_hidden(const float* tab, const float xs[4], float one_g0, in
         for (int r = 0; r < 4; ++r) h2[t][r] = mlp_act<ACT>(h2[t][r]);
 }
 
+template <int ACT>
+WL_DEV void forward_hidden(const float* tab, const float xs[4], float one_g0, int lane, f32x4 h1[kTiles], f32x4 h2[kTiles]) {
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) h1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const f32x4 a = quad(tab + T_F1, s, lane);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) h1[t] = mfma4(a[t], xs[s], h1[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[t][r] = mlp_act<ACT>(h1[t][r]);
+    forward_layer2<ACT>(tab, one_g0, lane, h1, h2);
+}
+
 // gradient accumulators of one net, in MFMA accumulator layout (rows 4 g + r, column n of each 16 x 16 tile)
 struct NetGrads {
     f32x4 w2[kTiles][kTiles];   // [out tile][in tile]
-    f32x4 w1[kTiles];           // columns = input features (14 = bias, 15 unused)
+    f32x4 w1[kTiles];           // columns = input features (14 = bias, 15 unused); wide form: this lane's partial sums of delta1 (db1)
     f32x4 w3[kTiles];           // rows 0 / 4 (actor) or 8 (critic) of the joint output layer, columns = units of tile t'
     f32x4 b2[kTiles];           // this lane's partial sums over its sample column
     WL_DEV void zero() {
@@ -163,9 +169,24 @@ struct NetGrads {
 
 // backward of one net from delta3 (B operand of the joint layer) + weight-gradient accumulation for this tile.  One LDS
 // buffer per wavefront: a matrix is written, the operands it feeds are read into registers, then the next one is written.
-template <int ACT>
+// The wide form (first layer outside this kernel, see wl_ppo_wide.hip): delta1 leaves as two bf16 planes (x = hi + lo to
+// 16 mantissa bits) in [unit][sample] order -- the shared operand of the dW1 = delta1^T . X contraction -- and db1 is summed here.
+struct WideOut {
+    uint16_t *hi, *lo;   // this net's 64 rows of the tile's 64-sample block ([unit][64] bf16), offset to the tile's 16 samples
+};
+WL_DEV uint32_t bf16_rne(float x) {   // round to nearest even (finite inputs)
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+WL_DEV void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
+    hi = bf16_rne(x);
+    lo = bf16_rne(x - __uint_as_float(hi << 16));
+}
+
+template <int ACT, bool WIDE>
 WL_DEV void backward_net(const float* tab, float* T, const f32x4 h1[kTiles], const f32x4 h2[kTiles], float d3,
-                         const float xb[4] /* obs rows in B layout: sample 4 s + g, feature n */, int lane, NetGrads& A) {
+                         const float xb[4] /* obs rows in B layout: sample 4 s + g, feature n */, int lane, NetGrads& A,
+                         const WideOut wo) {
     const int g = lane >> 4, n = lane & 15;
     // dW3 += delta3^T . H2 : A operand = delta3 of row i's output at sample 4 s + g (rows 0 / 4 / 8)
     {
@@ -235,11 +256,26 @@ WL_DEV void backward_net(const float* tab, float* T, const f32x4 h1[kTiles], con
     __builtin_amdgcn_wave_barrier();
     put_transposed(T, d1, g, n);
     __builtin_amdgcn_wave_barrier();
+    if constexpr (!WIDE) {
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) {
-        const f32x4 a4 = get_transposed4(T, t, g, n);
+        for (int t = 0; t < kTiles; ++t) {
+            const f32x4 a4 = get_transposed4(T, t, g, n);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) A.w1[t] = mfma4(a4[s], xb[s], A.w1[t]);
+            for (int s = 0; s < 4; ++s) A.w1[t] = mfma4(a4[s], xb[s], A.w1[t]);
+        }
+    } else {
+        // unit 16 t + n, samples 4 g .. 4 g + 3 (sample s sits at column 4 (s & 3) + (s >> 2)): 8 bytes per plane and lane
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            uint32_t h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_bf16(T[(16 * t + n) * kTStride + 4 * j + g], h[j], l[j]);
+            const int at = (16 * t + n) * 64 + 4 * g;
+            *reinterpret_cast<uint2*>(wo.hi + at) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            *reinterpret_cast<uint2*>(wo.lo + at) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A.w1[t][r] += d1[t][r];
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -256,6 +292,7 @@ WL_DEV float sum_over_n(float v) {
 // one wavefront adds its accumulators into the block's [G] buffer.  The caller serialises the four wavefronts (barriers
 // in between), so these are plain read-modify-writes to addresses no other lane touches: LDS float atomics from four
 // wavefronts at once made this epilogue ~40 us of the kernel.
+template <bool WIDE>
 WL_DEV void flush_net(float* acc, const NetGrads& A, int lane, bool actor) {
     const int g = lane >> 4, n = lane & 15;
     const int o_w1 = actor ? O_AW1 : O_CW1, o_b1 = actor ? O_AB1 : O_CB1, o_w2 = actor ? O_AW2 : O_CW2,
@@ -269,15 +306,21 @@ WL_DEV void flush_net(float* acc, const NetGrads& A, int lane, bool actor) {
             const int uo = 16 * t + 4 * g + r;
 #pragma unroll
             for (int u = 0; u < kTiles; ++u) o2[r][u] = acc[o_w2 + uo * kHid + 16 * u + n];
-            o1[r] = n < kIn ? acc[o_w1 + uo * kIn + n] : n == kIn ? acc[o_b1 + uo] : 0.f;
+            if constexpr (WIDE) o1[r] = n == 0 ? acc[o_b1 + uo] : 0.f;
+            else o1[r] = n < kIn ? acc[o_w1 + uo * kIn + n] : n == kIn ? acc[o_b1 + uo] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int uo = 16 * t + 4 * g + r;
 #pragma unroll
             for (int u = 0; u < kTiles; ++u) acc[o_w2 + uo * kHid + 16 * u + n] = o2[r][u] + A.w2[t][u][r];
-            if (n < kIn) acc[o_w1 + uo * kIn + n] = o1[r] + A.w1[t][r];
-            else if (n == kIn) acc[o_b1 + uo] = o1[r] + A.w1[t][r];
+            if constexpr (WIDE) {   // the w1 slots of the row stay zero: dW1 comes from the contraction kernel
+                const float b1 = sum_over_n(A.w1[t][r]);
+                if (n == 0) acc[o_b1 + uo] = o1[r] + b1;
+            } else {
+                if (n < kIn) acc[o_w1 + uo * kIn + n] = o1[r] + A.w1[t][r];
+                else if (n == kIn) acc[o_b1 + uo] = o1[r] + A.w1[t][r];
+            }
         }
     }
     float b2[kTiles][4], ob[kTiles][4];
@@ -319,10 +362,16 @@ __global__ void __launch_bounds__(256) ppo_operands_kernel(const PpoNets N, floa
 // surrogate / KL / std terms need only the actor's outputs, the value loss only the critic's, so the two never talk).
 // Each half needs ~250 registers, which puts one actor and one critic wavefront on every SIMD: while one is in its
 // activation / transpose (VALU, LDS) phases the other keeps the matrix pipe busy.
-template <int ACT>
+// WIDE: the first layer lives outside (wl_ppo_wide.hip): `wio.h1` holds the activated layer-1 outputs of the minibatch,
+// [position in the minibatch][actor units 0..63 | critic units 64..127], and delta1 leaves through `wio.dt_*`.
+struct WideIo {
+    const float* h1;
+    uint16_t *dt_hi, *dt_lo;   // bf16 planes, blocked [position / 64][128 units][position % 64]
+};
+template <int ACT, bool WIDE>
 __global__ void __launch_bounds__(64 * kPpoWaves) ppo_grad_kernel(const PpoNets N, const float* __restrict__ operands,
                                                                   const WlPpoBatch bt, const int mb_start, const int mb_size,
-                                                                  const PpoHyper hp, float* __restrict__ partials) {
+                                                                  const PpoHyper hp, float* __restrict__ partials, const WideIo wio) {
     constexpr int kThreads = 64 * kPpoWaves;
     extern __shared__ float lds[];
     float* tab = lds;
@@ -358,24 +407,30 @@ __global__ void __launch_bounds__(64 * kPpoWaves) ppo_grad_kernel(const PpoNets 
         const int k_n = tile * 16 + n;                       // position in the minibatch of "my" sample (column n)
         const bool valid = k_n < mb_size;
         const int smp = bt.perm[mb_start + (valid ? k_n : 0)];
-        // observation of sample n in forward-B layout (feature 4 s + g) ...
-        float xs[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int f = 4 * s + g;
-            xs[s] = f == kIn ? 1.f : f < kIn ? bt.obs[(int64_t)smp * kIn + f] : 0.f;
-        }
-        // ... and of sample 4 s + g in weight-gradient-B layout (feature n)
-        float xb[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k_s = tile * 16 + 4 * s + g;
-            const int smp_s = bt.perm[mb_start + (k_s < mb_size ? k_s : 0)];
-            xb[s] = (k_s >= mb_size) ? 0.f : n == kIn ? 1.f : n < kIn ? bt.obs[(int64_t)smp_s * kIn + n] : 0.f;
-        }
-
         f32x4 h1[kTiles], h2[kTiles];
-        forward_hidden<ACT>(net_tab, xs, one_g0, lane, h1, h2);
+        float xb[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (WIDE) {   // units 16 t + 4 g .. + 3 of sample n: the accumulator layout, 16 bytes per tile
+            const float* row = wio.h1 + (int64_t)(valid ? k_n : 0) * (2 * kHid) + (actor_wave ? 0 : kHid) + 4 * g;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) h1[t] = *reinterpret_cast<const f32x4*>(row + 16 * t);
+            forward_layer2<ACT>(net_tab, one_g0, lane, h1, h2);
+        } else {
+            // observation of sample n in forward-B layout (feature 4 s + g) ...
+            float xs[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int f = 4 * s + g;
+                xs[s] = f == kIn ? 1.f : f < kIn ? bt.obs[(int64_t)smp * kIn + f] : 0.f;
+            }
+            // ... and of sample 4 s + g in weight-gradient-B layout (feature n)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k_s = tile * 16 + 4 * s + g;
+                const int smp_s = bt.perm[mb_start + (k_s < mb_size ? k_s : 0)];
+                xb[s] = (k_s >= mb_size) ? 0.f : n == kIn ? 1.f : n < kIn ? bt.obs[(int64_t)smp_s * kIn + n] : 0.f;
+            }
+            forward_hidden<ACT>(net_tab, xs, one_g0, lane, h1, h2);
+        }
         // this net's rows of the joint output layer: k-steps 0..15 (actor units) or 16..31 (critic units), then the biases
         f32x4 out = {0.f, 0.f, 0.f, 0.f}, out_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -428,7 +483,12 @@ __global__ void __launch_bounds__(64 * kPpoWaves) ppo_grad_kernel(const PpoNets 
                 s_vloss += vloss;
             }
         }
-        backward_net<ACT>(net_tab, T, h1, h2, d3, xb, lane, GN);
+        WideOut wo{nullptr, nullptr};
+        if constexpr (WIDE) {
+            const int64_t at = ((int64_t)(tile >> 2) * (2 * kHid) + (actor_wave ? 0 : kHid)) * 64 + (tile & 3) * 16;
+            wo = WideOut{wio.dt_hi + at, wio.dt_lo + at};
+        }
+        backward_net<ACT, WIDE>(net_tab, T, h1, h2, d3, xb, lane, GN, wo);
     }
 
     // ---- block reduction: the operand tables become the [G + stats] accumulator ------------------------------------------
@@ -443,7 +503,7 @@ __global__ void __launch_bounds__(64 * kPpoWaves) ppo_grad_kernel(const PpoNets 
     s_kl = sum_over_n(s_kl);
     for (int w = 0; w < 4; ++w) {      // one actor and one critic wavefront at a time (their parameter ranges are disjoint)
         if ((wave & 3) == w) {
-            flush_net(acc, GN, lane, actor_wave);
+            flush_net<WIDE>(acc, GN, lane, actor_wave);
             if (n == 0) {
                 if (actor_wave && g < 2) {
                     acc[O_STD + g] += d_sigma;
@@ -498,15 +558,23 @@ __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float* __restrict
     }
 }
 
-WL_DEV float* param_ptr(const PpoNets& N, float* std, int i) {
-    if (i < O_AW1) return std + i;
-    const bool a = i < O_CW1;
+// flat parameter order for an input width `in` (the constants above are in = 14)
+struct PpoLayout {
+    int in, o_aw1, o_cw1, G;
+};
+inline PpoLayout ppo_layout(int in) {
+    const int per_net = kHid * in + kHid + kHid * kHid + kHid;
+    return PpoLayout{in, 2, 2 + per_net + 2 * kHid + 2, 2 + 2 * per_net + 3 * kHid + 3};
+}
+WL_DEV float* param_ptr(const PpoNets& N, float* std, int i, const PpoLayout& L) {
+    if (i < L.o_aw1) return std + i;
+    const bool a = i < L.o_cw1;
     const WlMlp& net = a ? N.actor : N.critic;
-    const int j = i - (a ? O_AW1 : O_CW1);
+    const int j = i - (a ? L.o_aw1 : L.o_cw1);
     const int nw3 = a ? 2 * kHid : kHid;
-    if (j < kHid * kIn) return const_cast<float*>(net.w1) + j;
-    if (j < kHid * kIn + kHid) return const_cast<float*>(net.b1) + (j - kHid * kIn);
-    const int k = j - kHid * kIn - kHid;
+    if (j < kHid * L.in) return const_cast<float*>(net.w1) + j;
+    if (j < kHid * L.in + kHid) return const_cast<float*>(net.b1) + (j - kHid * L.in);
+    const int k = j - kHid * L.in - kHid;
     if (k < kHid * kHid) return const_cast<float*>(net.w2) + k;
     if (k < kHid * kHid + kHid) return const_cast<float*>(net.b2) + (k - kHid * kHid);
     const int m = k - kHid * kHid - kHid;
@@ -518,7 +586,8 @@ WL_DEV float* param_ptr(const PpoNets& N, float* std, int i) {
 __global__ void __launch_bounds__(256) ppo_apply_kernel(const PpoNets N, float* std, const WlPpoParams hp, const float inv_batch,
                                                         const float* __restrict__ grad, float* __restrict__ adam_m,
                                                         float* __restrict__ adam_v, float* __restrict__ ctrl, const int parity,
-                                                        const int step /* 1-based */) {
+                                                        const int step /* 1-based */, const PpoLayout L) {
+    const int G = L.G, S_VLOSS = L.G, S_SURR = L.G + 1, S_KL = L.G + 2;   // the statistics follow the parameters
     const int i = blockIdx.x * 256 + threadIdx.x;
     const float lr_old = ctrl[WL_PPO_CTRL_LR + parity];
     float lr = lr_old;
@@ -544,7 +613,7 @@ __global__ void __launch_bounds__(256) ppo_apply_kernel(const PpoNets N, float* 
         adam_v[i] = v;
         const float bc1 = 1.f - powf(hp.beta1, (float)step), bc2 = 1.f - powf(hp.beta2, (float)step);
         const float denom = sqrtf(v) / sqrtf(bc2) + hp.eps;
-        float* p = param_ptr(N, std, i);
+        float* p = param_ptr(N, std, i, L);
         *p -= (lr / bc1) * (m / denom);
     }
     if (i == 0) {   // hand the learning rate to the next call, clear its norm accumulator, book the statistics
@@ -591,8 +660,11 @@ int check_ppo(const WlMlp* actor, const WlMlp* critic, const float* std, const W
     return WL_OK;
 }
 
+// operands -> gradient kernel -> reduction of the per-block rows into `grad` ([kRow], narrow layout) + squared norm + std snapshot.
+// wio == nullptr: the drift agents' form (first layer in-kernel); else the wide form (wl_ppo_wide.hip).
 int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
-                const WlPpoParams* hp, const WlPpoState* st, int parity, hipStream_t stream) {
+                const WlPpoParams* hp, float* partials, float* operands, float* grad, float* norm2, float* std_snapshot,
+                const WideIo* wio, hipStream_t stream) {
     const PpoNets N{*actor, *critic, std};
     const PpoHyper h{hp->clip, hp->value_loss_coef, 1.f / (float)mb_size, hp->use_clipped_value_loss};
     const int n_tiles = (mb_size + 15) / 16;
@@ -600,22 +672,55 @@ int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const
     const size_t lds_bytes = (size_t)kLdsFloats * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ppo_grad_kernel<WL_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void*)ppo_grad_kernel<WL_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        for (const void* f : {(const void*)ppo_grad_kernel<WL_ACT_ELU, false>, (const void*)ppo_grad_kernel<WL_ACT_RELU, false>,
+                              (const void*)ppo_grad_kernel<WL_ACT_ELU, true>, (const void*)ppo_grad_kernel<WL_ACT_RELU, true>})
+            (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
     clear_error();
-    ppo_operands_kernel<<<(kTabFloats + 255) / 256, 256, 0, stream>>>(N, st->operands);
-    if (actor->activation == WL_ACT_ELU)
-        ppo_grad_kernel<WL_ACT_ELU><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, st->operands, *bt, mb_start, mb_size, h, st->partials);
-    else
-        ppo_grad_kernel<WL_ACT_RELU><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, st->operands, *bt, mb_start, mb_size, h, st->partials);
-    ppo_reduce_kernel<<<(kRow + 63) / 64, 256, 0, stream>>>(st->partials, blocks, st->grad, st->ctrl + WL_PPO_CTRL_NORM2 + parity, std,
-                                                             st->ctrl + WL_PPO_CTRL_STD);
+    ppo_operands_kernel<<<(kTabFloats + 255) / 256, 256, 0, stream>>>(N, operands);
+    const bool elu = actor->activation == WL_ACT_ELU;
+    const WideIo none{nullptr, nullptr, nullptr};
+    if (!wio) {
+        if (elu) ppo_grad_kernel<WL_ACT_ELU, false><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, operands, *bt, mb_start, mb_size, h, partials, none);
+        else ppo_grad_kernel<WL_ACT_RELU, false><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, operands, *bt, mb_start, mb_size, h, partials, none);
+    } else {
+        if (elu) ppo_grad_kernel<WL_ACT_ELU, true><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, operands, *bt, mb_start, mb_size, h, partials, *wio);
+        else ppo_grad_kernel<WL_ACT_RELU, true><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, operands, *bt, mb_start, mb_size, h, partials, *wio);
+    }
+    ppo_reduce_kernel<<<(kRow + 63) / 64, 256, 0, stream>>>(partials, blocks, grad, norm2, std, std_snapshot);
+    return launch_status();
+}
+int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
+                const WlPpoParams* hp, const WlPpoState* st, int parity, hipStream_t stream) {
+    return launch_grad(actor, critic, std, bt, mb_start, mb_size, hp, st->partials, st->operands, st->grad,
+                       st->ctrl + WL_PPO_CTRL_NORM2 + parity, st->ctrl + WL_PPO_CTRL_STD, nullptr, stream);
+}
+
+int launch_apply(const WlMlp* actor, const WlMlp* critic, float* std, int in_dim, int mb_size, const WlPpoParams* hp,
+                 const float* grad, float* adam_m, float* adam_v, float* ctrl, int parity, int adam_step, hipStream_t stream) {
+    const PpoNets N{*actor, *critic, std};
+    const PpoLayout L = ppo_layout(in_dim);
+    ppo_apply_kernel<<<(L.G + 255) / 256, 256, 0, stream>>>(N, std, *hp, 1.f / (float)mb_size, grad, adam_m, adam_v, ctrl, parity,
+                                                             adam_step, L);
     return launch_status();
 }
 
 }  // namespace
+
+namespace wl_internal {   // wl_ppo_internal.h: what wl_ppo_wide.hip drives
+int ppo_tail_wide(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
+                  const WlPpoParams* hp, float* partials, float* operands, float* narrow_grad, float* norm2, float* std_snapshot,
+                  const float* h1, uint16_t* dt_hi, uint16_t* dt_lo, hipStream_t stream) {
+    const WideIo wio{h1, dt_hi, dt_lo};
+    return launch_grad(actor, critic, std, bt, mb_start, mb_size, hp, partials, operands, narrow_grad, norm2, std_snapshot, &wio, stream);
+}
+int ppo_apply_any(const WlMlp* actor, const WlMlp* critic, float* std, int in_dim, int mb_size, const WlPpoParams* hp,
+                  const float* grad, float* adam_m, float* adam_v, float* ctrl, int parity, int adam_step, hipStream_t stream) {
+    clear_error();
+    return launch_apply(actor, critic, std, in_dim, mb_size, hp, grad, adam_m, adam_v, ctrl, parity, adam_step, stream);
+}
+}  // namespace wl_internal
 
 extern "C" {
 
@@ -644,10 +749,8 @@ int wl_ppo_minibatch(const WlMlp* actor, const WlMlp* critic, float* std, const 
     if (!hp || !state->adam_m || !state->adam_v || (parity != 0 && parity != 1) || adam_step < 1) return WL_EINVAL;
     rc = launch_grad(actor, critic, std, batch, mb_start, mb_size, hp, state, parity, (hipStream_t)stream);
     if (rc != WL_OK) return rc;
-    const PpoNets N{*actor, *critic, std};
-    ppo_apply_kernel<<<(G + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, std, *hp, 1.f / (float)mb_size, state->grad, state->adam_m,
-                                                                       state->adam_v, state->ctrl, parity, adam_step);
-    return launch_status();
+    return launch_apply(actor, critic, std, kIn, mb_size, hp, state->grad, state->adam_m, state->adam_v, state->ctrl, parity, adam_step,
+                        (hipStream_t)stream);
 }
 
 int wl_ppo_apply(const WlMlp* actor, const WlMlp* critic, float* std, int32_t mb_size, const WlPpoParams* hp,
@@ -660,10 +763,8 @@ int wl_ppo_apply(const WlMlp* actor, const WlMlp* critic, float* std, int32_t mb
         (parity != 0 && parity != 1) || adam_step < 1)
         return WL_EINVAL;
     clear_error();
-    const PpoNets N{*actor, *critic, std};
-    ppo_apply_kernel<<<(G + 255) / 256, 256, 0, (hipStream_t)stream>>>(N, std, *hp, 1.f / (float)mb_size, state->grad, state->adam_m,
-                                                                       state->adam_v, state->ctrl, parity, adam_step);
-    return launch_status();
+    return launch_apply(actor, critic, std, kIn, mb_size, hp, state->grad, state->adam_m, state->adam_v, state->ctrl, parity, adam_step,
+                        (hipStream_t)stream);
 }
 
 }  // extern "C"

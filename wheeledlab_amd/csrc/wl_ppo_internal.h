@@ -1,0 +1,22 @@
+// wl_ppo_internal.h -- pieces of wl_ppo.hip that wl_ppo_wide.hip drives (library-internal C++ linkage, not part of the C ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/wheeledlab_amd.h"
+
+namespace wl_internal {
+
+// The gradient kernel of wl_ppo.hip with the first layer cut off: reads the activated layer-1 outputs `h1`
+// ([position in the minibatch][actor 64 | critic 64]), writes delta1^T as bf16 planes `dt_hi / dt_lo` (blocked [position / 64][128 units][position % 64]) and reduces
+// every other gradient (db1 included) + the three loss sums into `narrow_grad` ([WL_PPO_PARTIAL_STRIDE], the drift agents'
+// row layout with its first-layer weight slots left at zero).  Adds the squared norm of that row to *norm2 and copies
+// std[0..1] to std_snapshot.
+int ppo_tail_wide(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
+                  const WlPpoParams* hp, float* partials, float* operands, float* narrow_grad, float* norm2, float* std_snapshot,
+                  const float* h1, uint16_t* dt_hi, uint16_t* dt_lo, hipStream_t stream);
+
+// entropy term + clipping + adaptive-KL rule + Adam on a flat gradient row of input width `in_dim` (statistics behind it)
+int ppo_apply_any(const WlMlp* actor, const WlMlp* critic, float* std, int in_dim, int mb_size, const WlPpoParams* hp,
+                  const float* grad, float* adam_m, float* adam_v, float* ctrl, int parity, int adam_step, hipStream_t stream);
+
+}  // namespace wl_internal

@@ -179,9 +179,13 @@ class PPO:
         # the drift agents' nets on a GPU: the whole minibatch step runs in the HIP library (FusedPpoStep below)
         can_fuse = (dev.type == "cuda" and actor_critic.fusable() and actor_critic.actor[0].in_features == 14
                     and actor_critic.actor[4].out_features == 2)
-        if fused_update and not can_fuse:
-            raise ValueError("fused_update needs the 14-64-64-2 / 14-64-64-1 elu / relu nets on a GPU")
-        self.fused_update = can_fuse if fused_update is None else bool(fused_update)
+        # the wide agents (elevation 689, visual 3208 inputs): first layer as bf16-split streaming contractions (FusedWidePpoStep)
+        self._wide = (not can_fuse and dev.type == "cuda" and actor_critic.act_fusable()
+                      and actor_critic.actor[0].in_features >= 16
+                      and actor_critic.actor[0].in_features == actor_critic.critic[0].in_features)
+        if fused_update and not (can_fuse or self._wide):
+            raise ValueError("fused_update needs D-64-64-2 / D-64-64-1 elu / relu nets (D = 14 or D >= 16) on a GPU")
+        self.fused_update = (can_fuse or self._wide) if fused_update is None else bool(fused_update)
         self._fused = None
         # data-parallel learner: ranks hold identical parameters (same seed), step their own env shards, and average the
         # gradient (and the KL statistic of the adaptive rule) once per minibatch step
@@ -259,15 +263,19 @@ class PPO:
         batch = K * n
         mb = batch // self.num_mini_batches
         stats = torch.zeros(3, device=flat["obs"].device)
-        if self.fused_update:
+        fused = self.fused_update and (not self._wide or FusedWidePpoStep.shapes_ok(self.num_mini_batches * mb, mb))
+        if fused:
             if self._fused is None:
-                self._fused = FusedPpoStep(self.actor_critic, self)
+                self._fused = (FusedWidePpoStep(self.actor_critic, self, self.num_mini_batches * mb, mb) if self._wide
+                               else FusedPpoStep(self.actor_critic, self))
                 self._fused.state_from_optimizer(self.optimizer, float(self._lr))
             fz = self._fused
             fz.ctrl[4:7] = 0.0
             flat = {k: v.contiguous() for k, v in flat.items()}
             # rsl_rl's mini_batch_generator draws ONE permutation per update and walks it in every epoch
             perm = torch.randperm(self.num_mini_batches * mb, device=flat["obs"].device, generator=generator).to(torch.int32)
+            if self._wide:      # the observation block in the order of `perm`, as bf16 planes: once per update
+                fz.stage(flat["obs"], perm)
             for _ in range(self.num_learning_epochs):
                 for i in range(self.num_mini_batches):    # the kernel gathers through `perm`: no shuffled copies
                     fz.minibatch(flat, perm, i * mb, mb, sigma_old, split=self.world > 1)
@@ -582,3 +590,101 @@ class FusedPpoStep:
             off += k
         self.adam_step = step
         self.ctrl[self._A.PPO_CTRL_LR:self._A.PPO_CTRL_LR + 2] = float(lr)
+
+
+class FusedWidePpoStep(FusedPpoStep):
+    """The same step for the wide agents (D = 689 elevation / 3208 visual): csrc/wl_ppo_wide.hip.  The observation block is
+    staged once per update as bf16 planes in the order of the update's permutation (`stage`), the first layer of both nets
+    and its weight gradient are streaming contractions on the bf16 matrix pipe (operands split hi + lo: 16 mantissa bits,
+    f32 accumulation), everything behind it is the drift agents' kernel."""
+
+    @staticmethod
+    def shapes_ok(rows: int, mb: int) -> bool:
+        return rows % 64 == 0 and mb % 512 == 0
+
+    @staticmethod
+    def pick_splits(dp: int, mb: int) -> int:
+        row_blocks = (dp + 127) // 128
+        s = max(8, min(64, (512 // row_blocks) // 8 * 8))
+        while s > 8 and mb % (64 * s):
+            s -= 8
+        return s
+
+    def __init__(self, actor_critic: ActorCritic, ppo: "PPO", capacity: int, mb_capacity: int):
+        import ctypes as C
+
+        from .. import _abi as A
+        D_in = actor_critic.actor[0].in_features
+        if not actor_critic.act_fusable() or D_in < 16 or actor_critic.critic[0].in_features != D_in:
+            raise ValueError("the wide fused PPO step needs D-64-64-2 / D-64-64-1 elu / relu MLPs with D >= 16")
+        if not self.shapes_ok(capacity, mb_capacity):
+            raise ValueError("rows per update must be a multiple of 64 and the minibatch a multiple of 512")
+        self._C, self._A, self.lib = C, A, A.load()
+        self.ac, self.view = actor_critic, actor_critic.fused()
+        dev = actor_critic.std.device
+        self.dev = dev
+        self.in_dim, self.dp = D_in, (D_in + 63) // 64 * 64
+        self.capacity, self.mb_capacity = int(capacity), int(mb_capacity)
+        self.splits = self.pick_splits(self.dp, self.mb_capacity)
+        self.G = int(self.lib.wl_ppo_wide_num_params(D_in))
+        assert self.G == sum(p.numel() for p in actor_critic.parameters())
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        h = lambda *s: torch.zeros(*s, dtype=torch.int16, device=dev)
+        dp = self.dp
+        self.x_hi, self.x_lo = h(capacity, dp), h(capacity, dp)
+        self.xt_hi, self.xt_lo = h(capacity // 64, dp, 64), h(capacity // 64, dp, 64)      # X^T blocked by 64 rows
+        self.w_hi, self.w_lo = h(128, dp), h(128, dp)
+        self.h1, self.dt_hi, self.dt_lo = z(mb_capacity, 128), h(mb_capacity // 64, 128, 64), h(mb_capacity // 64, 128, 64)
+        self.dw_partials = z(self.splits, dp, 128)
+        self.partials, self.narrow = z(A.PPO_BLOCKS, A.PPO_PARTIAL_STRIDE), z(A.PPO_PARTIAL_STRIDE)
+        self.grad = z(self.G + 3)
+        self.adam_m, self.adam_v, self.ctrl = z(self.G), z(self.G), z(16)
+        self.operands = z(A.PPO_OPERAND_FLOATS)
+        self.ctrl[A.PPO_CTRL_LR:A.PPO_CTRL_LR + 2] = float(ppo.learning_rate)
+        ptr = lambda t: t.data_ptr()
+        self.state = A.WlPpoWideState(ptr(self.x_hi), ptr(self.x_lo), ptr(self.xt_hi), ptr(self.xt_lo), ptr(self.w_hi), ptr(self.w_lo),
+                                      ptr(self.h1), ptr(self.dt_hi), ptr(self.dt_lo), ptr(self.dw_partials), ptr(self.partials),
+                                      ptr(self.narrow), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.ctrl),
+                                      ptr(self.operands), self.in_dim, self.dp, self.capacity, self.mb_capacity, self.splits)
+        adaptive = int(ppo.desired_kl is not None and ppo.schedule == "adaptive")
+        self.hp = A.WlPpoParams(ppo.clip_param, ppo.value_loss_coef, ppo.entropy_coef, float(ppo.desired_kl or 0.0),
+                                ppo.max_grad_norm, 0.9, 0.999, 1e-8, 1e-5, 1e-2, int(ppo.use_clipped_value_loss), adaptive)
+        self.parity, self.adam_step = 0, 0
+        self._actor, self._critic = self.view.actor.struct(), self.view.critic.struct()
+
+    def stage(self, obs, perm):
+        """rows perm[k] of `obs` ([B, D] f32) -> staged row k (bf16 planes X and X^T)"""
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.in_dim and obs.device == self.dev
+        assert perm.dtype == torch.int32 and perm.is_contiguous() and perm.numel() <= self.capacity
+        self._keep_stage = (obs, perm)
+        self._A.check(self.lib.wl_ppo_wide_stage(obs.data_ptr(), perm.data_ptr(), int(perm.numel()), self._C.byref(self.state),
+                                                 self._stream()), "wl_ppo_wide_stage")
+
+    def gradients(self, flat, perm, mb_start, mb_size, sigma_old):
+        C, A = self._C, self._A
+        bt = self._batch(flat, perm, sigma_old)
+        self.ctrl[A.PPO_CTRL_NORM2:A.PPO_CTRL_NORM2 + 2] = 0.0
+        A.check(self.lib.wl_ppo_wide_gradients(C.byref(self._actor), C.byref(self._critic), self.ac.std.data_ptr(), C.byref(bt),
+                                               int(mb_start), int(mb_size), C.byref(self.hp), C.byref(self.state), self.parity,
+                                               self._stream()), "wl_ppo_wide_gradients")
+        return self.grad
+
+    def minibatch(self, flat, perm, mb_start, mb_size, sigma_old, split: bool = False):
+        C, A = self._C, self._A
+        bt = self._batch(flat, perm, sigma_old)
+        self.adam_step += 1
+        if split:
+            self.ctrl[A.PPO_CTRL_NORM2 + self.parity] = 0.0
+            A.check(self.lib.wl_ppo_wide_gradients(C.byref(self._actor), C.byref(self._critic), self.ac.std.data_ptr(), C.byref(bt),
+                                                   int(mb_start), int(mb_size), C.byref(self.hp), C.byref(self.state), self.parity,
+                                                   self._stream()), "wl_ppo_wide_gradients")
+            D.average_(self.grad)
+            self.ctrl[A.PPO_CTRL_NORM2 + self.parity] = self.grad[:self.G].square().sum()
+            A.check(self.lib.wl_ppo_wide_apply(C.byref(self._actor), C.byref(self._critic), self.ac.std.data_ptr(), int(mb_size),
+                                               C.byref(self.hp), C.byref(self.state), self.parity, self.adam_step, self._stream()),
+                    "wl_ppo_wide_apply")
+        else:
+            A.check(self.lib.wl_ppo_wide_minibatch(C.byref(self._actor), C.byref(self._critic), self.ac.std.data_ptr(), C.byref(bt),
+                                                   int(mb_start), int(mb_size), C.byref(self.hp), C.byref(self.state), self.parity,
+                                                   self.adam_step, self._stream()), "wl_ppo_wide_minibatch")
+        self.parity ^= 1
