@@ -370,7 +370,7 @@ typedef struct WlPpoWideState {      /* caller-owned device memory; the caller z
     float* operands;                 /* [WL_PPO_OPERAND_FLOATS], 16-byte aligned */
     int32_t in_dim, dp;              /* D and D rounded up to 64 */
     int32_t capacity, mb_capacity;   /* rows staged per update (multiple of 64) / largest minibatch (multiple of 64) */
-    int32_t splits;                  /* split-K factor of the dW1 contraction: multiple of 8, minibatch size / splits a multiple of 64 */
+    int32_t splits;                  /* rows of dw_partials: the dW1 contraction is split over at most this many blocks per 128 features */
 } WlPpoWideState;
 
 /* number of parameters of the D-64-64-2 / D-64-64-1 pair incl. the 2 std entries (10437 for D = 14) */

@@ -82,6 +82,7 @@ def test_staging_splits_and_transposes_the_permuted_rows():
     (689, 12288, 4096, 8192, "relu"),       # a minibatch that starts inside the staged block
     (3208, 4096, 1024, 2048, "elu"),        # the visual agent (dp = 3264: 25.5 row blocks of the dW1 contraction)
     (33, 1024, 512, 512, "elu"),            # a narrow "wide" net: one K chunk, a single partly-filled row block
+    (689, 8192, 1600, 6400, "elu"),         # 100 K chunks at 2 per split: 50 of the 85 partial-sum rows, grid padded to 56
 ])
 def test_wide_gradients_match_autograd(D, B, mb_start, mb_size, activation):
     from wheeledlab_amd.rl.ppo import FusedWidePpoStep, PPO

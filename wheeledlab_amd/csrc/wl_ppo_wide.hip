@@ -107,7 +107,7 @@ struct SkinnyArgs {
     const float *bias_a, *bias_c;  // epilogue: + bias (units 0..63 / 64..127), then the activation
     int rows_b, row_blocks;
     int64_t b_row, b_chunk, a_row, a_chunk;   // element (r, k) of an operand sits at r * row + (k >> 6) * chunk + (k & 63)
-    int k_per_split, splits;       // k range of split s: [s kps, (s + 1) kps), kps a multiple of 64
+    int n_chunks, chunks_per_split, splits;   // split s contracts the 64-wide K chunks [s cps, min((s + 1) cps, n_chunks))
 };
 
 constexpr int kChunk = 64;                       // K elements per LDS stage
@@ -124,9 +124,10 @@ __global__ void __launch_bounds__(256, 2) skinny_kernel(const SkinnyArgs a) {
     if (a.splits > 1) {   // the blocks of one split share the A stream: keep them on one XCD (blockIdx round-robins over 8)
         sp = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * a.row_blocks));
         rb = (blockIdx.x >> 3) % a.row_blocks;
+        if (sp >= a.splits) return;   // the grid is padded to a multiple of 8 splits
     }
-    const int n_chunks = a.k_per_split / kChunk;
-    const int64_t c0 = (int64_t)sp * n_chunks;   // first K chunk of this split
+    const int64_t c0 = (int64_t)sp * a.chunks_per_split;   // first K chunk of this split
+    const int n_chunks = min(a.chunks_per_split, a.n_chunks - (int)c0);
 
     // streamed operand: fragments of rows row0 + 16 q + n, k = 32 j + 8 g .. + 7 of the chunk
     const int row0 = rb * 128 + 32 * wave;
@@ -307,7 +308,7 @@ int check_wide(const WlMlp* actor, const WlMlp* critic, const WlPpoWideState* st
         actor->activation != critic->activation)
         return WL_EINVAL;
     if (st->in_dim < 16 || st->dp != (st->in_dim + 63) / 64 * 64 || st->capacity <= 0 || (st->capacity & 63) || st->mb_capacity <= 0 ||
-        (st->mb_capacity & 63) || st->splits < 8 || (st->splits & 7))
+        (st->mb_capacity & 63) || st->splits < 1)
         return WL_EINVAL;
     if (!st->x_hi || !st->x_lo || !st->xt_hi || !st->xt_lo || !st->w_hi || !st->w_lo || !st->h1 || !st->dt_hi || !st->dt_lo ||
         !st->dw_partials || !st->partials || !st->narrow || !st->grad || !st->ctrl || !st->operands || ((uintptr_t)st->operands & 15u))
@@ -337,7 +338,7 @@ int launch_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* 
         a.row_blocks = (mb_size + 127) / 128;
         a.b_row = a.a_row = dp;        // row-major [row][dp]
         a.b_chunk = a.a_chunk = kChunk;
-        a.k_per_split = dp;
+        a.n_chunks = a.chunks_per_split = dp / kChunk;
         a.splits = 1;
         if (actor->activation == WL_ACT_ELU) skinny_kernel<WL_ACT_ELU + 1><<<a.row_blocks, 256, 0, stream>>>(a);
         else skinny_kernel<WL_ACT_RELU + 1><<<a.row_blocks, 256, 0, stream>>>(a);
@@ -347,7 +348,8 @@ int launch_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* 
     int rc = wl_internal::ppo_tail_wide(actor, critic, std, bt, mb_start, mb_size, hp, st->partials, st->operands, st->narrow, norm2,
                                         st->ctrl + WL_PPO_CTRL_STD, st->h1, st->dt_hi, st->dt_lo, stream);
     if (rc != WL_OK) return rc;
-    {   // dW1^T = X^T delta1: rows = features, K = the minibatch's samples, split over `splits` blocks per row block
+    int splits_used = 1;
+    {   // dW1^T = X^T delta1: rows = features, K = the minibatch's samples, split over <= `splits` blocks per row block
         SkinnyArgs a{};
         a.b_hi = st->xt_hi + (int64_t)mb_start * dp;   // blocked [sample / 64][dp][64]: chunk mb_start / 64
         a.b_lo = st->xt_lo + (int64_t)mb_start * dp;
@@ -360,13 +362,14 @@ int launch_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* 
         a.b_chunk = (int64_t)dp * kChunk;
         a.a_row = kChunk;                               // delta1^T likewise: [sample / 64][128][64]
         a.a_chunk = (int64_t)kUnits * kChunk;
-        a.k_per_split = mb_size / st->splits;
-        a.splits = st->splits;
-        skinny_kernel<0><<<a.row_blocks * a.splits, 256, 0, stream>>>(a);
+        a.n_chunks = mb_size / kChunk;
+        a.chunks_per_split = (a.n_chunks + st->splits - 1) / st->splits;
+        a.splits = splits_used = (a.n_chunks + a.chunks_per_split - 1) / a.chunks_per_split;   // <= st->splits, none empty
+        skinny_kernel<0><<<a.row_blocks * ((a.splits + 7) / 8 * 8), 256, 0, stream>>>(a);
     }
     const WideLayout L = wide_layout(D);
     const int nb_w1 = dp * kUnits / 256, nb_rest = (kRowN + 255) / 256;
-    ppo_wide_scatter_kernel<<<nb_w1 + nb_rest, 256, 0, stream>>>(st->dw_partials, st->splits, dp, st->narrow, L, nb_w1, st->grad, norm2);
+    ppo_wide_scatter_kernel<<<nb_w1 + nb_rest, 256, 0, stream>>>(st->dw_partials, splits_used, dp, st->narrow, L, nb_w1, st->grad, norm2);
     return launch_status();
 }
 
@@ -375,7 +378,7 @@ int check_batch(const float* std, const WlPpoBatch* bt, int mb_start, int mb_siz
         !bt->sigma_old)
         return WL_EINVAL;
     if (mb_start < 0 || mb_size <= 0 || (mb_start & 63) || (mb_size & 63) || mb_size > st->mb_capacity ||
-        mb_start + mb_size > st->capacity || mb_size % (st->splits * 64) != 0)
+        mb_start + mb_size > st->capacity)
         return WL_EINVAL;
     return WL_OK;
 }

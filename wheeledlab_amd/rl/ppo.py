@@ -600,15 +600,18 @@ class FusedWidePpoStep(FusedPpoStep):
 
     @staticmethod
     def shapes_ok(rows: int, mb: int) -> bool:
-        return rows % 64 == 0 and mb % 512 == 0
+        return rows % 64 == 0 and mb % 64 == 0
 
     @staticmethod
     def pick_splits(dp: int, mb: int) -> int:
-        row_blocks = (dp + 127) // 128
-        s = max(8, min(64, (512 // row_blocks) // 8 * 8))
-        while s > 8 and mb % (64 * s):
-            s -= 8
-        return s
+        """split-K factor of the dW1 contraction: the smallest power of two that puts >= 768 blocks (1.5 rounds of the chip's
+        512 slots) on the launch -- measured on the elevation agent (6 row blocks x 2048 K chunks): 64 splits 122 us, 85
+        (unequal shares) 139 us, 128 107 us, 256 112 us; the visual agent (26 x 512) is flat at 122-128 us from 8 to 64"""
+        row_blocks, chunks = (dp + 127) // 128, max(1, mb // 64)
+        s = 1
+        while row_blocks * s < 768 and s < chunks:
+            s *= 2
+        return min(s, chunks)
 
     def __init__(self, actor_critic: ActorCritic, ppo: "PPO", capacity: int, mb_capacity: int):
         import ctypes as C
@@ -618,14 +621,14 @@ class FusedWidePpoStep(FusedPpoStep):
         if not actor_critic.act_fusable() or D_in < 16 or actor_critic.critic[0].in_features != D_in:
             raise ValueError("the wide fused PPO step needs D-64-64-2 / D-64-64-1 elu / relu MLPs with D >= 16")
         if not self.shapes_ok(capacity, mb_capacity):
-            raise ValueError("rows per update must be a multiple of 64 and the minibatch a multiple of 512")
+            raise ValueError("rows per update and the minibatch size must be multiples of 64")
         self._C, self._A, self.lib = C, A, A.load()
         self.ac, self.view = actor_critic, actor_critic.fused()
         dev = actor_critic.std.device
         self.dev = dev
         self.in_dim, self.dp = D_in, (D_in + 63) // 64 * 64
         self.capacity, self.mb_capacity = int(capacity), int(mb_capacity)
-        self.splits = self.pick_splits(self.dp, self.mb_capacity)
+        self.splits = int(os.environ.get("WL_WIDE_SPLITS", 0)) or self.pick_splits(self.dp, self.mb_capacity)
         self.G = int(self.lib.wl_ppo_wide_num_params(D_in))
         assert self.G == sum(p.numel() for p in actor_critic.parameters())
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
