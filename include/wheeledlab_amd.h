@@ -271,6 +271,26 @@ int wl_actor_critic_act(const WlMlp* actor, const WlMlp* critic, const float* st
                         int64_t obs_stride, float* actions, float* mu, float* log_prob, float* values, int32_t env_offset,
                         uint64_t seed, uint64_t step, int32_t deterministic, int32_t nets, void* stream);
 
+/* The same policy step with the first layer on the bf16 matrix pipe: the observation rows are split into two bf16 planes
+ * in registers (x = hi + lo, 16 mantissa bits; products hi.hi + lo.hi + hi.lo, f32 accumulation -- the arithmetic of the
+ * wide PPO step below, so a stored log-prob and the learner's first evaluation of it agree), the layer-1 weights of both
+ * nets come as planes through LDS and feed 128 rows per fetch.  Two launches.  Results differ from wl_actor_critic_act by
+ * the split's rounding (~2^-17 relative in the layer-1 pre-activations). */
+typedef struct WlActScratch {        /* caller-owned device memory */
+    uint16_t *w_hi, *w_lo;           /* [128][dp] layer-1 weights of actor (units 0..63) and critic (64..127) as bf16 planes */
+    float* partials;                 /* [splits][rows_capacity][128] split-K partial sums of layer 1 */
+    int32_t dp;                      /* in_dim rounded up to 64 */
+    int32_t splits;                  /* the contraction is split over at most this many blocks per 128 rows */
+    int32_t rows_capacity;
+    int32_t reserved;
+} WlActScratch;
+/* (re)build the weight planes: once after every change of the layer-1 weights */
+int wl_actor_critic_planes(const WlMlp* actor, const WlMlp* critic, const WlActScratch* scratch, void* stream);
+int wl_actor_critic_act_planes(const WlMlp* actor, const WlMlp* critic, const float* std, int32_t n_rows, const float* obs,
+                               int64_t obs_stride, float* actions, float* mu, float* log_prob, float* values, int32_t env_offset,
+                               uint64_t seed, uint64_t step, int32_t deterministic, int32_t nets, const WlActScratch* scratch,
+                               void* stream);
+
 /* ---- PPO learner step of the drift agents ("on-device PPO for the 64-64 MLP") ------------
  * One minibatch step of rsl_rl's PPO.update (modified_rsl_rl_runner.py:104-109; rsl_rl_ppo_cfg.py:18-31) for the
  * 14-64-64-2 actor / 14-64-64-1 critic pair: forward, clipped surrogate + clipped value loss + entropy bonus, backward,
@@ -342,12 +362,12 @@ int wl_ppo_apply(const WlMlp* actor, const WlMlp* critic, float* std, int32_t mb
                  const WlPpoState* state, int32_t parity, int32_t adam_step, void* stream);
 
 /* ---- PPO learner step of the WIDE agents (SURVEY section 8(f) rank 3 remainder): D-64-64-2 actor / D-64-64-1 critic with
- * D = 689 (elevation, config/agents/mushr/rsl_rl_ppo_cfg.py of that task) or 3208 (visual); any D >= 16 works.
+ * D = 689 (elevation, config/agents/mushr/rsl_rl_ppo_cfg.py of that task) or 3208 (visual); any D >= 64 works.
  * Same algorithm, same flat parameter order (with 14 -> D) and the same ctrl slots as the drift agents' step; what
  * differs is where the first layer runs.  With B = 131 072 rows of 689 floats a minibatch is 361 MB, so the layer-1
  * products are streaming contractions, done on the bf16 matrix pipe with every f32 operand split into two bf16 planes
  * (x = hi + lo, 16 mantissa bits; three products hi.hi + lo.hi + hi.lo, f32 accumulation):
- *   wl_ppo_wide_stage      once per update: rows of `obs` in the order of `perm` -> the planes X [row][Dp] and X^T [Dp][row]
+ *   wl_ppo_wide_stage      once per update: rows of `obs` in the order of `perm` -> the planes of X^T (the dW1 operand)
  *   wl_ppo_wide_gradients  per minibatch: H1 = act(X W1^T + b1) for both nets (one contraction, 128 units), the rest of
  *                          the forward / loss / backward pass as in wl_ppo_gradients (same kernel, first layer cut off),
  *                          delta1 out as bf16 planes, dW1 = delta1^T X as a split-K contraction over the samples, and the
@@ -356,8 +376,7 @@ int wl_ppo_apply(const WlMlp* actor, const WlMlp* critic, float* std, int32_t mb
  *   wl_ppo_wide_minibatch  = gradients + apply.
  * Dp = D rounded up to 64.  Minibatch starts / sizes must be multiples of 64 (rsl_rl's sizes are). */
 typedef struct WlPpoWideState {      /* caller-owned device memory; the caller zero-fills ctrl, adam_m, adam_v once */
-    uint16_t *x_hi, *x_lo;           /* [capacity][dp]  staged observations, bf16 planes */
-    uint16_t *xt_hi, *xt_lo;         /* [capacity / 64][dp][64]  their transposes, blocked by 64 rows */
+    uint16_t *xt_hi, *xt_lo;         /* [capacity / 64][dp][64]  the staged observations TRANSPOSED, bf16 planes, blocked by 64 rows */
     uint16_t *w_hi, *w_lo;           /* [128][dp]       layer-1 weights of both nets (rebuilt by every step) */
     float* h1;                       /* [mb_capacity][128]  activated layer-1 outputs of the minibatch */
     uint16_t *dt_hi, *dt_lo;         /* [mb_capacity / 64][128][64]  delta1^T planes, blocked likewise */
@@ -379,8 +398,8 @@ int32_t wl_ppo_wide_num_params(int32_t in_dim);
 /* rows [0, n_rows) of the staged planes <- obs[perm[k]] ([*][D] f32, row stride D).  n_rows <= capacity, multiple of 64. */
 int wl_ppo_wide_stage(const float* obs, const int32_t* perm, int32_t n_rows, const WlPpoWideState* state, void* stream);
 
-/* WlPpoBatch.obs is not read (the staged planes are); the other fields are gathered through `perm` as in wl_ppo_gradients,
- * and staged row k must be obs[perm[k]].  state->grad = d loss / d params (no entropy term, no clipping) + the three sums;
+/* All fields of the batch are gathered through `perm` as in wl_ppo_gradients (the forward contraction splits the f32
+ * observation rows in registers); staged row k must be obs[perm[k]] (the dW1 contraction reads the staged X^T).  state->grad = d loss / d params (no entropy term, no clipping) + the three sums;
  * ctrl[WL_PPO_CTRL_NORM2 + parity] accumulates its squared norm. */
 int wl_ppo_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* batch, int32_t mb_start,
                           int32_t mb_size, const WlPpoParams* hp, const WlPpoWideState* state, int32_t parity, void* stream);

@@ -58,7 +58,7 @@ def _bf16_planes(hi, lo):
 
 
 def test_staging_splits_and_transposes_the_permuted_rows():
-    """staged row k = obs[perm[k]] as hi + lo bf16 planes (relative error <= 2^-16), X^T its exact transpose, padding zero"""
+    """staged column k of X^T = obs[perm[k]] as hi + lo bf16 planes (relative error <= 2^-16), blocked by 64 rows, padding zero"""
     from wheeledlab_amd.rl.ppo import FusedWidePpoStep, PPO
     B, D = 2048, 689
     ac, flat, _ = _problem(B, D)
@@ -67,21 +67,20 @@ def test_staging_splits_and_transposes_the_permuted_rows():
     perm = torch.randperm(B, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).to(torch.int32)
     fz.stage(flat["obs"], perm)
     torch.cuda.synchronize()
-    x = _bf16_planes(fz.x_hi, fz.x_lo)
+    xt = _bf16_planes(fz.xt_hi, fz.xt_lo)                              # [row / 64][feature][row % 64]
+    x = xt.transpose(1, 2).reshape(B, fz.dp)
     want = flat["obs"][perm.long()]
     err = (x[:, :D] - want).abs()
     assert float((err / want.abs().clamp_min(1e-30)).max()) <= 2.0 ** -16
     assert float(x[:, D:].abs().max()) == 0.0
-    # X^T is blocked by 64 rows: [row / 64][feature][row % 64]
-    for xt, x in ((fz.xt_hi, fz.x_hi), (fz.xt_lo, fz.x_lo)):
-        assert torch.equal(xt.view(B // 64, fz.dp, 64), x.view(B // 64, 64, fz.dp).transpose(1, 2))
 
 
 @pytest.mark.parametrize("D,B,mb_start,mb_size,activation", [
     (689, 16384, 0, 16384, "elu"),          # the elevation agent
     (689, 12288, 4096, 8192, "relu"),       # a minibatch that starts inside the staged block
     (3208, 4096, 1024, 2048, "elu"),        # the visual agent (dp = 3264: 25.5 row blocks of the dW1 contraction)
-    (33, 1024, 512, 512, "elu"),            # a narrow "wide" net: one K chunk, a single partly-filled row block
+    (100, 1024, 512, 512, "elu"),           # a narrow "wide" net: two overlapping K chunks, a single partly-filled row block
+    (128, 2048, 1024, 1024, "relu"),        # D a multiple of 64: no overlapped chunk
     (689, 8192, 1600, 6400, "elu"),         # 100 K chunks at 2 per split: 50 of the 85 partial-sum rows, grid padded to 56
 ])
 def test_wide_gradients_match_autograd(D, B, mb_start, mb_size, activation):

@@ -12,7 +12,7 @@ from wheeledlab_amd.rl.ppo import ActorCritic
 dev = "cuda:0"
 res = {}
 for D, act in ((689, "relu"), (3208, "elu")):
-    for n in (512, 4096, 16384):
+    for n in (512, 1024, 4096, 16384):
         ac = ActorCritic(D, D, 2, activation=act).to(dev)
         view = ac.fused()
         obs = torch.randn(n, D, device=dev)
@@ -20,7 +20,12 @@ for D, act in ((689, "relu"), (3208, "elu")):
         logp, val = torch.empty(n, device=dev), torch.empty(n, device=dev)
 
         def fused(k):
+            view.planes = False
             view.act(obs, a, mu, logp, val, 1, k)
+
+        def planes(k):
+            view.planes = True
+            view.act(obs, a, mu, logp, val, 1, k, planes_fresh=k > 0)
 
         def eager(k):
             with torch.inference_mode():
@@ -28,7 +33,7 @@ for D, act in ((689, "relu"), (3208, "elu")):
                 ac.get_actions_log_prob(x)
                 ac.evaluate(obs)
 
-        for name, fn in (("kernel", fused),) + (() if os.environ.get("WL_LIB") else (("torch", eager),)):
+        for name, fn in (("kernel", fused), ("planes", planes)) + (() if os.environ.get("WL_LIB") else (("torch", eager),)):
             for k in range(20):
                 fn(k)
             torch.cuda.synchronize()

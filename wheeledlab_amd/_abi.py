@@ -160,8 +160,13 @@ class WlPpoState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("partials", "grad", "adam_m", "adam_v", "ctrl", "operands")]
 
 
+class WlActScratch(C.Structure):
+    _fields_ = [("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("partials", C.c_void_p), ("dp", C.c_int32), ("splits", C.c_int32),
+                ("rows_capacity", C.c_int32), ("reserved", C.c_int32)]
+
+
 class WlPpoWideState(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("x_hi", "x_lo", "xt_hi", "xt_lo", "w_hi", "w_lo", "h1", "dt_hi", "dt_lo", "dw_partials",
+    _fields_ = [(n, C.c_void_p) for n in ("xt_hi", "xt_lo", "w_hi", "w_lo", "h1", "dt_hi", "dt_lo", "dw_partials",
                                           "partials", "narrow", "grad", "adam_m", "adam_v", "ctrl", "operands")] + [
         (n, C.c_int32) for n in ("in_dim", "dp", "capacity", "mb_capacity", "splits")]
 
@@ -184,6 +189,9 @@ SIGNATURES = {
                                           _u64, _u64, _vp]),
     "wl_actor_critic_act": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _u64, _u64, _i32, _i32,
                                       _vp]),
+    "wl_actor_critic_planes": (C.c_int, [_P(WlMlp), _P(WlMlp), _P(WlActScratch), _vp]),
+    "wl_actor_critic_act_planes": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _u64, _u64, _i32,
+                                             _i32, _P(WlActScratch), _vp]),
     "wl_gae": (C.c_int, [_i32, _i32, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp]),
     "wl_ppo_gradients": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _P(WlPpoBatch), _i32, _i32, _P(WlPpoParams), _P(WlPpoState), _i32,
                                    _vp]),

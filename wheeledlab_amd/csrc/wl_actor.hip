@@ -16,6 +16,7 @@
 #include "../../include/wheeledlab_amd.h"
 #include "wl_kernel_common.h"
 #include "wl_mlp.h"
+#include "wl_ppo_internal.h"
 #include "wl_rng.h"
 
 namespace {
@@ -229,6 +230,69 @@ __global__ void __launch_bounds__(64 * KS) actor_critic_act_kernel(const WlMlp a
     }
 }
 
+// The policy step with the first layer on the bf16 matrix pipe (wl_actor_critic_act_planes): layer 1 of both nets is the
+// split-K contraction of wl_ppo_wide.hip (observation rows split into bf16 planes in registers, weights as planes through
+// LDS -- every weight operand feeds 128 rows instead of 16-64, which is what bound the kernel above); this kernel sums
+// the partial products, adds the bias and finishes the net as above.  One wavefront per 16-row tile and net.
+template <int ACT>
+__global__ void __launch_bounds__(64) act_tail_kernel(const WlMlp actor, const WlMlp critic, const float* __restrict__ std,
+                                                      const int n_rows, const float* __restrict__ partials, const int splits,
+                                                      float* __restrict__ actions, float* __restrict__ mu_out,
+                                                      float* __restrict__ log_prob, float* __restrict__ values, const int env_offset,
+                                                      const uint64_t seed, const uint64_t step, const int deterministic,
+                                                      const int first_net) {
+    const int lane = threadIdx.x, m = lane & 15, g = lane >> 4;
+    const int which = (int)blockIdx.y + first_net;
+    const WlMlp& net = which == 0 ? actor : critic;
+    const int r_out = (int)blockIdx.x * 16 + m, row = min(r_out, n_rows - 1);
+    // accumulator layout of layer 1: units 16 t + 4 g .. + 3 of row m -- 16 bytes per tile and split
+    const float* src = partials + (int64_t)row * (2 * kMlpHidden) + which * kMlpHidden + 4 * g;
+    const int64_t plane = (int64_t)n_rows * (2 * kMlpHidden);
+    f32x4 h[kMlpTiles];
+#pragma unroll
+    for (int t = 0; t < kMlpTiles; ++t) h[t] = *reinterpret_cast<const f32x4*>(net.b1 + 16 * t + 4 * g);
+    // eight splits' loads in flight per round (rolled, every split was a dependent memory round trip: 20 us at 51 splits)
+    int s = 0;
+    for (; s + 8 <= splits; s += 8) {
+        f32x4 v[8][kMlpTiles];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int t = 0; t < kMlpTiles; ++t) v[i][t] = *reinterpret_cast<const f32x4*>(src + (s + i) * plane + 16 * t);
+#pragma unroll
+        for (int t = 0; t < kMlpTiles; ++t)
+            h[t] += ((v[0][t] + v[1][t]) + (v[2][t] + v[3][t])) + ((v[4][t] + v[5][t]) + (v[6][t] + v[7][t]));
+    }
+    {
+        f32x4 v[8][kMlpTiles];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int t = 0; t < kMlpTiles; ++t)
+                v[i][t] = s + i < splits ? *reinterpret_cast<const f32x4*>(src + (s + i) * plane + 16 * t) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < kMlpTiles; ++t)
+            h[t] += ((v[0][t] + v[1][t]) + (v[2][t] + v[3][t])) + ((v[4][t] + v[5][t]) + (v[6][t] + v[7][t]));
+    }
+    MlpTail W;
+    load_tail(net, lane, W);
+    float z0 = 0.f, z1 = 0.f;
+    if (which == 0 && !deterministic) {
+        const F4 u = philox_uniform4((uint32_t)(env_offset + r_out), step, WL_RS_POLICY, seed);
+        box_muller(u.x, u.y, z0, z1);
+    }
+    const f32x4 out = eval_tail<ACT>(W, h, lane);
+    if (g != 0 || r_out >= n_rows) return;
+    if (which == 1) {
+        values[r_out] = out[0];
+        return;
+    }
+    const float std0 = std[0], std1 = std[1];
+    reinterpret_cast<float2*>(actions)[r_out] = make_float2(fmaf(std0, z0, out[0]), fmaf(std1, z1, out[1]));
+    reinterpret_cast<float2*>(mu_out)[r_out] = make_float2(out[0], out[1]);
+    log_prob[r_out] = fmaf(-0.5f, fmaf(z0, z0, z1 * z1), -(log_fast(std0) + log_fast(std1)) - kLog2PiA);
+}
+
 int check_wide(const WlMlp* net, int out_dim) {
     if (!net || !net->w1 || !net->b1 || !net->w2 || !net->b2 || !net->w3 || !net->b3) return WL_EINVAL;
     if (net->hidden != kMlpHidden || net->in_dim < 1 || net->in_dim > (1 << 20) || net->out_dim != out_dim) return WL_EINVAL;
@@ -294,6 +358,47 @@ int wl_actor_critic_act(const WlMlp* actor, const WlMlp* critic, const float* st
         else launch_act<WL_ACT_RELU, 1>(WL_ACT_ARGS);
     }
 #undef WL_ACT_ARGS
+    return launch_status();
+}
+
+int wl_actor_critic_planes(const WlMlp* actor, const WlMlp* critic, const WlActScratch* sc, void* stream) {
+    int rc = check_wide(actor, 2);
+    if (rc == WL_OK) rc = check_wide(critic, 1);
+    if (rc != WL_OK) return rc;
+    if (!sc || !sc->w_hi || !sc->w_lo || actor->in_dim != critic->in_dim || actor->in_dim < 64 || sc->dp != (actor->in_dim + 63) / 64 * 64)
+        return WL_EINVAL;
+    if (((uintptr_t)sc->w_hi & 15u) || ((uintptr_t)sc->w_lo & 15u)) return WL_EALIGN;
+    return wl_internal::mlp_weight_planes(actor, critic, sc->dp, sc->w_hi, sc->w_lo, (hipStream_t)stream);
+}
+
+int wl_actor_critic_act_planes(const WlMlp* actor, const WlMlp* critic, const float* std, int32_t n_rows, const float* obs,
+                               int64_t obs_stride, float* actions, float* mu, float* log_prob, float* values, int32_t env_offset,
+                               uint64_t seed, uint64_t step, int32_t deterministic, int32_t nets, const WlActScratch* sc,
+                               void* stream) {
+    int rc = check_wide(actor, 2);
+    if (rc == WL_OK) rc = check_wide(critic, 1);
+    if (rc != WL_OK) return rc;
+    if (actor->in_dim != critic->in_dim || actor->activation != critic->activation) return WL_EINVAL;
+    if (nets < 1 || nets > 3 || n_rows <= 0 || !obs || obs_stride < actor->in_dim) return WL_EINVAL;
+    if ((nets & 1) && (!std || !actions || !mu || !log_prob)) return WL_EINVAL;
+    if ((nets & 2) && !values) return WL_EINVAL;
+    if ((nets & 1) && (((uintptr_t)actions & 7u) || ((uintptr_t)mu & 7u))) return WL_EALIGN;
+    if ((uintptr_t)obs & 3u) return WL_EALIGN;
+    if (!sc || !sc->w_hi || !sc->w_lo || !sc->partials || actor->in_dim < 64 || sc->dp != (actor->in_dim + 63) / 64 * 64 || sc->splits < 1 ||
+        n_rows > sc->rows_capacity)
+        return WL_EINVAL;
+    if (((uintptr_t)sc->w_hi & 15u) || ((uintptr_t)sc->w_lo & 15u) || ((uintptr_t)sc->partials & 15u)) return WL_EALIGN;
+    const int splits = wl_internal::layer1_partials(obs, obs_stride, n_rows, actor->in_dim, sc->dp, sc->w_hi, sc->w_lo, sc->splits,
+                                                    sc->partials, (hipStream_t)stream);
+    if (splits < 0) return splits;
+    const dim3 grid((n_rows + 15) / 16, nets == 3 ? 2 : 1);
+    const int first_net = nets == 2 ? 1 : 0;
+    if (actor->activation == WL_ACT_ELU)
+        act_tail_kernel<WL_ACT_ELU><<<grid, 64, 0, (hipStream_t)stream>>>(*actor, *critic, std, n_rows, sc->partials, splits, actions, mu,
+                                                                          log_prob, values, env_offset, seed, step, deterministic, first_net);
+    else
+        act_tail_kernel<WL_ACT_RELU><<<grid, 64, 0, (hipStream_t)stream>>>(*actor, *critic, std, n_rows, sc->partials, splits, actions, mu,
+                                                                           log_prob, values, env_offset, seed, step, deterministic, first_net);
     return launch_status();
 }
 

@@ -19,4 +19,13 @@ int ppo_tail_wide(const WlMlp* actor, const WlMlp* critic, const float* std, con
 int ppo_apply_any(const WlMlp* actor, const WlMlp* critic, float* std, int in_dim, int mb_size, const WlPpoParams* hp,
                   const float* grad, float* adam_m, float* adam_v, float* ctrl, int parity, int adam_step, hipStream_t stream);
 
+// wl_ppo_wide.hip: layer-1 weights of both nets -> bf16 planes [128][dp] (dp = in_dim rounded up to 64, padding zero)
+int mlp_weight_planes(const WlMlp* actor, const WlMlp* critic, int dp, uint16_t* w_hi, uint16_t* w_lo, hipStream_t stream);
+
+// wl_ppo_wide.hip: out[s][r][u] = sum over the 64-wide K chunks of split s of x[r][k] . W[u][k] (both nets: 128 units), x = f32 rows
+// ([n_rows][x_stride], in_dim valid features) split into bf16 planes in registers, W = planes from mlp_weight_planes.
+// Returns the number of splits used (<= max_splits, partial sums [splits][n_rows][128]) or a negative WL_E* code.
+int layer1_partials(const float* x, int64_t x_stride, int n_rows, int in_dim, int dp, const uint16_t* w_hi, const uint16_t* w_lo,
+                    int max_splits, float* out, hipStream_t stream);
+
 }  // namespace wl_internal

@@ -22,11 +22,14 @@
 //   * a block = 4 wavefronts x 32 rows, two blocks per CU; per 64-wide chunk and wavefront 96 MFMAs, 32 ds_read_b128, 16
 //     fragment loads.
 // X^T exists because the MFMA wants both operands contiguous along the contraction index, and dW1 contracts over samples:
-// `wl_ppo_wide_stage` writes X and X^T (through an LDS tile) once per update, in the order of the update's permutation, so
-// that the minibatches of all its epochs are contiguous row / column ranges.
+// `wl_ppo_wide_stage` writes its planes (through an LDS tile) once per update, in the order of the update's permutation,
+// so that the minibatches of all its epochs are contiguous column ranges.  The forward contraction needs no staged copy:
+// it reads the f32 observation rows through the permutation and splits them in registers (v_cvt_pk_bf16_f32, 5
+// instructions per pair, hidden under the MFMAs) -- the same bytes as reading two planes.
 #include <hip/hip_runtime.h>
 
 #include "../../include/wheeledlab_amd.h"
+#include "wl_bf16.h"
 #include "wl_kernel_common.h"
 #include "wl_ppo_internal.h"
 
@@ -40,22 +43,15 @@ constexpr int kHid = 64, kUnits = 2 * kHid;      // both nets side by side
 constexpr int kRowN = WL_PPO_PARTIAL_STRIDE;     // narrow row (drift layout, in = 14)
 constexpr int kInN = 14;
 
-WL_DEV uint32_t bf16_rne(float x) {   // round to nearest even (finite inputs)
-    const uint32_t u = __float_as_uint(x);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-WL_DEV void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
-    hi = bf16_rne(x);
-    lo = bf16_rne(x - __uint_as_float(hi << 16));
-}
+typedef float wl_f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (rows of odd length)
 
-// ---- staging: obs rows in permuted order -> X planes [row][dp] and X^T planes, blocked [row / 64][dp][row % 64] ----------------
-// (a 64-row K chunk of X^T is then one contiguous 2 * 64 * dp-byte run instead of dp pieces a row of `capacity` apart)
+// ---- staging: obs rows in permuted order -> X^T planes, blocked [row / 64][dp][row % 64] ------------------------------------
+// (a 64-row K chunk of X^T is then one contiguous 2 * 64 * dp-byte run instead of dp pieces a row of `capacity` apart).
+// X itself is not staged: the forward contraction reads the f32 rows through `perm` and splits them in registers.
 // block = 64 rows x 64 features; thread (ty, tx) = (i >> 4, i & 15): rows 16 m + ty, features 4 tx .. 4 tx + 3
 __global__ void __launch_bounds__(256) ppo_wide_stage_kernel(const float* __restrict__ obs, const int32_t* __restrict__ perm,
-                                                             const int in_dim, const int dp, const int capacity,
-                                                             uint16_t* __restrict__ x_hi, uint16_t* __restrict__ x_lo,
-                                                             uint16_t* __restrict__ xt_hi, uint16_t* __restrict__ xt_lo) {
+                                                             const int in_dim, const int dp, uint16_t* __restrict__ xt_hi,
+                                                             uint16_t* __restrict__ xt_lo) {
     __shared__ uint16_t t_hi[64][68], t_lo[64][68];   // [feature][row]; 136-byte rows: 8-byte reads stay aligned
     const int r0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
@@ -63,17 +59,21 @@ __global__ void __launch_bounds__(256) ppo_wide_stage_kernel(const float* __rest
     for (int m = 0; m < 4; ++m) {
         const int r = 16 * m + ty;
         const float* src = obs + (int64_t)perm[r0 + r] * in_dim;
-        uint32_t h[4], l[4];
+        float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int f = f0 + 4 * tx + j;
-            split_bf16(f < in_dim ? src[f] : 0.f, h[j], l[j]);
-            t_hi[4 * tx + j][r] = (uint16_t)h[j];
-            t_lo[4 * tx + j][r] = (uint16_t)l[j];
+            v[j] = f < in_dim ? src[f] : 0.f;
         }
-        const int64_t at = (int64_t)(r0 + r) * dp + f0 + 4 * tx;
-        *reinterpret_cast<uint2*>(x_hi + at) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-        *reinterpret_cast<uint2*>(x_lo + at) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            uint32_t h, l;
+            split_bf16_pair(v[j], v[j + 1], h, l);
+            t_hi[4 * tx + j][r] = (uint16_t)h;
+            t_hi[4 * tx + j + 1][r] = (uint16_t)(h >> 16);
+            t_lo[4 * tx + j][r] = (uint16_t)l;
+            t_lo[4 * tx + j + 1][r] = (uint16_t)(l >> 16);
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -85,27 +85,35 @@ __global__ void __launch_bounds__(256) ppo_wide_stage_kernel(const float* __rest
     }
 }
 
-// layer-1 weights of both nets -> planes [128][dp] (features >= D: zero)
+// layer-1 weights of both nets -> planes [128][dp], dp = D rounded up to 64.  K chunk c holds features 64 c .. 64 c + 63,
+// except the LAST chunk of a D that is not a multiple of 64: it holds the row's last 64 features, D - 64 .. D - 1, with
+// the ones the previous chunk already covers set to zero.  The f32 operand of the contraction is then read at
+// min(64 c, D - 64): every load stays inside its row, at full width, with no padding of the observation rows.
+WL_DEV float chunked_weight(const float* __restrict__ w, int in_dim, int dp, int pos) {
+    const int c = pos >> 6, last = dp / 64 - 1;
+    if (c < last || in_dim == dp) return w[pos];
+    const int f = in_dim - 64 + (pos & 63);
+    return f < 64 * last ? 0.f : w[f];
+}
 __global__ void __launch_bounds__(256) ppo_wide_weights_kernel(const float* __restrict__ w1_actor, const float* __restrict__ w1_critic,
-                                                               const int in_dim, const int dp, uint16_t* __restrict__ w_hi,
-                                                               uint16_t* __restrict__ w_lo) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= kUnits * dp) return;
-    const int u = i / dp, f = i - u * dp;
+                                                               const int in_dim, const int dp, uint32_t* __restrict__ w_hi,
+                                                               uint32_t* __restrict__ w_lo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // pair of positions
+    if (i >= kUnits * dp / 2) return;
+    const int u = i / (dp / 2), pos = 2 * (i - u * (dp / 2));
     const float* w = u < kHid ? w1_actor + (int64_t)u * in_dim : w1_critic + (int64_t)(u - kHid) * in_dim;
-    uint32_t h, l;
-    split_bf16(f < in_dim ? w[f] : 0.f, h, l);
-    w_hi[i] = (uint16_t)h;
-    w_lo[i] = (uint16_t)l;
+    split_bf16_pair(chunked_weight(w, in_dim, dp, pos), chunked_weight(w, in_dim, dp, pos + 1), w_hi[i], w_lo[i]);
 }
 
 // ---- the contraction ----------------------------------------------------------------------------------------------------------
 struct SkinnyArgs {
-    const uint16_t *b_hi, *b_lo;   // streamed operand, rows_b rows, already offset to the first k of the contraction
+    const uint16_t *b_hi, *b_lo;   // streamed operand as bf16 planes, rows_b rows, already offset to the first k of the contraction
+    const float* b_f32;            // ... or (BF32) as f32 rows [*][b_row] of b_k >= 64 features, split in registers
+    const int32_t* b_perm;         // BF32: row r of the operand is row b_perm[r] of b_f32 (NULL: r)
     const uint16_t *a_hi, *a_lo;   // shared operand, 128 rows, likewise
     float* out;                    // [splits][rows_b][128]
     const float *bias_a, *bias_c;  // epilogue: + bias (units 0..63 / 64..127), then the activation
-    int rows_b, row_blocks;
+    int rows_b, row_blocks, b_k;
     int64_t b_row, b_chunk, a_row, a_chunk;   // element (r, k) of an operand sits at r * row + (k >> 6) * chunk + (k & 63)
     int n_chunks, chunks_per_split, splits;   // split s contracts the 64-wide K chunks [s cps, min((s + 1) cps, n_chunks))
 };
@@ -116,7 +124,13 @@ WL_DEV int piece_offset(int row, int piece) { return row * (kChunk * 2) + ((piec
 
 WL_DEV float act_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
-template <int EPI /* 0: raw partial sums, WL_ACT_ELU / WL_ACT_RELU + 1: bias + activation */>
+// the streamed operand's registers for one 64-wide chunk: per (row tile q, k-step j) either the two planes' fragments
+// (8 bf16 each) or the 8 raw floats they are split from
+struct BRegs {
+    u32x4 x[2][2], y[2][2];   // planes: x = hi, y = lo; BF32: x = floats 0..3, y = floats 4..7
+};
+
+template <int EPI /* 0: raw partial sums, WL_ACT_ELU / WL_ACT_RELU + 1: bias + activation */, bool BF32>
 __global__ void __launch_bounds__(256, 2) skinny_kernel(const SkinnyArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * kPlaneBytes];   // [buffer][hi / lo][kPlaneBytes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, n = lane & 15;
@@ -132,12 +146,22 @@ __global__ void __launch_bounds__(256, 2) skinny_kernel(const SkinnyArgs a) {
     // streamed operand: fragments of rows row0 + 16 q + n, k = 32 j + 8 g .. + 7 of the chunk
     const int row0 = rb * 128 + 32 * wave;
     const uint16_t *pbh[2], *pbl[2];
+    const float* pbf[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int r = min(row0 + 16 * q + n, a.rows_b - 1);
-        pbh[q] = a.b_hi + r * a.b_row + c0 * a.b_chunk + 8 * g;
-        pbl[q] = a.b_lo + r * a.b_row + c0 * a.b_chunk + 8 * g;
+        if constexpr (BF32) {
+            const int64_t src = a.b_perm ? a.b_perm[r] : r;
+            pbf[q] = a.b_f32 + src * a.b_row + 8 * g;
+            pbh[q] = pbl[q] = nullptr;
+        } else {
+            pbh[q] = a.b_hi + r * a.b_row + c0 * a.b_chunk + 8 * g;
+            pbl[q] = a.b_lo + r * a.b_row + c0 * a.b_chunk + 8 * g;
+            pbf[q] = nullptr;
+        }
     }
+    // BF32: chunk c of a row starts at feature min(64 c, b_k - 64) (the weight planes' last chunk is laid out to match)
+    const int k_last = a.b_k - kChunk;
     // shared operand: thread -> piece (tid & 7) of rows (tid >> 3) + 32 m
     const int sp_piece = tid & 7, sp_row = tid >> 3;
     const uint16_t* pah = a.a_hi + sp_row * a.a_row + c0 * a.a_chunk + 8 * sp_piece;
@@ -150,11 +174,21 @@ __global__ void __launch_bounds__(256, 2) skinny_kernel(const SkinnyArgs a) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 bh[2][2], bl[2][2], nbh[2][2], nbl[2][2], sh[4], sl[4];
-#define WL_LOAD_B(H, L, C)                                                                  \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j) { \
-        H[q][j] = *reinterpret_cast<const u32x4*>(pbh[q] + (C) * a.b_chunk + 32 * j);           \
-        L[q][j] = *reinterpret_cast<const u32x4*>(pbl[q] + (C) * a.b_chunk + 32 * j);           \
+    BRegs cur, nxt;
+    u32x4 sh[4], sl[4];
+#define WL_LOAD_B(R, C)                                                                                     \
+    if constexpr (!BF32) {                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j) {       \
+            R.x[q][j] = *reinterpret_cast<const u32x4*>(pbh[q] + (C) * a.b_chunk + 32 * j);                 \
+            R.y[q][j] = *reinterpret_cast<const u32x4*>(pbl[q] + (C) * a.b_chunk + 32 * j);                 \
+        }                                                                                                   \
+    } else {                                                                                                \
+        const int k = min(((int)c0 + (C)) * kChunk, k_last);                                                \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) _Pragma("unroll") for (int j = 0; j < 2; ++j) {       \
+            const float* src = pbf[q] + k + 32 * j;                                                         \
+            R.x[q][j] = __builtin_bit_cast(u32x4, *reinterpret_cast<const wl_f4u*>(src));                   \
+            R.y[q][j] = __builtin_bit_cast(u32x4, *reinterpret_cast<const wl_f4u*>(src + 4));               \
+        }                                                                                                   \
     }
 #define WL_LOAD_A(C)                                                                        \
     _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                         \
@@ -169,43 +203,57 @@ __global__ void __launch_bounds__(256, 2) skinny_kernel(const SkinnyArgs a) {
     }
 
     WL_LOAD_A(0)
-    WL_LOAD_B(bh, bl, 0)
+    WL_LOAD_B(cur, 0)
     WL_STORE_A(0)
     // all prologue loads have landed before the loop: otherwise the wait-count pass, merging the loop entry with the back
-    // edge, protects the first use of `bh` inside the loop with a vmcnt that also drains the prefetch just issued
+    // edge, protects the first use of `cur` inside the loop with a vmcnt that also drains the prefetch just issued
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     for (int c = 0; c < n_chunks; ++c) {
         const bool more = c + 1 < n_chunks;
         if (more) {
             WL_LOAD_A(c + 1)
-            WL_LOAD_B(nbh, nbl, c + 1)
+            WL_LOAD_B(nxt, c + 1)
         }
         __syncthreads();   // buffer c & 1 is complete; everybody is done with buffer (c + 1) & 1
         const unsigned char* ph = lds + (c & 1) * 2 * kPlaneBytes;
         const unsigned char* pl = ph + kPlaneBytes;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            u32x4 bh[2], bl[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if constexpr (BF32) {   // 8 floats -> the two planes' fragments
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        uint32_t h0, l0, h1, l1;
+                        split_bf16_pair(__uint_as_float(cur.x[q][j][2 * i]), __uint_as_float(cur.x[q][j][2 * i + 1]), h0, l0);
+                        split_bf16_pair(__uint_as_float(cur.y[q][j][2 * i]), __uint_as_float(cur.y[q][j][2 * i + 1]), h1, l1);
+                        bh[q][i] = h0;
+                        bl[q][i] = l0;
+                        bh[q][2 + i] = h1;
+                        bl[q][2 + i] = l1;
+                    }
+                } else {
+                    bh[q] = cur.x[q][j];
+                    bl[q] = cur.y[q][j];
+                }
+            }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int off = piece_offset(16 * t + n, 4 * j + g);
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ph + off);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(pl + off);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, bh[q][j]), acc[q][t], 0, 0, 0);
+                for (int q = 0; q < 2; ++q) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8, bh[q]), acc[q][t], 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, bl[q][j]), acc[q][t], 0, 0, 0);
+                for (int q = 0; q < 2; ++q) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, bl[q]), acc[q][t], 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, bh[q][j]), acc[q][t], 0, 0, 0);
+                for (int q = 0; q < 2; ++q) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8, bh[q]), acc[q][t], 0, 0, 0);
             }
+        }
         if (more) {
             WL_STORE_A((c + 1) & 1)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    bh[q][j] = nbh[q][j];
-                    bl[q][j] = nbl[q][j];
-                }
+            cur = nxt;
         }
     }
 #undef WL_LOAD_A
@@ -307,13 +355,13 @@ int check_wide(const WlMlp* actor, const WlMlp* critic, const WlPpoWideState* st
     if (actor->in_dim != st->in_dim || critic->in_dim != st->in_dim || actor->out_dim != 2 || critic->out_dim != 1 ||
         actor->activation != critic->activation)
         return WL_EINVAL;
-    if (st->in_dim < 16 || st->dp != (st->in_dim + 63) / 64 * 64 || st->capacity <= 0 || (st->capacity & 63) || st->mb_capacity <= 0 ||
+    if (st->in_dim < 64 || st->dp != (st->in_dim + 63) / 64 * 64 || st->capacity <= 0 || (st->capacity & 63) || st->mb_capacity <= 0 ||
         (st->mb_capacity & 63) || st->splits < 1)
         return WL_EINVAL;
-    if (!st->x_hi || !st->x_lo || !st->xt_hi || !st->xt_lo || !st->w_hi || !st->w_lo || !st->h1 || !st->dt_hi || !st->dt_lo ||
+    if (!st->xt_hi || !st->xt_lo || !st->w_hi || !st->w_lo || !st->h1 || !st->dt_hi || !st->dt_lo ||
         !st->dw_partials || !st->partials || !st->narrow || !st->grad || !st->ctrl || !st->operands || ((uintptr_t)st->operands & 15u))
         return WL_EINVAL;
-    for (const void* p : {(const void*)st->x_hi, (const void*)st->x_lo, (const void*)st->xt_hi, (const void*)st->xt_lo, (const void*)st->w_hi,
+    for (const void* p : {(const void*)st->xt_hi, (const void*)st->xt_lo, (const void*)st->w_hi,
                           (const void*)st->w_lo, (const void*)st->h1, (const void*)st->dt_hi, (const void*)st->dt_lo,
                           (const void*)st->dw_partials})
         if ((uintptr_t)p & 15u) return WL_EINVAL;
@@ -324,11 +372,14 @@ int launch_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* 
                           const WlPpoParams* hp, const WlPpoWideState* st, int parity, hipStream_t stream) {
     const int dp = st->dp, D = st->in_dim;
     clear_error();
-    ppo_wide_weights_kernel<<<(kUnits * dp + 255) / 256, 256, 0, stream>>>(actor->w1, critic->w1, D, dp, st->w_hi, st->w_lo);
-    {   // H1 = act(X W1^T + b1): rows = samples of the minibatch, K = dp
+    ppo_wide_weights_kernel<<<(kUnits * dp / 2 + 255) / 256, 256, 0, stream>>>(actor->w1, critic->w1, D, dp, (uint32_t*)st->w_hi,
+                                                                                (uint32_t*)st->w_lo);
+    {   // H1 = act(X W1^T + b1): rows = samples of the minibatch (f32 rows of `obs` through `perm`), K = dp
         SkinnyArgs a{};
-        a.b_hi = st->x_hi + (int64_t)mb_start * dp;
-        a.b_lo = st->x_lo + (int64_t)mb_start * dp;
+        a.b_f32 = bt->obs;
+        a.b_perm = bt->perm + mb_start;
+        a.b_row = D;
+        a.b_k = D;
         a.a_hi = st->w_hi;
         a.a_lo = st->w_lo;
         a.out = st->h1;
@@ -336,12 +387,12 @@ int launch_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* 
         a.bias_c = critic->b1;
         a.rows_b = mb_size;
         a.row_blocks = (mb_size + 127) / 128;
-        a.b_row = a.a_row = dp;        // row-major [row][dp]
-        a.b_chunk = a.a_chunk = kChunk;
+        a.a_row = dp;        // row-major [unit][dp]
+        a.a_chunk = kChunk;
         a.n_chunks = a.chunks_per_split = dp / kChunk;
         a.splits = 1;
-        if (actor->activation == WL_ACT_ELU) skinny_kernel<WL_ACT_ELU + 1><<<a.row_blocks, 256, 0, stream>>>(a);
-        else skinny_kernel<WL_ACT_RELU + 1><<<a.row_blocks, 256, 0, stream>>>(a);
+        if (actor->activation == WL_ACT_ELU) skinny_kernel<WL_ACT_ELU + 1, true><<<a.row_blocks, 256, 0, stream>>>(a);
+        else skinny_kernel<WL_ACT_RELU + 1, true><<<a.row_blocks, 256, 0, stream>>>(a);
         if (launch_status() != WL_OK) return WL_ELAUNCH;
     }
     float* norm2 = st->ctrl + WL_PPO_CTRL_NORM2 + parity;
@@ -365,7 +416,7 @@ int launch_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* 
         a.n_chunks = mb_size / kChunk;
         a.chunks_per_split = (a.n_chunks + st->splits - 1) / st->splits;
         a.splits = splits_used = (a.n_chunks + a.chunks_per_split - 1) / a.chunks_per_split;   // <= st->splits, none empty
-        skinny_kernel<0><<<a.row_blocks * ((a.splits + 7) / 8 * 8), 256, 0, stream>>>(a);
+        skinny_kernel<0, false><<<a.row_blocks * ((a.splits + 7) / 8 * 8), 256, 0, stream>>>(a);
     }
     const WideLayout L = wide_layout(D);
     const int nb_w1 = dp * kUnits / 256, nb_rest = (kRowN + 255) / 256;
@@ -374,7 +425,7 @@ int launch_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* 
 }
 
 int check_batch(const float* std, const WlPpoBatch* bt, int mb_start, int mb_size, const WlPpoWideState* st) {
-    if (!std || !bt || !bt->actions || !bt->mu_old || !bt->logp_old || !bt->adv || !bt->returns || !bt->values_old || !bt->perm ||
+    if (!std || !bt || !bt->obs || !bt->actions || !bt->mu_old || !bt->logp_old || !bt->adv || !bt->returns || !bt->values_old || !bt->perm ||
         !bt->sigma_old)
         return WL_EINVAL;
     if (mb_start < 0 || mb_size <= 0 || (mb_start & 63) || (mb_size & 63) || mb_size > st->mb_capacity ||
@@ -385,17 +436,51 @@ int check_batch(const float* std, const WlPpoBatch* bt, int mb_start, int mb_siz
 
 }  // namespace
 
+namespace wl_internal {
+
+int mlp_weight_planes(const WlMlp* actor, const WlMlp* critic, int dp, uint16_t* w_hi, uint16_t* w_lo, hipStream_t stream) {
+    clear_error();
+    ppo_wide_weights_kernel<<<(kUnits * dp / 2 + 255) / 256, 256, 0, stream>>>(actor->w1, critic->w1, actor->in_dim, dp, (uint32_t*)w_hi,
+                                                                                (uint32_t*)w_lo);
+    return launch_status();
+}
+
+int layer1_partials(const float* x, int64_t x_stride, int n_rows, int in_dim, int dp, const uint16_t* w_hi, const uint16_t* w_lo,
+                    int max_splits, float* out, hipStream_t stream) {
+    SkinnyArgs a{};
+    a.b_f32 = x;
+    a.b_perm = nullptr;
+    a.b_row = x_stride;
+    a.b_k = in_dim;
+    a.a_hi = w_hi;
+    a.a_lo = w_lo;
+    a.out = out;
+    a.rows_b = n_rows;
+    a.row_blocks = (n_rows + 127) / 128;
+    a.a_row = dp;
+    a.a_chunk = kChunk;
+    a.n_chunks = dp / kChunk;
+    a.chunks_per_split = (a.n_chunks + max_splits - 1) / max_splits;
+    a.splits = (a.n_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    clear_error();
+    const int grid = a.splits > 1 ? a.row_blocks * ((a.splits + 7) / 8 * 8) : a.row_blocks;
+    skinny_kernel<0, true><<<grid, 256, 0, stream>>>(a);
+    return launch_status() == WL_OK ? a.splits : WL_ELAUNCH;
+}
+
+}  // namespace wl_internal
+
 extern "C" {
 
 int32_t wl_ppo_wide_num_params(int32_t in_dim) { return in_dim < 1 ? 0 : wide_layout(in_dim).G; }
 
 int wl_ppo_wide_stage(const float* obs, const int32_t* perm, int32_t n_rows, const WlPpoWideState* st, void* stream) {
-    if (!obs || !perm || !st || !st->x_hi || !st->x_lo || !st->xt_hi || !st->xt_lo || n_rows <= 0 || (n_rows & 63) ||
+    if (!obs || !perm || !st || !st->xt_hi || !st->xt_lo || n_rows <= 0 || (n_rows & 63) ||
         n_rows > st->capacity || st->dp != (st->in_dim + 63) / 64 * 64 || st->in_dim < 1)
         return WL_EINVAL;
     clear_error();
-    ppo_wide_stage_kernel<<<dim3(n_rows / 64, st->dp / 64), 256, 0, (hipStream_t)stream>>>(obs, perm, st->in_dim, st->dp, st->capacity,
-                                                                                            st->x_hi, st->x_lo, st->xt_hi, st->xt_lo);
+    ppo_wide_stage_kernel<<<dim3(n_rows / 64, st->dp / 64), 256, 0, (hipStream_t)stream>>>(obs, perm, st->in_dim, st->dp,
+                                                                                            st->xt_hi, st->xt_lo);
     return launch_status();
 }
 

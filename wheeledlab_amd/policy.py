@@ -76,12 +76,36 @@ class ActorCritic:
         self.critic = Mlp(num_obs, 1, activation, device, generator=g)
         self.std = torch.full((num_actions,), float(init_noise_std), dtype=torch.float32, device=device)
 
+    # policy step with the first layer on the bf16 matrix pipe (wl_actor_critic_act_planes): None = by size, True / False = forced
+    planes: bool | None = None
+
+    @staticmethod
+    def planes_pay(n: int, D: int) -> bool:
+        """where the two-launch bf16 form measured faster than the one-launch f32 kernel (tools/act_probe.py)"""
+        return D >= 1024 and n <= 8192
+
+    def _scratch(self, n: int):
+        """the bf16 form's device scratch (weight planes, split-K partial sums) for up to n rows"""
+        D = self.actor.in_dim
+        sc = getattr(self, "_act_scratch", None)
+        if sc is None or sc[0].rows_capacity < n or sc[0].dp != (D + 63) // 64 * 64:
+            dp, dev = (D + 63) // 64 * 64, self.std.device
+            row_blocks, chunks = (n + 127) // 128, dp // 64
+            splits = max(1, min(chunks, 256 // row_blocks if row_blocks <= 256 else 1))
+            w_hi, w_lo = (torch.zeros(128, dp, dtype=torch.int16, device=dev) for _ in range(2))
+            part = torch.zeros(splits, n, 128, dtype=torch.float32, device=dev)
+            sc = (A.WlActScratch(w_hi.data_ptr(), w_lo.data_ptr(), part.data_ptr(), dp, splits, n, 0), w_hi, w_lo, part)
+            self._act_scratch = sc
+        return sc[0]
+
     def act(self, obs: torch.Tensor, actions: torch.Tensor, mu: torch.Tensor, log_prob: torch.Tensor, values: torch.Tensor,
-            seed: int, step: int, env_offset: int = 0, deterministic: bool = False, nets: int = 3):
-        """One policy step for observations of ANY width in one launch (wl_actor_critic_act): fills `actions`, `mu` [n, 2],
-        `log_prob`, `values` [n] (rows of a RolloutStorage) from obs [n, D]; the draw is keyed by (seed, env_offset + row, step).
-        nets = 1: only the actor's half (actions / mu / log_prob; `values` may be None), nets = 2: only the critic's
-        (`values`; the other outputs may be None)."""
+            seed: int, step: int, env_offset: int = 0, deterministic: bool = False, nets: int = 3, planes_fresh: bool = False):
+        """One policy step for observations of ANY width (wl_actor_critic_act: one launch, f32 matrix pipe; or, for large
+        row x width products, wl_actor_critic_act_planes: two launches, first layer on the bf16 pipe): fills `actions`, `mu`
+        [n, 2], `log_prob`, `values` [n] (rows of a RolloutStorage) from obs [n, D]; the draw is keyed by
+        (seed, env_offset + row, step).  nets = 1: only the actor's half (actions / mu / log_prob; `values` may be None),
+        nets = 2: only the critic's (`values`; the other outputs may be None).  planes_fresh: the weight planes of the bf16
+        form are current (the caller has run this method since the last parameter update) -- skips their rebuild."""
         n, D = obs.shape
         assert D == self.actor.in_dim == self.critic.in_dim and obs.dtype == torch.float32 and obs.stride(1) == 1
         needed = (((actions, (n, 2)), (mu, (n, 2)), (log_prob, (n,))) if nets & 1 else ()) + (((values, (n,)),) if nets & 2 else ())
@@ -91,11 +115,23 @@ class ActorCritic:
         key = (self.actor.w1.data_ptr(), self.critic.w1.data_ptr(), self.std.data_ptr())
         if getattr(self, "_act_key", None) != key:   # the structs only hold pointers: rebuilt when the tensors are replaced
             self._act_key, self._act_structs, self._act_fn = key, (self.actor.struct(), self.critic.struct()), A.load().wl_actor_critic_act
+            self._act_scratch = None
         a, c = self._act_structs
+        stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+        if self.planes if self.planes is not None else self.planes_pay(n, D):
+            lib = A.load()
+            new = getattr(self, "_act_scratch", None) is None
+            sc = self._scratch(n)
+            if new or not planes_fresh:
+                A.check(lib.wl_actor_critic_planes(C.byref(a), C.byref(c), C.byref(sc), stream), "wl_actor_critic_planes")
+            A.check(lib.wl_actor_critic_act_planes(C.byref(a), C.byref(c), self.std.data_ptr(), n, obs.data_ptr(), obs.stride(0),
+                                                   ptr(actions), ptr(mu), ptr(log_prob), ptr(values), int(env_offset), int(seed),
+                                                   int(step), int(bool(deterministic)), int(nets), C.byref(sc), stream),
+                    "wl_actor_critic_act_planes")
+            return
         A.check(self._act_fn(C.byref(a), C.byref(c), self.std.data_ptr(), n, obs.data_ptr(), obs.stride(0),
                                              ptr(actions), ptr(mu), ptr(log_prob), ptr(values),
-                                             int(env_offset), int(seed), int(step), int(bool(deterministic)), int(nets),
-                                             C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)),
+                                             int(env_offset), int(seed), int(step), int(bool(deterministic)), int(nets), stream),
                 "wl_actor_critic_act")
 
     def values(self, obs: torch.Tensor, out: torch.Tensor):

@@ -181,10 +181,10 @@ class PPO:
                     and actor_critic.actor[4].out_features == 2)
         # the wide agents (elevation 689, visual 3208 inputs): first layer as bf16-split streaming contractions (FusedWidePpoStep)
         self._wide = (not can_fuse and dev.type == "cuda" and actor_critic.act_fusable()
-                      and actor_critic.actor[0].in_features >= 16
+                      and actor_critic.actor[0].in_features >= 64
                       and actor_critic.actor[0].in_features == actor_critic.critic[0].in_features)
         if fused_update and not (can_fuse or self._wide):
-            raise ValueError("fused_update needs D-64-64-2 / D-64-64-1 elu / relu nets (D = 14 or D >= 16) on a GPU")
+            raise ValueError("fused_update needs D-64-64-2 / D-64-64-1 elu / relu nets (D = 14 or D >= 64) on a GPU")
         self.fused_update = (can_fuse or self._wide) if fused_update is None else bool(fused_update)
         self._fused = None
         # data-parallel learner: ranks hold identical parameters (same seed), step their own env shards, and average the
@@ -618,8 +618,8 @@ class FusedWidePpoStep(FusedPpoStep):
 
         from .. import _abi as A
         D_in = actor_critic.actor[0].in_features
-        if not actor_critic.act_fusable() or D_in < 16 or actor_critic.critic[0].in_features != D_in:
-            raise ValueError("the wide fused PPO step needs D-64-64-2 / D-64-64-1 elu / relu MLPs with D >= 16")
+        if not actor_critic.act_fusable() or D_in < 64 or actor_critic.critic[0].in_features != D_in:
+            raise ValueError("the wide fused PPO step needs D-64-64-2 / D-64-64-1 elu / relu MLPs with D >= 64")
         if not self.shapes_ok(capacity, mb_capacity):
             raise ValueError("rows per update and the minibatch size must be multiples of 64")
         self._C, self._A, self.lib = C, A, A.load()
@@ -634,7 +634,6 @@ class FusedWidePpoStep(FusedPpoStep):
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         h = lambda *s: torch.zeros(*s, dtype=torch.int16, device=dev)
         dp = self.dp
-        self.x_hi, self.x_lo = h(capacity, dp), h(capacity, dp)
         self.xt_hi, self.xt_lo = h(capacity // 64, dp, 64), h(capacity // 64, dp, 64)      # X^T blocked by 64 rows
         self.w_hi, self.w_lo = h(128, dp), h(128, dp)
         self.h1, self.dt_hi, self.dt_lo = z(mb_capacity, 128), h(mb_capacity // 64, 128, 64), h(mb_capacity // 64, 128, 64)
@@ -645,7 +644,7 @@ class FusedWidePpoStep(FusedPpoStep):
         self.operands = z(A.PPO_OPERAND_FLOATS)
         self.ctrl[A.PPO_CTRL_LR:A.PPO_CTRL_LR + 2] = float(ppo.learning_rate)
         ptr = lambda t: t.data_ptr()
-        self.state = A.WlPpoWideState(ptr(self.x_hi), ptr(self.x_lo), ptr(self.xt_hi), ptr(self.xt_lo), ptr(self.w_hi), ptr(self.w_lo),
+        self.state = A.WlPpoWideState(ptr(self.xt_hi), ptr(self.xt_lo), ptr(self.w_hi), ptr(self.w_lo),
                                       ptr(self.h1), ptr(self.dt_hi), ptr(self.dt_lo), ptr(self.dw_partials), ptr(self.partials),
                                       ptr(self.narrow), ptr(self.grad), ptr(self.adam_m), ptr(self.adam_v), ptr(self.ctrl),
                                       ptr(self.operands), self.in_dim, self.dp, self.capacity, self.mb_capacity, self.splits)
