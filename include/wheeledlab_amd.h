@@ -278,9 +278,9 @@ int wl_actor_critic_act(const WlMlp* actor, const WlMlp* critic, const float* st
  * the split's rounding (~2^-17 relative in the layer-1 pre-activations). */
 typedef struct WlActScratch {        /* caller-owned device memory */
     uint16_t *w_hi, *w_lo;           /* [128][dp] layer-1 weights of actor (units 0..63) and critic (64..127) as bf16 planes */
-    float* partials;                 /* [splits][rows_capacity][128] split-K partial sums of layer 1 */
+    float* partials;                 /* [splits][rows_capacity][128] split-K partial sums of layer 1 (128 features per split) */
     int32_t dp;                      /* in_dim rounded up to 64 */
-    int32_t splits;                  /* the contraction is split over at most this many blocks per 128 rows */
+    int32_t splits;                  /* >= ceil(dp / 128) */
     int32_t rows_capacity;
     int32_t reserved;
 } WlActScratch;

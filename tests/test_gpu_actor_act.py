@@ -119,3 +119,74 @@ def test_actor_and_critic_halves_equal_the_joint_launch():
     assert float(v1.abs().max()) > 0 and float(a1.abs().max()) > 0
     v2 = torch.zeros(n, device=DEV)
     assert torch.equal(ac.values(obs, v2), v0)                       # the critic alone, no other outputs
+
+
+@pytest.mark.parametrize("D,n,activation", [(689, 4096, "elu"), (3208, 1024, "elu"), (3208, 1000, "relu"), (100, 77, "elu"), (128, 300, "relu")])
+def test_bf16_plane_form_matches_oracle_and_the_f32_kernel(D, n, activation):
+    """wl_actor_critic_act_planes (layer 1 on the bf16 pipe, observation rows split hi + lo in registers: 16 mantissa bits)
+    against the numpy oracle at the f32 kernel's bars, and against the f32 kernel itself; the draws are the same numbers.
+    Sizes cover a D that is a multiple of 64, D mod 64 != 0 (the overlapped last K chunk) and row counts off the tile grid."""
+    ac, actor_np, critic_np = _nets(D, activation, seed=D + n)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    obs = torch.randn(n, D, device=DEV, generator=g)
+    obs[:, : D // 3] *= 30.0                      # mixed magnitudes
+    out = {}
+    for planes in (False, True):
+        ac.planes = planes
+        a, mu = torch.empty(n, 2, device=DEV), torch.empty(n, 2, device=DEV)
+        logp, val = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+        ac.act(obs, a, mu, logp, val, 42, 99, env_offset=512)
+        torch.cuda.synchronize()
+        out[planes] = (a, mu, logp, val)
+    a, mu, logp, val = out[True]
+    o_a, o_mu, o_logp = OPOL.act(actor_np, ac.std.cpu().numpy(), obs.cpu().numpy(), np.arange(n) + 512, 99, 42)
+    o_val = OPOL.mlp(critic_np, obs.cpu().numpy())[:, 0]
+    scale = max(1.0, float(np.abs(o_mu).max()), float(np.abs(o_val).max()))
+    np.testing.assert_allclose(mu.cpu().numpy(), o_mu, rtol=0, atol=3e-4 * scale)
+    np.testing.assert_allclose(val.cpu().numpy(), o_val, rtol=0, atol=3e-4 * scale)
+    torch.testing.assert_close(mu, out[False][1], rtol=0, atol=2e-4 * scale)
+    torch.testing.assert_close(val, out[False][3], rtol=0, atol=2e-4 * scale)
+    torch.testing.assert_close(a - mu, out[False][0] - out[False][1], rtol=0, atol=2e-6)      # same draw, same std
+    torch.testing.assert_close(logp, torch.distributions.Normal(mu, ac.std).log_prob(a).sum(-1), rtol=0, atol=1e-4)
+
+
+def test_bf16_plane_form_is_independent_of_the_batch_a_row_arrives_in():
+    """two half-size calls with env_offset reproduce the full call bit for bit (fixed split-K shares: 128 features per
+    partial sum whatever the row count), stale weight planes are refreshed unless the caller vouches for them, and the
+    scratch is refused when it is too small"""
+    import ctypes as C
+
+    from wheeledlab_amd import _abi as A
+    D, n = 3208, 1024
+    ac, _, _ = _nets(D, "elu", seed=3)
+    ac.planes = True
+    obs = torch.randn(n, D, device=DEV)
+    full = [torch.empty(n, 2, device=DEV), torch.empty(n, 2, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV)]
+    ac.act(obs, *full, 7, 11, env_offset=0)
+    half = [torch.empty_like(t) for t in full]
+    for lo in (0, n // 2):
+        sl = slice(lo, lo + n // 2)
+        ac.act(obs[sl], half[0][sl], half[1][sl], half[2][sl], half[3][sl], 7, 11, env_offset=lo)
+    torch.cuda.synchronize()
+    for x, y in zip(full, half):
+        assert torch.equal(x, y)
+    # parameters change behind the planes' back: the default call rebuilds them, planes_fresh=True keeps the stale ones
+    ac.actor.w1.mul_(1.01)
+    stale = [torch.empty_like(t) for t in full]
+    ac.act(obs, *stale, 7, 11, planes_fresh=True)
+    fresh = [torch.empty_like(t) for t in full]
+    ac.act(obs, *fresh, 7, 11)
+    torch.cuda.synchronize()
+    assert torch.equal(stale[1], full[1]) and not torch.equal(fresh[1], full[1])
+    assert torch.equal(stale[3], fresh[3])                                        # the critic did not change
+    # too small a scratch
+    sc = ac._scratch(n)
+    a, c = ac._act_structs
+    small = A.WlActScratch(sc.w_hi, sc.w_lo, sc.partials, sc.dp, sc.splits - 1, sc.rows_capacity, 0)
+    call = lambda s, rows: A.load().wl_actor_critic_act_planes(
+        C.byref(a), C.byref(c), ac.std.data_ptr(), rows, obs.data_ptr(), obs.stride(0), full[0].data_ptr(), full[1].data_ptr(),
+        full[2].data_ptr(), full[3].data_ptr(), 0, 7, 11, 0, 3, C.byref(s), None)
+    assert call(small, n) == -1 and call(sc, n) == 0
+    rows_small = A.WlActScratch(sc.w_hi, sc.w_lo, sc.partials, sc.dp, sc.splits, n - 1, 0)
+    assert call(rows_small, n) == -1
+    torch.cuda.synchronize()

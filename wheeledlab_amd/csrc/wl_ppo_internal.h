@@ -24,7 +24,8 @@ int mlp_weight_planes(const WlMlp* actor, const WlMlp* critic, int dp, uint16_t*
 
 // wl_ppo_wide.hip: out[s][r][u] = sum over the 64-wide K chunks of split s of x[r][k] . W[u][k] (both nets: 128 units), x = f32 rows
 // ([n_rows][x_stride], in_dim valid features) split into bf16 planes in registers, W = planes from mlp_weight_planes.
-// Returns the number of splits used (<= max_splits, partial sums [splits][n_rows][128]) or a negative WL_E* code.
+// Two chunks per split (whatever n_rows: results do not depend on the batch a row arrives in); returns the number of
+// splits = ceil(dp / 128) (partial sums [splits][n_rows][128]; WL_EINVAL if that exceeds max_splits) or a negative WL_E* code.
 int layer1_partials(const float* x, int64_t x_stride, int n_rows, int in_dim, int dp, const uint16_t* w_hi, const uint16_t* w_lo,
                     int max_splits, float* out, hipStream_t stream);
 

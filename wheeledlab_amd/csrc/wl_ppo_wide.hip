@@ -460,8 +460,11 @@ int layer1_partials(const float* x, int64_t x_stride, int n_rows, int in_dim, in
     a.a_row = dp;
     a.a_chunk = kChunk;
     a.n_chunks = dp / kChunk;
-    a.chunks_per_split = (a.n_chunks + max_splits - 1) / max_splits;
+    // a fixed share per split: the grouping of the partial sums -- hence every bit of the result -- depends on the width
+    // of the rows only, not on how many rows the call has (a shard of a batch must reproduce its rows of the batch)
+    a.chunks_per_split = 2;
     a.splits = (a.n_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    if (a.splits > max_splits) return WL_EINVAL;
     clear_error();
     const int grid = a.splits > 1 ? a.row_blocks * ((a.splits + 7) / 8 * 8) : a.row_blocks;
     skinny_kernel<0, true><<<grid, 256, 0, stream>>>(a);

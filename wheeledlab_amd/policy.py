@@ -81,8 +81,11 @@ class ActorCritic:
 
     @staticmethod
     def planes_pay(n: int, D: int) -> bool:
-        """where the two-launch bf16 form measured faster than the one-launch f32 kernel (tools/act_probe.py)"""
-        return D >= 1024 and n <= 8192
+        """where the two-launch bf16 form measured faster than the one-launch f32 kernel (tools/act_probe.py, us per step,
+        f32 kernel / bf16 form): D = 3208: 512 rows 26.5 / 18.1, 1024 27.4 / 21.3, 4096 43.6 / 40.5, 16 384 125 / 157;
+        D = 689: 512 10.7 / 12.4, 4096 15.6 / 18.5 -- the wide, short batches, where the f32 kernel re-streams the whole
+        first-layer matrix for every 16-64 rows"""
+        return D >= 1024 and n <= 4096
 
     def _scratch(self, n: int):
         """the bf16 form's device scratch (weight planes, split-K partial sums) for up to n rows"""
@@ -90,8 +93,7 @@ class ActorCritic:
         sc = getattr(self, "_act_scratch", None)
         if sc is None or sc[0].rows_capacity < n or sc[0].dp != (D + 63) // 64 * 64:
             dp, dev = (D + 63) // 64 * 64, self.std.device
-            row_blocks, chunks = (n + 127) // 128, dp // 64
-            splits = max(1, min(chunks, 256 // row_blocks if row_blocks <= 256 else 1))
+            splits = (dp + 127) // 128      # 128 features per split, whatever n: a shard reproduces its rows of the batch
             w_hi, w_lo = (torch.zeros(128, dp, dtype=torch.int16, device=dev) for _ in range(2))
             part = torch.zeros(splits, n, 128, dtype=torch.float32, device=dev)
             sc = (A.WlActScratch(w_hi.data_ptr(), w_lo.data_ptr(), part.data_ptr(), dp, splits, n, 0), w_hi, w_lo, part)
