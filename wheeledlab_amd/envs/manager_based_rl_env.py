@@ -355,8 +355,9 @@ class ManagerBasedRLEnv:
         a = storage.actions[k]
         # (running only the actor's half here and the critic's on a side stream next to the env's launches was measured
         # SLOWER -- elevation 7.1e7 -> 5.8e7 env-steps/s: the event / stream hand-off per step costs more than the overlap gains)
+        # (planes_fresh: the parameters only change between collections, so the bf16 form's weight planes built at k = 0 hold)
         actor_critic.act(storage.observations[k], a, storage.mu[k], storage.actions_log_prob[k], storage.values[k], b.seed,
-                         b.step_count, b.env_offset)
+                         b.step_count, b.env_offset, planes_fresh=k > 0)
         self.action_manager.prev_action = a
         if self._task == "visual" and self._flat.extra.get("augment"):
             b.sample_augmentation()

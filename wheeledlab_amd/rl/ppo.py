@@ -356,7 +356,7 @@ class OnPolicyRunner:
                 st.observations[k].copy_(obs)
                 if one_launch:
                     view.act(st.observations[k], st.actions[k], st.mu[k], st.actions_log_prob[k], st.values[k], batch.seed,
-                             batch.step_count, batch.env_offset)
+                             batch.step_count, batch.env_offset, planes_fresh=k > 0)
                     a = st.actions[k]
                 else:
                     a = ac.act(obs)
@@ -608,8 +608,9 @@ class FusedWidePpoStep(FusedPpoStep):
         512 slots) on the launch -- measured on the elevation agent (6 row blocks x 2048 K chunks): 64 splits 122 us, 85
         (unequal shares) 139 us, 128 107 us, 256 112 us; the visual agent (26 x 512) is flat at 122-128 us from 8 to 64"""
         row_blocks, chunks = (dp + 127) // 128, max(1, mb // 64)
+        want = 768 if row_blocks <= 8 else 384      # wide operands: fewer splits, the partial sums' reduction is 15 us per 16
         s = 1
-        while row_blocks * s < 768 and s < chunks:
+        while row_blocks * s < want and s < chunks:
             s *= 2
         return min(s, chunks)
 
