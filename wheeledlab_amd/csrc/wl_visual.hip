@@ -240,7 +240,12 @@ WL_DEV int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i :
 // VisualObsCfg.PolicyCfg (:38-58): camera (3200) | base_lin_vel (3) | base_ang_vel (3) | last_action clip +-1 (2)
 __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
                                                             float* __restrict__ obs) {
-    __shared__ float img[kImgH * kImgW];
+    // the rendered image with its two reflected border columns on either side: pitch 84 floats = 21 sixteen-byte slots, so
+    // the 8-float window of a 4 x 4 output patch is two aligned ds_read_b128 and, 4 rows x 21 slots being 4 mod 16, the 16-lane
+    // groups a b128 read is served in (lanes of one patch row + 8 lanes of the next) hit 16 distinct slots.  (With the
+    // unpadded [40][80] image each of the 64 reads per thread was a 4-byte read at a lane stride of 4 floats: 8-way conflicts.)
+    constexpr int kPitch = kImgW + 4;
+    __shared__ __attribute__((aligned(16))) float img[kImgH * kPitch];
     __shared__ float red[kBlock / 64];
     const int e = blockIdx.x;
     const Rows S = make_rows(b.state, b.stride);
@@ -263,23 +268,46 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
     // ---- render: one ray per pixel against the z = 0 plane.  d = R (1, dy(col), dz(row)) ----
     const V3 c0 = v3(R.r0.x, R.r1.x, R.r2.x), c1 = v3(R.r0.y, R.r1.y, R.r2.y), c2 = v3(R.r0.z, R.r1.z, R.r2.z);
     float part = 0.f;
-    for (int k = threadIdx.x; k < kImgH * kImgW; k += kBlock) {
-        const int r = k / kImgW, c = k - r * kImgW;
-        const float dy = -(((float)c + 0.5f - p.cx) * inv_fx), dz = -(((float)(r + WL_VIS_CROP) + 0.5f - p.cy) * inv_fy);
-        const V3 d = fma3(dz, c2, fma3(dy, c1, c0));
-        float v = p.sky;
-        if (d.z < -1e-6f) {
-            const float t = -o.z * rcp(d.z);
-            const float hx = fmaf(t, d.x, o.x), hy = fmaf(t, d.y, o.y);
-            const bool on_map = fabsf(hx) <= mf.half_w && fabsf(hy) <= mf.half_h;
-            v = (on_map && traversable_fast(m, mf, hx, hy)) ? 1.f : 0.f;   // white path on black (utils/__init__.py:47-50)
-        }
-        v = clampf(v * p.brightness, 0.f, 1.f);                    // ColorJitter brightness
-        if (plain) {
-            row[k] = (v * 0.9999f - 0.5f) * 2.f;                   // grayscale + Normalize([0.5], [0.5]) straight to HBM
-        } else {
-            img[k] = v;
-            part += v;
+    // Thread -> one image column and every third row (240 of the 256 threads: 3 rows x 80 columns per pass, 14 passes):
+    // the ray direction then advances by a constant vector per pass (3 adds instead of 2 conversions + 8 fma), and the
+    // lanes of a wavefront still store consecutive columns.  Software-pipelined like the height scan: every pixel of
+    // this lane computes its map cell and issues its byte gather first (14 in flight per lane), then all are shaded and
+    // stored -- rolled, each pixel paid the gather latency in turn.
+    constexpr int kRowsPerPass = kBlock / kImgW, kIter = (kImgH + kRowsPerPass - 1) / kRowsPerPass;
+    const int tc = (int)threadIdx.x % kImgW, tr = (int)threadIdx.x / kImgW;
+    const bool lane_on = tr < kRowsPerPass;
+    const float dy = -(((float)tc + 0.5f - p.cx) * inv_fx), dz0 = -(((float)(tr + WL_VIS_CROP) + 0.5f - p.cy) * inv_fy);
+    V3 d = fma3(dz0, c2, fma3(dy, c1, c0));
+    const V3 dstep = (-(float)kRowsPerPass * inv_fy) * c2;
+    const float mx = mf.off_x * mf.inv_rs, my = mf.off_y * mf.inv_cs;   // cell = (int)(h * inv + off * inv)
+    uint8_t cell[kIter];
+    bool hit[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const float t = -o.z * rcp(fminf(d.z, -1e-6f));
+        const float hx = fmaf(t, d.x, o.x), hy = fmaf(t, d.y, o.y);
+        hit[it] = d.z < -1e-6f;                                         // else: sky
+        const bool on_map = hit[it] && fabsf(hx) <= mf.half_w && fabsf(hy) <= mf.half_h;
+        const int xi = min(max((int)fmaf(hx, mf.inv_rs, mx), 0), m.rows - 1);
+        const int yi = min(max((int)fmaf(hy, mf.inv_cs, my), 0), m.cols - 1);
+        cell[it] = on_map ? m.map[yi * m.cols + xi] : (uint8_t)0;       // white path on black (utils/__init__.py:47-50)
+        d = d + dstep;
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const int r = tr + it * kRowsPerPass;
+        if (lane_on && r < kImgH) {
+            float v = hit[it] ? (cell[it] != 0 ? 1.f : 0.f) : p.sky;
+            v = clampf(v * p.brightness, 0.f, 1.f);                    // ColorJitter brightness
+            if (plain) {
+                row[r * kImgW + tc] = (v * 0.9999f - 0.5f) * 2.f;      // grayscale + Normalize([0.5], [0.5]) straight to HBM
+            } else {
+                float* line = img + r * kPitch + 2;
+                line[tc] = v;
+                if (tc == 1 || tc == 2) line[-tc] = v;                            // reflect padding (torchvision): -1 -> 1, -2 -> 2
+                if (tc == kImgW - 2 || tc == kImgW - 3) line[2 * kImgW - 2 - tc] = v;   // 80 -> 78, 81 -> 77
+                part += v;
+            }
         }
     }
     if (plain) return;
@@ -288,6 +316,10 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
     // Gaussian run in registers, and each patch row leaves as one 16-byte store.
     const float mean = 0.9999f * block_sum(part, red) * (1.f / (float)(kImgH * kImgW));   // also orders the img writes
     const float cc = p.contrast, cm = (1.f - p.contrast) * mean;   // ColorJitter contrast: blend with the grey mean
+    // a blend TOWARDS the mean (contrast <= 1) stays inside [0, 1], its clamp is the identity, and the blur is linear with
+    // weights summing to one: blur(cc v + cm) = cc blur(v) + cm -- applied to the 16 outputs instead of the 64 inputs
+    const bool fold = cc <= 1.f && cc >= 0.f;
+    const float oc_ = fold ? cc : 1.f, om_ = fold ? cm : 0.f;
     float w[5] = {0.f, 0.f, 1.f, 0.f, 0.f};
     if (p.blur_sigma > 0.f) {                                      // GaussianBlur(5, sigma): torchvision's kernel1d
         float wsum = 0.f;
@@ -304,20 +336,15 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
     constexpr int kPatchCols = kImgW / 4, kPatches = (kImgH / 4) * kPatchCols;
     if (threadIdx.x < kPatches) {
         const int pr = (threadIdx.x / kPatchCols) * 4, pc = (threadIdx.x % kPatchCols) * 4;
-        int ro[8], co[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            ro[i] = reflect(pr + i - 2, kImgH) * kImgW;           // reflect padding (torchvision)
-            co[i] = reflect(pc + i - 2, kImgW);
-        }
         float hrow[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float v[8];
+            const float4* line = reinterpret_cast<const float4*>(img + reflect(pr + i - 2, kImgH) * kPitch + pc);   // columns pc - 2 .. pc + 5
+            const float4 lo4 = line[0], hi4 = line[1];
+            float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            if (!fold) {   // contrast > 1 can leave [0, 1]: the clamp sits between the blend and the blur
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[j] = img[ro[i] + co[j]];
-                if (cc != 1.f) v[j] = clampf(fmaf(cc, v[j], cm), 0.f, 1.f);
+                for (int j = 0; j < 8; ++j) v[j] = clampf(fmaf(cc, v[j], cm), 0.f, 1.f);
             }
 #pragma unroll
             for (int o = 0; o < 4; ++o)
@@ -331,7 +358,7 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
             for (int oc = 0; oc < 4; ++oc) {
                 const float g = fmaf(w[0], hrow[orow][oc], fmaf(w[1], hrow[orow + 1][oc], fmaf(w[2], hrow[orow + 2][oc],
                                 fmaf(w[3], hrow[orow + 3][oc], w[4] * hrow[orow + 4][oc]))));
-                o4[oc] = (g * 0.9999f - 0.5f) * 2.f;             // grayscale + Normalize([0.5], [0.5])
+                o4[oc] = (fmaf(oc_, g, om_) * 0.9999f - 0.5f) * 2.f;   // (folded contrast,) grayscale + Normalize([0.5], [0.5])
             }
             // row base = e * 3208 floats = e * 12832 B (16-B aligned), patch column is a multiple of 4 floats
             *reinterpret_cast<float4*>(row + (pr + orow) * kImgW + pc) = out4;
