@@ -1,10 +1,15 @@
 // wl_elev.hip -- elevation task (wheeledlab_tasks/elevation/mushr_elevation_env_cfg.py) for gfx950.
 //
-// Two launches per env.step():
-//   1. elev_step_kernel  (lane = env): 4WD action term -> decimation x substeps of the rigid body + 4 tyre contacts on
-//      the heightfield (bilinear height + normal gathers, L2-resident grid) -> terminations -> rewards -> in-kernel
-//      reset -> goal-command update.  State is read once / written once; sub-steps stay in VGPRs.
-//      The step kernel also writes the 13 proprioceptive values of the observation row.
+// Launches per env.step():
+//   quad form (n <= 32 768): ONE -- elev_step_scan_kernel: block = 16 envs; wavefront 0 steps them (one quad of lanes per
+//      env: 4WD action term -> decimation x substeps of the rigid body + 4 tyre contacts on the heightfield (bilinear
+//      height + normal gathers, L2-resident grid) -> terminations -> rewards -> in-kernel reset -> goal-command update),
+//      then all 8 wavefronts cast the 16 x 676 height rays from the poses wavefront 0 left in LDS.  Round 2: 30.3 ->
+//      27.8 us per step at 4096 envs against the two launches below (the scan no longer pays its own launch gap, wave
+//      ramp and pose-row latency; a first fused version with 4 wavefronts and 4 batches of gathers per lane gained nothing).
+//   lane form: TWO --
+//   1. elev_step_kernel  (lane = env): the same step; state is read once / written once, sub-steps stay in VGPRs; also
+//      writes the 13 proprioceptive values of the observation row.
 //   2. elev_scan_kernel  (block = env): the 26 x 26 yaw-aligned height rays (4 L2-resident gathers each), written with
 //      contiguous dword stores -- this launch carries ~90 % of the task's HBM bytes (2.7 KB / env).  (Staging the env's
 //      terrain patch in LDS -- its bounding box fetched row by row with coalesced 8-byte requests, corners read from
@@ -116,6 +121,165 @@ WL_DEV ElevReset draw_elev_reset(const WlElevParams& p, const HeightFieldGround&
     return r;
 }
 
+// what the height scan needs of an env after its step: root position and the cos / sin of its yaw
+struct ScanPose {
+    float px, py, pz, c, s;
+};
+
+// one env.step() of env `e` (all LANES lanes of the env take part): the body of the step kernels below
+template <int LANES>
+WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const WlEnvBuffers& b, const HeightFieldGround& ground,
+                              const float2* __restrict__ actions, const WlStepOut& out, const uint64_t seed, const uint64_t step,
+                              const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics) {
+    const WlVehicleParams& vp = p.vehicle;
+    const uint32_t gid = (uint32_t)(b.env_offset + e);
+    float2 a = actions[e];
+    float v_t, delta;
+    process_action(p.action, a.x, a.y, v_t, delta);
+    EnvConst ec;
+    joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
+    env_const_rows(ec, vp, vd, S.ld(WL_S_MASS, e), S.ld(WL_S_MU_S, e), S.ld(WL_S_MU_D, e), S.ld(WL_S_DAMP, e));
+    if constexpr (LANES == 4) env_const_lane(ec, vp, vd, wid);
+    VehState s;
+    V3 pos = ld3(S, WL_S_PX, e);
+    s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+    s.v = ld3(S, WL_S_VX, e);
+    V3 ww = ld3(S, WL_S_WX, e);
+    if constexpr (LANES == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
+    } else {
+        s.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
+    }
+    s.th = S.ld(WL_S_STEER_POS, e);
+    s.om = S.ld(WL_S_STEER_VEL, e);
+    {
+        const Mat3 R = mat_from_quat(s.q);
+        s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
+        s.wb = mul_t(R, ww);
+    }
+    vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
+    asm volatile("" ::: "memory");   // bookkeeping rows are fetched after the physics loop (register pressure)
+    const Mat3 R = mat_from_quat(s.q);
+    ww = mul(R, s.wb);
+    pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
+    int ep_len = b.episode_len[e] + 1;
+    const bool truncated = ep_len >= p.max_episode_length;
+    float wheel_sum;
+    if constexpr (LANES == 1) wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
+    else wheel_sum = quad_sum(s.wheel[0]);
+    const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y +
+                      ww.z + wheel_sum + s.th + s.om;
+    const bool finite = __builtin_isfinite(chk);
+    const V3 vb = mul_t(R, s.v);
+    // terminations / rewards use the command as the PREVIOUS step's command update left it (IsaacLab step order)
+    float cbx = S.ld(WL_S_CMD_BX, e), cby = S.ld(WL_S_CMD_BY, e);
+    const ElevTerms tm = elev_terms(p, pos, R.r2.z, vb, s.v, wheel_sum, cbx, cby, truncated);
+    const bool terminated = !finite || tm.flag[0] || tm.flag[1] || tm.flag[2] || tm.flag[3];
+    const float step_dt = p.sim_dt * (float)p.decimation;
+    float reward = 0.f;
+    float epsum[WL_ER_NTERMS];
+#pragma unroll
+    for (int i = 0; i < WL_ER_NTERMS; ++i) {
+        const float w = p.weight[i];
+        const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;
+        reward += c;
+        epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;
+    }
+    if (lead) {
+        out.reward[e] = reward;
+        out.terminated[e] = terminated ? 1 : 0;
+        out.truncated[e] = truncated ? 1 : 0;
+        if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
+    }
+    float a0 = a.x, a1 = a.y;
+    float tgt_x = S.ld(WL_S_TGT_X, e), tgt_y = S.ld(WL_S_TGT_Y, e), tgt_h = S.ld(WL_S_TGT_H, e), cmd_timer = S.ld(WL_S_CMD_TIMER, e);
+    if (terminated || truncated) {
+        if (lead) {
+#pragma unroll
+        for (int i = 0; i < WL_ER_NTERMS; ++i) atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
+        atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
+        if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
+#pragma unroll
+        for (int k = 0; k < WL_ET_NTERMS; ++k)
+            if (finite && tm.flag[k]) atomicAdd(&blk_metrics[WL_M_TERM0 + k], 1.f);
+        if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
+        atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
+        }
+#pragma unroll
+        for (int i = 0; i < WL_ER_NTERMS; ++i) epsum[i] = 0.f;
+        if (!finite) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
+            s.th = s.om = 0.f;
+        }
+        const ElevReset rd = draw_elev_reset(p, ground, gid, step, seed);
+        pos = rd.pos;
+        s.q = rd.q;
+        s.v = v3(rd.vx, rd.vy, 0.f);
+        ww = v3(0.f, 0.f, 0.f);
+        tgt_x = rd.tgt_x;
+        tgt_y = rd.tgt_y;
+        tgt_h = rd.tgt_h;
+        cmd_timer = p.cmd_resample_s;
+        ep_len = 0;
+        a0 = a1 = 0.f;
+    }
+    // command manager: count down, resample expired targets, re-express the target in the yaw-aligned base frame
+    cmd_timer -= step_dt;
+    if (cmd_timer <= 0.f) {
+        const F4 u = philox_uniform4(gid, step, ES_CMD_RESAMPLE, seed);
+        tgt_x = sym(u.x, p.cmd_xy);
+        tgt_y = sym(u.y, p.cmd_xy);
+        tgt_h = sym(u.z, p.cmd_heading);
+        cmd_timer = p.cmd_resample_s;
+    }
+    {
+        float c, sn;
+        yaw_cs(s.q, c, sn);
+        const float dx = tgt_x - pos.x, dy = tgt_y - pos.y;
+        cbx = fmaf(c, dx, sn * dy);
+        cby = fmaf(-sn, dx, c * dy);
+    }
+    if constexpr (LANES == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, s.wheel[i]);
+    } else {
+        S.st(WL_S_WHEEL_BL + wid, e, s.wheel[0]);
+    }
+    if (lead) {
+        st3(S, WL_S_PX, e, pos);
+        S.st(WL_S_QW, e, s.q.w);
+        S.st(WL_S_QX, e, s.q.x);
+        S.st(WL_S_QY, e, s.q.y);
+        S.st(WL_S_QZ, e, s.q.z);
+        st3(S, WL_S_VX, e, s.v);
+        st3(S, WL_S_WX, e, ww);
+        S.st(WL_S_STEER_POS, e, s.th);
+        S.st(WL_S_STEER_VEL, e, s.om);
+        S.st(WL_S_ACT0, e, a0);
+        S.st(WL_S_ACT1, e, a1);
+        if (p.log_episode_sums) {
+#pragma unroll
+            for (int i = 0; i < WL_ER_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
+        }
+        S.st(WL_S_CMD_BX, e, cbx);
+        S.st(WL_S_CMD_BY, e, cby);
+        S.st(WL_S_TGT_X, e, tgt_x);
+        S.st(WL_S_TGT_Y, e, tgt_y);
+        S.st(WL_S_TGT_H, e, tgt_h);
+        S.st(WL_S_CMD_TIMER, e, cmd_timer);
+        b.episode_len[e] = ep_len;
+    }
+    // proprioceptive part of the observation, from the post-reset state (all lanes of a quad take part)
+    const Mat3 R2 = mat_from_quat(s.q);
+    write_elev_prop<LANES>(p, out.obs + (int64_t)e * WL_ELEV_OBS_DIM, pos, s.q, mul_t(R2, s.v), mul_t(R2, ww), cbx, cby, a0, a1,
+                           wid, lead);
+    float yc, ys;
+    yaw_cs(s.q, yc, ys);
+    return ScanPose{pos.x, pos.y, pos.z, yc, ys};
+}
+
 template <int LANES>
 __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b,
                                                            const HeightFieldGround ground, const float2* __restrict__ actions,
@@ -138,151 +302,8 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
     if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
     __syncthreads();
     const Rows S = make_rows(b.state, b.stride);
-    const WlVehicleParams& vp = p.vehicle;
     if (e < b.n_envs) {
-        const uint32_t gid = (uint32_t)(b.env_offset + e);
-        float2 a = actions[e];
-        float v_t, delta;
-        process_action(p.action, a.x, a.y, v_t, delta);
-        EnvConst ec;
-        joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-        env_const_rows(ec, vp, vd, S.ld(WL_S_MASS, e), S.ld(WL_S_MU_S, e), S.ld(WL_S_MU_D, e), S.ld(WL_S_DAMP, e));
-        if constexpr (LANES == 4) env_const_lane(ec, vp, vd, wid);
-        VehState s;
-        V3 pos = ld3(S, WL_S_PX, e);
-        s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
-        s.v = ld3(S, WL_S_VX, e);
-        V3 ww = ld3(S, WL_S_WX, e);
-        if constexpr (LANES == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
-        } else {
-            s.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
-        }
-        s.th = S.ld(WL_S_STEER_POS, e);
-        s.om = S.ld(WL_S_STEER_VEL, e);
-        {
-            const Mat3 R = mat_from_quat(s.q);
-            s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
-            s.wb = mul_t(R, ww);
-        }
-        vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
-        asm volatile("" ::: "memory");   // bookkeeping rows are fetched after the physics loop (register pressure)
-        const Mat3 R = mat_from_quat(s.q);
-        ww = mul(R, s.wb);
-        pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
-        int ep_len = b.episode_len[e] + 1;
-        const bool truncated = ep_len >= p.max_episode_length;
-        float wheel_sum;
-        if constexpr (LANES == 1) wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
-        else wheel_sum = quad_sum(s.wheel[0]);
-        const float chk = pos.x + pos.y + pos.z + s.q.w + s.q.x + s.q.y + s.q.z + s.v.x + s.v.y + s.v.z + ww.x + ww.y +
-                          ww.z + wheel_sum + s.th + s.om;
-        const bool finite = __builtin_isfinite(chk);
-        const V3 vb = mul_t(R, s.v);
-        // terminations / rewards use the command as the PREVIOUS step's command update left it (IsaacLab step order)
-        float cbx = S.ld(WL_S_CMD_BX, e), cby = S.ld(WL_S_CMD_BY, e);
-        const ElevTerms tm = elev_terms(p, pos, R.r2.z, vb, s.v, wheel_sum, cbx, cby, truncated);
-        const bool terminated = !finite || tm.flag[0] || tm.flag[1] || tm.flag[2] || tm.flag[3];
-        const float step_dt = p.sim_dt * (float)p.decimation;
-        float reward = 0.f;
-        float epsum[WL_ER_NTERMS];
-#pragma unroll
-        for (int i = 0; i < WL_ER_NTERMS; ++i) {
-            const float w = p.weight[i];
-            const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;
-            reward += c;
-            epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;
-        }
-        if (lead) {
-            out.reward[e] = reward;
-            out.terminated[e] = terminated ? 1 : 0;
-            out.truncated[e] = truncated ? 1 : 0;
-            if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
-        }
-        float a0 = a.x, a1 = a.y;
-        float tgt_x = S.ld(WL_S_TGT_X, e), tgt_y = S.ld(WL_S_TGT_Y, e), tgt_h = S.ld(WL_S_TGT_H, e), cmd_timer = S.ld(WL_S_CMD_TIMER, e);
-        if (terminated || truncated) {
-            if (lead) {
-#pragma unroll
-            for (int i = 0; i < WL_ER_NTERMS; ++i) atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
-            atomicAdd(&blk_metrics[WL_M_RESETS], 1.f);
-            if (truncated) atomicAdd(&blk_metrics[WL_M_TIMEOUTS], 1.f);
-#pragma unroll
-            for (int k = 0; k < WL_ET_NTERMS; ++k)
-                if (finite && tm.flag[k]) atomicAdd(&blk_metrics[WL_M_TERM0 + k], 1.f);
-            if (!finite) atomicAdd(&blk_metrics[WL_M_NONFINITE], 1.f);
-            atomicAdd(&blk_metrics[WL_M_EPLEN], (float)ep_len);
-            }
-#pragma unroll
-            for (int i = 0; i < WL_ER_NTERMS; ++i) epsum[i] = 0.f;
-            if (!finite) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
-                s.th = s.om = 0.f;
-            }
-            const ElevReset rd = draw_elev_reset(p, ground, gid, step, seed);
-            pos = rd.pos;
-            s.q = rd.q;
-            s.v = v3(rd.vx, rd.vy, 0.f);
-            ww = v3(0.f, 0.f, 0.f);
-            tgt_x = rd.tgt_x;
-            tgt_y = rd.tgt_y;
-            tgt_h = rd.tgt_h;
-            cmd_timer = p.cmd_resample_s;
-            ep_len = 0;
-            a0 = a1 = 0.f;
-        }
-        // command manager: count down, resample expired targets, re-express the target in the yaw-aligned base frame
-        cmd_timer -= step_dt;
-        if (cmd_timer <= 0.f) {
-            const F4 u = philox_uniform4(gid, step, ES_CMD_RESAMPLE, seed);
-            tgt_x = sym(u.x, p.cmd_xy);
-            tgt_y = sym(u.y, p.cmd_xy);
-            tgt_h = sym(u.z, p.cmd_heading);
-            cmd_timer = p.cmd_resample_s;
-        }
-        {
-            float c, sn;
-            yaw_cs(s.q, c, sn);
-            const float dx = tgt_x - pos.x, dy = tgt_y - pos.y;
-            cbx = fmaf(c, dx, sn * dy);
-            cby = fmaf(-sn, dx, c * dy);
-        }
-        if constexpr (LANES == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, s.wheel[i]);
-        } else {
-            S.st(WL_S_WHEEL_BL + wid, e, s.wheel[0]);
-        }
-        if (lead) {
-            st3(S, WL_S_PX, e, pos);
-            S.st(WL_S_QW, e, s.q.w);
-            S.st(WL_S_QX, e, s.q.x);
-            S.st(WL_S_QY, e, s.q.y);
-            S.st(WL_S_QZ, e, s.q.z);
-            st3(S, WL_S_VX, e, s.v);
-            st3(S, WL_S_WX, e, ww);
-            S.st(WL_S_STEER_POS, e, s.th);
-            S.st(WL_S_STEER_VEL, e, s.om);
-            S.st(WL_S_ACT0, e, a0);
-            S.st(WL_S_ACT1, e, a1);
-            if (p.log_episode_sums) {
-    #pragma unroll
-                for (int i = 0; i < WL_ER_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
-            }
-            S.st(WL_S_CMD_BX, e, cbx);
-            S.st(WL_S_CMD_BY, e, cby);
-            S.st(WL_S_TGT_X, e, tgt_x);
-            S.st(WL_S_TGT_Y, e, tgt_y);
-            S.st(WL_S_TGT_H, e, tgt_h);
-            S.st(WL_S_CMD_TIMER, e, cmd_timer);
-            b.episode_len[e] = ep_len;
-        }
-        // proprioceptive part of the observation, from the post-reset state (all lanes of a quad take part)
-        const Mat3 R2 = mat_from_quat(s.q);
-        write_elev_prop<LANES>(p, out.obs + (int64_t)e * WL_ELEV_OBS_DIM, pos, s.q, mul_t(R2, s.v), mul_t(R2, ww), cbx, cby, a0, a1,
-                               wid, lead);
+        (void)elev_env_step<LANES>(p, vd, b, ground, actions, out, seed, step, S, e, wid, lead, blk_metrics);
     }
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
@@ -329,6 +350,75 @@ __global__ void __launch_bounds__(kBlock) elev_scan_kernel(const WlElevParams p,
             // world_height_map = -(sensor_z - hit_z - offset) + (root_z - plane_init_value); rays that miss return +inf
             const float val = cr[it].inside ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
             row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
+        }
+    }
+}
+
+// env.step() AND the height scan as ONE launch (quad form, n <= 32 768): block = 16 envs, 8 wavefronts.  Wavefront 0
+// steps them (16 quads, as in elev_step_kernel<4>) and leaves each env's post-step pose in LDS; then all eight
+// wavefronts cast the 16 x 676 rays (flat index over (env, ray): 21.1 per lane, in two batches of gathers).  Against the
+// two-launch form this removes the scan kernel's own start (launch gap, wave ramp, the pose rows' first-touch latency)
+// from the step's dependent chain, and one physics wavefront per CU spreads the step over 256 CUs instead of 64 (4096 envs).
+constexpr int kFusedThreads = 512, kFusedEnvs = 16;
+__global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlElevParams p_arg, const VehDerived vd_arg,
+                                                                       const WlEnvBuffers b, const HeightFieldGround ground,
+                                                                       const float2* __restrict__ actions, const WlStepOut out,
+                                                                       const uint64_t seed, const uint64_t step) {
+    __shared__ float blk_metrics[WL_M_COUNT];
+    __shared__ ScanPose pose[kFusedEnvs];
+    const int tid = threadIdx.x;
+    if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
+    const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
+    if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
+    __syncthreads();
+    const int e0 = blockIdx.x * kFusedEnvs;
+    if (tid < 64) {
+        WlElevParams p = kernarg_vector_copy<WlElevParams>(0);   // one batch of vector loads instead of dependent scalar round trips
+        keep_scalar_common(p, p_arg);
+        VehDerived vd = kernarg_vector_copy<VehDerived>((int)sizeof(WlElevParams));
+        vd.n_sub = vd_arg.n_sub;
+        const int wid = tid & 3, e = e0 + (tid >> 2);
+        if (e < b.n_envs) {
+            const Rows S = make_rows(b.state, b.stride);
+            const ScanPose sp = elev_env_step<4>(p, vd, b, ground, actions, out, seed, step, S, e, wid, wid == 0, blk_metrics);
+            if (wid == 0) pose[tid >> 2] = sp;
+        }
+    }
+    __syncthreads();
+    if (tid < WL_M_COUNT) {
+        const float m = blk_metrics[tid];
+        if (m != 0.f) atomicAdd(metric_shard(b, m_slot) + tid, m);
+    }
+    // ---- the scan ----
+    const WlElevParams& p = p_arg;
+    constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N, kAll = kFusedEnvs * kRays;
+    constexpr int kSlots = (kAll + kFusedThreads - 1) / kFusedThreads, kBatch = (kSlots + 1) / 2;
+    const int n_here = min(kFusedEnvs, b.n_envs - e0);
+    const float g0 = -0.5f * p.scan_size;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        HeightFieldGround::Corners cr[kBatch];
+        float pz[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            const int idx = min(tid + (half * kBatch + i) * kFusedThreads, kAll - 1);
+            const int j = idx / kRays, k = idx - j * kRays;
+            const int iy = k / WL_ELEV_SCAN_N, ix = k - iy * WL_ELEV_SCAN_N;   // meshgrid "xy": x fastest
+            const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
+            const ScanPose sp = pose[min(j, n_here - 1)];
+            pz[i] = sp.pz;
+            cr[i] = ground.corners(sp.px + (sp.c * lx - sp.s * ly), sp.py + (sp.s * lx + sp.c * ly));
+        }
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+            const int idx = tid + (half * kBatch + i) * kFusedThreads;
+            const int j = idx / kRays, k = idx - j * kRays;
+            if (idx < kAll && j < n_here) {
+                const float hz = ground.blend(cr[i]);
+                // world_height_map = -(sensor_z - hit_z - offset) + (root_z - plane_init_value); rays that miss return +inf
+                const float val = cr[i].inside ? (-(pz[i] - hz - p.scan_offset) + (pz[i] - p.elev_z0)) : __builtin_inff();
+                out.obs[(int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
+            }
         }
     }
 }
@@ -444,11 +534,12 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
         o.truncated += k * vec_step_stride;
         if (o.dones) o.dones += k * vec_step_stride;
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
-        if (quad)
-            elev_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, g, a, o, seed, step0 + (uint64_t)k);
-        else
+        if (quad) {   // step + scan in one launch
+            elev_step_scan_kernel<<<(b->n_envs + kFusedEnvs - 1) / kFusedEnvs, kFusedThreads, 0, (hipStream_t)stream>>>(*p, vd, *b, g, a, o, seed, step0 + (uint64_t)k);
+        } else {
             elev_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, g, a, o, seed, step0 + (uint64_t)k);
-        elev_scan_kernel<<<(b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
+            elev_scan_kernel<<<(b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
+        }
     }
     return launch_status();
 }
