@@ -18,7 +18,10 @@ constexpr int kHotArgBytes = 56;   // state 0, episode_len 8, actions 16, stride
 // UNROLL (lane form only): the four wheels inlined and interleaved by the scheduler (more registers, more ILP: better
 // while the SIMDs hold few wavefronts) or fenced one after the other (fewer registers -> one more wavefront per SIMD).
 // DRIVE (lane form): the drive train compiled in (wl_vehicle.h); -1: the quad form decides per lane at run time.
-template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1>
+// QB (quad form): threads per block.  The wavefronts of a block share a CU; at 4096 envs (256 wavefronts) blocks of 256
+// threads put four of them on each of 64 CUs and leave 192 CUs idle: 6.63 us per launch against 6.27 with 128 threads and
+// 6.37 with 64 (1024 envs: 6.38 / 6.03 / 5.87; 16 384 envs: 7.61 / 8.79 / 8.39) -- launch_step picks by env count.
+template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1, int QB = kBlock>
 __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? WL_LANE_WAVES : WL_LOWREG_WAVES)) drift_step_kernel(float* __restrict__ state, int32_t* __restrict__ episode_len,
                                                             const float2* __restrict__ actions, const int stride,
                                                             const int n_envs, const int env_offset, const uint64_t seed,
@@ -26,7 +29,7 @@ __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? 
                                                             const VehDerived vd_arg, const WlEnvBuffers b_arg,
                                                             const float* __restrict__ noise, const WlStepOut out,
                                                             const Ground ground, const MetricSlots slots) {
-    constexpr int kEnvs = kBlock / LANES;   // envs per block
+    constexpr int kEnvs = (LANES == 4 ? QB : kBlock) / LANES;   // envs per block
     // quad (latency) form: parameters by one batch of vector loads from the kernarg segment (p_arg right behind the
     // hot arguments, vd_arg behind it); lane (throughput) form: the compiler's scalar loads -- latency is hidden by
     // occupancy there and the VGPRs are needed for the env
@@ -99,13 +102,13 @@ __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? 
 // rows stay in registers across steps -- per step only the action is read and obs / reward / flags are written -- so the
 // launch boundary, the state round trip through L2 and its address arithmetic are paid once per rollout.  Episode
 // metrics of all K steps accumulate into ring slot (step0 % R); slot ((step0 + K) % R) is cleared for the next launch.
-template <class Ground>
+template <class Ground, int QB = kBlock /* threads per block, see drift_step_kernel */>
 __global__ void __launch_bounds__(kBlock) drift_rollout_kernel(const WlDriftParams p_arg, const WlEnvBuffers b,
                                                                const float2* __restrict__ actions, const WlStepOut out,
                                                                const int64_t obs_step_stride, const int64_t vec_step_stride,
                                                                const int n_steps, const uint64_t seed, const uint64_t step0,
                                                                const Ground ground, const VehDerived vd_arg, const MetricSlots slots) {
-    constexpr int LANES = 4, kEnvs = kBlock / LANES;
+    constexpr int LANES = 4, kEnvs = QB / LANES;
     WlDriftParams p = p_arg;
     VehDerived vd = vd_arg;
     pin_params_vgpr(p, vd);
@@ -271,7 +274,12 @@ static void launch_step(const WlDriftParams* p, const WlEnvBuffers* b, const Veh
 #define WL_STEP_ARGS b->state, b->episode_len, actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b, noise, out, FlatGround{}, slots
     const int grid = grid_for(b->n_envs);
     const bool awd = p->vehicle.drive == 1;
-    if (use_quad(b)) drift_step_kernel<4, FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, stream>>>(WL_STEP_ARGS);
+    if (use_quad(b)) {
+        const int lanes = b->n_envs * 4;
+        if (b->n_envs <= 2048) drift_step_kernel<4, FlatGround, true, -1, 64><<<(lanes + 63) / 64, 64, 0, stream>>>(WL_STEP_ARGS);
+        else if (b->n_envs <= 8192) drift_step_kernel<4, FlatGround, true, -1, 128><<<(lanes + 127) / 128, 128, 0, stream>>>(WL_STEP_ARGS);
+        else drift_step_kernel<4, FlatGround><<<grid_for(lanes), kBlock, 0, stream>>>(WL_STEP_ARGS);
+    }
     else if (use_unrolled(b)) {
         if (awd) drift_step_kernel<1, FlatGround, true, 1><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
         else drift_step_kernel<1, FlatGround, true, 0><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
@@ -321,9 +329,13 @@ int wl_drift_rollout_persistent(const WlDriftParams* p, const WlEnvBuffers* b, c
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
     if (b->metrics_slots > 1 && n_steps % b->metrics_slots == 0 && n_steps > 0) return WL_EINVAL;   // ring slot aliasing
     clear_error();
-    drift_rollout_kernel<FlatGround><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(
-        *p, *b, (const float2*)actions, *out, obs_step_stride, vec_step_stride, n_steps, seed, step0, FlatGround{},
-        derive_vehicle(p->vehicle, p->sim_dt, p->decimation), metric_slots(b, step0, (uint64_t)n_steps));
+#define WL_ROLLOUT_ARGS *p, *b, (const float2*)actions, *out, obs_step_stride, vec_step_stride, n_steps, seed, step0, FlatGround{}, \
+                        derive_vehicle(p->vehicle, p->sim_dt, p->decimation), metric_slots(b, step0, (uint64_t)n_steps)
+    const int lanes = b->n_envs * 4;
+    if (b->n_envs <= 2048) drift_rollout_kernel<FlatGround, 64><<<(lanes + 63) / 64, 64, 0, (hipStream_t)stream>>>(WL_ROLLOUT_ARGS);
+    else if (b->n_envs <= 8192) drift_rollout_kernel<FlatGround, 128><<<(lanes + 127) / 128, 128, 0, (hipStream_t)stream>>>(WL_ROLLOUT_ARGS);
+    else drift_rollout_kernel<FlatGround><<<grid_for(lanes), kBlock, 0, (hipStream_t)stream>>>(WL_ROLLOUT_ARGS);
+#undef WL_ROLLOUT_ARGS
     return launch_status();
 }
 

@@ -145,7 +145,7 @@ WL_DEV float* metric_shard(const WlEnvBuffers& b, int slot) {   // this wavefron
 }
 WL_DEV void clear_metric_slot(const WlEnvBuffers& b, int slot) {   // block 0 zeroes all shards of `slot`
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < kMetricSlotFloats; i += kBlock) b.metrics[(int64_t)slot * kMetricSlotFloats + i] = 0.f;
+        for (int i = threadIdx.x; i < kMetricSlotFloats; i += (int)blockDim.x) b.metrics[(int64_t)slot * kMetricSlotFloats + i] = 0.f;
 }
 
 // The slot of the metric ring a launch accumulates into and the slot it clears for its successor, computed by the

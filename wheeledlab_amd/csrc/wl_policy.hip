@@ -49,13 +49,13 @@ __global__ void __launch_bounds__(kBlock) mlp_forward_kernel(const WlMlp net, co
 
 // K steps of { actor -> sample -> env.step } in one launch (quad form).  Lanes whose env index is past n_envs mirror
 // the last env (the matrix pipe and the cross-lane pulls want whole wavefronts) and never store.
-template <int ACT, class Ground>
+template <int ACT, class Ground, int QB = kBlock /* threads per block, see drift_step_kernel */>
 __global__ void __launch_bounds__(kBlock) drift_policy_rollout_kernel(const WlDriftParams p_arg, const WlEnvBuffers b, const WlMlp actor,
                                                                       const float* __restrict__ action_std,
                                                                       const WlPolicyRollout io, const int n_steps,
                                                                       const uint64_t seed, const uint64_t step0,
                                                                       const Ground ground, const VehDerived vd_arg, const MetricSlots slots) {
-    constexpr int LANES = 4, kEnvs = kBlock / LANES;
+    constexpr int LANES = 4, kEnvs = QB / LANES;
     WlDriftParams p = p_arg;
     VehDerived vd = vd_arg;
     pin_params_vgpr(p, vd);
@@ -162,13 +162,19 @@ int wl_drift_rollout_policy(const WlDriftParams* p, const WlEnvBuffers* b, const
     if (b->metrics_slots > 1 && n_steps % b->metrics_slots == 0 && n_steps > 0) return WL_EINVAL;   // ring slot aliasing
     clear_error();
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
-    const int grid = grid_for(b->n_envs * 4);
-    if (actor->activation == WL_ACT_ELU)
-        drift_policy_rollout_kernel<WL_ACT_ELU, FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-            *p, *b, *actor, action_std, *io, n_steps, seed, step0, FlatGround{}, vd, metric_slots(b, step0, (uint64_t)n_steps));
-    else
-        drift_policy_rollout_kernel<WL_ACT_RELU, FlatGround><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-            *p, *b, *actor, action_std, *io, n_steps, seed, step0, FlatGround{}, vd, metric_slots(b, step0, (uint64_t)n_steps));
+#define WL_PR_ARGS *p, *b, *actor, action_std, *io, n_steps, seed, step0, FlatGround{}, vd, metric_slots(b, step0, (uint64_t)n_steps)
+#define WL_PR_LAUNCH(ACT)                                                                                                       \
+    if (b->n_envs <= 2048) drift_policy_rollout_kernel<ACT, FlatGround, 64><<<(lanes + 63) / 64, 64, 0, (hipStream_t)stream>>>(WL_PR_ARGS);   \
+    else if (b->n_envs <= 8192) drift_policy_rollout_kernel<ACT, FlatGround, 128><<<(lanes + 127) / 128, 128, 0, (hipStream_t)stream>>>(WL_PR_ARGS); \
+    else drift_policy_rollout_kernel<ACT, FlatGround><<<grid_for(lanes), kBlock, 0, (hipStream_t)stream>>>(WL_PR_ARGS)
+    const int lanes = b->n_envs * 4;
+    if (actor->activation == WL_ACT_ELU) {
+        WL_PR_LAUNCH(WL_ACT_ELU);
+    } else {
+        WL_PR_LAUNCH(WL_ACT_RELU);
+    }
+#undef WL_PR_LAUNCH
+#undef WL_PR_ARGS
     return launch_status();
 }
 

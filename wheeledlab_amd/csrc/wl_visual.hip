@@ -73,7 +73,7 @@ WL_DEV VisReset draw_visual_reset(const WlVisualParams& p, const WlTravMap& m, u
     return r;
 }
 
-template <int LANES>
+template <int LANES, int QB = kBlock /* quad form: threads per block (see drift_step_kernel) */>
 __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b,
                                                              const WlTravMap m, const float2* __restrict__ actions,
                                                              const WlStepOut out, const uint64_t seed, const uint64_t step) {
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
         vd = kernarg_vector_copy<VehDerived>((int)sizeof(WlVisualParams));
         vd.n_sub = vd_arg.n_sub;
     }
-    constexpr int kEnvs = kBlock / LANES;
+    constexpr int kEnvs = (LANES == 4 ? QB : kBlock) / LANES;
     const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);
     const bool lead = LANES == 1 || wid == 0;
     const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
@@ -480,7 +480,12 @@ int wl_visual_rollout(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
         if (o.dones) o.dones += k * vec_step_stride;
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
         if (quad)
-            visual_step_kernel<4><<<grid_for(b->n_envs * 4), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
+        {
+            const int lanes = b->n_envs * 4;
+            if (b->n_envs <= 2048) visual_step_kernel<4, 64><<<(lanes + 63) / 64, 64, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
+            else if (b->n_envs <= 8192) visual_step_kernel<4, 128><<<(lanes + 127) / 128, 128, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
+            else visual_step_kernel<4><<<grid_for(lanes), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
+        }
         else
             visual_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
         visual_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, o.obs);
