@@ -240,28 +240,43 @@ def main():
     trunc_buf = torch.zeros(ROLLOUT, n, dtype=torch.uint8, device=dev)
     metric_sum = torch.zeros_like(env.metrics)
 
+    # The episode-metric all-reduce (the path's only collective) runs at the LOGGING cadence -- once per ROLLOUT = 128 steps,
+    # the reference's num_steps_per_env -- whatever --steps is: a 20-step timed block does not contain 1 / 20 th of a
+    # logging event, it contains one every 6.4 blocks.  It is issued async on RCCL's own stream and joined one logging
+    # interval later, so the next 128 launches overlap it instead of queueing behind it.  drain() (after the timing)
+    # reduces what is left so that short runs report their episode metrics too.
+    cadence = {"since": 0, "pending": None}
+
+    def join():
+        p = cadence["pending"]
+        if p is not None:
+            p[0].wait()
+            metric_sum.add_(p[1])
+            cadence["pending"] = None
+
+    def reduce_metrics():
+        m = env.read_metrics(zero=True)
+        if dist is not None:
+            join()
+            cadence["pending"] = (dist.all_reduce(m, async_op=True), m)
+        else:
+            metric_sum.add_(m)
+        cadence["since"] = 0
+
     def run(k_steps):
-        # the episode-metric all-reduce (the path's only collective) is issued async on RCCL's own stream and joined one
-        # logging interval later, so the next 128 launches overlap it instead of queueing behind it
-        done, pending = 0, None
-
-        def join(p):
-            if p is not None:
-                p[0].wait()
-                metric_sum.add_(p[1])
-
+        done = 0
         while done < k_steps:
-            k = min(ROLLOUT, k_steps - done)
+            k = min(ROLLOUT - cadence["since"], k_steps - done)
             env.rollout(actions[:k], obs_buf, rew_buf, term_buf, trunc_buf)
             done += k
-            if k == ROLLOUT or done == k_steps:  # episode-metric reduction at the logging cadence (+ the tail of a short run)
-                m = env.read_metrics(zero=True)
-                if dist is not None:
-                    join(pending)
-                    pending = (dist.all_reduce(m, async_op=True), m)
-                else:
-                    metric_sum.add_(m)
-        join(pending)
+            cadence["since"] += k
+            if cadence["since"] >= ROLLOUT:
+                reduce_metrics()
+
+    def drain():
+        if cadence["since"] > 0:
+            reduce_metrics()
+        join()
 
     def barrier():
         if dist is not None:
@@ -289,6 +304,7 @@ def main():
         gpu.append(ev0.elapsed_time(ev1))
     wall = sorted(walls)[len(walls) // 2]
     gpu_ms = sorted(gpu)[len(gpu) // 2]
+    drain()   # what the timed blocks left in the accumulators (outside the timing: short runs report their metrics too)
 
     # kernel-only duration: K back-to-back launches of the fused step between two events on the launch stream
     env.rollout(actions, obs_buf, rew_buf, term_buf, trunc_buf)
