@@ -229,3 +229,41 @@ def test_chunked_weight_gradients_equal_the_blas_ones():
     assert abs(grads[0][0] - grads[1][0]) < 1e-6 * abs(grads[1][0])
     for a, b in zip(grads[0][1], grads[1][1]):
         torch.testing.assert_close(a, b, rtol=0, atol=1e-5 * float(b.abs().max()) + 1e-9)
+
+
+@pytest.mark.parametrize("n,activation", [(4096, "elu"), (1000, "relu")])
+def test_one_launch_elevation_collector_equals_policy_step_plus_env_step(n, activation):
+    """wl_elev_collect_step (policy step, env.step() and the height scan in ONE launch) against wl_actor_critic_act followed by
+    wl_elev_step on a twin batch: every storage row and the env state bit for bit (the collector's layer 1 repeats the
+    four-way feature split of the policy kernel at these row counts), 10 steps incl. resets; n = 1000 leaves the last
+    16-env block partly empty"""
+    from wheeledlab_amd.core import ElevBatch
+    from wheeledlab_amd.policy import RolloutStorage
+    from wheeledlab_amd.rl.ppo import ActorCritic
+    K, D = 10, 689
+    torch.manual_seed(3)
+    ac = ActorCritic(D, D, 2, activation=activation).to(DEV)
+    view = ac.fused()
+    view.planes = False
+    ea, eb = ElevBatch(n, device=DEV, seed=11), ElevBatch(n, device=DEV, seed=11)
+    for e in (ea, eb):
+        e.reset()
+        e.episode_len[:n] = torch.randint(0, 245, (n,), device=DEV, dtype=torch.int32, generator=torch.Generator(device=DEV).manual_seed(1))
+    sa, sb = RolloutStorage(K, n, D, 2, DEV), RolloutStorage(K, n, D, 2, DEV)
+    sa.observations[0].copy_(ea.observe())
+    sb.observations[0].copy_(eb.observe())
+    for k in range(K):
+        ea.collect_step(view, sa, k)
+        view.act(sb.observations[k], sb.actions[k], sb.mu[k], sb.actions_log_prob[k], sb.values[k], eb.seed, eb.step_count, eb.env_offset)
+        eb.rollout(sb.actions[k:k + 1], sb.observations[k + 1:k + 2], sb.rewards[k:k + 1], sb.terminated[k:k + 1], sb.time_outs[k:k + 1],
+                   dones_out=sb.dones[k:k + 1])
+    torch.cuda.synchronize()
+    for name in ("actions", "mu", "actions_log_prob", "observations", "rewards", "terminated", "time_outs", "dones"):
+        assert torch.equal(getattr(sa, name), getattr(sb, name)), name
+    assert torch.equal(sa.values[:K], sb.values[:K])
+    assert torch.equal(ea.state, eb.state) and torch.equal(ea.episode_len, eb.episode_len) and ea.step_count == eb.step_count == K
+    assert int(sa.dones.sum()) > 0
+    # the play policy: a = mu
+    ea.collect_step(view, sa, 0, deterministic=True)
+    torch.cuda.synchronize()
+    assert torch.equal(sa.actions[0], sa.mu[0])

@@ -160,6 +160,10 @@ class WlPpoState(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("partials", "grad", "adam_m", "adam_v", "ctrl", "operands")]
 
 
+class WlCollectIo(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("obs_in", "actions", "mu", "log_prob", "values")]
+
+
 class WlActScratch(C.Structure):
     _fields_ = [("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("partials", C.c_void_p), ("dp", C.c_int32), ("splits", C.c_int32),
                 ("rows_capacity", C.c_int32), ("reserved", C.c_int32)]
@@ -214,6 +218,8 @@ SIGNATURES = {
     "wl_elev_step": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _P(WlStepOut), _u64, _u64, _vp]),
     "wl_elev_rollout": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _P(WlStepOut), _i64, _i64,
                                   _i32, _u64, _u64, _vp]),
+    "wl_elev_collect_step": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _P(WlMlp), _P(WlMlp), _vp, _P(WlCollectIo),
+                                       _P(WlStepOut), _i32, _u64, _u64, _vp]),
     "wl_elev_reset": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _u64, _u64, _vp]),
     "wl_elev_observe": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _vp]),
     "wl_elev_mdp": (C.c_int, [_P(WlElevParams), _i32, _i64] + [_vp] * 7 + [_i32] + [_vp] * 7),

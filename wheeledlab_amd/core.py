@@ -274,6 +274,28 @@ class ElevBatch(_MetricsView):
         self.step_count += K
 
 
+    def collect_step(self, actor_critic, storage, k: int, deterministic: bool = False):
+        """rows k of the storage <- policy(observation row k); env.step(); observation row k + 1, reward / flags / dones rows k
+        -- the runner's collection step (modified_rsl_rl_runner.py:70-80) as ONE launch (wl_elev_collect_step).
+        `actor_critic`: the kernel view (policy.ActorCritic: .actor, .critic, .std).  Quad form only (n <= 32 768)."""
+        st = storage
+        key = (st.observations.data_ptr(), actor_critic.actor.w1.data_ptr(), actor_critic.critic.w1.data_ptr(), actor_critic.std.data_ptr())
+        if getattr(self, "_collect_key", None) != key:
+            assert st.n_envs == self.n and st.observations.shape[2] == self.OBS_DIM and st.observations.is_contiguous()
+            self._collect_key = key
+            self._collect_nets = (actor_critic.actor.struct(), actor_critic.critic.struct())
+        a, c = self._collect_nets
+        obs = st.observations
+        io = A.WlCollectIo(obs[k].data_ptr(), st.actions[k].data_ptr(), st.mu[k].data_ptr(), st.actions_log_prob[k].data_ptr(),
+                           st.values[k].data_ptr())
+        out = A.WlStepOut(obs[k + 1].data_ptr(), st.rewards[k].data_ptr(), st.terminated[k].data_ptr(), st.time_outs[k].data_ptr(),
+                          st.dones[k].data_ptr())
+        A.check(self.lib.wl_elev_collect_step(C.byref(self.p), C.byref(self._bufs), C.byref(self._hf), C.byref(a), C.byref(c),
+                                              actor_critic.std.data_ptr(), C.byref(io), C.byref(out), int(bool(deterministic)),
+                                              self.seed, self.step_count, self._stream()), "wl_elev_collect_step")
+        self.step_count += 1
+
+
 class VisualBatch(_MetricsView):
     """n visual-task envs on one GPU: flat black/white traversability plane + ray-cast grey camera."""
 

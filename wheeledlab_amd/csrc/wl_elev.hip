@@ -19,6 +19,7 @@
 
 #include "../../include/wheeledlab_amd.h"
 #include "wl_kernel_common.h"
+#include "wl_actor_dev.h"
 #include "wl_drift_terms.h"   // process_action / joint_targets (shared action term)
 #include "wl_rng.h"
 #include "wl_vehicle.h"
@@ -129,11 +130,11 @@ struct ScanPose {
 // one env.step() of env `e` (all LANES lanes of the env take part): the body of the step kernels below
 template <int LANES>
 WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const WlEnvBuffers& b, const HeightFieldGround& ground,
-                              const float2* __restrict__ actions, const WlStepOut& out, const uint64_t seed, const uint64_t step,
+                              const float2 action, const WlStepOut& out, const uint64_t seed, const uint64_t step,
                               const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics) {
     const WlVehicleParams& vp = p.vehicle;
     const uint32_t gid = (uint32_t)(b.env_offset + e);
-    float2 a = actions[e];
+    float2 a = action;
     float v_t, delta;
     process_action(p.action, a.x, a.y, v_t, delta);
     EnvConst ec;
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
     __syncthreads();
     const Rows S = make_rows(b.state, b.stride);
     if (e < b.n_envs) {
-        (void)elev_env_step<LANES>(p, vd, b, ground, actions, out, seed, step, S, e, wid, lead, blk_metrics);
+        (void)elev_env_step<LANES>(p, vd, b, ground, actions[e], out, seed, step, S, e, wid, lead, blk_metrics);
     }
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
@@ -360,18 +361,140 @@ __global__ void __launch_bounds__(kBlock) elev_scan_kernel(const WlElevParams p,
 // two-launch form this removes the scan kernel's own start (launch gap, wave ramp, the pose rows' first-touch latency)
 // from the step's dependent chain, and one physics wavefront per CU spreads the step over 256 CUs instead of 64 (4096 envs).
 constexpr int kFusedThreads = 512, kFusedEnvs = 16;
+
+// what the policy phase of the collector kernel reads and fills: rows k of an rsl_rl RolloutStorage
+struct PolicyIo {
+    WlMlp actor, critic;
+    const float* std;
+    const float* obs_in;   // [n][689] observation row k
+    float *actions, *mu, *log_prob, *values;
+    int deterministic;
+};
+
+// POLICY: the runner's whole collection step -- actions = alg.act(obs) -> env.step(actions) -> next observation
+// (modified_rsl_rl_runner.py:70-80) -- in this one launch.  Phase A: the eight wavefronts are 2 nets x 4 shares of the 689
+// features of layer 1 for the block's 16 observation rows -- the structure AND the arithmetic of
+// actor_critic_act_kernel<ACT, 4, RT> (same feature ranges, bias on the first share, partial accumulators summed in the same
+// order; f32 MFMA is an fmaf chain), so the collector equals { wl_actor_critic_act; wl_elev_step } bit for bit wherever that
+// kernel splits the features four ways (the elevation agent at <= 8192 rows).  Wavefront 0 (actor) and wavefront 4 (critic)
+// then finish their nets (layers 2-3, draw, log-prob) and wavefront 0 hands the 16 actions to the physics through LDS.
+// MEASURED SLOWER than the two launches it replaces (4096 envs: 47.9 us against 16.2 + 29.1 = 45.4 us per collection step;
+// with layer 1's MFMA loop cut out 34.4, with the tail cut out 44.0): a block of 16 rows streams BOTH first-layer matrices
+// (352 KB) from L2 -- 90 MB per launch, twice the stand-alone policy kernel's traffic (32 rows per block), and that kernel
+// is already bound by exactly this L2 -> L1 operand stream.  More rows per block would halve it and double the scan phase
+// per CU.  The entry point stays (bit-identical to the two calls, tests/test_gpu_training.py); the runner does not use it.
+template <bool POLICY, int ACT = WL_ACT_ELU>
 __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlElevParams p_arg, const VehDerived vd_arg,
                                                                        const WlEnvBuffers b, const HeightFieldGround ground,
                                                                        const float2* __restrict__ actions, const WlStepOut out,
-                                                                       const uint64_t seed, const uint64_t step) {
+                                                                       const uint64_t seed, const uint64_t step, const PolicyIo pio) {
     __shared__ float blk_metrics[WL_M_COUNT];
     __shared__ ScanPose pose[kFusedEnvs];
+    __shared__ __attribute__((aligned(16))) float hbuf[POLICY ? 2 * 3 * kMlpTiles * 64 * 4 : 4];   // partial accumulators [net][share - 1][tile][lane][4]
+    __shared__ float2 act_lds[kFusedEnvs];
     const int tid = threadIdx.x;
     if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
     if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
-    __syncthreads();
     const int e0 = blockIdx.x * kFusedEnvs;
+    if constexpr (POLICY) {
+        const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+        const int which = wave >> 2, share = wave & 3;        // net, share of the features
+        const WlMlp& net = which == 0 ? pio.actor : pio.critic;
+        constexpr int D = WL_ELEV_OBS_DIM, kShares = 4, kFull = D >> 4, kPer = (kFull + kShares - 1) / kShares;
+        const float* w_lane = net.w1 + (int64_t)m * D + 4 * g;      // unit m (+ 16 t), features 4 g ..
+        const float* x_lane = pio.obs_in + (int64_t)min(e0 + m, b.n_envs - 1) * D + 4 * g;
+        // the tail's weights and the draw are independent of layer 1: requested / computed in the shadow of its loads
+        MlpTail W;
+        float z0 = 0.f, z1 = 0.f;
+        if (share == 0) {
+            load_tail(net, lane, W);
+            if (which == 0 && !pio.deterministic) {
+                const F4 u = philox_uniform4((uint32_t)(b.env_offset + e0 + m), step, WL_RS_POLICY, seed);
+                box_muller(u.x, u.y, z0, z1);
+            }
+        }
+        f32x4 h[kMlpTiles];
+#pragma unroll
+        for (int t = 0; t < kMlpTiles; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[t][r] = share == 0 ? net.b1[16 * t + 4 * g + r] : 0.f;   // the bias seeds the first share
+        const int c0 = min(share * kPer, kFull), c1 = min(c0 + kPer, kFull);
+        constexpr int kDepth = 4;   // chunks of operands in flight (4 weight tiles + the observation rows each)
+        wl_f4u ra[kDepth][kMlpTiles], rb[kDepth];
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j)
+            if (c0 + j < c1) {
+#pragma unroll
+                for (int t = 0; t < kMlpTiles; ++t) ra[j][t] = *reinterpret_cast<const wl_f4u*>(w_lane + (int64_t)16 * t * D + ((c0 + j) << 4));
+                rb[j] = *reinterpret_cast<const wl_f4u*>(x_lane + ((c0 + j) << 4));
+            }
+        wl_f4u la[kMlpTiles], lb;   // the partial last chunk (last share), requested up front as well
+        const bool has_last = share == kShares - 1 && (D & 15);
+        if (has_last) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool in = (kFull << 4) + 4 * g + s < D;
+#pragma unroll
+                for (int t = 0; t < kMlpTiles; ++t) la[t][s] = in ? w_lane[(int64_t)16 * t * D + (kFull << 4) + s] : 0.f;
+                lb[s] = in ? x_lane[(kFull << 4) + s] : 0.f;
+            }
+        }
+        for (int c = c0; c < c1; c += kDepth) {
+#pragma unroll
+            for (int j = 0; j < kDepth; ++j) {
+                if (c + j < c1) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int t = 0; t < kMlpTiles; ++t) h[t] = mfma4(ra[j][t][s], rb[j][s], h[t]);
+                    if (c + j + kDepth < c1) {
+#pragma unroll
+                        for (int t = 0; t < kMlpTiles; ++t)
+                            ra[j][t] = *reinterpret_cast<const wl_f4u*>(w_lane + (int64_t)16 * t * D + ((c + j + kDepth) << 4));
+                        rb[j] = *reinterpret_cast<const wl_f4u*>(x_lane + ((c + j + kDepth) << 4));
+                    }
+                }
+            }
+        }
+        if (has_last) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < kMlpTiles; ++t) h[t] = mfma4(la[t][s], lb[s], h[t]);
+        }
+        // shares 1..3 hand their partial accumulators to share 0 through LDS: [net][share - 1][tile][lane] f32x4
+        if (share > 0) {
+#pragma unroll
+            for (int t = 0; t < kMlpTiles; ++t)
+                *reinterpret_cast<f32x4*>(hbuf + (((which * 3 + share - 1) * kMlpTiles + t) * 64 + lane) * 4) = h[t];
+        }
+        __syncthreads();
+        if (share == 0) {
+#pragma unroll
+            for (int k = 0; k < kShares - 1; ++k)
+#pragma unroll
+                for (int t = 0; t < kMlpTiles; ++t)
+                    h[t] += *reinterpret_cast<const f32x4*>(hbuf + (((which * 3 + k) * kMlpTiles + t) * 64 + lane) * 4);
+            const f32x4 o4 = eval_tail<ACT>(W, h, lane);
+            const int r_out = e0 + m;
+            if (g == 0) {
+                if (which == 1) {
+                    if (r_out < b.n_envs) pio.values[r_out] = o4[0];
+                } else {
+                    const float std0 = pio.std[0], std1 = pio.std[1];
+                    const float2 av = make_float2(fmaf(std0, z0, o4[0]), fmaf(std1, z1, o4[1]));
+                    act_lds[m] = av;
+                    if (r_out < b.n_envs) {
+                        reinterpret_cast<float2*>(pio.actions)[r_out] = av;
+                        reinterpret_cast<float2*>(pio.mu)[r_out] = make_float2(o4[0], o4[1]);
+                        pio.log_prob[r_out] = fmaf(-0.5f, fmaf(z0, z0, z1 * z1), -(log_fast(std0) + log_fast(std1)) - kLog2PiA);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
     if (tid < 64) {
         WlElevParams p = kernarg_vector_copy<WlElevParams>(0);   // one batch of vector loads instead of dependent scalar round trips
         keep_scalar_common(p, p_arg);
@@ -380,7 +503,8 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
         const int wid = tid & 3, e = e0 + (tid >> 2);
         if (e < b.n_envs) {
             const Rows S = make_rows(b.state, b.stride);
-            const ScanPose sp = elev_env_step<4>(p, vd, b, ground, actions, out, seed, step, S, e, wid, wid == 0, blk_metrics);
+            const float2 a = POLICY ? act_lds[tid >> 2] : actions[e];
+            const ScanPose sp = elev_env_step<4>(p, vd, b, ground, a, out, seed, step, S, e, wid, wid == 0, blk_metrics);
             if (wid == 0) pose[tid >> 2] = sp;
         }
     }
@@ -535,12 +659,38 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
         if (o.dones) o.dones += k * vec_step_stride;
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
         if (quad) {   // step + scan in one launch
-            elev_step_scan_kernel<<<(b->n_envs + kFusedEnvs - 1) / kFusedEnvs, kFusedThreads, 0, (hipStream_t)stream>>>(*p, vd, *b, g, a, o, seed, step0 + (uint64_t)k);
+            elev_step_scan_kernel<false><<<(b->n_envs + kFusedEnvs - 1) / kFusedEnvs, kFusedThreads, 0, (hipStream_t)stream>>>(*p, vd, *b, g, a, o, seed, step0 + (uint64_t)k, PolicyIo{});
         } else {
             elev_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, g, a, o, seed, step0 + (uint64_t)k);
             elev_scan_kernel<<<(b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
         }
     }
+    return launch_status();
+}
+
+int wl_elev_collect_step(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const WlMlp* actor, const WlMlp* critic,
+                         const float* std, const WlCollectIo* io, const WlStepOut* out, int32_t deterministic, uint64_t seed,
+                         uint64_t step, void* stream) {
+    int rc = check_elev(p, b, hf);
+    if (rc != WL_OK) return rc;
+    if (!use_quad(b)) return WL_EINVAL;   // the one-launch collector is the quad form's (n <= 32 768); beyond: act + step
+    if (!actor || !critic || !std || !io || !io->obs_in || !io->actions || !io->mu || !io->log_prob || !io->values) return WL_EINVAL;
+    if (!out || !out->obs || !out->reward || !out->terminated || !out->truncated) return WL_EINVAL;
+    for (const WlMlp* m : {actor, critic})
+        if (!m->w1 || !m->b1 || !m->w2 || !m->b2 || !m->w3 || !m->b3 || m->hidden != kMlpHidden || m->in_dim != WL_ELEV_OBS_DIM ||
+            (m->activation != WL_ACT_ELU && m->activation != WL_ACT_RELU))
+            return WL_EINVAL;
+    if (actor->out_dim != 2 || critic->out_dim != 1 || actor->activation != critic->activation) return WL_EINVAL;
+    if (((uintptr_t)io->actions & 7u) || ((uintptr_t)io->mu & 7u) || ((uintptr_t)io->obs_in & 3u)) return WL_EALIGN;
+    const HeightFieldGround g = make_ground(hf);
+    const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
+    const PolicyIo pio{*actor, *critic, std, io->obs_in, io->actions, io->mu, io->log_prob, io->values, deterministic};
+    const int grid = (b->n_envs + kFusedEnvs - 1) / kFusedEnvs;
+    clear_error();
+    if (actor->activation == WL_ACT_ELU)
+        elev_step_scan_kernel<true, WL_ACT_ELU><<<grid, kFusedThreads, 0, (hipStream_t)stream>>>(*p, vd, *b, g, nullptr, *out, seed, step, pio);
+    else
+        elev_step_scan_kernel<true, WL_ACT_RELU><<<grid, kFusedThreads, 0, (hipStream_t)stream>>>(*p, vd, *b, g, nullptr, *out, seed, step, pio);
     return launch_status();
 }
 

@@ -9,6 +9,8 @@ utils/modified_rsl_rl_runner.py:47-109): `step/reset/seed/close`, `num_envs`, `d
 step() is ONE launch of the fused HIP kernel; the managers below are thin views/config holders, not executors."""
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 
@@ -353,6 +355,18 @@ class ManagerBasedRLEnv:
             raise ValueError("custom (torch) reward terms run between steps; use step()")
         b = self._batch
         a = storage.actions[k]
+        if self._task == "elevation" and b.n <= 32768 and os.environ.get("WL_ELEV_COLLECT", "0") == "1":
+            # policy step, env.step() and the height scan in ONE launch (wl_elev_collect_step): measured 5 % SLOWER than the
+            # two launches below (the 16-row blocks double the first-layer operand traffic), so it is opt-in
+            b.collect_step(actor_critic, storage, k)
+            self.action_manager.prev_action = a
+            self.common_step_counter += 1
+            self._sim_step_counter += self.cfg.decimation
+            if self._has_curriculum and self.common_step_counter % self.max_episode_length == 0:
+                if bool(storage.dones[k].any()):
+                    for name, term in self._flat.curriculum:
+                        term.func(self, None, **term.params)
+            return
         # (running only the actor's half here and the critic's on a side stream next to the env's launches was measured
         # SLOWER -- elevation 7.1e7 -> 5.8e7 env-steps/s: the event / stream hand-off per step costs more than the overlap gains)
         # (planes_fresh: the parameters only change between collections, so the bf16 form's weight planes built at k = 0 hold)
