@@ -300,7 +300,7 @@ int wl_actor_critic_act_planes(const WlMlp* actor, const WlMlp* critic, const fl
 #define WL_PPO_NUM_PARAMS 10437
 #define WL_PPO_PARTIAL_STRIDE 10440   /* + value-loss, surrogate and KL sums of the minibatch */
 #define WL_PPO_BLOCKS 256             /* rows of WlPpoState.partials */
-#define WL_PPO_OPERAND_FLOATS 21760   /* both nets laid out in MFMA operand order (rebuilt by every step) */
+#define WL_PPO_OPERAND_FLOATS 23296   /* both nets laid out in MFMA operand order (rebuilt by every step) */
 /* WlPpoState.ctrl (16 floats, zero-initialised by the caller once): */
 #define WL_PPO_CTRL_LR 0      /* [2] learning rate, ping-pong by `parity` (the caller seeds BOTH with the initial lr) */
 #define WL_PPO_CTRL_NORM2 2   /* [2] squared gradient norm accumulator, ping-pong */

@@ -21,6 +21,22 @@ def _problem(B, activation="elu", seed=0):
     g = torch.Generator(device=DEV).manual_seed(seed + 1)
     r = lambda *s: torch.randn(*s, device=DEV, generator=g)
     obs = r(B, 14)
+    if activation == "relu":
+        # ReLU's derivative jumps at 0.  Layer 2 (forward and its transpose backward) runs on the bf16 pipe with operands
+        # split into two planes (16 mantissa bits): a hidden pre-activation within ~1e-5 of zero can take the other branch
+        # than torch's f32 GEMM and move a weight gradient by |delta . h| -- a different (equally valid) subgradient, not a
+        # rounding-sized difference.  The comparison therefore runs on observations whose pre-activations keep clear of 0.
+        with torch.no_grad():
+            for _ in range(20):
+                risky = torch.zeros(B, dtype=torch.bool, device=DEV)
+                for net in (ac.actor, ac.critic):
+                    z1 = obs.double() @ net[0].weight.double().t() + net[0].bias.double()
+                    z2 = torch.relu(z1) @ net[2].weight.double().t() + net[2].bias.double()
+                    risky |= (z1.abs() < 1e-5).any(1) | (z2.abs() < 1e-4).any(1)
+                if not bool(risky.any()):
+                    break
+                obs[risky] = r(int(risky.sum()), 14)
+            assert not bool(risky.any())
     with torch.no_grad():
         ac.update_distribution(obs)
         actions = ac.distribution.sample()
@@ -31,6 +47,15 @@ def _problem(B, activation="elu", seed=0):
                 values=values.contiguous())
     sigma_old = torch.tensor([0.85, 1.05], device=DEV)
     return ac, flat, sigma_old
+
+
+def _close_up_to_adam_noise(p, q, lr, steps, what):
+    """parameters of two learners after `steps` Adam steps: all but a few elements within (rtol 1e-3, atol 2e-4); the
+    elements whose gradient is within rounding of zero may differ by a fraction of lr per step (see the trajectory test)"""
+    d = (p - q).abs()
+    bad = d > 2e-4 + 1e-3 * q.abs()
+    assert float(bad.float().mean()) < 2e-3, (what, float(bad.float().mean()))
+    assert float(d.max()) < 0.25 * lr * steps + 2e-4, (what, float(d.max()))
 
 
 def _torch_loss(ac, ppo, b, sigma_old):
@@ -50,7 +75,7 @@ def _torch_loss(ac, ppo, b, sigma_old):
 @pytest.mark.parametrize("B,mb_start,mb_size", [(4096, 0, 4096), (5000, 700, 3001), (40, 3, 21)])
 def test_fused_gradients_match_autograd(activation, B, mb_start, mb_size):
     """every parameter gradient of the surrogate + value loss (no entropy term, no clipping) vs torch autograd on the
-    permuted minibatch: f32 MFMA sums vs rocBLAS sums -> 2e-4 relative to the gradient's scale; ragged sizes cover
+    permuted minibatch: f32 / split-bf16 MFMA sums vs rocBLAS sums -> 2e-4 relative to the gradient's scale; ragged sizes cover
     partial 16-sample tiles and a minibatch that starts inside the permutation"""
     from wheeledlab_amd.rl.ppo import FusedPpoStep, PPO
     ac, flat, sigma_old = _problem(B, activation)
@@ -103,8 +128,13 @@ def test_fused_step_tracks_the_torch_step():
         lrs_f.append(fused.learning_rate)
         lrs_t.append(pt.learning_rate)
         for (name, a), b in zip(ac_f.named_parameters(), ac_t.parameters()):
-            d = float((a - b).abs().max())
-            assert d < 2e-5 * (step + 1) + 2e-3 * lrs_t[-1] * (step + 1), (step, name, d)
+            # Adam normalises every element's move to ~lr whatever the size of its gradient, so the few elements whose
+            # gradient is within the split-bf16 rounding of zero (|g| ~ eps = 1e-8: their update lr g / (|g| + eps) is
+            # ill-conditioned in g) move differently by a fraction of lr; everything else stays within the f32 bound
+            d = (a - b).abs().flatten()
+            tight = 2e-5 * (step + 1) + 2e-3 * lrs_t[-1] * (step + 1)
+            assert float((d > tight).float().mean()) < 2e-3, (step, name, float((d > tight).float().mean()))
+            assert float(d.max()) < 0.25 * max(lrs_t) * (step + 1), (step, name, float(d.max()))
     assert np.allclose(lrs_f, lrs_t, rtol=1e-6), (lrs_f, lrs_t)
     assert len(set(lrs_t)) > 1                                     # the adaptive rule actually moved the learning rate
 
@@ -156,7 +186,7 @@ def test_update_with_the_fused_step_equals_the_torch_update_and_checkpoints_roun
         lf = pf.update(st, generator=torch.Generator(device=DEV).manual_seed(20 + it))
         lt = pt.update(st, generator=torch.Generator(device=DEV).manual_seed(20 + it))
         for (name, p), q in zip(ac_f.named_parameters(), ac_t.parameters()):
-            assert torch.allclose(p, q, rtol=1e-3, atol=2e-4), (it, name, float((p - q).abs().max()))
+            _close_up_to_adam_noise(p, q, max(1e-3, lt["learning_rate"]), (it + 1) * 20, (it, name))   # the schedule starts at 1e-3
         assert abs(lf["learning_rate"] - lt["learning_rate"]) < 1e-9
         assert abs(lf["kl"] - lt["kl"]) < 1e-4 and abs(lf["surrogate"] - lt["surrogate"]) < 1e-4
         assert abs(lf["value_function"] - lt["value_function"]) < 1e-3 * (1 + abs(lt["value_function"]))
@@ -168,7 +198,7 @@ def test_update_with_the_fused_step_equals_the_torch_update_and_checkpoints_roun
     pf.update(st, generator=torch.Generator(device=DEV).manual_seed(77))
     pr.update(st, generator=torch.Generator(device=DEV).manual_seed(77))
     for (name, p), q in zip(ac_f.named_parameters(), ac_r.parameters()):
-        assert torch.allclose(p, q, rtol=1e-3, atol=2e-4), (name, float((p - q).abs().max()))
+        _close_up_to_adam_noise(p, q, 1e-2, 20, name)
 
 
 def test_gae_kernel_matches_the_oracle():

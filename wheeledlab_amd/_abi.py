@@ -135,7 +135,7 @@ class WlPolicyRollout(C.Structure):
                 ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("dones", C.c_void_p)]
 
 
-PPO_NUM_PARAMS, PPO_PARTIAL_STRIDE, PPO_BLOCKS, PPO_OPERAND_FLOATS = 10437, 10440, 256, 21760
+PPO_NUM_PARAMS, PPO_PARTIAL_STRIDE, PPO_BLOCKS, PPO_OPERAND_FLOATS = 10437, 10440, 256, 23296
 PPO_CTRL_LR, PPO_CTRL_NORM2, PPO_CTRL_STATS = 0, 2, 4
 
 

@@ -3,7 +3,9 @@
 // as three launches: forward + losses + backward + weight gradients fused on the f32 matrix pipe, a partial-sum
 // reduction, and gradient clipping + Adam + the adaptive-KL learning-rate rule.
 //
-// Gradient kernel, one wavefront per 16-sample tile (v_mfma_f32_16x16x4_f32 throughout, lane l: g = l >> 4, n = l & 15):
+// Gradient kernel, one wavefront per 16-sample tile (v_mfma_f32_16x16x4_f32, lane l: g = l >> 4, n = l & 15; round 2: the two
+// 64 x 64 products per net -- layer 2 forward and delta1 = W2^T delta2 -- on v_mfma_f32_16x16x32_bf16 with split operands,
+// see the F2 / B2 slabs below: 124 -> 99 us per 131 072-sample gradient call):
 //   * forward in the transposed formulation of wl_mlp.h: H^T[unit][sample] = W . X^T, so a layer's accumulator (lane
 //     (g, n): units 16 t + 4 g + r of sample n) is the next layer's B operand when k is walked as (tile t', register r);
 //   * the output layer is ONE accumulator for both nets with its rows spread so that lane group g ends up holding
@@ -21,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/wheeledlab_amd.h"
+#include "wl_bf16.h"
 #include "wl_kernel_common.h"
 #include "wl_mlp.h"
 #include "wl_ppo_internal.h"
@@ -40,11 +43,16 @@ constexpr int S_VLOSS = G, S_SURR = G + 1, S_KL = G + 2;
 // ((quad * 64 + lane) * 4 + j) -- so that one ds_read_b128 per lane fetches the A operands of four consecutive MFMAs
 // (with one ds_read_b32 per MFMA the kernel waited on LDS latency for every matrix instruction: 210 us per minibatch).
 //   F1 quad s        : the four output tiles t = j of layer-1 k-step s
-//   F2 quad ks       : the four output tiles t = j of layer-2 k-step ks (ks = 4 t' + r, 16 = bias)
-//   B2 quad ks       : the four input tiles t = j of the W2^T k-step ks
+//   F2 slab (jj, t, plane): layer 2 on the bf16 pipe (v_mfma_f32_16x16x32_bf16; every f32 operand two bf16 planes, x = hi + lo,
+//                      product = lo.hi + hi.lo + hi.hi -- 3 MFMAs of 16 cycles for a K of 32 against 8 f32 MFMAs of 32 cycles):
+//                      slab (jj * 4 + t) * 2 + plane = lane (i, g)'s 8 bf16 of W2[16 t + i][in(e)], in(e) = 16 (2 jj + (e >> 2)) +
+//                      4 g + (e & 3) -- exactly the 8 inputs lane group g already HOLDS as accumulators h1[2 jj][0..3],
+//                      h1[2 jj + 1][0..3], so the B operand is packed from registers with no data movement;
+//      slabs 16 + t    : the bias b2 in accumulator layout (f32x4 per lane: units 16 t + 4 g + r), the accumulators' start value
+//   B2 slab (jj, t, plane): the same for W2^T: W2[out(e)][16 t + i], out(e) = 16 (2 jj + (e >> 2)) + 4 g + (e & 3)
 //   B3 quad 0        : the four unit tiles t = j of W3^T
 //   F3 quad q        : k-steps 4 q + j of the joint output layer (0..15 actor units, 16..31 critic units, 32 bias, pad)
-constexpr int T_F1 = 0, T_F2 = T_F1 + 4 * 256, T_B2 = T_F2 + 17 * 256, T_B3 = T_B2 + 16 * 256, kNetTab = T_B3 + 256;
+constexpr int T_F1 = 0, T_F2 = T_F1 + 4 * 256, T_B2 = T_F2 + 20 * 256, T_B3 = T_B2 + 16 * 256, kNetTab = T_B3 + 256;
 constexpr int T_F3 = 2 * kNetTab, kTabFloats = T_F3 + 9 * 256;
 static_assert(kTabFloats == WL_PPO_OPERAND_FLOATS, "header constant");
 constexpr int kTStride = 20, kTBuf = kHid * kTStride;          // transposition buffer [unit][sample], padded rows
@@ -71,14 +79,32 @@ WL_DEV float operand_value(const PpoNets& N, int idx) {
             return f < kIn ? net.w1[unit * kIn + f] : f == kIn ? net.b1[unit] : 0.f;
         }
         q -= 4;
-        if (q < 17) {                                           // forward layer 2: k-step ks = q, tile t = j
-            const int unit = 16 * j + i;
-            if (q == 16) return g == 0 ? net.b2[unit] : 0.f;
-            return net.w2[unit * kHid + 16 * (q >> 2) + 4 * g + (q & 3)];
+        if (q < 20) {                                           // forward layer 2: bf16 planes + the bias slabs
+            if (q >= 16) return net.b2[16 * (q - 16) + 4 * g + j];
+            const int jj = q >> 3, t = (q >> 1) & 3, plane = q & 1;
+            float w[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * j + h;
+                w[h] = net.w2[(16 * t + i) * kHid + 16 * (2 * jj + (e >> 2)) + 4 * g + (e & 3)];
+            }
+            uint32_t hi, lo;
+            split_bf16_pair(w[0], w[1], hi, lo);
+            return __uint_as_float(plane == 0 ? hi : lo);
         }
-        q -= 17;
-        if (q < 16)                                             // backward W2^T: k-step ks = q (output unit), input tile t = j
-            return net.w2[(16 * (q >> 2) + 4 * g + (q & 3)) * kHid + 16 * j + i];
+        q -= 20;
+        if (q < 16) {                                           // backward W2^T: bf16 planes
+            const int jj = q >> 3, t = (q >> 1) & 3, plane = q & 1;
+            float w[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * j + h;
+                w[h] = net.w2[(16 * (2 * jj + (e >> 2)) + 4 * g + (e & 3)) * kHid + 16 * t + i];
+            }
+            uint32_t hi, lo;
+            split_bf16_pair(w[0], w[1], hi, lo);
+            return __uint_as_float(plane == 0 ? hi : lo);
+        }
         const int unit = 16 * j + i;                            // backward W3^T: k = g = output index of the joint layer
         if (is_actor) return g < 2 ? net.w3[g * kHid + unit] : 0.f;
         return g == 2 ? net.w3[unit] : 0.f;
@@ -117,16 +143,40 @@ WL_DEV f32x4 get_transposed4(const float* T, int t, int g, int n) {
     return *reinterpret_cast<const f32x4*>(T + (16 * t + n) * kTStride + 4 * g);
 }
 
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+// B operand of the bf16 products from two accumulator tiles: this lane's 8 inputs as two planes
+WL_DEV void pack_planes(const f32x4& x0, const f32x4& x1, u32x4& hi, u32x4& lo) {
+    uint32_t h, l;
+    split_bf16_pair(x0[0], x0[1], h, l); hi[0] = h; lo[0] = l;
+    split_bf16_pair(x0[2], x0[3], h, l); hi[1] = h; lo[1] = l;
+    split_bf16_pair(x1[0], x1[1], h, l); hi[2] = h; lo[2] = l;
+    split_bf16_pair(x1[2], x1[3], h, l); hi[3] = h; lo[3] = l;
+}
+// acc[t] += W . x over 32 inputs (slab group `base`: (jj, t, plane) order), three products per tile
+WL_DEV void mma_planes(const float* slabs, int jj, int lane, const u32x4& bh, const u32x4& bl, f32x4 acc[kTiles]) {
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, bh), xl = __builtin_bit_cast(bf16x8, bl);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) {
+        const float* at = slabs + ((jj * 4 + t) * 2) * 256 + lane * 4;
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(at), al = *reinterpret_cast<const bf16x8*>(at + 256);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc[t], 0, 0, 0);
+    }
+}
+
 template <int ACT>
 WL_DEV void forward_layer2(const float* tab, float one_g0, int lane, const f32x4 h1[kTiles], f32x4 h2[kTiles]) {
+    (void)one_g0;
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) h2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < kTiles; ++t) h2[t] = *reinterpret_cast<const f32x4*>(tab + T_F2 + (16 + t) * 256 + lane * 4);   // bias
 #pragma unroll
-    for (int ks = 0; ks < 17; ++ks) {
-        const f32x4 a = quad(tab + T_F2, ks, lane);
-        const float b = ks < 16 ? h1[ks >> 2][ks & 3] : one_g0;
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) h2[t] = mfma4(a[t], b, h2[t]);
+    for (int jj = 0; jj < 2; ++jj) {
+        u32x4 bh, bl;
+        pack_planes(h1[2 * jj], h1[2 * jj + 1], bh, bl);
+        mma_planes(tab + T_F2, jj, lane, bh, bl, h2);
     }
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
@@ -220,10 +270,10 @@ WL_DEV void backward_net(const float* tab, float* T, const f32x4 h1[kTiles], con
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) d1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-        const f32x4 a = quad(tab + T_B2, ks, lane);
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) d1[t] = mfma4(a[t], d2[ks >> 2][ks & 3], d1[t]);
+    for (int jj = 0; jj < 2; ++jj) {   // bf16 planes, as layer 2 forward
+        u32x4 bh, bl;
+        pack_planes(d2[2 * jj], d2[2 * jj + 1], bh, bl);
+        mma_planes(tab + T_B2, jj, lane, bh, bl, d1);
     }
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
