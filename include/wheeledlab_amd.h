@@ -282,7 +282,7 @@ typedef struct WlActScratch {        /* caller-owned device memory */
     int32_t dp;                      /* in_dim rounded up to 64 */
     int32_t splits;                  /* >= ceil(dp / 128) */
     int32_t rows_capacity;
-    int32_t reserved;
+    int32_t reserved;                /* 0: one launch (feature shares folded through LDS); 1: two launches (split-K partial sums) */
 } WlActScratch;
 /* (re)build the weight planes: once after every change of the layer-1 weights */
 int wl_actor_critic_planes(const WlMlp* actor, const WlMlp* critic, const WlActScratch* scratch, void* stream);

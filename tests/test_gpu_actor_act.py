@@ -121,12 +121,17 @@ def test_actor_and_critic_halves_equal_the_joint_launch():
     assert torch.equal(ac.values(obs, v2), v0)                       # the critic alone, no other outputs
 
 
-@pytest.mark.parametrize("D,n,activation", [(689, 4096, "elu"), (3208, 1024, "elu"), (3208, 1000, "relu"), (100, 77, "elu"), (128, 300, "relu")])
-def test_bf16_plane_form_matches_oracle_and_the_f32_kernel(D, n, activation):
-    """wl_actor_critic_act_planes (layer 1 on the bf16 pipe, observation rows split hi + lo in registers: 16 mantissa bits)
-    against the numpy oracle at the f32 kernel's bars, and against the f32 kernel itself; the draws are the same numbers.
-    Sizes cover a D that is a multiple of 64, D mod 64 != 0 (the overlapped last K chunk) and row counts off the tile grid."""
+@pytest.mark.parametrize("two_launches", [False, True])
+@pytest.mark.parametrize("D,n,activation", [(689, 4096, "elu"), (3208, 1024, "elu"), (3208, 1000, "relu"), (100, 77, "elu"), (128, 300, "relu"),
+                                            (3208, 2000, "elu"), (689, 1700, "relu")])
+def test_bf16_plane_form_matches_oracle_and_the_f32_kernel(D, n, activation, two_launches):
+    """wl_actor_critic_act_planes (layer 1 on the bf16 pipe, observation rows split hi + lo in registers: 16 mantissa bits), in
+    its one-launch form (feature shares folded through LDS; row tiles per block 1 / 2 / 4 by the row count) and its two-launch
+    form (split-K partial sums), against the numpy oracle at the f32 kernel's bars and against the f32 kernel itself; the
+    draws are the same numbers.  Sizes cover a D that is a multiple of 64, D mod 64 != 0 (the overlapped last K chunk) and
+    row counts off the tile grid."""
     ac, actor_np, critic_np = _nets(D, activation, seed=D + n)
+    ac.planes_two_launch = two_launches
     g = torch.Generator(device=DEV).manual_seed(1)
     obs = torch.randn(n, D, device=DEV, generator=g)
     obs[:, : D // 3] *= 30.0                      # mixed magnitudes
@@ -150,22 +155,23 @@ def test_bf16_plane_form_matches_oracle_and_the_f32_kernel(D, n, activation):
     torch.testing.assert_close(logp, torch.distributions.Normal(mu, ac.std).log_prob(a).sum(-1), rtol=0, atol=1e-4)
 
 
-def test_bf16_plane_form_is_independent_of_the_batch_a_row_arrives_in():
-    """two half-size calls with env_offset reproduce the full call bit for bit (fixed split-K shares: 128 features per
-    partial sum whatever the row count), stale weight planes are refreshed unless the caller vouches for them, and the
+@pytest.mark.parametrize("two_launches", [False, True])
+def test_bf16_plane_form_is_independent_of_the_batch_a_row_arrives_in(two_launches):
+    """two half-size calls with env_offset reproduce the full call bit for bit (the feature shares depend on the width
+    only, whatever the row count), stale weight planes are refreshed unless the caller vouches for them, and the
     scratch is refused when it is too small"""
     import ctypes as C
 
     from wheeledlab_amd import _abi as A
-    D, n = 3208, 1024
+    D, n = 3208, 4096            # the full call runs two row tiles per block, the halves one
     ac, _, _ = _nets(D, "elu", seed=3)
-    ac.planes = True
+    ac.planes, ac.planes_two_launch = True, two_launches
     obs = torch.randn(n, D, device=DEV)
     full = [torch.empty(n, 2, device=DEV), torch.empty(n, 2, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV)]
     ac.act(obs, *full, 7, 11, env_offset=0)
     half = [torch.empty_like(t) for t in full]
-    for lo in (0, n // 2):
-        sl = slice(lo, lo + n // 2)
+    for lo in range(0, n, n // 4):
+        sl = slice(lo, lo + n // 4)
         ac.act(obs[sl], half[0][sl], half[1][sl], half[2][sl], half[3][sl], 7, 11, env_offset=lo)
     torch.cuda.synchronize()
     for x, y in zip(full, half):

@@ -24,7 +24,11 @@ for D, act in ((689, "relu"), (3208, "elu")):
             view.act(obs, a, mu, logp, val, 1, k)
 
         def planes(k):
-            view.planes = True
+            view.planes, view.planes_two_launch = True, False
+            view.act(obs, a, mu, logp, val, 1, k, planes_fresh=k > 0)
+
+        def planes2(k):
+            view.planes, view.planes_two_launch = True, True
             view.act(obs, a, mu, logp, val, 1, k, planes_fresh=k > 0)
 
         def eager(k):
@@ -33,7 +37,7 @@ for D, act in ((689, "relu"), (3208, "elu")):
                 ac.get_actions_log_prob(x)
                 ac.evaluate(obs)
 
-        for name, fn in (("kernel", fused), ("planes", planes)) + (() if os.environ.get("WL_LIB") else (("torch", eager),)):
+        for name, fn in (("kernel", fused), ("planes", planes), ("planes2", planes2)) + (() if os.environ.get("WL_LIB") else (("torch", eager),)):
             for k in range(20):
                 fn(k)
             torch.cuda.synchronize()

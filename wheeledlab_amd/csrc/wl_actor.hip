@@ -16,11 +16,15 @@
 #include "../../include/wheeledlab_amd.h"
 #include "wl_kernel_common.h"
 #include "wl_actor_dev.h"
+#include "wl_bf16.h"
 #include "wl_mlp.h"
 #include "wl_ppo_internal.h"
 #include "wl_rng.h"
 
 namespace {
+
+using u32x4_t = __attribute__((ext_vector_type(4))) uint32_t;
+using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int kRing = 4;   // chunks of operands in flight per wavefront (deeper rings measured no different: the
                            // kernel is bound by L2 -> L1 operand traffic, not by its latency)
@@ -233,6 +237,138 @@ __global__ void __launch_bounds__(64) act_tail_kernel(const WlMlp actor, const W
     log_prob[r_out] = fmaf(-0.5f, fmaf(z0, z0, z1 * z1), -(log_fast(std0) + log_fast(std1)) - kLog2PiA);
 }
 
+// ---- one launch, layer 1 on the bf16 pipe ------------------------------------------------------------------------------------
+// The f32 kernel above is bound by its operand stream from L2: every 16 x RT rows re-read a whole first-layer matrix, and
+// more rows per block (fewer re-reads) cost f32 matrix time it does not have.  v_mfma_f32_16x16x32_bf16 with split operands
+// (x = hi + lo, three products) is 5x cheaper per feature, which buys RT = 4 (64 rows per block: half the stream of RT = 2)
+// with room to spare.  Weights come as the bf16 planes of wl_actor_critic_planes ([128][dp], 64-wide chunks, the last one
+// overlapping its predecessor), observation rows are f32 and split in registers; KS wavefronts split the features, fold
+// their partial accumulators through LDS in a fixed order, and wavefront q finishes row tile q (layers 2-3, draw, log-prob).
+struct PlaneStep {
+    u32x4_t ah[kMlpTiles], al[kMlpTiles];   // weights: 8 bf16 per plane and unit tile
+};
+WL_DEV int plane_feature(int s, int D) { return min(64 * (s >> 1), D - 64) + 32 * (s & 1); }   // first feature of k-step s
+
+template <int ACT, int KS, int RT>
+__global__ void __launch_bounds__(64 * KS) act_bf16_kernel(const WlMlp actor, const WlMlp critic, const float* __restrict__ std,
+                                                           const int n_rows, const float* __restrict__ obs, const int64_t obs_stride,
+                                                           float* __restrict__ actions, float* __restrict__ mu_out,
+                                                           float* __restrict__ log_prob, float* __restrict__ values,
+                                                           const int env_offset, const uint64_t seed, const uint64_t step,
+                                                           const int deterministic, const int first_net,
+                                                           const uint16_t* __restrict__ w_hi, const uint16_t* __restrict__ w_lo,
+                                                           const int dp) {
+    static_assert(RT <= KS, "wavefront q finishes row tile q");
+    __shared__ __attribute__((aligned(16))) float part[KS][RT * kMlpTiles][64 * 4];   // [share][tile][lane] f32x4
+    const int lane = threadIdx.x & 63, kpart = threadIdx.x >> 6;
+    const int which = (int)blockIdx.y + first_net;
+    const WlMlp& net = which == 0 ? actor : critic;
+    const int D = net.in_dim;
+    const int m = lane & 15, g = lane >> 4;
+    const int row0 = (int)blockIdx.x * (16 * RT);
+    const uint16_t* wh = w_hi + (int64_t)(which * kMlpHidden + m) * dp + 8 * g;
+    const uint16_t* wl = w_lo + (int64_t)(which * kMlpHidden + m) * dp + 8 * g;
+    const float* x_lane[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) x_lane[q] = obs + (int64_t)min(row0 + 16 * q + m, n_rows - 1) * obs_stride + 8 * g;
+
+    f32x4 h[RT][kMlpTiles];
+#pragma unroll
+    for (int t = 0; t < kMlpTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float bias = kpart == 0 ? net.b1[16 * t + 4 * g + r] : 0.f;
+#pragma unroll
+            for (int q = 0; q < RT; ++q) h[q][t][r] = bias;
+        }
+    const int n_steps = dp >> 5, per = (n_steps + KS - 1) / KS;
+    const int s0 = min(kpart * per, n_steps), s1 = min(s0 + per, n_steps);
+    constexpr int kDepth = 2;
+    PlaneStep ra[kDepth];
+    wl_f4u rb[kDepth][RT][2];
+    auto load_step = [&](int j, int s) {
+#pragma unroll
+        for (int t = 0; t < kMlpTiles; ++t) {
+            ra[j].ah[t] = *reinterpret_cast<const u32x4_t*>(wh + (int64_t)16 * t * dp + 32 * s);
+            ra[j].al[t] = *reinterpret_cast<const u32x4_t*>(wl + (int64_t)16 * t * dp + 32 * s);
+        }
+        const int f = plane_feature(s, D);
+#pragma unroll
+        for (int q = 0; q < RT; ++q) {
+            rb[j][q][0] = *reinterpret_cast<const wl_f4u*>(x_lane[q] + f);
+            rb[j][q][1] = *reinterpret_cast<const wl_f4u*>(x_lane[q] + f + 4);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j)
+        if (s0 + j < s1) load_step(j, s0 + j);
+    // the tail's weights and the draw of the row tile this wavefront will finish: in the shadow of the operand loads
+    MlpTail W;
+    float z0 = 0.f, z1 = 0.f;
+    if (kpart < RT) {
+        load_tail(net, lane, W);
+        if (which == 0 && !deterministic) {
+            const F4 u = philox_uniform4((uint32_t)(env_offset + row0 + 16 * kpart + m), step, WL_RS_POLICY, seed);
+            box_muller(u.x, u.y, z0, z1);
+        }
+    }
+    for (int s = s0; s < s1; s += kDepth) {
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j) {
+            if (s + j < s1) {
+                bf16x8_t bh[RT], bl[RT];
+#pragma unroll
+                for (int q = 0; q < RT; ++q) {
+                    u32x4_t ph, pl;
+                    uint32_t a_, b_;
+                    split_bf16_pair(rb[j][q][0][0], rb[j][q][0][1], a_, b_); ph[0] = a_; pl[0] = b_;
+                    split_bf16_pair(rb[j][q][0][2], rb[j][q][0][3], a_, b_); ph[1] = a_; pl[1] = b_;
+                    split_bf16_pair(rb[j][q][1][0], rb[j][q][1][1], a_, b_); ph[2] = a_; pl[2] = b_;
+                    split_bf16_pair(rb[j][q][1][2], rb[j][q][1][3], a_, b_); ph[3] = a_; pl[3] = b_;
+                    bh[q] = __builtin_bit_cast(bf16x8_t, ph);
+                    bl[q] = __builtin_bit_cast(bf16x8_t, pl);
+                }
+#pragma unroll
+                for (int t = 0; t < kMlpTiles; ++t) {
+                    const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, ra[j].ah[t]), al = __builtin_bit_cast(bf16x8_t, ra[j].al[t]);
+#pragma unroll
+                    for (int q = 0; q < RT; ++q) h[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[q], h[q][t], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < RT; ++q) h[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[q], h[q][t], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < RT; ++q) h[q][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[q], h[q][t], 0, 0, 0);
+                }
+                if (s + j + kDepth < s1) load_step(j, s + j + kDepth);
+            }
+        }
+    }
+    // every share's accumulators -> LDS; wavefront q sums row tile q over the shares in a fixed order and finishes it
+#pragma unroll
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+        for (int t = 0; t < kMlpTiles; ++t) *reinterpret_cast<f32x4*>(&part[kpart][q * kMlpTiles + t][lane * 4]) = h[q][t];
+    __syncthreads();
+    if (kpart >= RT) return;
+    f32x4 hq[kMlpTiles];
+#pragma unroll
+    for (int t = 0; t < kMlpTiles; ++t) {
+        hq[t] = *reinterpret_cast<const f32x4*>(&part[0][kpart * kMlpTiles + t][lane * 4]);
+#pragma unroll
+        for (int k = 1; k < KS; ++k) hq[t] += *reinterpret_cast<const f32x4*>(&part[k][kpart * kMlpTiles + t][lane * 4]);
+    }
+    const f32x4 out = eval_tail<ACT>(W, hq, lane);
+    const int r_out = row0 + 16 * kpart + m;
+    if (g != 0 || r_out >= n_rows) return;
+    if (which == 1) {
+        values[r_out] = out[0];
+        return;
+    }
+    const float std0 = std[0], std1 = std[1];
+    reinterpret_cast<float2*>(actions)[r_out] = make_float2(fmaf(std0, z0, out[0]), fmaf(std1, z1, out[1]));
+    reinterpret_cast<float2*>(mu_out)[r_out] = make_float2(out[0], out[1]);
+    log_prob[r_out] = fmaf(-0.5f, fmaf(z0, z0, z1 * z1), -(log_fast(std0) + log_fast(std1)) - kLog2PiA);
+}
+
 int check_wide(const WlMlp* net, int out_dim) {
     if (!net || !net->w1 || !net->b1 || !net->w2 || !net->b2 || !net->w3 || !net->b3) return WL_EINVAL;
     if (net->hidden != kMlpHidden || net->in_dim < 1 || net->in_dim > (1 << 20) || net->out_dim != out_dim) return WL_EINVAL;
@@ -324,10 +460,33 @@ int wl_actor_critic_act_planes(const WlMlp* actor, const WlMlp* critic, const fl
     if ((nets & 2) && !values) return WL_EINVAL;
     if ((nets & 1) && (((uintptr_t)actions & 7u) || ((uintptr_t)mu & 7u))) return WL_EALIGN;
     if ((uintptr_t)obs & 3u) return WL_EALIGN;
-    if (!sc || !sc->w_hi || !sc->w_lo || !sc->partials || actor->in_dim < 64 || sc->dp != (actor->in_dim + 63) / 64 * 64 || sc->splits < 1 ||
-        n_rows > sc->rows_capacity)
+    if (!sc || !sc->w_hi || !sc->w_lo || !sc->partials || actor->in_dim < 64 || sc->dp != (actor->in_dim + 63) / 64 * 64 ||
+        sc->splits < (sc->dp + 127) / 128 || n_rows > sc->rows_capacity)
         return WL_EINVAL;
     if (((uintptr_t)sc->w_hi & 15u) || ((uintptr_t)sc->w_lo & 15u) || ((uintptr_t)sc->partials & 15u)) return WL_EALIGN;
+    if (sc->reserved == 0) {   // one launch: feature shares folded through LDS (reserved = 1: the two-launch split-K form below)
+        const int tiles = (n_rows + 15) / 16, n_nets = nets == 3 ? 2 : 1, first = nets == 2 ? 1 : 0;
+        const bool elu = actor->activation == WL_ACT_ELU;
+        clear_error();
+#define WL_BF16_ACT(KS, RT)                                                                                                         \
+    do {                                                                                                                            \
+        const dim3 grid((tiles + RT - 1) / RT, n_nets);                                                                             \
+        if (elu) act_bf16_kernel<WL_ACT_ELU, KS, RT><<<grid, 64 * KS, 0, (hipStream_t)stream>>>(*actor, *critic, std, n_rows, obs, obs_stride, actions, mu, log_prob, values, env_offset, seed, step, deterministic, first, sc->w_hi, sc->w_lo, sc->dp); \
+        else act_bf16_kernel<WL_ACT_RELU, KS, RT><<<grid, 64 * KS, 0, (hipStream_t)stream>>>(*actor, *critic, std, n_rows, obs, obs_stride, actions, mu, log_prob, values, env_offset, seed, step, deterministic, first, sc->w_hi, sc->w_lo, sc->dp); \
+    } while (0)
+        // rows per block by the batch (fewer re-reads of the weight planes while enough blocks remain), the feature split by the width
+        // (the feature split depends on the WIDTH only: a row's result must not depend on the batch it arrives in)
+        if (sc->dp >= 1024) {
+            if (tiles >= 96) WL_BF16_ACT(8, 2);
+            else WL_BF16_ACT(8, 1);
+        } else {
+            if (tiles >= 192) WL_BF16_ACT(4, 4);
+            else if (tiles >= 96) WL_BF16_ACT(4, 2);
+            else WL_BF16_ACT(4, 1);
+        }
+#undef WL_BF16_ACT
+        return launch_status();
+    }
     const int splits = wl_internal::layer1_partials(obs, obs_stride, n_rows, actor->in_dim, sc->dp, sc->w_hi, sc->w_lo, sc->splits,
                                                     sc->partials, (hipStream_t)stream);
     if (splits < 0) return splits;

@@ -78,14 +78,19 @@ class ActorCritic:
 
     # policy step with the first layer on the bf16 matrix pipe (wl_actor_critic_act_planes): None = by size, True / False = forced
     planes: bool | None = None
+    planes_two_launch: bool | None = None   # None = by size; the bf16 path's form: split-K partial sums + a tail launch, or one launch
 
     @staticmethod
-    def planes_pay(n: int, D: int) -> bool:
-        """where the two-launch bf16 form measured faster than the one-launch f32 kernel (tools/act_probe.py, us per step,
-        f32 kernel / bf16 form): D = 3208: 512 rows 26.5 / 18.1, 1024 27.4 / 21.3, 4096 43.6 / 40.5, 16 384 125 / 157;
-        D = 689: 512 10.7 / 12.4, 4096 15.6 / 18.5 -- the wide, short batches, where the f32 kernel re-streams the whole
-        first-layer matrix for every 16-64 rows"""
-        return D >= 1024 and n <= 4096
+    def planes_form(n: int, D: int):
+        """which policy-step kernel for n rows of D features: None = the one-launch f32 kernel, "one" / "two" = the bf16 forms.
+        Measured (tools/act_probe.py, us per step: f32 / bf16 one launch / bf16 two launches):
+          D = 3208:  512 rows 26.4 / 28.6 / 18.1,  1024: 27.9 / 28.6 / 21.2,  4096: 44.5 / 35.7 / 42.0,  16 384: 126 / 141 / 163
+          D =  689:  512 rows 10.7 / 10.2 / 12.4,  1024: 10.9 / 10.2 / 12.9,  4096: 15.6 / 15.8 / 17.9,  16 384: 38.5 / 32.5 / 45.3
+        At the agents' sizes the step is a chain of dependent round trips (launch, first operands, the feature shares, the LDS
+        fold, the 64-64 tail), so the forms differ by a few us; the f32 kernel stays the default where it is not clearly beaten."""
+        if D >= 1024:
+            return "two" if n <= 2048 else "one" if n <= 8192 else None
+        return "one" if n >= 8192 and D >= 64 else None
 
     def _scratch(self, n: int):
         """the bf16 form's device scratch (weight planes, split-K partial sums) for up to n rows"""
@@ -120,10 +125,13 @@ class ActorCritic:
             self._act_scratch = None
         a, c = self._act_structs
         stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
-        if self.planes if self.planes is not None else self.planes_pay(n, D):
+        form = self.planes_form(n, D)
+        if self.planes if self.planes is not None else form is not None:
+            two = self.planes_two_launch if self.planes_two_launch is not None else form != "one"
             lib = A.load()
             new = getattr(self, "_act_scratch", None) is None
             sc = self._scratch(n)
+            sc.reserved = int(two)
             if new or not planes_fresh:
                 A.check(lib.wl_actor_critic_planes(C.byref(a), C.byref(c), C.byref(sc), stream), "wl_actor_critic_planes")
             A.check(lib.wl_actor_critic_act_planes(C.byref(a), C.byref(c), self.std.data_ptr(), n, obs.data_ptr(), obs.stride(0),
