@@ -249,7 +249,7 @@ struct PlaneStep {
 };
 WL_DEV int plane_feature(int s, int D) { return min(64 * (s >> 1), D - 64) + 32 * (s & 1); }   // first feature of k-step s
 
-template <int ACT, int KS, int RT>
+template <int ACT, int KS, int RT, int DEPTH = 2>
 __global__ void __launch_bounds__(64 * KS) act_bf16_kernel(const WlMlp actor, const WlMlp critic, const float* __restrict__ std,
                                                            const int n_rows, const float* __restrict__ obs, const int64_t obs_stride,
                                                            float* __restrict__ actions, float* __restrict__ mu_out,
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(64 * KS) act_bf16_kernel(const WlMlp actor, co
         }
     const int n_steps = dp >> 5, per = (n_steps + KS - 1) / KS;
     const int s0 = min(kpart * per, n_steps), s1 = min(s0 + per, n_steps);
-    constexpr int kDepth = 2;
+    constexpr int kDepth = DEPTH;
     PlaneStep ra[kDepth];
     wl_f4u rb[kDepth][RT][2];
     auto load_step = [&](int j, int s) {
