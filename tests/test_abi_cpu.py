@@ -146,3 +146,66 @@ def test_product_does_not_import_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
                     bad.append(f)
     assert not bad
+
+
+def test_layout_of_learner_structs_and_their_argument_checks(tmp_path):
+    """round-2 structs (startup randomisation, policy-step scratch, wide PPO state, collection rows) match the header, the
+    learner constants agree, and the wide entry points refuse misuse before any launch (no GPU needed)"""
+    probe = tmp_path / "probe3.c"
+    probe.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "wheeledlab_amd.h"\n'
+        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %d %d %d %d\\n\", sizeof(WlStartupParams), sizeof(WlActScratch),"
+        " sizeof(WlPpoWideState), sizeof(WlCollectIo), sizeof(WlPpoBatch), sizeof(WlPpoParams), sizeof(WlPpoState),"
+        " offsetof(WlPpoWideState, in_dim), offsetof(WlActScratch, dp), (int)WL_PPO_NUM_PARAMS, (int)WL_PPO_PARTIAL_STRIDE,"
+        " (int)WL_PPO_OPERAND_FLOATS, (int)WL_ABI_VERSION);return 0;}\n")
+    exe = tmp_path / "probe3"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [C.sizeof(A.WlStartupParams), C.sizeof(A.WlActScratch), C.sizeof(A.WlPpoWideState), C.sizeof(A.WlCollectIo),
+            C.sizeof(A.WlPpoBatch), C.sizeof(A.WlPpoParams), C.sizeof(A.WlPpoState), A.WlPpoWideState.in_dim.offset,
+            A.WlActScratch.dp.offset, A.PPO_NUM_PARAMS, A.PPO_PARTIAL_STRIDE, A.PPO_OPERAND_FLOATS, A.WL_ABI_VERSION]
+    assert got == want
+    _ensure_built()
+    lib = A.load()
+    # flat parameter count of the D-64-64-2 / D-64-64-1 pair (std included): the drift agents' constant at D = 14
+    assert lib.wl_ppo_wide_num_params(14) == A.PPO_NUM_PARAMS
+    assert lib.wl_ppo_wide_num_params(689) == 2 + 2 * (64 * 689 + 64 + 64 * 64 + 64) + 3 * 64 + 3
+    buf = (C.c_float * 4096)()
+    base = C.addressof(buf)
+    mlp = lambda d, o: A.WlMlp(base, base, base, base, base, base, d, o, 64, 1)
+    a, c = mlp(689, 2), mlp(689, 1)
+    st = A.WlPpoWideState(*([base] * 15), 689, 704, 1024, 512, 8)
+    bt = A.WlPpoBatch(*([base] * 9))
+    hp = A.WlPpoParams(0.2, 1.0, 0.005, 0.01, 1.0, 0.9, 0.999, 1e-8, 1e-5, 1e-2, 1, 1)
+    call = lambda s, start, size, actor=a: lib.wl_ppo_wide_gradients(C.byref(actor), C.byref(c), base, C.byref(bt), start, size,
+                                                                     C.byref(hp), C.byref(s), 0, None)
+    assert call(st, 32, 512) == -1                 # minibatch starts are multiples of 64
+    assert call(st, 0, 500) == -1                  # ... and sizes
+    assert call(st, 768, 512) == -1                # runs past the staged rows
+    assert call(st, 0, 1024) == -1                 # larger than the minibatch capacity
+    wrong_dp = A.WlPpoWideState(*([base] * 15), 689, 768, 1024, 512, 8)
+    assert call(wrong_dp, 0, 512) == -1            # dp is D rounded up to 64
+    assert call(st, 0, 512, actor=mlp(600, 2)) == -1   # the nets' width must be the state's
+    assert lib.wl_ppo_wide_stage(base, base, 1000, C.byref(st), None) == -1          # rows are staged 64 at a time
+    sc = A.WlActScratch(base, base, base, 704, 5, 4096, 0)                            # needs ceil(704 / 128) = 6 partial-sum rows
+    assert lib.wl_actor_critic_act_planes(C.byref(a), C.byref(c), base, 128, base, 689, base, base, base, base, 0, 1, 2, 0, 3,
+                                          C.byref(sc), None) == -1
+    io = A.WlCollectIo(base, base, base, base, base)
+    out = A.WlStepOut(base, base, base, base, None)
+    ep = PP.elev_params()
+    big = A.WlEnvBuffers(state=base, episode_len=base, ref_poses=base, metrics=base, stride=65536, n_envs=65536, env_offset=0,
+                         metrics_slots=1)
+    assert lib.wl_elev_collect_step(C.byref(ep), C.byref(big), None, C.byref(a), C.byref(c), base, C.byref(io), C.byref(out), 0, 1, 2,
+                                    None) == -1       # no heightfield (and beyond the quad form)
+
+
+def test_host_rules_of_the_wide_learner_and_the_policy_step_forms():
+    """pure host logic: split-K factor of the dW1 contraction and the policy-step form by size (tables in DESIGN.md section 6)"""
+    from wheeledlab_amd.policy import ActorCritic as KernelAC
+    from wheeledlab_amd.rl.ppo import FusedWidePpoStep as F
+    assert F.pick_splits(704, 131072) == 128 and F.pick_splits(3264, 32768) == 16      # elevation / visual agents
+    assert F.pick_splits(704, 6400) == 100 and F.pick_splits(64, 512) == 8             # never more splits than K chunks
+    assert F.shapes_ok(524288, 131072) and not F.shapes_ok(1000, 500)
+    form = KernelAC.planes_form
+    assert form(4096, 689) is None and form(16384, 689) == "one" and form(1024, 3208) == "two" and form(4096, 3208) == "one"
+    assert form(16384, 3208) is None and form(100000, 40) is None
