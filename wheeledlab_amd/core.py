@@ -142,9 +142,11 @@ class DriftBatch(_MetricsView):
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
         if obs_out is not None:
-            out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(),
-                              None if dones_out is None else dones_out.data_ptr())
-            os_, vs_ = self.n * self.OBS_DIM, self.n
+            key = (obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(),
+                   None if dones_out is None else dones_out.data_ptr())
+            if getattr(self, "_out_key", None) != key:      # the struct of the caller's storage rows, rebuilt when they change
+                self._out_key, self._out_rows = key, A.WlStepOut(*key)
+            out, os_, vs_ = self._out_rows, self.n * self.OBS_DIM, self.n
         else:
             out, os_, vs_ = self._out, 0, 0
         fn = self.lib.wl_drift_rollout_persistent if persistent else self.lib.wl_drift_rollout
