@@ -46,6 +46,8 @@ def main():
     ap.add_argument("-r", "--run-config-name", default="RSS_DRIFT_CONFIG")
     ap.add_argument("--stepwise", action="store_true", help="one launch per env.step() with a torch actor")
     ap.add_argument("--torch-policy", action="store_true", help="per-step collection with the policy step in torch eager")
+    ap.add_argument("--torch-learner", action="store_true", help="PPO.update in torch (autograd + Adam) instead of the HIP learner")
+    ap.add_argument("--history-out", default=None, help="write the per-iteration history (JSON) here")
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("overrides", nargs="*", help="Hydra-style key=value overrides")
     args = ap.parse_args()
@@ -80,6 +82,8 @@ def main():
     env = RslRlVecEnvWrapper(ClipAction(env))
     if not log_cfg.no_checkpoints:
         agent_cfg.save_interval = min(agent_cfg.save_interval, log_cfg.checkpoint_every)
+    if args.torch_learner:
+        agent_cfg.algorithm.fused_update = False
     runner = OnPolicyRunner(env, agent_cfg, log_dir=None if log_cfg.no_checkpoints else log_dir, device=train_cfg.device,
                             fused=False if args.stepwise else None, kernel_policy=False if args.torch_policy else None)
     if world > 1:
@@ -96,6 +100,9 @@ def main():
     hist = runner.learn(train_cfg.num_iterations, verbose=not args.quiet)
     if log_dir:
         with open(os.path.join(log_dir, "history.json"), "w") as f:
+            json.dump(hist, f)
+    if args.history_out and rank == 0:
+        with open(args.history_out, "w") as f:
             json.dump(hist, f)
     first, last = hist[0], hist[-1]
     # replicated state must not have drifted apart (identical averaged gradients -> identical steps on every rank)
