@@ -159,12 +159,36 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
         s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
         s.wb = mul_t(R, ww);
     }
+    // Bookkeeping rows (episode length, goal command, episode sums): the lane form fetches them after the physics loop --
+    // it runs several wavefronts per SIMD and the registers are worth more than the latency; the quad form is one wavefront
+    // per SIMD with registers to spare, so it requests them BEFORE the loop and finds them landed behind it.
+    int ep_len_in = 0;
+    float cb_in[2] = {0.f, 0.f}, epsum_in[WL_ER_NTERMS], tgt_in[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < WL_ER_NTERMS; ++i) epsum_in[i] = 0.f;
+    auto fetch_bookkeeping = [&]() {
+        ep_len_in = b.episode_len[e];
+        cb_in[0] = S.ld(WL_S_CMD_BX, e);
+        cb_in[1] = S.ld(WL_S_CMD_BY, e);
+        if (p.log_episode_sums) {
+#pragma unroll
+            for (int i = 0; i < WL_ER_NTERMS; ++i) epsum_in[i] = S.ld(WL_S_EPSUM0 + i, e);
+        }
+        tgt_in[0] = S.ld(WL_S_TGT_X, e);
+        tgt_in[1] = S.ld(WL_S_TGT_Y, e);
+        tgt_in[2] = S.ld(WL_S_TGT_H, e);
+        tgt_in[3] = S.ld(WL_S_CMD_TIMER, e);
+    };
+    if constexpr (LANES == 4) fetch_bookkeeping();
     vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
-    asm volatile("" ::: "memory");   // bookkeeping rows are fetched after the physics loop (register pressure)
+    if constexpr (LANES != 4) {
+        asm volatile("" ::: "memory");
+        fetch_bookkeeping();
+    }
     const Mat3 R = mat_from_quat(s.q);
     ww = mul(R, s.wb);
     pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
-    int ep_len = b.episode_len[e] + 1;
+    int ep_len = ep_len_in + 1;
     const bool truncated = ep_len >= p.max_episode_length;
     float wheel_sum;
     if constexpr (LANES == 1) wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
@@ -174,7 +198,7 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
     const bool finite = __builtin_isfinite(chk);
     const V3 vb = mul_t(R, s.v);
     // terminations / rewards use the command as the PREVIOUS step's command update left it (IsaacLab step order)
-    float cbx = S.ld(WL_S_CMD_BX, e), cby = S.ld(WL_S_CMD_BY, e);
+    float cbx = cb_in[0], cby = cb_in[1];
     const ElevTerms tm = elev_terms(p, pos, R.r2.z, vb, s.v, wheel_sum, cbx, cby, truncated);
     const bool terminated = !finite || tm.flag[0] || tm.flag[1] || tm.flag[2] || tm.flag[3];
     const float step_dt = p.sim_dt * (float)p.decimation;
@@ -185,7 +209,7 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
         const float w = p.weight[i];
         const float c = (w != 0.f && finite) ? tm.t[i] * w * step_dt : 0.f;
         reward += c;
-        epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;
+        epsum[i] = p.log_episode_sums ? epsum_in[i] + c : 0.f;
     }
     if (lead) {
         out.reward[e] = reward;
@@ -194,7 +218,7 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
         if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
     }
     float a0 = a.x, a1 = a.y;
-    float tgt_x = S.ld(WL_S_TGT_X, e), tgt_y = S.ld(WL_S_TGT_Y, e), tgt_h = S.ld(WL_S_TGT_H, e), cmd_timer = S.ld(WL_S_CMD_TIMER, e);
+    float tgt_x = tgt_in[0], tgt_y = tgt_in[1], tgt_h = tgt_in[2], cmd_timer = tgt_in[3];
     if (terminated || truncated) {
         if (lead) {
 #pragma unroll

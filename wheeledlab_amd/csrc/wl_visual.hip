@@ -124,12 +124,29 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
             s.wb = mul_t(R, ww);
         }
         const FlatGround ground{};
+        // bookkeeping rows: the quad form (one wavefront per SIMD, registers to spare) requests them BEFORE the physics loop
+        // and finds them landed behind it; the lane form fetches them after it (registers are worth more there)
+        int ep_len_in = 0;
+        float epsum_in[WL_VR_NTERMS];
+#pragma unroll
+        for (int i = 0; i < WL_VR_NTERMS; ++i) epsum_in[i] = 0.f;
+        auto fetch_bookkeeping = [&]() {
+            ep_len_in = b.episode_len[e];
+            if (p.log_episode_sums) {
+#pragma unroll
+                for (int i = 0; i < WL_VR_NTERMS; ++i) epsum_in[i] = S.ld(WL_S_EPSUM0 + i, e);
+            }
+        };
+        if constexpr (LANES == 4) fetch_bookkeeping();
         vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
-        asm volatile("" ::: "memory");
+        if constexpr (LANES != 4) {
+            asm volatile("" ::: "memory");
+            fetch_bookkeeping();
+        }
         const Mat3 R = mat_from_quat(s.q);
         ww = mul(R, s.wb);
         pos = s.x - vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
-        int ep_len = b.episode_len[e] + 1;
+        int ep_len = ep_len_in + 1;
         const bool truncated = ep_len >= p.max_episode_length;
         float wheel_sum;
         if constexpr (LANES == 1) wheel_sum = s.wheel[0] + s.wheel[1] + s.wheel[2] + s.wheel[3];
@@ -151,7 +168,7 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
             const float w = p.weight[i];
             const float c = (w != 0.f && finite) ? t[i] * w * step_dt : 0.f;
             reward += c;
-            epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) + c : 0.f;
+            epsum[i] = p.log_episode_sums ? epsum_in[i] + c : 0.f;
         }
         if (lead) {
             out.reward[e] = reward;
