@@ -127,11 +127,39 @@ struct ScanPose {
     float px, py, pz, c, s;
 };
 
+// the dynamic rows of an env as the step needs them at its start (requested in one go, ahead of the parameter block)
+template <int LANES>
+struct ElevRows {
+    float mass, mu_s, mu_d, damp;
+    V3 pos, v, ww;
+    Quat q;
+    float wheel[LANES == 1 ? 4 : 1];
+    float th, om;
+};
+template <int LANES>
+WL_DEV ElevRows<LANES> load_elev_rows(const Rows& S, int e, int wid) {
+    ElevRows<LANES> r;
+    r.mass = S.ld(WL_S_MASS, e), r.mu_s = S.ld(WL_S_MU_S, e), r.mu_d = S.ld(WL_S_MU_D, e), r.damp = S.ld(WL_S_DAMP, e);
+    r.pos = ld3(S, WL_S_PX, e);
+    r.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+    r.v = ld3(S, WL_S_VX, e);
+    r.ww = ld3(S, WL_S_WX, e);
+    if constexpr (LANES == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
+    } else {
+        r.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
+    }
+    r.th = S.ld(WL_S_STEER_POS, e);
+    r.om = S.ld(WL_S_STEER_VEL, e);
+    return r;
+}
+
 // one env.step() of env `e` (all LANES lanes of the env take part): the body of the step kernels below
 template <int LANES>
 WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const WlEnvBuffers& b, const HeightFieldGround& ground,
-                              const float2 action, const WlStepOut& out, const uint64_t seed, const uint64_t step,
-                              const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics) {
+                              const float2 action, const ElevRows<LANES>& rows, const WlStepOut& out, const uint64_t seed,
+                              const uint64_t step, const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics) {
     const WlVehicleParams& vp = p.vehicle;
     const uint32_t gid = (uint32_t)(b.env_offset + e);
     float2 a = action;
@@ -139,21 +167,17 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
     process_action(p.action, a.x, a.y, v_t, delta);
     EnvConst ec;
     joint_targets(p.action, v_t, delta, ec.steer_target, ec.wheel_target);
-    env_const_rows(ec, vp, vd, S.ld(WL_S_MASS, e), S.ld(WL_S_MU_S, e), S.ld(WL_S_MU_D, e), S.ld(WL_S_DAMP, e));
+    env_const_rows(ec, vp, vd, rows.mass, rows.mu_s, rows.mu_d, rows.damp);
     if constexpr (LANES == 4) env_const_lane(ec, vp, vd, wid);
     VehState s;
-    V3 pos = ld3(S, WL_S_PX, e);
-    s.q = Quat{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
-    s.v = ld3(S, WL_S_VX, e);
-    V3 ww = ld3(S, WL_S_WX, e);
-    if constexpr (LANES == 1) {
+    V3 pos = rows.pos;
+    s.q = rows.q;
+    s.v = rows.v;
+    V3 ww = rows.ww;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s.wheel[i] = S.ld(WL_S_WHEEL_BL + i, e);
-    } else {
-        s.wheel[0] = S.ld(WL_S_WHEEL_BL + wid, e);
-    }
-    s.th = S.ld(WL_S_STEER_POS, e);
-    s.om = S.ld(WL_S_STEER_VEL, e);
+    for (int i = 0; i < (LANES == 1 ? 4 : 1); ++i) s.wheel[i] = rows.wheel[i];
+    s.th = rows.th;
+    s.om = rows.om;
     {
         const Mat3 R = mat_from_quat(s.q);
         s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
@@ -328,7 +352,7 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
     __syncthreads();
     const Rows S = make_rows(b.state, b.stride);
     if (e < b.n_envs) {
-        (void)elev_env_step<LANES>(p, vd, b, ground, actions[e], out, seed, step, S, e, wid, lead, blk_metrics);
+        (void)elev_env_step<LANES>(p, vd, b, ground, actions[e], load_elev_rows<LANES>(S, e, wid), out, seed, step, S, e, wid, lead, blk_metrics);
     }
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
@@ -381,7 +405,7 @@ __global__ void __launch_bounds__(kBlock) elev_scan_kernel(const WlElevParams p,
 
 // env.step() AND the height scan as ONE launch (quad form, n <= 32 768): block = 16 envs, 8 wavefronts.  Wavefront 0
 // steps them (16 quads, as in elev_step_kernel<4>) and leaves each env's post-step pose in LDS; then all eight
-// wavefronts cast the 16 x 676 rays (flat index over (env, ray): 21.1 per lane, in two batches of gathers).  Against the
+// wavefronts cast the 16 x 676 rays (flat index over (env, ray): 21.1 per lane, in three batches of gathers).  Against the
 // two-launch form this removes the scan kernel's own start (launch gap, wave ramp, the pose rows' first-touch latency)
 // from the step's dependent chain, and one physics wavefront per CU spreads the step over 256 CUs instead of 64 (4096 envs).
 constexpr int kFusedThreads = 512, kFusedEnvs = 16;
@@ -520,16 +544,37 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     }
     __syncthreads();
     if (tid < 64) {
-        WlElevParams p = kernarg_vector_copy<WlElevParams>(0);   // one batch of vector loads instead of dependent scalar round trips
-        keep_scalar_common(p, p_arg);
-        VehDerived vd = kernarg_vector_copy<VehDerived>((int)sizeof(WlElevParams));
-        vd.n_sub = vd_arg.n_sub;
         const int wid = tid & 3, e = e0 + (tid >> 2);
         if (e < b.n_envs) {
+            // ONE memory round trip in front of the physics instead of four in series (parameter block, derived block, action,
+            // state rows -- each waited for where it was first used): the state rows and the action are requested first (they
+            // need only scalar arguments), the two argument structs right behind them as one burst, and a basic-block boundary
+            // keeps the instruction selector from sinking the requests back to their first uses (as in drift_step_kernel).
+            // (the action through a buffer resource, like the state rows: as a plain global load the scheduler parked it behind
+            // the parameter block, waiting for a register the burst still had in flight -- a second round trip)
+            float2 a;
+            if constexpr (POLICY) {
+                a = act_lds[tid >> 2];
+            } else {
+                float2* ap = const_cast<float2*>(actions);
+                asm volatile("" : "+s"(ap));   // launder the read-only / no-alias argument: its loads are otherwise free to cross the boundary below
+                const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(ap, 0, b.n_envs * 8, 0x00020000);
+                a.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ar, e * 8, 0, 0));
+                a.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ar, e * 8, 4, 0));
+            }
             const Rows S = make_rows(b.state, b.stride);
-            const float2 a = POLICY ? act_lds[tid >> 2] : actions[e];
-            const ScanPose sp = elev_env_step<4>(p, vd, b, ground, a, out, seed, step, S, e, wid, wid == 0, blk_metrics);
-            if (wid == 0) pose[tid >> 2] = sp;
+            const ElevRows<4> rows = load_elev_rows<4>(S, e, wid);
+            WlElevParams p;
+            VehDerived vd;
+            kernarg_vector_copy2(0, p, vd);
+            int go = 1;
+            asm volatile("" : "+s"(go) : : "memory");
+            if (go) {
+                keep_scalar_common(p, p_arg);
+                vd.n_sub = vd_arg.n_sub;
+                const ScanPose sp = elev_env_step<4>(p, vd, b, ground, a, rows, out, seed, step, S, e, wid, wid == 0, blk_metrics);
+                if (wid == 0) pose[tid >> 2] = sp;
+            }
         }
     }
     __syncthreads();
@@ -540,11 +585,13 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     // ---- the scan ----
     const WlElevParams& p = p_arg;
     constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N, kAll = kFusedEnvs * kRays;
-    constexpr int kSlots = (kAll + kFusedThreads - 1) / kFusedThreads, kBatch = (kSlots + 1) / 2;
+    // (rays per lane in 1 / 2 / 3 batches of gathers: 28.4 / 26.2 / 25.9 us per step at 4096 envs -- one batch needs 256 VGPRs)
+    constexpr int kScanBatches = 3;
+    constexpr int kSlots = (kAll + kFusedThreads - 1) / kFusedThreads, kBatch = (kSlots + kScanBatches - 1) / kScanBatches;
     const int n_here = min(kFusedEnvs, b.n_envs - e0);
     const float g0 = -0.5f * p.scan_size;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < kScanBatches; ++half) {
         HeightFieldGround::Corners cr[kBatch];
         float pz[kBatch];
 #pragma unroll
