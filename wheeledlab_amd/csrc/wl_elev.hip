@@ -337,9 +337,8 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
     WlElevParams p = p_arg;
     VehDerived vd = vd_arg;
     if constexpr (LANES == 4) {   // latency form: one batch of vector loads instead of dependent scalar-load round trips
-        p = kernarg_vector_copy<WlElevParams>(0);
+        kernarg_vector_copy2(0, p, vd);
         keep_scalar_common(p, p_arg);
-        vd = kernarg_vector_copy<VehDerived>((int)sizeof(WlElevParams));
         vd.n_sub = vd_arg.n_sub;
     }
     constexpr int kEnvs = kBlock / LANES;

@@ -81,9 +81,8 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
     WlVisualParams p = p_arg;
     VehDerived vd = vd_arg;
     if constexpr (LANES == 4) {   // latency form: one batch of vector loads instead of dependent scalar-load round trips
-        p = kernarg_vector_copy<WlVisualParams>(0);
+        kernarg_vector_copy2(0, p, vd);   // both argument structs as ONE burst (two copies: a wait in the middle, see the helper)
         keep_scalar_common(p, p_arg);
-        vd = kernarg_vector_copy<VehDerived>((int)sizeof(WlVisualParams));
         vd.n_sub = vd_arg.n_sub;
     }
     constexpr int kEnvs = (LANES == 4 ? QB : kBlock) / LANES;
