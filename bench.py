@@ -431,7 +431,25 @@ def main():
             torch.cuda.synchronize()
             us = q0.elapsed_time(q1) * 1e3 / (4 * k)
             other[name] = {"us_per_step": us, "env_steps_per_s": n / (us * 1e-6), "obs_dim": t.OBS_DIM,
-                           "obs_GBs": n * t.OBS_DIM * 4 / (us * 1e-6) / 1e9}
+                           "obs_GBs": n * t.OBS_DIM * 4 / (us * 1e-6) / 1e9, "launches": "one per env.step()" if name == "elevation"
+                           else "two per env.step() (step, camera)"}
+            if name == "elevation" and n <= 32768:
+                # open-loop rollouts (pre-staged actions) as ONE launch: state in registers, the height scan of step k while
+                # step k + 1 is integrated (wl_elev_rollout_persistent; same results bit for bit)
+                po = torch.zeros(k, n, t.OBS_DIM, device=dev)
+                pr = torch.zeros(k, n, device=dev)
+                pt, pu = torch.zeros(k, n, dtype=torch.bool, device=dev), torch.zeros(k, n, dtype=torch.bool, device=dev)
+                t.rollout(a, po, pr, pt, pu, persistent=True)
+                torch.cuda.synchronize()
+                q0.record()
+                for _ in range(4):
+                    t.rollout(a, po, pr, pt, pu, persistent=True)
+                q1.record()
+                torch.cuda.synchronize()
+                pus = q0.elapsed_time(q1) * 1e3 / (4 * k)
+                other[name]["persistent_rollout_us_per_step"] = pus
+                other[name]["persistent_rollout_env_steps_per_s"] = n / (pus * 1e-6)
+                del po, pr, pt, pu
             # the agent's policy step on this observation width (actor -> sample -> log-prob + critic value) as ONE launch
             # (wl_actor_critic_act: the first layers as skinny fp32 GEMMs on the matrix pipe)
             from wheeledlab_amd.policy import ActorCritic as KernelAC

@@ -511,6 +511,15 @@ int wl_elev_mdp(const WlElevParams* p, int32_t n, int64_t stride, const float* p
                 const uint8_t* timed_out, int32_t n_rays, const float* sensor_z, const float* hit_z, float* terms,
                 uint8_t* flags, float* goal_rel, float* height_map, void* stream);
 
+/* wl_elev_rollout as ONE launch for open-loop rollouts (pre-staged actions): the envs' rows stay in registers across the
+ * n_steps steps and the height scan of step k runs while step k + 1 is integrated (the actions do not depend on the
+ * observations).  Same results as wl_elev_rollout bit for bit.  Quad form only (n_envs <= 32 768, else WL_EINVAL); with more
+ * than one step the per-step observation rows must be distinct (obs_step_stride >= n_envs * WL_ELEV_OBS_DIM).  Episode metrics
+ * of all steps go to ring slot (step0 % slots), slot ((step0 + n_steps) % slots) is cleared (as wl_drift_rollout_persistent). */
+int wl_elev_rollout_persistent(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* actions,
+                               const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps, uint64_t seed,
+                               uint64_t step0, void* stream);
+
 /* ---- the runner's collection step in ONE launch, elevation task (policy in the loop) -------------------
  * modified_rsl_rl_runner.py:70-80 per step: actions = alg.act(obs) -> obs, rewards, dones = env.step(actions) -> storage.
  * `io` are rows k of an rsl_rl RolloutStorage: the observation row the policy reads and the action / mean / log-prob /

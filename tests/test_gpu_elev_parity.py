@@ -164,3 +164,38 @@ def test_elev_full_size_properties(n):
     # cars ride on the terrain (root within a few cm of the surface unless airborne right after a reset)
     riding = (env.episode_len[:n] > 5).cpu().numpy() & sel
     assert np.abs(st[2].cpu().numpy()[riding] - z_t[riding]).max() < 0.12
+
+
+@pytest.mark.parametrize("n,K,slots", [(4096, 24, 1), (1000, 7, 1), (256, 5, 4)])
+def test_persistent_rollout_equals_stepping(n, K, slots):
+    """wl_elev_rollout_persistent (K steps in one launch: state in registers, the scan of step k overlapped with the
+    integration of step k + 1) against wl_elev_rollout (a launch per step): every output row and the final state bit for bit,
+    the episode metrics to summation order -- incl. in-rollout resets, a partly filled last block (n = 1000) and the metric ring"""
+    from wheeledlab_amd.core import ElevBatch
+    ea, eb = ElevBatch(n, device=DEV, seed=21, metrics_slots=slots), ElevBatch(n, device=DEV, seed=21, metrics_slots=1)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    for e in (ea, eb):
+        e.reset()
+        e.episode_len[:n] = torch.randint(0, 248, (n,), device=DEV, dtype=torch.int32, generator=torch.Generator(device=DEV).manual_seed(1))
+    a = torch.rand(K, n, 2, device=DEV, generator=g) * 2 - 1
+    outs = []
+    for e, persistent in ((ea, True), (eb, False)):
+        obs = torch.zeros(K, n, e.OBS_DIM, device=DEV)
+        rew = torch.zeros(K, n, device=DEV)
+        term = torch.zeros(K, n, dtype=torch.bool, device=DEV)
+        trunc = torch.zeros(K, n, dtype=torch.bool, device=DEV)
+        dones = torch.zeros(K, n, dtype=torch.long, device=DEV)
+        e.rollout(a, obs, rew, term, trunc, dones_out=dones, persistent=persistent)
+        outs.append((obs, rew, term, trunc, dones))
+    torch.cuda.synchronize()
+    for x, y, name in zip(outs[0], outs[1], ("obs", "reward", "terminated", "truncated", "dones")):
+        assert torch.equal(x, y), name
+    assert torch.equal(ea.state, eb.state) and torch.equal(ea.episode_len, eb.episode_len) and ea.step_count == eb.step_count == K
+    assert int(outs[0][4].sum()) > 0
+    # episode metrics: the same events, summed in a different order (K steps folded in LDS before they reach the shards) --
+    # counts exact, float sums to rounding; with a ring the one launch books all K steps into the first step's slot
+    ma, mb = ea.metrics_raw.sum((0, 1)), eb.metrics_raw.sum((0, 1))
+    if slots > 1:
+        assert float(ea.metrics_raw[1:].abs().sum()) == 0.0
+    torch.testing.assert_close(ma, mb, rtol=1e-5, atol=1e-3)
+    assert torch.equal(ma[8:12], mb[8:12]) and float(ma[8]) == float(outs[0][4].sum())      # resets, time-outs, first two terminations

@@ -155,11 +155,71 @@ WL_DEV ElevRows<LANES> load_elev_rows(const Rows& S, int e, int wid) {
     return r;
 }
 
-// one env.step() of env `e` (all LANES lanes of the env take part): the body of the step kernels below
+// the bookkeeping rows of an env (episode length, goal command, episode sums) + the last action: with ElevRows everything a
+// persistent rollout carries in registers from step to step
+struct ElevBook {
+    int ep_len;
+    float cb[2], epsum[WL_ER_NTERMS], tgt[4];   // tgt: target x, y, heading, resample timer
+    float act[2];
+};
 template <int LANES>
+WL_DEV void store_elev_state(const WlElevParams& p, const WlEnvBuffers& b, const Rows& S, int e, int wid, bool lead,
+                             const ElevRows<LANES>& r, const ElevBook& k) {
+    if constexpr (LANES == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, r.wheel[i]);
+    } else {
+        S.st(WL_S_WHEEL_BL + wid, e, r.wheel[0]);
+    }
+    if (lead) {
+        st3(S, WL_S_PX, e, r.pos);
+        S.st(WL_S_QW, e, r.q.w);
+        S.st(WL_S_QX, e, r.q.x);
+        S.st(WL_S_QY, e, r.q.y);
+        S.st(WL_S_QZ, e, r.q.z);
+        st3(S, WL_S_VX, e, r.v);
+        st3(S, WL_S_WX, e, r.ww);
+        S.st(WL_S_STEER_POS, e, r.th);
+        S.st(WL_S_STEER_VEL, e, r.om);
+        S.st(WL_S_ACT0, e, k.act[0]);
+        S.st(WL_S_ACT1, e, k.act[1]);
+        if (p.log_episode_sums) {
+#pragma unroll
+            for (int i = 0; i < WL_ER_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, k.epsum[i]);
+        }
+        S.st(WL_S_CMD_BX, e, k.cb[0]);
+        S.st(WL_S_CMD_BY, e, k.cb[1]);
+        S.st(WL_S_TGT_X, e, k.tgt[0]);
+        S.st(WL_S_TGT_Y, e, k.tgt[1]);
+        S.st(WL_S_TGT_H, e, k.tgt[2]);
+        S.st(WL_S_CMD_TIMER, e, k.tgt[3]);
+        b.episode_len[e] = k.ep_len;
+    }
+}
+template <int LANES>
+WL_DEV ElevBook load_elev_book(const WlElevParams& p, const WlEnvBuffers& b, const Rows& S, int e) {
+    ElevBook k;
+    k.ep_len = b.episode_len[e];
+    k.cb[0] = S.ld(WL_S_CMD_BX, e);
+    k.cb[1] = S.ld(WL_S_CMD_BY, e);
+#pragma unroll
+    for (int i = 0; i < WL_ER_NTERMS; ++i) k.epsum[i] = p.log_episode_sums ? S.ld(WL_S_EPSUM0 + i, e) : 0.f;
+    k.tgt[0] = S.ld(WL_S_TGT_X, e);
+    k.tgt[1] = S.ld(WL_S_TGT_Y, e);
+    k.tgt[2] = S.ld(WL_S_TGT_H, e);
+    k.tgt[3] = S.ld(WL_S_CMD_TIMER, e);
+    k.act[0] = k.act[1] = 0.f;
+    return k;
+}
+
+// one env.step() of env `e` (all LANES lanes of the env take part): the body of the step kernels below.
+// PERSIST: the env's rows and bookkeeping live in `rows` / `*carry` across calls (persistent rollout): nothing is loaded
+// from or stored to the state matrix here, both are updated in place.
+template <int LANES, bool PERSIST = false>
 WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const WlEnvBuffers& b, const HeightFieldGround& ground,
-                              const float2 action, const ElevRows<LANES>& rows, const WlStepOut& out, const uint64_t seed,
-                              const uint64_t step, const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics) {
+                              const float2 action, ElevRows<LANES>& rows, const WlStepOut& out, const uint64_t seed,
+                              const uint64_t step, const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics,
+                              ElevBook* carry = nullptr) {
     const WlVehicleParams& vp = p.vehicle;
     const uint32_t gid = (uint32_t)(b.env_offset + e);
     float2 a = action;
@@ -191,6 +251,15 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
 #pragma unroll
     for (int i = 0; i < WL_ER_NTERMS; ++i) epsum_in[i] = 0.f;
     auto fetch_bookkeeping = [&]() {
+        if constexpr (PERSIST) {
+            ep_len_in = carry->ep_len;
+            cb_in[0] = carry->cb[0], cb_in[1] = carry->cb[1];
+#pragma unroll
+            for (int i = 0; i < WL_ER_NTERMS; ++i) epsum_in[i] = carry->epsum[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tgt_in[i] = carry->tgt[i];
+            return;
+        }
         ep_len_in = b.episode_len[e];
         cb_in[0] = S.ld(WL_S_CMD_BX, e);
         cb_in[1] = S.ld(WL_S_CMD_BY, e);
@@ -290,35 +359,19 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
         cbx = fmaf(c, dx, sn * dy);
         cby = fmaf(-sn, dx, c * dy);
     }
-    if constexpr (LANES == 1) {
+    {   // the env's new rows: kept (persistent rollout) or written back
+        rows.pos = pos, rows.q = s.q, rows.v = s.v, rows.ww = ww, rows.th = s.th, rows.om = s.om;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) S.st(WL_S_WHEEL_BL + i, e, s.wheel[i]);
-    } else {
-        S.st(WL_S_WHEEL_BL + wid, e, s.wheel[0]);
-    }
-    if (lead) {
-        st3(S, WL_S_PX, e, pos);
-        S.st(WL_S_QW, e, s.q.w);
-        S.st(WL_S_QX, e, s.q.x);
-        S.st(WL_S_QY, e, s.q.y);
-        S.st(WL_S_QZ, e, s.q.z);
-        st3(S, WL_S_VX, e, s.v);
-        st3(S, WL_S_WX, e, ww);
-        S.st(WL_S_STEER_POS, e, s.th);
-        S.st(WL_S_STEER_VEL, e, s.om);
-        S.st(WL_S_ACT0, e, a0);
-        S.st(WL_S_ACT1, e, a1);
-        if (p.log_episode_sums) {
+        for (int i = 0; i < (LANES == 1 ? 4 : 1); ++i) rows.wheel[i] = s.wheel[i];
+        ElevBook k;
+        k.ep_len = ep_len;
+        k.cb[0] = cbx, k.cb[1] = cby;
 #pragma unroll
-            for (int i = 0; i < WL_ER_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
-        }
-        S.st(WL_S_CMD_BX, e, cbx);
-        S.st(WL_S_CMD_BY, e, cby);
-        S.st(WL_S_TGT_X, e, tgt_x);
-        S.st(WL_S_TGT_Y, e, tgt_y);
-        S.st(WL_S_TGT_H, e, tgt_h);
-        S.st(WL_S_CMD_TIMER, e, cmd_timer);
-        b.episode_len[e] = ep_len;
+        for (int i = 0; i < WL_ER_NTERMS; ++i) k.epsum[i] = epsum[i];
+        k.tgt[0] = tgt_x, k.tgt[1] = tgt_y, k.tgt[2] = tgt_h, k.tgt[3] = cmd_timer;
+        k.act[0] = a0, k.act[1] = a1;
+        if constexpr (PERSIST) *carry = k;
+        else store_elev_state<LANES>(p, b, S, e, wid, lead, rows, k);
     }
     // proprioceptive part of the observation, from the post-reset state (all lanes of a quad take part)
     const Mat3 R2 = mat_from_quat(s.q);
@@ -351,7 +404,8 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
     __syncthreads();
     const Rows S = make_rows(b.state, b.stride);
     if (e < b.n_envs) {
-        (void)elev_env_step<LANES>(p, vd, b, ground, actions[e], load_elev_rows<LANES>(S, e, wid), out, seed, step, S, e, wid, lead, blk_metrics);
+        ElevRows<LANES> rows = load_elev_rows<LANES>(S, e, wid);
+        (void)elev_env_step<LANES>(p, vd, b, ground, actions[e], rows, out, seed, step, S, e, wid, lead, blk_metrics);
     }
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
@@ -562,7 +616,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
                 a.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ar, e * 8, 4, 0));
             }
             const Rows S = make_rows(b.state, b.stride);
-            const ElevRows<4> rows = load_elev_rows<4>(S, e, wid);
+            ElevRows<4> rows = load_elev_rows<4>(S, e, wid);
             WlElevParams p;
             VehDerived vd;
             kernarg_vector_copy2(0, p, vd);
@@ -612,6 +666,102 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
                 // world_height_map = -(sensor_z - hit_z - offset) + (root_z - plane_init_value); rays that miss return +inf
                 const float val = cr[i].inside ? (-(pz[i] - hz - p.scan_offset) + (pz[i] - p.elev_z0)) : __builtin_inff();
                 out.obs[(int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
+            }
+        }
+    }
+}
+
+// K env.step()s in ONE launch with pre-staged actions [K][n][2] (open-loop rollouts: sampling-based planners, system
+// identification, the bench; quad form, n <= 32 768).  Block = 16 envs.  Wavefront 0 keeps their rows and bookkeeping in
+// registers across the K steps (ElevRows / ElevBook: no state round trip, no launch boundary per step) and leaves each
+// step's poses in one of two LDS buffers; wavefronts 1..7 cast the height rays of step k WHILE wavefront 0 already
+// integrates step k + 1 -- with actions that do not depend on the observations the scan is off the critical path.  One
+// s_barrier per step and wavefront: at barrier k wavefront 0 has finished step k, the others the scan of step k - 1.
+// Episode metrics of all K steps go to ring slot `slots.cur`, `slots.next` is cleared for the next launch.
+constexpr int kScanLanes = kFusedThreads - 64;
+__global__ void __launch_bounds__(kFusedThreads) elev_rollout_persistent_kernel(const WlElevParams p_arg, const VehDerived vd_arg,
+                                                                                const WlEnvBuffers b, const HeightFieldGround ground,
+                                                                                const float2* __restrict__ actions, const WlStepOut out,
+                                                                                const int64_t obs_step_stride, const int64_t vec_step_stride,
+                                                                                const int n_steps, const uint64_t seed, const uint64_t step0,
+                                                                                const MetricSlots slots) {
+    __shared__ float blk_metrics[WL_M_COUNT];
+    __shared__ ScanPose pose[2][kFusedEnvs];
+    const int tid = threadIdx.x;
+    if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
+    if (b.metrics_slots > 1) clear_metric_slot(b, slots.next);
+    __syncthreads();
+    const int e0 = blockIdx.x * kFusedEnvs;
+    if (tid < 64) {
+        const int wid = tid & 3, e = e0 + (tid >> 2);
+        const bool valid = e < b.n_envs;
+        const Rows S = make_rows(b.state, b.stride);
+        ElevRows<4> rows;
+        ElevBook book;
+        WlElevParams p;
+        VehDerived vd;
+        if (valid) {
+            rows = load_elev_rows<4>(S, e, wid);
+            kernarg_vector_copy2(0, p, vd);
+            keep_scalar_common(p, p_arg);
+            vd.n_sub = vd_arg.n_sub;
+            book = load_elev_book<4>(p, b, S, e);
+        }
+        for (int k = 0; k < n_steps; ++k) {
+            if (valid) {
+                WlStepOut o = out;
+                o.obs += k * obs_step_stride;
+                o.reward += k * vec_step_stride;
+                o.terminated += k * vec_step_stride;
+                o.truncated += k * vec_step_stride;
+                if (o.dones) o.dones += k * vec_step_stride;
+                const float2 a = actions[(int64_t)k * b.n_envs + e];
+                const ScanPose sp = elev_env_step<4, true>(p, vd, b, ground, a, rows, o, seed, step0 + (uint64_t)k, S, e, wid, wid == 0,
+                                                           blk_metrics, &book);
+                if (wid == 0) pose[k & 1][tid >> 2] = sp;
+            }
+            __syncthreads();   // barrier k: the poses of step k are published
+        }
+        if (valid) store_elev_state<4>(p, b, S, e, wid, wid == 0, rows, book);
+        if (tid < WL_M_COUNT) {   // only this wavefront accumulated
+            const float m = blk_metrics[tid];
+            if (m != 0.f) atomicAdd(metric_shard(b, slots.cur) + tid, m);
+        }
+        return;
+    }
+    // ---- wavefronts 1..7: the scan of step k, one step behind the physics ----
+    const WlElevParams& p = p_arg;
+    const int t7 = tid - 64;
+    constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N, kAll = kFusedEnvs * kRays;
+    constexpr int kBatches = 3, kSlots = (kAll + kScanLanes - 1) / kScanLanes, kBatch = (kSlots + kBatches - 1) / kBatches;
+    const int n_here = min(kFusedEnvs, b.n_envs - e0);
+    const float g0 = -0.5f * p.scan_size;
+    for (int k = 0; k < n_steps; ++k) {
+        __syncthreads();       // barrier k
+        float* obs_k = out.obs + k * obs_step_stride;
+#pragma unroll
+        for (int part = 0; part < kBatches; ++part) {
+            HeightFieldGround::Corners cr[kBatch];
+            float pz[kBatch];
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+                const int idx = min(t7 + (part * kBatch + i) * kScanLanes, kAll - 1);
+                const int j = idx / kRays, r = idx - j * kRays;
+                const int iy = r / WL_ELEV_SCAN_N, ix = r - iy * WL_ELEV_SCAN_N;
+                const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
+                const ScanPose sp = pose[k & 1][min(j, n_here - 1)];
+                pz[i] = sp.pz;
+                cr[i] = ground.corners(sp.px + (sp.c * lx - sp.s * ly), sp.py + (sp.s * lx + sp.c * ly));
+            }
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+                const int idx = t7 + (part * kBatch + i) * kScanLanes;
+                const int j = idx / kRays, r = idx - j * kRays;
+                if (idx < kAll && j < n_here) {
+                    const float hz = ground.blend(cr[i]);
+                    const float val = cr[i].inside ? (-(pz[i] - hz - p.scan_offset) + (pz[i] - p.elev_z0)) : __builtin_inff();
+                    obs_k[(int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13 + r] = clampf(val, -p.obs_clip, p.obs_clip);
+                }
             }
         }
     }
@@ -761,6 +911,22 @@ int wl_elev_collect_step(const WlElevParams* p, const WlEnvBuffers* b, const WlH
         elev_step_scan_kernel<true, WL_ACT_ELU><<<grid, kFusedThreads, 0, (hipStream_t)stream>>>(*p, vd, *b, g, nullptr, *out, seed, step, pio);
     else
         elev_step_scan_kernel<true, WL_ACT_RELU><<<grid, kFusedThreads, 0, (hipStream_t)stream>>>(*p, vd, *b, g, nullptr, *out, seed, step, pio);
+    return launch_status();
+}
+
+int wl_elev_rollout_persistent(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* actions,
+                               const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps, uint64_t seed,
+                               uint64_t step0, void* stream) {
+    int rc = check_elev(p, b, hf);
+    if (rc != WL_OK) return rc;
+    if (!use_quad(b)) return WL_EINVAL;   // the quad form's (n <= 32 768)
+    if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
+    if (n_steps > 1 && obs_step_stride < (int64_t)b->n_envs * WL_ELEV_OBS_DIM) return WL_EINVAL;   // the scan runs a step behind: rows must differ
+    if (b->metrics_slots > 1 && n_steps % b->metrics_slots == 0 && n_steps > 0) return WL_EINVAL;   // ring slot aliasing
+    clear_error();
+    elev_rollout_persistent_kernel<<<(b->n_envs + kFusedEnvs - 1) / kFusedEnvs, kFusedThreads, 0, (hipStream_t)stream>>>(
+        *p, derive_vehicle(p->vehicle, p->sim_dt, p->decimation), *b, make_ground(hf), (const float2*)actions, *out, obs_step_stride,
+        vec_step_stride, n_steps, seed, step0, metric_slots(b, step0, (uint64_t)n_steps));
     return launch_status();
 }
 
