@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -2 > $O/gpu_tests.txt
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|^FAILED|^ERROR" > $O/gpu_tests.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 > $O/smoke.txt
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 300 python bench.py --steps 20 --warmup 5 --no-sweep > $O/bench_s20.json 2>> $O/bench.err
