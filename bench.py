@@ -433,9 +433,9 @@ def main():
             other[name] = {"us_per_step": us, "env_steps_per_s": n / (us * 1e-6), "obs_dim": t.OBS_DIM,
                            "obs_GBs": n * t.OBS_DIM * 4 / (us * 1e-6) / 1e9, "launches": "one per env.step()" if name == "elevation"
                            else "two per env.step() (step, camera)"}
-            if name == "elevation" and n <= 32768:
-                # open-loop rollouts (pre-staged actions) as ONE launch: state in registers, the height scan of step k while
-                # step k + 1 is integrated (wl_elev_rollout_persistent; same results bit for bit)
+            if n <= 32768:
+                # open-loop rollouts (pre-staged actions) as ONE launch: the height scan / camera of step k while step k + 1 is
+                # integrated (wl_elev_rollout_persistent, wl_visual_rollout_persistent; same results bit for bit)
                 po = torch.zeros(k, n, t.OBS_DIM, device=dev)
                 pr = torch.zeros(k, n, device=dev)
                 pt, pu = torch.zeros(k, n, dtype=torch.bool, device=dev), torch.zeros(k, n, dtype=torch.bool, device=dev)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 15
+#define WL_ABI_VERSION 16
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -581,16 +581,24 @@ typedef struct WlVisualParams {
 /*
  * Fused visual env.step(): 4WD action term -> decimation x substeps on the flat plane -> time_out + out_of_map
  * (:390-398) -> traversable_reward (:309-312, lookup traversability_utils.py:68-88) + forward_vel (:370-371) -> reset
- * onto a random traversable cell (visual/mdp/events.py:11-42) in one launch (lane = env); then the observation launch
- * (block = env): 40 x 80 ray-cast grey image of the traversability plane staged in LDS, brightness / contrast / 5x5
- * Gaussian blur / grayscale / normalise (mdp_sensors/observations.py:75-87), + base_lin_vel, base_ang_vel,
- * last_action.  obs is [n][WL_VIS_OBS_DIM].
+ * onto a random traversable cell (visual/mdp/events.py:11-42), then the observation: 40 x 80 ray-cast grey image of the
+ * traversability plane staged in LDS, brightness / contrast / 5x5 Gaussian blur / grayscale / normalise
+ * (mdp_sensors/observations.py:75-87), + base_lin_vel, base_ang_vel, last_action.  obs is [n][WL_VIS_OBS_DIM].
+ * Two launches per step: the step (lane or quad of lanes = env), then the camera (block = env).
  */
 int wl_visual_step(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const float* actions,
                    const WlStepOut* out, uint64_t seed, uint64_t step, void* stream);
 int wl_visual_rollout(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const float* actions,
                       const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps,
                       uint64_t seed, uint64_t step0, void* stream);
+/* wl_visual_rollout as ONE launch for open-loop rollouts (pre-staged actions): the camera of step k is rendered by twelve
+ * wavefronts of each 16-env block while a thirteenth already integrates step k + 1.  Same results as wl_visual_rollout bit for
+ * bit.  Quad form only (n_envs <= 32 768, else WL_EINVAL); with more than one step the per-step observation rows must be
+ * distinct (obs_step_stride >= n_envs * WL_VIS_OBS_DIM).  Episode metrics of all steps go to ring slot (step0 % slots),
+ * slot ((step0 + n_steps) % slots) is cleared (as wl_drift_rollout_persistent). */
+int wl_visual_rollout_persistent(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const float* actions,
+                                 const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps,
+                                 uint64_t seed, uint64_t step0, void* stream);
 int wl_visual_reset(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const uint8_t* mask,
                     uint64_t seed, uint64_t step, void* stream);
 int wl_visual_observe(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, float* obs, void* stream);

@@ -130,6 +130,16 @@ def test_layout_of_task_structs_and_misuse_codes(tmp_path):
     assert lib.wl_drift_step(C.byref(p), C.byref(good), base, None, C.byref(out), 0, 0, None) == -1      # > 32 ref poses
     ep = PP.elev_params()
     assert lib.wl_elev_step(C.byref(ep), C.byref(good), None, base, C.byref(out), 0, 0, None) == -1      # no heightfield
+    # persistent visual rollout: refused without a map, in the lane form, and with per-step rows that alias
+    vp = PP.visual_params()
+    tm = A.WlTravMap(base, base, 500, 500, 10, 0.5, 0.5)
+    vr = lib.wl_visual_rollout_persistent
+    assert vr(C.byref(vp), C.byref(good), None, base, C.byref(out), 100 * A.VIS_OBS_DIM, 100, 2, 0, 0, None) == -1
+    lanes1 = A.WlEnvBuffers(stride=128, n_envs=100, env_offset=0, metrics_slots=1, lanes=1, **ok_bufs)
+    assert vr(C.byref(vp), C.byref(lanes1), C.byref(tm), base, C.byref(out), 100 * A.VIS_OBS_DIM, 100, 2, 0, 0, None) == -1
+    assert vr(C.byref(vp), C.byref(good), C.byref(tm), base, C.byref(out), 0, 0, 2, 0, 0, None) == -1
+    ring = A.WlEnvBuffers(stride=128, n_envs=100, env_offset=0, metrics_slots=2, **ok_bufs)
+    assert vr(C.byref(vp), C.byref(ring), C.byref(tm), base, C.byref(out), 100 * A.VIS_OBS_DIM, 100, 4, 0, 0, None) == -1   # ring slot aliasing
 
 
 def test_missing_library_fails_loudly(tmp_path):

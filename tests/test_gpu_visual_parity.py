@@ -160,3 +160,78 @@ def test_visual_full_size_properties_and_depth(trav):
     d_w = R @ d_b
     assert d_w[2] < 0
     assert abs(float(dep[e, row, col]) - (-o[2] / d_w[2])) < 0.03
+
+
+@pytest.mark.parametrize("n", [300, 1500, 4100])
+@pytest.mark.parametrize("aug", [(1.0, 1.0, 0.0), (1.3, 0.9, 1.2)])
+def test_step_observation_is_the_observation_of_the_stored_state(trav, n, aug):
+    """The observation a step returns must be the observation of the state the step stored (wl_visual_observe on it) -- bit for
+    bit, every env in its own row, at env counts that take each of the quad launcher's block sizes and leave a partly filled
+    last block -- and the quad form's step must agree with the lane form's."""
+    ea, eb = _batch(n, trav, seed=9), _batch(n, trav, seed=9)
+    eb.set_lanes(1)
+    for e in (ea, eb):
+        e.p.brightness, e.p.contrast, e.p.blur_sigma = aug
+        e.episode_len[:n] = torch.randint(0, 49, (n,), device=DEV, dtype=torch.int32, generator=torch.Generator(device=DEV).manual_seed(2))
+    g = torch.Generator(device=DEV).manual_seed(6)
+    dones = 0
+    for k in range(6):
+        a = torch.rand(n, 2, device=DEV, generator=g) * 2.4 - 1.2
+        obs, rew, term, trunc = ea.step(a)
+        got = obs.clone()
+        dones += int((term | trunc).sum())
+        assert torch.equal(got, ea.observe()), k
+        eb.state.copy_(ea.state)                    # same start for the next comparison
+        eb.episode_len.copy_(ea.episode_len)
+        if k < 5:
+            a2 = torch.rand(n, 2, device=DEV, generator=torch.Generator(device=DEV).manual_seed(100 + k)) * 2 - 1
+            sa, ep = ea.state.clone(), ea.episode_len.clone()
+            oa = [t.clone() for t in ea.step(a2)]
+            eb.step_count = ea.step_count - 1
+            ob = eb.step(a2)
+            torch.testing.assert_close(ea.state[:21, :n], eb.state[:21, :n], rtol=5e-4, atol=5e-4)
+            assert torch.equal(oa[2], ob[2]) and torch.equal(oa[3], ob[3]) and torch.equal(ea.episode_len, eb.episode_len)
+            torch.testing.assert_close(oa[1], ob[1], rtol=2e-3, atol=2e-3)
+            assert ((oa[0] - ob[0]).abs()[:, :3200] > 2e-3).float().mean() < 5e-3
+            dones += int((oa[2] | oa[3]).sum())
+    assert dones > 0
+
+
+@pytest.mark.parametrize("n,K,slots,aug", [(4096, 10, 1, (1.2, 0.9, 1.5)), (1000, 7, 1, (1.0, 1.0, 0.0)), (256, 5, 4, (0.7, 1.1, 0.6))])
+def test_persistent_visual_rollout_equals_stepping(trav, n, K, slots, aug):
+    """wl_visual_rollout_persistent (K steps in one launch: the camera of step k rendered by twelve wavefronts per block while
+    a thirteenth integrates step k + 1; render groups meeting through an LDS counting barrier) against wl_visual_rollout
+    (a launch per step): every output row and the final state bit for bit, the episode metrics to summation order -- incl.
+    in-rollout resets, a partly filled last block (n = 1000), the metric ring, with and without the augmentation"""
+    from wheeledlab_amd.core import VisualBatch
+    ea = VisualBatch(n, device=DEV, seed=21, trav_map=trav, metrics_slots=slots)
+    eb = VisualBatch(n, device=DEV, seed=21, trav_map=trav, metrics_slots=1)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    for e in (ea, eb):
+        e.reset()
+        e.p.brightness, e.p.contrast, e.p.blur_sigma = aug
+        e.episode_len[:n] = torch.randint(0, 49, (n,), device=DEV, dtype=torch.int32, generator=torch.Generator(device=DEV).manual_seed(1))
+    a = torch.rand(K, n, 2, device=DEV, generator=g) * 2 - 1
+    outs = []
+    for e, persistent in ((ea, True), (eb, False)):
+        obs = torch.zeros(K, n, e.OBS_DIM, device=DEV)
+        rew = torch.zeros(K, n, device=DEV)
+        term = torch.zeros(K, n, dtype=torch.bool, device=DEV)
+        trunc = torch.zeros(K, n, dtype=torch.bool, device=DEV)
+        dones = torch.zeros(K, n, dtype=torch.long, device=DEV)
+        e.rollout(a, obs, rew, term, trunc, dones_out=dones, persistent=persistent)
+        outs.append((obs, rew, term, trunc, dones))
+    torch.cuda.synchronize()
+    for x, y, name in zip(outs[0], outs[1], ("obs", "reward", "terminated", "truncated", "dones")):
+        assert torch.equal(x, y), name
+    assert torch.equal(ea.state, eb.state) and torch.equal(ea.episode_len, eb.episode_len) and ea.step_count == eb.step_count == K
+    assert int(outs[0][4].sum()) > 0
+    ma, mb = ea.metrics_raw.sum((0, 1)), eb.metrics_raw.sum((0, 1))
+    if slots > 1:
+        assert float(ea.metrics_raw[1:].abs().sum()) == 0.0
+    torch.testing.assert_close(ma, mb, rtol=1e-5, atol=1e-3)
+    assert torch.equal(ma[8:12], mb[8:12]) and float(ma[8]) == float(outs[0][4].sum())
+    # and with too few rows per step the launch is refused (the camera runs a step behind the physics)
+    rc = ea.lib.wl_visual_rollout_persistent(C.byref(ea.p), C.byref(ea._bufs), C.byref(ea._map), a.data_ptr(), C.byref(ea._out), 0, 0, 2,
+                                             ea.seed, ea.step_count, None)
+    assert rc == -1      # WL_EINVAL

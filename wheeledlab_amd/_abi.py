@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 15
+WL_ABI_VERSION = 16
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -228,6 +228,8 @@ SIGNATURES = {
     "wl_visual_step": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _P(WlStepOut), _u64, _u64, _vp]),
     "wl_visual_rollout": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _P(WlStepOut), _i64, _i64,
                                     _i32, _u64, _u64, _vp]),
+    "wl_visual_rollout_persistent": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _P(WlStepOut), _i64, _i64,
+                                               _i32, _u64, _u64, _vp]),
     "wl_visual_reset": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _u64, _u64, _vp]),
     "wl_visual_observe": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _vp]),
     "wl_visual_mdp": (C.c_int, [_P(WlVisualParams), _P(WlTravMap), _i32, _i64] + [_vp] * 7),

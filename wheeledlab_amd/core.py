@@ -385,7 +385,11 @@ class VisualBatch(_MetricsView):
         self.step_count += 1
         return self.obs, self.reward, self.terminated, self.truncated
 
-    def rollout(self, actions: torch.Tensor, obs_out=None, rew_out=None, term_out=None, trunc_out=None, dones_out=None):
+    def rollout(self, actions: torch.Tensor, obs_out=None, rew_out=None, term_out=None, trunc_out=None, dones_out=None,
+                persistent: bool = False):
+        """K fused steps with pre-staged actions [K,n,2]; optional [K,...] output storage (else overwrite).  persistent=True
+        (needs the storage, n <= 32 768) runs them as ONE launch with the camera of step k rendered while step k + 1 is
+        integrated (wl_visual_rollout_persistent); same results."""
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
         if obs_out is not None:
@@ -393,10 +397,14 @@ class VisualBatch(_MetricsView):
                               None if dones_out is None else dones_out.data_ptr())
             os_, vs_ = self.n * self.OBS_DIM, self.n
         else:
+            assert not persistent or K == 1, "a persistent rollout needs per-step output rows"
             out, os_, vs_ = self._out, 0, 0
-        A.check(self.lib.wl_visual_rollout(C.byref(self.p), C.byref(self._bufs), C.byref(self._map), actions.data_ptr(),
-                                           C.byref(out), os_, vs_, K, self.seed, self.step_count, self._stream()),
-                "wl_visual_rollout")
+        if persistent and self.metrics_slots > 1 and K > 1:
+            R = self.metrics_slots       # the launch folds all K steps into slot step0 % R: the slots it skips keep old counts
+            self.metrics_raw[[(self.step_count + i) % R for i in range(1, K)]] = 0
+        fn = self.lib.wl_visual_rollout_persistent if persistent else self.lib.wl_visual_rollout
+        A.check(fn(C.byref(self.p), C.byref(self._bufs), C.byref(self._map), actions.data_ptr(), C.byref(out), os_, vs_, K, self.seed,
+                   self.step_count, self._stream()), "wl_visual_rollout")
         self.step_count += K
 
     def depth(self, heightfield, max_depth: float = 20.0) -> torch.Tensor:

@@ -1,6 +1,6 @@
 // wl_visual.hip -- visual task (wheeledlab_tasks/visual/mushr_visual_env_cfg.py) for gfx950.
 //
-// Two launches per env.step():
+// Two launches per env.step() (ONE for K steps of an open-loop rollout: visual_rollout_persistent_kernel):
 //   1. visual_step_kernel (lane = env): 4WD action term -> sub-steps on the flat plane -> time_out / out_of_map ->
 //      traversable_reward (byte-map gather) + forward_vel -> reset onto a random traversable cell.
 //   2. visual_obs_kernel  (block = env): the 3208-dim observation.  3200 camera rays against the z = 0 plane with a
@@ -19,6 +19,11 @@
 namespace {
 
 constexpr int kImgH = WL_VIS_IMG_H - WL_VIS_CROP, kImgW = WL_VIS_IMG_W;
+// threads that render one image (whole wavefronts, whole image rows per pass)
+#ifndef WL_CAM_THREADS
+#define WL_CAM_THREADS 256
+#endif
+constexpr int kCam = WL_CAM_THREADS;
 
 // TraversabilityHashmapUtil.get_map_id (visual/utils/traversability_utils.py:83-88): float32 arithmetic, truncation
 // toward zero (`.long()`), clamp to the map.
@@ -73,31 +78,19 @@ WL_DEV VisReset draw_visual_reset(const WlVisualParams& p, const WlTravMap& m, u
     return r;
 }
 
-template <int LANES, int QB = kBlock /* quad form: threads per block (see drift_step_kernel) */>
-__global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b,
-                                                             const WlTravMap m, const float2* __restrict__ actions,
-                                                             const WlStepOut out, const uint64_t seed, const uint64_t step) {
-    __shared__ float blk_metrics[WL_M_COUNT];
-    WlVisualParams p = p_arg;
-    VehDerived vd = vd_arg;
-    if constexpr (LANES == 4) {   // latency form: one batch of vector loads instead of dependent scalar-load round trips
-        kernarg_vector_copy2(0, p, vd);   // both argument structs as ONE burst (two copies: a wait in the middle, see the helper)
-        keep_scalar_common(p, p_arg);
-        vd.n_sub = vd_arg.n_sub;
-    }
-    constexpr int kEnvs = (LANES == 4 ? QB : kBlock) / LANES;
-    const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);
-    const bool lead = LANES == 1 || wid == 0;
-    const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
-    if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
-    const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
-    if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
-    __syncthreads();
-    const Rows S = make_rows(b.state, b.stride);
+// what the camera needs of an env after its step: exactly the values the step leaves in the state rows (post-reset)
+struct CamPose {
+    float px, py, pz, qw, qx, qy, qz, vx, vy, vz, wx, wy, wz, a0, a1;
+};
+
+// one env.step() of env e (lane form: one lane; quad form: the four lanes of a quad, wid = wheel)
+template <int LANES>
+WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, const WlEnvBuffers& b, const WlTravMap& m, float2 a,
+                               const WlStepOut& out, const uint64_t seed, const uint64_t step, const Rows& S, const int e, const int wid,
+                               const bool lead, float* blk_metrics) {
     const WlVehicleParams& vp = p.vehicle;
-    if (e < b.n_envs) {
+    {
         const uint32_t gid = (uint32_t)(b.env_offset + e);
-        float2 a = actions[e];
         float v_t, delta;
         process_action(p.action, a.x, a.y, v_t, delta);
         EnvConst ec;
@@ -225,7 +218,32 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
             }
             b.episode_len[e] = ep_len;
         }
+        return CamPose{pos.x, pos.y, pos.z, s.q.w, s.q.x, s.q.y, s.q.z, s.v.x, s.v.y, s.v.z, ww.x, ww.y, ww.z, a0, a1};
     }
+}
+
+template <int LANES, int QB = kBlock /* quad form: threads per block (see drift_step_kernel) */>
+__global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b,
+                                                             const WlTravMap m, const float2* __restrict__ actions,
+                                                             const WlStepOut out, const uint64_t seed, const uint64_t step) {
+    __shared__ float blk_metrics[WL_M_COUNT];
+    WlVisualParams p = p_arg;
+    VehDerived vd = vd_arg;
+    if constexpr (LANES == 4) {   // latency form: one batch of vector loads instead of dependent scalar-load round trips
+        kernarg_vector_copy2(0, p, vd);   // both argument structs as ONE burst (two copies: a wait in the middle, see the helper)
+        keep_scalar_common(p, p_arg);
+        vd.n_sub = vd_arg.n_sub;
+    }
+    constexpr int kEnvs = (LANES == 4 ? QB : kBlock) / LANES;
+    const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);
+    const bool lead = LANES == 1 || wid == 0;
+    const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
+    if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
+    const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
+    if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
+    __syncthreads();
+    const Rows S = make_rows(b.state, b.stride);
+    if (e < b.n_envs) visual_env_step<LANES>(p, vd, b, m, actions[e], out, seed, step, S, e, wid, lead, blk_metrics);
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
         const float v = blk_metrics[threadIdx.x];
@@ -239,58 +257,79 @@ WL_DEV V3 pixel_ray_body(const WlVisualParams& p, int row, int col) {
     return v3(1.f, -(((float)col + 0.5f - p.cx) / p.fx), -(((float)row + 0.5f - p.cy) / p.fy));
 }
 
-WL_DEV float block_sum(float v, float* scratch /* [kBlock/64] */) {
+// How the wavefronts that render one image meet.  BlockSync: the block's s_barrier -- every group of the block makes the
+// same calls.  GroupSync: a counting barrier in LDS among the group's own wavefronts, for blocks in which other wavefronts
+// do something else meanwhile (the persistent rollout's physics wavefront would have to join an s_barrier).  Spinning is
+// safe: the wavefronts of a workgroup are always co-resident.  The counter only grows (target = arrivals so far).
+struct BlockSync {
+    WL_DEV void operator()() { __syncthreads(); }
+};
+struct GroupSync {
+    int* cnt;
+    int target, n_waves;
+    WL_DEV void operator()() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        target += n_waves;
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+
+// sum over the GT threads (whole wavefronts) that render one image
+template <int GT, class SYNC>
+WL_DEV float group_sum(float v, float* scratch /* [GT / 64], this group's */, int gt, SYNC& sync) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
+    sync();
+    if ((gt & 63) == 0) scratch[gt >> 6] = v;
+    sync();
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) t += scratch[w];
+    for (int w = 0; w < GT / 64; ++w) t += scratch[w];
     return t;
 }
 
 WL_DEV int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-// VisualObsCfg.PolicyCfg (:38-58): camera (3200) | base_lin_vel (3) | base_ang_vel (3) | last_action clip +-1 (2)
-__global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
-                                                            float* __restrict__ obs) {
-    // the rendered image with its two reflected border columns on either side: pitch 84 floats = 21 sixteen-byte slots, so
-    // the 8-float window of a 4 x 4 output patch is two aligned ds_read_b128 and, 4 rows x 21 slots being 4 mod 16, the 16-lane
-    // groups a b128 read is served in (lanes of one patch row + 8 lanes of the next) hit 16 distinct slots.  (With the
-    // unpadded [40][80] image each of the 64 reads per thread was a 4-byte read at a lane stride of 4 floats: 8-way conflicts.)
-    constexpr int kPitch = kImgW + 4;
-    __shared__ __attribute__((aligned(16))) float img[kImgH * kPitch];
-    __shared__ float red[kBlock / 64];
-    const int e = blockIdx.x;
-    const Rows S = make_rows(b.state, b.stride);
-    const V3 pos = ld3(S, WL_S_PX, e);
-    const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+// the rendered image with its two reflected border columns on either side: pitch 84 floats = 21 sixteen-byte slots, so
+// the 8-float window of a 4 x 4 output patch is two aligned ds_read_b128 and, 4 rows x 21 slots being 4 mod 16, the 16-lane
+// groups a b128 read is served in (lanes of one patch row + 8 lanes of the next) hit 16 distinct slots.  (With the
+// unpadded [40][80] image each of the 64 reads per thread was a 4-byte read at a lane stride of 4 floats: 8-way conflicts.)
+constexpr int kPitch = kImgW + 4, kImgFloats = kImgH * kPitch;
+
+// VisualObsCfg.PolicyCfg (:38-58): camera (3200) | base_lin_vel (3) | base_ang_vel (3) | last_action clip +-1 (2) of ONE env,
+// by a group of GT threads (gt = thread in the group; `img` [kImgFloats] and `red` [GT / 64] are the group's LDS).  Two
+// `sync()`s inside when the augmentation needs the whole image; a group without an env (`valid` false) renders its
+// neighbour's pose and stores nothing.
+template <int GT, class SYNC>
+WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const CamPose& cp, float* __restrict__ row, float* img, float* red,
+                         const int gt, const bool valid, SYNC& sync) {
+    const V3 pos = v3(cp.px, cp.py, cp.pz);
+    const Quat q{cp.qw, cp.qx, cp.qy, cp.qz};
     const Mat3 R = mat_from_quat(q);
     const V3 o = pos + mul(R, v3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
     const MapFast mf = map_fast(m);
     const float inv_fx = rcp(p.fx), inv_fy = rcp(p.fy);
     const bool plain = p.contrast == 1.f && !(p.blur_sigma > 0.f);   // no augmentation that needs the whole image
-    float* row = obs + (int64_t)e * WL_VIS_OBS_DIM;
-    if (threadIdx.x == kBlock - 1) {   // proprioception: the last lane (its wave renders the fewest pixels)
-        const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
+    if (gt == GT - 1 && valid) {   // proprioception: the last lane (its wave renders the fewest pixels)
+        const V3 vb = mul_t(R, v3(cp.vx, cp.vy, cp.vz)), wb = mul_t(R, v3(cp.wx, cp.wy, cp.wz));
         float* t = row + WL_VIS_NPIX;
         t[0] = vb.x; t[1] = vb.y; t[2] = vb.z;
         t[3] = wb.x; t[4] = wb.y; t[5] = wb.z;
-        t[6] = clampf(S.ld(WL_S_ACT0, e), -1.f, 1.f);
-        t[7] = clampf(S.ld(WL_S_ACT1, e), -1.f, 1.f);
+        t[6] = clampf(cp.a0, -1.f, 1.f);
+        t[7] = clampf(cp.a1, -1.f, 1.f);
     }
     // ---- render: one ray per pixel against the z = 0 plane.  d = R (1, dy(col), dz(row)) ----
     const V3 c0 = v3(R.r0.x, R.r1.x, R.r2.x), c1 = v3(R.r0.y, R.r1.y, R.r2.y), c2 = v3(R.r0.z, R.r1.z, R.r2.z);
     float part = 0.f;
-    // Thread -> one image column and every third row (240 of the 256 threads: 3 rows x 80 columns per pass, 14 passes):
+    // Thread -> one image column and every third row (GT = 256: 240 of the threads, 3 rows x 80 columns per pass, 14 passes):
     // the ray direction then advances by a constant vector per pass (3 adds instead of 2 conversions + 8 fma), and the
     // lanes of a wavefront still store consecutive columns.  Software-pipelined like the height scan: every pixel of
     // this lane computes its map cell and issues its byte gather first (14 in flight per lane), then all are shaded and
     // stored -- rolled, each pixel paid the gather latency in turn.
-    constexpr int kRowsPerPass = kBlock / kImgW, kIter = (kImgH + kRowsPerPass - 1) / kRowsPerPass;
-    const int tc = (int)threadIdx.x % kImgW, tr = (int)threadIdx.x / kImgW;
+    constexpr int kRowsPerPass = GT / kImgW, kIter = (kImgH + kRowsPerPass - 1) / kRowsPerPass;
+    const int tc = gt % kImgW, tr = gt / kImgW;
     const bool lane_on = tr < kRowsPerPass;
     const float dy = -(((float)tc + 0.5f - p.cx) * inv_fx), dz0 = -(((float)(tr + WL_VIS_CROP) + 0.5f - p.cy) * inv_fy);
     V3 d = fma3(dz0, c2, fma3(dy, c1, c0));
@@ -316,7 +355,7 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
             float v = hit[it] ? (cell[it] != 0 ? 1.f : 0.f) : p.sky;
             v = clampf(v * p.brightness, 0.f, 1.f);                    // ColorJitter brightness
             if (plain) {
-                row[r * kImgW + tc] = (v * 0.9999f - 0.5f) * 2.f;      // grayscale + Normalize([0.5], [0.5]) straight to HBM
+                if (valid) row[r * kImgW + tc] = (v * 0.9999f - 0.5f) * 2.f;   // grayscale + Normalize([0.5], [0.5]) straight to HBM
             } else {
                 float* line = img + r * kPitch + 2;
                 line[tc] = v;
@@ -330,7 +369,7 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
     // ---- augmentation on the LDS-resident image.  One 4 x 4 output patch per thread (10 x 20 patches = 200 threads):
     // the 8 x 8 input neighbourhood is read once (contrast blend applied on the fly), both passes of the separable 5-tap
     // Gaussian run in registers, and each patch row leaves as one 16-byte store.
-    const float mean = 0.9999f * block_sum(part, red) * (1.f / (float)(kImgH * kImgW));   // also orders the img writes
+    const float mean = 0.9999f * group_sum<GT>(part, red, gt, sync) * (1.f / (float)(kImgH * kImgW));   // also orders the img writes
     const float cc = p.contrast, cm = (1.f - p.contrast) * mean;   // ColorJitter contrast: blend with the grey mean
     // a blend TOWARDS the mean (contrast <= 1) stays inside [0, 1], its clamp is the identity, and the blur is linear with
     // weights summing to one: blur(cc v + cm) = cc blur(v) + cm -- applied to the 16 outputs instead of the 64 inputs
@@ -350,8 +389,8 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
         for (int j = 0; j < 5; ++j) w[j] *= inv;
     }
     constexpr int kPatchCols = kImgW / 4, kPatches = (kImgH / 4) * kPatchCols;
-    if (threadIdx.x < kPatches) {
-        const int pr = (threadIdx.x / kPatchCols) * 4, pc = (threadIdx.x % kPatchCols) * 4;
+    if (gt < kPatches && valid) {
+        const int pr = (gt / kPatchCols) * 4, pc = (gt % kPatchCols) * 4;
         float hrow[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -378,6 +417,105 @@ __global__ void __launch_bounds__(kBlock) visual_obs_kernel(const WlVisualParams
             }
             // row base = e * 3208 floats = e * 12832 B (16-B aligned), patch column is a multiple of 4 floats
             *reinterpret_cast<float4*>(row + (pr + orow) * kImgW + pc) = out4;
+        }
+    }
+}
+
+WL_DEV CamPose load_cam_pose(const Rows& S, const int e) {
+    return CamPose{S.ld(WL_S_PX, e), S.ld(WL_S_PX + 1, e), S.ld(WL_S_PX + 2, e), S.ld(WL_S_QW, e), S.ld(WL_S_QX, e),
+                   S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e), S.ld(WL_S_VX, e), S.ld(WL_S_VX + 1, e), S.ld(WL_S_VX + 2, e),
+                   S.ld(WL_S_WX, e), S.ld(WL_S_WX + 1, e), S.ld(WL_S_WX + 2, e), S.ld(WL_S_ACT0, e), S.ld(WL_S_ACT1, e)};
+}
+
+// block = env: the observation of the state as it stands (reset / first observation / lane-form steps)
+__global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
+                                                          float* __restrict__ obs) {
+    __shared__ __attribute__((aligned(16))) float img[kImgFloats];
+    __shared__ float red[kCam / 64];
+    const int e = blockIdx.x;
+    const CamPose cp = load_cam_pose(make_rows(b.state, b.stride), e);
+    BlockSync sync;
+    render_image<kCam>(p, m, cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img, red, (int)threadIdx.x, true, sync);
+}
+
+// K env.step()s in ONE launch with pre-staged actions [K][n][2] (open-loop rollouts; quad form, n <= 32 768), the visual
+// counterpart of elev_rollout_persistent_kernel.  Block = 16 envs, 1024 threads.  Wavefront 0 steps them (through the
+// state rows, which stay in this CU's cache: the camera, not the physics, is the longer leg here) and leaves each step's
+// poses in one of two LDS buffers; the other twelve wavefronts -- three groups of GT = 256 threads, one image per group
+// and pass -- render step k WHILE wavefront 0 already integrates step k + 1.  One s_barrier per step and wavefront; the
+// render groups meet among themselves through GroupSync.  Episode metrics of all K steps go to ring slot `slots.cur`.
+// (GT is visual_obs_kernel's: a group of 320 threads -- 4 image rows per pass, fifteen render wavefronts -- advances the
+// ray direction in different increments, and rays that graze a cell edge then resolve differently: not bit-identical.)
+constexpr int kPersistGroups = (1024 - 64) / kCam, kPersistThreads = 64 + kPersistGroups * kCam;
+template <int EPB>
+__global__ void __launch_bounds__(kPersistThreads) visual_rollout_persistent_kernel(
+    const WlVisualParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b, const WlTravMap m, const float2* __restrict__ actions,
+    const WlStepOut out, const int64_t obs_step_stride, const int64_t vec_step_stride, const int n_steps, const uint64_t seed,
+    const uint64_t step0, const MetricSlots slots) {
+    constexpr int GT = kCam, kGroups = kPersistGroups, kPasses = (EPB + kGroups - 1) / kGroups;
+    static_assert(GT % 64 == 0 && GT >= kImgW && kGroups >= 1 && 4 * EPB <= 64, "whole wavefronts per render group; one physics wavefront");
+    __shared__ float blk_metrics[WL_M_COUNT];
+    __shared__ CamPose pose[2][EPB];
+    __shared__ __attribute__((aligned(16))) float img[kGroups * kImgFloats];
+    __shared__ float red[kGroups * (GT / 64)];
+    __shared__ int arrivals[kGroups];
+    const int tid = threadIdx.x;
+    if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
+    if (tid < kGroups) arrivals[tid] = 0;
+    if (b.metrics_slots > 1) clear_metric_slot(b, slots.next);
+    __syncthreads();
+    const int e0 = blockIdx.x * EPB;
+    if (tid < 64) {
+        const int wid = tid & 3, e = e0 + (tid >> 2);
+        const bool valid = tid < 4 * EPB && e < b.n_envs;
+        const Rows S = make_rows(b.state, b.stride);
+        WlVisualParams p;
+        VehDerived vd;
+        kernarg_vector_copy2(0, p, vd);
+        keep_scalar_common(p, p_arg);
+        vd.n_sub = vd_arg.n_sub;
+#pragma unroll 1
+        for (int k = 0; k < n_steps; ++k) {
+            if (valid) {
+                WlStepOut o = out;
+                o.obs += k * obs_step_stride;
+                o.reward += k * vec_step_stride;
+                o.terminated += k * vec_step_stride;
+                o.truncated += k * vec_step_stride;
+                if (o.dones) o.dones += k * vec_step_stride;
+                const float2 a = actions[(int64_t)k * b.n_envs + e];
+                const CamPose cp = visual_env_step<4>(p, vd, b, m, a, o, seed, step0 + (uint64_t)k, S, e, wid, wid == 0, blk_metrics);
+                if (wid == 0) pose[k & 1][tid >> 2] = cp;
+            }
+            __syncthreads();   // barrier k: the poses of step k are published
+        }
+        if (tid < WL_M_COUNT) {   // only this wavefront accumulated
+            const float v = blk_metrics[tid];
+            if (v != 0.f) atomicAdd(metric_shard(b, slots.cur) + tid, v);
+        }
+        return;
+    }
+    // ---- the other wavefronts: the camera of step k, one step behind the physics ----
+    const int t = tid - 64, grp = t / GT, gt = t % GT;
+    const int n_here = min(EPB, b.n_envs - e0);
+    const bool plain = p_arg.contrast == 1.f && !(p_arg.blur_sigma > 0.f);
+    GroupSync sync{arrivals + min(grp, kGroups - 1), 0, GT / 64};
+#pragma unroll 1
+    for (int k = 0; k < n_steps; ++k) {
+        __syncthreads();       // barrier k (also: every group is done with its previous image)
+        if (grp >= kGroups) continue;   // wavefronts left over when the block is no whole number of groups
+        float* obs_k = out.obs + k * obs_step_stride;
+#pragma unroll 1
+        for (int pass = 0; pass < kPasses; ++pass) {
+            const int j = pass * kGroups + grp;
+            if (j >= n_here) break;                    // group-uniform: GroupSync involves this group only
+            if (pass > 0 && !plain) sync();            // the previous image is still being read by the blur
+            const CamPose cp = pose[k & 1][j];
+            int gtl = gt;
+            asm volatile("" : "+v"(gtl));              // per-pass copy: keeps the pixel / patch bookkeeping from being hoisted out of
+                                                       // the loops and held in ~50 registers across them
+            render_image<GT>(p_arg, m, cp, obs_k + (int64_t)(e0 + j) * WL_VIS_OBS_DIM, img + grp * kImgFloats, red + grp * (GT / 64),
+                             gtl, true, sync);
         }
     }
 }
@@ -495,17 +633,44 @@ int wl_visual_rollout(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
         o.truncated += k * vec_step_stride;
         if (o.dones) o.dones += k * vec_step_stride;
         const float2* a = (const float2*)(actions + (int64_t)k * b->n_envs * 2);
+        const uint64_t st = step0 + (uint64_t)k;
+        const hipStream_t hs = (hipStream_t)stream;
+        const int n = b->n_envs;
         if (quad)
         {
-            const int lanes = b->n_envs * 4;
-            if (b->n_envs <= 2048) visual_step_kernel<4, 64><<<(lanes + 63) / 64, 64, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
-            else if (b->n_envs <= 8192) visual_step_kernel<4, 128><<<(lanes + 127) / 128, 128, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
-            else visual_step_kernel<4><<<grid_for(lanes), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
+            const int lanes = n * 4;
+            if (n <= 2048) visual_step_kernel<4, 64><<<(lanes + 63) / 64, 64, 0, hs>>>(*p, vd, *b, *m, a, o, seed, st);
+            else if (n <= 8192) visual_step_kernel<4, 128><<<(lanes + 127) / 128, 128, 0, hs>>>(*p, vd, *b, *m, a, o, seed, st);
+            else visual_step_kernel<4><<<grid_for(lanes), kBlock, 0, hs>>>(*p, vd, *b, *m, a, o, seed, st);
         }
         else
-            visual_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, *m, a, o, seed, step0 + (uint64_t)k);
-        visual_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, o.obs);
+            visual_step_kernel<1><<<grid_for(n), kBlock, 0, hs>>>(*p, vd, *b, *m, a, o, seed, st);
+        visual_obs_kernel<<<n, kCam, 0, hs>>>(*p, *b, *m, o.obs);
     }
+    return launch_status();
+}
+
+int wl_visual_rollout_persistent(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const float* actions,
+                                 const WlStepOut* out, int64_t obs_step_stride, int64_t vec_step_stride, int32_t n_steps,
+                                 uint64_t seed, uint64_t step0, void* stream) {
+    int rc = check_visual(p, b, m);
+    if (rc != WL_OK) return rc;
+    if (!use_quad(b)) return WL_EINVAL;   // the quad form's (n <= 32 768)
+    if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
+    if (n_steps > 1 && obs_step_stride < (int64_t)b->n_envs * WL_VIS_OBS_DIM) return WL_EINVAL;   // the camera runs a step behind: rows must differ
+    if (b->metrics_slots > 1 && n_steps % b->metrics_slots == 0 && n_steps > 0) return WL_EINVAL;   // ring slot aliasing
+    clear_error();
+    // envs per block: one round of blocks on the 256 CUs (a block's thirteen-plus wavefronts at 128 VGPRs fill a CU)
+    const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
+    const MetricSlots ms = metric_slots(b, step0, (uint64_t)n_steps);
+    const int n = b->n_envs;
+#define WL_VIS_PERSIST(E)                                                                                                   \
+    visual_rollout_persistent_kernel<E><<<(n + (E) - 1) / (E), kPersistThreads, 0, (hipStream_t)stream>>>(                  \
+        *p, vd, *b, *m, (const float2*)actions, *out, obs_step_stride, vec_step_stride, n_steps, seed, step0, ms)
+    if (n <= 1024) WL_VIS_PERSIST(4);
+    else if (n <= 2048) WL_VIS_PERSIST(8);
+    else WL_VIS_PERSIST(16);
+#undef WL_VIS_PERSIST
     return launch_status();
 }
 
@@ -523,7 +688,7 @@ int wl_visual_observe(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
     if (rc != WL_OK) return rc;
     if (!obs) return WL_EINVAL;
     clear_error();
-    visual_obs_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, obs);
+    visual_obs_kernel<<<b->n_envs, kCam, 0, (hipStream_t)stream>>>(*p, *b, *m, obs);
     return launch_status();
 }
 
