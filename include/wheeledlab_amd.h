@@ -382,7 +382,7 @@ typedef struct WlPpoWideState {      /* caller-owned device memory; the caller z
     uint16_t *dt_hi, *dt_lo;         /* [mb_capacity / 64][128][64]  delta1^T planes, blocked likewise */
     float* dw_partials;              /* [splits][dp][128]   split-K partial sums of dW1^T */
     float* partials;                 /* [WL_PPO_BLOCKS][WL_PPO_PARTIAL_STRIDE]  per-block sums of the narrow part */
-    float* narrow;                   /* [WL_PPO_PARTIAL_STRIDE]  their reduction (first-layer weight slots unused) */
+    float* narrow;                   /* [WL_PPO_PARTIAL_STRIDE]  reserved (the rows are reduced straight into `grad`) */
     float* grad;                     /* [wl_ppo_wide_num_params(D) + 3]  flat gradient + value-loss / surrogate / KL sums */
     float *adam_m, *adam_v;          /* [wl_ppo_wide_num_params(D)] */
     float* ctrl;                     /* [16], WL_PPO_CTRL_* */

@@ -7,6 +7,9 @@ import torch
 
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wheeledlab_amd import _abi  # noqa: E402
+if os.environ.get("WL_PROBE_LIB"):          # A/B of another build of the library (gpurun_variants/lib_*.so)
+    _abi.load(os.environ["WL_PROBE_LIB"])
 from wheeledlab_amd.rl.ppo import ActorCritic, FusedWidePpoStep, PPO  # noqa: E402
 
 DEV = "cuda:0"

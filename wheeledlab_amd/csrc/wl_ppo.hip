@@ -403,9 +403,20 @@ struct PpoHyper {
 
 // the nets in MFMA operand order, built once per minibatch step (each slot is a dependent gather from the weight tensors:
 // done by every block of the gradient kernel it cost more than the matrix work)
-__global__ void __launch_bounds__(256) ppo_operands_kernel(const PpoNets N, float* __restrict__ operands) {
+// (wide agents: the same launch also splits the first-layer weights into the bf16 planes of wl_ppo_wide.hip's contractions
+// -- blocks behind the table's; everything that depends on the weights only, one launch in front of the step)
+struct WeightPlanes {
+    uint32_t *w_hi, *w_lo;   // [128][dp] as pairs, or NULL
+    int dp;
+};
+constexpr int kTabBlocks = (kTabFloats + 255) / 256;
+__global__ void __launch_bounds__(256) ppo_operands_kernel(const PpoNets N, float* __restrict__ operands, const WeightPlanes wp) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < kTabFloats) operands[i] = operand_value(N, i);
+    if ((int)blockIdx.x < kTabBlocks) {
+        if (i < kTabFloats) operands[i] = operand_value(N, i);
+        return;
+    }
+    weight_plane_pair(N.actor.w1, N.critic.w1, N.actor.in_dim, wp.dp, i - kTabBlocks * 256, wp.w_hi, wp.w_lo);
 }
 
 // Eight wavefronts per block: wavefronts 0..3 differentiate the ACTOR, 4..7 the CRITIC, pairwise on the same tiles (the
@@ -711,7 +722,9 @@ int check_ppo(const WlMlp* actor, const WlMlp* critic, const float* std, const W
 }
 
 // operands -> gradient kernel -> reduction of the per-block rows into `grad` ([kRow], narrow layout) + squared norm + std snapshot.
-// wio == nullptr: the drift agents' form (first layer in-kernel); else the wide form (wl_ppo_wide.hip).
+// wio == nullptr: the drift agents' form (first layer in-kernel); else the wide form (wl_ppo_wide.hip): the operand tables
+// are there already (ppo_prepare_wide) and the reduction is the caller's (ppo_wide_scatter_kernel); returns the number of
+// per-block rows written instead of WL_OK.
 int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
                 const WlPpoParams* hp, float* partials, float* operands, float* grad, float* norm2, float* std_snapshot,
                 const WideIo* wio, hipStream_t stream) {
@@ -728,7 +741,7 @@ int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const
         attr_set = true;
     }
     clear_error();
-    ppo_operands_kernel<<<(kTabFloats + 255) / 256, 256, 0, stream>>>(N, operands);
+    if (!wio) ppo_operands_kernel<<<kTabBlocks, 256, 0, stream>>>(N, operands, WeightPlanes{nullptr, nullptr, 0});
     const bool elu = actor->activation == WL_ACT_ELU;
     const WideIo none{nullptr, nullptr, nullptr};
     if (!wio) {
@@ -738,6 +751,7 @@ int launch_grad(const WlMlp* actor, const WlMlp* critic, const float* std, const
         if (elu) ppo_grad_kernel<WL_ACT_ELU, true><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, operands, *bt, mb_start, mb_size, h, partials, *wio);
         else ppo_grad_kernel<WL_ACT_RELU, true><<<blocks, 64 * kPpoWaves, lds_bytes, stream>>>(N, operands, *bt, mb_start, mb_size, h, partials, *wio);
     }
+    if (wio) return launch_status() == WL_OK ? blocks : WL_ELAUNCH;
     ppo_reduce_kernel<<<(kRow + 63) / 64, 256, 0, stream>>>(partials, blocks, grad, norm2, std, std_snapshot);
     return launch_status();
 }
@@ -759,11 +773,19 @@ int launch_apply(const WlMlp* actor, const WlMlp* critic, float* std, int in_dim
 }  // namespace
 
 namespace wl_internal {   // wl_ppo_internal.h: what wl_ppo_wide.hip drives
+int ppo_prepare_wide(const WlMlp* actor, const WlMlp* critic, const float* std, float* operands, int dp, uint16_t* w_hi, uint16_t* w_lo,
+                     hipStream_t stream) {
+    const PpoNets N{*actor, *critic, std};
+    clear_error();
+    ppo_operands_kernel<<<kTabBlocks + (128 * dp / 2 + 255) / 256, 256, 0, stream>>>(N, operands,
+                                                                                         WeightPlanes{(uint32_t*)w_hi, (uint32_t*)w_lo, dp});
+    return launch_status();
+}
 int ppo_tail_wide(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
-                  const WlPpoParams* hp, float* partials, float* operands, float* narrow_grad, float* norm2, float* std_snapshot,
-                  const float* h1, uint16_t* dt_hi, uint16_t* dt_lo, hipStream_t stream) {
+                  const WlPpoParams* hp, float* partials, float* operands, const float* h1, uint16_t* dt_hi, uint16_t* dt_lo,
+                  hipStream_t stream) {
     const WideIo wio{h1, dt_hi, dt_lo};
-    return launch_grad(actor, critic, std, bt, mb_start, mb_size, hp, partials, operands, narrow_grad, norm2, std_snapshot, &wio, stream);
+    return launch_grad(actor, critic, std, bt, mb_start, mb_size, hp, partials, operands, nullptr, nullptr, nullptr, &wio, stream);
 }
 int ppo_apply_any(const WlMlp* actor, const WlMlp* critic, float* std, int in_dim, int mb_size, const WlPpoParams* hp,
                   const float* grad, float* adam_m, float* adam_v, float* ctrl, int parity, int adam_step, hipStream_t stream) {

@@ -6,14 +6,20 @@
 
 namespace wl_internal {
 
+// Everything of a wide step that depends on the weights only, as one launch: the tail's operand tables (`operands`,
+// WL_PPO_OPERAND_FLOATS) and the first-layer weights of both nets as bf16 planes [128][dp] (as mlp_weight_planes).
+int ppo_prepare_wide(const WlMlp* actor, const WlMlp* critic, const float* std, float* operands, int dp, uint16_t* w_hi, uint16_t* w_lo,
+                     hipStream_t stream);
+
 // The gradient kernel of wl_ppo.hip with the first layer cut off: reads the activated layer-1 outputs `h1`
-// ([position in the minibatch][actor 64 | critic 64]), writes delta1^T as bf16 planes `dt_hi / dt_lo` (blocked [position / 64][128 units][position % 64]) and reduces
-// every other gradient (db1 included) + the three loss sums into `narrow_grad` ([WL_PPO_PARTIAL_STRIDE], the drift agents'
-// row layout with its first-layer weight slots left at zero).  Adds the squared norm of that row to *norm2 and copies
-// std[0..1] to std_snapshot.
+// ([position in the minibatch][actor 64 | critic 64]) and the tables of ppo_prepare_wide, writes delta1^T as bf16 planes
+// `dt_hi / dt_lo` (blocked [position / 64][128 units][position % 64]) and every other gradient (db1 included) + the three
+// loss sums as per-block rows `partials` ([WL_PPO_BLOCKS][WL_PPO_PARTIAL_STRIDE], the drift agents' row layout with its
+// first-layer weight slots left at zero).  Returns the number of rows written (the caller reduces them:
+// ppo_wide_scatter_kernel) or a negative WL_E* code.
 int ppo_tail_wide(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
-                  const WlPpoParams* hp, float* partials, float* operands, float* narrow_grad, float* norm2, float* std_snapshot,
-                  const float* h1, uint16_t* dt_hi, uint16_t* dt_lo, hipStream_t stream);
+                  const WlPpoParams* hp, float* partials, float* operands, const float* h1, uint16_t* dt_hi, uint16_t* dt_lo,
+                  hipStream_t stream);
 
 // entropy term + clipping + adaptive-KL rule + Adam on a flat gradient row of input width `in_dim` (statistics behind it)
 int ppo_apply_any(const WlMlp* actor, const WlMlp* critic, float* std, int in_dim, int mb_size, const WlPpoParams* hp,

@@ -85,24 +85,11 @@ __global__ void __launch_bounds__(256) ppo_wide_stage_kernel(const float* __rest
     }
 }
 
-// layer-1 weights of both nets -> planes [128][dp], dp = D rounded up to 64.  K chunk c holds features 64 c .. 64 c + 63,
-// except the LAST chunk of a D that is not a multiple of 64: it holds the row's last 64 features, D - 64 .. D - 1, with
-// the ones the previous chunk already covers set to zero.  The f32 operand of the contraction is then read at
-// min(64 c, D - 64): every load stays inside its row, at full width, with no padding of the observation rows.
-WL_DEV float chunked_weight(const float* __restrict__ w, int in_dim, int dp, int pos) {
-    const int c = pos >> 6, last = dp / 64 - 1;
-    if (c < last || in_dim == dp) return w[pos];
-    const int f = in_dim - 64 + (pos & 63);
-    return f < 64 * last ? 0.f : w[f];
-}
+// layer-1 weights of both nets -> planes [128][dp] (wl_bf16.h: weight_plane_pair)
 __global__ void __launch_bounds__(256) ppo_wide_weights_kernel(const float* __restrict__ w1_actor, const float* __restrict__ w1_critic,
                                                                const int in_dim, const int dp, uint32_t* __restrict__ w_hi,
                                                                uint32_t* __restrict__ w_lo) {
-    const int i = blockIdx.x * 256 + threadIdx.x;   // pair of positions
-    if (i >= kUnits * dp / 2) return;
-    const int u = i / (dp / 2), pos = 2 * (i - u * (dp / 2));
-    const float* w = u < kHid ? w1_actor + (int64_t)u * in_dim : w1_critic + (int64_t)(u - kHid) * in_dim;
-    split_bf16_pair(chunked_weight(w, in_dim, dp, pos), chunked_weight(w, in_dim, dp, pos + 1), w_hi[i], w_lo[i]);
+    weight_plane_pair(w1_actor, w1_critic, in_dim, dp, blockIdx.x * 256 + threadIdx.x, w_hi, w_lo);
 }
 
 // ---- the contraction ----------------------------------------------------------------------------------------------------------
@@ -303,15 +290,19 @@ constexpr int kActorRest = kHid + kHid * kHid + kHid + 2 * kHid + 2, kCriticRest
 static_assert(kN_CB1 + kCriticRest == kN_G, "narrow layout");
 
 // blocks [0, nb_w1): thread -> (feature, unit): sum over the splits (coalesced over the unit index), write grad[w1 slot],
-// add the squares to *norm2.  Remaining blocks: copy the narrow row's entries to their wide places + the three statistics.
+// add the squares to *norm2.  Remaining blocks: the reduction of the gradient kernel's per-block rows (`partials`
+// [n_rows][kRowN], the drift agents' layout with its first-layer weight slots unused) straight into their wide places + the
+// three statistics -- the arithmetic of ppo_reduce_kernel (64 columns per block, four row groups of threads), whose launch
+// and whose place in the dependent chain (it ran between the tail and the dW1 contraction) this saves; and the std snapshot.
 // VEC = 1: few features, many splits (the elevation agent: 704 x 128 sums of 128 terms) -- a thread per sum.  VEC = 4: many
 // features, few splits (the visual agent: 3264 x 128 sums of 16): a thread per four units, 16-byte loads, all of a
 // thread's loads in flight at once (a thread per sum ran at 0.9 TB/s there: 16 dependent-looking 4-byte loads each).
 // The same order of summation in both.
 template <int VEC>
 __global__ void __launch_bounds__(256) ppo_wide_scatter_kernel(const float* __restrict__ dw_partials, const int splits, const int dp,
-                                                               const float* __restrict__ narrow, const WideLayout L,
-                                                               const int nb_w1, float* __restrict__ grad, float* __restrict__ norm2) {
+                                                               const float* __restrict__ partials, const int n_rows, const WideLayout L,
+                                                               const int nb_w1, float* __restrict__ grad, float* __restrict__ norm2,
+                                                               const float* __restrict__ std, float* __restrict__ std_snapshot) {
     if ((int)blockIdx.x < nb_w1) {
         typedef float vec_t __attribute__((ext_vector_type(VEC)));
         const int i = (blockIdx.x * 256 + threadIdx.x) * VEC;    // = f * 128 + u
@@ -347,16 +338,38 @@ __global__ void __launch_bounds__(256) ppo_wide_scatter_kernel(const float* __re
         if (threadIdx.x == 0) atomicAdd(norm2, (part[0] + part[1]) + (part[2] + part[3]));
         return;
     }
-    const int j = (blockIdx.x - nb_w1) * 256 + threadIdx.x;   // index into the narrow row
-    if (j >= kRowN) return;
-    int to;
+    const int rb = blockIdx.x - nb_w1;
+    if (rb == 0 && threadIdx.x < 2) std_snapshot[threadIdx.x] = std[threadIdx.x];   // see ppo_reduce_kernel
+    __shared__ float part[4][64];
+    const int j = rb * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;   // j = index into the narrow row
+    int to = -1;
     if (j < 2) to = j;
-    else if (j < kN_AB1) return;                               // actor w1 slots: unused
+    else if (j < kN_AB1) to = -1;                              // actor w1 slots: unused
     else if (j < kN_CW1) to = L.o_arest + (j - kN_AB1);
-    else if (j < kN_CB1) return;                               // critic w1 slots
+    else if (j < kN_CB1) to = -1;                              // critic w1 slots
     else if (j < kN_G) to = L.o_crest + (j - kN_CB1);
-    else to = L.G + (j - kN_G);                                // value-loss, surrogate, KL sums
-    grad[to] = narrow[j];
+    else if (j < kRowN) to = L.G + (j - kN_G);                 // value-loss, surrogate, KL sums
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (to >= 0) {
+        int b = rg;
+        for (; b + 12 < n_rows; b += 16) {
+            s0 += partials[(int64_t)b * kRowN + j];
+            s1 += partials[(int64_t)(b + 4) * kRowN + j];
+            s2 += partials[(int64_t)(b + 8) * kRowN + j];
+            s3 += partials[(int64_t)(b + 12) * kRowN + j];
+        }
+        for (; b < n_rows; b += 4) s0 += partials[(int64_t)b * kRowN + j];
+    }
+    part[rg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0) {
+        const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (to >= 0) grad[to] = v;
+        float q = (to >= 0 && j < kN_G) ? v * v : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+        if (threadIdx.x == 0) atomicAdd(norm2, q);
+    }
 }
 
 int check_wide(const WlMlp* actor, const WlMlp* critic, const WlPpoWideState* st) {
@@ -385,8 +398,9 @@ int launch_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* 
                           const WlPpoParams* hp, const WlPpoWideState* st, int parity, hipStream_t stream) {
     const int dp = st->dp, D = st->in_dim;
     clear_error();
-    ppo_wide_weights_kernel<<<(kUnits * dp / 2 + 255) / 256, 256, 0, stream>>>(actor->w1, critic->w1, D, dp, (uint32_t*)st->w_hi,
-                                                                                (uint32_t*)st->w_lo);
+    // one launch for everything that depends on the weights only: the tail's operand tables and layer 1's bf16 planes
+    int rc = wl_internal::ppo_prepare_wide(actor, critic, std, st->operands, dp, st->w_hi, st->w_lo, stream);
+    if (rc != WL_OK) return rc;
     {   // H1 = act(X W1^T + b1): rows = samples of the minibatch (f32 rows of `obs` through `perm`), K = dp
         SkinnyArgs a{};
         a.b_f32 = bt->obs;
@@ -409,9 +423,9 @@ int launch_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* 
         if (launch_status() != WL_OK) return WL_ELAUNCH;
     }
     float* norm2 = st->ctrl + WL_PPO_CTRL_NORM2 + parity;
-    int rc = wl_internal::ppo_tail_wide(actor, critic, std, bt, mb_start, mb_size, hp, st->partials, st->operands, st->narrow, norm2,
-                                        st->ctrl + WL_PPO_CTRL_STD, st->h1, st->dt_hi, st->dt_lo, stream);
-    if (rc != WL_OK) return rc;
+    const int n_rows = wl_internal::ppo_tail_wide(actor, critic, std, bt, mb_start, mb_size, hp, st->partials, st->operands, st->h1,
+                                                  st->dt_hi, st->dt_lo, stream);   // rows of `partials` it filled
+    if (n_rows < 0) return n_rows;
     int splits_used = 1;
     {   // dW1^T = X^T delta1: rows = features, K = the minibatch's samples, split over <= `splits` blocks per row block
         SkinnyArgs a{};
@@ -432,13 +446,16 @@ int launch_wide_gradients(const WlMlp* actor, const WlMlp* critic, const float* 
         skinny_kernel<0, false><<<a.row_blocks * ((a.splits + 7) / 8 * 8), 256, 0, stream>>>(a);
     }
     const WideLayout L = wide_layout(D);
-    const int nb_rest = (kRowN + 255) / 256;
+    const int nb_rest = (kRowN + 63) / 64;
+    float* snap = st->ctrl + WL_PPO_CTRL_STD;
     if (splits_used <= 32 && dp >= 1024) {
         const int nb_w1 = dp * kUnits / (256 * 4);
-        ppo_wide_scatter_kernel<4><<<nb_w1 + nb_rest, 256, 0, stream>>>(st->dw_partials, splits_used, dp, st->narrow, L, nb_w1, st->grad, norm2);
+        ppo_wide_scatter_kernel<4><<<nb_w1 + nb_rest, 256, 0, stream>>>(st->dw_partials, splits_used, dp, st->partials, n_rows, L, nb_w1,
+                                                                         st->grad, norm2, std, snap);
     } else {
         const int nb_w1 = dp * kUnits / 256;
-        ppo_wide_scatter_kernel<1><<<nb_w1 + nb_rest, 256, 0, stream>>>(st->dw_partials, splits_used, dp, st->narrow, L, nb_w1, st->grad, norm2);
+        ppo_wide_scatter_kernel<1><<<nb_w1 + nb_rest, 256, 0, stream>>>(st->dw_partials, splits_used, dp, st->partials, n_rows, L, nb_w1,
+                                                                         st->grad, norm2, std, snap);
     }
     return launch_status();
 }
