@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 16
+#define WL_ABI_VERSION 17
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -537,6 +537,21 @@ typedef struct WlCollectIo {
 int wl_elev_collect_step(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const WlMlp* actor, const WlMlp* critic,
                          const float* std, const WlCollectIo* io, const WlStepOut* out, int32_t deterministic, uint64_t seed,
                          uint64_t step, void* stream);
+
+/* The runner's collection loop -- n_steps x { actions = actor(obs) -> env.step -> storage rows } (modified_rsl_rl_runner.py:
+ * 70-80) -- as ONE launch.  `io` / `out` are rows 0 of [n_steps (+ 1)][n]... blocks of an rsl_rl RolloutStorage: step k reads
+ * observation row io->obs_in + k n 689, writes actions / mu (+ k n 2), log_prob (+ k n), reward / flags / dones (+ k n) and the
+ * next observation row out->obs + k n 689 -- out->obs MUST be io->obs_in + n 689 (the policy of step k + 1 reads what step k
+ * wrote).  io->values is NOT written: the critic's values are not needed to step; evaluate the n_steps + 1 observation rows
+ * in one batched call afterwards (wl_actor_critic_act with nets = critic half).  `critic` is validated and otherwise unused.
+ * Block = 16 envs: the actor's first-layer matrix stays in the block's registers for the whole launch, the block's
+ * observation rows in LDS.  Quad form only (n_envs <= 32 768).  Per step equal to { wl_actor_critic_act; wl_elev_step } to
+ * fp32 rounding (first layer summed in eight partial sums instead of four), same random streams; a K-step launch equals K
+ * one-step launches bit for bit.  Episode metrics of all steps go to ring slot (step0 % slots), slot ((step0 + n_steps) %
+ * slots) is cleared. */
+int wl_elev_collect_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const WlMlp* actor, const WlMlp* critic,
+                            const float* std, const WlCollectIo* io, const WlStepOut* out, int32_t n_steps, int32_t deterministic,
+                            uint64_t seed, uint64_t step0, void* stream);
 
 
 /* ======================================================================================================== */

@@ -267,3 +267,69 @@ def test_one_launch_elevation_collector_equals_policy_step_plus_env_step(n, acti
     ea.collect_step(view, sa, 0, deterministic=True)
     torch.cuda.synchronize()
     assert torch.equal(sa.actions[0], sa.mu[0])
+
+
+@pytest.mark.parametrize("n,activation", [(4096, "relu"), (1000, "elu")])
+def test_persistent_elevation_collector(n, activation):
+    """wl_elev_collect_rollout (the runner's collection loop as ONE launch: actor layer 1 from the blocks' registers, observation
+    rows in LDS; the critic's values come from a batched pass afterwards).  (1) A K-step launch equals K one-step launches of
+    itself bit for bit (storage rows, env state).  (2) Each step against the per-step path -- wl_actor_critic_act + wl_elev_step
+    on a twin batch re-synchronised to the same state and observation row before the step: policy outputs to fp32 rounding
+    (layer 1 is summed in eight partial sums instead of four), the same random draws, and an env.step that agrees wherever the
+    actions do.  n = 1000 leaves the last 16-env block partly empty."""
+    from wheeledlab_amd.core import ElevBatch
+    from wheeledlab_amd.policy import RolloutStorage
+    from wheeledlab_amd.rl.ppo import ActorCritic
+    K, D = 8, 689
+    torch.manual_seed(5)
+    ac = ActorCritic(D, D, 2, activation=activation).to(DEV)
+    view = ac.fused()
+    view.planes = False
+    ea, eb, ec = (ElevBatch(n, device=DEV, seed=13) for _ in range(3))
+    for e in (ea, eb, ec):
+        e.reset()
+        e.episode_len[:n] = torch.randint(0, 198, (n,), device=DEV, dtype=torch.int32, generator=torch.Generator(device=DEV).manual_seed(2))
+    sa, sb, sc = (RolloutStorage(K, n, D, 2, DEV) for _ in range(3))
+    for e, s in ((ea, sa), (eb, sb), (ec, sc)):
+        s.observations[0].copy_(e.observe())
+    ea.collect_rollout(view, sa)                      # one launch
+    for k in range(K):                                # K launches of one step
+        eb.collect_rollout(view, sb, start=k, count=1)
+    torch.cuda.synchronize()
+    names = ("actions", "mu", "actions_log_prob", "observations", "rewards", "terminated", "time_outs", "dones")
+    for name in names:
+        assert torch.equal(getattr(sa, name), getattr(sb, name)), name
+    assert float(sa.values.abs().sum()) == 0.0        # not the collector's job
+    assert torch.equal(ea.state, eb.state) and torch.equal(ea.episode_len, eb.episode_len) and ea.step_count == eb.step_count == K
+    assert int(sa.dones.sum()) > 0 and bool(torch.isfinite(sa.observations).all())
+    torch.testing.assert_close(ea.metrics_raw.sum((0, 1)), eb.metrics_raw.sum((0, 1)), rtol=1e-5, atol=1e-3)
+    # (2) step by step against the two-launch path
+    ea2 = ElevBatch(n, device=DEV, seed=13)
+    ea2.reset()
+    ea2.state.copy_(ec.state)
+    ea2.episode_len.copy_(ec.episode_len)
+    sa2 = RolloutStorage(1, n, D, 2, DEV)
+    for k in range(K):
+        ea2.state.copy_(ec.state)                     # same start, same observation row
+        ea2.episode_len.copy_(ec.episode_len)
+        ea2.step_count = ec.step_count
+        sa2.observations[0].copy_(sc.observations[k])
+        ea2.collect_rollout(view, sa2, start=0, count=1)
+        view.act(sc.observations[k], sc.actions[k], sc.mu[k], sc.actions_log_prob[k], sc.values[k], ec.seed, ec.step_count, ec.env_offset)
+        ec.rollout(sc.actions[k:k + 1], sc.observations[k + 1:k + 2], sc.rewards[k:k + 1], sc.terminated[k:k + 1], sc.time_outs[k:k + 1],
+                   dones_out=sc.dones[k:k + 1])
+        torch.cuda.synchronize()
+        torch.testing.assert_close(sa2.mu[0], sc.mu[k], rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(sa2.actions[0], sc.actions[k], rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(sa2.actions_log_prob[0], sc.actions_log_prob[k], rtol=1e-5, atol=1e-5)
+        assert torch.equal(sa2.time_outs[0], sc.time_outs[k])
+        same = sa2.terminated[0] == sc.terminated[k]
+        assert int((~same).sum()) <= 1                # an action 1e-6 apart may tip a termination threshold
+        torch.testing.assert_close(sa2.rewards[0][same], sc.rewards[k][same], rtol=1e-3, atol=1e-2)
+        d = (sa2.observations[1] - sc.observations[k + 1]).abs()[same]
+        assert float(d[:, :13].max()) < 1e-3 and float((d[:, 13:] > 1e-3).float().mean()) < 1e-3
+        torch.testing.assert_close(ea2.state[:21, :n][:, same], ec.state[:21, :n][:, same], rtol=1e-3, atol=1e-3)
+    # the play policy: a = mu
+    ea.collect_rollout(view, sa, start=0, count=1, deterministic=True)
+    torch.cuda.synchronize()
+    assert torch.equal(sa.actions[0], sa.mu[0])

@@ -1,5 +1,6 @@
-"""us per collection step of the elevation task: the one-launch collector (wl_elev_collect_step) against policy step +
-env step (wl_actor_critic_act; wl_elev_step).  usage: collect_probe.py [n]"""
+"""us per collection step of the elevation task: the persistent collector (wl_elev_collect_rollout: K steps per launch) and the
+one-launch-per-step collector (wl_elev_collect_step) against policy step + env step (wl_actor_critic_act; wl_elev_step).
+usage: collect_probe.py [n]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -34,7 +35,11 @@ def two():
                     dones_out=st.dones[k:k + 1])
 
 
-for name, fn in (("one launch", one), ("policy step + env step", two)):
+def persistent():
+    env.collect_rollout(view, st)
+
+
+for name, fn in (("persistent collector (one launch per rollout)", persistent), ("one launch per step", one), ("policy step + env step", two)):
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 16
+WL_ABI_VERSION = 17
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -220,6 +220,8 @@ SIGNATURES = {
                                   _i32, _u64, _u64, _vp]),
     "wl_elev_collect_step": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _P(WlMlp), _P(WlMlp), _vp, _P(WlCollectIo),
                                        _P(WlStepOut), _i32, _u64, _u64, _vp]),
+    "wl_elev_collect_rollout": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _P(WlMlp), _P(WlMlp), _vp, _P(WlCollectIo),
+                                          _P(WlStepOut), _i32, _i32, _u64, _u64, _vp]),
     "wl_elev_rollout_persistent": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _P(WlStepOut), _i64, _i64,
                                              _i32, _u64, _u64, _vp]),
     "wl_elev_reset": (C.c_int, [_P(WlElevParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, _u64, _u64, _vp]),

@@ -305,6 +305,31 @@ class ElevBatch(_MetricsView):
                                               self.seed, self.step_count, self._stream()), "wl_elev_collect_step")
         self.step_count += 1
 
+    def collect_rollout(self, actor_critic, storage, start: int = 0, count: int | None = None, deterministic: bool = False):
+        """rows start .. start + count - 1 of the storage (and observation row start + count) from observation row `start`: the
+        runner's whole collection loop as ONE launch (wl_elev_collect_rollout: the actor's first layer in the blocks' registers,
+        their observation rows in LDS, the critic beside the physics).  Quad form only (n <= 32 768)."""
+        st = storage
+        count = st.n_steps - start if count is None else int(count)
+        key = (st.observations.data_ptr(), actor_critic.actor.w1.data_ptr(), actor_critic.critic.w1.data_ptr(), actor_critic.std.data_ptr())
+        if getattr(self, "_collect_key", None) != key:
+            assert st.n_envs == self.n and st.observations.shape[2] == self.OBS_DIM and st.observations.is_contiguous()
+            self._collect_key = key
+            self._collect_nets = (actor_critic.actor.struct(), actor_critic.critic.struct())
+        a, c = self._collect_nets
+        obs, k = st.observations, int(start)
+        io = A.WlCollectIo(obs[k].data_ptr(), st.actions[k].data_ptr(), st.mu[k].data_ptr(), st.actions_log_prob[k].data_ptr(),
+                           st.values[k].data_ptr())
+        out = A.WlStepOut(obs[k + 1].data_ptr(), st.rewards[k].data_ptr(), st.terminated[k].data_ptr(), st.time_outs[k].data_ptr(),
+                          st.dones[k].data_ptr())
+        if self.metrics_slots > 1 and count > 1:
+            R = self.metrics_slots       # the launch folds all its steps into slot step0 % R: the slots it skips keep old counts
+            self.metrics_raw[[(self.step_count + i) % R for i in range(1, count)]] = 0
+        A.check(self.lib.wl_elev_collect_rollout(C.byref(self.p), C.byref(self._bufs), C.byref(self._hf), C.byref(a), C.byref(c),
+                                                 actor_critic.std.data_ptr(), C.byref(io), C.byref(out), count, int(bool(deterministic)),
+                                                 self.seed, self.step_count, self._stream()), "wl_elev_collect_rollout")
+        self.step_count += count
+
 
 class VisualBatch(_MetricsView):
     """n visual-task envs on one GPU: flat black/white traversability plane + ray-cast grey camera."""

@@ -66,7 +66,7 @@ WL_DEV ElevTerms elev_terms(const WlElevParams& p, V3 pos, float up_dot, V3 vb, 
 // observation row by the lane-per-env kernels (step / prop); the block-per-env scan kernel adds the 676 map values
 template <int LANES>
 WL_DEV void write_elev_prop(const WlElevParams& p, float* __restrict__ row, V3 pos, Quat q, V3 vb, V3 wb, float cbx, float cby,
-                            float a0, float a1, int wid, bool lead) {
+                            float a0, float a1, int wid, bool lead, float* row2 = nullptr /* a second copy (the collector's LDS tile) */) {
     V3 eu;
     if constexpr (LANES == 4) {   // roll / pitch / yaw as one lane-parallel atan2 (asin x = atan2(x, sqrt(1 - x^2)))
         const float sp = 2.f * (q.w * q.y - q.z * q.x);
@@ -80,19 +80,18 @@ WL_DEV void write_elev_prop(const WlElevParams& p, float* __restrict__ row, V3 p
     }
     if (!lead) return;
     const float gx = cbx - pos.x, gy = cby - pos.y;
-    row[0] = gx != gx ? 0.f : gx;   // nan_to_num(nan=0) (:55); +-inf are left to the policy as in the reference
-    row[1] = gy != gy ? 0.f : gy;
-    row[2] = eu.x;
-    row[3] = eu.y;
-    row[4] = eu.z;
-    row[5] = clampf(vb.x, -p.obs_clip, p.obs_clip);
-    row[6] = clampf(vb.y, -p.obs_clip, p.obs_clip);
-    row[7] = clampf(vb.z, -p.obs_clip, p.obs_clip);
-    row[8] = clampf(wb.x, -p.obs_clip, p.obs_clip);
-    row[9] = clampf(wb.y, -p.obs_clip, p.obs_clip);
-    row[10] = clampf(wb.z, -p.obs_clip, p.obs_clip);
-    row[11] = clampf(a0, -1.f, 1.f);
-    row[12] = clampf(a1, -1.f, 1.f);
+    const float v[13] = {gx != gx ? 0.f : gx,   // nan_to_num(nan=0) (:55); +-inf are left to the policy as in the reference
+                         gy != gy ? 0.f : gy,
+                         eu.x, eu.y, eu.z,
+                         clampf(vb.x, -p.obs_clip, p.obs_clip), clampf(vb.y, -p.obs_clip, p.obs_clip), clampf(vb.z, -p.obs_clip, p.obs_clip),
+                         clampf(wb.x, -p.obs_clip, p.obs_clip), clampf(wb.y, -p.obs_clip, p.obs_clip), clampf(wb.z, -p.obs_clip, p.obs_clip),
+                         clampf(a0, -1.f, 1.f), clampf(a1, -1.f, 1.f)};
+#pragma unroll
+    for (int i = 0; i < 13; ++i) row[i] = v[i];
+    if (row2) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) row2[i] = v[i];
+    }
 }
 
 struct ElevReset {
@@ -219,7 +218,7 @@ template <int LANES, bool PERSIST = false>
 WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const WlEnvBuffers& b, const HeightFieldGround& ground,
                               const float2 action, ElevRows<LANES>& rows, const WlStepOut& out, const uint64_t seed,
                               const uint64_t step, const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics,
-                              ElevBook* carry = nullptr) {
+                              ElevBook* carry = nullptr, float* prop2 = nullptr) {
     const WlVehicleParams& vp = p.vehicle;
     const uint32_t gid = (uint32_t)(b.env_offset + e);
     float2 a = action;
@@ -376,7 +375,7 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
     // proprioceptive part of the observation, from the post-reset state (all lanes of a quad take part)
     const Mat3 R2 = mat_from_quat(s.q);
     write_elev_prop<LANES>(p, out.obs + (int64_t)e * WL_ELEV_OBS_DIM, pos, s.q, mul_t(R2, s.v), mul_t(R2, ww), cbx, cby, a0, a1,
-                           wid, lead);
+                           wid, lead, prop2);
     float yc, ys;
     yaw_cs(s.q, yc, ys);
     return ScanPose{pos.x, pos.y, pos.z, yc, ys};
@@ -768,6 +767,258 @@ __global__ void __launch_bounds__(kFusedThreads) elev_rollout_persistent_kernel(
 }
 
 // proprioceptive part only, lane per env: used by wl_elev_observe (reset / get_observations path)
+// ---- the runner's collection, K x { actions = actor(obs) -> env.step -> storage rows } (modified_rsl_rl_runner.py:70-80), as ONE launch ----
+// Block = 16 envs, eight wavefronts, K steps in a loop.  What makes the policy step cheap enough to live inside the env's
+// block: the ACTOR's first-layer matrix (64 x 689 f32 = 176 KB) is held in the block's REGISTERS for the whole launch (each
+// of the eight wavefronts keeps the MFMA A fragments of its 5 - 6 sixteen-feature chunks: <= 96 VGPRs; a CU's register
+// file is 512 KB), and the block's 16 observation rows live in LDS, where the scan writes them.  Per step and block:
+//   A  all eight wavefronts: partial layer-1 products of the actor from registers x LDS rows (<= 96 MFMAs each), to LDS
+//   B  wavefront 0: sums them, layers 2 - 3 (tail weights parked in LDS), draw, log-prob, storage rows; then the 16 envs'
+//      physics as in elev_rollout_persistent_kernel (rows and bookkeeping parked in LDS between steps: registers are the
+//      scarce resource here -- every wavefront's allocation carries the 96 weight registers)
+//   D  all wavefronts: the 16 x 676 height rays of the post-step poses, into the storage's next observation row AND the LDS rows
+// Three s_barriers per step.  (The one-launch-per-step collector above streams both matrices from L2 for 16 rows per step
+// and block -- 90 MB per step chip-wide -- and is bound by exactly that.)
+// The CRITIC is not in here: its values are not needed to step, and the caller evaluates all K + 1 observation rows in one
+// batched pass afterwards.  Measured with the critic inside (its first layer streamed from L2 by wavefronts 1..7 beside
+// the physics, wavefront 1 finishing the net): 55 us per step against 33.7 without -- not the streaming itself (pacing it
+// and cache-policy bits changed nothing) but its registers: the allocator answered with 85 - 160 spills, part of them
+// inside the sub-step loop of the lone physics wavefront.
+// Arithmetic: layer 1 is summed in eight partial sums per unit (wl_actor_critic_act: four): equal to that kernel to rounding,
+// not bit for bit; the env.step is elev_env_step's.
+constexpr int kColWavesA = 8;                                                  // wavefronts sharing the actor's first layer
+constexpr int kColChunks = (WL_ELEV_OBS_DIM + 15) / 16;                        // 44 (the last holds one feature)
+constexpr int kColMaxA = (kColChunks + kColWavesA - 1) / kColWavesA;           // 6
+constexpr int kTilePitch = (WL_ELEV_OBS_DIM + 3) / 4 * 4;                      // 692 floats: 16-byte aligned LDS rows
+constexpr int kPartFloats = kColWavesA * kMlpTiles * 64 * 4;                   // one net's partial accumulators
+constexpr int kTailFloats = (kMlpTiles * kMlpHidSteps + kMlpHidSteps) * 64;    // an MlpTail, [value][lane]
+constexpr int kCarryWords = 20 + 3 + WL_ER_NTERMS + 4 + 2;                      // wavefront 0's rows + bookkeeping (carry_io), [word][lane]
+constexpr int kColLdsFloats = kFusedEnvs * kTilePitch + kPartFloats + kTailFloats + kCarryWords * 64 + kFusedEnvs * 13 +
+                              kFusedEnvs * 8 + kFusedEnvs * 2 + WL_M_COUNT + 4;
+WL_DEV int col_chunk_begin(int w, int waves) { return w * (kColChunks / waves) + min(w, kColChunks % waves); }
+
+// wavefront-private values parked in LDS, one column per lane (no barrier: the lane that writes is the lane that reads).
+// Field by field: a memcpy through a word array left the array on the stack.
+struct LdsColumn {
+    float* base;
+    int lane, i;
+    WL_DEV void put(float v) { base[(i++) * 64 + lane] = v; }
+    WL_DEV void put(int v) { base[(i++) * 64 + lane] = __int_as_float(v); }
+    WL_DEV void get(float& v) { v = base[(i++) * 64 + lane]; }
+    WL_DEV void get(int& v) { v = __float_as_int(base[(i++) * 64 + lane]); }
+};
+template <bool PUT, class T>
+WL_DEV void col_io(LdsColumn& c, T& v) {
+    if constexpr (PUT) c.put(v); else c.get(v);
+}
+template <bool PUT>
+WL_DEV void tail_io(float* base, int lane, MlpTail& W) {
+    LdsColumn c{base, lane, 0};
+#pragma unroll
+    for (int t = 0; t < kMlpTiles; ++t)
+#pragma unroll
+        for (int i = 0; i < kMlpHidSteps; ++i) col_io<PUT>(c, W.w2[t][i]);
+#pragma unroll
+    for (int i = 0; i < kMlpHidSteps; ++i) col_io<PUT>(c, W.w3[i]);
+}
+template <bool PUT>
+WL_DEV void carry_io(float* base, int lane, ElevRows<4>& r, ElevBook& k) {
+    LdsColumn c{base, lane, 0};
+    col_io<PUT>(c, r.mass), col_io<PUT>(c, r.mu_s), col_io<PUT>(c, r.mu_d), col_io<PUT>(c, r.damp);
+    col_io<PUT>(c, r.pos.x), col_io<PUT>(c, r.pos.y), col_io<PUT>(c, r.pos.z);
+    col_io<PUT>(c, r.v.x), col_io<PUT>(c, r.v.y), col_io<PUT>(c, r.v.z);
+    col_io<PUT>(c, r.ww.x), col_io<PUT>(c, r.ww.y), col_io<PUT>(c, r.ww.z);
+    col_io<PUT>(c, r.q.w), col_io<PUT>(c, r.q.x), col_io<PUT>(c, r.q.y), col_io<PUT>(c, r.q.z);
+    col_io<PUT>(c, r.wheel[0]), col_io<PUT>(c, r.th), col_io<PUT>(c, r.om);
+    col_io<PUT>(c, k.ep_len), col_io<PUT>(c, k.cb[0]), col_io<PUT>(c, k.cb[1]);
+#pragma unroll
+    for (int i = 0; i < WL_ER_NTERMS; ++i) col_io<PUT>(c, k.epsum[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) col_io<PUT>(c, k.tgt[i]);
+    col_io<PUT>(c, k.act[0]), col_io<PUT>(c, k.act[1]);
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(kFusedThreads) elev_collect_rollout_kernel(const WlElevParams p, const VehDerived vd, const WlEnvBuffers b,
+                                                                             const HeightFieldGround ground, const WlStepOut out,
+                                                                             const int n_steps, const uint64_t seed, const uint64_t step0,
+                                                                             const PolicyIo pio, const MetricSlots slots) {
+    extern __shared__ __attribute__((aligned(16))) float col_lds[];
+    float* obs_tile = col_lds;                                   // [16][kTilePitch]
+    float* part_a = obs_tile + kFusedEnvs * kTilePitch;          // [8][4][64][4]
+    float* tail_a = part_a + kPartFloats;                        // the actor's MlpTail, [85][64]
+    float* carry = tail_a + kTailFloats;                         // wavefront 0's ElevRows + ElevBook between steps, [words][64]
+    float* prop = carry + kCarryWords * 64;                      // [16][13]
+    ScanPose* pose = reinterpret_cast<ScanPose*>(prop + kFusedEnvs * 13);   // [16] (5 floats each, 8 reserved)
+    float2* act_lds = reinterpret_cast<float2*>(prop + kFusedEnvs * 13 + kFusedEnvs * 8);
+    float* blk_metrics = reinterpret_cast<float*>(act_lds + kFusedEnvs);
+    constexpr int D = WL_ELEV_OBS_DIM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+    const int e0 = blockIdx.x * kFusedEnvs, n = b.n_envs;
+    const int n_here = min(kFusedEnvs, n - e0);
+    if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
+    if (b.metrics_slots > 1) clear_metric_slot(b, slots.next);
+    // the block's first observation rows -> LDS (rows past the batch and the pad columns: zero)
+    for (int i = tid; i < kFusedEnvs * kTilePitch; i += kFusedThreads) {
+        const int r = i / kTilePitch, c = i - r * kTilePitch;
+        obs_tile[i] = (r < n_here && c < D) ? pio.obs_in[(int64_t)(e0 + r) * D + c] : 0.f;
+    }
+    // every wavefront: its chunks of the actor's first layer as MFMA A fragments (unit 16 t + m, features 16 c + 4 g ..)
+    const int a0 = col_chunk_begin(wave, kColWavesA), a1 = col_chunk_begin(wave + 1, kColWavesA);
+    f32x4 ra[kColMaxA][kMlpTiles];
+#pragma unroll
+    for (int j = 0; j < kColMaxA; ++j)
+#pragma unroll
+        for (int t = 0; t < kMlpTiles; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = 16 * (a0 + j) + 4 * g + q;
+                ra[j][t][q] = (a0 + j < a1 && f < D) ? pio.actor.w1[(int64_t)(16 * t + m) * D + f] : 0.f;
+            }
+    // wavefront 0: the actor's tail weights and the envs' rows / bookkeeping, parked in LDS between their uses
+    const int wid = tid & 3, e = e0 + (tid >> 2);
+    const bool phys = wave == 0 && e < n;
+    const Rows S = make_rows(b.state, b.stride);
+    if (wave == 0) {
+        MlpTail Wa;
+        load_tail(pio.actor, lane, Wa);
+        tail_io<true>(tail_a, lane, Wa);
+        if (phys) {
+            ElevRows<4> rows = load_elev_rows<4>(S, e, wid);
+            ElevBook book = load_elev_book<4>(p, b, S, e);
+            carry_io<true>(carry, lane, rows, book);
+        }
+    }
+    const float g0 = -0.5f * p.scan_size;
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < n_steps; ++k) {
+        const uint64_t step = step0 + (uint64_t)k;
+        const int64_t kn = (int64_t)k * n;
+        // ---- A: actor layer 1, partial sums (all eight wavefronts) ----
+        {
+            f32x4 h[kMlpTiles];
+#pragma unroll
+            for (int t = 0; t < kMlpTiles; ++t) h[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < kColMaxA; ++j)
+                if (a0 + j < a1) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(obs_tile + m * kTilePitch + 16 * (a0 + j) + 4 * g);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int t = 0; t < kMlpTiles; ++t) h[t] = mfma4(ra[j][t][q], x[q], h[t]);
+                }
+#pragma unroll
+            for (int t = 0; t < kMlpTiles; ++t) *reinterpret_cast<f32x4*>(part_a + ((wave * kMlpTiles + t) * 64 + lane) * 4) = h[t];
+        }
+        __syncthreads();   // barrier 1: the actor's partial sums are in LDS
+        if (wave == 0) {
+            // ---- B: the rest of the actor, the draw, the storage rows; then the physics ----
+            {
+                f32x4 h[kMlpTiles];
+#pragma unroll
+                for (int t = 0; t < kMlpTiles; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[t][r] = pio.actor.b1[16 * t + 4 * g + r];
+#pragma unroll
+                for (int w = 0; w < kColWavesA; ++w)
+#pragma unroll
+                    for (int t = 0; t < kMlpTiles; ++t) h[t] += *reinterpret_cast<const f32x4*>(part_a + ((w * kMlpTiles + t) * 64 + lane) * 4);
+                MlpTail Wa;
+                tail_io<false>(tail_a, lane, Wa);
+                const f32x4 o4 = eval_tail<ACT>(Wa, h, lane);
+                if (g == 0) {
+                    float z0 = 0.f, z1 = 0.f;
+                    if (!pio.deterministic) {
+                        const F4 u = philox_uniform4((uint32_t)(b.env_offset + e0 + m), step, WL_RS_POLICY, seed);
+                        box_muller(u.x, u.y, z0, z1);
+                    }
+                    const float std0 = pio.std[0], std1 = pio.std[1];
+                    const float2 av = make_float2(fmaf(std0, z0, o4[0]), fmaf(std1, z1, o4[1]));
+                    act_lds[m] = av;
+                    if (e0 + m < n) {
+                        reinterpret_cast<float2*>(pio.actions)[kn + e0 + m] = av;
+                        reinterpret_cast<float2*>(pio.mu)[kn + e0 + m] = make_float2(o4[0], o4[1]);
+                        pio.log_prob[kn + e0 + m] = fmaf(-0.5f, fmaf(z0, z0, z1 * z1), -(log_fast(std0) + log_fast(std1)) - kLog2PiA);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // act_lds: written by lanes 0..15, read by all 64 below
+            __builtin_amdgcn_wave_barrier();
+            if (phys) {
+                WlStepOut o = out;
+                o.obs += kn * D;
+                o.reward += kn;
+                o.terminated += kn;
+                o.truncated += kn;
+                if (o.dones) o.dones += kn;
+                const float2 a = act_lds[tid >> 2];
+                ElevRows<4> rows;
+                ElevBook book;
+                carry_io<false>(carry, lane, rows, book);
+                const ScanPose sp = elev_env_step<4, true>(p, vd, b, ground, a, rows, o, seed, step, S, e, wid, wid == 0, blk_metrics, &book,
+                                                           prop + (tid >> 2) * 13);
+                carry_io<true>(carry, lane, rows, book);
+                if (wid == 0) pose[tid >> 2] = sp;
+            }
+        }
+        __syncthreads();   // barrier 2: poses and proprioception of step k published; nobody reads the old observation rows any more
+        // ---- D: the next observation rows: proprioception from wavefront 0, the height scan by everyone ----
+        int tl = tid;
+        asm volatile("" : "+v"(tl));   // per-step copy: keeps the 22 rays' index arithmetic of a thread inside the loop (registers)
+        if (tl < kFusedEnvs * 13) {
+            const int r = tl / 13, c = tl - r * 13;
+            obs_tile[r * kTilePitch + c] = prop[tl];
+        }
+        {
+            constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N, kAll = kFusedEnvs * kRays;
+            constexpr int kBatches = 3, kSlots = (kAll + kFusedThreads - 1) / kFusedThreads, kBatch = (kSlots + kBatches - 1) / kBatches;
+            float* obs_k = out.obs + kn * D;
+#pragma unroll
+            for (int part = 0; part < kBatches; ++part) {
+                HeightFieldGround::Corners cr[kBatch];
+                float pz[kBatch];
+#pragma unroll
+                for (int i = 0; i < kBatch; ++i) {
+                    const int idx = min(tl + (part * kBatch + i) * kFusedThreads, kAll - 1);
+                    const int j = idx / kRays, r = idx - j * kRays;
+                    const int iy = r / WL_ELEV_SCAN_N, ix = r - iy * WL_ELEV_SCAN_N;
+                    const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
+                    const ScanPose sp = pose[min(j, n_here - 1)];
+                    pz[i] = sp.pz;
+                    cr[i] = ground.corners(sp.px + (sp.c * lx - sp.s * ly), sp.py + (sp.s * lx + sp.c * ly));
+                }
+#pragma unroll
+                for (int i = 0; i < kBatch; ++i) {
+                    const int idx = tl + (part * kBatch + i) * kFusedThreads;
+                    const int j = idx / kRays, r = idx - j * kRays;
+                    if (idx < kAll && j < n_here) {
+                        const float hz = ground.blend(cr[i]);
+                        const float val = cr[i].inside ? (-(pz[i] - hz - p.scan_offset) + (pz[i] - p.elev_z0)) : __builtin_inff();
+                        const float v = clampf(val, -p.obs_clip, p.obs_clip);
+                        obs_k[(int64_t)(e0 + j) * D + 13 + r] = v;
+                        obs_tile[j * kTilePitch + 13 + r] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();   // barrier 3: the observation rows of step k + 1 are complete
+    }
+    if (wave == 0) {
+        if (phys) {
+            ElevRows<4> rows;
+            ElevBook book;
+            carry_io<false>(carry, lane, rows, book);
+            store_elev_state<4>(p, b, S, e, wid, wid == 0, rows, book);
+        }
+        if (tid < WL_M_COUNT) {   // only this wavefront accumulated
+            const float v = blk_metrics[tid];
+            if (v != 0.f) atomicAdd(metric_shard(b, slots.cur) + tid, v);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) elev_prop_kernel(const WlElevParams p, const WlEnvBuffers b, float* __restrict__ obs) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= b.n_envs) return;
@@ -911,6 +1162,43 @@ int wl_elev_collect_step(const WlElevParams* p, const WlEnvBuffers* b, const WlH
         elev_step_scan_kernel<true, WL_ACT_ELU><<<grid, kFusedThreads, 0, (hipStream_t)stream>>>(*p, vd, *b, g, nullptr, *out, seed, step, pio);
     else
         elev_step_scan_kernel<true, WL_ACT_RELU><<<grid, kFusedThreads, 0, (hipStream_t)stream>>>(*p, vd, *b, g, nullptr, *out, seed, step, pio);
+    return launch_status();
+}
+
+int wl_elev_collect_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const WlMlp* actor, const WlMlp* critic,
+                            const float* std, const WlCollectIo* io, const WlStepOut* out, int32_t n_steps, int32_t deterministic,
+                            uint64_t seed, uint64_t step0, void* stream) {
+    int rc = check_elev(p, b, hf);
+    if (rc != WL_OK) return rc;
+    if (!use_quad(b)) return WL_EINVAL;   // the quad form's (n <= 32 768); beyond: act + step
+    if (!actor || !critic || !std || !io || !io->obs_in || !io->actions || !io->mu || !io->log_prob || !io->values || n_steps < 0) return WL_EINVAL;
+    if (!out || !out->obs || !out->reward || !out->terminated || !out->truncated) return WL_EINVAL;
+    for (const WlMlp* m : {actor, critic})
+        if (!m->w1 || !m->b1 || !m->w2 || !m->b2 || !m->w3 || !m->b3 || m->hidden != kMlpHidden || m->in_dim != WL_ELEV_OBS_DIM ||
+            (m->activation != WL_ACT_ELU && m->activation != WL_ACT_RELU))
+            return WL_EINVAL;
+    if (actor->out_dim != 2 || critic->out_dim != 1 || actor->activation != critic->activation) return WL_EINVAL;
+    if (((uintptr_t)io->actions & 7u) || ((uintptr_t)io->mu & 7u) || ((uintptr_t)io->obs_in & 3u)) return WL_EALIGN;
+    // rows k of a [K + 1][n][689] observation block: the kernel writes row k + 1 where the caller's policy would read it
+    if (out->obs != io->obs_in + (int64_t)b->n_envs * WL_ELEV_OBS_DIM) return WL_EINVAL;
+    if (b->metrics_slots > 1 && n_steps % b->metrics_slots == 0 && n_steps > 0) return WL_EINVAL;   // ring slot aliasing
+    const HeightFieldGround g = make_ground(hf);
+    const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
+    const PolicyIo pio{*actor, *critic, std, io->obs_in, io->actions, io->mu, io->log_prob, io->values, deterministic};
+    const int grid = (b->n_envs + kFusedEnvs - 1) / kFusedEnvs;
+    const size_t lds_bytes = (size_t)kColLdsFloats * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)elev_collect_rollout_kernel<WL_ACT_ELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        (void)hipFuncSetAttribute((const void*)elev_collect_rollout_kernel<WL_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    const MetricSlots ms = metric_slots(b, step0, (uint64_t)n_steps);
+    clear_error();
+    if (actor->activation == WL_ACT_ELU)
+        elev_collect_rollout_kernel<WL_ACT_ELU><<<grid, kFusedThreads, lds_bytes, (hipStream_t)stream>>>(*p, vd, *b, g, *out, n_steps, seed, step0, pio, ms);
+    else
+        elev_collect_rollout_kernel<WL_ACT_RELU><<<grid, kFusedThreads, lds_bytes, (hipStream_t)stream>>>(*p, vd, *b, g, *out, n_steps, seed, step0, pio, ms);
     return launch_status();
 }
 

@@ -148,6 +148,25 @@ WL_DEV void clear_metric_slot(const WlEnvBuffers& b, int slot) {   // block 0 ze
         for (int i = threadIdx.x; i < kMetricSlotFloats; i += (int)blockDim.x) b.metrics[(int64_t)slot * kMetricSlotFloats + i] = 0.f;
 }
 
+// How a GROUP of wavefronts of a block meets (the visual camera's render groups, the elevation collector's layer-1 wavefronts).
+// BlockSync: the block's s_barrier -- every group of the block makes the same calls.  GroupSync: a counting barrier in LDS among the group's own wavefronts, for blocks in which other wavefronts
+// do something else meanwhile (the persistent rollout's physics wavefront would have to join an s_barrier).  Spinning is
+// safe: the wavefronts of a workgroup are always co-resident.  The counter only grows (target = arrivals so far).
+struct BlockSync {
+    WL_DEV void operator()() { __syncthreads(); }
+};
+struct GroupSync {
+    int* cnt;
+    int target, n_waves;
+    WL_DEV void operator()() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        target += n_waves;
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+
 // The slot of the metric ring a launch accumulates into and the slot it clears for its successor, computed by the
 // C-ABI wrapper: `step % slots` on a 64-bit step is ~110 scalar instructions in-kernel (no hardware divide), twice,
 // on the latency-critical head and tail of a 7 us launch.

@@ -257,25 +257,7 @@ WL_DEV V3 pixel_ray_body(const WlVisualParams& p, int row, int col) {
     return v3(1.f, -(((float)col + 0.5f - p.cx) / p.fx), -(((float)row + 0.5f - p.cy) / p.fy));
 }
 
-// How the wavefronts that render one image meet.  BlockSync: the block's s_barrier -- every group of the block makes the
-// same calls.  GroupSync: a counting barrier in LDS among the group's own wavefronts, for blocks in which other wavefronts
-// do something else meanwhile (the persistent rollout's physics wavefront would have to join an s_barrier).  Spinning is
-// safe: the wavefronts of a workgroup are always co-resident.  The counter only grows (target = arrivals so far).
-struct BlockSync {
-    WL_DEV void operator()() { __syncthreads(); }
-};
-struct GroupSync {
-    int* cnt;
-    int target, n_waves;
-    WL_DEV void operator()() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        target += n_waves;
-        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-};
-
+// (BlockSync / GroupSync -- how the wavefronts that render one image meet -- are in wl_kernel_common.h)
 // sum over the GT threads (whole wavefronts) that render one image
 template <int GT, class SYNC>
 WL_DEV float group_sum(float v, float* scratch /* [GT / 64], this group's */, int gt, SYNC& sync) {

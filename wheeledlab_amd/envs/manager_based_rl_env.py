@@ -384,6 +384,34 @@ class ManagerBasedRLEnv:
                 for name, term in self._flat.curriculum:
                     term.func(self, None, **term.params)
 
+    def can_collect_rollout(self) -> bool:
+        """the whole collection loop as one launch per curriculum segment (collect_rollout): elevation task, quad form"""
+        return (self._task == "elevation" and self._batch.n <= 32768 and not self._has_custom_rewards
+                and os.environ.get("WL_ELEV_PERSISTENT_COLLECT", "1") != "0")
+
+    def collect_rollout(self, actor_critic, storage):
+        """storage.n_steps x { actor -> sample -> env.step } of the runner's collection loop (modified_rsl_rl_runner.py:70-80) in ONE
+        launch per curriculum segment (wl_elev_collect_rollout: the actor's first layer in the blocks' registers, the
+        observation rows in LDS); observation row 0 of the storage must hold the current observation.  The critic's values
+        are NOT filled in (not needed to step): evaluate storage.observations in one batched pass afterwards.  The rollout is
+        cut at curriculum boundaries exactly as rollout_policy() cuts the drift task's; call finish_collection() after it."""
+        if not self.can_collect_rollout():
+            raise NotImplementedError("the persistent collector exists for the elevation task (quad form, built-in reward terms)")
+        b, K, k = self._batch, storage.n_steps, 0
+        while k < K:
+            seg = K - k
+            if self._has_curriculum:
+                seg = min(seg, self.max_episode_length - self.common_step_counter % self.max_episode_length)
+            b.collect_rollout(actor_critic, storage, start=k, count=seg)
+            k += seg
+            self.common_step_counter += seg
+            self._sim_step_counter += seg * self.cfg.decimation
+            if self._has_curriculum and self.common_step_counter % self.max_episode_length == 0:
+                if bool(storage.dones[k - 1].any()):
+                    for name, term in self._flat.curriculum:
+                        term.func(self, None, **term.params)
+        self.action_manager.prev_action = storage.actions[K - 1]
+
     def finish_collection(self, storage, n_steps: int | None = None):
         """after the last collect_step(): the env's own observation buffer and episode log catch up with the storage"""
         b, K = self._batch, storage.n_steps if n_steps is None else n_steps

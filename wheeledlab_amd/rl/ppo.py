@@ -341,6 +341,18 @@ class OnPolicyRunner:
         view = ac.fused() if one_launch else None
         base = self.env.unwrapped
         batch = getattr(base, "_batch", None)
+        if one_launch and hasattr(base, "can_collect_rollout") and base.can_collect_rollout():
+            # the whole loop as one launch per curriculum segment, then every row's value in one batched pass (the critic is
+            # not needed to step)
+            with torch.inference_mode():
+                st.observations[0].copy_(obs)
+                base.collect_rollout(view, st)
+                base.finish_collection(st)
+                K, n = st.n_steps, st.n_envs
+                rows, vals = st.observations.view((K + 1) * n, -1), st.values.view((K + 1) * n)
+                for r0 in range(0, (K + 1) * n, 32768):
+                    view.values(rows[r0:r0 + 32768], vals[r0:r0 + 32768])
+            return st.observations[K]
         if one_launch and hasattr(base, "collect_step") and not getattr(base, "_has_custom_rewards", False):
             # every output straight into the storage rows: per step one policy launch + the env's own launches, no copies
             with torch.inference_mode():
