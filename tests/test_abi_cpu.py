@@ -130,6 +130,18 @@ def test_layout_of_task_structs_and_misuse_codes(tmp_path):
     assert lib.wl_drift_step(C.byref(p), C.byref(good), base, None, C.byref(out), 0, 0, None) == -1      # > 32 ref poses
     ep = PP.elev_params()
     assert lib.wl_elev_step(C.byref(ep), C.byref(good), None, base, C.byref(out), 0, 0, None) == -1      # no heightfield
+    # persistent elevation collector: observation rows k + 1 must be where the policy of step k + 1 reads them; quad form only
+    hfb = A.WlHeightField(base, 8, 8, 0.0, 0.0, 1.0, 0.0)
+    net = lambda o: A.WlMlp(base, base, base, base, base, base, A.ELEV_OBS_DIM, o, 64, A.ACT_ELU)
+    na, nc = net(2), net(1)
+    io = A.WlCollectIo(base, base, base, base, base)
+    nxt = A.WlStepOut(base + 100 * A.ELEV_OBS_DIM * 4, base, base, base, None)
+    cr = lib.wl_elev_collect_rollout
+    assert cr(C.byref(ep), C.byref(good), C.byref(hfb), C.byref(na), C.byref(nc), base, C.byref(io), C.byref(out), 4, 0, 0, 0, None) == -1   # rows alias
+    lanes1e = A.WlEnvBuffers(stride=128, n_envs=100, env_offset=0, metrics_slots=1, lanes=1, **ok_bufs)
+    assert cr(C.byref(ep), C.byref(lanes1e), C.byref(hfb), C.byref(na), C.byref(nc), base, C.byref(io), C.byref(nxt), 4, 0, 0, 0, None) == -1
+    assert cr(C.byref(ep), C.byref(good), C.byref(hfb), C.byref(na), C.byref(net(3)), base, C.byref(io), C.byref(nxt), 4, 0, 0, 0, None) == -1  # critic out_dim
+    assert cr(C.byref(ep), C.byref(good), C.byref(hfb), C.byref(na), C.byref(nc), None, C.byref(io), C.byref(nxt), 4, 0, 0, 0, None) == -1       # no std
     # persistent visual rollout: refused without a map, in the lane form, and with per-step rows that alias
     vp = PP.visual_params()
     tm = A.WlTravMap(base, base, 500, 500, 10, 0.5, 0.5)
