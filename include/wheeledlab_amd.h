@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 17
+#define WL_ABI_VERSION 18
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -280,9 +280,11 @@ typedef struct WlActScratch {        /* caller-owned device memory */
     uint16_t *w_hi, *w_lo;           /* [128][dp] layer-1 weights of actor (units 0..63) and critic (64..127) as bf16 planes */
     float* partials;                 /* [splits][rows_capacity][128] split-K partial sums of layer 1 (128 features per split) */
     int32_t dp;                      /* in_dim rounded up to 64 */
-    int32_t splits;                  /* >= ceil(dp / 128) */
+    int32_t splits;                  /* >= ceil(dp / 128) (form 2: >= 1) */
     int32_t rows_capacity;
-    int32_t reserved;                /* 0: one launch (feature shares folded through LDS); 1: two launches (split-K partial sums) */
+    int32_t reserved;                /* form.  0: one launch (feature shares folded through LDS); 1: two launches (split-K partial sums,
+                                        128 features each); 2: two launches, ONE sum over the whole width per row and unit -- for long
+                                        batches (the values of a whole rollout): partials is [rows_capacity][128] */
 } WlActScratch;
 /* (re)build the weight planes: once after every change of the layer-1 weights */
 int wl_actor_critic_planes(const WlMlp* actor, const WlMlp* critic, const WlActScratch* scratch, void* stream);
@@ -340,6 +342,16 @@ typedef struct WlPpoState {          /* caller-owned device scratch */
  * [K + 1][n] (row K = bootstrap value of the last observation); writes returns and (un-normalised) advantages [K][n]. */
 int wl_gae(int32_t n_steps, int32_t n_envs, const float* rewards, const float* values, const int64_t* dones, float gamma,
            float lam, float* returns, float* advantages, void* stream);
+
+/* The runner's per-rollout bookkeeping in one launch (modified_rsl_rl_runner.py:74-75 "NaN in actions", :88-98 episode returns /
+ * lengths, and rsl_rl PPO.process_env_step's time-out bootstrap): rewards / dones / time_outs [K][n], values [K + 1][n], actions
+ * [K][n][2].  Writes the return and the length of every episode that ends at transition (t, e) to ep_ret / ep_len [K][n] (other
+ * entries untouched), updates the carries of the running episodes ([n], in / out), then adds gamma * values[t] to the rewards
+ * of timed-out transitions in place.  stats [3][ceil(n / 256)]: per-block sums of the RAW rewards, of the non-finite action
+ * components and of the finished episodes (sum over the blocks on the caller's side: a fixed order). */
+int wl_rollout_bookkeeping(int32_t n_steps, int32_t n_envs, float* rewards, const float* values, const int64_t* dones,
+                           const uint8_t* time_outs, const float* actions, float gamma, float* carry_ret, float* carry_len,
+                           float* ep_ret, float* ep_len, float* stats, void* stream);
 
 /* gradients only (parity entry point): state->grad = d loss / d params (entropy term and clipping NOT applied) + the
  * three sums; accumulates the squared norm into ctrl[WL_PPO_CTRL_NORM2 + parity]. */

@@ -196,3 +196,20 @@ def test_bf16_plane_form_is_independent_of_the_batch_a_row_arrives_in(two_launch
     rows_small = A.WlActScratch(sc.w_hi, sc.w_lo, sc.partials, sc.dp, sc.splits, n - 1, 0)
     assert call(rows_small, n) == -1
     torch.cuda.synchronize()
+
+
+def test_batched_values_equal_the_policy_step_values():
+    """ActorCritic.values_batched (a rollout's K + 1 observation rows through the streaming bf16 contraction, one sum per row and
+    unit, in chunks) against the critic half of the f32 policy-step kernel: bf16-split rounding apart; independent of the chunking"""
+    from wheeledlab_amd.policy import ActorCritic
+    D, N = 689, 5000
+    kac = ActorCritic(D, 2, "relu", device=DEV, seed=2)
+    obs = torch.randn(N, D, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    want, got, got2 = (torch.zeros(N, device=DEV) for _ in range(3))
+    kac.planes = False
+    kac.values(obs, want)
+    kac.values_batched(obs, got, chunk=2048)
+    kac.values_batched(obs, got2, chunk=65536)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(got, want, rtol=3e-4, atol=3e-4)
+    assert torch.equal(got, got2)

@@ -333,3 +333,38 @@ def test_persistent_elevation_collector(n, activation):
     ea.collect_rollout(view, sa, start=0, count=1, deterministic=True)
     torch.cuda.synchronize()
     assert torch.equal(sa.actions[0], sa.mu[0])
+
+
+def test_rollout_bookkeeping_kernel_equals_the_torch_bookkeeping():
+    """wl_rollout_bookkeeping against the torch form of the runner's per-rollout bookkeeping (_finished_episodes, the raw-reward
+    mean, the action guard, bootstrap_time_outs): finished episodes' returns / lengths in time order, updated carries, bootstrapped
+    rewards; two consecutive rollouts so that the carries matter; a NaN action is reported"""
+    from types import SimpleNamespace
+    from wheeledlab_amd.policy import RolloutStorage
+    from wheeledlab_amd.rl.ppo import OnPolicyRunner, _finished_episodes
+    K, n = 24, 1000
+    g = torch.Generator(device=DEV).manual_seed(0)
+    runner = SimpleNamespace(device=torch.device(DEV), alg=SimpleNamespace(gamma=0.99))
+    ca, cb = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)      # kernel carries
+    ra, rb = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)      # torch carries
+    for it in range(2):
+        st = RolloutStorage(K, n, 14, 2, DEV)
+        st.rewards.copy_(torch.randn(K, n, device=DEV, generator=g))
+        st.values.copy_(torch.randn(K + 1, n, device=DEV, generator=g))
+        st.actions.copy_(torch.randn(K, n, 2, device=DEV, generator=g))
+        done = torch.rand(K, n, device=DEV, generator=g) < 0.04
+        st.time_outs.copy_(done & (torch.rand(K, n, device=DEV, generator=g) < 0.5))
+        st.dones.copy_(done.long())
+        raw = st.rewards.clone()
+        ret, length, ra, rb = _finished_episodes(raw, done, ra, rb)
+        want_rew = raw + 0.99 * st.values[:-1] * st.time_outs
+        rets, lens, mean, finite = OnPolicyRunner._bookkeeping(runner, st, ca, cb)
+        torch.cuda.synchronize()
+        assert finite and abs(mean - float(raw.mean())) < 1e-6
+        torch.testing.assert_close(torch.tensor(rets), ret[-100:].cpu(), rtol=1e-5, atol=1e-5)
+        assert lens == length[-100:].tolist()
+        torch.testing.assert_close(ca, ra, rtol=1e-5, atol=1e-5)
+        assert torch.equal(cb, rb)
+        torch.testing.assert_close(st.rewards, want_rew, rtol=1e-6, atol=1e-6)
+    st.actions[3, 7, 1] = float("nan")
+    assert not OnPolicyRunner._bookkeeping(runner, st, ca, cb)[3]

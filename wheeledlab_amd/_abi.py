@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 17
+WL_ABI_VERSION = 18
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -197,6 +197,7 @@ SIGNATURES = {
     "wl_actor_critic_act_planes": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _u64, _u64, _i32,
                                              _i32, _P(WlActScratch), _vp]),
     "wl_gae": (C.c_int, [_i32, _i32, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp]),
+    "wl_rollout_bookkeeping": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wl_ppo_gradients": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _P(WlPpoBatch), _i32, _i32, _P(WlPpoParams), _P(WlPpoState), _i32,
                                    _vp]),
     "wl_ppo_minibatch": (C.c_int, [_P(WlMlp), _P(WlMlp), _vp, _P(WlPpoBatch), _i32, _i32, _P(WlPpoParams), _P(WlPpoState), _i32,

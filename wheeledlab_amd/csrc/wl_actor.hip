@@ -461,7 +461,7 @@ int wl_actor_critic_act_planes(const WlMlp* actor, const WlMlp* critic, const fl
     if ((nets & 1) && (((uintptr_t)actions & 7u) || ((uintptr_t)mu & 7u))) return WL_EALIGN;
     if ((uintptr_t)obs & 3u) return WL_EALIGN;
     if (!sc || !sc->w_hi || !sc->w_lo || !sc->partials || actor->in_dim < 64 || sc->dp != (actor->in_dim + 63) / 64 * 64 ||
-        sc->splits < (sc->dp + 127) / 128 || n_rows > sc->rows_capacity)
+        sc->splits < (sc->reserved == 2 ? 1 : (sc->dp + 127) / 128) || n_rows > sc->rows_capacity || sc->reserved < 0 || sc->reserved > 2)
         return WL_EINVAL;
     if (((uintptr_t)sc->w_hi & 15u) || ((uintptr_t)sc->w_lo & 15u) || ((uintptr_t)sc->partials & 15u)) return WL_EALIGN;
     if (sc->reserved == 0) {   // one launch: feature shares folded through LDS (reserved = 1: the two-launch split-K form below)
@@ -488,7 +488,7 @@ int wl_actor_critic_act_planes(const WlMlp* actor, const WlMlp* critic, const fl
         return launch_status();
     }
     const int splits = wl_internal::layer1_partials(obs, obs_stride, n_rows, actor->in_dim, sc->dp, sc->w_hi, sc->w_lo, sc->splits,
-                                                    sc->partials, (hipStream_t)stream);
+                                                    sc->partials, (hipStream_t)stream, sc->reserved == 2);
     if (splits < 0) return splits;
     const dim3 grid((n_rows + 15) / 16, nets == 3 ? 2 : 1);
     const int first_net = nets == 2 ? 1 : 0;

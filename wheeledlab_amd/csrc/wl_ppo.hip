@@ -705,6 +705,73 @@ __global__ void __launch_bounds__(256) gae_kernel(const int K, const int n, cons
     }
 }
 
+// The runner's per-rollout bookkeeping (modified_rsl_rl_runner.py:74-75, 88-98 does it per step, with a host sync each) in one
+// pass, one lane per env walking its K transitions forwards: the return / length of every episode that ends inside the rollout
+// (written at its last transition; the carries of episodes still running are updated in place), the sum of the RAW rewards,
+// the number of non-finite action components, and then rsl_rl's time-out bootstrap rewards += gamma V(obs_t) time_outs in place.
+// Per-block partial sums (no float atomics: the logged mean must not depend on the block order).
+__global__ void __launch_bounds__(256) rollout_bookkeeping_kernel(const int K, const int n, float* __restrict__ rewards,
+                                                                  const float* __restrict__ values, const int64_t* __restrict__ dones,
+                                                                  const uint8_t* __restrict__ time_outs, const float2* __restrict__ actions,
+                                                                  const float gamma, float* __restrict__ carry_ret,
+                                                                  float* __restrict__ carry_len, float* __restrict__ ep_ret,
+                                                                  float* __restrict__ ep_len, float* __restrict__ stats) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    float rsum = 0.f, bad = 0.f, n_done = 0.f;
+    if (e < n) {
+        float ret = carry_ret[e], len = carry_len[e];
+        // eight transitions' rows requested together: the stores of the loop body may alias the loads for all the compiler knows,
+        // so one by one every transition paid a memory round trip (0.12 ms for 128 steps)
+        constexpr int kB = 8;
+        for (int t0 = 0; t0 < K; t0 += kB) {
+            float r[kB], v[kB];
+            float2 a[kB];
+            int64_t d[kB];
+            uint8_t to[kB];
+#pragma unroll
+            for (int i = 0; i < kB; ++i) {
+                const int64_t at = (int64_t)min(t0 + i, K - 1) * n + e;
+                r[i] = rewards[at], v[i] = values[at], a[i] = actions[at], d[i] = dones[at], to[i] = time_outs[at];
+            }
+#pragma unroll
+            for (int i = 0; i < kB; ++i) {
+                if (t0 + i >= K) break;
+                const int64_t at = (int64_t)(t0 + i) * n + e;
+                rsum += r[i];
+                bad += (__builtin_isfinite(a[i].x) ? 0.f : 1.f) + (__builtin_isfinite(a[i].y) ? 0.f : 1.f);
+                ret += r[i];
+                len += 1.f;
+                if (d[i] != 0) {
+                    ep_ret[at] = ret;
+                    ep_len[at] = len;
+                    ret = len = 0.f;
+                    n_done += 1.f;
+                }
+                if (to[i]) rewards[at] = fmaf(gamma, v[i], r[i]);
+            }
+        }
+        carry_ret[e] = ret;
+        carry_len[e] = len;
+    }
+    __shared__ float part[3][4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        rsum += __shfl_down(rsum, off, 64);
+        bad += __shfl_down(bad, off, 64);
+        n_done += __shfl_down(n_done, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = rsum;
+        part[1][threadIdx.x >> 6] = bad;
+        part[2][threadIdx.x >> 6] = n_done;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float* q = part[threadIdx.x];
+        stats[threadIdx.x * gridDim.x + blockIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
+    }
+}
+
 int check_ppo(const WlMlp* actor, const WlMlp* critic, const float* std, const WlPpoBatch* bt, int mb_start, int mb_size,
               const WlPpoState* st) {
     int rc = check_mlp(actor);
@@ -802,6 +869,20 @@ int wl_gae(int32_t n_steps, int32_t n_envs, const float* rewards, const float* v
     clear_error();
     gae_kernel<<<(n_envs + 255) / 256, 256, 0, (hipStream_t)stream>>>(n_steps, n_envs, rewards, values, dones, gamma, lam, returns,
                                                                       advantages);
+    return launch_status();
+}
+
+int wl_rollout_bookkeeping(int32_t n_steps, int32_t n_envs, float* rewards, const float* values, const int64_t* dones,
+                           const uint8_t* time_outs, const float* actions, float gamma, float* carry_ret, float* carry_len,
+                           float* ep_ret, float* ep_len, float* stats, void* stream) {
+    if (n_steps <= 0 || n_envs <= 0 || !rewards || !values || !dones || !time_outs || !actions || !carry_ret || !carry_len || !ep_ret ||
+        !ep_len || !stats)
+        return WL_EINVAL;
+    if ((uintptr_t)actions & 7u) return WL_EALIGN;
+    clear_error();
+    rollout_bookkeeping_kernel<<<(n_envs + 255) / 256, 256, 0, (hipStream_t)stream>>>(n_steps, n_envs, rewards, values, dones, time_outs,
+                                                                                     (const float2*)actions, gamma, carry_ret, carry_len,
+                                                                                     ep_ret, ep_len, stats);
     return launch_status();
 }
 

@@ -32,7 +32,9 @@ int mlp_weight_planes(const WlMlp* actor, const WlMlp* critic, int dp, uint16_t*
 // ([n_rows][x_stride], in_dim valid features) split into bf16 planes in registers, W = planes from mlp_weight_planes.
 // Two chunks per split (whatever n_rows: results do not depend on the batch a row arrives in); returns the number of
 // splits = ceil(dp / 128) (partial sums [splits][n_rows][128]; WL_EINVAL if that exceeds max_splits) or a negative WL_E* code.
+// whole_k: ONE split (the whole width per block; also independent of the batch) -- for long batches, where the six partial
+// sums per row of the default would be more traffic than the rows themselves.
 int layer1_partials(const float* x, int64_t x_stride, int n_rows, int in_dim, int dp, const uint16_t* w_hi, const uint16_t* w_lo,
-                    int max_splits, float* out, hipStream_t stream);
+                    int max_splits, float* out, hipStream_t stream, bool whole_k = false);
 
 }  // namespace wl_internal

@@ -482,7 +482,7 @@ int mlp_weight_planes(const WlMlp* actor, const WlMlp* critic, int dp, uint16_t*
 }
 
 int layer1_partials(const float* x, int64_t x_stride, int n_rows, int in_dim, int dp, const uint16_t* w_hi, const uint16_t* w_lo,
-                    int max_splits, float* out, hipStream_t stream) {
+                    int max_splits, float* out, hipStream_t stream, bool whole_k) {
     SkinnyArgs a{};
     a.b_f32 = x;
     a.b_perm = nullptr;
@@ -498,7 +498,7 @@ int layer1_partials(const float* x, int64_t x_stride, int n_rows, int in_dim, in
     a.n_chunks = dp / kChunk;
     // a fixed share per split: the grouping of the partial sums -- hence every bit of the result -- depends on the width
     // of the rows only, not on how many rows the call has (a shard of a batch must reproduce its rows of the batch)
-    a.chunks_per_split = 2;
+    a.chunks_per_split = whole_k ? a.n_chunks : 2;   // whole_k: one sum per row and unit (long batches: a sixth of the partial-sum traffic)
     a.splits = (a.n_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
     if (a.splits > max_splits) return WL_EINVAL;
     clear_error();

@@ -144,6 +144,31 @@ class ActorCritic:
                                              int(env_offset), int(seed), int(step), int(bool(deterministic)), int(nets), stream),
                 "wl_actor_critic_act")
 
+    def values_batched(self, obs: torch.Tensor, out: torch.Tensor, chunk: int = 65536):
+        """critic(obs) -> out [N] for a long batch of stored observations (the K + 1 rows of a rollout): the first layer as the
+        streaming bf16 contraction with one sum per row and unit (wl_actor_critic_act_planes, form 2), `chunk` rows per call"""
+        N, D = obs.shape
+        assert D == self.critic.in_dim and obs.is_contiguous() and out.shape == (N,) and out.is_contiguous()
+        if D < 64:
+            return self.values(obs, out)
+        key = (self.actor.w1.data_ptr(), self.critic.w1.data_ptr(), D, chunk)
+        vb = getattr(self, "_values_scratch", None)
+        if vb is None or vb[0] != key:
+            dp, dev = (D + 63) // 64 * 64, self.std.device
+            w_hi, w_lo = (torch.zeros(128, dp, dtype=torch.int16, device=dev) for _ in range(2))
+            part = torch.zeros(chunk, 128, dtype=torch.float32, device=dev)
+            vb = self._values_scratch = (key, A.WlActScratch(w_hi.data_ptr(), w_lo.data_ptr(), part.data_ptr(), dp, 1, chunk, 2), w_hi, w_lo,
+                                         part, (self.actor.struct(), self.critic.struct()))
+        sc, (a, c) = vb[1], vb[5]
+        lib, stream = A.load(), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+        A.check(lib.wl_actor_critic_planes(C.byref(a), C.byref(c), C.byref(sc), stream), "wl_actor_critic_planes")
+        for r0 in range(0, N, chunk):
+            m = min(chunk, N - r0)
+            A.check(lib.wl_actor_critic_act_planes(C.byref(a), C.byref(c), self.std.data_ptr(), m, obs[r0:r0 + m].data_ptr(), obs.stride(0),
+                                                   None, None, None, out[r0:r0 + m].data_ptr(), 0, 0, 0, 0, 2, C.byref(sc), stream),
+                    "wl_actor_critic_act_planes")
+        return out
+
     def values(self, obs: torch.Tensor, out: torch.Tensor):
         """critic(obs) -> out [n] for observations of any width (the critic's half of wl_actor_critic_act)"""
         self.act(obs, None, None, None, out, 0, 0, nets=2)

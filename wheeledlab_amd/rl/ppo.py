@@ -349,9 +349,7 @@ class OnPolicyRunner:
                 base.collect_rollout(view, st)
                 base.finish_collection(st)
                 K, n = st.n_steps, st.n_envs
-                rows, vals = st.observations.view((K + 1) * n, -1), st.values.view((K + 1) * n)
-                for r0 in range(0, (K + 1) * n, 32768):
-                    view.values(rows[r0:r0 + 32768], vals[r0:r0 + 32768])
+                view.values_batched(st.observations.view((K + 1) * n, -1), st.values.view((K + 1) * n))
             return st.observations[K]
         if one_launch and hasattr(base, "collect_step") and not getattr(base, "_has_custom_rewards", False):
             # every output straight into the storage rows: per step one policy launch + the env's own launches, no copies
@@ -388,6 +386,30 @@ class OnPolicyRunner:
                 st.values.copy_(ac.evaluate(st.observations.reshape((K + 1) * n, -1)).reshape(K + 1, n))
         return obs
 
+    def _bookkeeping(self, st, carry_ret, carry_len):
+        """returns / lengths of the (last <= 100) episodes that ended inside the rollout in time order, the mean RAW reward per
+        step, whether every action is finite; updates the carries of the running episodes in place and applies the time-out
+        bootstrap to st.rewards -- _finished_episodes + isfinite + mean + bootstrap_time_outs as one launch"""
+        import ctypes as C
+
+        from .. import _abi as A
+        K, n = st.n_steps, st.n_envs
+        buf = getattr(self, "_book", None)
+        if buf is None or buf[0].shape != (K, n):
+            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
+            buf = self._book = (z(K, n), z(K, n), z(3, (n + 255) // 256))
+        ep_ret, ep_len, stats = buf
+        assert st.time_outs.dtype == torch.bool and st.dones.dtype == torch.int64 and carry_ret.is_contiguous() and carry_len.is_contiguous()
+        A.check(A.load().wl_rollout_bookkeeping(K, n, st.rewards.data_ptr(), st.values.data_ptr(), st.dones.data_ptr(),
+                                                st.time_outs.data_ptr(), st.actions.data_ptr(), float(self.alg.gamma),
+                                                carry_ret.data_ptr(), carry_len.data_ptr(), ep_ret.data_ptr(), ep_len.data_ptr(),
+                                                stats.data_ptr(), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                "wl_rollout_bookkeeping")
+        sel = st.dones.view(-1).nonzero().view(-1)[-100:]
+        out = torch.cat([stats.sum(1), ep_ret.view(-1)[sel], ep_len.view(-1)[sel]]).tolist()
+        m = sel.numel()
+        return out[3:3 + m], out[3 + m:3 + 2 * m], out[0] / (K * n), out[1] == 0.0
+
     # ---- the learning loop (modified_rsl_rl_runner.py:34-128) ----------------------------------------------
     def learn(self, num_learning_iterations: int, init_at_random_ep_len: bool = False, verbose: bool = True):
         env = self.env
@@ -409,18 +431,27 @@ class OnPolicyRunner:
             # book keeping of finished episodes (runner :88-98 does it per step with a host sync each): here the whole
             # rollout at once with cumulative sums, one device->host copy of the finished episodes' returns / lengths
             with torch.no_grad():
-                # the runner's runtime guard (modified_rsl_rl_runner.py:74-75: "NaN in actions"), once per rollout instead
-                # of a host round trip per step
-                if not bool(torch.isfinite(st.actions).all()):
-                    raise ValueError(f"non-finite values in the actions of iteration {it} (diverged policy?)")
-                ret, length, cur_reward_sum, cur_episode_length = _finished_episodes(st.rewards, st.dones != 0, cur_reward_sum,
-                                                                                     cur_episode_length)
-                rewbuffer.extend(ret[-100:].tolist())
-                lenbuffer.extend(length[-100:].tolist())
-                # the learning signal that is logged is the RAW env reward: bootstrap_time_outs adds gamma * V(obs) at
-                # time-out steps, which grows as the critic learns even when the policy does not
-                mean_step_reward = float(st.rewards.mean())
-                st.bootstrap_time_outs(self.alg.gamma)
+                if self.device.type == "cuda":
+                    # the same bookkeeping as below in one launch + one small device->host copy (wl_rollout_bookkeeping): as
+                    # ~25 torch ops it cost 0.41 ms per iteration -- a tenth of the drift task's iteration
+                    rets, lens, mean_step_reward, finite = self._bookkeeping(st, cur_reward_sum, cur_episode_length)
+                    if not finite:
+                        raise ValueError(f"non-finite values in the actions of iteration {it} (diverged policy?)")
+                    rewbuffer.extend(rets)
+                    lenbuffer.extend(lens)
+                else:
+                    # the runner's runtime guard (modified_rsl_rl_runner.py:74-75: "NaN in actions"), once per rollout instead
+                    # of a host round trip per step
+                    if not bool(torch.isfinite(st.actions).all()):
+                        raise ValueError(f"non-finite values in the actions of iteration {it} (diverged policy?)")
+                    ret, length, cur_reward_sum, cur_episode_length = _finished_episodes(st.rewards, st.dones != 0, cur_reward_sum,
+                                                                                         cur_episode_length)
+                    rewbuffer.extend(ret[-100:].tolist())
+                    lenbuffer.extend(length[-100:].tolist())
+                    # the learning signal that is logged is the RAW env reward: bootstrap_time_outs adds gamma * V(obs) at
+                    # time-out steps, which grows as the critic learns even when the policy does not
+                    mean_step_reward = float(st.rewards.mean())
+                    st.bootstrap_time_outs(self.alg.gamma)
             torch.cuda.synchronize() if self.device.type == "cuda" else None
             t1 = time.time()
             losses = self.alg.update(st)
