@@ -599,6 +599,7 @@ __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float* __restrict
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < kRow) {
         int b = rg;
+#pragma unroll 4   // 16 loads in flight per thread (4: every round of four was a dependent round trip, 12 us for 256 rows)
         for (; b + 12 < n_blocks; b += 16) {
             s0 += partials[(int64_t)b * kRow + c];
             s1 += partials[(int64_t)(b + 4) * kRow + c];
@@ -694,14 +695,26 @@ __global__ void __launch_bounds__(256) gae_kernel(const int K, const int n, cons
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
     float adv = 0.f, v_next = values[(int64_t)K * n + e];
-    for (int t = K - 1; t >= 0; --t) {
-        const int64_t at = (int64_t)t * n + e;
-        const float nd = dones[at] != 0 ? 0.f : 1.f, v = values[at];
-        const float delta = rewards[at] + nd * gamma * v_next - v;
-        adv = delta + nd * gamma * lam * adv;
-        advantages[at] = adv;
-        returns[at] = adv + v;
-        v_next = v;
+    constexpr int kB = 8;   // eight transitions' rows requested together (one by one each was a memory round trip: the stores may alias)
+    for (int t0 = K - 1; t0 >= 0; t0 -= kB) {
+        float r[kB], vv[kB];
+        int64_t d[kB];
+#pragma unroll
+        for (int i = 0; i < kB; ++i) {
+            const int64_t at = (int64_t)max(t0 - i, 0) * n + e;
+            r[i] = rewards[at], vv[i] = values[at], d[i] = dones[at];
+        }
+#pragma unroll
+        for (int i = 0; i < kB; ++i) {
+            if (t0 - i < 0) break;
+            const int64_t at = (int64_t)(t0 - i) * n + e;
+            const float nd = d[i] != 0 ? 0.f : 1.f, v = vv[i];
+            const float delta = r[i] + nd * gamma * v_next - v;
+            adv = delta + nd * gamma * lam * adv;
+            advantages[at] = adv;
+            returns[at] = adv + v;
+            v_next = v;
+        }
     }
 }
 

@@ -352,6 +352,7 @@ __global__ void __launch_bounds__(256) ppo_wide_scatter_kernel(const float* __re
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (to >= 0) {
         int b = rg;
+#pragma unroll 4
         for (; b + 12 < n_rows; b += 16) {
             s0 += partials[(int64_t)b * kRowN + j];
             s1 += partials[(int64_t)(b + 4) * kRowN + j];
