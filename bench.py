@@ -469,6 +469,25 @@ def main():
             flop = 2.0 * n * (2 * t.OBS_DIM * 64 + 2 * 64 * 64 + 3 * 64)
             other[name]["policy_step_us"] = pus
             other[name]["policy_step_TFLOPs"] = flop / (pus * 1e-6) / 1e12
+            if name == "elevation" and n <= 32768:
+                # the runner's collection loop (actor -> sample -> env.step -> storage rows) as ONE persistent launch
+                # (wl_elev_collect_rollout: actor layer 1 in the blocks' registers, observation rows in LDS)
+                from wheeledlab_amd.policy import RolloutStorage
+                kc = 32
+                cst = RolloutStorage(kc, n, t.OBS_DIM, 2, dev)
+                cst.observations[0].copy_(t.observe())
+                kac.planes = False
+                t.collect_rollout(kac, cst)
+                torch.cuda.synchronize()
+                q0.record()
+                for _ in range(4):
+                    t.collect_rollout(kac, cst)
+                q1.record()
+                torch.cuda.synchronize()
+                cus = q0.elapsed_time(q1) * 1e3 / (4 * kc)
+                other[name]["collect_rollout_us_per_step"] = cus
+                other[name]["collect_rollout_env_steps_per_s"] = n / (cus * 1e-6)
+                del cst
             del t, a, kac, ob
 
     # secondary: the same workload driven step by step through the drop-in Python surface
