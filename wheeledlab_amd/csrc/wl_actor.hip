@@ -192,6 +192,14 @@ __global__ void __launch_bounds__(64) act_tail_kernel(const WlMlp actor, const W
     // accumulator layout of layer 1: units 16 t + 4 g .. + 3 of row m -- 16 bytes per tile and split
     const float* src = partials + (int64_t)row * (2 * kMlpHidden) + which * kMlpHidden + 4 * g;
     const int64_t plane = (int64_t)n_rows * (2 * kMlpHidden);
+    // the tail's weights and the draw do not depend on layer 1: requested / computed in the shadow of the partial sums' loads
+    MlpTail W;
+    load_tail(net, lane, W);
+    float z0 = 0.f, z1 = 0.f;
+    if (which == 0 && !deterministic) {
+        const F4 u = philox_uniform4((uint32_t)(env_offset + r_out), step, WL_RS_POLICY, seed);
+        box_muller(u.x, u.y, z0, z1);
+    }
     f32x4 h[kMlpTiles];
 #pragma unroll
     for (int t = 0; t < kMlpTiles; ++t) h[t] = *reinterpret_cast<const f32x4*>(net.b1 + 16 * t + 4 * g);
@@ -217,13 +225,6 @@ __global__ void __launch_bounds__(64) act_tail_kernel(const WlMlp actor, const W
 #pragma unroll
         for (int t = 0; t < kMlpTiles; ++t)
             h[t] += ((v[0][t] + v[1][t]) + (v[2][t] + v[3][t])) + ((v[4][t] + v[5][t]) + (v[6][t] + v[7][t]));
-    }
-    MlpTail W;
-    load_tail(net, lane, W);
-    float z0 = 0.f, z1 = 0.f;
-    if (which == 0 && !deterministic) {
-        const F4 u = philox_uniform4((uint32_t)(env_offset + r_out), step, WL_RS_POLICY, seed);
-        box_muller(u.x, u.y, z0, z1);
     }
     const f32x4 out = eval_tail<ACT>(W, h, lane);
     if (g != 0 || r_out >= n_rows) return;
