@@ -269,8 +269,8 @@ def test_one_launch_elevation_collector_equals_policy_step_plus_env_step(n, acti
     assert torch.equal(sa.actions[0], sa.mu[0])
 
 
-@pytest.mark.parametrize("n,activation", [(4096, "relu"), (1000, "elu")])
-def test_persistent_elevation_collector(n, activation):
+@pytest.mark.parametrize("n,activation,slots", [(4096, "relu", 1), (1000, "elu", 1), (256, "relu", 3)])
+def test_persistent_elevation_collector(n, activation, slots):
     """wl_elev_collect_rollout (the runner's collection loop as ONE launch: actor layer 1 from the blocks' registers, observation
     rows in LDS; the critic's values come from a batched pass afterwards).  (1) A K-step launch equals K one-step launches of
     itself bit for bit (storage rows, env state).  (2) Each step against the per-step path -- wl_actor_critic_act + wl_elev_step
@@ -285,7 +285,7 @@ def test_persistent_elevation_collector(n, activation):
     ac = ActorCritic(D, D, 2, activation=activation).to(DEV)
     view = ac.fused()
     view.planes = False
-    ea, eb, ec = (ElevBatch(n, device=DEV, seed=13) for _ in range(3))
+    ea, eb, ec = (ElevBatch(n, device=DEV, seed=13, metrics_slots=s) for s in (slots, 1, 1))   # slots > 1: the episode-metric ring
     for e in (ea, eb, ec):
         e.reset()
         e.episode_len[:n] = torch.randint(0, 198, (n,), device=DEV, dtype=torch.int32, generator=torch.Generator(device=DEV).manual_seed(2))
@@ -303,6 +303,8 @@ def test_persistent_elevation_collector(n, activation):
     assert torch.equal(ea.state, eb.state) and torch.equal(ea.episode_len, eb.episode_len) and ea.step_count == eb.step_count == K
     assert int(sa.dones.sum()) > 0 and bool(torch.isfinite(sa.observations).all())
     torch.testing.assert_close(ea.metrics_raw.sum((0, 1)), eb.metrics_raw.sum((0, 1)), rtol=1e-5, atol=1e-3)
+    if slots > 1:                                     # the one launch books all K steps into the first step's slot
+        assert float(ea.metrics_raw[1:].abs().sum()) == 0.0 and float(ea.metrics_raw[0].abs().sum()) > 0.0
     # (2) step by step against the two-launch path
     ea2 = ElevBatch(n, device=DEV, seed=13)
     ea2.reset()
