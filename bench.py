@@ -39,15 +39,90 @@ BYTES_WRITE = (23 + 7) * 4 + 4 + 14 * 4 + 4 + 2
 BYTES_PER_ENV_STEP = BYTES_READ + BYTES_WRITE
 
 
+# algorithmic HBM bytes per unit of the other hot kernels: elevation 270 + 676 x 4
+# (height map) + 8 (goal); visual 270 + 3200 x 4 (image); depth ray-cast: the 60 x 80 fp32 image + the camera pose (7 fp32)
+ALGO_BYTES = {"drift": BYTES_PER_ENV_STEP, "elev": 2982, "visual": 13070, "depth": 60 * 80 * 4 + 28}
+
+
+_SHARED_SRC = ["wl_kernel_common.h", "wl_math.h", "wl_rng.h", "wl_vehicle.h", "wl_drift_terms.h"]
+TASK_SOURCES = {"drift": ["wl_drift.hip", "wl_drift_env.h"] + _SHARED_SRC,
+                "elev": ["wl_elev.hip", "wl_heightfield.h", "wl_actor_dev.h", "wl_mlp.h"] + _SHARED_SRC,
+                "visual": ["wl_visual.hip"] + _SHARED_SRC,
+                "depth": ["wl_depth.hip", "wl_depth_dev.h", "wl_heightfield.h", "wl_kernel_common.h", "wl_math.h"]}
+
+
+def csrc_fingerprint(task: str):
+    """sha256 over the sources a task's kernels are built from (+ the build flags): stamps the rocprofv3 --pmc digests under
+    profiles/ so that counters measured on an older build of THAT kernel are marked stale instead of riding silently next to
+    live timings"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in TASK_SOURCES[task] + ["../../include/wheeledlab_amd.h", "../../__graft_entry__.py"]:
+        path = os.path.normpath(os.path.join(ROOT, "wheeledlab_amd", "csrc", f))
+        data = open(path, "rb").read()
+        if f.endswith(".py"):   # only the compiler flags matter
+            data = b"\n".join(l for l in data.splitlines() if b"HIPCC_FLAGS" in l or b"-mllvm" in l)
+        h.update(f.encode())
+        h.update(data)
+    return h.hexdigest()[:16]
+
+
+def pmc_entry(task: str, n_envs: int):
+    """the newest committed counter digest (profiles/r*_pmc.json, tools/r03_pmc_report.py) for (task, env count), or None;
+    `stale` when the kernels have changed since it was measured"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        d = json.load(open(f))
+        e = d.get("entries", {}).get(f"{task}:{n_envs}")
+        if e:
+            e = dict(e)
+            e["source"] = os.path.relpath(f, ROOT)
+            e["stale"] = d.get("csrc_fingerprints", {}).get(task) != csrc_fingerprint(task)
+            return e
+    return None
+
+
+def rocprof_avg_us(kernel_substr: str):
+    """average duration of a kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of bench.py itself
+    (profiles/r*_bench_kernel_stats.csv), for the reader who recomputes `frac` from profiles/"""
+    import csv
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")), reverse=True):
+        try:
+            best = None
+            for r in csv.DictReader(open(f)):
+                if kernel_substr in r.get("Name", "") and (best is None or int(r["Calls"]) > best[0]):
+                    best = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
+            if best:
+                return {"avg_us": best[1], "calls": best[0], "source": os.path.relpath(f, ROOT)}
+        except (KeyError, ValueError):
+            continue
+    return None
+
+
+def roofline_block(task, n, us, kernel, bound, bytes_per_unit=None):
+    """HBM roofline of one kernel / step: algorithmic bytes per launch / live duration, + the committed counters"""
+    bpu = bytes_per_unit or ALGO_BYTES[task]
+    achieved = bpu * n / (us * 1e-6) / 1e9
+    e = pmc_entry(task, n)
+    blk = {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": None, "kernel": kernel, "launch_us": us, "bytes_per_unit": bpu, "units_per_launch": n,
+           "frac_uses": "launch_us (HIP events on the launch stream, live in this run)"}
+    if e:
+        blk["traffic"] = None if e["stale"] else e.get("traffic_bytes")
+        blk["traffic_source"], blk["traffic_stale"] = e["source"], e["stale"]
+        if not e["stale"]:
+            blk["counters"] = e.get("kernels")
+    return blk
+
+
 def pmc_traffic(n_envs: int):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r*_pmc_traffic.json); bench.py cannot
     profile itself, so the number is the one measured with tools/pmc_run.py on the same kernel and env count."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-        e = json.load(open(f)).get("entries", {}).get(str(n_envs))
-        if e:
-            return e["traffic_bytes"], os.path.relpath(f, ROOT)
-    return None, None
+    e = pmc_entry("drift", n_envs)
+    if e and e.get("traffic_bytes"):
+        return (None if e["stale"] else e["traffic_bytes"]), e["source"], e["stale"]
+    return None, None, None
 
 
 def pmc_sq(n_envs: int):
@@ -55,13 +130,12 @@ def pmc_sq(n_envs: int):
     (profiles/r*_pmc_sq.json, made by tools/pmc_sq_profile.sh): VALU instructions per wavefront, the fractions of a
     wavefront's life spent issuing VALU / parked in s_waitcnt / stalled at issue, and the share of the VALU pipe's time
     the instruction mix occupies -- the second roofline of this kernel (it is not bandwidth-shaped at 4096 envs)."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")), reverse=True):
-        e = json.load(open(f)).get("entries", {}).get(str(n_envs))
-        if e:
-            e = dict(e)
-            e["source"] = os.path.relpath(f, ROOT)
-            return e
+    e = pmc_entry("drift", n_envs)
+    if e and not e["stale"]:
+        k = dict(e.get("kernels", {}).get("drift_step_kernel", {}))
+        if k:
+            k["source"] = e["source"]
+            return k
     return None
 
 
@@ -189,6 +263,55 @@ def large_n_sweep(dev):
     return sweep
 
 
+def other_tasks_sweep(dev):
+    """the elevation / visual steps and the depth ray-cast at env counts past the latency regime (per-step launches, outputs
+    overwritten in place): the HBM fraction of SURVEY 8(d)'s bytes per unit"""
+    from wheeledlab_amd.core import DepthCamera, ElevBatch, VisualBatch
+
+    out = []
+    for task, cls, sizes, K in (("elev", ElevBatch, (65536, 262144, 1048576), 4), ("visual", VisualBatch, (65536, 262144), 2)):
+        for big in sizes:
+            e2 = cls(big, device=dev, seed=42)
+            e2.reset()
+            if task == "visual":
+                e2.sample_augmentation(torch.Generator().manual_seed(0))
+            a2 = torch.rand(K, big, 2, device=dev) * 2 - 1
+            e2.rollout(a2)
+            torch.cuda.synchronize()
+            best = 1e30
+            for _ in range(2):
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                for _ in range(3):
+                    e2.rollout(a2)
+                s1.record()
+                torch.cuda.synchronize()
+                best = min(best, s0.elapsed_time(s1) * 1e3 / (3 * K))
+            blk = roofline_block(task, big, best, "step + scan" if task == "elev" else "step + camera", "hbm+valu")
+            out.append({"task": task, "n_envs": big, "us_per_step": round(best, 2), "env_steps_per_s": big / (best * 1e-6),
+                        "achieved_GBs": blk["achieved"], "frac_of_8TBs": blk["frac"], "bytes_per_env_step": ALGO_BYTES[task],
+                        "traffic": blk.get("traffic"), "traffic_stale": blk.get("traffic_stale")})
+            if task == "elev" and big == 65536:
+                cam = DepthCamera((e2.height, float(e2._hf.x0), float(e2._hf.y0), float(e2._hf.cell)), dev)
+                img = torch.empty(big, 60, 80, device=dev)
+                cam.render(e2, 100.0, img)
+                torch.cuda.synchronize()
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                for _ in range(3):
+                    cam.render(e2, 100.0, img)
+                s1.record()
+                torch.cuda.synchronize()
+                dus = s0.elapsed_time(s1) * 1e3 / 3
+                blk = roofline_block("depth", big, dus, "visual_depth_kernel", "valu+latency")
+                out.append({"task": "depth", "n_envs": big, "us_per_render": round(dus, 2), "rays_per_s": big * 4800 / (dus * 1e-6),
+                            "achieved_GBs": blk["achieved"], "frac_of_8TBs": blk["frac"], "bytes_per_image": ALGO_BYTES["depth"]})
+                del cam, img
+            del e2, a2
+            torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,13 +319,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allreduce-every", type=int, default=ROLLOUT,
+                    help="steps between episode-metric all-reduces (default 128 = the reference's logging cadence; 1 = SURVEY 8(d) "
+                         "config 4's worst case: one collective per env.step())")
     ap.add_argument("--sweep", action="store_true", help="(default at N=1) large-N sweep of the same kernel: the HBM-bound regime")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--sweep-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.sweep_child:
         assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
-        print(json.dumps(large_n_sweep(torch.device("cuda", 0))), flush=True)
+        d0 = torch.device("cuda", 0)
+        print(json.dumps({"drift": large_n_sweep(d0), "other": other_tasks_sweep(d0)}), flush=True)
         return
 
     rank = int(os.environ.get("RANK", "0"))
@@ -245,7 +372,8 @@ def main():
     # logging event, it contains one every 6.4 blocks.  It is issued async on RCCL's own stream and joined one logging
     # interval later, so the next 128 launches overlap it instead of queueing behind it.  drain() (after the timing)
     # reduces what is left so that short runs report their episode metrics too.
-    cadence = {"since": 0, "pending": None}
+    every = max(1, min(args.allreduce_every, ROLLOUT))
+    cadence = {"since": 0, "pending": None, "reductions": 0}
 
     def join():
         p = cadence["pending"]
@@ -262,15 +390,16 @@ def main():
         else:
             metric_sum.add_(m)
         cadence["since"] = 0
+        cadence["reductions"] += 1
 
     def run(k_steps):
         done = 0
         while done < k_steps:
-            k = min(ROLLOUT - cadence["since"], k_steps - done)
+            k = min(every - cadence["since"], k_steps - done)
             env.rollout(actions[:k], obs_buf, rew_buf, term_buf, trunc_buf)
             done += k
             cadence["since"] += k
-            if cadence["since"] >= ROLLOUT:
+            if cadence["since"] >= every:
                 reduce_metrics()
 
     def drain():
@@ -283,11 +412,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # attestation that the collective really spans `world` ranks on the RCCL backend: a sum all-reduce of ones
+    rccl = None
+    if dist is not None:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks_seen": int(ones.item()),
+                "allreduce_every": every}
     run(args.warmup)
     # EXACTLY --steps steps per timed block, bracketed by barrier + synchronize, max over ranks -- and REPEATS such blocks:
     # at the driver's K = 20 one block is 0.15 ms, a single sample of which is launch-queue noise (round 1 reported
     # 10.9 us / step where the steady state was 7.2); the headline is the median block
     walls, gpu = [], []
+    cadence["reductions"] = 0
     for _ in range(REPEATS):
         barrier()
         t0 = time.perf_counter()
@@ -298,6 +435,7 @@ def main():
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         walls.append(float(t.item()))
+    reductions_in_timed_blocks = cadence["reductions"]
     # the same block between two events on the launch stream (secondary figure; NOT inside the wall-timed blocks above:
     # two event records are 8 us of host work, 6 % of a 20-step block)
     for _ in range(5):
@@ -309,6 +447,7 @@ def main():
         barrier()
         gpu.append(ev0.elapsed_time(ev1))
     wall = sorted(walls)[len(walls) // 2]
+    wall_mean = sum(walls) / len(walls)
     gpu_ms = sorted(gpu)[len(gpu) // 2]
     drain()   # what the timed blocks left in the accumulators (outside the timing: short runs report their metrics too)
 
@@ -324,7 +463,7 @@ def main():
     torch.cuda.synchronize()
     launch_us = k0.elapsed_time(k1) * 1e3 / (reps * ROLLOUT)
     achieved = BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
-    traffic, traffic_src = pmc_traffic(n)
+    traffic, traffic_src, traffic_stale = pmc_traffic(n)
     sq = pmc_sq(n)
     # which roofline binds: at the BASELINE size the state is L2 / Infinity-Cache resident and one wavefront per SIMD
     # issues dependent instructions -- launch floor + instruction latency, not bandwidth; the HBM fraction is reported
@@ -433,6 +572,24 @@ def main():
             other[name] = {"us_per_step": us, "env_steps_per_s": n / (us * 1e-6), "obs_dim": t.OBS_DIM,
                            "obs_GBs": n * t.OBS_DIM * 4 / (us * 1e-6) / 1e9, "launches": "one per env.step()" if name == "elevation"
                            else "two per env.step() (step, camera)"}
+            # roofline of the whole step (SURVEY 8(d) bytes per env-step / live us per step) and, for the visual task, of its
+            # dominant kernel alone (the camera: 12 832 B of observation row per env)
+            if name == "elevation":
+                other[name]["roofline"] = roofline_block("elev", n, us, "elev_step_scan_kernel" if n <= 32768 else
+                                                         "elev_step_kernel + elev_scan_kernel",
+                                                         "latency (20 dependent integrator sub-steps with terrain gathers)" if n <= 32768 else "hbm+valu")
+            else:
+                other[name]["roofline"] = roofline_block("visual", n, us, "visual_step_kernel + visual_obs_kernel", "hbm+lds")
+                t.observe()
+                torch.cuda.synchronize()
+                q0.record()
+                for _ in range(32):
+                    t.observe()
+                q1.record()
+                torch.cuda.synchronize()
+                cam_us = q0.elapsed_time(q1) * 1e3 / 32
+                other[name]["camera_roofline"] = roofline_block("visual", n, cam_us, "visual_obs_kernel", "hbm+lds",
+                                                                bytes_per_unit=t.OBS_DIM * 4 + 60)
             if n <= 32768:
                 # open-loop rollouts (pre-staged actions) as ONE launch: the height scan / camera of step k while step k + 1 is
                 # integrated (wl_elev_rollout_persistent, wl_visual_rollout_persistent; same results bit for bit)
@@ -490,6 +647,34 @@ def main():
                 del cst
             del t, a, kac, ob
 
+    # secondary: BASELINE.json configs[4]'s named kernel -- the depth ray-cast of the visual task's camera against the
+    # heightfield: n cars of the elevation task standing on the synthetic 800 x 800 terrain after 8 steps, one 60 x 80
+    # distance_to_image_plane image each (clipping range 100 m, visual/mushr_visual_env_cfg.py:240)
+    if rank == 0 and world == 1:
+        from wheeledlab_amd.core import DepthCamera, ElevBatch
+        t = ElevBatch(n, device=dev, seed=42)
+        t.reset()
+        t.rollout(torch.rand(8, n, 2, device=dev) * 2 - 1)
+        cam = DepthCamera((t.height, float(t._hf.x0), float(t._hf.y0), float(t._hf.cell)), dev)
+        img = torch.empty(n, 60, 80, device=dev)
+        for _ in range(3):
+            cam.render(t, 100.0, img)
+        torch.cuda.synchronize()
+        q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        q0.record()
+        for _ in range(16):
+            cam.render(t, 100.0, img)
+        q1.record()
+        torch.cuda.synchronize()
+        dus = q0.elapsed_time(q1) * 1e3 / 16
+        hit = float((img < 100.0).float().mean())
+        other["visual_depth"] = {"us_per_render": dus, "images_per_s": n / (dus * 1e-6), "rays_per_s": n * 4800 / (dus * 1e-6),
+                                 "image": "60 x 80 fp32 distance_to_image_plane", "hit_fraction": hit,
+                                 "workload": f"{n} elevation-task cars on the synthetic 800 x 800 heightfield (0.05 m), max depth 100 m",
+                                 "roofline": roofline_block("depth", n, dus, "visual_depth_kernel",
+                                                            "valu+latency (pyramid walk: dependent gathers; the image write is the only HBM stream)")}
+        del t, cam, img
+
     # secondary: the same workload driven step by step through the drop-in Python surface
     # (registry.make -> ClipAction -> RslRlVecEnvWrapper.step), i.e. what a Python RL loop sees per env.step() call
     py_rate = None
@@ -516,12 +701,13 @@ def main():
     # secondary: the SAME fused step at env counts where it is throughput- rather than launch-bound (SURVEY 8(d) config 2:
     # "also sweep N ... to expose the bandwidth-bound regime").  Run in a fresh process: with the GB-sized buffers carved
     # out of this process's caching-allocator leftovers the same launches measured 12-15 % slower (tools/lanes_probe.py)
-    sweep = []
+    sweep, other_sweep = [], []
     if rank == 0 and world == 1 and not args.no_sweep:
         try:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--sweep-child"], capture_output=True, text=True,
                                  timeout=600, check=True).stdout.strip().splitlines()[-1]
-            sweep = json.loads(out)
+            both = json.loads(out)
+            sweep, other_sweep = both["drift"], both["other"]
         except Exception as ex:   # noqa: BLE001 -- the sweep is a secondary figure: never lose the headline line over it
             print(f"[bench] sweep subprocess failed ({ex!r}); measuring in-process", file=sys.stderr, flush=True)
             sweep = large_n_sweep(dev)
@@ -539,15 +725,21 @@ def main():
             "config": {"workload": f"RSS_DRIFT_CONFIG drift task, {n} envs/GPU, flat terrain, fused dynamics+mdp HIP "
                                    f"kernel, U(-1,1) actions pre-staged in HBM, {ROLLOUT}-step rollout storage",
                        "envs_per_gpu": n, "total_envs": total_envs, "decimation": 4, "sim_dt": 0.005,
-                       "parallelism": f"env-shard x{world}, metric all-reduce / {ROLLOUT} steps"},
+                       "parallelism": f"env-shard x{world}, metric all-reduce / {every} steps"},
             "gpu_event_ms_per_step": gpu_ms / args.steps,
             "timing": {"repeats": REPEATS, "statistic": "median of the per-block max-over-ranks wall time",
-                       "block_ms": [round(w * 1e3, 4) for w in walls]},
+                       "block_ms": [round(w * 1e3, 4) for w in walls],
+                       # every block counted, incl. the ones the metric all-reduce falls into (the median skips them at K < 128)
+                       "mean_value": total_envs * args.steps / wall_mean, "mean_ms_per_step": wall_mean * 1e3 / args.steps,
+                       "metric_reductions_in_timed_blocks": reductions_in_timed_blocks, "allreduce_every": every},
+            "rccl": rccl,
             "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
                          "valu_frac": sq.get("valu_pipe_frac") if sq else None, "sq_counters": sq,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "kernel": "drift_step_kernel<FlatGround>", "launch_us": launch_us,
+                         "frac_uses": "launch_us (HIP events on the launch stream, live in this run)",
+                         "rocprof_kernel_stats": rocprof_avg_us("drift_step_kernel"),
                          "bytes_per_env_step": BYTES_PER_ENV_STEP, "envs_per_launch": n},
             "episode_metrics": {"resets": float(metric_sum[8]), "timeouts": float(metric_sum[9]),
                                 "out_of_bounds": float(metric_sum[10]), "nonfinite": float(metric_sum[14])},
@@ -559,6 +751,8 @@ def main():
         line["other_tasks"] = other
         if sweep:
             line["large_n_sweep"] = sweep
+        if other_sweep:
+            line["other_tasks_large_n"] = other_sweep
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(line), flush=True)

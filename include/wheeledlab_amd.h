@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 18
+#define WL_ABI_VERSION 19
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -638,11 +638,21 @@ int wl_visual_mdp(const WlVisualParams* p, const WlTravMap* m, int32_t n, int64_
                   const float* lin_vel_b, float* terms, uint8_t* out_of_map, int32_t* x_idx, int32_t* y_idx,
                   void* stream);
 /*
- * Extension (BASELINE.json config 5; unused in the reference, mdp_sensors/observations.py:89-95): per-pixel
- * distance_to_image_plane of the same camera against a heightfield (ray march + bisection), depth [n][60][80].
+ * Depth ray-cast of the same camera against a heightfield (BASELINE.json config 5 "depth raycast against heightfield";
+ * the observation functions mdp_sensors/observations.py:89-95 `camera_data_depth` / `raycast_depth` forward IsaacLab's
+ * `distance_to_image_plane` of the camera visual/mushr_visual_env_cfg.py:230-246 -- defined but unwired in the
+ * reference's VisualObsCfg).  depth [n][60][80]: per pixel the distance along the optical axis to the first point of the
+ * ray on or below the terrain solid -- bilinear patches of `hf` inside the grid, the plane z = hf->outside_z beyond it --
+ * exact per cell (the patch along the ray is a quadratic; no marching step), clipped at max_depth.  The ray's ground
+ * track is walked through a max-pyramid of the field that the caller builds ONCE per heightfield:
+ *   wl_heightfield_pyramid_floats(nx, ny)  -> floats the pyramid needs (0: unsupported size; nx, ny <= 16 385)
+ *   wl_heightfield_build_pyramid(hf, pyramid, stream)
+ * The poses are rows WL_S_PX.. / WL_S_QW.. of `b->state` (any task's batch).  Spec: oracle/depth.c.
  */
-int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, float max_depth,
-                    float* depth, void* stream);
+int64_t wl_heightfield_pyramid_floats(int32_t nx, int32_t ny);
+int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* stream);
+int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid,
+                    float max_depth, float* depth, void* stream);
 
 /*
  * Startup-mode events (domain randomisation applied ONCE per env, at construction): bucketed wheel friction

@@ -1,0 +1,50 @@
+"""Camera poses for the depth ray-cast tests (CPU and GPU): cars standing / tilted on the synthetic 800 x 800 terrain of SURVEY
+8(d) config 3, plus the edge cases -- cameras outside the grid looking in (side wall of the terrain solid) and out (the z =
+outside_z plane), at the border, high above, and underground."""
+import numpy as np
+
+from oracle import heightfield as HF
+from oracle.mathlib import quat_from_euler_xyz
+
+EDGE = np.array([
+    # x, y, z, roll, pitch, yaw
+    [-20.5, 3.0, 0.30, 0.0, 0.0, 0.0],        # outside, looking into the grid through the wall of the base (0.19 above z = 0)
+    [-20.5, 3.0, -0.05, 0.0, 0.0, 0.0],       # same with the CAMERA (root + 0.18) below the top of the wall
+    [19.7, -19.8, 0.50, 0.0, 0.1, -0.7],      # inside near the corner, looking out over the edge
+    [25.0, 25.0, 1.00, 0.0, 0.2, 0.3],        # far outside looking away: only the outside plane
+    [0.0, -20.02, 0.10, 0.0, 0.0, 1.5708],    # just outside, heading in along +y
+    [0.0, 0.0, 30.0, 0.0, 1.3, 0.0],          # high above, looking steeply down
+    [3.0, 4.0, -0.5, 0.0, 0.0, 0.0],          # underground: depth 0 everywhere
+    [-7.0, 9.0, 0.45, 0.5, -0.4, 2.0],        # rolled over on a slope
+    [12.0, -3.0, 0.60, 0.0, -0.6, -2.5],      # nose up (sky in most rows)
+    [0.0, 0.0, 0.40, 0.0, 0.0, 0.0],          # axis-aligned: du or dv exactly zero in the centre column
+], np.float64)
+
+
+def terrain():
+    return HF.make_terrain()
+
+
+def poses(n, seed, hf=None, span=17.5, tilt=0.15, edge=True):
+    """-> pos [n,3], quat [n,4] float32.  Roots 0.04-0.3 m above the terrain with N(0, tilt) roll / pitch and uniform yaw; the
+    first len(EDGE) are the edge cases (when n allows and `edge`)."""
+    hf = hf or terrain()
+    rng = np.random.RandomState(seed)
+    xy = rng.uniform(-span, span, (n, 2)).astype(np.float32)
+    z, _, _ = HF.sample(*hf, xy[:, 0], xy[:, 1])
+    pos = np.concatenate([xy, (z + rng.uniform(0.04, 0.3, n))[:, None]], 1).astype(np.float32)
+    eul = np.stack([rng.normal(0, tilt, n), rng.normal(0, tilt, n), rng.uniform(-np.pi, np.pi, n)], 1)
+    if edge and n >= 2 * len(EDGE):
+        pos[: len(EDGE)] = EDGE[:, :3]
+        eul[: len(EDGE)] = EDGE[:, 3:]
+    eul = eul.astype(np.float32)
+    quat = quat_from_euler_xyz(eul[:, 0], eul[:, 1], eul[:, 2]).astype(np.float32)
+    return pos, np.ascontiguousarray(quat)
+
+
+def mismatch(got, want, max_depth, rtol=2e-4, atol=2e-4):
+    """pixels whose depth differs beyond fp32-vs-double rounding of the same intersection: -> (bad mask, abs error).  A ray that
+    grazes a crest resolves to the crest in one arithmetic and to what lies behind it in the other: those are counted, not
+    excused silently (the callers bound their number)."""
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    return err > atol + rtol * np.abs(want), err

@@ -1,0 +1,35 @@
+// TEST INFRASTRUCTURE ONLY: the depth ray-cast's device walk (wheeledlab_amd/csrc/wl_depth_dev.h: max-pyramid + per-ray
+// traversal, fp32) compiled for the host through the stand-in hip_runtime.h and driven over arrays, so that
+// tests/test_oracle_depth.py can hold it against oracle/depth.c without a GPU.  Built by the test into a scratch directory.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+using std::max;
+using std::min;
+
+#include "wl_depth_dev.h"
+
+extern "C" {
+// pos [n][3], quat [n][4]; depth [n][60][80]; steps (optional) [n][60][80]: unused, reserved
+int hs_depth(const WlVisualParams* p, const WlHeightField* hf, int n, const float* pos, const float* quat, float max_depth, float* depth) {
+    const int P = pyramid_pow2(hf->nx, hf->ny), lmax = pyramid_levels(P);
+    std::vector<float> mip((size_t)pyramid_offset(P, lmax) + 1);
+    for (int J = 0; J < (P >> 1); ++J)
+        for (int I = 0; I < (P >> 1); ++I) mip[(size_t)J * (P >> 1) + I] = pyramid_level1_value(*hf, I, J);
+    for (int L = 2; L <= lmax; ++L)
+        for (int J = 0; J < (P >> L); ++J)
+            for (int I = 0; I < (P >> L); ++I) mip[(size_t)pyramid_offset(P, L) + (size_t)J * (P >> L) + I] = pyramid_reduce_value(mip.data(), P, L, I, J);
+    const Pyramid py{mip.data(), P, lmax};
+    const HeightFieldGround g = make_ground(hf);
+    for (int e = 0; e < n; ++e) {
+        const Quat q{quat[4 * e], quat[4 * e + 1], quat[4 * e + 2], quat[4 * e + 3]};
+        const Mat3 R = mat_from_quat(q);
+        const V3 o = v3(pos[3 * e], pos[3 * e + 1], pos[3 * e + 2]) + mul(R, v3(p->cam_pos[0], p->cam_pos[1], p->cam_pos[2]));
+        for (int r = 0; r < WL_VIS_IMG_H; ++r)
+            for (int c = 0; c < WL_VIS_IMG_W; ++c)
+                depth[((size_t)e * WL_VIS_IMG_H + r) * WL_VIS_IMG_W + c] = cast_ray(g, py, o, mul(R, depth_pixel_ray_body(*p, r, c)), max_depth);
+    }
+    return 0;
+}
+}

@@ -213,3 +213,35 @@ def test_batched_values_equal_the_policy_step_values():
     torch.cuda.synchronize()
     torch.testing.assert_close(got, want, rtol=3e-4, atol=3e-4)
     assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("D,n_total", [(689, 8192), (3208, 4096), (3208, 8192)])
+def test_default_form_of_a_shard_is_the_form_of_the_whole_batch(D, n_total):
+    """ActorCritic.act picks its kernel (f32 / bf16 one launch / bf16 two launches) from the row count, and the
+    crossovers sit between a shard's and the batch's size (D = 689: bf16 from 8192 rows, f32 below; D = 3208: two launches up to
+    2048 rows, one up to 8192).  With `global_rows` set to the whole batch's row count a shard takes the batch's form and
+    reproduces its rows bit for bit; and a larger batch on the same view (scratch reallocated) never runs on unbuilt planes."""
+    ac, _, _ = _nets(D, "elu", seed=5)
+    obs = torch.randn(n_total, D, device=DEV)
+    full = [torch.empty(n_total, 2, device=DEV), torch.empty(n_total, 2, device=DEV), torch.empty(n_total, device=DEV), torch.empty(n_total, device=DEV)]
+    ac.act(obs, *full, 7, 3)
+    shard = [torch.empty_like(t) for t in full]
+    ac.global_rows = n_total
+    for lo in range(0, n_total, n_total // 4):
+        sl = slice(lo, lo + n_total // 4)
+        ac.act(obs[sl], shard[0][sl], shard[1][sl], shard[2][sl], shard[3][sl], 7, 3, env_offset=lo)
+    torch.cuda.synchronize()
+    for x, y in zip(full, shard):
+        assert torch.equal(x, y)
+    # the planes_fresh hazard: a small call builds the planes, a larger one reallocates the scratch -- the caller's
+    # planes_fresh=True must not leave layer 1 running on zero-filled planes
+    ac2, _, _ = _nets(D, "elu", seed=5)
+    ac2.planes = True
+    small = [t[:256].clone() for t in full]
+    ac2.act(obs[:256], *small, 7, 3)
+    big = [torch.empty_like(t) for t in full]
+    ac2.act(obs, *big, 7, 3, planes_fresh=True)
+    ref = [torch.empty_like(t) for t in full]
+    ac2.act(obs, *ref, 7, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(big[1], ref[1]) and torch.equal(big[3], ref[3])

@@ -1,0 +1,144 @@
+"""Depth ray-cast against a heightfield on the GPU (BASELINE.json config 5; reference hook
+wheeledlab_tasks/visual/mdp_sensors/observations.py:89-95): wl_visual_depth through the C ABI against oracle/depth.c (exact
+per-cell intersection in double precision, walking cell by cell -- pinned on the CPU side by tests/test_oracle_depth.py).
+Tolerance: |d_gpu - d_oracle| <= 2e-4 + 2e-4 d (fp32 walk vs double); rays that graze a crest may resolve to the crest or to
+what lies behind it -- those pixels are COUNTED and bounded (< 1e-4 of the image), never excused silently."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import depth as D
+from oracle import visual_step as VS
+from tests import depth_cases as DC
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+P = VS.visual_params()
+
+
+@pytest.fixture(scope="module")
+def hf():
+    return DC.terrain()
+
+
+def _posed_batch(pos, quat):
+    """a VisualBatch whose state rows carry the given root poses (the depth entry reads rows WL_S_PX.. / WL_S_QW.. only)"""
+    from wheeledlab_amd.core import VisualBatch
+    trav = np.ones((500, 500), bool)
+    env = VisualBatch(len(pos), device=DEV, seed=1, trav_map=trav)
+    env.state[0:3, : env.n] = torch.from_numpy(np.ascontiguousarray(pos.T)).to(DEV)
+    env.state[3:7, : env.n] = torch.from_numpy(np.ascontiguousarray(quat.T)).to(DEV)
+    return env
+
+
+def test_pyramid_levels_are_the_block_maxima(hf):
+    from wheeledlab_amd.core import DepthCamera
+    for field in (hf, (hf[0][:613, :349].copy(), hf[1], hf[2], hf[3])):
+        cam = DepthCamera(field, DEV)
+        torch.cuda.synchronize()
+        h = field[0]
+        ny, nx = h.shape
+        Pw = 2
+        while Pw < nx - 1 or Pw < ny - 1:
+            Pw *= 2
+        pyr = cam.pyramid.cpu().numpy()
+        L, off = 1, 0
+        while (Pw >> L) >= 1:
+            W = Pw >> L
+            got = pyr[off: off + W * W].reshape(W, W)
+            s = 1 << L
+            want = np.full((W, W), -np.inf, np.float32)
+            for J in range(min(W, (ny - 1 + s - 1) // s)):
+                for I in range(min(W, (nx - 1 + s - 1) // s)):
+                    want[J, I] = h[J * s: min((J + 1) * s, ny - 1) + 1, I * s: min((I + 1) * s, nx - 1) + 1].max()
+            np.testing.assert_array_equal(got, want, err_msg=f"level {L}")
+            off += W * W
+            if W == 1:
+                break
+            L += 1
+        assert off == len(pyr)
+
+
+@pytest.mark.parametrize("max_depth", [100.0, 20.0])
+def test_full_images_match_the_oracle_at_4096_envs(hf, max_depth):
+    """BASELINE config 5 at full size: 4096 cameras on the sloped synthetic terrain, every pixel of every 60 x 80 image"""
+    from wheeledlab_amd.core import DepthCamera
+    n = 4096
+    pos, quat = DC.poses(n, seed=7, hf=hf)
+    env = _posed_batch(pos, quat)
+    cam = DepthCamera(hf, DEV)
+    got = cam.render(env, max_depth)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    want = D.depth(P, pos, quat, hf, max_depth)
+    assert got.shape == want.shape == (n, 60, 80)
+    bad, err = DC.mismatch(got, want, max_depth)
+    hit = want < max_depth
+    print(f"depth parity n={n} max_depth={max_depth}: grazing pixels {int(bad.sum())} of {bad.size} ({bad.mean():.2e}), "
+          f"hit fraction {hit.mean():.3f}, median err {np.median(err):.2e}, p99.99 err {np.quantile(err, 0.9999):.2e}")
+    assert bad.mean() < 1e-4, (int(bad.sum()), float(err.max()))
+    assert np.quantile(err, 0.999) < 1e-4
+    assert 0.3 < hit.mean() < 0.9          # both outcomes well represented
+    # the same launch through the batch's own entry (cached camera) and into a caller's buffer
+    out = torch.empty(n, 60, 80, device=DEV)
+    env.depth(hf, max_depth, out=out)
+    assert torch.equal(out.cpu(), torch.from_numpy(got))
+
+
+def test_odd_grid_edge_cases_and_short_range(hf):
+    """a 349 x 613 grid (partial pyramid cells on both axes), cameras incl. all edge cases, max_depth shorter than most hits"""
+    from wheeledlab_amd.core import DepthCamera
+    field = (hf[0][:613, :349].copy(), hf[1], hf[2], hf[3])
+    span = 0.5 * 349 * float(hf[3]) - 1.5
+    pos, quat = DC.poses(300, seed=9, hf=field, span=span)
+    env = _posed_batch(pos, quat)
+    cam = DepthCamera(field, DEV)
+    for md in (2.5, 60.0):
+        got = cam.render(env, md).cpu().numpy()
+        want = D.depth(P, pos, quat, field, md)
+        bad, err = DC.mismatch(got, want, md)
+        assert bad.mean() < 1e-4, (md, int(bad.sum()), float(err.max()))
+    assert (got[6] == 0).all()             # EDGE[6]: underground
+
+
+def test_depth_of_driving_elevation_cars(hf):
+    """the poses the elevation task's physics produces (cars settled on slopes after 30 steps), rendered from the
+    ElevBatch's own state rows"""
+    from wheeledlab_amd.core import DepthCamera, ElevBatch
+    n = 512
+    env = ElevBatch(n, device=DEV, seed=4)
+    env.reset()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for _ in range(30):
+        env.step(torch.rand(n, 2, device=DEV, generator=g) * 2 - 1)
+    cam = DepthCamera((env.height, float(env._hf.x0), float(env._hf.y0), float(env._hf.cell)), DEV)
+    got = cam.render(env, 30.0)
+    torch.cuda.synchronize()
+    st = env.state[:, :n].cpu().numpy()
+    field = (env.height.cpu().numpy(), float(env._hf.x0), float(env._hf.y0), float(env._hf.cell))
+    want = D.depth(P, st[0:3].T, st[3:7].T, field, 30.0)
+    bad, err = DC.mismatch(got.cpu().numpy(), want, 30.0)
+    assert bad.mean() < 1e-4, (int(bad.sum()), float(err.max()))
+
+
+def test_invalid_arguments_are_refused(hf):
+    from wheeledlab_amd import _abi as A
+    from wheeledlab_amd.core import DepthCamera
+    pos, quat = DC.poses(64, seed=1, hf=hf, edge=False)
+    env = _posed_batch(pos, quat)
+    cam = DepthCamera(hf, DEV)
+    out = torch.empty(64, 60, 80, device=DEV)
+    lib = env.lib
+    args = lambda **kw: (C.byref(kw.get("p", env.p)), C.byref(kw.get("b", env._bufs)), C.byref(kw.get("hf", cam._hf)),
+                         kw.get("pyr", cam.pyramid.data_ptr()), kw.get("md", 10.0), kw.get("out", out.data_ptr()), None)
+    assert lib.wl_visual_depth(*args()) == 0
+    assert lib.wl_visual_depth(*args(pyr=None)) == -1
+    assert lib.wl_visual_depth(*args(out=None)) == -1
+    assert lib.wl_visual_depth(*args(md=0.0)) == -1
+    bad_hf = A.WlHeightField(cam._hf.height, 1, 800, 0.0, 0.0, 0.05, 0.0)
+    assert lib.wl_visual_depth(*args(hf=bad_hf)) == -1
+    assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == (1024 * 1024 - 1) // 3
+    assert lib.wl_heightfield_build_pyramid(C.byref(bad_hf), cam.pyramid.data_ptr(), None) == -1
+    torch.cuda.synchronize()

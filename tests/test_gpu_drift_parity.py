@@ -140,28 +140,23 @@ def test_reset_kernel_matches_oracle(lib):
     assert d.max() <= 0.5 * np.sqrt(2) + 1e-5
 
 
-@pytest.mark.parametrize("lanes", [4, 1, 2])
-@pytest.mark.parametrize("mode", ["philox", "noise_tensor", "no_corruption"])
-def test_fused_step_matches_oracle_single_steps(lib, mode, lanes):
+def _single_step_parity(env, p, n, seed, mode, steps=40):
     """Each step starts from the device state (copied to the host), so differences do not accumulate:
     tolerance 2e-4 abs/rel on state (4 sub-steps of fp32 with hardware rcp/rsq vs numpy), rewards 2e-3 abs
-    (weights up to 5000 * dt amplify), observation 1e-3."""
-    n = 1024
-    env = _fresh(n, seed=5)
-    env.set_lanes(lanes)      # every form of the step kernel: quad-per-env (latency), lane-per-env with packed axles,
-                              # lane-per-env with the scalar wheel loop (throughput)
-    p = OP.drift_params()
+    (weights up to 5000 * dt amplify), observation 1e-3.  `p`: the oracle's parameter set (a namespace, or the product's
+    own ctypes struct: same field names)."""
     if mode == "no_corruption":
         env.p.enable_corruption = 0
         p.enable_corruption = 0
+    max_len = int(p.max_episode_length)
     rng = np.random.RandomState(0)
     ref = env.ref_table.cpu().numpy()
     flips = 0
-    for k in range(40):
+    for k in range(steps):
         st = env.state.cpu().numpy().copy()
         ep = env.episode_len.cpu().numpy().copy()
-        if k == 20:  # push a quarter of the envs to the end of their episode -> time_out path
-            ep[: n // 4] = 249
+        if k == steps // 2:  # push a quarter of the envs to the end of their episode -> time_out path
+            ep[: n // 4] = max_len - 1
             env.episode_len.copy_(torch.from_numpy(ep))
         a = rng.uniform(-1.2, 1.2, (n, 2)).astype(np.float32)
         a[:, 0] = np.abs(a[:, 0])
@@ -173,7 +168,7 @@ def test_fused_step_matches_oracle_single_steps(lib, mode, lanes):
         obs, rew, term, trunc = env.step(dev(a), noise_t)
         torch.cuda.synchronize()
         met = np.zeros(16)
-        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, ref, a, 5, k, met,
+        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, ref, a, seed, k, met,
                                                        noise_np[:, :n] if noise_np is not None else None)
         got = env.state.cpu().numpy()
         g_term = term.cpu().numpy().astype(bool)
@@ -193,6 +188,75 @@ def test_fused_step_matches_oracle_single_steps(lib, mode, lanes):
             np.testing.assert_allclose(dm[8:16], met[8:16], atol=1e-3)
             np.testing.assert_allclose(dm[:8], met[:8], rtol=1e-3, atol=5e-2)
     assert flips <= 2, f"{flips} termination decisions differ (expected only at fp32 boundary ties)"
+
+
+@pytest.mark.parametrize("lanes", [4, 1, 2])
+@pytest.mark.parametrize("mode", ["philox", "noise_tensor", "no_corruption"])
+def test_fused_step_matches_oracle_single_steps(lib, mode, lanes):
+    n = 1024
+    env = _fresh(n, seed=5)
+    env.set_lanes(lanes)      # every form of the step kernel: quad-per-env (latency), lane-per-env with packed axles,
+                              # lane-per-env with the scalar wheel loop (throughput)
+    _single_step_parity(env, OP.drift_params(), n, 5, mode)
+
+
+def _f1tenth_batch(n, seed):
+    """the F1Tenth drift variant exactly as the registry builds it (drifting/f1tenth_drift_env_cfg.py:42-161,
+    wheeledlab_assets/f1tenth.py:9-27): 4WD drive train (vehicle.drive = 1), 4WD action map, L 0.365 / W 0.284, F1Tenth
+    actuator constants, startup randomisation of the throttle damping of all four wheels"""
+    from wheeledlab_amd import registry, tasks  # noqa: F401
+    from wheeledlab_amd.core import DriftBatch
+    from wheeledlab_amd.envs.flatten import flatten_drift_cfg
+    flat = flatten_drift_cfg(registry.parse_env_cfg("Isaac-F1TenthDriftRL-v0", device=DEV, num_envs=n))
+    flat.params.action.clip_wrapper = 1     # gym's ClipAction folded into the kernel (driven with +-1.2 actions below)
+    env = DriftBatch(n, device=DEV, seed=seed, params=flat.params, startup=flat.startup)
+    env.reset()
+    torch.cuda.synchronize()
+    p = flat.params
+    assert p.vehicle.drive == 1 and p.action.map == 1 and abs(p.action.base_length - 0.365) < 1e-6 and abs(p.action.base_width - 0.284) < 1e-6
+    assert abs(p.vehicle.motor_sat - 1.0) < 1e-6 and abs(p.vehicle.motor_vel_limit - 400.0) < 1e-3 and abs(p.vehicle.steer_kp - 120.0) < 1e-4
+    return env, flat
+
+
+@pytest.mark.parametrize("lanes", [4, 1, 2])
+@pytest.mark.parametrize("mode", ["philox", "no_corruption"])
+def test_f1tenth_fused_step_matches_oracle_single_steps(lib, mode, lanes):
+    """the drive = 1 instantiations of the drift step kernel (all three forms) against the oracle, with the parameter struct
+    the registry flattens from the F1Tenth cfg handed to BOTH sides (the oracle reads the same field names)"""
+    n = 1024
+    env, flat = _f1tenth_batch(n, seed=5)
+    env.set_lanes(lanes)
+    damp = env.state[25, :n]
+    assert float(damp.min()) >= 10.0 and float(damp.max()) <= 50.0 and float(damp.std()) > 5.0   # randomize_gains (:57-65)
+    _single_step_parity(env, flat.params, n, 5, mode)
+
+
+def test_f1tenth_full_size_properties(lib):
+    """size-independent invariants of the F1Tenth variant at BASELINE's env count (as test_full_size_properties)"""
+    n = 4096
+    env, flat = _f1tenth_batch(n, seed=1)
+    K = 300
+    g = torch.Generator(device=DEV).manual_seed(0)
+    resets, moved = 0, 0.0
+    for k in range(K):
+        obs, rew, term, trunc = env.step(torch.rand(n, 2, device=DEV, generator=g) * 2 - 1)
+        resets += int((term | trunc).sum())
+        moved = max(moved, float(env.state[7:9, :n].norm(dim=0).mean()))
+    torch.cuda.synchronize()
+    st = env.state[:, :n]
+    assert torch.isfinite(st).all() and torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert ((st[3:7] ** 2).sum(0).sqrt() - 1).abs().max() < 1e-5
+    assert (obs[:, 12:14].abs() <= 1).all() and (env.episode_len[:n] < 250).all()
+    m = env.metrics.cpu().numpy()
+    assert m[8] == resets and resets > 0 and m[14] == 0
+    assert st[2].abs().max() < 0.05 and st[17].abs().max() <= 0.5312 and moved > 0.5     # on the plane, steering bounded, driving
+    # all four wheels are driven: front wheels spin up under throttle with the car held on an open plane
+    env.p.r_out, env.p.r_in, env.p.max_episode_length = 1e18, 0.0, 10 ** 9
+    a = torch.zeros(n, 2, device=DEV)
+    a[:, 0] = 1.0
+    for _ in range(25):
+        env.step(a)
+    assert float(env.state[15:17, :n].mean()) > 10.0 and float(env.state[13:15, :n].mean()) > 10.0
 
 
 def test_rollout_api_equals_step_api(lib):

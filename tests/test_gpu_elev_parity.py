@@ -199,3 +199,43 @@ def test_persistent_rollout_equals_stepping(n, K, slots):
         assert float(ea.metrics_raw[1:].abs().sum()) == 0.0
     torch.testing.assert_close(ma, mb, rtol=1e-5, atol=1e-3)
     assert torch.equal(ma[8:12], mb[8:12]) and float(ma[8]) == float(outs[0][4].sum())      # resets, time-outs, first two terminations
+
+
+@pytest.mark.parametrize("lanes", [4, 1])
+def test_settled_cars_need_no_contact_excuse(lanes):
+    """Companion of test_elev_fused_step_matches_oracle_single_steps: that test excuses up to 1 % of envs per step as contact
+    make / break discontinuities (the spawn drop).  Here nothing spawns: every termination is switched off on BOTH sides, the cars
+    settle for 12 steps and then crawl over the terrain with all wheels in contact -- the excused set must be EMPTY for 24
+    steps, in both forms of the kernel."""
+    n = 512
+    env, hf = _fresh(n, seed=8)
+    env.set_lanes(lanes)
+    p = OS.elev_params()
+    for q in (env.p, p):      # no resets: no time-out, no below-minimum-height, no stuck, no rollover, no at-goal
+        q.max_episode_length = 10 ** 9
+        q.min_height, q.stuck_min_vel, q.upright_cos, q.goal_dist = -1e9, -1e9, -2.0, -1.0
+    env.p.reset_xy = 12.0     # spawn away from the border (no drive off the edge of the field within the test)
+    env.reset()
+    rng = np.random.RandomState(1)
+    gentle = lambda: np.stack([rng.uniform(0.1, 0.3, n), rng.uniform(-0.3, 0.3, n)], -1).astype(np.float32)
+    for _ in range(12):
+        env.step(torch.from_numpy(gentle()).to(DEV))
+    torch.cuda.synchronize()
+    assert int(env.metrics[8]) == 0
+    for k in range(24):
+        st = env.state.cpu().numpy().copy()
+        ep = env.episode_len.cpu().numpy().copy()
+        a = gentle()
+        obs, rew, term, trunc = env.step(torch.from_numpy(a).to(DEV))
+        torch.cuda.synchronize()
+        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, hf, a, 8, 12 + k)
+        got = env.state.cpu().numpy()
+        assert not term.any() and not trunc.any() and not o_term.any() and not o_trunc.any()
+        err = np.abs(got[:21, :n] - st[:21, :n]) / (5e-4 + 5e-4 * np.abs(st[:21, :n]))
+        touchy = err.max(0) > 1.0
+        assert touchy.sum() == 0, (k, int(touchy.sum()), float(err.max()))
+        np.testing.assert_allclose(rew.cpu().numpy(), o_rew, rtol=2e-3, atol=5e-2)
+        d = np.abs(obs.cpu().numpy() - o_obs)
+        d[:, 2:5] = np.minimum(d[:, 2:5], np.abs(2 * np.pi - d[:, 2:5]))
+        assert d[:, :13].max() < 3e-3 and (d[:, 13:] > 2e-3).sum() <= 4
+    assert float(np.abs(env.state[7:9, :n].cpu().numpy()).mean()) > 0.05     # they do drive

@@ -1,5 +1,7 @@
 """GPU: the learner end to end on the drift task -- fused collection through the env surface (curriculum cuts, metric
 ring, counters) and a short PPO run that must improve the policy."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -269,7 +271,7 @@ def test_one_launch_elevation_collector_equals_policy_step_plus_env_step(n, acti
     assert torch.equal(sa.actions[0], sa.mu[0])
 
 
-@pytest.mark.parametrize("n,activation,slots", [(4096, "relu", 1), (1000, "elu", 1), (256, "relu", 3)])
+@pytest.mark.parametrize("n,activation,slots", [(4096, "relu", 1), (1000, "elu", 1), (256, "relu", 3), (256, "relu", 8)])
 def test_persistent_elevation_collector(n, activation, slots):
     """wl_elev_collect_rollout (the runner's collection loop as ONE launch: actor layer 1 from the blocks' registers, observation
     rows in LDS; the critic's values come from a batched pass afterwards).  (1) A K-step launch equals K one-step launches of
@@ -302,6 +304,11 @@ def test_persistent_elevation_collector(n, activation, slots):
     assert float(sa.values.abs().sum()) == 0.0        # not the collector's job
     assert torch.equal(ea.state, eb.state) and torch.equal(ea.episode_len, eb.episode_len) and ea.step_count == eb.step_count == K
     assert int(sa.dones.sum()) > 0 and bool(torch.isfinite(sa.observations).all())
+    if slots == K:
+        # a rollout whose length is a multiple of the ring (num_steps_per_env == metrics_slots): the C ABI refuses it as
+        # ONE launch (slot aliasing) and the host layer runs 1 + (K - 1) steps; the ring is left holding steps 1 .. K - 1
+        assert float(ea.metrics_raw[2:].abs().sum()) == 0.0 and float(ea.metrics_raw[0].abs().sum()) == 0.0
+        return
     torch.testing.assert_close(ea.metrics_raw.sum((0, 1)), eb.metrics_raw.sum((0, 1)), rtol=1e-5, atol=1e-3)
     if slots > 1:                                     # the one launch books all K steps into the first step's slot
         assert float(ea.metrics_raw[1:].abs().sum()) == 0.0 and float(ea.metrics_raw[0].abs().sum()) > 0.0

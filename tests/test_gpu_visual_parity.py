@@ -235,3 +235,37 @@ def test_persistent_visual_rollout_equals_stepping(trav, n, K, slots, aug):
     rc = ea.lib.wl_visual_rollout_persistent(C.byref(ea.p), C.byref(ea._bufs), C.byref(ea._map), a.data_ptr(), C.byref(ea._out), 0, 0, 2,
                                              ea.seed, ea.step_count, None)
     assert rc == -1      # WL_EINVAL
+
+
+@pytest.mark.parametrize("lanes", [4, 1])
+def test_settled_cars_need_no_contact_excuse(trav, lanes):
+    """Companion of test_visual_fused_step_matches_oracle_single_steps (which excuses up to 2 % of envs per step as wheel
+    touch-downs of the 10 cm spawn drop): no resets here (no time-out; nobody reaches the map's edge), the cars settle for 6
+    steps, and then the excused set must be EMPTY for 24 steps in both forms of the kernel."""
+    n = 256
+    env = _batch(n, trav, seed=8)
+    env.set_lanes(lanes)
+    p = OS.visual_params()
+    cells = OS.spawn_cells(trav)
+    env.p.max_episode_length = p.max_episode_length = 10 ** 9
+    env.state[0:2, :n] *= 0.5                                   # away from the map's edge
+    rng = np.random.RandomState(1)
+    for _ in range(6):
+        env.step(torch.from_numpy(rng.uniform(-0.5, 0.5, (n, 2)).astype(np.float32)).to(DEV))
+    torch.cuda.synchronize()
+    assert int(env.metrics[8]) == 0
+    for k in range(24):
+        st = env.state.cpu().numpy().copy()
+        ep = env.episode_len.cpu().numpy().copy()
+        a = rng.uniform(-1.2, 1.2, (n, 2)).astype(np.float32)
+        obs, rew, term, trunc = env.step(torch.from_numpy(a).to(DEV))
+        torch.cuda.synchronize()
+        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, trav, cells, a, 8, 6 + k)
+        got = env.state.cpu().numpy()
+        assert not term.any() and not trunc.any() and not o_term.any() and not o_trunc.any()
+        err = np.abs(got[:21, :n] - st[:21, :n]) / (5e-4 + 5e-4 * np.abs(st[:21, :n]))
+        touchy = err.max(0) > 1.0
+        assert touchy.sum() == 0, (k, int(touchy.sum()), float(err.max()))
+        cell_flip = np.abs(rew.cpu().numpy() - o_rew) > 0.5    # +-1 traversability flips exactly on a cell edge
+        assert cell_flip.sum() <= 1
+        np.testing.assert_allclose(rew.cpu().numpy()[~cell_flip], o_rew[~cell_flip], rtol=2e-3, atol=2e-3)

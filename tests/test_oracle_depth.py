@@ -1,0 +1,103 @@
+"""Depth ray-cast (BASELINE config 5), CPU side: the C oracle (oracle/depth.c: exact per-cell intersection in double) pinned
+against an independent brute-force marcher over oracle/heightfield.py::sample and against closed-form cases; and the DEVICE
+walk (wheeledlab_amd/csrc/wl_depth_dev.h: max-pyramid traversal in fp32) compiled for the host and held against the oracle --
+so the kernel's arithmetic is checked here before it ever runs on a GPU (tests/test_gpu_depth_parity.py does that)."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import depth as D
+from oracle import heightfield as HF
+from oracle import visual_step as VS
+from oracle.mathlib import matrix_from_quat
+from tests import depth_cases as DC
+from wheeledlab_amd import _abi
+from wheeledlab_amd.params import visual_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = os.environ.get("WL_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+P = VS.visual_params()
+
+
+@pytest.fixture(scope="module")
+def hf():
+    return DC.terrain()
+
+
+def test_c_oracle_matches_bruteforce_marcher(hf):
+    """two independent statements of `depth`: cell-exact quadratic roots (C, double) vs dense marching + bisection over the
+    float32 bilinear sampler the physics uses"""
+    pos, quat = DC.poses(24, seed=0, hf=hf)
+    rng = np.random.RandomState(5)
+    pix = rng.choice(4800, 300, replace=False)
+    want = D.depth_bruteforce(P, pos, quat, hf, 12.0, pixels=pix)
+    got = D.depth(P, pos, quat, hf, 12.0).reshape(len(pos), -1)[:, pix]
+    bad, err = DC.mismatch(got, want, 12.0, rtol=1e-4, atol=1e-4)
+    # the marcher can step over a crest thinner than its 4 mm stride: a handful of grazing rays at most
+    assert bad.mean() < 2e-3, (bad.sum(), err.max())
+    assert np.median(err) < 1e-5
+
+
+def test_flat_field_is_the_analytic_plane_distance():
+    flat = (np.full((64, 64), 0.25, np.float32), np.float32(-10.0), np.float32(-10.0), np.float32(20.0 / 63))
+    pos, quat = DC.poses(16, seed=2, hf=flat, span=4.0, edge=False)
+    got = D.depth(P, pos, quat, flat, 30.0)
+    o, d = D.pixel_rays(P, pos, quat)
+    t = (0.25 - o[:, None, 2]) / np.where(d[..., 2] < 0, d[..., 2], np.nan)
+    hx, hy = o[:, None, 0] + t * d[..., 0], o[:, None, 1] + t * d[..., 1]
+    inside = (np.abs(hx) < 10.0 - 1e-3) & (np.abs(hy) < 10.0 - 1e-3) & (t < 30.0)    # hits on the raised square
+    want = np.where(inside, t, np.nan).reshape(got.shape)
+    m = np.isfinite(want)
+    assert m.mean() > 0.2
+    np.testing.assert_allclose(got[m], want[m], rtol=1e-5, atol=1e-5)
+
+
+def test_known_answers_walls_underground_sky(hf):
+    pos, quat = DC.poses(32, seed=3, hf=hf)
+    d = D.depth(P, pos, quat, hf, 50.0)
+    # EDGE[6]: camera underground -> 0 everywhere
+    assert (d[6] == 0).all()
+    # EDGE[1]: outside the grid, 0.5 m from its x = -20 wall, camera below the wall's top (base 0.19) and looking straight at
+    # it: the centre pixels hit the wall at the distance to the plane x = -20 (the optical axis is +x)
+    R = matrix_from_quat(quat[1:2])[0]
+    o = pos[1] + R @ np.asarray(P.cam_pos, np.float32)
+    assert abs(d[1, 29, 40] - (-20.0 - o[0])) < 1e-4 and abs(d[1, 31, 40] - (-20.0 - o[0])) < 1e-4
+    # EDGE[3]: far outside looking away: rows below the horizon hit the z = 0 plane analytically, rows above are sky
+    o3, d3 = D.pixel_rays(P, pos[3:4], quat[3:4])
+    t = np.where(d3[0, :, 2] < 0, -o3[0, 2] / np.where(d3[0, :, 2] < 0, d3[0, :, 2], 1.0), 50.0).clip(max=50.0).reshape(60, 80)
+    np.testing.assert_allclose(d[3], t, rtol=1e-5, atol=1e-5)
+    assert (d <= 50.0).all() and (d >= 0).all()
+
+
+@pytest.fixture(scope="module")
+def hostlib(tmp_path_factory):
+    if not (os.path.exists(CLANG) or shutil.which(CLANG)):
+        pytest.skip("no clang++ to build the host simulation")
+    out = tmp_path_factory.mktemp("host_sim") / "libwl_depth_host.so"
+    subprocess.run([CLANG, "-O1", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                    "-I", os.path.join(ROOT, "tests", "host_sim", "hip_stub"), "-I", os.path.join(ROOT, "wheeledlab_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host_sim", "depth_host.cpp"), "-o", str(out)], check=True)
+    lib = C.CDLL(str(out))
+    lib.hs_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("max_depth", [100.0, 20.0, 2.5])
+def test_device_walk_on_the_host_matches_the_oracle(hostlib, hf, max_depth):
+    """the kernel's per-ray function (pyramid walk, fp32) against the cell-by-cell double oracle on sloped terrain incl. the
+    edge cases; non-square and odd-sized grids exercise the pyramid's partial cells"""
+    vp = visual_params()
+    for field, seed in ((hf, 11), ((hf[0][:613, :349].copy(), hf[1], hf[2], hf[3]), 12)):
+        pos, quat = DC.poses(96, seed=seed, hf=field, span=0.5 * min(field[0].shape) * float(field[3]) - 1.5)
+        h = np.ascontiguousarray(field[0])
+        hfs = _abi.WlHeightField(h.ctypes.data, h.shape[1], h.shape[0], float(field[1]), float(field[2]), float(field[3]), 0.0)
+        got = np.zeros((len(pos), 60, 80), np.float32)
+        assert hostlib.hs_depth(C.byref(vp), C.byref(hfs), len(pos), pos.ctypes.data, quat.ctypes.data, max_depth, got.ctypes.data) == 0
+        want = D.depth(P, pos, quat, field, max_depth)
+        bad, err = DC.mismatch(got, want, max_depth)
+        assert bad.mean() < 1e-4, (bad.sum(), err.max())      # grazing rays only
+        assert np.quantile(err, 0.999) < 1e-4

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 18
+WL_ABI_VERSION = 19
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -236,7 +236,9 @@ SIGNATURES = {
     "wl_visual_reset": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _u64, _u64, _vp]),
     "wl_visual_observe": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _vp]),
     "wl_visual_mdp": (C.c_int, [_P(WlVisualParams), _P(WlTravMap), _i32, _i64] + [_vp] * 7),
-    "wl_visual_depth": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlHeightField), C.c_float, _vp, _vp]),
+    "wl_heightfield_pyramid_floats": (C.c_int64, [_i32, _i32]),
+    "wl_heightfield_build_pyramid": (C.c_int, [_P(WlHeightField), _vp, _vp]),
+    "wl_visual_depth": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, C.c_float, _vp, _vp]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwheeledlab_amd.so")

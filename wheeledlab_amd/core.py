@@ -55,6 +55,13 @@ class _MetricsView:
         m = self.metrics_raw.sum(1)
         return m[0] if self.metrics_slots == 1 else m
 
+    def _ring_aliases(self, n_steps: int) -> bool:
+        """a persistent launch folds its steps into ring slot step0 % R and clears slot (step0 + n) % R for its successor: with n
+        a multiple of R those are the same slot and the C ABI refuses the launch (WL_EINVAL).  The host layer then runs the
+        rollout as two launches (1 and n - 1 steps) -- the same rollout; like n single steps it leaves the ring without the
+        first step's counts (a ring of R slots holds R - 1 steps)."""
+        return self.metrics_slots > 1 and n_steps > 1 and n_steps % self.metrics_slots == 0
+
 
 class DriftBatch(_MetricsView):
     """n drift envs resident on one GPU as a SoA state matrix [S_COUNT, stride] (fp32)."""
@@ -141,6 +148,12 @@ class DriftBatch(_MetricsView):
         persistent=True runs them as ONE launch with the state held in registers (wl_drift_rollout_persistent)."""
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
+        if persistent and self._ring_aliases(K):
+            cut = lambda t, a, b: None if t is None else t[a:b]
+            for a, b in ((0, 1), (1, K)):
+                self.rollout(actions[a:b], cut(obs_out, a, b), cut(rew_out, a, b), cut(term_out, a, b), cut(trunc_out, a, b), True,
+                             cut(dones_out, a, b))
+            return
         if obs_out is not None:
             key = (obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(),
                    None if dones_out is None else dones_out.data_ptr())
@@ -162,6 +175,9 @@ class DriftBatch(_MetricsView):
         current observation; self.obs ends as the last one."""
         K = storage.n_steps - start if count is None else int(count)
         assert storage.n_envs == self.n and actor_critic.actor.in_dim == self.OBS_DIM and 0 <= start and start + K <= storage.n_steps
+        if self._ring_aliases(K):
+            self.rollout_policy(actor_critic, storage, False, start, 1)
+            return self.rollout_policy(actor_critic, storage, evaluate_critic, start + 1, K - 1)
         storage.observations[start].copy_(self.obs)
         if self.metrics_slots > 1 and K > 1:
             # the launch folds all K steps into ring slot step0 % R and clears slot (step0 + K) % R; the slots it skips
@@ -268,6 +284,11 @@ class ElevBatch(_MetricsView):
         overlapped with the integration of step k + 1 (wl_elev_rollout_persistent); same results."""
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
+        if persistent and obs_out is not None and self._ring_aliases(K):
+            cut = lambda t, a, b: None if t is None else t[a:b]
+            for a, b in ((0, 1), (1, K)):
+                self.rollout(actions[a:b], obs_out[a:b], rew_out[a:b], term_out[a:b], trunc_out[a:b], cut(dones_out, a, b), True)
+            return
         if obs_out is not None:
             out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(),
                               None if dones_out is None else dones_out.data_ptr())
@@ -311,6 +332,9 @@ class ElevBatch(_MetricsView):
         their observation rows in LDS, the critic beside the physics).  Quad form only (n <= 32 768)."""
         st = storage
         count = st.n_steps - start if count is None else int(count)
+        if self._ring_aliases(count):
+            self.collect_rollout(actor_critic, storage, start, 1, deterministic)
+            return self.collect_rollout(actor_critic, storage, start + 1, count - 1, deterministic)
         key = (st.observations.data_ptr(), actor_critic.actor.w1.data_ptr(), actor_critic.critic.w1.data_ptr(), actor_critic.std.data_ptr())
         if getattr(self, "_collect_key", None) != key:
             assert st.n_envs == self.n and st.observations.shape[2] == self.OBS_DIM and st.observations.is_contiguous()
@@ -417,6 +441,11 @@ class VisualBatch(_MetricsView):
         integrated (wl_visual_rollout_persistent); same results."""
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
+        if persistent and obs_out is not None and self._ring_aliases(K):
+            cut = lambda t, a, b: None if t is None else t[a:b]
+            for a, b in ((0, 1), (1, K)):
+                self.rollout(actions[a:b], obs_out[a:b], rew_out[a:b], term_out[a:b], trunc_out[a:b], cut(dones_out, a, b), True)
+            return
         if obs_out is not None:
             out = A.WlStepOut(obs_out.data_ptr(), rew_out.data_ptr(), term_out.data_ptr(), trunc_out.data_ptr(),
                               None if dones_out is None else dones_out.data_ptr())
@@ -432,13 +461,58 @@ class VisualBatch(_MetricsView):
                    self.step_count, self._stream()), "wl_visual_rollout")
         self.step_count += K
 
-    def depth(self, heightfield, max_depth: float = 20.0) -> torch.Tensor:
-        """extension: distance_to_image_plane of the camera against a heightfield -> [n, 60, 80]"""
+    def depth(self, heightfield, max_depth: float = 20.0, out: torch.Tensor | None = None) -> torch.Tensor:
+        """distance_to_image_plane of the camera against a heightfield -> [n, 60, 80] (BASELINE config 5); `heightfield` is
+        (height [ny, nx], x0, y0, cell) or a DepthCamera (build it once when rendering every step)"""
+        cam = heightfield if isinstance(heightfield, DepthCamera) else _cached_depth_camera(self, heightfield)
+        return cam.render(self, max_depth, out)
+
+
+class DepthCamera:
+    """The visual task's pinhole camera rendering distance_to_image_plane against a heightfield (wl_visual_depth): owns the
+    device copy of the field and its max-pyramid (built once), renders the poses of ANY batch (rows WL_S_PX.. / WL_S_QW.. of
+    its state matrix).  Reference hook: mdp_sensors/observations.py:89-95; camera visual/mushr_visual_env_cfg.py:230-246."""
+
+    IMG_H, IMG_W = 60, 80
+
+    def __init__(self, heightfield, device="cuda:0", params: A.WlVisualParams | None = None, outside_z: float = 0.0):
+        from .params import visual_params
+        self.lib = A.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise A.HipExtensionMissing("DepthCamera needs a HIP device; there is no CPU path")
+        self.p = params if params is not None else visual_params()
         h, x0, y0, cell = heightfield
-        ht = torch.as_tensor(h, dtype=torch.float32).contiguous().to(self.device)
-        hf = A.WlHeightField(ht.data_ptr(), ht.shape[1], ht.shape[0], float(x0), float(y0), float(cell), 0.0)
-        out = torch.zeros(self.n, 60, 80, device=self.device)
-        A.check(self.lib.wl_visual_depth(C.byref(self.p), C.byref(self._bufs), C.byref(hf), float(max_depth),
-                                         out.data_ptr(), self._stream()), "wl_visual_depth")
-        torch.cuda.current_stream(self.device).synchronize()  # `ht` must outlive the launch
+        self.height = h if isinstance(h, torch.Tensor) and h.device == self.device and h.dtype == torch.float32 and h.is_contiguous() \
+            else torch.as_tensor(h, dtype=torch.float32).contiguous().to(self.device)
+        ny, nx = self.height.shape
+        self._hf = A.WlHeightField(self.height.data_ptr(), nx, ny, float(x0), float(y0), float(cell), float(outside_z))
+        n_f = int(self.lib.wl_heightfield_pyramid_floats(nx, ny))
+        if n_f <= 0:
+            raise A.WlError(f"heightfield of {nx} x {ny} points is outside the pyramid's range")
+        self.pyramid = torch.empty(n_f, dtype=torch.float32, device=self.device)
+        A.check(self.lib.wl_heightfield_build_pyramid(C.byref(self._hf), self.pyramid.data_ptr(), self._stream()),
+                "wl_heightfield_build_pyramid")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def render(self, batch, max_depth: float = 20.0, out: torch.Tensor | None = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(batch.n, self.IMG_H, self.IMG_W, dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == torch.float32 and out.numel() == batch.n * self.IMG_H * self.IMG_W
+        A.check(self.lib.wl_visual_depth(C.byref(self.p), C.byref(batch._bufs), C.byref(self._hf), self.pyramid.data_ptr(),
+                                         float(max_depth), out.data_ptr(), self._stream()), "wl_visual_depth")
         return out
+
+
+def _cached_depth_camera(batch, heightfield) -> DepthCamera:
+    """one DepthCamera per (batch, heightfield object): the pyramid is built on first use"""
+    cache = batch.__dict__.setdefault("_depth_cameras", {})
+    key = id(heightfield[0])
+    cam = cache.get(key)
+    if cam is None or cam._src is not heightfield[0]:
+        cam = DepthCamera(heightfield, batch.device, batch.p if isinstance(batch.p, A.WlVisualParams) else None)
+        cam._src = heightfield[0]    # keeps the key's object alive: an id is only unique among live objects
+        cache[key] = cam
+    return cam

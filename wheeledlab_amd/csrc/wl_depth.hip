@@ -1,0 +1,91 @@
+// wl_depth.hip -- depth ray-cast of the visual task's camera against a heightfield (BASELINE.json config 5) for gfx950.
+//
+// distance_to_image_plane per pixel of the 60 x 80 pinhole camera (visual/mushr_visual_env_cfg.py:230-246; what
+// mdp_sensors/observations.py:89-95 `camera_data_depth` / `raycast_depth` forward from IsaacLab's camera) against the
+// terrain SOLID of wl_heightfield.h: bilinear patches on a regular grid, the plane z = outside_z beyond it.  Spec:
+// oracle/depth.c (exact per-cell intersection in double, walking cell by cell).
+//
+// lane = ray.  A ray's ground track is walked through a MAX-PYRAMID of the field (level L cell = 2^L x 2^L grid cells,
+// value = highest corner inside): where the ray stays above a cell's maximum over the cell's whole parameter interval the
+// cell is skipped in one step and the walk climbs a level when it crosses into a new parent; otherwise it descends, and
+// at level 0 the patch along the ray is the quadratic g(s) = A s^2 + B s + C whose first root in the cell is the hit --
+// exact, no marching step.  Sky rays leave after ~log2(grid) steps, ground rays after a descent plus the few fine cells in
+// front of the hit; near-horizontal rays skimming the surface are the long ones (the pyramid cannot skip what the ray
+// nearly touches).
+//
+// Mapping: block = one 4-row strip of one env's image (4 x 80 pixels = 1280 contiguous output bytes), 5 wavefronts, each
+// a 4 x 16 pixel tile -- neighbouring pixels take nearly the same walk, so a wavefront's lanes stay together and its
+// gathers hit the same cache lines.  The field (2.56 MB) and the pyramid (levels >= 1: <= 0.85 MB touched) are L2-resident.
+// Output is the only HBM stream: 19 200 B per env.
+#include <hip/hip_runtime.h>
+
+#include "../../include/wheeledlab_amd.h"
+#include "wl_kernel_common.h"
+#include "wl_depth_dev.h"
+
+namespace {
+
+constexpr int kStripRows = 4, kStripThreads = kStripRows * WL_VIS_IMG_W;   // 320 threads = 5 wavefronts
+constexpr int kStrips = WL_VIS_IMG_H / kStripRows;
+constexpr int kTileCols = 16;
+static_assert(WL_VIS_IMG_H % kStripRows == 0 && WL_VIS_IMG_W % kTileCols == 0 && kStripRows * kTileCols == 64, "one wavefront per tile");
+
+__global__ void __launch_bounds__(kBlock) pyramid_level1_kernel(const WlHeightField f, float* __restrict__ mip, const int P) {
+    const int W = P >> 1;
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < W * W) mip[k] = pyramid_level1_value(f, k % W, k / W);
+}
+__global__ void __launch_bounds__(kBlock) pyramid_reduce_kernel(float* __restrict__ mip, const int P, const int L) {
+    const int W = P >> L;
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < W * W) mip[pyramid_offset(P, L) + k] = pyramid_reduce_value(mip, P, L, k % W, k / W);
+}
+
+__global__ void __launch_bounds__(kStripThreads) visual_depth_kernel(const WlVisualParams p, const WlEnvBuffers b, const HeightFieldGround g,
+                                                                     const Pyramid py, const float max_depth, float* __restrict__ depth) {
+    const int e = blockIdx.x / kStrips, strip = blockIdx.x - e * kStrips;
+    const Rows S = make_rows(b.state, b.stride);
+    const V3 pos = ld3(S, WL_S_PX, e);
+    const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+    const Mat3 R = mat_from_quat(q);
+    const V3 o = pos + mul(R, v3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = strip * kStripRows + (lane >> 4), col = wave * kTileCols + (lane & 15);
+    const V3 d = mul(R, depth_pixel_ray_body(p, row, col));
+    const float t = cast_ray(g, py, o, d, max_depth);
+    depth[(int64_t)e * (WL_VIS_IMG_H * WL_VIS_IMG_W) + row * WL_VIS_IMG_W + col] = t;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t wl_heightfield_pyramid_floats(int32_t nx, int32_t ny) {
+    if (nx < 2 || ny < 2 || nx > 16385 || ny > 16385) return 0;
+    const int P = pyramid_pow2(nx, ny);
+    return pyramid_offset(P, pyramid_levels(P)) + 1;
+}
+
+int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* stream) {
+    if (!hf || !hf->height || !pyramid || hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f)) return WL_EINVAL;
+    const int P = pyramid_pow2(hf->nx, hf->ny), lmax = pyramid_levels(P);
+    clear_error();
+    const hipStream_t hs = (hipStream_t)stream;
+    pyramid_level1_kernel<<<grid_for((P >> 1) * (P >> 1)), kBlock, 0, hs>>>(*hf, pyramid, P);
+    for (int L = 2; L <= lmax; ++L) pyramid_reduce_kernel<<<grid_for((P >> L) * (P >> L)), kBlock, 0, hs>>>(pyramid, P, L);
+    return launch_status();
+}
+
+int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
+                    float* depth, void* stream) {
+    if (!p || !b || !hf || !b->state || !hf->height || !pyramid || !depth || b->n_envs <= 0 || !(max_depth > 0.f)) return WL_EINVAL;
+    if (hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || b->stride < b->n_envs || !(p->fx > 0.f) || !(p->fy > 0.f)) return WL_EINVAL;
+    if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (int64_t)b->n_envs * kStrips > 0x7fffffffLL) return WL_EINVAL;
+    const int P = pyramid_pow2(hf->nx, hf->ny);
+    const Pyramid py{pyramid, P, pyramid_levels(P)};
+    clear_error();
+    visual_depth_kernel<<<b->n_envs * kStrips, kStripThreads, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), py, max_depth, depth);
+    return launch_status();
+}
+
+}  // extern "C"

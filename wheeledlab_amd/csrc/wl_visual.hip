@@ -14,7 +14,6 @@
 #include "wl_drift_terms.h"
 #include "wl_rng.h"
 #include "wl_vehicle.h"
-#include "wl_heightfield.h"
 
 namespace {
 
@@ -539,47 +538,6 @@ __global__ void __launch_bounds__(kBlock) visual_mdp_kernel(const WlVisualParams
     oom[e] = out_of_map(m, x, y) ? 1 : 0;
 }
 
-// depth extension: distance_to_image_plane of the camera against a heightfield (march 0.05 m steps along the optical
-// axis, then 6 bisection steps); rays that leave the grid hit the z = outside_z plane
-__global__ void __launch_bounds__(kBlock) visual_depth_kernel(const WlVisualParams p, const WlEnvBuffers b, const HeightFieldGround g,
-                                                              float max_depth, float* __restrict__ depth) {
-    const int e = blockIdx.x;
-    const Rows S = make_rows(b.state, b.stride);
-    const V3 pos = ld3(S, WL_S_PX, e);
-    const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
-    const Mat3 R = mat_from_quat(q);
-    const V3 o = pos + mul(R, v3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
-    for (int k = threadIdx.x; k < WL_VIS_IMG_H * WL_VIS_IMG_W; k += kBlock) {
-        const int r = k / WL_VIS_IMG_W, c = k - r * WL_VIS_IMG_W;
-        const V3 d = mul(R, pixel_ray_body(p, r, c));   // |d.x_body| = 1: the ray parameter IS the image-plane distance
-        float t0 = 0.f, t1 = 0.f, res = max_depth;
-        bool found = false;
-        for (float t = 0.05f; t <= max_depth; t += 0.05f) {
-            float z;
-            V3 n;
-            g.sample(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), z, n);
-            if (fmaf(t, d.z, o.z) <= z) {
-                t0 = t - 0.05f;
-                t1 = t;
-                found = true;
-                break;
-            }
-        }
-        if (found) {
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const float tm = 0.5f * (t0 + t1);
-                float z;
-                V3 n;
-                g.sample(fmaf(tm, d.x, o.x), fmaf(tm, d.y, o.y), z, n);
-                if (fmaf(tm, d.z, o.z) <= z) t1 = tm; else t0 = tm;
-            }
-            res = 0.5f * (t0 + t1);
-        }
-        depth[(int64_t)e * WL_VIS_IMG_H * WL_VIS_IMG_W + k] = res;
-    }
-}
-
 int check_visual(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m) {
     if (!p || !b || !m || !b->state || !b->episode_len || !b->metrics || !m->map || !m->cells) return WL_EINVAL;
     if (b->n_envs <= 0 || b->stride < b->n_envs || b->metrics_slots < 1 || m->n_cells <= 0) return WL_EINVAL;
@@ -681,14 +639,6 @@ int wl_visual_mdp(const WlVisualParams* p, const WlTravMap* m, int32_t n, int64_
     clear_error();
     visual_mdp_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(*p, *m, n, stride, pos, lin_vel_b, terms, out_of_map_,
                                                                         x_idx, y_idx);
-    return launch_status();
-}
-
-int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, float max_depth, float* depth,
-                    void* stream) {
-    if (!p || !b || !hf || !b->state || !hf->height || !depth || b->n_envs <= 0 || !(max_depth > 0.f)) return WL_EINVAL;
-    clear_error();
-    visual_depth_kernel<<<b->n_envs, kBlock, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), max_depth, depth);
     return launch_status();
 }
 

@@ -529,9 +529,13 @@ class ManagerBasedRLEnv:
             obs.copy_(torch.where(newly.unsqueeze(-1), b.observe().clone(), kept))   # fresh observation for those envs only
         done = ~live if newly is None else (~live | newly)
         cnt = done.sum().to(torch.float32)
-        self._custom_log = {}
+        prev, self._custom_log = self._custom_log, {}
         for name, acc in self._custom_epsum.items():
-            self._custom_log[f"Episode_Reward/{name}"] = (acc * done).sum() / cnt / self.max_episode_length_s
+            # IsaacLab refreshes these keys only inside _reset_idx: on a step where no episode ends the previous value stands
+            # (0 before the first one) -- never 0 / 0
+            key = f"Episode_Reward/{name}"
+            fresh = (acc * done).sum() / cnt.clamp_min(1.0) / self.max_episode_length_s
+            self._custom_log[key] = torch.where(cnt > 0, fresh, torch.as_tensor(prev.get(key, 0.0), dtype=fresh.dtype, device=fresh.device))
             acc *= ~done
         for name, flag in self._custom_flags.items():
             self._custom_log[f"Episode_Termination/{name}"] = flag.sum()

@@ -105,6 +105,11 @@ class ActorCritic:
             self._act_scratch = sc
         return sc[0]
 
+    # rows of the WHOLE batch when this view evaluates one env shard of it (world x local rows): the kernel form -- and with it
+    # the summation order and precision of layer 1 -- is chosen from this count, so that a shard reproduces its rows of the
+    # one-process batch (None: the local row count)
+    global_rows: int | None = None
+
     def act(self, obs: torch.Tensor, actions: torch.Tensor, mu: torch.Tensor, log_prob: torch.Tensor, values: torch.Tensor,
             seed: int, step: int, env_offset: int = 0, deterministic: bool = False, nets: int = 3, planes_fresh: bool = False):
         """One policy step for observations of ANY width (wl_actor_critic_act: one launch, f32 matrix pipe; or, for large
@@ -125,15 +130,17 @@ class ActorCritic:
             self._act_scratch = None
         a, c = self._act_structs
         stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
-        form = self.planes_form(n, D)
+        form = self.planes_form(max(n, self.global_rows or 0), D)
         if self.planes if self.planes is not None else form is not None:
             two = self.planes_two_launch if self.planes_two_launch is not None else form != "one"
             lib = A.load()
-            new = getattr(self, "_act_scratch", None) is None
             sc = self._scratch(n)
             sc.reserved = int(two)
-            if new or not planes_fresh:
+            # the planes live in the scratch: a caller's "fresh" only holds for the scratch object they were last built into
+            # (a larger batch on the same view reallocates it -- zero-filled planes would make layer 1 bias-only)
+            if not planes_fresh or getattr(self, "_planes_built_for", None) is not sc:
                 A.check(lib.wl_actor_critic_planes(C.byref(a), C.byref(c), C.byref(sc), stream), "wl_actor_critic_planes")
+                self._planes_built_for = sc
             A.check(lib.wl_actor_critic_act_planes(C.byref(a), C.byref(c), self.std.data_ptr(), n, obs.data_ptr(), obs.stride(0),
                                                    ptr(actions), ptr(mu), ptr(log_prob), ptr(values), int(env_offset), int(seed),
                                                    int(step), int(bool(deterministic)), int(nets), C.byref(sc), stream),

@@ -339,6 +339,8 @@ class OnPolicyRunner:
         # and the critic's value straight into the storage rows
         one_launch = self.kernel_policy
         view = ac.fused() if one_launch else None
+        if view is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            view.global_rows = st.n_envs * torch.distributed.get_world_size()   # kernel form as for the one-process batch
         base = self.env.unwrapped
         batch = getattr(base, "_batch", None)
         if one_launch and hasattr(base, "can_collect_rollout") and base.can_collect_rollout():
