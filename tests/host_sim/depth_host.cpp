@@ -13,22 +13,25 @@ using std::min;
 extern "C" {
 // pos [n][3], quat [n][4]; depth [n][60][80]; steps (optional) [n][60][80]: unused, reserved
 int hs_depth(const WlVisualParams* p, const WlHeightField* hf, int n, const float* pos, const float* quat, float max_depth, float* depth) {
-    const int P = pyramid_pow2(hf->nx, hf->ny), lmax = pyramid_levels(P);
-    std::vector<float> mip((size_t)pyramid_offset(P, lmax) + 1);
+    const Pyramid py = make_pyramid(hf->nx, hf->ny);
+    const int P = 1 << py.lp;
+    std::vector<float> buf((size_t)pyramid_total_floats(hf->nx, hf->ny), -INFINITY);
     for (int J = 0; J < (P >> 1); ++J)
-        for (int I = 0; I < (P >> 1); ++I) mip[(size_t)J * (P >> 1) + I] = pyramid_level1_value(*hf, I, J);
-    for (int L = 2; L <= lmax; ++L)
+        for (int I = 0; I < (P >> 1); ++I) buf[(size_t)pyramid_level_offset(py.lp, 1) + (size_t)J * (P >> 1) + I] = pyramid_level1_value(*hf, I, J);
+    for (int L = 2; L <= py.lp; ++L)
         for (int J = 0; J < (P >> L); ++J)
-            for (int I = 0; I < (P >> L); ++I) mip[(size_t)pyramid_offset(P, L) + (size_t)J * (P >> L) + I] = pyramid_reduce_value(mip.data(), P, L, I, J);
-    const Pyramid py{mip.data(), P, lmax};
-    const HeightFieldGround g = make_ground(hf);
+            for (int I = 0; I < (P >> L); ++I)
+                buf[(size_t)pyramid_level_offset(py.lp, L) + (size_t)J * (P >> L) + I] = pyramid_reduce_value(buf.data(), py.lp, L, I, J);
+    std::copy(hf->height, hf->height + (size_t)hf->nx * hf->ny, buf.begin() + py.h0);
+    const DepthGrid g = make_depth_grid(hf);
+    const FieldMem mem{buf.data()};
     for (int e = 0; e < n; ++e) {
         const Quat q{quat[4 * e], quat[4 * e + 1], quat[4 * e + 2], quat[4 * e + 3]};
         const Mat3 R = mat_from_quat(q);
         const V3 o = v3(pos[3 * e], pos[3 * e + 1], pos[3 * e + 2]) + mul(R, v3(p->cam_pos[0], p->cam_pos[1], p->cam_pos[2]));
         for (int r = 0; r < WL_VIS_IMG_H; ++r)
             for (int c = 0; c < WL_VIS_IMG_W; ++c)
-                depth[((size_t)e * WL_VIS_IMG_H + r) * WL_VIS_IMG_W + c] = cast_ray(g, py, o, mul(R, depth_pixel_ray_body(*p, r, c)), max_depth);
+                depth[((size_t)e * WL_VIS_IMG_H + r) * WL_VIS_IMG_W + c] = cast_ray(g, py, mem, o, mul(R, depth_pixel_ray_body(*p, r, c)), max_depth);
     }
     return 0;
 }

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstring>
 
+#define WL_HOST_SIM 1
 #define __device__
 #define __host__
 #define __forceinline__ inline

@@ -44,21 +44,18 @@ def test_pyramid_levels_are_the_block_maxima(hf):
         while Pw < nx - 1 or Pw < ny - 1:
             Pw *= 2
         pyr = cam.pyramid.cpu().numpy()
-        L, off = 1, 0
-        while (Pw >> L) >= 1:
-            W = Pw >> L
+        lp = int(np.log2(Pw))
+        assert len(pyr) == Pw * Pw // 2 + nx * ny
+        np.testing.assert_array_equal(pyr[Pw * Pw // 2:].reshape(ny, nx), h)       # the walk's copy of the heights
+        for L in range(1, lp + 1):
+            W, s = Pw >> L, 1 << L
+            off = (Pw * Pw) >> (2 * L)
             got = pyr[off: off + W * W].reshape(W, W)
-            s = 1 << L
             want = np.full((W, W), -np.inf, np.float32)
             for J in range(min(W, (ny - 1 + s - 1) // s)):
                 for I in range(min(W, (nx - 1 + s - 1) // s)):
                     want[J, I] = h[J * s: min((J + 1) * s, ny - 1) + 1, I * s: min((I + 1) * s, nx - 1) + 1].max()
             np.testing.assert_array_equal(got, want, err_msg=f"level {L}")
-            off += W * W
-            if W == 1:
-                break
-            L += 1
-        assert off == len(pyr)
 
 
 @pytest.mark.parametrize("max_depth", [100.0, 20.0])
@@ -139,6 +136,6 @@ def test_invalid_arguments_are_refused(hf):
     assert lib.wl_visual_depth(*args(md=0.0)) == -1
     bad_hf = A.WlHeightField(cam._hf.height, 1, 800, 0.0, 0.0, 0.05, 0.0)
     assert lib.wl_visual_depth(*args(hf=bad_hf)) == -1
-    assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == (1024 * 1024 - 1) // 3
+    assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800
     assert lib.wl_heightfield_build_pyramid(C.byref(bad_hf), cam.pyramid.data_ptr(), None) == -1
     torch.cuda.synchronize()

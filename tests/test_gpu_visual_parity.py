@@ -257,7 +257,9 @@ def test_settled_cars_need_no_contact_excuse(trav, lanes):
     for k in range(24):
         st = env.state.cpu().numpy().copy()
         ep = env.episode_len.cpu().numpy().copy()
-        a = rng.uniform(-1.2, 1.2, (n, 2)).astype(np.float32)
+        # moderate driving: at ground friction 2.0 full-lock turns at full throttle lift the inner wheels -- a contact break of
+        # its own, which the other test covers
+        a = np.stack([rng.uniform(-0.2, 0.7, n), rng.uniform(-0.5, 0.5, n)], -1).astype(np.float32)
         obs, rew, term, trunc = env.step(torch.from_numpy(a).to(DEV))
         torch.cuda.synchronize()
         o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, trav, cells, a, 8, 6 + k)

@@ -30,19 +30,24 @@ constexpr int kStrips = WL_VIS_IMG_H / kStripRows;
 constexpr int kTileCols = 16;
 static_assert(WL_VIS_IMG_H % kStripRows == 0 && WL_VIS_IMG_W % kTileCols == 0 && kStripRows * kTileCols == 64, "one wavefront per tile");
 
-__global__ void __launch_bounds__(kBlock) pyramid_level1_kernel(const WlHeightField f, float* __restrict__ mip, const int P) {
-    const int W = P >> 1;
+__global__ void __launch_bounds__(kBlock) pyramid_level1_kernel(const WlHeightField f, float* __restrict__ buf, const int lp) {
+    const int W = (1 << lp) >> 1;
     const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k < W * W) mip[k] = pyramid_level1_value(f, k % W, k / W);
+    if (k < W * W) buf[pyramid_level_offset(lp, 1) + k] = pyramid_level1_value(f, k % W, k / W);
 }
-__global__ void __launch_bounds__(kBlock) pyramid_reduce_kernel(float* __restrict__ mip, const int P, const int L) {
-    const int W = P >> L;
+__global__ void __launch_bounds__(kBlock) pyramid_reduce_kernel(float* __restrict__ buf, const int lp, const int L) {
+    const int W = (1 << lp) >> L;
     const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k < W * W) mip[pyramid_offset(P, L) + k] = pyramid_reduce_value(mip, P, L, k % W, k / W);
+    if (k < W * W) buf[pyramid_level_offset(lp, L) + k] = pyramid_reduce_value(buf, lp, L, k % W, k / W);
+}
+__global__ void __launch_bounds__(kBlock) pyramid_copy_heights_kernel(const float* __restrict__ h, float* __restrict__ dst, const int n) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < n) dst[k] = h[k];
 }
 
-__global__ void __launch_bounds__(kStripThreads) visual_depth_kernel(const WlVisualParams p, const WlEnvBuffers b, const HeightFieldGround g,
-                                                                     const Pyramid py, const float max_depth, float* __restrict__ depth) {
+__global__ void __launch_bounds__(kStripThreads) visual_depth_kernel(const WlVisualParams p, const WlEnvBuffers b, const DepthGrid g,
+                                                                     const Pyramid py, const float* __restrict__ buf, const unsigned buf_bytes,
+                                                                     const float max_depth, float* __restrict__ depth) {
     const int e = blockIdx.x / kStrips, strip = blockIdx.x - e * kStrips;
     const Rows S = make_rows(b.state, b.stride);
     const V3 pos = ld3(S, WL_S_PX, e);
@@ -52,7 +57,8 @@ __global__ void __launch_bounds__(kStripThreads) visual_depth_kernel(const WlVis
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = strip * kStripRows + (lane >> 4), col = wave * kTileCols + (lane & 15);
     const V3 d = mul(R, depth_pixel_ray_body(p, row, col));
-    const float t = cast_ray(g, py, o, d, max_depth);
+    const FieldMem mem{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(buf), 0, (int)buf_bytes, 0x00020000)};
+    const float t = cast_ray(g, py, mem, o, d, max_depth);
     depth[(int64_t)e * (WL_VIS_IMG_H * WL_VIS_IMG_W) + row * WL_VIS_IMG_W + col] = t;
 }
 
@@ -62,29 +68,33 @@ extern "C" {
 
 int64_t wl_heightfield_pyramid_floats(int32_t nx, int32_t ny) {
     if (nx < 2 || ny < 2 || nx > 16385 || ny > 16385) return 0;
-    const int P = pyramid_pow2(nx, ny);
-    return pyramid_offset(P, pyramid_levels(P)) + 1;
+    return pyramid_total_floats(nx, ny);
 }
 
 int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* stream) {
     if (!hf || !hf->height || !pyramid || hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f)) return WL_EINVAL;
-    const int P = pyramid_pow2(hf->nx, hf->ny), lmax = pyramid_levels(P);
+    const Pyramid py = make_pyramid(hf->nx, hf->ny);
     clear_error();
     const hipStream_t hs = (hipStream_t)stream;
-    pyramid_level1_kernel<<<grid_for((P >> 1) * (P >> 1)), kBlock, 0, hs>>>(*hf, pyramid, P);
-    for (int L = 2; L <= lmax; ++L) pyramid_reduce_kernel<<<grid_for((P >> L) * (P >> L)), kBlock, 0, hs>>>(pyramid, P, L);
+    const int P = 1 << py.lp;
+    pyramid_level1_kernel<<<grid_for((P >> 1) * (P >> 1)), kBlock, 0, hs>>>(*hf, pyramid, py.lp);
+    for (int L = 2; L <= py.lp; ++L) pyramid_reduce_kernel<<<grid_for((P >> L) * (P >> L)), kBlock, 0, hs>>>(pyramid, py.lp, L);
+    pyramid_copy_heights_kernel<<<grid_for(hf->nx * hf->ny), kBlock, 0, hs>>>(hf->height, pyramid + py.h0, hf->nx * hf->ny);
     return launch_status();
 }
 
 int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
                     float* depth, void* stream) {
     if (!p || !b || !hf || !b->state || !hf->height || !pyramid || !depth || b->n_envs <= 0 || !(max_depth > 0.f)) return WL_EINVAL;
-    if (hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || b->stride < b->n_envs || !(p->fx > 0.f) || !(p->fy > 0.f)) return WL_EINVAL;
+    if (hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || b->stride < b->n_envs || !(p->fx > 0.f) ||
+        !(p->fy > 0.f))
+        return WL_EINVAL;
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (int64_t)b->n_envs * kStrips > 0x7fffffffLL) return WL_EINVAL;
-    const int P = pyramid_pow2(hf->nx, hf->ny);
-    const Pyramid py{pyramid, P, pyramid_levels(P)};
+    const Pyramid py = make_pyramid(hf->nx, hf->ny);
+    const unsigned bytes = (unsigned)(pyramid_total_floats(hf->nx, hf->ny) * 4);
     clear_error();
-    visual_depth_kernel<<<b->n_envs * kStrips, kStripThreads, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), py, max_depth, depth);
+    visual_depth_kernel<<<b->n_envs * kStrips, kStripThreads, 0, (hipStream_t)stream>>>(*p, *b, make_depth_grid(hf), py, pyramid, bytes,
+                                                                                        max_depth, depth);
     return launch_status();
 }
 

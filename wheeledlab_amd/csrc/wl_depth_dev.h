@@ -2,33 +2,32 @@
 // A header of its own so that tests/host_sim can compile the walk for the host and hold it against oracle/depth.c.
 #pragma once
 #include "../../include/wheeledlab_amd.h"
-#include "wl_heightfield.h"
 #include "wl_math.h"
 
 namespace {
 
-// Max-pyramid layout: level L (1 <= L <= lmax) is a (P >> L) x (P >> L) array, P = the power of two >= the cell count of the
-// longer side; levels are stored back to back, so level L starts at (P^2 - (P >> (L - 1))^2) / 3 floats.  Entries
-// that cover no cell hold -inf.  Level 0 is not stored: a cell's maximum is the largest of the four corners the
-// intersection needs anyway.
+// ONE device buffer holds everything the walk gathers, so that every access is a 32-bit offset from one base:
+//   floats [PP >> 2L, 2 (PP >> 2L))  level L of the max-pyramid, 1 <= L <= lp: a (P >> L) x (P >> L) array (P = 2^lp = the
+//                                    power of two >= the cell count of the longer side, PP = P^2); entry (J, I) = the highest
+//                                    grid corner inside the 2^L x 2^L block of cells (J, I); blocks that cover no cell: -inf
+//   floats [PP / 2, PP / 2 + ny nx)  a copy of the heights [ny][nx] (level 0 is not stored: a cell's maximum is the largest
+//                                    of the four corners the intersection needs anyway)
+// The level offsets are shifts (no table, no division); the price is PP / 6 floats of padding.
 struct Pyramid {
-    const float* mip;
-    int P, lmax;
+    int lp;        // log2 P = the top level (one entry)
+    int h0;        // float offset of the height copy = PP / 2
 };
-__host__ __device__ inline int pyramid_offset(int P, int L) {   // P <= 16 384: 32-bit arithmetic (a division by 3 per walk step)
-    const unsigned a = (unsigned)P * (unsigned)P, q = (unsigned)(P >> (L - 1));
-    return (int)((a - q * q) / 3u);
+inline int pyramid_log2(int nx, int ny) {
+    int lp = 1;
+    while ((1 << lp) < nx - 1 || (1 << lp) < ny - 1) ++lp;
+    return lp;
 }
-inline int pyramid_pow2(int nx, int ny) {
-    int P = 2;
-    while (P < nx - 1 || P < ny - 1) P <<= 1;
-    return P;
+__host__ __device__ inline int pyramid_level_offset(int lp, int L) { return (1 << (2 * lp)) >> (2 * L); }
+inline Pyramid make_pyramid(int nx, int ny) {
+    const int lp = pyramid_log2(nx, ny);
+    return Pyramid{lp, (1 << (2 * lp)) >> 1};
 }
-inline int pyramid_levels(int P) {
-    int l = 0;
-    while ((P >> l) > 1) ++l;
-    return l;
-}
+inline int64_t pyramid_total_floats(int nx, int ny) { return (int64_t)make_pyramid(nx, ny).h0 + (int64_t)nx * ny; }
 
 // level 1 from the heights: cell (I, J) covers grid cells (2I .. 2I+1, 2J .. 2J+1), i.e. corners (2I .. 2I+2, 2J .. 2J+2)
 WL_DEV float pyramid_level1_value(const WlHeightField& f, int I, int J) {
@@ -41,11 +40,30 @@ WL_DEV float pyramid_level1_value(const WlHeightField& f, int I, int J) {
     return m;
 }
 // level L >= 2 from level L - 1
-WL_DEV float pyramid_reduce_value(const float* mip, int P, int L, int I, int J) {
-    const int W = P >> L;
-    const float* src = mip + pyramid_offset(P, L - 1) + (2 * J) * (2 * W) + 2 * I;
+WL_DEV float pyramid_reduce_value(const float* buf, int lp, int L, int I, int J) {
+    const int W = (1 << lp) >> L;
+    const float* src = buf + pyramid_level_offset(lp, L - 1) + (2 * J) * (2 * W) + 2 * I;
     return fmaxf(fmaxf(src[0], src[1]), fmaxf(src[2 * W], src[2 * W + 1]));
 }
+
+// the walk's view of that buffer: 4- and 8-byte gathers at float offsets
+struct FieldMem {
+#ifdef WL_HOST_SIM
+    const float* base;
+    WL_DEV float ld(int idx) const { return base[idx]; }
+    WL_DEV void ld2(int idx, float& a, float& b) const { a = base[idx], b = base[idx + 1]; }
+#else
+    __amdgpu_buffer_rsrc_t rsrc;   // buffer loads: ONE 32-bit VGPR offset per gather, no 64-bit address arithmetic
+    WL_DEV float ld(int idx) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, idx * 4, 0, 0)); }
+    WL_DEV void ld2(int idx, float& a, float& b) const {
+        // 4-byte aligned is enough.  The WHOLE result is bit-cast: indexing the builtin's own return type (v[0], v[1]) is folded
+        // to element 0 twice by this compiler (ROCm 7.2 clang, -O3: the load is narrowed to one dword).
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, idx * 4, 0, 0));
+        a = v.x, b = v.y;
+    }
+#endif
+};
 
 // first t in [ta, tb] at which the ray is on or below the plane z = zp; < 0: none
 WL_DEV float plane_hit(float oz, float dz, float zp, float ta, float tb) {
@@ -59,17 +77,30 @@ WL_DEV float plane_hit(float oz, float dz, float zp, float ta, float tb) {
 }
 
 #ifndef WL_DEPTH_START_LEVEL
-#define WL_DEPTH_START_LEVEL 2
+#define WL_DEPTH_START_LEVEL 4
 #endif
 constexpr int kMaxWalk = 8192;   // safety bound on walk steps (a ray crosses < 2 * 1024 cells; each costs <= 3 visits)
 
-WL_DEV float cast_ray(const HeightFieldGround& g, const Pyramid& py, const V3 o, const V3 d, const float tmax) {
-    const WlHeightField& f = g.f;
-    const int NX = f.nx - 1, NY = f.ny - 1;   // cells
-    const float ou = (o.x - f.x0) * g.inv_cell, ov = (o.y - f.y0) * g.inv_cell;
+// the grid the walk runs on: cells, not metres (u = (x - x0) / cell, integer cell lines)
+struct DepthGrid {
+    int nx, NX, NY;            // row pitch of the heights; cells per side
+    float x0, y0, inv_cell, outside_z;
+};
+inline DepthGrid make_depth_grid(const WlHeightField* hf) {
+    return DepthGrid{hf->nx, hf->nx - 1, hf->ny - 1, hf->x0, hf->y0, 1.f / hf->cell, hf->outside_z};
+}
+
+// Distance along the optical axis (|d_body.x| = 1) to the first point of the ray o + t d on or below the terrain solid,
+// clipped at tmax.  Spec: oracle/depth.c::cast_ray.
+WL_DEV float cast_ray(const DepthGrid& g, const Pyramid& py, const FieldMem& mem, const V3 o, const V3 d, const float tmax) {
+    const int NX = g.NX, NY = g.NY;
+    const float ou = (o.x - g.x0) * g.inv_cell, ov = (o.y - g.y0) * g.inv_cell;
     const float du = d.x * g.inv_cell, dv = d.y * g.inv_cell;
     const float oz = o.z, dz = d.z;
-    const float idu = du != 0.f ? 1.f / du : 0.f, idv = dv != 0.f ? 1.f / dv : 0.f;
+    // a direction component of exactly zero never reaches a cell line: the huge reciprocal with `up` set sends that line's
+    // parameter to +1e30 (the line above the entry cell is strictly above the entry point)
+    const bool up_u = du >= 0.f, up_v = dv >= 0.f;
+    const float idu = du != 0.f ? rcp(du) : 1e30f, idv = dv != 0.f ? rcp(dv) : 1e30f;
     // parameter interval of the ground track inside the grid domain [0, NX] x [0, NY]
     float t_in = -INFINITY, t_out = INFINITY;
     if (du != 0.f) {
@@ -87,11 +118,11 @@ WL_DEV float cast_ray(const HeightFieldGround& g, const Pyramid& py, const V3 o,
         t_in = INFINITY;
     }
     if (!(t_in <= t_out) || t_out < 0.f || t_in > tmax) {   // never over the grid within range
-        const float t = plane_hit(oz, dz, f.outside_z, 0.f, tmax);
+        const float t = plane_hit(oz, dz, g.outside_z, 0.f, tmax);
         return t >= 0.f ? t : tmax;
     }
     if (t_in > 0.f) {
-        const float t = plane_hit(oz, dz, f.outside_z, 0.f, t_in);
+        const float t = plane_hit(oz, dz, g.outside_z, 0.f, t_in);
         if (t >= 0.f) return t;
     } else {
         t_in = 0.f;
@@ -107,78 +138,73 @@ WL_DEV float cast_ray(const HeightFieldGround& g, const Pyramid& py, const V3 o,
         i = min(max(i, 0), NX - 1);
         j = min(max(j, 0), NY - 1);
     }
-    const bool up_u = du > 0.f, up_v = dv > 0.f;
-    int L = min(WL_DEPTH_START_LEVEL, py.lmax);
+    const int su = up_u ? 1 : 0, sv = up_v ? 1 : 0;
+    int L = min(WL_DEPTH_START_LEVEL, py.lp);
     float res = -1.f;
 #pragma unroll 1
     for (int it = 0; it < kMaxWalk; ++it) {
+        // the level-L cell of (i, j), the parameter at which the ray leaves it, the ray's lowest point inside it
         const int iL = i >> L, jL = j >> L;
-        const int bx = up_u ? (iL + 1) << L : iL << L, by = up_v ? (jL + 1) << L : jL << L;
-        const float tx = du != 0.f ? ((float)bx - ou) * idu : INFINITY;
-        const float ty = dv != 0.f ? ((float)by - ov) * idv : INFINITY;
+        const int bx = (iL + su) << L, by = (jL + sv) << L;
+        const float tx = ((float)bx - ou) * idu, ty = ((float)by - ov) * idv;
         const float te = fmaxf(fminf(fminf(tx, ty), t_stop), t);
         const float z_t = fmaf(t, dz, oz);
         const float zmin = dz < 0.f ? fmaf(te, dz, oz) : z_t;
-        bool advance;
-        if (L > 0) {
-            const float m = py.mip[pyramid_offset(py.P, L) + jL * (py.P >> L) + iL];
-            advance = zmin > m + 1e-6f;
-            if (!advance) {
+        const bool fine = L == 0;
+        float h00, h10, h01, h11, m;
+        if (fine) {
+            const int k = py.h0 + j * g.nx + i;
+            mem.ld2(k, h00, h10);
+            mem.ld2(k + g.nx, h01, h11);
+            m = fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
+        } else {
+            m = mem.ld(pyramid_level_offset(py.lp, L) + (jL << (py.lp - L)) + iL);
+        }
+        if (!(zmin > m + 1e-6f)) {      // the ray may touch something in this cell
+            if (!fine) {
                 --L;
                 continue;
             }
-        } else {
-            const float* r0 = f.height + (int64_t)j * f.nx + i;
-            const wl_float2_u lo = *reinterpret_cast<const wl_float2_u*>(r0);
-            const wl_float2_u hi = *reinterpret_cast<const wl_float2_u*>(r0 + f.nx);
-            const float m = fmaxf(fmaxf(lo.x, lo.y), fmaxf(hi.x, hi.y));
-            if (!(zmin > m + 1e-6f)) {
-                const float hx = lo.y - lo.x, hy = hi.x - lo.x, hxy = (hi.y - lo.y) - hy;
-                const float fu = clampf(fmaf(t, du, ou) - (float)i, 0.f, 1.f), fv = clampf(fmaf(t, dv, ov) - (float)j, 0.f, 1.f);
-                const float C = z_t - fmaf(fu * fv, hxy, fmaf(fv, hy, fmaf(fu, hx, lo.x)));
-                if (C <= 0.f) {
-                    res = t;
+            const float hx = h10 - h00, hy = h01 - h00, hxy = (h11 - h10) - hy;
+            const float fu = clampf(fmaf(t, du, ou) - (float)i, 0.f, 1.f), fv = clampf(fmaf(t, dv, ov) - (float)j, 0.f, 1.f);
+            const float C = z_t - fmaf(fu * fv, hxy, fmaf(fv, hy, fmaf(fu, hx, h00)));
+            if (C <= 0.f) {
+                res = t;
+                break;
+            }
+            const float A = -du * dv * hxy;
+            const float B = dz - fmaf(fmaf(fu, dv, fv * du), hxy, fmaf(dv, hy, du * hx));
+            const float disc = fmaf(B, B, -4.f * A * C);
+            if (disc >= 0.f) {
+                const float q = -0.5f * (B + copysignf(fsqrt(disc), B));
+                const float r1 = q * rcp(A), r2 = C * rcp(q);   // A == 0 / q == 0: inf or NaN, neither passes the tests below
+                float s = INFINITY;
+                if (r1 > 0.f && r1 < s) s = r1;
+                if (r2 > 0.f && r2 < s) s = r2;
+                if (s <= te - t) {
+                    res = t + s;
                     break;
                 }
-                const float A = -du * dv * hxy;
-                const float B = dz - fmaf(fmaf(fu, dv, fv * du), hxy, fmaf(dv, hy, du * hx));
-                const float disc = fmaf(B, B, -4.f * A * C);
-                if (disc >= 0.f) {
-                    const float sq = fsqrt(disc);
-                    const float q = -0.5f * (B + copysignf(sq, B));
-                    float s = INFINITY;
-                    const float r1 = q / A, r2 = C / q;   // A == 0 / q == 0: inf or NaN, neither passes the tests below
-                    if (r1 > 0.f && r1 < s) s = r1;
-                    if (r2 > 0.f && r2 < s) s = r2;
-                    if (s <= te - t) {
-                        res = t + s;
-                        break;
-                    }
-                }
             }
-            advance = true;
         }
-        // leave the level-L cell through its nearer boundary
+        // leave the level-L cell through its nearer line; climb when that line is also the parent's
         if (te >= t_stop) break;
         t = te;
-        const int lo_i = iL << L, lo_j = jL << L, span = (1 << L) - 1;
-        bool new_parent;
-        if (tx <= ty) {
-            i = up_u ? bx : bx - 1;
-            j = min(max((int)floorf(fmaf(t, dv, ov)), lo_j), min(lo_j + span, NY - 1));
-            new_parent = (i >> (L + 1)) != (iL >> 1);
-            if (i < 0 || i >= NX) break;
-        } else {
-            j = up_v ? by : by - 1;
-            i = min(max((int)floorf(fmaf(t, du, ou)), lo_i), min(lo_i + span, NX - 1));
-            new_parent = (j >> (L + 1)) != (jL >> 1);
-            if (j < 0 || j >= NY) break;
-        }
-        if (new_parent && L < py.lmax) ++L;
+        const bool exit_x = tx <= ty;
+        // the coordinate ALONG the line crossed, recomputed from t and kept inside the cell just left (rounding must not move it
+        // to a cell the ray has not reached); the coordinate ACROSS it steps by one cell of level L
+        const float w = floorf(fmaf(t, exit_x ? dv : du, exit_x ? ov : ou));
+        const int lo = (exit_x ? jL : iL) << L;
+        const int c = min(max((int)w, lo), min(lo + (1 << L) - 1, (exit_x ? NY : NX) - 1));
+        i = exit_x ? bx + su - 1 : c;
+        j = exit_x ? c : by + sv - 1;
+        if ((unsigned)i >= (unsigned)NX || (unsigned)j >= (unsigned)NY) break;
+        const int edge = exit_x ? iL ^ su : jL ^ sv;    // moving up out of an odd cell / down out of an even one: a new parent
+        L += ((edge & 1) == 0 && L < py.lp) ? 1 : 0;
     }
     if (res >= 0.f) return fminf(res, tmax);
     if (t_out < tmax) {
-        const float th = plane_hit(oz, dz, f.outside_z, t_out, tmax);
+        const float th = plane_hit(oz, dz, g.outside_z, t_out, tmax);
         if (th >= 0.f) return th;
     }
     return tmax;
