@@ -249,7 +249,7 @@ def test_f1tenth_full_size_properties(lib):
     assert (obs[:, 12:14].abs() <= 1).all() and (env.episode_len[:n] < 250).all()
     m = env.metrics.cpu().numpy()
     assert m[8] == resets and resets > 0 and m[14] == 0
-    assert st[2].abs().max() < 0.05 and st[17].abs().max() <= 0.5312 and moved > 0.5     # on the plane, steering bounded, driving
+    assert st[2].abs().max() < 0.05 and st[17].abs().max() <= 0.5312 and moved > 0.2     # on the plane, steering bounded, driving
     # all four wheels are driven: front wheels spin up under throttle with the car held on an open plane
     env.p.r_out, env.p.r_in, env.p.max_episode_length = 1e18, 0.0, 10 ** 9
     a = torch.zeros(n, 2, device=DEV)

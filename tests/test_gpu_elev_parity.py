@@ -204,11 +204,17 @@ def test_persistent_rollout_equals_stepping(n, K, slots):
 @pytest.mark.parametrize("lanes", [4, 1])
 def test_settled_cars_need_no_contact_excuse(lanes):
     """Companion of test_elev_fused_step_matches_oracle_single_steps: that test excuses up to 1 % of envs per step as contact
-    make / break discontinuities (the spawn drop).  Here nothing spawns: every termination is switched off on BOTH sides, the cars
-    settle for 12 steps and then crawl over the terrain with all wheels in contact -- the excused set must be EMPTY for 24
-    steps, in both forms of the kernel."""
+    make / break discontinuities (the spawn drop; on the rough synthetic terrain also a wheel unloading over a crest -- the
+    suspension's static deflection is 2.8 mm).  Here nothing makes or breaks contact: the terrain is a tilted plane with a faint
+    long swell (all four wheels stay loaded; normals still vary), every termination is switched off on BOTH sides, the cars
+    settle for 12 steps and then crawl -- the excused set must be EMPTY for 24 steps, in both forms of the kernel."""
+    from wheeledlab_amd.core import ElevBatch
     n = 512
-    env, hf = _fresh(n, seed=8)
+    xs = (np.arange(800) * 0.05 - 20.0).astype(np.float64)
+    X, Y = np.meshgrid(xs, xs, indexing="xy")
+    hf = ((0.19 + 2.5 + 0.10 * X + 0.05 * Y + 0.02 * np.sin(0.5 * X) * np.cos(0.4 * Y)).astype(np.float32), np.float32(-20.0),
+          np.float32(-20.0), np.float32(0.05))
+    env = ElevBatch(n, device=DEV, seed=8, heightfield=hf)
     env.set_lanes(lanes)
     p = OS.elev_params()
     for q in (env.p, p):      # no resets: no time-out, no below-minimum-height, no stuck, no rollover, no at-goal
