@@ -585,7 +585,13 @@ typedef struct WlTravMap {
     const int32_t* cells;      /* [n_cells][2] = (iy, ix) */
     int32_t rows, cols, n_cells;
     float row_spacing, col_spacing;
+    /* optional: the same map one BIT per cell, bit (k & 31) of word (k >> 5) for k = iy * cols + ix, ceil(rows * cols / 32)
+       words (+ 0 padding bits).  With it (and rows * cols <= WL_VIS_LDS_MAP_CELLS) the camera kernels keep the whole map in
+       LDS -- 31 KB for the reference's 500 x 500 map -- and a pixel's lookup is an LDS read instead of a byte gather (the
+       camera was bound by the texture addresser: one divergent gather per pixel).  NULL: byte gathers from `map`. */
+    const uint32_t* bits;
 } WlTravMap;
+#define WL_VIS_LDS_MAP_CELLS (512 * 512)
 
 typedef struct WlVisualParams {
     float sim_dt;              /* 0.02 (:435)                                                                */

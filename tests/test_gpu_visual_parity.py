@@ -271,3 +271,42 @@ def test_settled_cars_need_no_contact_excuse(trav, lanes):
         cell_flip = np.abs(rew.cpu().numpy() - o_rew) > 0.5    # +-1 traversability flips exactly on a cell edge
         assert cell_flip.sum() <= 1
         np.testing.assert_allclose(rew.cpu().numpy()[~cell_flip], o_rew[~cell_flip], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("aug", [(1.0, 1.0, 0.0), (1.3, 0.9, 1.2)])
+def test_lds_bit_map_camera_equals_the_byte_gather_camera(trav, aug):
+    """the camera with the whole traversability map in LDS as one bit per cell (WlTravMap.bits; three images per block) against
+    the camera that gathers bytes from the global map: every observation row bit for bit, at env counts that leave the last
+    block partly filled, through observe(), step() and the persistent rollout; a map too large for LDS takes the byte path"""
+    from wheeledlab_amd.core import VisualBatch
+    for n in (1, 64, 1000, 4097):
+        ea, eb = _batch(n, trav, seed=4), _batch(n, trav, seed=4)
+        eb._map.bits = None                              # byte gathers
+        for e in (ea, eb):
+            e.p.brightness, e.p.contrast, e.p.blur_sigma = aug
+        assert torch.equal(ea.observe(), eb.observe())
+        g = torch.Generator(device=DEV).manual_seed(0)
+        for k in range(3):
+            a = torch.rand(n, 2, device=DEV, generator=g) * 2 - 1
+            oa, ob = ea.step(a), eb.step(a)
+            assert all(torch.equal(x, y) for x, y in zip(oa, ob)), (n, k)
+    K, n = 4, 512
+    ea, eb = _batch(n, trav, seed=6), _batch(n, trav, seed=6)
+    eb._map.bits = None
+    a = torch.rand(K, n, 2, device=DEV) * 2 - 1
+    outs = []
+    for e in (ea, eb):
+        e.p.brightness, e.p.contrast, e.p.blur_sigma = aug
+        o = (torch.zeros(K, n, e.OBS_DIM, device=DEV), torch.zeros(K, n, device=DEV), torch.zeros(K, n, dtype=torch.bool, device=DEV),
+             torch.zeros(K, n, dtype=torch.bool, device=DEV))
+        e.rollout(a, *o, persistent=True)
+        outs.append(o)
+    assert all(torch.equal(x, y) for x, y in zip(*outs))
+    big = np.zeros((600, 600), bool)
+    big[::3] = True
+    eg = VisualBatch(100, device=DEV, seed=1, trav_map=big)      # 360 000 cells > the 512 x 512 the LDS form holds
+    eg.reset()
+    el = VisualBatch(100, device=DEV, seed=1, trav_map=big)
+    el.reset()
+    el._map.bits = None
+    assert torch.equal(eg.observe(), el.observe()) and torch.isfinite(eg.observe()).all()

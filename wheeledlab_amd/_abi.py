@@ -93,7 +93,7 @@ class WlElevParams(C.Structure):
 
 class WlTravMap(C.Structure):
     _fields_ = [("map", C.c_void_p), ("cells", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
-                ("n_cells", C.c_int32), ("row_spacing", C.c_float), ("col_spacing", C.c_float)]
+                ("n_cells", C.c_int32), ("row_spacing", C.c_float), ("col_spacing", C.c_float), ("bits", C.c_void_p)]
 
 
 class WlVisualParams(C.Structure):

@@ -388,8 +388,11 @@ class VisualBatch(_MetricsView):
         trav_map = np.ascontiguousarray(np.asarray(trav_map, dtype=bool))
         self.trav_map = torch.from_numpy(trav_map.astype(np.uint8)).to(dev)
         self.cells = torch.from_numpy(spawn_cells(trav_map)).contiguous().to(dev)
+        # one bit per cell (bit k & 31 of word k >> 5, k = iy * cols + ix): what the camera kernels keep in LDS
+        bits = np.packbits(np.concatenate([trav_map.reshape(-1), np.zeros((-trav_map.size) % 32, bool)]), bitorder="little")
+        self.trav_bits = torch.from_numpy(bits.view(np.int32).copy()).to(dev)
         self._map = A.WlTravMap(self.trav_map.data_ptr(), self.cells.data_ptr(), trav_map.shape[0], trav_map.shape[1],
-                                self.cells.shape[0], float(spacing[0]), float(spacing[1]))
+                                self.cells.shape[0], float(spacing[0]), float(spacing[1]), self.trav_bits.data_ptr())
         if startup is None:
             from .envs.flatten import StartupSpec
             startup = StartupSpec(wheel_mu_s=(0.5, 0.5), wheel_mu_d=(0.5, 0.5), damping=(1000.0, 1000.0), mass_add=(0.0, 0.0))

@@ -271,6 +271,25 @@ WL_DEV float group_sum(float v, float* scratch /* [GT / 64], this group's */, in
     return t;
 }
 
+// how a pixel's map cell is read: a byte gather from the global map, or one bit of the LDS-resident copy of the whole map
+// (WlTravMap.bits: the camera's 3200 divergent byte gathers per image were what bound it -- one lane per cycle and CU through
+// the texture addresser; an LDS read costs a thirty-second of that)
+struct GlobalMapLookup {
+    const uint8_t* map;
+    WL_DEV bool operator()(int k) const { return map[k] != 0; }
+};
+struct LdsBitLookup {
+    const uint32_t* bits;
+    WL_DEV bool operator()(int k) const { return (bits[k >> 5] >> (k & 31)) & 1u; }
+};
+constexpr int kMapWords = WL_VIS_LDS_MAP_CELLS / 32;   // 32 KB of LDS
+// all threads of the block copy the bit map into LDS (coalesced dwords; the caller syncs)
+WL_DEV void stage_map_bits(const WlTravMap& m, uint32_t* lds) {
+    const int n_words = (m.rows * m.cols + 31) >> 5;
+    for (int w = threadIdx.x; w < n_words; w += (int)blockDim.x) lds[w] = m.bits[w];
+}
+inline bool lds_map_ok(const WlTravMap* m) { return m->bits != nullptr && (int64_t)m->rows * m->cols <= WL_VIS_LDS_MAP_CELLS; }
+
 WL_DEV int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // the rendered image with its two reflected border columns on either side: pitch 84 floats = 21 sixteen-byte slots, so
@@ -283,9 +302,9 @@ constexpr int kPitch = kImgW + 4, kImgFloats = kImgH * kPitch;
 // by a group of GT threads (gt = thread in the group; `img` [kImgFloats] and `red` [GT / 64] are the group's LDS).  Two
 // `sync()`s inside when the augmentation needs the whole image; a group without an env (`valid` false) renders its
 // neighbour's pose and stores nothing.
-template <int GT, class SYNC>
-WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const CamPose& cp, float* __restrict__ row, float* img, float* red,
-                         const int gt, const bool valid, SYNC& sync) {
+template <int GT, class SYNC, class LOOKUP>
+WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOKUP& lookup, const CamPose& cp, float* __restrict__ row,
+                         float* img, float* red, const int gt, const bool valid, SYNC& sync) {
     const V3 pos = v3(cp.px, cp.py, cp.pz);
     const Quat q{cp.qw, cp.qx, cp.qy, cp.qz};
     const Mat3 R = mat_from_quat(q);
@@ -316,7 +335,7 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const CamP
     V3 d = fma3(dz0, c2, fma3(dy, c1, c0));
     const V3 dstep = (-(float)kRowsPerPass * inv_fy) * c2;
     const float mx = mf.off_x * mf.inv_rs, my = mf.off_y * mf.inv_cs;   // cell = (int)(h * inv + off * inv)
-    uint8_t cell[kIter];
+    bool cell[kIter];
     bool hit[kIter];
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
@@ -326,14 +345,14 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const CamP
         const bool on_map = hit[it] && fabsf(hx) <= mf.half_w && fabsf(hy) <= mf.half_h;
         const int xi = min(max((int)fmaf(hx, mf.inv_rs, mx), 0), m.rows - 1);
         const int yi = min(max((int)fmaf(hy, mf.inv_cs, my), 0), m.cols - 1);
-        cell[it] = on_map ? m.map[yi * m.cols + xi] : (uint8_t)0;       // white path on black (utils/__init__.py:47-50)
+        cell[it] = on_map ? lookup(yi * m.cols + xi) : false;           // white path on black (utils/__init__.py:47-50)
         d = d + dstep;
     }
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
         const int r = tr + it * kRowsPerPass;
         if (lane_on && r < kImgH) {
-            float v = hit[it] ? (cell[it] != 0 ? 1.f : 0.f) : p.sky;
+            float v = hit[it] ? (cell[it] ? 1.f : 0.f) : p.sky;
             v = clampf(v * p.brightness, 0.f, 1.f);                    // ColorJitter brightness
             if (plain) {
                 if (valid) row[r * kImgW + tc] = (v * 0.9999f - 0.5f) * 2.f;   // grayscale + Normalize([0.5], [0.5]) straight to HBM
@@ -408,7 +427,8 @@ WL_DEV CamPose load_cam_pose(const Rows& S, const int e) {
                    S.ld(WL_S_WX, e), S.ld(WL_S_WX + 1, e), S.ld(WL_S_WX + 2, e), S.ld(WL_S_ACT0, e), S.ld(WL_S_ACT1, e)};
 }
 
-// block = env: the observation of the state as it stands (reset / first observation / lane-form steps)
+// block = env: the observation of the state as it stands (reset / first observation / lane-form steps); map cells by byte
+// gathers from global memory (maps too large for LDS, or no bit map supplied)
 __global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
                                                           float* __restrict__ obs) {
     __shared__ __attribute__((aligned(16))) float img[kImgFloats];
@@ -416,7 +436,33 @@ __global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p
     const int e = blockIdx.x;
     const CamPose cp = load_cam_pose(make_rows(b.state, b.stride), e);
     BlockSync sync;
-    render_image<kCam>(p, m, cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img, red, (int)threadIdx.x, true, sync);
+    render_image<kCam>(p, m, GlobalMapLookup{m.map}, cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img, red, (int)threadIdx.x, true, sync);
+}
+
+// The same with the WHOLE map in LDS as one bit per cell (31 KB for the reference's 500 x 500 cells): block = kObsGroups envs,
+// one group of kCam threads each (the groups meet among themselves through GroupSync), so that the 31 KB are staged once per
+// kObsGroups images; 32 + 3 x 13.4 KB of LDS -> two blocks = 24 wavefronts per CU.
+constexpr int kObsGroups = 3, kObsThreads = kObsGroups * kCam;
+__global__ void __launch_bounds__(kObsThreads) visual_obs_lds_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
+                                                                     float* __restrict__ obs) {
+    __shared__ uint32_t mapbits[kMapWords];
+    __shared__ __attribute__((aligned(16))) float img[kObsGroups * kImgFloats];
+    __shared__ float red[kObsGroups * (kCam / 64)];
+    __shared__ int arrivals[kObsGroups];
+    const int grp = threadIdx.x / kCam, gt = threadIdx.x % kCam;
+    const int e = blockIdx.x * kObsGroups + grp;
+    const bool valid = e < b.n_envs;
+    const CamPose cp = load_cam_pose(make_rows(b.state, b.stride), min(e, b.n_envs - 1));   // requested ahead of the staging
+    if (threadIdx.x < kObsGroups) arrivals[threadIdx.x] = 0;
+    stage_map_bits(m, mapbits);
+    __syncthreads();
+    GroupSync sync{arrivals + grp, 0, kCam / 64};
+    render_image<kCam>(p, m, LdsBitLookup{mapbits}, cp, obs + (int64_t)min(e, b.n_envs - 1) * WL_VIS_OBS_DIM, img + grp * kImgFloats,
+                       red + grp * (kCam / 64), gt, valid, sync);
+}
+inline void launch_visual_obs(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, float* obs, hipStream_t hs) {
+    if (lds_map_ok(m)) visual_obs_lds_kernel<<<(b->n_envs + kObsGroups - 1) / kObsGroups, kObsThreads, 0, hs>>>(*p, *b, *m, obs);
+    else visual_obs_kernel<<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
 }
 
 // K env.step()s in ONE launch with pre-staged actions [K][n][2] (open-loop rollouts; quad form, n <= 32 768), the visual
@@ -428,7 +474,7 @@ __global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p
 // (GT is visual_obs_kernel's: a group of 320 threads -- 4 image rows per pass, fifteen render wavefronts -- advances the
 // ray direction in different increments, and rays that graze a cell edge then resolve differently: not bit-identical.)
 constexpr int kPersistGroups = (1024 - 64) / kCam, kPersistThreads = 64 + kPersistGroups * kCam;
-template <int EPB>
+template <int EPB, bool LDSMAP>
 __global__ void __launch_bounds__(kPersistThreads) visual_rollout_persistent_kernel(
     const WlVisualParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b, const WlTravMap m, const float2* __restrict__ actions,
     const WlStepOut out, const int64_t obs_step_stride, const int64_t vec_step_stride, const int n_steps, const uint64_t seed,
@@ -440,10 +486,12 @@ __global__ void __launch_bounds__(kPersistThreads) visual_rollout_persistent_ker
     __shared__ __attribute__((aligned(16))) float img[kGroups * kImgFloats];
     __shared__ float red[kGroups * (GT / 64)];
     __shared__ int arrivals[kGroups];
+    __shared__ uint32_t mapbits[LDSMAP ? kMapWords : 1];
     const int tid = threadIdx.x;
     if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
     if (tid < kGroups) arrivals[tid] = 0;
     if (b.metrics_slots > 1) clear_metric_slot(b, slots.next);
+    if constexpr (LDSMAP) stage_map_bits(m, mapbits);
     __syncthreads();
     const int e0 = blockIdx.x * EPB;
     if (tid < 64) {
@@ -495,8 +543,12 @@ __global__ void __launch_bounds__(kPersistThreads) visual_rollout_persistent_ker
             int gtl = gt;
             asm volatile("" : "+v"(gtl));              // per-pass copy: keeps the pixel / patch bookkeeping from being hoisted out of
                                                        // the loops and held in ~50 registers across them
-            render_image<GT>(p_arg, m, cp, obs_k + (int64_t)(e0 + j) * WL_VIS_OBS_DIM, img + grp * kImgFloats, red + grp * (GT / 64),
-                             gtl, true, sync);
+            if constexpr (LDSMAP)
+                render_image<GT>(p_arg, m, LdsBitLookup{mapbits}, cp, obs_k + (int64_t)(e0 + j) * WL_VIS_OBS_DIM, img + grp * kImgFloats,
+                                 red + grp * (GT / 64), gtl, true, sync);
+            else
+                render_image<GT>(p_arg, m, GlobalMapLookup{m.map}, cp, obs_k + (int64_t)(e0 + j) * WL_VIS_OBS_DIM, img + grp * kImgFloats,
+                                 red + grp * (GT / 64), gtl, true, sync);
         }
     }
 }
@@ -585,7 +637,7 @@ int wl_visual_rollout(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
         }
         else
             visual_step_kernel<1><<<grid_for(n), kBlock, 0, hs>>>(*p, vd, *b, *m, a, o, seed, st);
-        visual_obs_kernel<<<n, kCam, 0, hs>>>(*p, *b, *m, o.obs);
+        launch_visual_obs(p, b, m, o.obs, hs);
     }
     return launch_status();
 }
@@ -605,11 +657,15 @@ int wl_visual_rollout_persistent(const WlVisualParams* p, const WlEnvBuffers* b,
     const MetricSlots ms = metric_slots(b, step0, (uint64_t)n_steps);
     const int n = b->n_envs;
 #define WL_VIS_PERSIST(E)                                                                                                   \
-    visual_rollout_persistent_kernel<E><<<(n + (E) - 1) / (E), kPersistThreads, 0, (hipStream_t)stream>>>(                  \
-        *p, vd, *b, *m, (const float2*)actions, *out, obs_step_stride, vec_step_stride, n_steps, seed, step0, ms)
-    if (n <= 1024) WL_VIS_PERSIST(4);
-    else if (n <= 2048) WL_VIS_PERSIST(8);
-    else WL_VIS_PERSIST(16);
+    if (lds_map_ok(m))                                                                                                      \
+        visual_rollout_persistent_kernel<E, true><<<(n + (E) - 1) / (E), kPersistThreads, 0, (hipStream_t)stream>>>(        \
+            *p, vd, *b, *m, (const float2*)actions, *out, obs_step_stride, vec_step_stride, n_steps, seed, step0, ms);      \
+    else                                                                                                                    \
+        visual_rollout_persistent_kernel<E, false><<<(n + (E) - 1) / (E), kPersistThreads, 0, (hipStream_t)stream>>>(       \
+            *p, vd, *b, *m, (const float2*)actions, *out, obs_step_stride, vec_step_stride, n_steps, seed, step0, ms)
+    if (n <= 1024) { WL_VIS_PERSIST(4); }
+    else if (n <= 2048) { WL_VIS_PERSIST(8); }
+    else { WL_VIS_PERSIST(16); }
 #undef WL_VIS_PERSIST
     return launch_status();
 }
@@ -628,7 +684,7 @@ int wl_visual_observe(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
     if (rc != WL_OK) return rc;
     if (!obs) return WL_EINVAL;
     clear_error();
-    visual_obs_kernel<<<b->n_envs, kCam, 0, (hipStream_t)stream>>>(*p, *b, *m, obs);
+    launch_visual_obs(p, b, m, obs, (hipStream_t)stream);
     return launch_status();
 }
 
