@@ -5,7 +5,8 @@
 #include <cstdlib>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int R, int W, bool TILED>
+// AUXL / AUXS: the cache-policy operand of the buffer loads / stores (gfx940+: bit 0 sc0, bit 1 nt, bit 4 sc1)
+template <int R, int W, bool TILED, int AUXL = 0, int AUXS = 0>
 __global__ void __launch_bounds__(256) stream_kernel(float* __restrict__ base, long stride, int n) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n) return;
@@ -15,12 +16,12 @@ __global__ void __launch_bounds__(256) stream_kernel(float* __restrict__ base, l
     const int rowb = TILED ? 256 : (int)(stride * 4);
     float acc[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, r * rowb, 0));
+    for (int r = 0; r < R; ++r) acc[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, r * rowb, AUXL));
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) s += acc[r];
 #pragma unroll
-    for (int w = 0; w < W; ++w) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s + (float)w), rs, voff, w * rowb, 0);
+    for (int w = 0; w < W; ++w) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s + (float)w), rs, voff, w * rowb, AUXS);
 }
 
 // (c) rows grouped in fours: [group][n] of float4 -- 16 B per lane per access, 1 KB contiguous per wavefront
@@ -82,8 +83,60 @@ float run_rw(float* buf, long stride, int n) {
 __global__ void __launch_bounds__(256) copy4_kernel(const f4* __restrict__ src, f4* __restrict__ dst, long n4) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) dst[i] = src[i];
 }
+__global__ void __launch_bounds__(256) copy4_nt_kernel(const f4* __restrict__ src, f4* __restrict__ dst, long n4) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+template <int AUXL, int AUXS>
+float run_policy(float* buf, long stride, int n) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) stream_kernel<34, 30, false, AUXL, AUXS><<<(n + 255) / 256, 256>>>(buf, stride, n);
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < 10; ++i) stream_kernel<34, 30, false, AUXL, AUXS><<<(n + 255) / 256, 256>>>(buf, stride, n);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms * 100.f;
+}
 
 int main() {
+    {   // round 3: (a) the guide's float4 copy at a size well past the 256 MB Infinity Cache, plain and non-temporal; (b) the cache
+        // policy bits on the step kernel's own pattern (34 SoA rows in, 30 out, 4 B per lane, 4 M envs)
+        const long n4 = (1L << 30) / 16;     // 1 GiB -> 1 GiB
+        f4 *src, *dst;
+        CHECK(hipMalloc(&src, n4 * 16)); CHECK(hipMalloc(&dst, n4 * 16));
+        CHECK(hipMemset(src, 0, n4 * 16)); CHECK(hipMemset(dst, 0, n4 * 16));
+        hipEvent_t a, b;
+        CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+        for (int nt = 0; nt < 2; ++nt)
+            for (int g : {2048, 8192, 65536}) {
+                for (int i = 0; i < 2; ++i) nt ? copy4_nt_kernel<<<g, 256>>>(src, dst, n4) : copy4_kernel<<<g, 256>>>(src, dst, n4);
+                CHECK(hipEventRecord(a));
+                for (int i = 0; i < 5; ++i) nt ? copy4_nt_kernel<<<g, 256>>>(src, dst, n4) : copy4_kernel<<<g, 256>>>(src, dst, n4);
+                CHECK(hipEventRecord(b));
+                CHECK(hipEventSynchronize(b));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, a, b));
+                printf("float4 copy 1 GiB -> 1 GiB%s, grid %d: %.1f us (%.2f TB/s)\n", nt ? " non-temporal" : "", g, ms * 200.f,
+                       2.0 * n4 * 16 / (ms * 200.f) / 1e6);
+            }
+        CHECK(hipFree(src)); CHECK(hipFree(dst));
+        const int n = 1 << 22;
+        float* buf;
+        CHECK(hipMalloc(&buf, (long)n * 4 * 44));
+        CHECK(hipMemset(buf, 0, (long)n * 4 * 44));
+        const double bytes = 64.0 * 4 * n;
+        const float p00 = run_policy<0, 0>(buf, n, n), p02 = run_policy<0, 2>(buf, n, n), p22 = run_policy<2, 2>(buf, n, n),
+                    p20 = run_policy<2, 0>(buf, n, n), p016 = run_policy<0, 16>(buf, n, n), p018 = run_policy<0, 18>(buf, n, n), p218 = run_policy<2, 18>(buf, n, n),
+                    p1818 = run_policy<18, 18>(buf, n, n);
+        printf("SoA 34 in / 30 out, 4 M envs, cache policy (loads, stores): default %.1f us (%.2f TB/s)  (-, nt) %.1f (%.2f)  (nt, nt) %.1f (%.2f)  "
+               "(nt, -) %.1f (%.2f)  (-, sc1) %.1f (%.2f)  (-, sc1 nt) %.1f (%.2f)  (nt, sc1 nt) %.1f (%.2f)  (sc1 nt, sc1 nt) %.1f (%.2f)\n", p00, bytes / p00 / 1e6, p02, bytes / p02 / 1e6, p22,
+               bytes / p22 / 1e6, p20, bytes / p20 / 1e6, p016, bytes / p016 / 1e6, p018, bytes / p018 / 1e6, p218, bytes / p218 / 1e6, p1818,
+               bytes / p1818 / 1e6);
+        CHECK(hipFree(buf));
+    }
     {   // reference points on this box: plain float4 copy (grid-stride, 16 B / lane), read-mostly and write-mostly SoA streams
         const int n = 1 << 22;
         float* buf;

@@ -39,9 +39,11 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_variants", "lib_*.so")))
         rew = torch.zeros(K, n, device="cuda:0")
         term = torch.zeros(K, n, dtype=torch.bool, device="cuda:0")
         trunc = torch.zeros(K, n, dtype=torch.bool, device="cuda:0")
-        for aug in ((1.0, 1.0, 0.0), (1.3, 0.9, 1.2)):
+        bits = env._map.bits
+        for aug, lds in (((1.0, 1.0, 0.0), True), ((1.0, 1.0, 0.0), False), ((1.3, 0.9, 1.2), True), ((1.3, 0.9, 1.2), False)):
+            env._map.bits = bits if lds else None          # the camera's map in LDS (bits) / byte gathers from global memory
             env.p.brightness, env.p.contrast, env.p.blur_sigma = aug
             out = {"per_step_launches": timed(lambda: env.rollout(a, obs, rew, term, trunc)),
                    "camera_only": round(timed(lambda: [env.observe() for _ in range(K)]), 2),
                    "persistent": timed(lambda: env.rollout(a, obs, rew, term, trunc, persistent=True))}
-            print(os.path.basename(path) if path else "installed", n, "plain" if aug[2] == 0.0 else "aug", json.dumps(out), flush=True)
+            print(os.path.basename(path) if path else "installed", n, "plain" if aug[2] == 0.0 else "aug", "lds-bits" if lds else "byte-gathers", json.dumps(out), flush=True)

@@ -50,8 +50,10 @@ __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? 
     const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
     const MetricSink<LANES> ms{wave_metrics + (LANES == 1 ? wave * WL_M_COUNT : 0), metric_shard(b, slots.cur)};
     ms.open();
+    // the fenced lane form is the one the launcher picks beyond 262 144 envs: state and outputs stream through the caches
+    constexpr bool kStreaming = LANES == 1 && !UNROLL;
     if (e < b.n_envs) {
-        const Rows S = make_rows(b.state, b.stride);
+        const Rows S = make_rows(b.state, b.stride, kStreaming);
         EnvConst ec;
         DriftRows r;
         const float2 a = actions[e];
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? 
     if (b.metrics_slots > 1) clear_metric_slot(b, slots.next);   // the slot the NEXT launch will use
     if constexpr (LANES == 1) {
         const int wave_env0 = blockIdx.x * kEnvs + wave * 64;
-        if (wave_env0 < b.n_envs) flush_obs_wave(tile + wave * 64 * kObsPad, out.obs, wave_env0, b.n_envs);
+        if (wave_env0 < b.n_envs) flush_obs_wave<kStreaming>(tile + wave * 64 * kObsPad, out.obs, wave_env0, b.n_envs);
         ms.close();
     }
 }

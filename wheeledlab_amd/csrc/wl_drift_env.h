@@ -180,6 +180,7 @@ WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0
 // order, so the transposition needs no block barrier (round 1: one tile per block behind __syncthreads, the
 // wavefronts of a block waiting for the slowest).  Element f = lane + 64 j of the wavefront's 896 contiguous output
 // floats sits at tile[f + f / 14].
+template <bool STREAMING = false>   // non-temporal stores: the rows are not read again before the caches turn over (> 262 144 envs)
 WL_DEV void flush_obs_wave(const float* tile_w, float* __restrict__ obs, int wave_env0, int n) {
     const int lane = threadIdx.x & 63;
     const int n_valid = min(64, n - wave_env0);
@@ -189,7 +190,8 @@ WL_DEV void flush_obs_wave(const float* tile_w, float* __restrict__ obs, int wav
 #pragma unroll
         for (int j = 0; j < kObsDim; ++j) {
             const int e = (m + 64 * j * 4682) >> 16;
-            dst[64 * j] = tile_w[lane + 64 * j + e];
+            if constexpr (STREAMING) __builtin_nontemporal_store(tile_w[lane + 64 * j + e], dst + 64 * j);
+            else dst[64 * j] = tile_w[lane + 64 * j + e];
         }
     } else {
         const int total = n_valid * kObsDim;

@@ -16,11 +16,18 @@ constexpr int kBlock = 256;
 struct Rows {
     __amdgpu_buffer_rsrc_t rsrc;
     int row_bytes;   // stride * 4
+    // streaming: the batch is far larger than the caches (the > 262 144-env form of the drift step): rows written now are not
+    // read again before they are evicted, so their stores carry the `sc1 nt` policy (cache-policy operand 18: bit 1 nt, bit 4
+    // sc1).  Measured on the step's own pattern (34 SoA rows in, 30 out, 4 M envs; tools/microbench/layout_bw): 5.24 TB/s with
+    // default stores, 6.15 TB/s with sc1 nt.  A compile-time constant wherever it is used (set from a template parameter,
+    // everything inlined): the untaken form is dropped.
+    bool streaming;
     WL_DEV float ld(int row, int env) const {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, env * 4, row * row_bytes, 0));
     }
     WL_DEV void st(int row, int env, float v) const {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, env * 4, row * row_bytes, 0);
+        if (streaming) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, env * 4, row * row_bytes, 18);
+        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, env * 4, row * row_bytes, 0);
     }
     // row index that differs per LANE (quad form: lane `wid` owns wheel row WL_S_WHEEL_BL + wid): the row goes into the
     // per-lane byte offset.  (Through ld / st the row would be the SCALAR offset, and a lane-varying scalar operand
@@ -37,9 +44,9 @@ struct Rows {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, lane_row_offset(row_lane, env), 0, 0);
     }
 };
-WL_DEV Rows make_rows(float* base, int64_t stride) {
+WL_DEV Rows make_rows(float* base, int64_t stride, bool streaming = false) {
     // dword3 0x00020000: raw 32-bit data format on gfx90a / gfx94x / gfx950; num_records bounds the whole matrix
-    return Rows{__builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(stride * 4 * WL_S_COUNT), 0x00020000), (int)(stride * 4)};
+    return Rows{__builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(stride * 4 * WL_S_COUNT), 0x00020000), (int)(stride * 4), streaming};
 }
 
 WL_DEV V3 ld3(const Rows& s, int row, int e) { return v3(s.ld(row, e), s.ld(row + 1, e), s.ld(row + 2, e)); }

@@ -283,10 +283,24 @@ struct LdsBitLookup {
     WL_DEV bool operator()(int k) const { return (bits[k >> 5] >> (k & 31)) & 1u; }
 };
 constexpr int kMapWords = WL_VIS_LDS_MAP_CELLS / 32;   // 32 KB of LDS
-// all threads of the block copy the bit map into LDS (coalesced dwords; the caller syncs)
+// all threads of the block copy the bit map into LDS (coalesced dwords; the caller syncs).  Every request of a thread is issued
+// before the first LDS write (rolled, the copy was a chain of ~10 dependent L2 round trips per block: slower than the gathers
+// it replaces).
+template <int THREADS>
 WL_DEV void stage_map_bits(const WlTravMap& m, uint32_t* lds) {
+    constexpr int kPer = (kMapWords + THREADS - 1) / THREADS;
     const int n_words = (m.rows * m.cols + 31) >> 5;
-    for (int w = threadIdx.x; w < n_words; w += (int)blockDim.x) lds[w] = m.bits[w];
+    uint32_t w[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int idx = (int)threadIdx.x + k * THREADS;
+        w[k] = idx < n_words ? m.bits[idx] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int idx = (int)threadIdx.x + k * THREADS;
+        if (idx < kMapWords) lds[idx] = w[k];
+    }
 }
 inline bool lds_map_ok(const WlTravMap* m) { return m->bits != nullptr && (int64_t)m->rows * m->cols <= WL_VIS_LDS_MAP_CELLS; }
 
@@ -439,10 +453,11 @@ __global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p
     render_image<kCam>(p, m, GlobalMapLookup{m.map}, cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img, red, (int)threadIdx.x, true, sync);
 }
 
-// The same with the WHOLE map in LDS as one bit per cell (31 KB for the reference's 500 x 500 cells): block = kObsGroups envs,
-// one group of kCam threads each (the groups meet among themselves through GroupSync), so that the 31 KB are staged once per
-// kObsGroups images; 32 + 3 x 13.4 KB of LDS -> two blocks = 24 wavefronts per CU.
-constexpr int kObsGroups = 3, kObsThreads = kObsGroups * kCam;
+// The same with the WHOLE map in LDS as one bit per cell (31 KB for the reference's 500 x 500 cells).  Persistent blocks of
+// kObsGroups groups of kCam threads: the map is staged ONCE per block, then every group renders image after image (its next
+// pose requested while the current image is rendered; the groups meet only among themselves, through GroupSync).
+// 32 + 3 x 13.4 KB of LDS -> two blocks = 24 wavefronts per CU.
+constexpr int kObsGroups = 3, kObsThreads = kObsGroups * kCam, kObsBlocksPerCu = 2;
 __global__ void __launch_bounds__(kObsThreads) visual_obs_lds_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
                                                                      float* __restrict__ obs) {
     __shared__ uint32_t mapbits[kMapWords];
@@ -450,18 +465,35 @@ __global__ void __launch_bounds__(kObsThreads) visual_obs_lds_kernel(const WlVis
     __shared__ float red[kObsGroups * (kCam / 64)];
     __shared__ int arrivals[kObsGroups];
     const int grp = threadIdx.x / kCam, gt = threadIdx.x % kCam;
-    const int e = blockIdx.x * kObsGroups + grp;
-    const bool valid = e < b.n_envs;
-    const CamPose cp = load_cam_pose(make_rows(b.state, b.stride), min(e, b.n_envs - 1));   // requested ahead of the staging
+    const int stride = (int)gridDim.x * kObsGroups;
+    int e = blockIdx.x * kObsGroups + grp;
+    const Rows S = make_rows(b.state, b.stride);
+    CamPose cp = load_cam_pose(S, min(e, b.n_envs - 1));   // requested ahead of the staging
     if (threadIdx.x < kObsGroups) arrivals[threadIdx.x] = 0;
-    stage_map_bits(m, mapbits);
+    stage_map_bits<kObsThreads>(m, mapbits);
     __syncthreads();
     GroupSync sync{arrivals + grp, 0, kCam / 64};
-    render_image<kCam>(p, m, LdsBitLookup{mapbits}, cp, obs + (int64_t)min(e, b.n_envs - 1) * WL_VIS_OBS_DIM, img + grp * kImgFloats,
-                       red + grp * (kCam / 64), gt, valid, sync);
+    const bool plain = p.contrast == 1.f && !(p.blur_sigma > 0.f);
+    bool first = true;
+#pragma unroll 1
+    for (; e < b.n_envs; e += stride) {
+        const CamPose nxt = load_cam_pose(S, min(e + stride, b.n_envs - 1));
+        if (!first && !plain) sync();            // the previous image is still being read by the blur
+        first = false;
+        int gtl = gt;
+        asm volatile("" : "+v"(gtl));             // per-image copy of the pixel bookkeeping (see the persistent rollout)
+        render_image<kCam>(p, m, LdsBitLookup{mapbits}, cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img + grp * kImgFloats,
+                           red + grp * (kCam / 64), gtl, true, sync);
+        cp = nxt;
+    }
 }
 inline void launch_visual_obs(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, float* obs, hipStream_t hs) {
-    if (lds_map_ok(m)) visual_obs_lds_kernel<<<(b->n_envs + kObsGroups - 1) / kObsGroups, kObsThreads, 0, hs>>>(*p, *b, *m, obs);
+    if (lds_map_ok(m)) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+        const int want = (b->n_envs + kObsGroups - 1) / kObsGroups, cap = (cus > 0 ? cus : 256) * kObsBlocksPerCu;
+        visual_obs_lds_kernel<<<want < cap ? want : cap, kObsThreads, 0, hs>>>(*p, *b, *m, obs);
+    }
     else visual_obs_kernel<<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
 }
 
@@ -491,7 +523,7 @@ __global__ void __launch_bounds__(kPersistThreads) visual_rollout_persistent_ker
     if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
     if (tid < kGroups) arrivals[tid] = 0;
     if (b.metrics_slots > 1) clear_metric_slot(b, slots.next);
-    if constexpr (LDSMAP) stage_map_bits(m, mapbits);
+    if constexpr (LDSMAP) stage_map_bits<kPersistThreads>(m, mapbits);
     __syncthreads();
     const int e0 = blockIdx.x * EPB;
     if (tid < 64) {
