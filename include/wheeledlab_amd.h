@@ -586,9 +586,9 @@ typedef struct WlTravMap {
     int32_t rows, cols, n_cells;
     float row_spacing, col_spacing;
     /* optional: the same map one BIT per cell, bit (k & 31) of word (k >> 5) for k = iy * cols + ix, ceil(rows * cols / 32)
-       words (+ 0 padding bits).  With it (and rows * cols <= WL_VIS_LDS_MAP_CELLS) the camera kernels keep the whole map in
-       LDS -- 31 KB for the reference's 500 x 500 map -- and a pixel's lookup is an LDS read instead of a byte gather (the
-       camera was bound by the texture addresser: one divergent gather per pixel).  NULL: byte gathers from `map`. */
+       words (+ 0 padding bits).  With it (and rows * cols <= WL_VIS_LDS_MAP_CELLS) the persistent rollout keeps the whole map in
+       LDS -- 31 KB for the reference's 500 x 500 map -- and a pixel's lookup is an LDS read instead of a byte gather (10 % off
+       its step; the per-step camera launch keeps the byte gathers: measured faster there).  NULL: byte gathers from `map`. */
     const uint32_t* bits;
 } WlTravMap;
 #define WL_VIS_LDS_MAP_CELLS (512 * 512)
@@ -608,6 +608,10 @@ typedef struct WlVisualParams {
     /* augmentation of this call (torchvision ColorJitter brightness / contrast + GaussianBlur(5) sigma,
        mdp_sensors/observations.py:21-23,82-84); 1, 1, 0 = none                                              */
     float brightness, contrast, blur_sigma;
+    /* torchvision's ColorJitter.forward applies its four ops in a random permutation per call (torch.randperm(4)); on the
+       rendered image (R = G = B) hue is the identity and saturation a scale within 1.8e-4 of 1, so what matters is whether the
+       contrast blend runs BEFORE the brightness scale (1) or after it (0): they do not commute (clamps, mean)             */
+    int32_t contrast_first;
     int32_t log_episode_sums;
 } WlVisualParams;
 

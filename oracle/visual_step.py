@@ -33,7 +33,7 @@ def visual_params():
         reset_z=0.1,                                                                            # :203
         cam_pos=[0.23, 0.0, 0.18], fx=80 * 1.9299999475479126 / 3.8959999084472656,
         fy=60 * 1.9299999475479126 / 2.453000068664551, cx=40.0, cy=30.0,                      # :230-241 (pose: designed)
-        sky=0.5, brightness=1.0, contrast=1.0, blur_sigma=0.0,
+        sky=0.5, brightness=1.0, contrast=1.0, blur_sigma=0.0, contrast_first=0,
         log_episode_sums=1,
     )
 
@@ -89,10 +89,19 @@ def camera(p, state, trav):
     tv = VM.get_traversability(trav, np.stack([hx.reshape(-1), hy.reshape(-1)], -1), num_rows=p.map_rows,
                                num_cols=p.map_cols, row_spacing=p.row_spacing, col_spacing=p.col_spacing).reshape(n, -1)
     img = np.where(hit, np.where(on_map & tv, F(1), F(0)), F(p.sky)).astype(F)
-    img = np.clip(img * F(p.brightness), 0, 1)
-    if p.contrast != 1.0:
-        mean = (img * F(0.9999)).mean(-1, keepdims=True, dtype=np.float32)    # grayscale mean (0.2989+0.587+0.114)
-        img = np.clip(F(p.contrast) * img + (F(1) - F(p.contrast)) * mean, 0, 1)
+    # torchvision ColorJitter.forward: the ops run in the order of a torch.randperm(4) drawn per call (mdp_sensors/observations.py:21,
+    # 82: one call per batch).  adjust_brightness: blend with zeros = clamp(b x); adjust_contrast: blend with the mean of the
+    # grayscale image, clamp.  Hue is the identity on a grey image, saturation a scale within 1.8e-4 of 1 (tests/test_oracle_
+    # golden_elev_visual.py::test_saturation_and_hue_on_a_grey_image): only the brightness / contrast order is modelled.
+    def brightness(x):
+        return np.clip(x * F(p.brightness), 0, 1)
+
+    def contrast(x):
+        if p.contrast == 1.0:
+            return x
+        mean = (x * F(0.9999)).mean(-1, keepdims=True, dtype=np.float32)    # grayscale mean (0.2989+0.587+0.114)
+        return np.clip(F(p.contrast) * x + (F(1) - F(p.contrast)) * mean, 0, 1)
+    img = brightness(contrast(img)) if getattr(p, "contrast_first", 0) else contrast(brightness(img))
     if p.blur_sigma > 0:
         k = gaussian_kernel5(p.blur_sigma)
         im = img.reshape(n, IMG_H - CROP, IMG_W)

@@ -70,9 +70,10 @@ def test_visual_reset_and_camera_match_oracle(trav):
     OS.reset_envs(p, o, ep, cells, np.arange(128), 11, 0)
     np.testing.assert_allclose(st[:, :128], o[:, :128], rtol=1e-6, atol=2e-6)
     assert trav[VM.get_map_id(st[0, :128], st[1, :128])[1], VM.get_map_id(st[0, :128], st[1, :128])[0]].all()   # spawned on the path
-    for aug in ((1.0, 1.0, 0.0), (1.4, 0.85, 1.7), (0.5, 1.15, 0.4)):
-        env.p.brightness, env.p.contrast, env.p.blur_sigma = aug
-        p.brightness, p.contrast, p.blur_sigma = aug
+    # (brightness, contrast, blur sigma, contrast before brightness): torchvision's ColorJitter draws the op order per call
+    for aug in ((1.0, 1.0, 0.0, 0), (1.4, 0.85, 1.7, 0), (0.5, 1.15, 0.4, 0), (1.4, 0.85, 1.7, 1), (1.7, 1.2, 0.0, 1), (0.4, 1.2, 3.0, 1)):
+        env.p.brightness, env.p.contrast, env.p.blur_sigma, env.p.contrast_first = aug
+        p.brightness, p.contrast, p.blur_sigma, p.contrast_first = aug
         obs = env.observe().cpu().numpy()
         want = OS.observe(p, st[:, :128].copy(), trav)
         assert obs.shape == (128, 3208)
@@ -82,8 +83,13 @@ def test_visual_reset_and_camera_match_oracle(trav):
         assert bad < 2e-3, (aug, bad)
         assert d[:, 3200:].max() < 1e-5
         assert np.median(d[:, :3200]) < 1e-5
+    # the two orders really differ (brightness 1.4 pushes the sky band over the clamp before / after the blend)
+    env.p.brightness, env.p.contrast, env.p.blur_sigma, env.p.contrast_first = 1.4, 0.85, 1.7, 0
+    a0 = env.observe().clone()
+    env.p.contrast_first = 1
+    assert (env.observe() - a0).abs().max() > 1e-2
     # the image shows something: both colours and the sky band are present
-    env.p.brightness, env.p.contrast, env.p.blur_sigma = 1.0, 1.0, 0.0
+    env.p.brightness, env.p.contrast, env.p.blur_sigma, env.p.contrast_first = 1.0, 1.0, 0.0, 0
     img = env.observe()[:, :3200]
     assert (img > 0.9).any() and (img < -0.9).any() and ((img.abs() < 0.05).float().mean() > 0.1)
 
@@ -275,9 +281,9 @@ def test_settled_cars_need_no_contact_excuse(trav, lanes):
 
 @pytest.mark.parametrize("aug", [(1.0, 1.0, 0.0), (1.3, 0.9, 1.2)])
 def test_lds_bit_map_camera_equals_the_byte_gather_camera(trav, aug):
-    """the camera with the whole traversability map in LDS as one bit per cell (WlTravMap.bits; three images per block) against
-    the camera that gathers bytes from the global map: every observation row bit for bit, at env counts that leave the last
-    block partly filled, through observe(), step() and the persistent rollout; a map too large for LDS takes the byte path"""
+    """the persistent rollout's camera with the whole traversability map in LDS as one bit per cell (WlTravMap.bits) against the
+    camera that gathers bytes from the global map: every observation row bit for bit; observe() / step() (byte gathers either
+    way) at env counts that leave the last block partly filled; a map too large for LDS takes the byte path"""
     from wheeledlab_amd.core import VisualBatch
     for n in (1, 64, 1000, 4097):
         ea, eb = _batch(n, trav, seed=4), _batch(n, trav, seed=4)

@@ -111,3 +111,51 @@ def test_heightfield_sampling_matches_scipy_interpolation():
     np.testing.assert_allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-6)
     zo, no, ins = HF.sample(hf, x0, y0, cell, np.array([25.0, -21.0, 0.0]), np.array([0.0, 0.0, 30.0]), outside=0.19)
     assert not ins.any() and np.allclose(zo, 0.19) and np.allclose(no, [0, 0, 1])
+
+
+def test_saturation_and_hue_on_a_grey_image():
+    """ColorJitter(saturation=.8, hue=.5) of the reference's augmentation chain (mdp_sensors/observations.py:21) on the rendered
+    image, which is grey (R = G = B).  numpy restatement of torchvision's published tensor ops: adjust_saturation = blend(img,
+    rgb_to_grayscale(img), f) with grayscale weights (0.2989, 0.587, 0.114) -- they sum to 0.9999, so on a grey image it is the
+    scale 0.9999 + 0.0001 f: within 1.8e-4 of the identity for f in [0.2, 1.8], NOT exactly the identity; adjust_hue = RGB -> HSV,
+    h += shift, -> RGB: with zero saturation the hue drops out, the identity to rounding.  Neither is modelled by the camera
+    kernel (its parity tolerance per pixel is 2e-3); the op ORDER of brightness / contrast, which does matter, is."""
+    rng = np.random.RandomState(0)
+    v = rng.rand(5, 1, 40, 80).astype(np.float32)
+    img = np.repeat(v, 3, 1)
+
+    def grayscale(x):
+        return (0.2989 * x[:, 0] + 0.587 * x[:, 1] + 0.114 * x[:, 2])[:, None]
+
+    def adjust_saturation(x, f):
+        return np.clip(f * x + (1.0 - f) * grayscale(x), 0, 1)
+
+    def adjust_hue(x, shift):      # torchvision _rgb2hsv / _hsv2rgb
+        r, g, b = x[:, 0], x[:, 1], x[:, 2]
+        maxc, minc = x.max(1), x.min(1)
+        eqc = maxc == minc
+        cr = maxc - minc
+        ones = np.ones_like(maxc)
+        s = cr / np.where(eqc, ones, maxc)
+        crd = np.where(eqc, ones, cr)
+        rc, gc, bc = (maxc - r) / crd, (maxc - g) / crd, (maxc - b) / crd
+        hr = (maxc == r) * (bc - gc)
+        hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+        hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+        h = np.fmod(np.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0) + shift, 1.0)
+        i = np.floor(h * 6.0)
+        f = h * 6.0 - i
+        i = i.astype(np.int32) % 6
+        p_ = np.clip(maxc * (1.0 - s), 0, 1)
+        q = np.clip(maxc * (1.0 - f * s), 0, 1)
+        t = np.clip(maxc * (1.0 - (1.0 - f) * s), 0, 1)
+        a1 = np.stack([maxc, q, p_, p_, t, maxc]), np.stack([t, maxc, maxc, q, p_, p_]), np.stack([p_, p_, t, maxc, maxc, q])
+        pick = lambda a: np.take_along_axis(a, i[None], 0)[0]
+        return np.stack([pick(a1[0]), pick(a1[1]), pick(a1[2])], 1)
+
+    for f in (0.2, 1.0, 1.8):
+        out = adjust_saturation(img, f)
+        np.testing.assert_allclose(out, np.clip(img * (0.9999 + 0.0001 * f), 0, 1), rtol=0, atol=1e-6)
+        assert np.abs(out - img).max() <= 1.8e-4 + 1e-7
+    for shift in (-0.5, -0.2, 0.3, 0.5):
+        np.testing.assert_allclose(adjust_hue(img, shift), img, rtol=0, atol=1e-6)

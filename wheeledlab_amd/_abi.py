@@ -102,7 +102,7 @@ class WlVisualParams(C.Structure):
         ("action", WlActionParams), ("vehicle", WlVehicleParams), ("weight", C.c_float * WL_MAX_REW_TERMS),
         ("reset_z", C.c_float), ("cam_pos", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
         ("cy", C.c_float), ("sky", C.c_float), ("brightness", C.c_float), ("contrast", C.c_float),
-        ("blur_sigma", C.c_float), ("log_episode_sums", C.c_int32),
+        ("blur_sigma", C.c_float), ("contrast_first", C.c_int32), ("log_episode_sums", C.c_int32),
     ]
 
 

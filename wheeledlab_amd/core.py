@@ -413,10 +413,14 @@ class VisualBatch(_MetricsView):
     def sample_augmentation(self, generator: torch.Generator | None = None):
         """one (brightness, contrast, blur sigma) per call, like torchvision's ColorJitter(brightness=.8, contrast=.2)
         and GaussianBlur(5, sigma=(0.1, 5)) on a batched tensor (mdp_sensors/observations.py:21-23)"""
+        # ColorJitter.forward: fn_idx = torch.randperm(4) over (brightness, contrast, saturation, hue), then the factors; ONE
+        # draw per call, i.e. per batch (the reference passes the whole [B, C, H, W] tensor).  Hue / saturation: see the header.
+        order = torch.randperm(4, generator=generator).tolist()
         u = torch.rand(3, generator=generator)
         self.p.brightness = float(0.2 + 1.6 * u[0])
         self.p.contrast = float(0.8 + 0.4 * u[1])
         self.p.blur_sigma = float(0.1 + 4.9 * u[2])
+        self.p.contrast_first = int(order.index(1) < order.index(0))
 
     def reset(self, mask: torch.Tensor | None = None):
         m = None if mask is None else mask.to(torch.uint8).contiguous()

@@ -405,10 +405,17 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         epsum[i] += c;
     }
     if (lead) {
-        out.reward[e] = reward;
-        out.terminated[e] = terminated ? 1 : 0;
-        out.truncated[e] = truncated ? 1 : 0;
-        if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
+        if (S.streaming) {   // compile-time constant (Rows::streaming): outputs of a batch far larger than the caches
+            __builtin_nontemporal_store(reward, out.reward + e);
+            __builtin_nontemporal_store((uint8_t)(terminated ? 1 : 0), out.terminated + e);
+            __builtin_nontemporal_store((uint8_t)(truncated ? 1 : 0), out.truncated + e);
+            if (out.dones) __builtin_nontemporal_store((int64_t)((terminated || truncated) ? 1 : 0), out.dones + e);
+        } else {
+            out.reward[e] = reward;
+            out.terminated[e] = terminated ? 1 : 0;
+            out.truncated[e] = truncated ? 1 : 0;
+            if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
+        }
     }
     // ---- reset (done envs) ----
     // The observation wants the body-frame velocities of the state AFTER reset and pushes.  Round 1 rebuilt the rotation

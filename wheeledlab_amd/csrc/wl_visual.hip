@@ -326,6 +326,8 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
     const MapFast mf = map_fast(m);
     const float inv_fx = rcp(p.fx), inv_fy = rcp(p.fy);
     const bool plain = p.contrast == 1.f && !(p.blur_sigma > 0.f);   // no augmentation that needs the whole image
+    // torchvision draws the order of ColorJitter's ops per call: contrast before brightness when set (only matters with a blend)
+    const bool cfirst = p.contrast_first != 0 && p.contrast != 1.f;
     if (gt == GT - 1 && valid) {   // proprioception: the last lane (its wave renders the fewest pixels)
         const V3 vb = mul_t(R, v3(cp.vx, cp.vy, cp.vz)), wb = mul_t(R, v3(cp.wx, cp.wy, cp.wz));
         float* t = row + WL_VIS_NPIX;
@@ -367,7 +369,7 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
         const int r = tr + it * kRowsPerPass;
         if (lane_on && r < kImgH) {
             float v = hit[it] ? (cell[it] ? 1.f : 0.f) : p.sky;
-            v = clampf(v * p.brightness, 0.f, 1.f);                    // ColorJitter brightness
+            if (!cfirst) v = clampf(v * p.brightness, 0.f, 1.f);       // ColorJitter brightness (before the contrast blend)
             if (plain) {
                 if (valid) row[r * kImgW + tc] = (v * 0.9999f - 0.5f) * 2.f;   // grayscale + Normalize([0.5], [0.5]) straight to HBM
             } else {
@@ -387,7 +389,7 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
     const float cc = p.contrast, cm = (1.f - p.contrast) * mean;   // ColorJitter contrast: blend with the grey mean
     // a blend TOWARDS the mean (contrast <= 1) stays inside [0, 1], its clamp is the identity, and the blur is linear with
     // weights summing to one: blur(cc v + cm) = cc blur(v) + cm -- applied to the 16 outputs instead of the 64 inputs
-    const bool fold = cc <= 1.f && cc >= 0.f;
+    const bool fold = cc <= 1.f && cc >= 0.f && !cfirst;   // (contrast first: the brightness clamp sits between blend and blur)
     const float oc_ = fold ? cc : 1.f, om_ = fold ? cm : 0.f;
     float w[5] = {0.f, 0.f, 1.f, 0.f, 0.f};
     if (p.blur_sigma > 0.f) {                                      // GaussianBlur(5, sigma): torchvision's kernel1d
@@ -414,6 +416,10 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
             if (!fold) {   // contrast > 1 can leave [0, 1]: the clamp sits between the blend and the blur
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = clampf(fmaf(cc, v[j], cm), 0.f, 1.f);
+                if (cfirst) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = clampf(v[j] * p.brightness, 0.f, 1.f);
+                }
             }
 #pragma unroll
             for (int o = 0; o < 4; ++o)
@@ -453,48 +459,13 @@ __global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p
     render_image<kCam>(p, m, GlobalMapLookup{m.map}, cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img, red, (int)threadIdx.x, true, sync);
 }
 
-// The same with the WHOLE map in LDS as one bit per cell (31 KB for the reference's 500 x 500 cells).  Persistent blocks of
-// kObsGroups groups of kCam threads: the map is staged ONCE per block, then every group renders image after image (its next
-// pose requested while the current image is rendered; the groups meet only among themselves, through GroupSync).
-// 32 + 3 x 13.4 KB of LDS -> two blocks = 24 wavefronts per CU.
-constexpr int kObsGroups = 3, kObsThreads = kObsGroups * kCam, kObsBlocksPerCu = 2;
-__global__ void __launch_bounds__(kObsThreads) visual_obs_lds_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
-                                                                     float* __restrict__ obs) {
-    __shared__ uint32_t mapbits[kMapWords];
-    __shared__ __attribute__((aligned(16))) float img[kObsGroups * kImgFloats];
-    __shared__ float red[kObsGroups * (kCam / 64)];
-    __shared__ int arrivals[kObsGroups];
-    const int grp = threadIdx.x / kCam, gt = threadIdx.x % kCam;
-    const int stride = (int)gridDim.x * kObsGroups;
-    int e = blockIdx.x * kObsGroups + grp;
-    const Rows S = make_rows(b.state, b.stride);
-    CamPose cp = load_cam_pose(S, min(e, b.n_envs - 1));   // requested ahead of the staging
-    if (threadIdx.x < kObsGroups) arrivals[threadIdx.x] = 0;
-    stage_map_bits<kObsThreads>(m, mapbits);
-    __syncthreads();
-    GroupSync sync{arrivals + grp, 0, kCam / 64};
-    const bool plain = p.contrast == 1.f && !(p.blur_sigma > 0.f);
-    bool first = true;
-#pragma unroll 1
-    for (; e < b.n_envs; e += stride) {
-        const CamPose nxt = load_cam_pose(S, min(e + stride, b.n_envs - 1));
-        if (!first && !plain) sync();            // the previous image is still being read by the blur
-        first = false;
-        int gtl = gt;
-        asm volatile("" : "+v"(gtl));             // per-image copy of the pixel bookkeeping (see the persistent rollout)
-        render_image<kCam>(p, m, LdsBitLookup{mapbits}, cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img + grp * kImgFloats,
-                           red + grp * (kCam / 64), gtl, true, sync);
-        cp = nxt;
-    }
-}
+// (Round 3: the same camera with the whole map in LDS as one bit per cell -- persistent blocks of three render groups, map staged
+// once per block -- measured SLOWER than the byte gathers at 4096 envs: 26.1 against 18.2 us plain, 38.3 against 28.1 us
+// augmented.  The gathers were not what bound it: 52.6 MB of observation rows in 18 us are 2.9 TB/s of stores, and the LDS form
+// gives up a quarter of the resident wavefronts for its 32 KB.  In the persistent rollout below, where the blocks are resident
+// for the whole rollout anyway, the LDS map does pay: 29.0 -> 26.0 us per step plain, 37.5 -> 35.9 augmented.)
 inline void launch_visual_obs(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, float* obs, hipStream_t hs) {
-    if (lds_map_ok(m)) {
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
-        const int want = (b->n_envs + kObsGroups - 1) / kObsGroups, cap = (cus > 0 ? cus : 256) * kObsBlocksPerCu;
-        visual_obs_lds_kernel<<<want < cap ? want : cap, kObsThreads, 0, hs>>>(*p, *b, *m, obs);
-    }
-    else visual_obs_kernel<<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
+    visual_obs_kernel<<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
 }
 
 // K env.step()s in ONE launch with pre-staged actions [K][n][2] (open-loop rollouts; quad form, n <= 32 768), the visual

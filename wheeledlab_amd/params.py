@@ -124,6 +124,6 @@ def visual_params():
     p.fx = 80 * 1.9299999475479126 / 3.8959999084472656                 # :236-238
     p.fy = 60 * 1.9299999475479126 / 2.453000068664551
     p.cx, p.cy = 40.0, 30.0
-    p.sky, p.brightness, p.contrast, p.blur_sigma = 0.5, 1.0, 1.0, 0.0
+    p.sky, p.brightness, p.contrast, p.blur_sigma, p.contrast_first = 0.5, 1.0, 1.0, 0.0, 0
     p.log_episode_sums = 1
     return p
