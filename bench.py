@@ -325,6 +325,7 @@ def main():
     ap.add_argument("--sweep", action="store_true", help="(default at N=1) large-N sweep of the same kernel: the HBM-bound regime")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--sweep-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--headline-only", action="store_true", help="only the timed headline workload: no secondary sections, no CPU baseline")
     args = ap.parse_args()
     if args.sweep_child:
         assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
@@ -332,6 +333,8 @@ def main():
         print(json.dumps({"drift": large_n_sweep(d0), "other": other_tasks_sweep(d0)}), flush=True)
         return
 
+    if args.headline_only:
+        args.no_sweep = args.no_cpu_baseline = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -473,7 +476,7 @@ def main():
     # secondary: the same K-step rollouts as ONE persistent launch each (state in registers across steps; only possible
     # with pre-staged actions, so it is NOT the headline; the policy-in-the-loop form follows)
     persistent = None
-    if rank == 0 and world == 1 and n <= 32768:
+    if rank == 0 and world == 1 and n <= 32768 and not args.headline_only:
         env.rollout(actions, obs_buf, rew_buf, term_buf, trunc_buf, persistent=True)
         torch.cuda.synchronize()
         p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -490,7 +493,7 @@ def main():
     # rsl_rl_ppo_cfg.py:6) as ONE launch with the actor on the f32 matrix pipe + the critic over the stored observations;
     # next to it the same loop with per-step launches and the actor in torch (what a rsl_rl user runs today)
     policy = None
-    if rank == 0 and world == 1 and n <= 32768:
+    if rank == 0 and world == 1 and n <= 32768 and not args.headline_only:
         from wheeledlab_amd.policy import ActorCritic, RolloutStorage
         ac = ActorCritic(device=dev, seed=0)
         store = RolloutStorage(ROLLOUT, n, device=dev)
@@ -528,7 +531,7 @@ def main():
 
     # secondary: whole training iterations (fused collection + GAE + 20 fused PPO minibatch steps), env-steps/s end to end
     train = None
-    if rank == 0 and world == 1 and n <= 32768:
+    if rank == 0 and world == 1 and n <= 32768 and not args.headline_only:
         import wheeledlab_amd.tasks  # noqa: F401
         from wheeledlab_amd import registry
         from wheeledlab_amd.rl import ClipAction, RslRlVecEnvWrapper
@@ -552,7 +555,7 @@ def main():
 
     # secondary: the other two tasks at the same env count (configs[2] and [4] of BASELINE.json), per-step launches
     other = {}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.headline_only:
         from wheeledlab_amd.core import ElevBatch, VisualBatch
         for name, cls, k in (("elevation", ElevBatch, 32), ("visual", VisualBatch, 16)):
             t = cls(n, device=dev, seed=42)
@@ -650,7 +653,7 @@ def main():
     # secondary: BASELINE.json configs[4]'s named kernel -- the depth ray-cast of the visual task's camera against the
     # heightfield: n cars of the elevation task standing on the synthetic 800 x 800 terrain after 8 steps, one 60 x 80
     # distance_to_image_plane image each (clipping range 100 m, visual/mushr_visual_env_cfg.py:240)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.headline_only:
         from wheeledlab_amd.core import DepthCamera, ElevBatch
         t = ElevBatch(n, device=dev, seed=42)
         t.reset()
@@ -678,7 +681,7 @@ def main():
     # secondary: the same workload driven step by step through the drop-in Python surface
     # (registry.make -> ClipAction -> RslRlVecEnvWrapper.step), i.e. what a Python RL loop sees per env.step() call
     py_rate = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.headline_only:
         from wheeledlab_amd import registry, tasks  # noqa: F401
         from wheeledlab_amd.rl import ClipAction, RslRlVecEnvWrapper
         cfg = registry.parse_env_cfg("Isaac-MushrDriftRL-v0", device=str(dev), num_envs=n)
