@@ -14,7 +14,11 @@
 //      contiguous dword stores -- this launch carries ~90 % of the task's HBM bytes (2.7 KB / env).  (Staging the env's
 //      terrain patch in LDS -- its bounding box fetched row by row with coalesced 8-byte requests, corners read from
 //      the tile -- was measured slower in every form tried: block per env 15.8 us, persistent blocks with the next
-//      env's pose prefetched 18 us, against 11.3 us for the gathers; round 2)
+//      env's pose prefetched 18 us, against 11.3 us for the gathers; round 2, DESIGN.md section 6.  Round 3: the same for the
+//      PHYSICS -- the 24 x 24 grid points under each car staged in LDS by all eight wavefronts of the fused kernel, the wheel
+//      contacts of the 20 sub-steps reading their corners from there: + 2.7 us for the staging and NOTHING back per sub-step
+//      (1.12 against 1.09 us per decimation step): the sub-step is a dependent VALU chain, its two gathers per wheel are
+//      already hidden behind it.)
 #include <hip/hip_runtime.h>
 
 #include "../../include/wheeledlab_amd.h"
@@ -214,13 +218,11 @@ WL_DEV ElevBook load_elev_book(const WlElevParams& p, const WlEnvBuffers& b, con
 // one env.step() of env `e` (all LANES lanes of the env take part): the body of the step kernels below.
 // PERSIST: the env's rows and bookkeeping live in `rows` / `*carry` across calls (persistent rollout): nothing is loaded
 // from or stored to the state matrix here, both are updated in place.
-// PG: the ground the PHYSICS samples (the field itself, or PatchGround: its LDS-staged copy around the car); resets and the
-// rest read `ground`.
-template <int LANES, bool PERSIST = false, class PG = HeightFieldGround>
-WL_DEV ScanPose elev_env_step_on(const WlElevParams& p, const VehDerived& vd, const WlEnvBuffers& b, const HeightFieldGround& ground,
-                                 const PG& phys_ground, const float2 action, ElevRows<LANES>& rows, const WlStepOut& out,
-                                 const uint64_t seed, const uint64_t step, const Rows& S, const int e, const int wid, const bool lead,
-                                 float* blk_metrics, ElevBook* carry = nullptr, float* prop2 = nullptr) {
+template <int LANES, bool PERSIST = false>
+WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const WlEnvBuffers& b, const HeightFieldGround& ground,
+                              const float2 action, ElevRows<LANES>& rows, const WlStepOut& out, const uint64_t seed,
+                              const uint64_t step, const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics,
+                              ElevBook* carry = nullptr, float* prop2 = nullptr) {
     const WlVehicleParams& vp = p.vehicle;
     const uint32_t gid = (uint32_t)(b.env_offset + e);
     float2 a = action;
@@ -274,7 +276,7 @@ WL_DEV ScanPose elev_env_step_on(const WlElevParams& p, const VehDerived& vd, co
         tgt_in[3] = S.ld(WL_S_CMD_TIMER, e);
     };
     if constexpr (LANES == 4) fetch_bookkeeping();
-    vehicle_integrate<LANES>(vp, vd, ec, s, phys_ground, wid);
+    vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
     if constexpr (LANES != 4) {
         asm volatile("" ::: "memory");
         fetch_bookkeeping();
@@ -381,13 +383,6 @@ WL_DEV ScanPose elev_env_step_on(const WlElevParams& p, const VehDerived& vd, co
     float yc, ys;
     yaw_cs(s.q, yc, ys);
     return ScanPose{pos.x, pos.y, pos.z, yc, ys};
-}
-template <int LANES, bool PERSIST = false>
-WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const WlEnvBuffers& b, const HeightFieldGround& ground,
-                              const float2 action, ElevRows<LANES>& rows, const WlStepOut& out, const uint64_t seed,
-                              const uint64_t step, const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics,
-                              ElevBook* carry = nullptr, float* prop2 = nullptr) {
-    return elev_env_step_on<LANES, PERSIST>(p, vd, b, ground, ground, action, rows, out, seed, step, S, e, wid, lead, blk_metrics, carry, prop2);
 }
 
 template <int LANES>
@@ -501,27 +496,11 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     __shared__ ScanPose pose[kFusedEnvs];
     __shared__ __attribute__((aligned(16))) float hbuf[POLICY ? 2 * 3 * kMlpTiles * 64 * 4 : 4];   // partial accumulators [net][share - 1][tile][lane][4]
     __shared__ float2 act_lds[kFusedEnvs];
-    // the terrain under each of the block's cars, staged by all eight wavefronts while wavefront 0's own state rows are in
-    // flight (BASELINE config 3: "heightfield gather + contact in LDS"); the policy form keeps the direct gathers
-    __shared__ float patches[POLICY ? 1 : kFusedEnvs * kPatchFloats];
     const int tid = threadIdx.x;
     if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
     if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
     const int e0 = blockIdx.x * kFusedEnvs;
-    constexpr int kStagePer = (kFusedEnvs * kPatchFloats + kFusedThreads - 1) / kFusedThreads;
-    float stage[POLICY ? 1 : kStagePer];
-    if constexpr (!POLICY) {
-        const Rows S0 = make_rows(b.state, b.stride);
-#pragma unroll
-        for (int k = 0; k < kStagePer; ++k) {     // every request goes out before the first LDS write
-            const int idx = tid + k * kFusedThreads;
-            const int j = idx / kPatchFloats, r = idx - j * kPatchFloats;
-            const int ee = min(e0 + j, b.n_envs - 1);
-            const PatchOrigin po = patch_origin(ground, S0.ld(WL_S_PX, ee), S0.ld(WL_S_PY, ee));
-            stage[k] = patch_point(ground, po, r % kPatchPts, r / kPatchPts);
-        }
-    }
     if constexpr (POLICY) {
         const int lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
         const int which = wave >> 2, share = wave & 3;        // net, share of the features
@@ -619,13 +598,6 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
             }
         }
     }
-    if constexpr (!POLICY) {
-#pragma unroll
-        for (int k = 0; k < kStagePer; ++k) {
-            const int idx = tid + k * kFusedThreads;
-            if (idx < kFusedEnvs * kPatchFloats) patches[idx] = stage[k];
-        }
-    }
     __syncthreads();
     if (tid < 64) {
         const int wid = tid & 3, e = e0 + (tid >> 2);
@@ -656,13 +628,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
             if (go) {
                 keep_scalar_common(p, p_arg);
                 vd.n_sub = vd_arg.n_sub;
-                ScanPose sp;
-                if constexpr (POLICY) {
-                    sp = elev_env_step<4>(p, vd, b, ground, a, rows, out, seed, step, S, e, wid, wid == 0, blk_metrics);
-                } else {
-                    const PatchGround pg{ground, patches + (tid >> 2) * kPatchFloats, patch_origin(ground, rows.pos.x, rows.pos.y)};
-                    sp = elev_env_step_on<4, false>(p, vd, b, ground, pg, a, rows, out, seed, step, S, e, wid, wid == 0, blk_metrics);
-                }
+                const ScanPose sp = elev_env_step<4>(p, vd, b, ground, a, rows, out, seed, step, S, e, wid, wid == 0, blk_metrics);
                 if (wid == 0) pose[tid >> 2] = sp;
             }
         }

@@ -74,60 +74,4 @@ struct HeightFieldGround {
 
 inline HeightFieldGround make_ground(const WlHeightField* hf) { return HeightFieldGround{*hf, 1.f / hf->cell}; }
 
-// The same sampler with the terrain around ONE car staged in LDS: kPatchPts x kPatchPts grid points (23 x 23 cells = 1.15 m
-// square at the 0.05 m grid) around the root's cell at the start of the env.step().  The 20 integrator sub-steps of an
-// elevation step each sample the ground under four wheels -- a chain of dependent gathers whose L2 latency is most of a
-// sub-step; from LDS the corners arrive in a tenth of the time.  Same arithmetic as HeightFieldGround::sample_full (cell
-// index, fractions, blend), same values (the patch is a copy): bit-identical results.  A wheel that leaves the patch (wheel
-// base 0.19 m from the root + at most 0.3 m of travel per step fit with room to spare; a car in free fall may not) reads the
-// field itself.
-constexpr int kPatchPts = 24, kPatchFloats = kPatchPts * kPatchPts;
-struct PatchOrigin {
-    int i0, j0;
-};
-WL_DEV PatchOrigin patch_origin(const HeightFieldGround& g, float px, float py) {
-    const float u = (px - g.f.x0) * g.inv_cell, v = (py - g.f.y0) * g.inv_cell;
-    // float -> int saturates; the clamp keeps products with nx inside 32 bits for cars far off the field
-    const int ic = min(max((int)floorf(u), -65536), 65536), jc = min(max((int)floorf(v), -65536), 65536);
-    return PatchOrigin{ic - (kPatchPts / 2 - 1), jc - (kPatchPts / 2 - 1)};
-}
-// grid point (li, lj) of the patch = field point clamped into the grid (points beyond the border are never used as such: the
-// sampler's own `inside` test sends those samples to outside_z)
-WL_DEV float patch_point(const HeightFieldGround& g, PatchOrigin o, int li, int lj) {
-    const int i = min(max(o.i0 + li, 0), g.f.nx - 1), j = min(max(o.j0 + lj, 0), g.f.ny - 1);
-    return g.f.height[(int64_t)j * g.f.nx + i];
-}
-struct PatchGround {
-    static constexpr bool kFlat = false;
-    HeightFieldGround g;
-    const float* patch;   // LDS, [kPatchPts][kPatchPts]
-    PatchOrigin o;
-    WL_DEV void sample(float x, float y, float& z, V3& n) const {
-        const WlHeightField& f = g.f;
-        const float inv_cell = g.inv_cell;
-        const float u = (x - f.x0) * inv_cell, v = (y - f.y0) * inv_cell;
-        const bool inside = u >= 0.f && v >= 0.f && u < (float)(f.nx - 1) && v < (float)(f.ny - 1);
-        const float uc = fminf(fmaxf(u, 0.f), (float)(f.nx - 1) - 1e-3f), vc = fminf(fmaxf(v, 0.f), (float)(f.ny - 1) - 1e-3f);
-        const float fi = floorf(uc), fj = floorf(vc);
-        const int i = (int)fi, j = (int)fj;
-        const float fu = uc - fi, fv = vc - fj;
-        const int li = i - o.i0, lj = j - o.j0;
-        float h00, h10, h01, h11;
-        if ((unsigned)li < (unsigned)(kPatchPts - 1) && (unsigned)lj < (unsigned)(kPatchPts - 1)) {
-            const float* r = patch + lj * kPatchPts + li;
-            h00 = r[0], h10 = r[1], h01 = r[kPatchPts], h11 = r[kPatchPts + 1];
-        } else {
-            const float* row0 = f.height + (int64_t)j * f.nx + i;
-            h00 = row0[0], h10 = row0[1], h01 = row0[f.nx], h11 = row0[f.nx + 1];
-        }
-        const float a = fmaf(fu, h10 - h00, h00), b = fmaf(fu, h11 - h01, h01);
-        const float zz = fmaf(fv, b - a, a);
-        const float dzdx = fmaf(fv, (h11 - h01) - (h10 - h00), h10 - h00) * inv_cell;
-        const float dzdy = (b - a) * inv_cell;
-        const float inv_len = rsq(fmaf(dzdx, dzdx, fmaf(dzdy, dzdy, 1.f)));
-        z = inside ? zz : f.outside_z;
-        n = inside ? v3(-dzdx * inv_len, -dzdy * inv_len, inv_len) : v3(0.f, 0.f, 1.f);
-    }
-};
-
 }  // namespace
