@@ -388,6 +388,9 @@ def out_of_map(env):                                            # :390-398
     return env._eval_visual_terms()["out_of_map"]
 
 
+_CAMERA = SceneEntityCfg("camera")
+
+
 def camera_data_rgb_flattened_aug(env, sensor_cfg=None):        # mdp_sensors/observations.py:75-87
     return env._batch.observe()[:, : A.VIS_NPIX]
 
@@ -401,9 +404,19 @@ def camera_data_rgb_flattened(env, sensor_cfg=None):            # mdp_sensors/ob
     return out
 
 
-def raycast_depth(env, sensor_cfg=None, heightfield=None, max_depth: float = 20.0):   # mdp_sensors/observations.py:93-95
-    """extension (unused in the reference): distance_to_image_plane against a heightfield"""
-    return env._batch.depth(heightfield, max_depth)
+def camera_data_depth(env, sensor_cfg=_CAMERA):                 # mdp_sensors/observations.py:89-91
+    """distance_to_image_plane of the robot's camera [N, 60, 80, 1] (defined but unwired in the reference's VisualObsCfg)"""
+    return env.scene.sensors[sensor_cfg.name].data.output["distance_to_image_plane"]
+
+
+def raycast_depth(env, sensor_cfg=_CAMERA, heightfield=None, max_depth: float | None = None):   # mdp_sensors/observations.py:93-95
+    """the same data; `heightfield` / `max_depth` (not in the reference): render against another terrain / range"""
+    if heightfield is None and max_depth is None:
+        return camera_data_depth(env, sensor_cfg)
+    far = env.scene.sensors[sensor_cfg.name].data.far if max_depth is None else max_depth
+    if heightfield is None:
+        return env.scene.sensors[sensor_cfg.name].data._camera().render(env._batch, far).unsqueeze(-1)
+    return env._batch.depth(heightfield, far).unsqueeze(-1)
 
 
 @_event("reset_traversable")

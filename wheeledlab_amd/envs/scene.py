@@ -163,6 +163,54 @@ class RayCasterView:
         self.num_instances = batch.n
 
 
+class CameraData:
+    """`sensor.data` of the robot's camera (isaaclab TiledCamera, un-vendored) as far as the reference's observation functions
+    read it: `output["distance_to_image_plane"]` [N, 60, 80, 1] (mdp_sensors/observations.py:89-95 `camera_data_depth` /
+    `raycast_depth`), rendered on access by the depth ray-cast kernel (wl_visual_depth) against the task's terrain -- the
+    heightfield of the elevation task, the z = 0 plane of the others -- and clipped at the camera's far plane."""
+
+    def __init__(self, batch, cfg):
+        self._b, self._cam = batch, None
+        clip = getattr(getattr(cfg, "spawn", None), "clipping_range", None) or (0.01, 100.0)
+        self.far = float(clip[1])
+
+    def _camera(self):
+        if self._cam is None:
+            from ..core import DepthCamera
+            b = self._b
+            if hasattr(b, "height"):        # elevation task: its own heightfield (already on the device)
+                hf = (b.height, float(b._hf.x0), float(b._hf.y0), float(b._hf.cell))
+            else:                           # flat ground: any grid at z = 0 (beyond it the outside plane is z = 0 as well)
+                hf = (torch.zeros(3, 3, dtype=torch.float32, device=b.device), -1.0, -1.0, 1.0)
+            self._cam = DepthCamera(hf, b.device, b.p if isinstance(b.p, A.WlVisualParams) else None)
+        return self._cam
+
+    @property
+    def output(self):
+        return _CameraOutputs(self)
+
+
+class _CameraOutputs:
+    def __init__(self, data):
+        self._d = data
+
+    def __getitem__(self, key):
+        if key != "distance_to_image_plane":
+            raise KeyError(f"camera data type {key!r} is not rendered here (the fused observation carries the grey image)")
+        d = self._d
+        return d._camera().render(d._b, d.far).unsqueeze(-1)
+
+    def keys(self):
+        return ["distance_to_image_plane"]
+
+
+class CameraView:
+    def __init__(self, batch, cfg):
+        self.cfg = cfg
+        self.data = CameraData(batch, cfg)
+        self.num_instances = batch.n
+
+
 class SceneView:
     def __init__(self, batch, cfg=None, task: str = "drift"):
         self._b = batch
@@ -174,6 +222,8 @@ class SceneView:
         self.sensors = {}
         if task == "elevation" and getattr(cfg, "height_scanner", None) is not None:
             self.sensors["height_scanner"] = RayCasterView(batch, cfg.height_scanner)
+        if getattr(cfg, "camera", None) is not None:
+            self.sensors["camera"] = CameraView(batch, cfg.camera)
         self.terrain = getattr(cfg, "terrain", None)
 
     def __getitem__(self, key):
