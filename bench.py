@@ -675,7 +675,7 @@ def main():
                                  "image": "60 x 80 fp32 distance_to_image_plane", "hit_fraction": hit,
                                  "workload": f"{n} elevation-task cars on the synthetic 800 x 800 heightfield (0.05 m), max depth 100 m",
                                  "roofline": roofline_block("depth", n, dus, "visual_depth_kernel",
-                                                            "valu+latency (pyramid walk: dependent gathers; the image write is the only HBM stream)")}
+                                                            "valu issue + divergence (max-pyramid walk, one wavefront per 4 x 16 pixel tile; the image write is the only HBM stream)")}
         del t, cam, img
 
     # secondary: the same workload driven step by step through the drop-in Python surface
