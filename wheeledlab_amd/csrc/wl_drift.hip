@@ -21,7 +21,7 @@ constexpr int kHotArgBytes = 56;   // state 0, episode_len 8, actions 16, stride
 // QB (quad form): threads per block.  The wavefronts of a block share a CU; at 4096 envs (256 wavefronts) blocks of 256
 // threads put four of them on each of 64 CUs and leave 192 CUs idle: 6.63 us per launch against 6.27 with 128 threads and
 // 6.37 with 64 (1024 envs: 6.38 / 6.03 / 5.87; 16 384 envs: 7.61 / 8.79 / 8.39) -- launch_step picks by env count.
-template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1, int QB = kBlock>
+template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1, int QB = kBlock, bool STREAM = false>
 __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? WL_LANE_WAVES : WL_LOWREG_WAVES)) drift_step_kernel(float* __restrict__ state, int32_t* __restrict__ episode_len,
                                                             const float2* __restrict__ actions, const int stride,
                                                             const int n_envs, const int env_offset, const uint64_t seed,
@@ -50,8 +50,9 @@ __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? 
     const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
     const MetricSink<LANES> ms{wave_metrics + (LANES == 1 ? wave * WL_M_COUNT : 0), metric_shard(b, slots.cur)};
     ms.open();
-    // the fenced lane form is the one the launcher picks beyond 262 144 envs: state and outputs stream through the caches
-    constexpr bool kStreaming = LANES == 1 && !UNROLL;
+    // STREAM: the launcher sets it when the state matrix alone outgrows the 256 MB Infinity Cache (below that the rows written now
+    // are the next step's cache hits: at 1 M envs the non-temporal stores cost 4 %, at 4 M they gain 4 %)
+    constexpr bool kStreaming = STREAM;
     if (e < b.n_envs) {
         const Rows S = make_rows(b.state, b.stride, kStreaming);
         EnvConst ec;
@@ -269,6 +270,9 @@ const char* wl_strerror(int code) {
     }
 }
 
+// state matrices larger than this are streamed (sc1 nt stores): the Infinity Cache is 256 MB and the outputs want their share
+constexpr int64_t kStreamingStateBytes = 192ll << 20;   // = 1.22 M envs
+
 // one fused env.step() launch in the form the batch size (or WlEnvBuffers.lanes) selects
 static void launch_step(const WlDriftParams* p, const WlEnvBuffers* b, const VehDerived& vd, const float2* actions, const float* noise,
                         const WlStepOut& out, uint64_t seed, uint64_t step, hipStream_t stream) {
@@ -285,9 +289,12 @@ static void launch_step(const WlDriftParams* p, const WlEnvBuffers* b, const Veh
     else if (use_unrolled(b)) {
         if (awd) drift_step_kernel<1, FlatGround, true, 1><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
         else drift_step_kernel<1, FlatGround, true, 0><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
-    } else {
+    } else if ((int64_t)b->stride * 4 * WL_S_COUNT <= kStreamingStateBytes) {
         if (awd) drift_step_kernel<1, FlatGround, false, 1><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
         else drift_step_kernel<1, FlatGround, false, 0><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
+    } else {
+        if (awd) drift_step_kernel<1, FlatGround, false, 1, kBlock, true><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
+        else drift_step_kernel<1, FlatGround, false, 0, kBlock, true><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
     }
 #undef WL_STEP_ARGS
 }

@@ -16,7 +16,7 @@ constexpr int kBlock = 256;
 struct Rows {
     __amdgpu_buffer_rsrc_t rsrc;
     int row_bytes;   // stride * 4
-    // streaming: the batch is far larger than the caches (the > 262 144-env form of the drift step): rows written now are not
+    // streaming: the batch is far larger than the caches (state matrix > 192 MB: the drift step beyond 1.2 M envs): rows written now are not
     // read again before they are evicted, so their stores carry the `sc1 nt` policy (cache-policy operand 18: bit 1 nt, bit 4
     // sc1).  Measured on the step's own pattern (34 SoA rows in, 30 out, 4 M envs; tools/microbench/layout_bw): 5.24 TB/s with
     // default stores, 6.15 TB/s with sc1 nt.  A compile-time constant wherever it is used (set from a template parameter,
