@@ -423,6 +423,7 @@ constexpr int kScanThreads = 128;                       // threads per env: 676 
 constexpr int kScanEnvsPerBlock = kBlock / kScanThreads;
 // 4096 envs x 128 threads = 8192 wavefronts = exactly one resident round of the chip (32 waves x 256 CUs); with 256
 // threads per env the launch needs two rounds and each round pays the pose-load + gather latency chain again.
+template <bool STREAM>   // observation rows of the launch beyond the Infinity Cache: non-temporal stores
 __global__ void __launch_bounds__(kBlock) elev_scan_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
                                                            float* __restrict__ obs) {
     const int e = blockIdx.x * kScanEnvsPerBlock + threadIdx.x / kScanThreads;
@@ -454,9 +455,15 @@ __global__ void __launch_bounds__(kBlock) elev_scan_kernel(const WlElevParams p,
             const float hz = ground.blend(cr[it]);
             // world_height_map = -(sensor_z - hit_z - offset) + (root_z - plane_init_value); rays that miss return +inf
             const float val = cr[it].inside ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
-            row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
+            if constexpr (STREAM) __builtin_nontemporal_store(clampf(val, -p.obs_clip, p.obs_clip), row + 13 + k);
+            else row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
         }
     }
+}
+inline void launch_elev_scan(const WlElevParams* p, const WlEnvBuffers* b, const HeightFieldGround& g, float* obs, hipStream_t hs) {
+    const int grid = (b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock;
+    if ((int64_t)b->n_envs * WL_ELEV_OBS_DIM * 4 > (256ll << 20)) elev_scan_kernel<true><<<grid, kBlock, 0, hs>>>(*p, *b, g, obs);
+    else elev_scan_kernel<false><<<grid, kBlock, 0, hs>>>(*p, *b, g, obs);
 }
 
 // env.step() AND the height scan as ONE launch (quad form, n <= 32 768): block = 16 envs, 8 wavefronts.  Wavefront 0
@@ -1137,7 +1144,7 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
             elev_step_scan_kernel<false><<<(b->n_envs + kFusedEnvs - 1) / kFusedEnvs, kFusedThreads, 0, (hipStream_t)stream>>>(*p, vd, *b, g, a, o, seed, step0 + (uint64_t)k, PolicyIo{});
         } else {
             elev_step_kernel<1><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, vd, *b, g, a, o, seed, step0 + (uint64_t)k);
-            elev_scan_kernel<<<(b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock, kBlock, 0, (hipStream_t)stream>>>(*p, *b, g, o.obs);
+            launch_elev_scan(p, b, g, o.obs, (hipStream_t)stream);
         }
     }
     return launch_status();
@@ -1237,7 +1244,7 @@ int wl_elev_observe(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
     if (!obs) return WL_EINVAL;
     clear_error();
     elev_prop_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, obs);
-    elev_scan_kernel<<<(b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock, kBlock, 0, (hipStream_t)stream>>>(*p, *b, make_ground(hf), obs);
+    launch_elev_scan(p, b, make_ground(hf), obs, (hipStream_t)stream);
     return launch_status();
 }
 

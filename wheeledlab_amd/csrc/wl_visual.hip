@@ -316,7 +316,8 @@ constexpr int kPitch = kImgW + 4, kImgFloats = kImgH * kPitch;
 // by a group of GT threads (gt = thread in the group; `img` [kImgFloats] and `red` [GT / 64] are the group's LDS).  Two
 // `sync()`s inside when the augmentation needs the whole image; a group without an env (`valid` false) renders its
 // neighbour's pose and stores nothing.
-template <int GT, class SYNC, class LOOKUP>
+// STREAM: the observation block is far larger than the caches (> 256 MB of rows per launch): non-temporal row stores
+template <int GT, bool STREAM = false, class SYNC, class LOOKUP>
 WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOKUP& lookup, const CamPose& cp, float* __restrict__ row,
                          float* img, float* red, const int gt, const bool valid, SYNC& sync) {
     const V3 pos = v3(cp.px, cp.py, cp.pz);
@@ -371,7 +372,10 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
             float v = hit[it] ? (cell[it] ? 1.f : 0.f) : p.sky;
             if (!cfirst) v = clampf(v * p.brightness, 0.f, 1.f);       // ColorJitter brightness (before the contrast blend)
             if (plain) {
-                if (valid) row[r * kImgW + tc] = (v * 0.9999f - 0.5f) * 2.f;   // grayscale + Normalize([0.5], [0.5]) straight to HBM
+                if (valid) {   // grayscale + Normalize([0.5], [0.5]) straight to HBM
+                    if constexpr (STREAM) __builtin_nontemporal_store((v * 0.9999f - 0.5f) * 2.f, row + r * kImgW + tc);
+                    else row[r * kImgW + tc] = (v * 0.9999f - 0.5f) * 2.f;
+                }
             } else {
                 float* line = img + r * kPitch + 2;
                 line[tc] = v;
@@ -436,7 +440,12 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
                 o4[oc] = (fmaf(oc_, g, om_) * 0.9999f - 0.5f) * 2.f;   // (folded contrast,) grayscale + Normalize([0.5], [0.5])
             }
             // row base = e * 3208 floats = e * 12832 B (16-B aligned), patch column is a multiple of 4 floats
-            *reinterpret_cast<float4*>(row + (pr + orow) * kImgW + pc) = out4;
+            if constexpr (STREAM) {
+                typedef float wl_f4v __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(wl_f4v{out4.x, out4.y, out4.z, out4.w}, reinterpret_cast<wl_f4v*>(row + (pr + orow) * kImgW + pc));
+            } else {
+                *reinterpret_cast<float4*>(row + (pr + orow) * kImgW + pc) = out4;
+            }
         }
     }
 }
@@ -449,6 +458,7 @@ WL_DEV CamPose load_cam_pose(const Rows& S, const int e) {
 
 // block = env: the observation of the state as it stands (reset / first observation / lane-form steps); map cells by byte
 // gathers from global memory (maps too large for LDS, or no bit map supplied)
+template <bool STREAM>
 __global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
                                                           float* __restrict__ obs) {
     __shared__ __attribute__((aligned(16))) float img[kImgFloats];
@@ -456,7 +466,7 @@ __global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p
     const int e = blockIdx.x;
     const CamPose cp = load_cam_pose(make_rows(b.state, b.stride), e);
     BlockSync sync;
-    render_image<kCam>(p, m, GlobalMapLookup{m.map}, cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img, red, (int)threadIdx.x, true, sync);
+    render_image<kCam, STREAM>(p, m, GlobalMapLookup{m.map}, cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img, red, (int)threadIdx.x, true, sync);
 }
 
 // (Round 3: the same camera with the whole map in LDS as one bit per cell -- persistent blocks of three render groups, map staged
@@ -465,7 +475,9 @@ __global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p
 // gives up a quarter of the resident wavefronts for its 32 KB.  In the persistent rollout below, where the blocks are resident
 // for the whole rollout anyway, the LDS map does pay: 29.0 -> 26.0 us per step plain, 37.5 -> 35.9 augmented.)
 inline void launch_visual_obs(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, float* obs, hipStream_t hs) {
-    visual_obs_kernel<<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
+    // rows of one launch beyond the 256 MB Infinity Cache (> 20 000 envs): stream them past the caches
+    if ((int64_t)b->n_envs * WL_VIS_OBS_DIM * 4 > (256ll << 20)) visual_obs_kernel<true><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
+    else visual_obs_kernel<false><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
 }
 
 // K env.step()s in ONE launch with pre-staged actions [K][n][2] (open-loop rollouts; quad form, n <= 32 768), the visual
