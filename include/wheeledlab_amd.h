@@ -465,12 +465,6 @@ typedef struct WlHeightField {
     const float* height;
     int32_t nx, ny;
     float x0, y0, cell, outside_z;
-    /* optional: the same field with every point stored next to its +y neighbour, pairs[j][i] = { height[j][i],
-       height[min(j + 1, ny - 1)][i] } (2 floats per point, [ny][nx][2]).  The four corners of cell (i, j) are then 16 contiguous
-       bytes -- pairs[j][i], pairs[j][i + 1] -- and a bilinear sample is ONE gather instead of two: the height scan (676 rays
-       per env) is bound by the rate at which the cache takes divergent line look-ups, not by bytes.  NULL: two 8-byte gathers
-       from `height`.  Same values either way. */
-    const float* pairs;
 } WlHeightField;
 
 enum WlElevRewTerm { WL_ER_GOAL_PROGRESS = 0, WL_ER_HIGHER_ELEVATION, WL_ER_FALLING, WL_ER_STUCK_PENALTY, WL_ER_NTERMS };

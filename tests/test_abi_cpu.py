@@ -131,7 +131,7 @@ def test_layout_of_task_structs_and_misuse_codes(tmp_path):
     ep = PP.elev_params()
     assert lib.wl_elev_step(C.byref(ep), C.byref(good), None, base, C.byref(out), 0, 0, None) == -1      # no heightfield
     # persistent elevation collector: observation rows k + 1 must be where the policy of step k + 1 reads them; quad form only
-    hfb = A.WlHeightField(base, 8, 8, 0.0, 0.0, 1.0, 0.0, None)
+    hfb = A.WlHeightField(base, 8, 8, 0.0, 0.0, 1.0, 0.0)
     net = lambda o: A.WlMlp(base, base, base, base, base, base, A.ELEV_OBS_DIM, o, 64, A.ACT_ELU)
     na, nc = net(2), net(1)
     io = A.WlCollectIo(base, base, base, base, base)

@@ -134,7 +134,7 @@ def test_invalid_arguments_are_refused(hf):
     assert lib.wl_visual_depth(*args(pyr=None)) == -1
     assert lib.wl_visual_depth(*args(out=None)) == -1
     assert lib.wl_visual_depth(*args(md=0.0)) == -1
-    bad_hf = A.WlHeightField(cam._hf.height, 1, 800, 0.0, 0.0, 0.05, 0.0, None)
+    bad_hf = A.WlHeightField(cam._hf.height, 1, 800, 0.0, 0.0, 0.05, 0.0)
     assert lib.wl_visual_depth(*args(hf=bad_hf)) == -1
     assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800
     assert lib.wl_heightfield_build_pyramid(C.byref(bad_hf), cam.pyramid.data_ptr(), None) == -1

@@ -245,21 +245,3 @@ def test_settled_cars_need_no_contact_excuse(lanes):
         d[:, 2:5] = np.minimum(d[:, 2:5], np.abs(2 * np.pi - d[:, 2:5]))
         assert d[:, :13].max() < 3e-3 and (d[:, 13:] > 2e-3).sum() <= 4
     assert float(np.abs(env.state[7:9, :n].cpu().numpy()).mean()) > 0.05     # they do drive
-
-
-@pytest.mark.parametrize("n", [300, 4096, 40000])
-def test_pair_layout_of_the_heightfield_gives_the_same_bits(n):
-    """WlHeightField.pairs (every grid point stored next to its +y neighbour: a cell's four corners in one 16-byte gather) against the
-    plain layout (two 8-byte gathers): same values, so every output of the step, the scan and the reset must be bit-identical --
-    in the fused quad form (n <= 32 768) and in the lane form with its separate scan kernel"""
-    ea, hf = _fresh(n, seed=6)
-    eb, _ = _fresh(n, seed=6)
-    eb._hf.pairs = None
-    assert ea._hf.pairs is not None
-    g = torch.Generator(device=DEV).manual_seed(0)
-    assert torch.equal(ea.observe(), eb.observe())
-    for k in range(5):
-        a = torch.rand(n, 2, device=DEV, generator=g) * 2 - 1
-        oa, ob = ea.step(a), eb.step(a)
-        assert all(torch.equal(x, y) for x, y in zip(oa, ob)), k
-    assert torch.equal(ea.state, eb.state) and torch.equal(ea.episode_len, eb.episode_len)

@@ -94,7 +94,7 @@ def test_device_walk_on_the_host_matches_the_oracle(hostlib, hf, max_depth):
     for field, seed in ((hf, 11), ((hf[0][:613, :349].copy(), hf[1], hf[2], hf[3]), 12)):
         pos, quat = DC.poses(96, seed=seed, hf=field, span=0.5 * min(field[0].shape) * float(field[3]) - 1.5)
         h = np.ascontiguousarray(field[0])
-        hfs = _abi.WlHeightField(h.ctypes.data, h.shape[1], h.shape[0], float(field[1]), float(field[2]), float(field[3]), 0.0, None)
+        hfs = _abi.WlHeightField(h.ctypes.data, h.shape[1], h.shape[0], float(field[1]), float(field[2]), float(field[3]), 0.0)
         got = np.zeros((len(pos), 60, 80), np.float32)
         assert hostlib.hs_depth(C.byref(vp), C.byref(hfs), len(pos), pos.ctypes.data, quat.ctypes.data, max_depth, got.ctypes.data) == 0
         want = D.depth(P, pos, quat, field, max_depth)

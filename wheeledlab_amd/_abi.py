@@ -74,7 +74,7 @@ class WlDriftParams(C.Structure):
 
 class WlHeightField(C.Structure):
     _fields_ = [("height", C.c_void_p), ("nx", C.c_int32), ("ny", C.c_int32), ("x0", C.c_float), ("y0", C.c_float),
-                ("cell", C.c_float), ("outside_z", C.c_float), ("pairs", C.c_void_p)]
+                ("cell", C.c_float), ("outside_z", C.c_float)]
 
 
 class WlElevParams(C.Structure):

@@ -235,10 +235,8 @@ class ElevBatch(_MetricsView):
         self.dones = torch.zeros(self.n, dtype=torch.long, device=dev)   # terminated | truncated, as RSL-RL consumes it
         h, x0, y0, cell = heightfield if heightfield is not None else synthetic_heightfield()
         self.height = torch.as_tensor(h, dtype=torch.float32).contiguous().to(dev)
-        # every grid point next to its +y neighbour: a cell's four corners in 16 contiguous bytes (one gather per bilinear sample)
-        self.height_pairs = torch.stack([self.height, torch.cat([self.height[1:], self.height[-1:]])], -1).contiguous()
         self._hf = A.WlHeightField(self.height.data_ptr(), self.height.shape[1], self.height.shape[0], float(x0), float(y0),
-                                   float(cell), 0.0, self.height_pairs.data_ptr())
+                                   float(cell), 0.0)
         # startup events (elevation cfg :387-407): wheel friction fixed (2.0, 1.0), base mass += U(0.2, 0.5)
         if startup is None:
             from .envs.flatten import StartupSpec
@@ -495,7 +493,7 @@ class DepthCamera:
         self.height = h if isinstance(h, torch.Tensor) and h.device == self.device and h.dtype == torch.float32 and h.is_contiguous() \
             else torch.as_tensor(h, dtype=torch.float32).contiguous().to(self.device)
         ny, nx = self.height.shape
-        self._hf = A.WlHeightField(self.height.data_ptr(), nx, ny, float(x0), float(y0), float(cell), float(outside_z), None)
+        self._hf = A.WlHeightField(self.height.data_ptr(), nx, ny, float(x0), float(y0), float(cell), float(outside_z))
         n_f = int(self.lib.wl_heightfield_pyramid_floats(nx, ny))
         if n_f <= 0:
             raise A.WlError(f"heightfield of {nx} x {ny} points is outside the pyramid's range")

@@ -7,12 +7,10 @@ namespace {
 
 // (Round 3: a pair layout -- every grid point stored next to its +y neighbour, so that a cell's four corners are ONE 16-byte
 // gather -- was measured: elevation step at 4096 envs 29.2 vs 26.2 us (the 5.1 MB table no longer fits an XCD's 4 MB L2), at
-// 262 144 envs 668 vs 685, at 1 M envs 2572 vs 2503: no gain where it fits nowhere, a loss where the plain field fits.  Reverted.)
+// 262 144 envs 668 vs 685, at 1 M envs 2572 vs 2503: no gain where nothing fits, a loss where the plain field does.  Reverted.)
 // two horizontally adjacent cells as ONE 8-byte gather (the address is only 4-byte aligned: fine for global loads on
 // gfx9+); halves the number of gather instructions per bilinear sample
 typedef float wl_float2_u __attribute__((ext_vector_type(2), aligned(4)));
-// all four corners of a cell as ONE 16-byte gather from the pair layout (WlHeightField.pairs): (h00, h01, h10, h11)
-typedef float wl_float4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 // bilinear heightfield sampler (spec: oracle/heightfield.py::sample)
 struct HeightFieldGround {
@@ -26,14 +24,8 @@ struct HeightFieldGround {
         const float fi = floorf(uc), fj = floorf(vc);
         const int i = (int)fi, j = (int)fj;
         const float fu = uc - fi, fv = vc - fj;
-        float h00, h10, h01, h11;
-        if (f.pairs) {
-            const wl_float4_u q = *reinterpret_cast<const wl_float4_u*>(f.pairs + 2 * ((int64_t)j * f.nx + i));
-            h00 = q.x, h01 = q.y, h10 = q.z, h11 = q.w;
-        } else {
-            const float* row0 = f.height + (int64_t)j * f.nx + i;
-            h00 = row0[0], h10 = row0[1], h01 = row0[f.nx], h11 = row0[f.nx + 1];
-        }
+        const float* row0 = f.height + (int64_t)j * f.nx + i;
+        const float h00 = row0[0], h10 = row0[1], h01 = row0[f.nx], h11 = row0[f.nx + 1];
         const float a = fmaf(fu, h10 - h00, h00), b = fmaf(fu, h11 - h01, h01);
         const float zz = fmaf(fv, b - a, a);
         const float dzdx = fmaf(fv, (h11 - h01) - (h10 - h00), h10 - h00) * inv_cell;
@@ -58,15 +50,9 @@ struct HeightFieldGround {
         const float fi = floorf(uc), fj = floorf(vc);
         c.fu = uc - fi;
         c.fv = vc - fj;
-        const int k = (int)fj * f.nx + (int)fi;
-        if (f.pairs) {
-            const wl_float4_u q = *reinterpret_cast<const wl_float4_u*>(f.pairs + 2 * k);
-            c.lo = wl_float2_u{q.x, q.z};
-            c.hi = wl_float2_u{q.y, q.w};
-        } else {
-            c.lo = *reinterpret_cast<const wl_float2_u*>(f.height + k);
-            c.hi = *reinterpret_cast<const wl_float2_u*>(f.height + k + f.nx);
-        }
+        const float* row0 = f.height + (int)fj * f.nx + (int)fi;
+        c.lo = *reinterpret_cast<const wl_float2_u*>(row0);
+        c.hi = *reinterpret_cast<const wl_float2_u*>(row0 + f.nx);
         return c;
     }
     WL_DEV float blend(const Corners& c) const {
@@ -80,16 +66,9 @@ struct HeightFieldGround {
         const float uc = fminf(fmaxf(u, 0.f), (float)(f.nx - 1) - 1e-3f), vc = fminf(fmaxf(v, 0.f), (float)(f.ny - 1) - 1e-3f);
         const float fi = floorf(uc), fj = floorf(vc);
         const float fu = uc - fi, fv = vc - fj;
-        const int64_t k = (int64_t)(int)fj * f.nx + (int)fi;
-        wl_float2_u lo, hi;
-        if (f.pairs) {
-            const wl_float4_u q = *reinterpret_cast<const wl_float4_u*>(f.pairs + 2 * k);
-            lo = wl_float2_u{q.x, q.z};
-            hi = wl_float2_u{q.y, q.w};
-        } else {
-            lo = *reinterpret_cast<const wl_float2_u*>(f.height + k);
-            hi = *reinterpret_cast<const wl_float2_u*>(f.height + k + f.nx);
-        }
+        const float* row0 = f.height + (int64_t)(int)fj * f.nx + (int)fi;
+        const wl_float2_u lo = *reinterpret_cast<const wl_float2_u*>(row0);
+        const wl_float2_u hi = *reinterpret_cast<const wl_float2_u*>(row0 + f.nx);
         const float a = fmaf(fu, lo.y - lo.x, lo.x), b = fmaf(fu, hi.y - hi.x, hi.x);
         z = inside ? fmaf(fv, b - a, a) : f.outside_z;
         return inside;
