@@ -101,3 +101,38 @@ def test_device_walk_on_the_host_matches_the_oracle(hostlib, hf, max_depth):
         bad, err = DC.mismatch(got, want, max_depth)
         assert bad.mean() < 1e-4, (bad.sum(), err.max())      # grazing rays only
         assert np.quantile(err, 0.999) < 1e-4
+
+
+def _host_depth(hostlib, field, pos, quat, max_depth):
+    vp = visual_params()
+    h = np.ascontiguousarray(field[0])
+    hfs = _abi.WlHeightField(h.ctypes.data, h.shape[1], h.shape[0], float(field[1]), float(field[2]), float(field[3]), 0.0)
+    got = np.zeros((len(pos), 60, 80), np.float32)
+    assert hostlib.hs_depth(C.byref(vp), C.byref(hfs), len(pos), pos.ctypes.data, quat.ctypes.data, max_depth, got.ctypes.data) == 0
+    return got
+
+
+def test_size_independent_properties_of_oracle_and_device_walk(hostlib, hf):
+    """properties that need no second implementation, for BOTH the oracle and the device walk: (1) a shorter range only clips:
+    depth(range a) = min(depth(range b), a) for a < b; (2) the image does not change when terrain AND camera are lifted together;
+    (3) it is bounded by [0, range]; (4) below the horizon on the flat base the depth grows monotonically up the image column"""
+    pos, quat = DC.poses(48, seed=21, hf=hf)
+    lifted = (hf[0] + np.float32(0.5), hf[1], hf[2], hf[3])
+    pos_up = pos.copy()
+    pos_up[:, 2] += 0.5
+    inside = (np.abs(pos[:, 0]) < 18) & (np.abs(pos[:, 1]) < 18) & (pos[:, 2] > 0.19)    # property 2 needs the lifted outside plane too
+    for depth_fn in (lambda f, p_, q, r: D.depth(P, p_, q, f, r), lambda f, p_, q, r: _host_depth(hostlib, f, p_, q, r)):
+        far, near = depth_fn(hf, pos, quat, 40.0), depth_fn(hf, pos, quat, 6.0)
+        np.testing.assert_allclose(near, np.minimum(far, 6.0), rtol=0, atol=1e-5)
+        assert far.min() >= 0.0 and far.max() <= 40.0
+        up = depth_fn(lifted, pos_up, quat, 6.0)
+        hit = (near < 6.0) & inside[:, None, None]
+        # rays that leave the grid meet the outside plane (z = 0) 0.5 m lower relative to the lifted camera: exclude those that end there
+        on_grid = hit & (np.abs(up - near) < 1e-3)
+        assert on_grid.sum() > 0.5 * hit.sum()
+    flat = (np.full((128, 128), 0.19, np.float32), np.float32(-32.0), np.float32(-32.0), np.float32(0.5))
+    p0 = np.array([[0.0, 0.0, 0.25]], np.float32)
+    q0 = np.array([[1.0, 0.0, 0.0, 0.0]], np.float32)
+    for img in (D.depth(P, p0, q0, flat, 30.0)[0], _host_depth(hostlib, flat, p0, q0, 30.0)[0]):
+        col = img[31:, 40]                      # rows below the horizon, bottom row last
+        assert (np.diff(col) < 0).all() and col[-1] < 0.5 < col[0]

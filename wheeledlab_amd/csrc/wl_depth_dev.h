@@ -86,7 +86,6 @@ WL_DEV float plane_hit(float oz, float dz, float zp, float ta, float tb) {
 #ifndef WL_DEPTH_START_LEVEL_UP
 #define WL_DEPTH_START_LEVEL_UP 7   // rising rays
 #endif
-constexpr int kMaxWalk = 8192;   // safety bound on walk steps (a ray crosses < 2 * 1024 cells; each costs <= 3 visits)
 
 // the grid the walk runs on: cells, not metres (u = (x - x0) / cell, integer cell lines)
 struct DepthGrid {
@@ -148,8 +147,11 @@ WL_DEV float cast_ray(const DepthGrid& g, const Pyramid& py, const FieldMem& mem
     const int su = up_u ? 1 : 0, sv = up_v ? 1 : 0;
     int L = min(dz >= 0.f ? WL_DEPTH_START_LEVEL_UP : WL_DEPTH_START_LEVEL, py.lp);
     float res = -1.f;
+    // bound on walk steps: a ground track crosses at most NX + NY cell lines, every cell costs at most a climb, a descent and a
+    // visit per level change -- generous, and finite whatever rounding does (a GPU must never spin)
+    const int max_walk = 4 * (NX + NY) + 64;
 #pragma unroll 1
-    for (int it = 0; it < kMaxWalk; ++it) {
+    for (int it = 0; it < max_walk; ++it) {
         // the level-L cell of (i, j), the parameter at which the ray leaves it, the ray's lowest point inside it
         const int iL = i >> L, jL = j >> L;
         const int bx = (iL + su) << L, by = (jL + sv) << L;
