@@ -676,6 +676,21 @@ def main():
                                  "workload": f"{n} elevation-task cars on the synthetic 800 x 800 heightfield (0.05 m), max depth 100 m",
                                  "roofline": roofline_block("depth", n, dus, "visual_depth_kernel",
                                                             "valu issue + divergence (max-pyramid walk, one wavefront per 4 x 16 pixel tile; the image write is the only HBM stream)")}
+        if not args.no_cpu_baseline:
+            # the CPU beside it: the oracle's exact cell-by-cell intersection (oracle/depth.c, double precision, OpenMP over the
+            # images) on this box's host cores, on the first 512 of the same poses
+            from oracle import depth as OD
+            from oracle import visual_step as OV
+            m = min(n, 512)
+            st = t.state[:, :m].cpu().numpy()
+            field = (t.height.cpu().numpy(), float(t._hf.x0), float(t._hf.y0), float(t._hf.cell))
+            OD.depth(OV.visual_params(), st[0:3, :8].T, st[3:7, :8].T, field, 100.0)        # builds / loads the library
+            c0 = time.perf_counter()
+            OD.depth(OV.visual_params(), st[0:3].T, st[3:7].T, field, 100.0)
+            c1 = time.perf_counter() - c0
+            other["visual_depth"]["cpu_baseline"] = {"value": m * 4800 / c1, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+                                                     "sample": f"{m} images of the same poses through oracle/depth.c (exact per-cell "
+                                                               f"intersection, double precision, OpenMP), {c1:.2f} s"}
         del t, cam, img
 
     # secondary: the same workload driven step by step through the drop-in Python surface
