@@ -155,6 +155,8 @@ WL_DEV float cast_ray(const DepthGrid& g, const Pyramid& py, const FieldMem& mem
         // the level-L cell of (i, j), the parameter at which the ray leaves it, the ray's lowest point inside it
         const int iL = i >> L, jL = j >> L;
         const int bx = (iL + su) << L, by = (jL + sv) << L;
+        // (line - origin) / direction -- NOT fma(line, 1 / d, -origin / d): for rays nearly parallel to a grid axis the two products
+        // are ~1e5 and their difference rounds to centimetres
         const float tx = ((float)bx - ou) * idu, ty = ((float)by - ov) * idv;
         const float te = fmaxf(fminf(fminf(tx, ty), t_stop), t);
         const float z_t = fmaf(t, dz, oz);
@@ -162,7 +164,7 @@ WL_DEV float cast_ray(const DepthGrid& g, const Pyramid& py, const FieldMem& mem
         const bool fine = L == 0;
         float h00, h10, h01, h11, m;
         if (fine) {
-            const int k = py.h0 + j * g.nx + i;
+            const int k = py.h0 + (int)__umul24((unsigned)j, (unsigned)g.nx) + i;   // j, nx < 2^24: the full-rate multiply
             mem.ld2(k, h00, h10);
             mem.ld2(k + g.nx, h01, h11);
             m = fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
