@@ -18,8 +18,8 @@ EDGE = np.array([
     [-7.0, 9.0, 0.45, 0.5, -0.4, 2.0],        # rolled over on a slope
     [12.0, -3.0, 0.60, 0.0, -0.6, -2.5],      # nose up (sky in most rows)
     [0.0, 0.0, 0.40, 0.0, 0.0, 0.0],          # axis-aligned
-    # the ground track of column 39 / 40 almost parallel to a grid axis (|du| or |dv| ~ 1e-6 cells per metre): the exit parameters
-    # of the walk are differences of large products there -- (line - origin) / d must not be computed as a fused a*b - c*d
+    # the ground track of column 39 / 40 almost parallel to a grid axis (|du| or |dv| ~ 1e-6 cells per metre): one of the walk's two
+    # exit parameters is then ~1e6 m away and every step leaves through the other axis
     [3.3, -4.7, 0.45, 0.0, 0.0, 1.5707963 - 0.5 / 39.6304],
     [3.3, -4.7, 0.45, 0.0, 0.0, 1.5707963 + 0.5 / 39.6304],
     [-6.1, 2.2, 0.50, 0.0, 0.0, 0.5 / 39.6304],

@@ -155,8 +155,10 @@ WL_DEV float cast_ray(const DepthGrid& g, const Pyramid& py, const FieldMem& mem
         // the level-L cell of (i, j), the parameter at which the ray leaves it, the ray's lowest point inside it
         const int iL = i >> L, jL = j >> L;
         const int bx = (iL + su) << L, by = (jL + sv) << L;
-        // (line - origin) / direction -- NOT fma(line, 1 / d, -origin / d): for rays nearly parallel to a grid axis the two products
-        // are ~1e5 and their difference rounds to centimetres
+        // (line - origin) / direction -- not fma(line, 1 / d, -origin / d), two instructions shorter: for rays nearly parallel to
+        // a grid axis the two products are ~1e5 and the exit parameter would carry their rounding (up to centimetres).  The walk
+        // survives that (a hit the shortened interval misses is caught by the next cell's entry test; the parity sets pass either
+        // way), but an exit parameter that is exact to rounding is worth two instructions
         const float tx = ((float)bx - ou) * idu, ty = ((float)by - ov) * idv;
         const float te = fmaxf(fminf(fminf(tx, ty), t_stop), t);
         const float z_t = fmaf(t, dz, oz);
