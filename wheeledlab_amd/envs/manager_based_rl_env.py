@@ -457,6 +457,8 @@ class ManagerBasedRLEnv:
         out = {}
         for key, (kind, i) in self._log_keys.items():
             out[key] = m[i] if kind == "c" else m[A.M_EPSUM0 + i] / resets / self.max_episode_length_s
+        for key, v in self._custom_log.items():      # terms that run as torch behind the kernel: their latest episode means / counts
+            out[key] = float(v)
         return out
 
     def _episode_log(self, slot):
