@@ -54,3 +54,23 @@ def mismatch(got, want, max_depth, rtol=2e-4, atol=2e-4):
     excused silently (the callers bound their number)."""
     err = np.abs(got.astype(np.float64) - want.astype(np.float64))
     return err > atol + rtol * np.abs(want), err
+
+
+def rough_fields(seed=3):
+    """terrains the max-pyramid cannot skip much of -- white noise, isolated spikes, stair steps -- with cameras above, inside and
+    on them, steeply tilted: (name, field, pos, quat) tuples"""
+    rng = np.random.RandomState(seed)
+    out = []
+    for name, h, cell in (("white noise", rng.uniform(0, 2, (256, 256)).astype(np.float32), 0.1),
+                          ("spikes", np.where(rng.rand(300, 200) < 0.02, 3.0, 0.0).astype(np.float32), 0.07),
+                          ("steps", (np.floor(np.arange(512)[None, :] / 32) * 0.25 + np.zeros((512, 1))).astype(np.float32), 0.05)):
+        ny, nx = h.shape
+        field = (h, np.float32(-0.5 * nx * cell), np.float32(-0.5 * ny * cell), np.float32(cell))
+        n = 48
+        xy = rng.uniform(-0.45 * min(nx, ny) * cell, 0.45 * min(nx, ny) * cell, (n, 2)).astype(np.float32)
+        z, _, _ = HF.sample(*field, xy[:, 0], xy[:, 1])
+        pos = np.concatenate([xy, (z + rng.uniform(-0.2, 1.0, n))[:, None]], 1).astype(np.float32)
+        e = np.stack([rng.normal(0, .3, n), rng.normal(0, .3, n), rng.uniform(-np.pi, np.pi, n)], 1).astype(np.float32)
+        quat = np.ascontiguousarray(quat_from_euler_xyz(e[:, 0], e[:, 1], e[:, 2]).astype(np.float32))
+        out.append((name, field, pos, quat))
+    return out

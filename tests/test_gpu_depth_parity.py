@@ -139,3 +139,16 @@ def test_invalid_arguments_are_refused(hf):
     assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800
     assert lib.wl_heightfield_build_pyramid(C.byref(bad_hf), cam.pyramid.data_ptr(), None) == -1
     torch.cuda.synchronize()
+
+
+def test_rough_terrain(hf):
+    """white noise, isolated spikes, stair steps (tests/depth_cases.py::rough_fields): the pyramid skips little, the walk descends
+    and climbs at almost every cell, cameras sit inside the terrain -- parity with the oracle and, above all, termination"""
+    from wheeledlab_amd.core import DepthCamera
+    for name, field, pos, quat in DC.rough_fields():
+        env = _posed_batch(pos, quat)
+        got = DepthCamera(field, DEV).render(env, 50.0)
+        torch.cuda.synchronize()
+        want = D.depth(P, pos, quat, field, 50.0)
+        bad, err = DC.mismatch(got.cpu().numpy(), want, 50.0)
+        assert bad.mean() < 5e-5, (name, int(bad.sum()), float(err.max()))

@@ -136,3 +136,13 @@ def test_size_independent_properties_of_oracle_and_device_walk(hostlib, hf):
     for img in (D.depth(P, p0, q0, flat, 30.0)[0], _host_depth(hostlib, flat, p0, q0, 30.0)[0]):
         col = img[31:, 40]                      # rows below the horizon, bottom row last
         assert (np.diff(col) < 0).all() and col[-1] < 0.5 < col[0]
+
+
+def test_device_walk_on_rough_terrain(hostlib):
+    """white noise, spikes and stair steps: nothing to skip, a descent and a climb at almost every cell, walls everywhere -- the walk
+    against the cell-by-cell oracle (a handful of grazing pixels at most)"""
+    for name, field, pos, quat in DC.rough_fields():
+        got = _host_depth(hostlib, field, pos, quat, 50.0)
+        want = D.depth(P, pos, quat, field, 50.0)
+        bad, err = DC.mismatch(got, want, 50.0)
+        assert bad.mean() < 5e-5, (name, int(bad.sum()), float(err.max()))
