@@ -205,3 +205,10 @@ def test_visual_depth_observation_term_through_the_scene_camera():
     got = d[..., 0].cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)
     assert (got[:, 45:] < 5.0).all() and (got[:, :20] == 100.0).mean() > 0.9      # ground close below, sky (far plane) above
+    # pixels beyond the far plane: "max" (default here) / "zero" / "none" (+inf, IsaacLab's default)
+    cam = env.scene.sensors["camera"].data
+    for mode, val in (("zero", 0.0), ("none", float("inf"))):
+        cam.beyond = val
+        dm = mdp.camera_data_depth(env)[..., 0]
+        assert torch.equal(dm == val, d[..., 0] >= 100.0) and torch.equal(dm[d[..., 0] < 100.0], d[..., 0][d[..., 0] < 100.0]), mode
+    cam.beyond = None

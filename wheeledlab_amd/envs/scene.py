@@ -173,6 +173,7 @@ class CameraData:
         self._b, self._cam = batch, None
         clip = getattr(getattr(cfg, "spawn", None), "clipping_range", None) or (0.01, 100.0)
         self.far = float(clip[1])
+        self.beyond = {"max": None, "zero": 0.0, "none": float("inf")}[getattr(cfg, "depth_clipping_behavior", "max")]
 
     def _camera(self):
         if self._cam is None:
@@ -198,7 +199,10 @@ class _CameraOutputs:
         if key != "distance_to_image_plane":
             raise KeyError(f"camera data type {key!r} is not rendered here (the fused observation carries the grey image)")
         d = self._d
-        return d._camera().render(d._b, d.far).unsqueeze(-1)
+        img = d._camera().render(d._b, d.far)
+        if d.beyond is not None:
+            img = torch.where(img >= d.far, torch.full_like(img, d.beyond), img)
+        return img.unsqueeze(-1)
 
     def keys(self):
         return ["distance_to_image_plane"]

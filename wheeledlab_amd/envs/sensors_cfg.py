@@ -39,6 +39,9 @@ class TiledCameraCfg:
     offset_rot: tuple = (1.0, 0.0, 0.0, 0.0)
     offset_convention: str = "ros"
     body_pos: tuple = (0.23, 0.0, 0.18)   # pose of the camera in the base frame (designed: camera_link is in the missing USD)
+    # what a depth pixel beyond the far clipping plane reads: "max" (the far distance), "zero", or "none" (+inf) -- the switch of
+    # IsaacLab's camera cfgs [IsaacLab-recalled; its own default is "none"]; "max" here keeps observation rows finite
+    depth_clipping_behavior: str = "max"
     debug_vis: bool = False
 
 
