@@ -62,6 +62,11 @@ def csrc_fingerprint(task: str):
         data = open(path, "rb").read()
         if f.endswith(".py"):   # only the compiler flags matter
             data = b"\n".join(l for l in data.splitlines() if b"HIPCC_FLAGS" in l or b"-mllvm" in l)
+        else:                   # code only: comments and blank space do not change a kernel
+            import re
+            data = re.sub(rb"/\*.*?\*/", b"", data, flags=re.S)
+            data = re.sub(rb"//[^\n]*", b"", data)
+            data = b"\n".join(l.strip() for l in data.splitlines() if l.strip())
         h.update(f.encode())
         h.update(data)
     return h.hexdigest()[:16]
