@@ -94,6 +94,22 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.wl_ppo_apply(C.byref(small_a), C.byref(small_c), base, 64, C.byref(hp), C.byref(st), 2, 1, None) == -1          # parity
     assert lib.wl_ppo_apply(C.byref(small_a), C.byref(small_c), base, 0, C.byref(hp), C.byref(st), 0, 1, None) == -1           # empty batch
     assert lib.wl_ppo_apply(C.byref(actor), C.byref(critic), base, 64, C.byref(hp), C.byref(st), 0, 1, None) == -1             # not the 14-wide nets
+    # depth ray-cast: pyramid sizing is host arithmetic; every malformed call is refused before a launch
+    assert lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800
+    assert lib.wl_heightfield_pyramid_floats(3, 3) == 2 * 2 // 2 + 9 and lib.wl_heightfield_pyramid_floats(349, 613) == 1024 * 1024 // 2 + 349 * 613
+    assert lib.wl_heightfield_pyramid_floats(1, 9) == 0 and lib.wl_heightfield_pyramid_floats(9, 16386) == 0
+    vp = PP.visual_params()
+    hf = A.WlHeightField(base, 16, 16, 0.0, 0.0, 0.5, 0.0)
+    good_b = A.WlEnvBuffers(base, base, None, base, 64, 40, 0, 1, 0, 0)
+    dep = lib.wl_visual_depth
+    assert dep(C.byref(vp), C.byref(good_b), C.byref(hf), None, 10.0, base, None) == -1               # no pyramid
+    assert dep(C.byref(vp), C.byref(good_b), C.byref(hf), base, 0.0, base, None) == -1                # range
+    assert dep(C.byref(vp), C.byref(good_b), C.byref(hf), base, 10.0, None, None) == -1               # no output
+    assert dep(C.byref(vp), C.byref(b), C.byref(hf), base, 10.0, base, None) == -1                    # null state
+    assert dep(C.byref(vp), C.byref(good_b), C.byref(A.WlHeightField(base, 1, 16, 0.0, 0.0, 0.5, 0.0)), base, 10.0, base, None) == -1
+    assert dep(C.byref(vp), C.byref(good_b), C.byref(A.WlHeightField(base, 16, 16, 0.0, 0.0, 0.0, 0.0)), base, 10.0, base, None) == -1   # cell 0
+    assert lib.wl_heightfield_build_pyramid(C.byref(A.WlHeightField(None, 16, 16, 0.0, 0.0, 0.5, 0.0)), base, None) == -1
+    assert lib.wl_heightfield_build_pyramid(C.byref(hf), None, None) == -1
 
 
 def test_layout_of_task_structs_and_misuse_codes(tmp_path):
