@@ -281,10 +281,11 @@ def other_tasks_sweep(dev):
             if task == "visual":
                 e2.sample_augmentation(torch.Generator().manual_seed(0))
             a2 = torch.rand(K, big, 2, device=dev) * 2 - 1
-            e2.rollout(a2)
+            for _ in range(4):
+                e2.rollout(a2)
             torch.cuda.synchronize()
             best = 1e30
-            for _ in range(2):
+            for _ in range(3):
                 s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s0.record()
                 for _ in range(3):
