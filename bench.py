@@ -572,12 +572,14 @@ def main():
             t.rollout(a)
             torch.cuda.synchronize()
             q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            q0.record()
-            for _ in range(4):
-                t.rollout(a)
-            q1.record()
-            torch.cuda.synchronize()
-            us = q0.elapsed_time(q1) * 1e3 / (4 * k)
+            us = 1e30
+            for _ in range(3):      # best of three blocks: one block once measured 12 x the others (a host hiccup in a 3 ms window)
+                q0.record()
+                for _ in range(4):
+                    t.rollout(a)
+                q1.record()
+                torch.cuda.synchronize()
+                us = min(us, q0.elapsed_time(q1) * 1e3 / (4 * k))
             other[name] = {"us_per_step": us, "env_steps_per_s": n / (us * 1e-6), "obs_dim": t.OBS_DIM,
                            "obs_GBs": n * t.OBS_DIM * 4 / (us * 1e-6) / 1e9, "launches": "one per env.step()" if name == "elevation"
                            else "two per env.step() (step, camera)"}
@@ -670,12 +672,14 @@ def main():
             cam.render(t, 100.0, img)
         torch.cuda.synchronize()
         q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        q0.record()
-        for _ in range(16):
-            cam.render(t, 100.0, img)
-        q1.record()
-        torch.cuda.synchronize()
-        dus = q0.elapsed_time(q1) * 1e3 / 16
+        dus = 1e30
+        for _ in range(3):
+            q0.record()
+            for _ in range(8):
+                cam.render(t, 100.0, img)
+            q1.record()
+            torch.cuda.synchronize()
+            dus = min(dus, q0.elapsed_time(q1) * 1e3 / 8)
         hit = float((img < 100.0).float().mean())
         other["visual_depth"] = {"us_per_render": dus, "images_per_s": n / (dus * 1e-6), "rays_per_s": n * 4800 / (dus * 1e-6),
                                  "image": "60 x 80 fp32 distance_to_image_plane", "hit_fraction": hit,
