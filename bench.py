@@ -87,37 +87,59 @@ def pmc_entry(task: str, n_envs: int):
     return None
 
 
-def rocprof_avg_us(kernel_substr: str):
-    """average duration of a kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of bench.py itself
-    (profiles/r*_bench_kernel_stats.csv), for the reader who recomputes `frac` from profiles/"""
+def rocprof_avg_us(kernel_substr):
+    """average duration of a kernel (or the sum over a list of kernels: the launches of one step) in the newest committed
+    `rocprofv3 --kernel-trace --stats` summary of bench.py itself (profiles/r*_bench_kernel_stats.csv), for the reader who
+    recomputes `frac` from profiles/.  Of several instantiations of a kernel the most-called one counts."""
     import csv
     import glob
+    names = [kernel_substr] if isinstance(kernel_substr, str) else list(kernel_substr)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")), reverse=True):
         try:
-            best = None
-            for r in csv.DictReader(open(f)):
-                if kernel_substr in r.get("Name", "") and (best is None or int(r["Calls"]) > best[0]):
-                    best = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
-            if best:
-                return {"avg_us": best[1], "calls": best[0], "source": os.path.relpath(f, ROOT)}
+            rows = list(csv.DictReader(open(f)))
+            tot, calls = 0.0, None
+            for nm in names:
+                best = None
+                for r in rows:
+                    if nm + "<" in r.get("Name", "") + "<" and nm in r.get("Name", "") and (best is None or int(r["Calls"]) > best[0]):
+                        best = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
+                if best is None:
+                    tot = None
+                    break
+                tot += best[1]
+                calls = best[0] if calls is None else min(calls, best[0])
+            if tot is not None:
+                return {"avg_us": tot, "calls": calls, "source": os.path.relpath(f, ROOT)}
         except (KeyError, ValueError):
             continue
     return None
 
 
-def roofline_block(task, n, us, kernel, bound, bytes_per_unit=None):
-    """HBM roofline of one kernel / step: algorithmic bytes per launch / live duration, + the committed counters"""
+def roofline_block(task, n, us, kernel, bound, bytes_per_unit=None, profile_kernels=None):
+    """HBM roofline of one kernel / step: algorithmic bytes per launch / live duration, + three figures a reader can check
+    without opening a CSV: `frac_profile` (the same bytes / the kernel's average duration in the committed rocprofv3 summary of
+    bench.py, profiles/r*_bench_kernel_stats.csv), `frac_counters` (HBM bytes the PMC passes counted / the kernel's duration in
+    those passes / peak) and `wasted_traffic` (counter bytes / algorithmic bytes: re-reads and write-allocate overhead)"""
     bpu = bytes_per_unit or ALGO_BYTES[task]
     achieved = bpu * n / (us * 1e-6) / 1e9
     e = pmc_entry(task, n)
     blk = {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": None, "kernel": kernel, "launch_us": us, "bytes_per_unit": bpu, "units_per_launch": n,
-           "frac_uses": "launch_us (HIP events on the launch stream, live in this run)"}
+           "frac_uses": "launch_us (HIP events on the launch stream, live in this run)",
+           "frac_profile": None, "frac_counters": None, "wasted_traffic": None}
+    if profile_kernels:
+        st = rocprof_avg_us(profile_kernels)
+        if st:
+            blk["rocprof_kernel_stats"] = st
+            blk["frac_profile"] = bpu * n / (st["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
     if e:
         blk["traffic"] = None if e["stale"] else e.get("traffic_bytes")
         blk["traffic_source"], blk["traffic_stale"] = e["source"], e["stale"]
         if not e["stale"]:
             blk["counters"] = e.get("kernels")
+            blk["frac_counters"] = e.get("frac_counters")
+            if e.get("traffic_bytes") and bytes_per_unit is None:
+                blk["wasted_traffic"] = e["traffic_bytes"] / (bpu * n)
     return blk
 
 
@@ -236,14 +258,21 @@ def _cpu_model():
     return "unknown"
 
 
+SWEEP_TESTS = {65536: "tests/test_gpu_forms.py::test_drift_65536_envs_equal_two_shards",
+               1048576: "tests/test_gpu_forms.py::test_drift_4m_envs_equal_four_1m_shards_and_the_oracle (the shards)",
+               4194304: "tests/test_gpu_forms.py::test_drift_4m_envs_equal_four_1m_shards_and_the_oracle + "
+                        "test_streaming_drift_form_matches_oracle_single_steps"}
+
+
 def large_n_sweep(dev):
-    """us per fused drift env.step() at 65 536 / 1 M / 4 M envs (outputs overwritten in place; these launches also write
-    the int64 `dones` row: + 8 B per env-step)"""
+    """us per fused drift env.step() at 65 536 / 1 M / 4 M envs (outputs overwritten in place; no int64 `dones` row: the 334 B
+    per env-step of the headline kernel).  `test`: the GPU test that runs the same size and kernel instantiation."""
     from wheeledlab_amd.core import DriftBatch
 
     sweep = []
     for big in (65536, 1048576, 4194304):
         e2 = DriftBatch(big, device=dev, seed=42)
+        e2.set_dones_output(False)
         e2.reset()
         a2 = torch.rand(8, big, 2, device=dev) * 2 - 1
         for _ in range(12):     # ~ 30 ms of launches at 4 M envs: clocks and the caches' contents settle (3 were not enough:
@@ -258,14 +287,25 @@ def large_n_sweep(dev):
             s1.record()
             torch.cuda.synchronize()
             best = min(best, s0.elapsed_time(s1) * 1e3 / 48)
-        gbs = (BYTES_PER_ENV_STEP + 8) * big / (best * 1e-6) / 1e9
+        gbs = BYTES_PER_ENV_STEP * big / (best * 1e-6) / 1e9
         sq = pmc_sq(big)
+        pe = pmc_entry("drift", big)
+        fresh = pe is not None and not pe["stale"]
         sweep.append({"n_envs": big, "us_per_step": round(best, 2), "env_steps_per_s": big / (best * 1e-6),
-                      "achieved_GBs": gbs, "frac_of_8TBs": gbs / 8000.0, "bytes_per_env_step": BYTES_PER_ENV_STEP + 8,
+                      "achieved_GBs": gbs, "frac_of_8TBs": gbs / 8000.0, "bytes_per_env_step": BYTES_PER_ENV_STEP,
+                      "frac_counters": pe.get("frac_counters") if fresh else None,
+                      "wasted_traffic": pe["traffic_bytes"] / (BYTES_PER_ENV_STEP * big) if fresh and pe.get("traffic_bytes") else None,
+                      "counters_source": pe["source"] if pe else None, "counters_stale": pe["stale"] if pe else None,
                       "bound": "valu+hbm" if big >= 1048576 else "latency+valu",
-                      "valu_frac": sq.get("valu_pipe_frac") if sq else None, "sq_counters": sq})
+                      "valu_frac": sq.get("valu_pipe_frac") if sq else None, "sq_counters": sq, "test": SWEEP_TESTS[big]})
         del e2, a2
     return sweep
+
+
+OTHER_SWEEP_TESTS = {("elev", 262144): "tests/test_gpu_forms.py::test_elevation_262144_envs_equal_two_shards + "
+                                        "test_height_scan_forms_are_bit_identical",
+                     ("visual", 65536): "tests/test_gpu_forms.py::test_visual_65536_envs_equal_two_shards + "
+                                        "test_streaming_camera_rows_are_bit_identical"}
 
 
 def other_tasks_sweep(dev):
@@ -296,7 +336,9 @@ def other_tasks_sweep(dev):
             blk = roofline_block(task, big, best, "step + scan" if task == "elev" else "step + camera", "hbm+valu")
             out.append({"task": task, "n_envs": big, "us_per_step": round(best, 2), "env_steps_per_s": big / (best * 1e-6),
                         "achieved_GBs": blk["achieved"], "frac_of_8TBs": blk["frac"], "bytes_per_env_step": ALGO_BYTES[task],
-                        "traffic": blk.get("traffic"), "traffic_stale": blk.get("traffic_stale")})
+                        "traffic": blk.get("traffic"), "traffic_stale": blk.get("traffic_stale"),
+                        "frac_counters": blk.get("frac_counters"), "wasted_traffic": blk.get("wasted_traffic"),
+                        "test": OTHER_SWEEP_TESTS.get((task, big))})
             if task == "elev" and big == 65536:
                 cam = DepthCamera((e2.height, float(e2._hf.x0), float(e2._hf.y0), float(e2._hf.cell)), dev)
                 img = torch.empty(big, 60, 80, device=dev)
@@ -471,6 +513,31 @@ def main():
     k1.record()
     torch.cuda.synchronize()
     launch_us = k0.elapsed_time(k1) * 1e3 / (reps * ROLLOUT)
+    # N > 1: the spread of the per-rank launch duration (a slow GPU shows here, not in the max-over-ranks headline) and the
+    # event-timed latency of ONE episode-metric all-reduce on an idle stream -- the path's only collective, so that the first
+    # multi-GPU run yields the scaling curve and the collective's cost in one shot
+    if dist is not None:
+        lu = torch.tensor([launch_us, -launch_us], device=dev, dtype=torch.float64)
+        dist.all_reduce(lu, op=dist.ReduceOp.MAX)
+        m = env.read_metrics(zero=False)
+        for _ in range(3):
+            dist.all_reduce(m)
+        barrier()
+        lat = []
+        for _ in range(20):
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            dist.all_reduce(m)
+            a1.record()
+            torch.cuda.synchronize()
+            lat.append(a0.elapsed_time(a1) * 1e3)
+        lat.sort()
+        lt = torch.tensor([lat[len(lat) // 2]], device=dev, dtype=torch.float64)
+        dist.all_reduce(lt, op=dist.ReduceOp.MAX)
+        rccl.update({"launch_us_max_over_ranks": float(lu[0]), "launch_us_min_over_ranks": float(-lu[1]),
+                     "metric_allreduce_us": {"median_max_over_ranks": float(lt.item()), "min_this_rank": lat[0], "max_this_rank": lat[-1],
+                                             "bytes": int(m.numel() * m.element_size()), "samples": len(lat),
+                                             "timing": "HIP events around one blocking all_reduce of the [16] metric vector on an idle stream"}})
     achieved = BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
     traffic, traffic_src, traffic_stale = pmc_traffic(n)
     sq = pmc_sq(n)
@@ -587,10 +654,12 @@ def main():
             # dominant kernel alone (the camera: 12 832 B of observation row per env)
             if name == "elevation":
                 other[name]["roofline"] = roofline_block("elev", n, us, "elev_step_scan_kernel" if n <= 32768 else
-                                                         "elev_step_kernel + elev_scan_kernel",
-                                                         "latency (20 dependent integrator sub-steps with terrain gathers)" if n <= 32768 else "hbm+valu")
+                                                         "elev_step_kernel + elev_scan_lds_kernel",
+                                                         "latency (20 dependent integrator sub-steps with terrain gathers)" if n <= 32768 else "hbm+valu",
+                                                         profile_kernels=["elev_step_scan_kernel"] if n == ENVS_PER_GPU else None)
             else:
-                other[name]["roofline"] = roofline_block("visual", n, us, "visual_step_kernel + visual_obs_kernel", "hbm+lds")
+                other[name]["roofline"] = roofline_block("visual", n, us, "visual_step_kernel + visual_obs_kernel", "hbm+lds",
+                                                         profile_kernels=["visual_step_kernel", "visual_obs_kernel"] if n == ENVS_PER_GPU else None)
                 t.observe()
                 torch.cuda.synchronize()
                 q0.record()
@@ -685,22 +754,30 @@ def main():
                                  "image": "60 x 80 fp32 distance_to_image_plane", "hit_fraction": hit,
                                  "workload": f"{n} elevation-task cars on the synthetic 800 x 800 heightfield (0.05 m), max depth 100 m",
                                  "roofline": roofline_block("depth", n, dus, "visual_depth_kernel",
-                                                            "valu issue + divergence (max-pyramid walk, one wavefront per 4 x 16 pixel tile; the image write is the only HBM stream)")}
+                                                            "valu issue + divergence (max-pyramid walk; the image write is the only HBM stream)",
+                                                            profile_kernels=["visual_depth_kernel"] if n == ENVS_PER_GPU else None)}
+        # this kernel's governing roofline is the VALU pipe, not HBM: instructions issued x 2 cycles / (1024 SIMDs x shader cycles)
+        dc = (other["visual_depth"]["roofline"].get("counters") or {}).get("visual_depth_kernel") or {}
+        other["visual_depth"]["roofline"]["valu_frac"] = dc.get("valu_pipe_frac")
+        other["visual_depth"]["roofline"]["governing"] = "valu_frac (HBM fraction reported for the contract; the walk is instruction-bound)"
         if not args.no_cpu_baseline:
-            # the CPU beside it: the oracle's exact cell-by-cell intersection (oracle/depth.c, double precision, OpenMP over the
-            # images) on this box's host cores, on the first 512 of the same poses
-            from oracle import depth as OD
-            from oracle import visual_step as OV
-            m = min(n, 512)
-            st = t.state[:, :m].cpu().numpy()
-            field = (t.height.cpu().numpy(), float(t._hf.x0), float(t._hf.y0), float(t._hf.cell))
-            OD.depth(OV.visual_params(), st[0:3, :8].T, st[3:7, :8].T, field, 100.0)        # builds / loads the library
-            c0 = time.perf_counter()
-            OD.depth(OV.visual_params(), st[0:3].T, st[3:7].T, field, 100.0)
-            c1 = time.perf_counter() - c0
-            other["visual_depth"]["cpu_baseline"] = {"value": m * 4800 / c1, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
-                                                     "sample": f"{m} images of the same poses through oracle/depth.c (exact per-cell "
-                                                               f"intersection, double precision, OpenMP), {c1:.2f} s"}
+            try:
+                # the CPU beside it: the oracle's exact cell-by-cell intersection (oracle/depth.c, double precision, OpenMP over the
+                # images) on this box's host cores, on the first 512 of the same poses
+                from oracle import depth as OD
+                from oracle import visual_step as OV
+                m = min(n, 512)
+                st = t.state[:, :m].cpu().numpy()
+                field = (t.height.cpu().numpy(), float(t._hf.x0), float(t._hf.y0), float(t._hf.cell))
+                OD.depth(OV.visual_params(), st[0:3, :8].T, st[3:7, :8].T, field, 100.0)        # builds / loads the library
+                c0 = time.perf_counter()
+                OD.depth(OV.visual_params(), st[0:3].T, st[3:7].T, field, 100.0)
+                c1 = time.perf_counter() - c0
+                other["visual_depth"]["cpu_baseline"] = {"value": m * 4800 / c1, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+                                                         "sample": f"{m} images of the same poses through oracle/depth.c (exact per-cell "
+                                                                   f"intersection, double precision, OpenMP), {c1:.2f} s"}
+            except Exception as ex:   # noqa: BLE001 -- building / loading oracle/depth.c needs make + gcc + OpenMP on the box: a
+                other["visual_depth"]["cpu_baseline"] = {"error": repr(ex)}   # secondary figure must never cost the headline line
         del t, cam, img
 
     # secondary: the same workload driven step by step through the drop-in Python surface
@@ -742,6 +819,12 @@ def main():
 
     if rank == 0:
         total_envs = n * world
+        # the same fraction from the committed artefacts: algorithmic bytes / the kernel's average duration in the rocprofv3
+        # summary of this script (profiles/), and counter bytes / duration in the PMC passes
+        prof = rocprof_avg_us("drift_step_kernel")
+        frac_profile = BYTES_PER_ENV_STEP * n / (prof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if prof and n == ENVS_PER_GPU else None
+        pe = pmc_entry("drift", n)
+        frac_counters = pe.get("frac_counters") if pe and not pe["stale"] else None
         line = {
             "metric": "env steps/sec (whole node), drift task @ 4096 envs/GPU",
             "value": total_envs * args.steps / wall,
@@ -767,7 +850,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "kernel": "drift_step_kernel<FlatGround>", "launch_us": launch_us,
                          "frac_uses": "launch_us (HIP events on the launch stream, live in this run)",
-                         "rocprof_kernel_stats": rocprof_avg_us("drift_step_kernel"),
+                         "rocprof_kernel_stats": prof, "frac_profile": frac_profile, "frac_counters": frac_counters,
+                         "wasted_traffic": traffic / (BYTES_PER_ENV_STEP * n) if traffic else None,
                          "bytes_per_env_step": BYTES_PER_ENV_STEP, "envs_per_launch": n},
             "episode_metrics": {"resets": float(metric_sum[8]), "timeouts": float(metric_sum[9]),
                                 "out_of_bounds": float(metric_sum[10]), "nonfinite": float(metric_sum[14])},

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 19
+#define WL_ABI_VERSION 20
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -154,8 +154,17 @@ typedef struct WlEnvBuffers {
                               /* kernel accumulates into slot (step % R) and clears slot ((step + 1) % R)         */
     int32_t lanes;            /* step-kernel form: 0 = choose by env count, 1 = lane per env (packed axles),       */
                               /* 2 = lane per env (scalar wheel loop, 5 waves / SIMD), 4 = quad per env            */
-    int32_t reserved;
+    int32_t flags;            /* WL_FLAG_* bits; 0 = every choice below is made from the batch size                  */
 } WlEnvBuffers;
+
+/* WlEnvBuffers.flags: force one of the instantiations the launchers otherwise pick from the batch size -- so that tests and
+ * probes can run EVERY instantiation at any size (the large-batch forms at 1000 envs, the cache-allocating forms at 4 M). */
+#define WL_FLAG_STREAM 1       /* streaming forms: rows / observation rows / outputs written with non-temporal (sc1 nt) stores; */
+                               /* drift: the lane-per-env streaming instantiation (`lanes` must not be 4)                        */
+#define WL_FLAG_NO_STREAM 2    /* cache-allocating stores whatever the batch size                                                */
+#define WL_FLAG_SCAN_LDS 4     /* elevation height scan: the env's terrain patch staged in LDS (lane form / wl_elev_observe)     */
+#define WL_FLAG_SCAN_GATHER 8  /* elevation height scan: per-ray gathers from the L2-resident field                              */
+#define WL_FLAG_MASK 15
 
 /* ---- outputs of one step -------------------------------------------------------------------------------- */
 typedef struct WlStepOut {

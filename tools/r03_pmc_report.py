@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import ALGO_BYTES, csrc_fingerprint  # noqa: E402
 
-KERNELS = {"drift": ["drift_step_kernel"], "elev": ["elev_step_scan_kernel", "elev_step_kernel", "elev_scan_kernel"],
+KERNELS = {"drift": ["drift_step_kernel"], "elev": ["elev_step_scan_kernel", "elev_step_kernel", "elev_scan_kernel", "elev_scan_lds_kernel"],
            "visual": ["visual_step_kernel", "visual_obs_kernel"], "depth": ["visual_depth_kernel"]}
 
 
@@ -81,10 +81,10 @@ for tag in tags:
     task, n = tag.rsplit("_", 1)
     n = int(n)
     entry = {"n_envs": n, "algorithmic_bytes": ALGO_BYTES.get(task, 0) * n, "kernels": {}}
-    tot = 0.0
+    tot, dur_tot = 0.0, 0.0
     for k in KERNELS.get(task, []):
-        f, _, nf = counters(f"FETCH_{tag}", k)
-        w, _, _ = counters(f"WRITE_{tag}", k)
+        f, dur_f, nf = counters(f"FETCH_{tag}", k)
+        w, dur_w, _ = counters(f"WRITE_{tag}", k)
         a, dur_a, na = counters(f"sqa_{tag}", k)
         b, dur_b, _ = counters(f"sqb_{tag}", k)
         if not (f or a):
@@ -94,6 +94,10 @@ for tag in tags:
             e["read_bytes"], e["write_bytes"] = f["FETCH_SIZE"] * 1024 * ff, w["WRITE_SIZE"] * 1024 * wf
             e["traffic_bytes"] = e["read_bytes"] + e["write_bytes"]
             tot += e["traffic_bytes"]
+            # the counters' own clock: bytes the counters saw / the kernel's mean duration in the two traffic passes
+            e["duration_traffic_passes_ns"] = 0.5 * (dur_f + dur_w)
+            e["frac_counters"] = e["traffic_bytes"] / (e["duration_traffic_passes_ns"] * 1e-9) / 8e12
+            dur_tot += e["duration_traffic_passes_ns"]
         if a and a.get("SQ_WAVES"):
             wc = a.get("SQ_WAVE_CYCLES", 0.0)
             e.update({"duration_ns": dur_a, "waves": a["SQ_WAVES"], "valu_insts_per_wave": a["SQ_INSTS_VALU"] / a["SQ_WAVES"],
@@ -110,6 +114,7 @@ for tag in tags:
         entry["kernels"][k] = e
     if tot:
         entry["traffic_bytes"] = tot
+        entry["frac_counters"] = tot / (dur_tot * 1e-9) / 8e12     # all kernels of the step: counter bytes / summed durations / 8 TB/s
         if entry["algorithmic_bytes"]:
             entry["ratio"] = tot / entry["algorithmic_bytes"]
     out["entries"][f"{task}:{n}"] = entry

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 19
+WL_ABI_VERSION = 20
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -24,6 +24,8 @@ ELEV_TERM_NAMES = ("vel_towards_goal", "height_z", "falling_penalty", "terminati
 ELEV_DONE_NAMES = ("cart_out_of_bounds", "stuck", "rollover", "at_goal")
 # WlMetric
 M_EPSUM0, M_RESETS, M_TIMEOUTS, M_TERM0, M_NONFINITE, M_EPLEN, M_COUNT = 0, 8, 9, 10, 14, 15, 16
+# WlEnvBuffers.flags (WL_FLAG_*): force an instantiation the launchers otherwise pick from the batch size
+FLAG_STREAM, FLAG_NO_STREAM, FLAG_SCAN_LDS, FLAG_SCAN_GATHER = 1, 2, 4, 8
 M_SHARDS = 32   # WL_M_SHARDS: an accumulator vector is [M_SHARDS][M_COUNT], its value the sum over shards
 # WlDriftRewTerm
 DRIFT_TERM_NAMES = ("side_slip", "vel", "progress", "tlgr", "turn_energy", "cross_track", "term_pens")
@@ -113,7 +115,7 @@ VIS_OBS_DIM = VIS_NPIX + 8
 class WlEnvBuffers(C.Structure):
     _fields_ = [("state", C.c_void_p), ("episode_len", C.c_void_p), ("ref_poses", C.c_void_p),
                 ("metrics", C.c_void_p), ("stride", C.c_int64), ("n_envs", C.c_int32), ("env_offset", C.c_int32),
-                ("metrics_slots", C.c_int32), ("lanes", C.c_int32), ("reserved", C.c_int32)]
+                ("metrics_slots", C.c_int32), ("lanes", C.c_int32), ("flags", C.c_int32)]
 
 
 class WlStepOut(C.Structure):

@@ -55,6 +55,12 @@ class _MetricsView:
         m = self.metrics_raw.sum(1)
         return m[0] if self.metrics_slots == 1 else m
 
+    def set_flags(self, flags: int = 0):
+        """WlEnvBuffers.flags (_abi.FLAG_*): force an instantiation the launchers otherwise pick from the batch size -- the
+        streaming (non-temporal store) forms, the cache-allocating forms, the height scan through LDS patches or through
+        gathers.  0 = by size.  What the tests use to run the large-batch forms at small sizes (and vice versa)."""
+        self._bufs.flags = int(flags)
+
     def _ring_aliases(self, n_steps: int) -> bool:
         """a persistent launch folds its steps into ring slot step0 % R and clears slot (step0 + n) % R for its successor: with n
         a multiple of R those are the same slot and the C ABI refuses the launch (WL_EINVAL).  The host layer then runs the
@@ -119,6 +125,11 @@ class DriftBatch(_MetricsView):
         scalar wheel loop beyond), 1 = lane per env / packed axles, 2 = lane per env / scalar wheel loop, 4 = quad per env"""
         assert lanes in (0, 1, 2, 4)   # 2: lane form with the scalar wheel loop (drift only; treated as 1 elsewhere)
         self._bufs.lanes = lanes
+
+    def set_dones_output(self, on: bool = True):
+        """the int64 `dones` row (terminated | truncated as RSL-RL's runner consumes it, + 8 B per env-step) of step() /
+        in-place rollouts on or off; callers that read the two byte rows do not need it"""
+        self._out.dones = self.dones.data_ptr() if on else None
 
     def reset(self, mask: torch.Tensor | None = None):
         m = None if mask is None else mask.to(torch.uint8).contiguous()

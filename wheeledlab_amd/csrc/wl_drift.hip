@@ -280,16 +280,19 @@ static void launch_step(const WlDriftParams* p, const WlEnvBuffers* b, const Veh
 #define WL_STEP_ARGS b->state, b->episode_len, actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b, noise, out, FlatGround{}, slots
     const int grid = grid_for(b->n_envs);
     const bool awd = p->vehicle.drive == 1;
-    if (use_quad(b)) {
+    // WL_FLAG_STREAM selects the streaming instantiation at any size (it is a lane form with the scalar wheel loop)
+    const bool streaming = use_streaming(b, (int64_t)b->stride * 4 * WL_S_COUNT, kStreamingStateBytes);
+    const bool forced_stream = (b->flags & WL_FLAG_STREAM) != 0;
+    if (!forced_stream && use_quad(b)) {
         const int lanes = b->n_envs * 4;
         if (b->n_envs <= 2048) drift_step_kernel<4, FlatGround, true, -1, 64><<<(lanes + 63) / 64, 64, 0, stream>>>(WL_STEP_ARGS);
         else if (b->n_envs <= 8192) drift_step_kernel<4, FlatGround, true, -1, 128><<<(lanes + 127) / 128, 128, 0, stream>>>(WL_STEP_ARGS);
         else drift_step_kernel<4, FlatGround><<<grid_for(lanes), kBlock, 0, stream>>>(WL_STEP_ARGS);
     }
-    else if (use_unrolled(b)) {
+    else if (!forced_stream && use_unrolled(b)) {
         if (awd) drift_step_kernel<1, FlatGround, true, 1><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
         else drift_step_kernel<1, FlatGround, true, 0><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
-    } else if ((int64_t)b->stride * 4 * WL_S_COUNT <= kStreamingStateBytes) {
+    } else if (!streaming) {
         if (awd) drift_step_kernel<1, FlatGround, false, 1><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
         else drift_step_kernel<1, FlatGround, false, 0><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
     } else {

@@ -183,7 +183,7 @@ WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0
 // order, so the transposition needs no block barrier (round 1: one tile per block behind __syncthreads, the
 // wavefronts of a block waiting for the slowest).  Element f = lane + 64 j of the wavefront's 896 contiguous output
 // floats sits at tile[f + f / 14].
-template <bool STREAMING = false>   // non-temporal stores: the rows are not read again before the caches turn over (> 262 144 envs)
+template <bool STREAMING = false>   // non-temporal stores: the rows are not read again before the caches turn over (launch_step: state matrix > 192 MB, 1.22 M envs)
 WL_DEV void flush_obs_wave(const float* tile_w, float* __restrict__ obs, int wave_env0, int n) {
     const int lane = threadIdx.x & 63;
     const int n_valid = min(64, n - wave_env0);
@@ -584,6 +584,7 @@ inline int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
     if (b->n_envs <= 0 || b->stride < b->n_envs) return WL_EINVAL;
     if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
     if (b->metrics_slots < 1 || (b->lanes != 0 && b->lanes != 1 && b->lanes != 2 && b->lanes != 4)) return WL_EINVAL;
+    if (!flags_ok(b) || ((b->flags & WL_FLAG_STREAM) && b->lanes == 4)) return WL_EINVAL;   // the streaming form is a lane form
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL) return WL_EINVAL;   // buffer-resource offsets are 32-bit (~13 M envs)
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || p->num_ref_points <= 0 || p->num_ref_points > 32) return WL_EINVAL;
     if (!(p->sim_dt > 0.f)) return WL_EINVAL;

@@ -462,9 +462,97 @@ __global__ void __launch_bounds__(kBlock) elev_scan_kernel(const WlElevParams p,
         }
     }
 }
+// The same scan with the env's terrain patch staged in LDS (BASELINE config 3: "heightfield gather ... in LDS").  The gather form
+// above asks the texture-address unit for 2 x 676 lane addresses per env (two 8-byte gathers per ray, nearly every lane its own
+// cache line once the car is not axis-aligned): ~1100 clocks per env and CU, which is what bounds the task beyond the latency
+// regime (round 3: 515 of the 730 us per step at 262 144 envs).  Here one block = one env: the bounding box of the yaw-rotated
+// 2.5 m footprint -- at most 73 x 73 grid points of the 0.05 m field -- is fetched as whole rows (consecutive lanes =
+// consecutive floats: full-rate coalesced requests, ~1/3 of the address-unit clocks of the gathers), the 676 rays read their four
+// corners from LDS (two ds_read2_b32 each) with the arithmetic of HeightFieldGround::cell_of / blend, so the rows are
+// bit-identical to the gather form's.  LDS pitch kPatch is a compile-time constant (row / column split by multiply-shift).
+constexpr int kPatch = 74;               // grid points per side of the staged patch (scan_size * sqrt 2 / cell + 3 must fit)
+constexpr int kLdsScanThreads = 256;
+template <bool STREAM>
+__global__ void __launch_bounds__(kLdsScanThreads) elev_scan_lds_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
+                                                                        float* __restrict__ obs) {
+    __shared__ float patch[kPatch * kPatch];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const Rows S = make_rows(b.state, b.stride);
+    const float px = S.ld(WL_S_PX, e), py = S.ld(WL_S_PY, e), pz = S.ld(WL_S_PZ, e);
+    const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+    float c, s;
+    yaw_cs(q, c, s);
+    const WlHeightField& f = ground.f;
+    // the patch: the footprint's bounding box in grid units, one point of margin below, two above (the +1 corner and rounding)
+    const float half = 0.5f * p.scan_size * ground.inv_cell * (fabsf(c) + fabsf(s)) + 0.05f;
+    const float uc = (px - f.x0) * ground.inv_cell, vc = (py - f.y0) * ground.inv_cell;
+    // (block-uniform values, kept in scalar registers)
+    const int i0 = __builtin_amdgcn_readfirstlane(min(max((int)floorf(uc - half), 0), f.nx - kPatch));
+    const int j0 = __builtin_amdgcn_readfirstlane(min(max((int)floorf(vc - half), 0), f.ny - kPatch));
+    const int rows = __builtin_amdgcn_readfirstlane(min(max((int)floorf(vc + half) + 2 - j0, 1), kPatch));
+    const int n_stage = rows * kPatch;
+    // the field through a buffer resource: one 32-bit lane offset per request, the patch origin in the scalar offset
+    const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f.height), 0, f.nx * f.ny * 4, 0x00020000);
+    const int origin = (j0 * f.nx + i0) * 4;
+    constexpr int kStage = (kPatch * kPatch + kLdsScanThreads - 1) / kLdsScanThreads;
+    float stage[kStage];
+    // whole passes of the block are skipped by a SCALAR branch (n_stage is block-uniform); inside a pass the flat index is clamped
+    // instead of predicated: the lanes past the end fetch and write the last element again (same value, same address)
+#pragma unroll
+    for (int it = 0; it < kStage; ++it) {   // all requests first
+        if (it * kLdsScanThreads < n_stage) {
+            const int k = min(tid + it * kLdsScanThreads, n_stage - 1);
+            const int r = (int)(__umul24((unsigned)k, 3543u) >> 18);   // k / 74, exact for k < 74 * 74 + 256 (checked exhaustively)
+            stage[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr, ((int)__umul24((unsigned)r, (unsigned)f.nx) + (k - r * kPatch)) * 4, origin, 0));
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < kStage; ++it) {
+        if (it * kLdsScanThreads < n_stage) patch[min(tid + it * kLdsScanThreads, n_stage - 1)] = stage[it];
+    }
+    __syncthreads();
+    float* row = obs + (int64_t)e * WL_ELEV_OBS_DIM;
+    const float g0 = -0.5f * p.scan_size;
+    constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N;
+    constexpr int kIter = (kRays + kLdsScanThreads - 1) / kLdsScanThreads;
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+        const int k = tid + it * kLdsScanThreads;
+        if (k < kRays) {
+            const int iy = k / WL_ELEV_SCAN_N, ix = k - iy * WL_ELEV_SCAN_N;   // meshgrid "xy": x fastest
+            const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
+            const HeightFieldGround::CellOf cell = ground.cell_of(px + (c * lx - s * ly), py + (s * lx + c * ly));
+            // clamped: a point the bounding box missed would read a wrong corner (the parity tests would show it), never out of bounds
+            const float* h = patch + min(max(cell.j - j0, 0), kPatch - 2) * kPatch + min(max(cell.i - i0, 0), kPatch - 2);
+            HeightFieldGround::Corners cr;
+            cr.lo.x = h[0], cr.lo.y = h[1], cr.hi.x = h[kPatch], cr.hi.y = h[kPatch + 1];
+            cr.fu = cell.fu, cr.fv = cell.fv, cr.inside = cell.inside;
+            const float hz = ground.blend(cr);
+            const float val = cr.inside ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
+            if constexpr (STREAM) __builtin_nontemporal_store(clampf(val, -p.obs_clip, p.obs_clip), row + 13 + k);
+            else row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
+        }
+    }
+}
+// the staged patch must hold the footprint's bounding box at any yaw
+inline bool scan_patch_fits(const WlElevParams* p, const WlHeightField* hf) {
+    return hf->nx >= kPatch && hf->ny >= kPatch && p->scan_size * 1.41422f / hf->cell + 3.2f <= (float)kPatch;
+}
+// gather form while the chip is not full (every env's 128 lanes in flight at once: latency, not address rate, is what counts
+// there), LDS patches beyond; WL_FLAG_SCAN_LDS / WL_FLAG_SCAN_GATHER force one
+#ifndef WL_SCAN_LDS_MIN_ENVS
+#define WL_SCAN_LDS_MIN_ENVS 16384
+#endif
 inline void launch_elev_scan(const WlElevParams* p, const WlEnvBuffers* b, const HeightFieldGround& g, float* obs, hipStream_t hs) {
+    const bool stream = use_streaming(b, (int64_t)b->n_envs * WL_ELEV_OBS_DIM * 4, 256ll << 20);
+    const bool lds = scan_patch_fits(p, &g.f) && ((b->flags & WL_FLAG_SCAN_LDS) || (!(b->flags & WL_FLAG_SCAN_GATHER) && b->n_envs >= WL_SCAN_LDS_MIN_ENVS));
+    if (lds) {
+        if (stream) elev_scan_lds_kernel<true><<<b->n_envs, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
+        else elev_scan_lds_kernel<false><<<b->n_envs, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
+        return;
+    }
     const int grid = (b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock;
-    if ((int64_t)b->n_envs * WL_ELEV_OBS_DIM * 4 > (256ll << 20)) elev_scan_kernel<true><<<grid, kBlock, 0, hs>>>(*p, *b, g, obs);
+    if (stream) elev_scan_kernel<true><<<grid, kBlock, 0, hs>>>(*p, *b, g, obs);
     else elev_scan_kernel<false><<<grid, kBlock, 0, hs>>>(*p, *b, g, obs);
 }
 
@@ -1109,6 +1197,7 @@ int check_elev(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField
     if (b->n_envs <= 0 || b->stride < b->n_envs || b->metrics_slots < 1) return WL_EINVAL;
     if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
+    if (!flags_ok(b)) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f)) return WL_EINVAL;
     if (hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f)) return WL_EINVAL;
     return WL_OK;

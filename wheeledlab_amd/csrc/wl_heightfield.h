@@ -42,15 +42,31 @@ struct HeightFieldGround {
         float fu, fv;
         bool inside;
     };
-    WL_DEV Corners corners(float x, float y) const {
-        Corners c;
+    // the cell a point falls into and its position inside it (the arithmetic every sampler of this file shares)
+    struct CellOf {
+        int i, j;
+        float fu, fv;
+        bool inside;
+    };
+    WL_DEV CellOf cell_of(float x, float y) const {
+        CellOf c;
         const float u = (x - f.x0) * inv_cell, v = (y - f.y0) * inv_cell;
         c.inside = u >= 0.f && v >= 0.f && u < (float)(f.nx - 1) && v < (float)(f.ny - 1);
         const float uc = fminf(fmaxf(u, 0.f), (float)(f.nx - 1) - 1e-3f), vc = fminf(fmaxf(v, 0.f), (float)(f.ny - 1) - 1e-3f);
         const float fi = floorf(uc), fj = floorf(vc);
         c.fu = uc - fi;
         c.fv = vc - fj;
-        const float* row0 = f.height + (int)fj * f.nx + (int)fi;
+        c.i = (int)fi;
+        c.j = (int)fj;
+        return c;
+    }
+    WL_DEV Corners corners(float x, float y) const {
+        const CellOf k = cell_of(x, y);
+        Corners c;
+        c.inside = k.inside;
+        c.fu = k.fu;
+        c.fv = k.fv;
+        const float* row0 = f.height + k.j * f.nx + k.i;
         c.lo = *reinterpret_cast<const wl_float2_u*>(row0);
         c.hi = *reinterpret_cast<const wl_float2_u*>(row0 + f.nx);
         return c;

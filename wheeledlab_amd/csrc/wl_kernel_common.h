@@ -203,6 +203,21 @@ inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 #ifndef WL_LOWREG_WAVES
 #define WL_LOWREG_WAVES 5   // .. and fenced
 #endif
+// WlEnvBuffers.flags: valid combinations only (a flag and its opposite together are refused)
+inline bool flags_ok(const WlEnvBuffers* b) {
+    const int f = b->flags;
+    if (f & ~WL_FLAG_MASK) return false;
+    if ((f & WL_FLAG_STREAM) && (f & WL_FLAG_NO_STREAM)) return false;
+    if ((f & WL_FLAG_SCAN_LDS) && (f & WL_FLAG_SCAN_GATHER)) return false;
+    return true;
+}
+// streaming (non-temporal) stores: forced by the flags, otherwise when `bytes` (what the launch writes and will not read again
+// before the caches turn over) exceed `threshold`
+inline bool use_streaming(const WlEnvBuffers* b, int64_t bytes, int64_t threshold) {
+    if (b->flags & WL_FLAG_STREAM) return true;
+    if (b->flags & WL_FLAG_NO_STREAM) return false;
+    return bytes > threshold;
+}
 inline bool use_unrolled(const WlEnvBuffers* b) {   // lane form only
     if (b->lanes == 1) return true;
     if (b->lanes == 2) return false;
@@ -210,6 +225,7 @@ inline bool use_unrolled(const WlEnvBuffers* b) {   // lane form only
 }
 inline bool use_quad(const WlEnvBuffers* b) {
     if (b->lanes == 1 || b->lanes == 2) return false;
+    if ((b->flags & WL_FLAG_STREAM) && b->lanes != 4) return false;   // the streaming instantiations are lane forms
     if (b->stride * 4 >= (1 << 24)) return false;   // Rows::lane_row_offset is a 24-bit multiply (4 M envs: never the quad regime)
     if (b->lanes == 4) return true;
     return b->n_envs <= WL_QUAD_MAX_ENVS;

@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p
 // for the whole rollout anyway, the LDS map does pay: 29.0 -> 26.0 us per step plain, 37.5 -> 35.9 augmented.)
 inline void launch_visual_obs(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, float* obs, hipStream_t hs) {
     // rows of one launch beyond the 256 MB Infinity Cache (> 20 000 envs): stream them past the caches
-    if ((int64_t)b->n_envs * WL_VIS_OBS_DIM * 4 > (256ll << 20)) visual_obs_kernel<true><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
+    if (use_streaming(b, (int64_t)b->n_envs * WL_VIS_OBS_DIM * 4, 256ll << 20)) visual_obs_kernel<true><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
     else visual_obs_kernel<false><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
 }
 
@@ -610,6 +610,7 @@ int check_visual(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap
     if (b->n_envs <= 0 || b->stride < b->n_envs || b->metrics_slots < 1 || m->n_cells <= 0) return WL_EINVAL;
     if (b->stride % 64 != 0 || ((uintptr_t)b->state & 15u)) return WL_EALIGN;
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
+    if (!flags_ok(b)) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f) || m->rows <= 0 || m->cols <= 0) return WL_EINVAL;
     return WL_OK;
 }
