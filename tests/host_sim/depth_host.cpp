@@ -25,13 +25,14 @@ int hs_depth(const WlVisualParams* p, const WlHeightField* hf, int n, const floa
     std::copy(hf->height, hf->height + (size_t)hf->nx * hf->ny, buf.begin() + py.h0);
     const DepthGrid g = make_depth_grid(hf);
     const FieldMem mem{buf.data()};
+    const float zclear = clear_height(g, py, mem);
     for (int e = 0; e < n; ++e) {
         const Quat q{quat[4 * e], quat[4 * e + 1], quat[4 * e + 2], quat[4 * e + 3]};
         const Mat3 R = mat_from_quat(q);
         const V3 o = v3(pos[3 * e], pos[3 * e + 1], pos[3 * e + 2]) + mul(R, v3(p->cam_pos[0], p->cam_pos[1], p->cam_pos[2]));
         for (int r = 0; r < WL_VIS_IMG_H; ++r)
             for (int c = 0; c < WL_VIS_IMG_W; ++c)
-                depth[((size_t)e * WL_VIS_IMG_H + r) * WL_VIS_IMG_W + c] = cast_ray(g, py, mem, o, mul(R, depth_pixel_ray_body(*p, r, c)), max_depth);
+                depth[((size_t)e * WL_VIS_IMG_H + r) * WL_VIS_IMG_W + c] = cast_ray(g, py, mem, zclear, o, mul(R, depth_pixel_ray_body(*p, r, c)), max_depth);
     }
     return 0;
 }

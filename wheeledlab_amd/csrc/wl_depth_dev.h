@@ -80,6 +80,9 @@ WL_DEV float plane_hit(float oz, float dz, float zp, float ta, float tb) {
 // out); rays that fall start near the level at which the ground in front of the car stops being skippable.  Same-box A/B at
 // 4096 cameras (us per render at 100 / 20 / 5 m range): 4 / 4: 694 / 665 / 566, 3 / 7: 694 / 673 / 565, 2 / 6: 685 / 683 / 563,
 // 4 / 8: 712 / 689 / 577 -- flat; the walk finds its level within two or three steps wherever it starts.
+#ifndef WL_DEPTH_STEP_HOOK
+#define WL_DEPTH_STEP_HOOK(L)       // host instrumentation (walk steps per ray): nothing in the device build
+#endif
 #ifndef WL_DEPTH_START_LEVEL
 #define WL_DEPTH_START_LEVEL 3      // falling rays
 #endif
@@ -96,131 +99,202 @@ inline DepthGrid make_depth_grid(const WlHeightField* hf) {
     return DepthGrid{hf->nx, hf->nx - 1, hf->ny - 1, hf->x0, hf->y0, 1.f / hf->cell, hf->outside_z};
 }
 
+// The walk of ONE ray as a state machine, so that a wavefront can keep its lanes busy: ray_begin() sets a ray up (or answers it
+// at once: never over the grid, underground, ...), ray_step() advances it by one pyramid cell, ray_result() closes it.  The
+// kernel (wl_depth.hip) hands a lane the next ray of its pool the moment the lane's ray is done.  Spec: oracle/depth.c::cast_ray.
+struct RayWalk {
+    // constants of the ray
+    float ou, ov, du, dv, idu, idv, oz, dz;
+    float t_stop, t_out, tmax;
+    int su, sv;
+    // the walk
+    float t, res;
+    int i, j, L;
+    bool live;      // still walking (false: `res` is final, or the walk left the grid / the range: see ray_result)
+    bool cleared;   // t_stop is the parameter beyond which a RISING ray is above every height of the field and the outside plane
+};
+
 // Distance along the optical axis (|d_body.x| = 1) to the first point of the ray o + t d on or below the terrain solid,
-// clipped at tmax.  Spec: oracle/depth.c::cast_ray.
-WL_DEV float cast_ray(const DepthGrid& g, const Pyramid& py, const FieldMem& mem, const V3 o, const V3 d, const float tmax) {
+// clipped at tmax: set-up.  `zclear`: the highest height of the field (the pyramid's top entry) or the outside plane, whichever
+// is higher -- a rising ray that has climbed past it can meet nothing any more, its walk ends there instead of at the grid's edge
+// (round 4: sky rays 6 -> 2.5 steps, every ray 10.3 -> 8.6 on the bench poses; same results bit for bit).
+WL_DEV RayWalk ray_begin(const DepthGrid& g, const Pyramid& py, const float zclear, const V3 o, const V3 d, const float tmax) {
     const int NX = g.NX, NY = g.NY;
-    const float ou = (o.x - g.x0) * g.inv_cell, ov = (o.y - g.y0) * g.inv_cell;
-    const float du = d.x * g.inv_cell, dv = d.y * g.inv_cell;
-    const float oz = o.z, dz = d.z;
+    RayWalk w;
+    w.ou = (o.x - g.x0) * g.inv_cell, w.ov = (o.y - g.y0) * g.inv_cell;
+    w.du = d.x * g.inv_cell, w.dv = d.y * g.inv_cell;
+    w.oz = o.z, w.dz = d.z;
+    w.tmax = tmax;
+    w.live = false;
+    w.cleared = false;
+    w.res = -1.f;
+    w.t = 0.f, w.i = w.j = 0, w.L = 0, w.t_stop = 0.f;
+    const float ou = w.ou, ov = w.ov, du = w.du, dv = w.dv, oz = w.oz, dz = w.dz;
     // a direction component of exactly zero never reaches a cell line: the huge reciprocal with `up` set sends that line's
     // parameter to +1e30 (the line above the entry cell is strictly above the entry point)
     const bool up_u = du >= 0.f, up_v = dv >= 0.f;
-    const float idu = du != 0.f ? rcp(du) : 1e30f, idv = dv != 0.f ? rcp(dv) : 1e30f;
+    w.idu = du != 0.f ? rcp(du) : 1e30f, w.idv = dv != 0.f ? rcp(dv) : 1e30f;
+    w.su = up_u ? 1 : 0, w.sv = up_v ? 1 : 0;
     // parameter interval of the ground track inside the grid domain [0, NX] x [0, NY]
     float t_in = -INFINITY, t_out = INFINITY;
     if (du != 0.f) {
-        const float a = (0.f - ou) * idu, b = ((float)NX - ou) * idu;
+        const float a = (0.f - ou) * w.idu, b = ((float)NX - ou) * w.idu;
         t_in = fmaxf(t_in, fminf(a, b));
         t_out = fminf(t_out, fmaxf(a, b));
     } else if (ou < 0.f || ou >= (float)NX) {
         t_in = INFINITY;
     }
     if (dv != 0.f) {
-        const float a = (0.f - ov) * idv, b = ((float)NY - ov) * idv;
+        const float a = (0.f - ov) * w.idv, b = ((float)NY - ov) * w.idv;
         t_in = fmaxf(t_in, fminf(a, b));
         t_out = fminf(t_out, fmaxf(a, b));
     } else if (ov < 0.f || ov >= (float)NY) {
         t_in = INFINITY;
     }
+    w.t_out = t_out;
     if (!(t_in <= t_out) || t_out < 0.f || t_in > tmax) {   // never over the grid within range
         const float t = plane_hit(oz, dz, g.outside_z, 0.f, tmax);
-        return t >= 0.f ? t : tmax;
+        w.res = t >= 0.f ? t : tmax;
+        return w;
     }
     if (t_in > 0.f) {
         const float t = plane_hit(oz, dz, g.outside_z, 0.f, t_in);
-        if (t >= 0.f) return t;
+        if (t >= 0.f) {
+            w.res = t;
+            return w;
+        }
     } else {
         t_in = 0.f;
     }
-    const float t_stop = fminf(t_out, tmax);
-    float t = t_in;
-    int i, j;
+    w.t_stop = fminf(t_out, tmax);
+    if (dz > 0.f) {     // rising: above everything from t_clear on
+        const float t_clear = (zclear + 1e-5f - oz) * rcp(dz);
+        if (t_clear < w.t_stop) {
+            w.t_stop = t_clear;
+            w.cleared = true;
+            if (t_clear <= t_in) {   // already above everything where it enters the grid
+                w.res = tmax;
+                return w;
+            }
+        }
+    }
+    w.t = t_in;
     {
-        const float u = fmaf(t, du, ou), v = fmaf(t, dv, ov);
+        const float u = fmaf(w.t, du, ou), v = fmaf(w.t, dv, ov);
         const float fu = floorf(u), fv = floorf(v);
-        i = (int)fu - ((fu == u && du < 0.f) ? 1 : 0);
-        j = (int)fv - ((fv == v && dv < 0.f) ? 1 : 0);
-        i = min(max(i, 0), NX - 1);
-        j = min(max(j, 0), NY - 1);
+        int i = (int)fu - ((fu == u && du < 0.f) ? 1 : 0);
+        int j = (int)fv - ((fv == v && dv < 0.f) ? 1 : 0);
+        w.i = min(max(i, 0), NX - 1);
+        w.j = min(max(j, 0), NY - 1);
     }
-    const int su = up_u ? 1 : 0, sv = up_v ? 1 : 0;
-    int L = min(dz >= 0.f ? WL_DEPTH_START_LEVEL_UP : WL_DEPTH_START_LEVEL, py.lp);
-    float res = -1.f;
-    // bound on walk steps: a ground track crosses at most NX + NY cell lines, every cell costs at most a climb, a descent and a
-    // visit per level change -- generous, and finite whatever rounding does (a GPU must never spin)
-    const int max_walk = 4 * (NX + NY) + 64;
-#pragma unroll 1
-    for (int it = 0; it < max_walk; ++it) {
-        // the level-L cell of (i, j), the parameter at which the ray leaves it, the ray's lowest point inside it
-        const int iL = i >> L, jL = j >> L;
-        const int bx = (iL + su) << L, by = (jL + sv) << L;
-        // (line - origin) / direction -- not fma(line, 1 / d, -origin / d), two instructions shorter: for rays nearly parallel to
-        // a grid axis the two products are ~1e5 and the exit parameter would carry their rounding (up to centimetres).  The walk
-        // survives that (a hit the shortened interval misses is caught by the next cell's entry test; the parity sets pass either
-        // way), but an exit parameter that is exact to rounding is worth two instructions
-        const float tx = ((float)bx - ou) * idu, ty = ((float)by - ov) * idv;
-        const float te = fmaxf(fminf(fminf(tx, ty), t_stop), t);
-        const float z_t = fmaf(t, dz, oz);
-        const float zmin = dz < 0.f ? fmaf(te, dz, oz) : z_t;
-        const bool fine = L == 0;
-        float h00, h10, h01, h11, m;
-        if (fine) {
-            const int k = py.h0 + (int)__umul24((unsigned)j, (unsigned)g.nx) + i;   // j, nx < 2^24: the full-rate multiply
-            mem.ld2(k, h00, h10);
-            mem.ld2(k + g.nx, h01, h11);
-            m = fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
-        } else {
-            m = mem.ld(pyramid_level_offset(py.lp, L) + (jL << (py.lp - L)) + iL);
-        }
-        if (!(zmin > m + 1e-6f)) {      // the ray may touch something in this cell
-            if (!fine) {
-                --L;
-                continue;
-            }
-            const float hx = h10 - h00, hy = h01 - h00, hxy = (h11 - h10) - hy;
-            const float fu = clampf(fmaf(t, du, ou) - (float)i, 0.f, 1.f), fv = clampf(fmaf(t, dv, ov) - (float)j, 0.f, 1.f);
-            const float C = z_t - fmaf(fu * fv, hxy, fmaf(fv, hy, fmaf(fu, hx, h00)));
-            if (C <= 0.f) {
-                res = t;
-                break;
-            }
-            const float A = -du * dv * hxy;
-            const float B = dz - fmaf(fmaf(fu, dv, fv * du), hxy, fmaf(dv, hy, du * hx));
-            const float disc = fmaf(B, B, -4.f * A * C);
-            if (disc >= 0.f) {
-                const float q = -0.5f * (B + copysignf(fsqrt(disc), B));
-                const float r1 = q * rcp(A), r2 = C * rcp(q);   // A == 0 / q == 0: inf or NaN, neither passes the tests below
-                float s = INFINITY;
-                if (r1 > 0.f && r1 < s) s = r1;
-                if (r2 > 0.f && r2 < s) s = r2;
-                if (s <= te - t) {
-                    res = t + s;
-                    break;
-                }
-            }
-        }
-        // leave the level-L cell through its nearer line; climb when that line is also the parent's
-        if (te >= t_stop) break;
-        t = te;
-        const bool exit_x = tx <= ty;
-        // the coordinate ALONG the line crossed, recomputed from t and kept inside the cell just left (rounding must not move it
-        // to a cell the ray has not reached); the coordinate ACROSS it steps by one cell of level L
-        const float w = floorf(fmaf(t, exit_x ? dv : du, exit_x ? ov : ou));
-        const int lo = (exit_x ? jL : iL) << L;
-        const int c = min(max((int)w, lo), min(lo + (1 << L) - 1, (exit_x ? NY : NX) - 1));
-        i = exit_x ? bx + su - 1 : c;
-        j = exit_x ? c : by + sv - 1;
-        if ((unsigned)i >= (unsigned)NX || (unsigned)j >= (unsigned)NY) break;
-        const int edge = exit_x ? iL ^ su : jL ^ sv;    // moving up out of an odd cell / down out of an even one: a new parent
-        L += ((edge & 1) == 0 && L < py.lp) ? 1 : 0;
+    w.L = min(dz >= 0.f ? WL_DEPTH_START_LEVEL_UP : WL_DEPTH_START_LEVEL, py.lp);
+    w.live = true;
+    return w;
+}
+
+// one step of the walk: test the level-L cell of (i, j); hit, descend, or leave it through its nearer line
+WL_DEV void ray_step(const DepthGrid& g, const Pyramid& py, const FieldMem& mem, RayWalk& w) {
+    const int NX = g.NX, NY = g.NY;
+    const float ou = w.ou, ov = w.ov, du = w.du, dv = w.dv, oz = w.oz, dz = w.dz, idu = w.idu, idv = w.idv, t = w.t, t_stop = w.t_stop;
+    const int su = w.su, sv = w.sv, i = w.i, j = w.j, L = w.L;
+    WL_DEPTH_STEP_HOOK(L);
+    // the level-L cell of (i, j), the parameter at which the ray leaves it, the ray's lowest point inside it
+    const int iL = i >> L, jL = j >> L;
+    const int bx = (iL + su) << L, by = (jL + sv) << L;
+    // (line - origin) / direction -- not fma(line, 1 / d, -origin / d), two instructions shorter: for rays nearly parallel to
+    // a grid axis the two products are ~1e5 and the exit parameter would carry their rounding (up to centimetres).  The walk
+    // survives that (a hit the shortened interval misses is caught by the next cell's entry test; the parity sets pass either
+    // way), but an exit parameter that is exact to rounding is worth two instructions
+    const float tx = ((float)bx - ou) * idu, ty = ((float)by - ov) * idv;
+    const float te = fmaxf(fminf(fminf(tx, ty), t_stop), t);
+    const float z_t = fmaf(t, dz, oz);
+    const float zmin = dz < 0.f ? fmaf(te, dz, oz) : z_t;
+    const bool fine = L == 0;
+    float h00, h10, h01, h11, m;
+    if (fine) {
+        const int k = py.h0 + (int)__umul24((unsigned)j, (unsigned)g.nx) + i;   // j, nx < 2^24: the full-rate multiply
+        mem.ld2(k, h00, h10);
+        mem.ld2(k + g.nx, h01, h11);
+        m = fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
+    } else {
+        m = mem.ld(pyramid_level_offset(py.lp, L) + (jL << (py.lp - L)) + iL);
     }
-    if (res >= 0.f) return fminf(res, tmax);
-    if (t_out < tmax) {
-        const float th = plane_hit(oz, dz, g.outside_z, t_out, tmax);
+    if (!(zmin > m + 1e-6f)) {      // the ray may touch something in this cell
+        if (!fine) {
+            w.L = L - 1;
+            return;
+        }
+        const float hx = h10 - h00, hy = h01 - h00, hxy = (h11 - h10) - hy;
+        const float fu = clampf(fmaf(t, du, ou) - (float)i, 0.f, 1.f), fv = clampf(fmaf(t, dv, ov) - (float)j, 0.f, 1.f);
+        const float C = z_t - fmaf(fu * fv, hxy, fmaf(fv, hy, fmaf(fu, hx, h00)));
+        if (C <= 0.f) {
+            w.res = t;
+            w.live = false;
+            return;
+        }
+        const float A = -du * dv * hxy;
+        const float B = dz - fmaf(fmaf(fu, dv, fv * du), hxy, fmaf(dv, hy, du * hx));
+        const float disc = fmaf(B, B, -4.f * A * C);
+        if (disc >= 0.f) {
+            const float q = -0.5f * (B + copysignf(fsqrt(disc), B));
+            const float r1 = q * rcp(A), r2 = C * rcp(q);   // A == 0 / q == 0: inf or NaN, neither passes the tests below
+            float s = INFINITY;
+            if (r1 > 0.f && r1 < s) s = r1;
+            if (r2 > 0.f && r2 < s) s = r2;
+            if (s <= te - t) {
+                w.res = t + s;
+                w.live = false;
+                return;
+            }
+        }
+    }
+    // leave the level-L cell through its nearer line; climb when that line is also the parent's
+    if (te >= t_stop) {
+        w.live = false;
+        return;
+    }
+    w.t = te;
+    const bool exit_x = tx <= ty;
+    // the coordinate ALONG the line crossed, recomputed from t and kept inside the cell just left (rounding must not move it
+    // to a cell the ray has not reached); the coordinate ACROSS it steps by one cell of level L
+    const float wl = floorf(fmaf(te, exit_x ? dv : du, exit_x ? ov : ou));
+    const int lo = (exit_x ? jL : iL) << L;
+    const int c = min(max((int)wl, lo), min(lo + (1 << L) - 1, (exit_x ? NY : NX) - 1));
+    const int ni = exit_x ? bx + su - 1 : c, nj = exit_x ? c : by + sv - 1;
+    w.i = ni, w.j = nj;
+    if ((unsigned)ni >= (unsigned)NX || (unsigned)nj >= (unsigned)NY) {
+        w.live = false;
+        return;
+    }
+    const int edge = exit_x ? iL ^ su : jL ^ sv;    // moving up out of an odd cell / down out of an even one: a new parent
+    w.L = L + (((edge & 1) == 0 && L < py.lp) ? 1 : 0);
+}
+
+// the answer of a ray whose walk has ended
+WL_DEV float ray_result(const DepthGrid& g, const RayWalk& w) {
+    if (w.res >= 0.f) return fminf(w.res, w.tmax);
+    if (!w.cleared && w.t_out < w.tmax) {
+        const float th = plane_hit(w.oz, w.dz, g.outside_z, w.t_out, w.tmax);
         if (th >= 0.f) return th;
     }
-    return tmax;
+    return w.tmax;
+}
+
+// bound on walk steps: a ground track crosses at most NX + NY cell lines, every cell costs at most a climb, a descent and a
+// visit per level change -- generous, and finite whatever rounding does (a GPU must never spin)
+WL_DEV int max_walk_steps(const DepthGrid& g) { return 4 * (g.NX + g.NY) + 64; }
+
+// one ray from start to end (the host simulation and the one-ray-per-lane kernel form)
+WL_DEV float cast_ray(const DepthGrid& g, const Pyramid& py, const FieldMem& mem, const float zclear, const V3 o, const V3 d, const float tmax) {
+    RayWalk w = ray_begin(g, py, zclear, o, d, tmax);
+    const int max_walk = max_walk_steps(g);
+#pragma unroll 1
+    for (int it = 0; it < max_walk && w.live; ++it) ray_step(g, py, mem, w);
+    return ray_result(g, w);
+}
+// the height nothing of the terrain solid rises above: the pyramid's top entry (the field's maximum) or the outside plane
+WL_DEV float clear_height(const DepthGrid& g, const Pyramid& py, const FieldMem& mem) {
+    return fmaxf(mem.ld(pyramid_level_offset(py.lp, py.lp)), g.outside_z);
 }
 
 // camera ray of pixel (row, col) of the FULL 60 x 80 image in the body frame: optical axis = body +x, image right = body -y,
