@@ -46,22 +46,114 @@ __global__ void __launch_bounds__(kBlock) pyramid_copy_heights_kernel(const floa
     if (k < n) dst[k] = h[k];
 }
 
-__global__ void __launch_bounds__(64) visual_depth_kernel(const WlVisualParams p, const WlEnvBuffers b, const DepthGrid g,
-                                                                     const Pyramid py, const float* __restrict__ buf, const unsigned buf_bytes,
-                                                                     const float max_depth, float* __restrict__ depth) {
-    const int e = blockIdx.x / kTiles, tile = blockIdx.x - e * kTiles;
-    const int strip = tile / kTilesPerStrip;
+// camera pose of env e: origin and the rotation of its body frame
+struct DepthCam {
+    V3 o;
+    Mat3 R;
+};
+WL_DEV DepthCam depth_cam(const WlVisualParams& p, const WlEnvBuffers& b, int e) {
     const Rows S = make_rows(b.state, b.stride);
     const V3 pos = ld3(S, WL_S_PX, e);
     const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
-    const Mat3 R = mat_from_quat(q);
-    const V3 o = pos + mul(R, v3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
+    DepthCam c;
+    c.R = mat_from_quat(q);
+    c.o = pos + mul(c.R, v3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]));
+    return c;
+}
+
+// one ray per lane, one 4 x 16 tile per wavefront: the wavefront lives as long as its longest ray (lanes busy 0.6 of the time on
+// the bench poses).  Kept as the A/B reference of the pool form below (-DWL_DEPTH_POOL_ROWS=0 builds the library with it).
+__global__ void __launch_bounds__(64) visual_depth_tile_kernel(const WlVisualParams p, const WlEnvBuffers b, const DepthGrid g,
+                                                                const Pyramid py, const float* __restrict__ buf, const unsigned buf_bytes,
+                                                                const float max_depth, float* __restrict__ depth) {
+    const int e = blockIdx.x / kTiles, tile = blockIdx.x - e * kTiles;
+    const int strip = tile / kTilesPerStrip;
+    const DepthCam cam = depth_cam(p, b, e);
     const int lane = threadIdx.x;
     const int row = strip * kStripRows + (lane >> 4), col = (tile - strip * kTilesPerStrip) * kTileCols + (lane & 15);
-    const V3 d = mul(R, depth_pixel_ray_body(p, row, col));
+    const V3 d = mul(cam.R, depth_pixel_ray_body(p, row, col));
     const FieldMem mem{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(buf), 0, (int)buf_bytes, 0x00020000)};
-    const float t = cast_ray(g, py, mem, o, d, max_depth);
+    const float t = cast_ray(g, py, mem, clear_height(g, py, mem), cam.o, d, max_depth);
     depth[(int64_t)e * (WL_VIS_IMG_H * WL_VIS_IMG_W) + row * WL_VIS_IMG_W + col] = t;
+}
+
+// Ray POOL per wavefront (round 4).  A tile's walk lengths differ 5 x between lanes (sky 2 - 3 steps, near ground 8 - 10, the rows
+// below the horizon 15 - 20, grazing rays 100 +): with one ray per lane 40 % of the lane-steps are idle lanes waiting for the
+// tile's longest ray.  Here a wavefront owns POOL_ROWS image rows of one env (POOL_ROWS x 80 rays, in 4 x 16 tile order so that
+// the lanes start as neighbours) and a lane whose ray is done takes the next ray of the pool: whenever at least THRESH lanes are
+// idle they are refilled in ONE pass of the set-up code (ballot + prefix count give each idle lane its pool index; the set-up costs
+// about as much as a step, so it has to be shared by many lanes).  On the bench poses the lanes are busy 0.80 of the steps instead
+// of 0.60 (host simulation of the same walk, tests/host_sim): 11.8 wave-steps per 64 rays against 15.2.
+#ifndef WL_DEPTH_POOL_ROWS
+#define WL_DEPTH_POOL_ROWS 12
+#endif
+#ifndef WL_DEPTH_POOL_THRESH
+#define WL_DEPTH_POOL_THRESH 20
+#endif
+template <int POOL_ROWS, int THRESH>
+__global__ void __launch_bounds__(64) visual_depth_pool_kernel(const WlVisualParams p, const WlEnvBuffers b, const DepthGrid g,
+                                                                const Pyramid py, const float* __restrict__ buf, const unsigned buf_bytes,
+                                                                const float max_depth, float* __restrict__ depth) {
+    static_assert(POOL_ROWS % kStripRows == 0 && WL_VIS_IMG_H % POOL_ROWS == 0, "whole strips per pool, whole pools per image");
+    constexpr int kPools = WL_VIS_IMG_H / POOL_ROWS, kPool = POOL_ROWS * WL_VIS_IMG_W;
+    const int e = blockIdx.x / kPools, r0 = (blockIdx.x - e * kPools) * POOL_ROWS;
+    const DepthCam cam = depth_cam(p, b, e);
+    const FieldMem mem{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(buf), 0, (int)buf_bytes, 0x00020000)};
+    const float zclear = clear_height(g, py, mem);
+    float* img = depth + (int64_t)e * (WL_VIS_IMG_H * WL_VIS_IMG_W) + r0 * WL_VIS_IMG_W;
+    const int lane = threadIdx.x;
+    const int max_walk = max_walk_steps(g);
+    // pool index -> pixel of the pool's rows: tile (q >> 6) = strip-major 4 x 16 tiles, (q & 63) = row-major inside the tile
+    auto pixel = [](int q, int& row, int& col) {
+        const int tile = q >> 6, in = q & 63;
+        const int strip = (int)(__umul24((unsigned)tile, 13108u) >> 16);    // tile / 5 for tile < 2^14
+        row = strip * kStripRows + (in >> 4);
+        col = (tile - strip * kTilesPerStrip) * kTileCols + (in & 15);
+    };
+    // pixel -> ray through the reciprocal focal lengths (one division each per wavefront, not two per ray set-up)
+    const float ifx = 1.f / p.fx, ify = 1.f / p.fy;
+    auto ray_dir = [&](int prow, int pcol) {
+        return mul(cam.R, v3(1.f, -(((float)pcol + 0.5f - p.cx) * ifx), -(((float)(r0 + prow) + 0.5f - p.cy) * ify)));
+    };
+    int q = lane, row, col, steps = 0;
+    pixel(q, row, col);
+    RayWalk w = ray_begin(g, py, zclear, cam.o, ray_dir(row, col), max_depth);
+    bool have = true;
+    int next = 64;          // wave-uniform: the first pool index nobody has taken
+#pragma unroll 1
+    for (;;) {
+        if (have) {
+            if (w.live && steps < max_walk) {
+                ray_step(g, py, mem, w);
+                ++steps;
+            } else {
+#ifdef WL_DEPTH_NT
+                __builtin_nontemporal_store(ray_result(g, w), img + row * WL_VIS_IMG_W + col);
+#else
+                img[row * WL_VIS_IMG_W + col] = ray_result(g, w);
+#endif
+                have = false;
+            }
+        }
+        const uint64_t idle = __ballot(!have);
+        const int n_idle = __popcll(idle);
+        if (next < kPool) {
+            if (n_idle >= THRESH) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                const int qn = next + rank;
+                if (!have && qn < kPool) {
+                    q = qn;
+                    pixel(q, row, col);
+                    w = ray_begin(g, py, zclear, cam.o, ray_dir(row, col), max_depth);
+                    steps = 0;
+                    have = true;
+                }
+                next += n_idle;
+            }
+        } else if (n_idle == 64) {
+            break;
+        }
+    }
 }
 
 }  // namespace
@@ -95,7 +187,12 @@ int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeig
     const Pyramid py = make_pyramid(hf->nx, hf->ny);
     const unsigned bytes = (unsigned)(pyramid_total_floats(hf->nx, hf->ny) * 4);
     clear_error();
-    visual_depth_kernel<<<b->n_envs * kTiles, 64, 0, (hipStream_t)stream>>>(*p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, depth);
+#if WL_DEPTH_POOL_ROWS > 0
+    visual_depth_pool_kernel<WL_DEPTH_POOL_ROWS, WL_DEPTH_POOL_THRESH><<<b->n_envs * (WL_VIS_IMG_H / WL_DEPTH_POOL_ROWS), 64, 0, (hipStream_t)stream>>>(
+        *p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, depth);
+#else
+    visual_depth_tile_kernel<<<b->n_envs * kTiles, 64, 0, (hipStream_t)stream>>>(*p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, depth);
+#endif
     return launch_status();
 }
 
