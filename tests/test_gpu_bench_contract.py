@@ -42,7 +42,14 @@ def test_two_ranks_reduce_their_metrics_every_step():
     line = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                  "--master-port", "29542", "bench.py", "--gpus", "2", *ARGS, "--allreduce-every", "1"], env={"WL_BENCH_BACKEND": "gloo"})
     assert line["n_gpus"] == 2 and line["config"]["total_envs"] == 8192
-    assert line["rccl"] == {"backend": "gloo", "world": 2, "ranks_seen": 2, "allreduce_every": 1}
+    rc = line["rccl"]
+    assert {k: rc[k] for k in ("backend", "world", "ranks_seen", "allreduce_every")} == {"backend": "gloo", "world": 2, "ranks_seen": 2,
+                                                                                      "allreduce_every": 1}
+    # what the first multi-GPU run is to yield beside the curve: the per-rank spread of the launch duration and the latency of the
+    # path's one collective
+    assert 0 < rc["launch_us_min_over_ranks"] <= rc["launch_us_max_over_ranks"] < 100
+    ar = rc["metric_allreduce_us"]
+    assert ar["bytes"] == 64 and ar["samples"] == 20 and 0 < ar["min_this_rank"] <= ar["median_max_over_ranks"]
     t = line["timing"]
     assert t["allreduce_every"] == 1 and t["metric_reductions_in_timed_blocks"] == 11 * 20      # one collective per env.step()
     assert line["episode_metrics"]["resets"] > 0 and line["roofline"]["envs_per_launch"] == 4096

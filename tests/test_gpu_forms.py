@@ -254,13 +254,15 @@ def test_drift_4m_envs_equal_four_1m_shards_and_the_oracle(A):
 
 
 def test_drift_65536_envs_equal_two_shards(A):
-    """large_n_sweep's first row: the lane form with packed axles"""
+    """large_n_sweep's first row: the lane form with packed axles (the 32 768-env shards are told to run the same form: by size they
+    would take the quad form, which orders its arithmetic differently -- equal to the oracle within tolerance, not to the lane form
+    bit for bit)"""
     from wheeledlab_amd.params import drift_params
 
     def make(m, off):
         p = drift_params()
         p.max_episode_length = 4
-        return _drift(m, 42, 0, 0, off, params=p)
+        return _drift(m, 42, 0, 0 if m == 65536 else 1, off, params=p)
     _, done = _shards_equal_big(make, 65536, 2, 6)
     assert done >= 65536
 
@@ -278,12 +280,12 @@ def test_elevation_262144_envs_equal_two_shards(A):
 
 
 def test_visual_65536_envs_equal_two_shards(A):
-    """other_tasks_large_n: lane-form step + the streaming camera"""
+    """other_tasks_large_n: lane-form step + the streaming camera (shards forced to the lane form, see the drift test)"""
     from wheeledlab_amd.params import visual_params
 
     def make(m, off):
         p = visual_params()
         p.max_episode_length = 2
-        return _visual(m, 42, 0, 0, off, params=p)
+        return _visual(m, 42, 0, 0 if m == 65536 else 1, off, params=p)
     _, done = _shards_equal_big(make, 65536, 2, 3)
     assert done >= 65536
