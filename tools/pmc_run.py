@@ -15,12 +15,15 @@ if argv and not argv[0].isdigit():
     task, argv = argv[0], argv[1:]
 n, K = int(argv[0]), int(argv[1])
 lanes = int(argv[2]) if len(argv) > 2 else 0
+flags = int(os.environ.get("WL_FLAGS", "0"))     # WlEnvBuffers.flags: force an instantiation (round 4: scan forms, streaming)
 dev = "cuda:0"
 if task == "drift":
     env = DriftBatch(n, device=dev, seed=42)
     env.reset()
     if lanes:
         env.set_lanes(lanes)   # force a step-kernel form (WlEnvBuffers.lanes)
+    if flags:
+        env.set_flags(flags)
     a = torch.rand(K, n, 2, device=dev) * 2 - 1
     obs = torch.zeros(K, n, 14, device=dev)
     rew = torch.zeros(K, n, device=dev)
@@ -32,6 +35,8 @@ elif task in ("elev", "visual"):
     env.reset()
     if lanes:
         env.set_lanes(lanes)
+    if flags:
+        env.set_flags(flags)
     if task == "visual":
         env.sample_augmentation(torch.Generator().manual_seed(0))
     a = torch.rand(K, n, 2, device=dev) * 2 - 1

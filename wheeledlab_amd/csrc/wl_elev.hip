@@ -35,7 +35,10 @@ enum ElevStream : uint32_t { ES_RESET = 0, ES_CMD_RESET = 1, ES_CMD_RESAMPLE = 2
 
 // cos / sin of the yaw of IsaacLab's yaw_quat(q) without the atan2 round trip
 WL_DEV void yaw_cs(Quat q, float& c, float& s) {
-    const float a = 1.f - 2.f * (q.y * q.y + q.z * q.z), b = 2.f * (q.w * q.z + q.x * q.y);
+    // every multiply-add spelled out: under -ffp-contract=fast the compiler picks WHICH product of a sum of products it fuses per
+    // inlining site, and two sites of one kernel then round differently (round 4: the first and the later envs of a persistent
+    // scan block disagreed in the last bit)
+    const float a = fmaf(-2.f, fmaf(q.z, q.z, q.y * q.y), 1.f), hb = fmaf(q.w, q.z, q.x * q.y), b = hb + hb;
     const float inv = rsq(fmaf(a, a, b * b));
     c = a * inv;
     s = b * inv;
@@ -129,6 +132,124 @@ WL_DEV ElevReset draw_elev_reset(const WlElevParams& p, const HeightFieldGround&
 struct ScanPose {
     float px, py, pz, c, s;
 };
+
+// ---- world_height_map (:44-48): the 26 x 26 yaw-aligned height scan -- what every form below evaluates per ray ------------------
+// The rays of one env form a lattice; in GRID units (cells of the heightfield) ray (ix, iy) stands at
+// (u0 + ix ux + iy uy, v0 + ix vx + iy vy).  Round 4: the lattice frame is set up once per env (7 floats, what the fused kernels
+// keep in LDS) and a ray costs ~35 VALU instructions instead of ~62 (the ray's metres -> rotate -> translate -> grid units chain,
+// four float compares for the inside test and 64-bit address arithmetic went; the scan was as much instruction- as gather-bound:
+// 676 rays x 62 / 64 lanes = 655 wavefront-instructions per env against ~1100 clocks per env and CU).  Same definition
+// (oracle/elev_step.py::height_map, heightfield.py::sample); fp32 rounding of the ray position differs by a few ulp of the grid
+// coordinate (<= 1e-4 cell) from the metre chain, and the sampler's 1e-3-cell guard at the far border is not needed (the
+// integer cell index is clamped instead): both far inside the parity tolerance (2e-5 m on the height map).
+struct ScanFrame {
+    float u0, v0, ux, vx, uy, vy, pz;
+};
+WL_DEV ScanFrame scan_frame(const WlElevParams& p, const HeightFieldGround& g, const ScanPose& sp) {
+    const float g0 = -0.5f * p.scan_size, k = p.scan_res * g.inv_cell;
+    ScanFrame f;
+    // (multiply-adds spelled out: see yaw_cs)
+    f.u0 = ((sp.px + fmaf(sp.c, g0, -(sp.s * g0))) - g.f.x0) * g.inv_cell;
+    f.v0 = ((sp.py + fmaf(sp.s, g0, sp.c * g0)) - g.f.y0) * g.inv_cell;
+    f.ux = sp.c * k, f.vx = sp.s * k;
+    f.uy = -sp.s * k, f.vy = sp.c * k;
+    f.pz = sp.pz;
+    return f;
+}
+// ray index r (< 1024) of the scan -> lattice coordinates, meshgrid "xy": x fastest (r / 26 by multiply-shift: exact, checked)
+WL_DEV void scan_ray_xy(int r, float& fix, float& fiy) {
+    const int iy = (int)(__umul24((unsigned)r, 1261u) >> 15);
+    fix = (float)(r - iy * WL_ELEV_SCAN_N);
+    fiy = (float)iy;
+}
+// the cell a ray falls into: float offset of its lower-left grid point, position inside the cell, inside-the-field flag
+struct ScanCell {
+    int i, j;      // NOT clamped: outside the field when !inside
+    float fu, fv;
+    bool inside;
+};
+WL_DEV ScanCell scan_cell(const ScanFrame& f, const WlHeightField& hf, float fix, float fiy) {
+    const float u = fmaf(fix, f.ux, fmaf(fiy, f.uy, f.u0)), v = fmaf(fix, f.vx, fmaf(fiy, f.vy, f.v0));
+    const float fl_u = floorf(u), fl_v = floorf(v);
+    const int i = (int)fl_u, j = (int)fl_v;      // saturating conversion: far-away rays stay far away
+    ScanCell c;
+    c.fu = u - fl_u;
+    c.fv = v - fl_v;
+    // 0 <= u < nx - 1 as ONE unsigned compare per axis; a NaN pose (converted to cell 0) is caught through its NaN fraction
+    c.inside = (unsigned)i < (unsigned)(hf.nx - 1) && (unsigned)j < (unsigned)(hf.ny - 1) && (c.fu + c.fv >= 0.f);
+    c.i = i, c.j = j;
+    return c;
+}
+// a ray in flight: the two 8-byte gathers of its cell's corners (issued by scan_request), consumed by scan_value
+struct ScanRay {
+    wl_float2_u lo, hi;
+    float fu, fv;
+    bool inside;
+};
+struct ScanField {   // the heightfield through a buffer resource: one 32-bit lane offset per gather
+    __amdgpu_buffer_rsrc_t rsrc;
+    int row_bytes;
+};
+WL_DEV ScanField scan_field(const WlHeightField& hf) {
+    return ScanField{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hf.height), 0, hf.nx * hf.ny * 4, 0x00020000), hf.nx * 4};
+}
+WL_DEV ScanRay scan_request(const ScanFrame& f, const WlHeightField& hf, const ScanField& sf, float fix, float fiy) {
+    const ScanCell c = scan_cell(f, hf, fix, fiy);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    ScanRay r;
+    r.fu = c.fu, r.fv = c.fv, r.inside = c.inside;
+    // a ray outside the field asks for whatever address its cell index wraps to: inside the buffer it reads a value nobody uses
+    // (the ray is a miss), outside it the resource's bounds check returns 0 -- four clamps per ray saved
+    const int idx4 = (c.j * hf.nx + c.i) * 4;
+    // (whole-result bit casts: see FieldMem::ld2 in wl_depth_dev.h)
+    const f32x2 lo = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(sf.rsrc, idx4, 0, 0));
+    const f32x2 hi = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(sf.rsrc, idx4, sf.row_bytes, 0));
+    r.lo.x = lo.x, r.lo.y = lo.y, r.hi.x = hi.x, r.hi.y = hi.y;
+    return r;
+}
+// FOUR consecutive rays per lane, stored as ONE 16-byte word (round 4).  The scan's 676 four-byte stores per env were what bound
+// it, in the gather form and the LDS form alike (both 500 us per launch at 262 144 envs whatever the read side did): a store
+// instruction costs the memory pipeline per INSTRUCTION far more than per byte (MI355X_MICROARCH.md: narrow stores are issue-bound,
+// a dword store ~6 x a dwordx4 store per byte).  Rays 4 q .. 4 q + 3 of an env (q < 169) are neighbours along x; the scan row has 26
+// = 6.5 quads, so a quad starting at ix = 24 continues at (0, iy + 1): ray pairs (0, 1) and (2, 3) never straddle a row.
+typedef float wl_float4_u __attribute__((ext_vector_type(4), aligned(4)));   // observation rows are only 4-byte aligned
+constexpr int kScanQuads = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N / 4;             // 169
+static_assert(WL_ELEV_SCAN_N % 2 == 0 && (WL_ELEV_SCAN_N * WL_ELEV_SCAN_N) % 4 == 0, "ray pairs stay inside a scan row, whole quads per env");
+// quad slot (env-in-block x 169 + quad, < 2^13) -> env j, quad q (idx / 169 by multiply-shift: exact, checked)
+WL_DEV void scan_quad_slot(int idx, int& j, int& q) {
+    j = (int)(__umul24((unsigned)idx, 6205u) >> 20);
+    q = idx - j * kScanQuads;
+}
+// bilinear height under the ray -> the observation value: -(sensor_z - hit_z - offset) + (root_z - plane_init_value), +inf on a
+// miss, clipped to +- obs_clip
+WL_DEV float scan_value(const WlElevParams& p, const ScanRay& r, float pz) {
+    const float a = fmaf(r.fu, r.lo.y - r.lo.x, r.lo.x), b = fmaf(r.fu, r.hi.y - r.hi.x, r.hi.x);
+    const float hz = fmaf(r.fv, b - a, a);
+    const float val = r.inside ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
+    return clampf(val, -p.obs_clip, p.obs_clip);
+}
+// the gathers of the four rays of quad q (8 x 8 B in flight per lane) ...
+WL_DEV void scan_quad_request(const ScanFrame& f, const WlHeightField& hf, const ScanField& sf, int q, ScanRay (&r)[4]) {
+    float fx0, fy0, fx2, fy2;
+    scan_ray_xy(4 * q, fx0, fy0);
+    scan_ray_xy(4 * q + 2, fx2, fy2);
+    r[0] = scan_request(f, hf, sf, fx0, fy0);
+    r[1] = scan_request(f, hf, sf, fx0 + 1.f, fy0);
+    r[2] = scan_request(f, hf, sf, fx2, fy2);
+    r[3] = scan_request(f, hf, sf, fx2 + 1.f, fy2);
+}
+// ... and their four values as one 16-byte word
+WL_DEV wl_float4_u scan_quad_value(const WlElevParams& p, const ScanRay (&r)[4], float pz) {
+    wl_float4_u v;
+    v.x = scan_value(p, r[0], pz), v.y = scan_value(p, r[1], pz), v.z = scan_value(p, r[2], pz), v.w = scan_value(p, r[3], pz);
+    return v;
+}
+template <bool STREAM>
+WL_DEV void scan_quad_store(float* __restrict__ row_map /* obs row + 13 */, int q, wl_float4_u v) {
+    wl_float4_u* dst = reinterpret_cast<wl_float4_u*>(row_map + 4 * q);
+    if constexpr (STREAM) __builtin_nontemporal_store(v, dst);
+    else *dst = v;
+}
 
 // the dynamic rows of an env as the step needs them at its start (requested in one go, ahead of the parameter block)
 template <int LANES>
@@ -421,116 +542,137 @@ __global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_
 
 // world_height_map (:44-48): the 26 x 26 yaw-aligned height scan, clipped to +-10, into obs[e][13:689].  One block per
 // env; the env's 13 proprioceptive values are written by the lane-per-env kernels (step / prop).
-constexpr int kScanThreads = 128;                       // threads per env: 676 rays -> 5.3 per thread
-constexpr int kScanEnvsPerBlock = kBlock / kScanThreads;
-// 4096 envs x 128 threads = 8192 wavefronts = exactly one resident round of the chip (32 waves x 256 CUs); with 256
-// threads per env the launch needs two rounds and each round pays the pose-load + gather latency chain again.
+// (Rounds 1 - 3: 128 threads per env, 5.3 rays per lane, dword stores.)
+constexpr int kScanThreads = 192;                       // threads per env: 169 quads of rays -> one quad per lane, three wavefronts
 template <bool STREAM>   // observation rows of the launch beyond the Infinity Cache: non-temporal stores
-__global__ void __launch_bounds__(kBlock) elev_scan_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
-                                                           float* __restrict__ obs) {
-    const int e = blockIdx.x * kScanEnvsPerBlock + threadIdx.x / kScanThreads;
-    if (e >= b.n_envs) return;
-    const int tid = threadIdx.x % kScanThreads;
+__global__ void __launch_bounds__(kScanThreads) elev_scan_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
+                                                                 float* __restrict__ obs) {
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (tid >= kScanQuads) return;
     const Rows S = make_rows(b.state, b.stride);
     const float px = S.ld(WL_S_PX, e), py = S.ld(WL_S_PY, e), pz = S.ld(WL_S_PZ, e);
     const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
     float c, s;
     yaw_cs(q, c, s);
-    float* row = obs + (int64_t)e * WL_ELEV_OBS_DIM;
-    const float g0 = -0.5f * p.scan_size;
-    // software-pipelined: all of this lane's rays issue their gathers first (12 x 8 B in flight per lane), then blend and
-    // store -- a rolled loop would pay the gather latency once per ray
-    constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N;
-    constexpr int kIter = (kRays + kScanThreads - 1) / kScanThreads;
-    HeightFieldGround::Corners cr[kIter];
-#pragma unroll
-    for (int it = 0; it < kIter; ++it) {
-        const int k = min(tid + it * kScanThreads, kRays - 1);
-        const int iy = k / WL_ELEV_SCAN_N, ix = k - iy * WL_ELEV_SCAN_N;   // meshgrid "xy": x fastest
-        const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
-        cr[it] = ground.corners(px + (c * lx - s * ly), py + (s * lx + c * ly));
-    }
-#pragma unroll
-    for (int it = 0; it < kIter; ++it) {
-        const int k = tid + it * kScanThreads;
-        if (k < kRays) {
-            const float hz = ground.blend(cr[it]);
-            // world_height_map = -(sensor_z - hit_z - offset) + (root_z - plane_init_value); rays that miss return +inf
-            const float val = cr[it].inside ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
-            if constexpr (STREAM) __builtin_nontemporal_store(clampf(val, -p.obs_clip, p.obs_clip), row + 13 + k);
-            else row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
-        }
-    }
+    const ScanFrame fr = scan_frame(p, ground, ScanPose{px, py, pz, c, s});
+    const ScanField sf = scan_field(ground.f);
+    ScanRay cr[4];
+    scan_quad_request(fr, ground.f, sf, tid, cr);     // this lane's four rays: their 8 gathers in flight together
+    scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, pz));
 }
-// The same scan with the env's terrain patch staged in LDS (BASELINE config 3: "heightfield gather ... in LDS").  The gather form
-// above asks the texture-address unit for 2 x 676 lane addresses per env (two 8-byte gathers per ray, nearly every lane its own
-// cache line once the car is not axis-aligned): ~1100 clocks per env and CU, which is what bounds the task beyond the latency
-// regime (round 3: 515 of the 730 us per step at 262 144 envs).  Here one block = one env: the bounding box of the yaw-rotated
-// 2.5 m footprint -- at most 73 x 73 grid points of the 0.05 m field -- is fetched as whole rows (consecutive lanes =
-// consecutive floats: full-rate coalesced requests, ~1/3 of the address-unit clocks of the gathers), the 676 rays read their four
-// corners from LDS (two ds_read2_b32 each) with the arithmetic of HeightFieldGround::cell_of / blend, so the rows are
-// bit-identical to the gather form's.  LDS pitch kPatch is a compile-time constant (row / column split by multiply-shift).
-constexpr int kPatch = 74;               // grid points per side of the staged patch (scan_size * sqrt 2 / cell + 3 must fit)
-constexpr int kLdsScanThreads = 256;
+// The same scan with the env's terrain patch staged in LDS (BASELINE config 3: "heightfield gather ... in LDS").  One block =
+// one env.  The bounding box of the yaw-rotated 2.5 m footprint -- at most 73 x 73 grid points of the 0.05 m field -- is fetched
+// as whole rows (consecutive lanes = consecutive floats: full-rate coalesced requests, against two divergent 8-byte gathers per
+// ray) and the 676 rays read their four corners from LDS (two ds_read2_b32 each) with the arithmetic of scan_cell / scan_value:
+// the rows are bit-identical to the gather form's.  The staging costs NO vector arithmetic per element: 320 threads = 4 patch rows
+// of pitch 80 per pass, so a thread's column never changes and its row advances by 4 -- the global offset of pass `it` is the
+// thread's constant lane offset + a SCALAR offset (it x 4 field rows), its LDS address the thread's constant + an immediate.
+// Rows past the field's end read 0 through the buffer resource's bounds check (never used: rays there are misses).
+// (Round 4, first version: 256 threads, pitch 74, flat index split by multiply-shift per element, pass count by a chain of scalar
+// branches -- 245 VALU + 216 SALU per wavefront, four wavefronts per env: SLOWER than the gathers at every size, 597 against
+// 502 us per observation launch at 262 144 envs: the scan is instruction-bound before it is address-rate-bound.)
+constexpr int kPatch = 74;               // grid points per side the bounding box can need (scan_size * sqrt 2 / cell + 3 must fit)
+constexpr int kPatchPitch = 80, kPatchRowsLds = 76;   // LDS: pitch 80 floats; 19 passes x 4 rows
+constexpr int kLdsScanThreads = 4 * kPatchPitch;
+// (Round 4, persistent blocks software-pipelined over their envs -- the patch rows of env k + 1 requested before the rays of env k
+// are evaluated: 746 us per launch at 262 144 envs against 483 for this block-per-env form.  1536 resident blocks fall into lock
+// step -- every block requests its rows at once, then every block computes -- and a fresh block per env desynchronises the CU's
+// six blocks for free.  Kept out.)
+// kLdsScanEnvs envs per block through the one LDS patch (the rows of all of them requested up front, the rays of env k evaluated
+// while the rows of env k + 1 are still landing).  Measured at 262 144 envs, us per observation launch: 1 env per block 483,
+// 2 envs per block 497, persistent blocks software-pipelined over ~170 envs 746 (1536 resident blocks fall into lock step), the
+// gather form 510 - 520; the launch without its stores 500, the stores alone 124.  Every form of the read side lands at ~1.9 ns per
+// env: what they share is ~20 KB per env (patch rows, or the cache lines under 1352 gathers) crossing from L2 to a CU -- 5 GB per
+// launch, 11 TB/s -- with a fresh, never re-used working set per block.  The LDS form is the cheapest way through that (7 - 10 %
+// under the gathers from 65 536 envs up) and stays the default there.
+constexpr int kLdsScanEnvs = 1;
 template <bool STREAM>
 __global__ void __launch_bounds__(kLdsScanThreads) elev_scan_lds_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
                                                                         float* __restrict__ obs) {
-    __shared__ float patch[kPatch * kPatch];
-    const int e = blockIdx.x, tid = threadIdx.x;
+    __shared__ float patch[kPatchPitch * kPatchRowsLds];
+    const int tid = threadIdx.x, n = b.n_envs;
+    const int e0 = blockIdx.x * kLdsScanEnvs;
     const Rows S = make_rows(b.state, b.stride);
-    const float px = S.ld(WL_S_PX, e), py = S.ld(WL_S_PY, e), pz = S.ld(WL_S_PZ, e);
-    const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
-    float c, s;
-    yaw_cs(q, c, s);
     const WlHeightField& f = ground.f;
-    // the patch: the footprint's bounding box in grid units, one point of margin below, two above (the +1 corner and rounding)
-    const float half = 0.5f * p.scan_size * ground.inv_cell * (fabsf(c) + fabsf(s)) + 0.05f;
-    const float uc = (px - f.x0) * ground.inv_cell, vc = (py - f.y0) * ground.inv_cell;
-    // (block-uniform values, kept in scalar registers)
-    const int i0 = __builtin_amdgcn_readfirstlane(min(max((int)floorf(uc - half), 0), f.nx - kPatch));
-    const int j0 = __builtin_amdgcn_readfirstlane(min(max((int)floorf(vc - half), 0), f.ny - kPatch));
-    const int rows = __builtin_amdgcn_readfirstlane(min(max((int)floorf(vc + half) + 2 - j0, 1), kPatch));
-    const int n_stage = rows * kPatch;
-    // the field through a buffer resource: one 32-bit lane offset per request, the patch origin in the scalar offset
     const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f.height), 0, f.nx * f.ny * 4, 0x00020000);
-    const int origin = (j0 * f.nx + i0) * 4;
-    constexpr int kStage = (kPatch * kPatch + kLdsScanThreads - 1) / kLdsScanThreads;
-    float stage[kStage];
-    // whole passes of the block are skipped by a SCALAR branch (n_stage is block-uniform); inside a pass the flat index is clamped
-    // instead of predicated: the lanes past the end fetch and write the last element again (same value, same address)
+    const int r0 = (int)(__umul24((unsigned)tid, 205u) >> 14);      // tid / 80 (tid < 320)
+    const int col = tid - r0 * kPatchPitch;
+    const int lane_off = ((int)__umul24((unsigned)r0, (unsigned)f.nx) + min(col, kPatch - 1)) * 4;   // columns 74 .. 79 duplicate column 73
+    const int pass_bytes = 4 * f.nx * 4;
+    constexpr int kPasses = kPatchRowsLds / 4;      // 19
+    constexpr int kAlways = 13;                     // 52 rows: the footprint itself at yaw 0
+    // pose rows of both envs first (one round trip for the block)
+    float pose[kLdsScanEnvs][7];
 #pragma unroll
-    for (int it = 0; it < kStage; ++it) {   // all requests first
-        if (it * kLdsScanThreads < n_stage) {
-            const int k = min(tid + it * kLdsScanThreads, n_stage - 1);
-            const int r = (int)(__umul24((unsigned)k, 3543u) >> 18);   // k / 74, exact for k < 74 * 74 + 256 (checked exhaustively)
-            stage[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr, ((int)__umul24((unsigned)r, (unsigned)f.nx) + (k - r * kPatch)) * 4, origin, 0));
+    for (int k = 0; k < kLdsScanEnvs; ++k) {
+        const int e = min(e0 + k, n - 1);
+        pose[k][0] = S.ld(WL_S_PX, e), pose[k][1] = S.ld(WL_S_PY, e), pose[k][2] = S.ld(WL_S_PZ, e);
+        pose[k][3] = S.ld(WL_S_QW, e), pose[k][4] = S.ld(WL_S_QX, e), pose[k][5] = S.ld(WL_S_QY, e), pose[k][6] = S.ld(WL_S_QZ, e);
+    }
+    ScanFrame fr[kLdsScanEnvs];
+    int i0[kLdsScanEnvs], j0[kLdsScanEnvs], rows[kLdsScanEnvs];
+    float stage[kLdsScanEnvs][kPasses];
+#pragma unroll
+    for (int k = 0; k < kLdsScanEnvs; ++k) {
+        float c, s;
+        yaw_cs(Quat{pose[k][3], pose[k][4], pose[k][5], pose[k][6]}, c, s);
+        fr[k] = scan_frame(p, ground, ScanPose{pose[k][0], pose[k][1], pose[k][2], c, s});
+        // the patch: the lattice's bounding box in grid units (its corners are rays (0,0), (25,0), (0,25), (25,25)), the +1 corner
+        // of the last cell, a little slack for rounding.  Block-uniform values, kept in scalar registers.
+        constexpr float kSpan = (float)(WL_ELEV_SCAN_N - 1);
+        const float u_lo = fr[k].u0 + fminf(kSpan * fr[k].ux, 0.f) + fminf(kSpan * fr[k].uy, 0.f);
+        const float v_lo = fr[k].v0 + fminf(kSpan * fr[k].vx, 0.f) + fminf(kSpan * fr[k].vy, 0.f);
+        const float v_hi = fr[k].v0 + fmaxf(kSpan * fr[k].vx, 0.f) + fmaxf(kSpan * fr[k].vy, 0.f);
+        i0[k] = __builtin_amdgcn_readfirstlane(min(max((int)floorf(u_lo - 0.02f), 0), f.nx - kPatch));
+        j0[k] = __builtin_amdgcn_readfirstlane(min(max((int)floorf(v_lo - 0.02f), 0), f.ny - kPatch));
+        rows[k] = __builtin_amdgcn_readfirstlane(min(max((int)floorf(v_hi + 0.02f) + 2 - j0[k], 1), kPatch));
+        // all requests of the patch at once; the pass count in three scalar steps (13 / 16 / 19 passes = 52 / 64 / 76 rows).  No
+        // vector arithmetic per element: the lane offset is constant, the pass goes into the scalar offset.
+        const int origin = (j0[k] * f.nx + i0[k]) * 4;
+#pragma unroll
+        for (int it = 0; it < kAlways; ++it) stage[k][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr, lane_off, origin + it * pass_bytes, 0));
+        if (rows[k] > 4 * kAlways) {
+#pragma unroll
+            for (int it = kAlways; it < 16; ++it) stage[k][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr, lane_off, origin + it * pass_bytes, 0));
+            if (rows[k] > 64) {
+#pragma unroll
+                for (int it = 16; it < kPasses; ++it) stage[k][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr, lane_off, origin + it * pass_bytes, 0));
+            }
         }
     }
+    // this lane's quad of rays (the first three wavefronts evaluate rays): the same lattice coordinates for both envs
+    float fx[4], fy[4];
+    scan_ray_xy(4 * min(tid, kScanQuads - 1), fx[0], fy[0]);
+    scan_ray_xy(4 * min(tid, kScanQuads - 1) + 2, fx[2], fy[2]);
+    fx[1] = fx[0] + 1.f, fy[1] = fy[0], fx[3] = fx[2] + 1.f, fy[3] = fy[2];
 #pragma unroll
-    for (int it = 0; it < kStage; ++it) {
-        if (it * kLdsScanThreads < n_stage) patch[min(tid + it * kLdsScanThreads, n_stage - 1)] = stage[it];
-    }
-    __syncthreads();
-    float* row = obs + (int64_t)e * WL_ELEV_OBS_DIM;
-    const float g0 = -0.5f * p.scan_size;
-    constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N;
-    constexpr int kIter = (kRays + kLdsScanThreads - 1) / kLdsScanThreads;
+    for (int k = 0; k < kLdsScanEnvs; ++k) {
+        if (k > 0) __syncthreads();       // every ray of the previous env has read the patch
+        // registers -> LDS: address = the thread's constant + an immediate
 #pragma unroll
-    for (int it = 0; it < kIter; ++it) {
-        const int k = tid + it * kLdsScanThreads;
-        if (k < kRays) {
-            const int iy = k / WL_ELEV_SCAN_N, ix = k - iy * WL_ELEV_SCAN_N;   // meshgrid "xy": x fastest
-            const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
-            const HeightFieldGround::CellOf cell = ground.cell_of(px + (c * lx - s * ly), py + (s * lx + c * ly));
-            // clamped: a point the bounding box missed would read a wrong corner (the parity tests would show it), never out of bounds
-            const float* h = patch + min(max(cell.j - j0, 0), kPatch - 2) * kPatch + min(max(cell.i - i0, 0), kPatch - 2);
-            HeightFieldGround::Corners cr;
-            cr.lo.x = h[0], cr.lo.y = h[1], cr.hi.x = h[kPatch], cr.hi.y = h[kPatch + 1];
-            cr.fu = cell.fu, cr.fv = cell.fv, cr.inside = cell.inside;
-            const float hz = ground.blend(cr);
-            const float val = cr.inside ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
-            if constexpr (STREAM) __builtin_nontemporal_store(clampf(val, -p.obs_clip, p.obs_clip), row + 13 + k);
-            else row[13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
+        for (int it = 0; it < kAlways; ++it) patch[tid + it * kLdsScanThreads] = stage[k][it];
+        if (rows[k] > 4 * kAlways) {
+#pragma unroll
+            for (int it = kAlways; it < 16; ++it) patch[tid + it * kLdsScanThreads] = stage[k][it];
+            if (rows[k] > 64) {
+#pragma unroll
+                for (int it = 16; it < kPasses; ++it) patch[tid + it * kLdsScanThreads] = stage[k][it];
+            }
+        }
+        __syncthreads();
+        if (tid < kScanQuads && e0 + k < n) {
+            ScanRay cr[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const ScanCell cell = scan_cell(fr[k], f, fx[m], fy[m]);
+                // clamped (unsigned minimum: a negative offset wraps to the top and is clamped with everything else): a point the
+                // bounding box missed would read a wrong corner (the parity tests would show it), never out of bounds
+                const float* h = patch + min((unsigned)(cell.j - j0[k]), (unsigned)(kPatchRowsLds - 2)) * kPatchPitch +
+                                 min((unsigned)(cell.i - i0[k]), (unsigned)(kPatchPitch - 2));
+                cr[m].lo.x = h[0], cr[m].lo.y = h[1], cr[m].hi.x = h[kPatchPitch], cr[m].hi.y = h[kPatchPitch + 1];
+                cr[m].fu = cell.fu, cr[m].fv = cell.fv, cr[m].inside = cell.inside;
+            }
+            scan_quad_store<STREAM>(obs + (int64_t)(e0 + k) * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, fr[k].pz));
         }
     }
 }
@@ -547,13 +689,13 @@ inline void launch_elev_scan(const WlElevParams* p, const WlEnvBuffers* b, const
     const bool stream = use_streaming(b, (int64_t)b->n_envs * WL_ELEV_OBS_DIM * 4, 256ll << 20);
     const bool lds = scan_patch_fits(p, &g.f) && ((b->flags & WL_FLAG_SCAN_LDS) || (!(b->flags & WL_FLAG_SCAN_GATHER) && b->n_envs >= WL_SCAN_LDS_MIN_ENVS));
     if (lds) {
-        if (stream) elev_scan_lds_kernel<true><<<b->n_envs, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
-        else elev_scan_lds_kernel<false><<<b->n_envs, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
+        const int grid = (b->n_envs + kLdsScanEnvs - 1) / kLdsScanEnvs;
+        if (stream) elev_scan_lds_kernel<true><<<grid, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
+        else elev_scan_lds_kernel<false><<<grid, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
         return;
     }
-    const int grid = (b->n_envs + kScanEnvsPerBlock - 1) / kScanEnvsPerBlock;
-    if (stream) elev_scan_kernel<true><<<grid, kBlock, 0, hs>>>(*p, *b, g, obs);
-    else elev_scan_kernel<false><<<grid, kBlock, 0, hs>>>(*p, *b, g, obs);
+    if (stream) elev_scan_kernel<true><<<b->n_envs, kScanThreads, 0, hs>>>(*p, *b, g, obs);
+    else elev_scan_kernel<false><<<b->n_envs, kScanThreads, 0, hs>>>(*p, *b, g, obs);
 }
 
 // env.step() AND the height scan as ONE launch (quad form, n <= 32 768): block = 16 envs, 8 wavefronts.  Wavefront 0
@@ -590,7 +732,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
                                                                        const float2* __restrict__ actions, const WlStepOut out,
                                                                        const uint64_t seed, const uint64_t step, const PolicyIo pio) {
     __shared__ float blk_metrics[WL_M_COUNT];
-    __shared__ ScanPose pose[kFusedEnvs];
+    __shared__ ScanFrame frame[kFusedEnvs];
     __shared__ __attribute__((aligned(16))) float hbuf[POLICY ? 2 * 3 * kMlpTiles * 64 * 4 : 4];   // partial accumulators [net][share - 1][tile][lane][4]
     __shared__ float2 act_lds[kFusedEnvs];
     const int tid = threadIdx.x;
@@ -726,7 +868,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
                 keep_scalar_common(p, p_arg);
                 vd.n_sub = vd_arg.n_sub;
                 const ScanPose sp = elev_env_step<4>(p, vd, b, ground, a, rows, out, seed, step, S, e, wid, wid == 0, blk_metrics);
-                if (wid == 0) pose[tid >> 2] = sp;
+                if (wid == 0) frame[tid >> 2] = scan_frame(p, ground, sp);
             }
         }
     }
@@ -737,36 +879,31 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     }
     // ---- the scan ----
     const WlElevParams& p = p_arg;
-    constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N, kAll = kFusedEnvs * kRays;
-    // (rays per lane in 1 / 2 / 3 batches of gathers: 28.4 / 26.2 / 25.9 us per step at 4096 envs -- one batch needs 256 VGPRs)
+    // flat index over (env, quad of rays): 16 x 169 quads / 512 lanes = 5.3 per lane, in three batches of two (16 gathers in flight)
+    // (rounds 2 - 3, single rays: 1 / 2 / 3 batches of gathers 28.4 / 26.2 / 25.9 us per step at 4096 envs -- one batch needs 256 VGPRs)
+    constexpr int kAll = kFusedEnvs * kScanQuads;
     constexpr int kScanBatches = 3;
     constexpr int kSlots = (kAll + kFusedThreads - 1) / kFusedThreads, kBatch = (kSlots + kScanBatches - 1) / kScanBatches;
     const int n_here = min(kFusedEnvs, b.n_envs - e0);
-    const float g0 = -0.5f * p.scan_size;
+    const ScanField sf = scan_field(ground.f);
 #pragma unroll
     for (int half = 0; half < kScanBatches; ++half) {
-        HeightFieldGround::Corners cr[kBatch];
+        ScanRay cr[kBatch][4];
         float pz[kBatch];
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
-            const int idx = min(tid + (half * kBatch + i) * kFusedThreads, kAll - 1);
-            const int j = idx / kRays, k = idx - j * kRays;
-            const int iy = k / WL_ELEV_SCAN_N, ix = k - iy * WL_ELEV_SCAN_N;   // meshgrid "xy": x fastest
-            const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
-            const ScanPose sp = pose[min(j, n_here - 1)];
-            pz[i] = sp.pz;
-            cr[i] = ground.corners(sp.px + (sp.c * lx - sp.s * ly), sp.py + (sp.s * lx + sp.c * ly));
+            int j, q;
+            scan_quad_slot(min(tid + (half * kBatch + i) * kFusedThreads, kAll - 1), j, q);
+            const ScanFrame fr = frame[min(j, n_here - 1)];
+            pz[i] = fr.pz;
+            scan_quad_request(fr, ground.f, sf, q, cr[i]);
         }
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
             const int idx = tid + (half * kBatch + i) * kFusedThreads;
-            const int j = idx / kRays, k = idx - j * kRays;
-            if (idx < kAll && j < n_here) {
-                const float hz = ground.blend(cr[i]);
-                // world_height_map = -(sensor_z - hit_z - offset) + (root_z - plane_init_value); rays that miss return +inf
-                const float val = cr[i].inside ? (-(pz[i] - hz - p.scan_offset) + (pz[i] - p.elev_z0)) : __builtin_inff();
-                out.obs[(int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13 + k] = clampf(val, -p.obs_clip, p.obs_clip);
-            }
+            int j, q;
+            scan_quad_slot(idx, j, q);
+            if (idx < kAll && j < n_here) scan_quad_store<false>(out.obs + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], pz[i]));
         }
     }
 }
@@ -786,7 +923,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_rollout_persistent_kernel(
                                                                                 const int n_steps, const uint64_t seed, const uint64_t step0,
                                                                                 const MetricSlots slots) {
     __shared__ float blk_metrics[WL_M_COUNT];
-    __shared__ ScanPose pose[2][kFusedEnvs];
+    __shared__ ScanFrame frame[2][kFusedEnvs];
     const int tid = threadIdx.x;
     if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
     if (b.metrics_slots > 1) clear_metric_slot(b, slots.next);
@@ -818,7 +955,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_rollout_persistent_kernel(
                 const float2 a = actions[(int64_t)k * b.n_envs + e];
                 const ScanPose sp = elev_env_step<4, true>(p, vd, b, ground, a, rows, o, seed, step0 + (uint64_t)k, S, e, wid, wid == 0,
                                                            blk_metrics, &book);
-                if (wid == 0) pose[k & 1][tid >> 2] = sp;
+                if (wid == 0) frame[k & 1][tid >> 2] = scan_frame(p, ground, sp);
             }
             __syncthreads();   // barrier k: the poses of step k are published
         }
@@ -832,36 +969,31 @@ __global__ void __launch_bounds__(kFusedThreads) elev_rollout_persistent_kernel(
     // ---- wavefronts 1..7: the scan of step k, one step behind the physics ----
     const WlElevParams& p = p_arg;
     const int t7 = tid - 64;
-    constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N, kAll = kFusedEnvs * kRays;
+    constexpr int kAll = kFusedEnvs * kScanQuads;
     constexpr int kBatches = 3, kSlots = (kAll + kScanLanes - 1) / kScanLanes, kBatch = (kSlots + kBatches - 1) / kBatches;
     const int n_here = min(kFusedEnvs, b.n_envs - e0);
-    const float g0 = -0.5f * p.scan_size;
+    const ScanField sf = scan_field(ground.f);
     for (int k = 0; k < n_steps; ++k) {
         __syncthreads();       // barrier k
         float* obs_k = out.obs + k * obs_step_stride;
 #pragma unroll
         for (int part = 0; part < kBatches; ++part) {
-            HeightFieldGround::Corners cr[kBatch];
+            ScanRay cr[kBatch][4];
             float pz[kBatch];
 #pragma unroll
             for (int i = 0; i < kBatch; ++i) {
-                const int idx = min(t7 + (part * kBatch + i) * kScanLanes, kAll - 1);
-                const int j = idx / kRays, r = idx - j * kRays;
-                const int iy = r / WL_ELEV_SCAN_N, ix = r - iy * WL_ELEV_SCAN_N;
-                const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
-                const ScanPose sp = pose[k & 1][min(j, n_here - 1)];
-                pz[i] = sp.pz;
-                cr[i] = ground.corners(sp.px + (sp.c * lx - sp.s * ly), sp.py + (sp.s * lx + sp.c * ly));
+                int j, q;
+                scan_quad_slot(min(t7 + (part * kBatch + i) * kScanLanes, kAll - 1), j, q);
+                const ScanFrame fr = frame[k & 1][min(j, n_here - 1)];
+                pz[i] = fr.pz;
+                scan_quad_request(fr, ground.f, sf, q, cr[i]);
             }
 #pragma unroll
             for (int i = 0; i < kBatch; ++i) {
                 const int idx = t7 + (part * kBatch + i) * kScanLanes;
-                const int j = idx / kRays, r = idx - j * kRays;
-                if (idx < kAll && j < n_here) {
-                    const float hz = ground.blend(cr[i]);
-                    const float val = cr[i].inside ? (-(pz[i] - hz - p.scan_offset) + (pz[i] - p.elev_z0)) : __builtin_inff();
-                    obs_k[(int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13 + r] = clampf(val, -p.obs_clip, p.obs_clip);
-                }
+                int j, q;
+                scan_quad_slot(idx, j, q);
+                if (idx < kAll && j < n_here) scan_quad_store<false>(obs_k + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], pz[i]));
             }
         }
     }
@@ -950,7 +1082,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_collect_rollout_kernel(con
     float* tail_a = part_a + kPartFloats;                        // the actor's MlpTail, [85][64]
     float* carry = tail_a + kTailFloats;                         // wavefront 0's ElevRows + ElevBook between steps, [words][64]
     float* prop = carry + kCarryWords * 64;                      // [16][13]
-    ScanPose* pose = reinterpret_cast<ScanPose*>(prop + kFusedEnvs * 13);   // [16] (5 floats each, 8 reserved)
+    ScanFrame* frame = reinterpret_cast<ScanFrame*>(prop + kFusedEnvs * 13);   // [16] (7 floats each, 8 reserved)
     float2* act_lds = reinterpret_cast<float2*>(prop + kFusedEnvs * 13 + kFusedEnvs * 8);
     float* blk_metrics = reinterpret_cast<float*>(act_lds + kFusedEnvs);
     constexpr int D = WL_ELEV_OBS_DIM;
@@ -990,7 +1122,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_collect_rollout_kernel(con
             carry_io<true>(carry, lane, rows, book);
         }
     }
-    const float g0 = -0.5f * p.scan_size;
+    const ScanField sf = scan_field(ground.f);
     __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < n_steps; ++k) {
@@ -1061,7 +1193,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_collect_rollout_kernel(con
                 const ScanPose sp = elev_env_step<4, true>(p, vd, b, ground, a, rows, o, seed, step, S, e, wid, wid == 0, blk_metrics, &book,
                                                            prop + (tid >> 2) * 13);
                 carry_io<true>(carry, lane, rows, book);
-                if (wid == 0) pose[tid >> 2] = sp;
+                if (wid == 0) frame[tid >> 2] = scan_frame(p, ground, sp);
             }
         }
         __syncthreads();   // barrier 2: poses and proprioception of step k published; nobody reads the old observation rows any more
@@ -1073,33 +1205,31 @@ __global__ void __launch_bounds__(kFusedThreads) elev_collect_rollout_kernel(con
             obs_tile[r * kTilePitch + c] = prop[tl];
         }
         {
-            constexpr int kRays = WL_ELEV_SCAN_N * WL_ELEV_SCAN_N, kAll = kFusedEnvs * kRays;
+            constexpr int kAll = kFusedEnvs * kScanQuads;
             constexpr int kBatches = 3, kSlots = (kAll + kFusedThreads - 1) / kFusedThreads, kBatch = (kSlots + kBatches - 1) / kBatches;
             float* obs_k = out.obs + kn * D;
 #pragma unroll
             for (int part = 0; part < kBatches; ++part) {
-                HeightFieldGround::Corners cr[kBatch];
+                ScanRay cr[kBatch][4];
                 float pz[kBatch];
 #pragma unroll
                 for (int i = 0; i < kBatch; ++i) {
-                    const int idx = min(tl + (part * kBatch + i) * kFusedThreads, kAll - 1);
-                    const int j = idx / kRays, r = idx - j * kRays;
-                    const int iy = r / WL_ELEV_SCAN_N, ix = r - iy * WL_ELEV_SCAN_N;
-                    const float lx = fmaf((float)ix, p.scan_res, g0), ly = fmaf((float)iy, p.scan_res, g0);
-                    const ScanPose sp = pose[min(j, n_here - 1)];
-                    pz[i] = sp.pz;
-                    cr[i] = ground.corners(sp.px + (sp.c * lx - sp.s * ly), sp.py + (sp.s * lx + sp.c * ly));
+                    int j, q;
+                    scan_quad_slot(min(tl + (part * kBatch + i) * kFusedThreads, kAll - 1), j, q);
+                    const ScanFrame fr = frame[min(j, n_here - 1)];
+                    pz[i] = fr.pz;
+                    scan_quad_request(fr, ground.f, sf, q, cr[i]);
                 }
 #pragma unroll
                 for (int i = 0; i < kBatch; ++i) {
                     const int idx = tl + (part * kBatch + i) * kFusedThreads;
-                    const int j = idx / kRays, r = idx - j * kRays;
+                    int j, q;
+                    scan_quad_slot(idx, j, q);
                     if (idx < kAll && j < n_here) {
-                        const float hz = ground.blend(cr[i]);
-                        const float val = cr[i].inside ? (-(pz[i] - hz - p.scan_offset) + (pz[i] - p.elev_z0)) : __builtin_inff();
-                        const float v = clampf(val, -p.obs_clip, p.obs_clip);
-                        obs_k[(int64_t)(e0 + j) * D + 13 + r] = v;
-                        obs_tile[j * kTilePitch + 13 + r] = v;
+                        const wl_float4_u v = scan_quad_value(p, cr[i], pz[i]);
+                        scan_quad_store<false>(obs_k + (int64_t)(e0 + j) * D + 13, q, v);
+                        float* t4 = obs_tile + j * kTilePitch + 13 + 4 * q;
+                        t4[0] = v.x, t4[1] = v.y, t4[2] = v.z, t4[3] = v.w;
                     }
                 }
             }
