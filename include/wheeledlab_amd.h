@@ -692,6 +692,8 @@ typedef struct WlStartupParams {
     float chassis_mass;                   /* base mass before the "add" operation                                */
     float mass_add[2];                    /* added mass range                                                    */
     int32_t randomize;
+    float wheel_mass[2];                  /* range of EACH wheel link's mass ("abs", visual cfg :289-298): the four draws add  */
+                                          /* to the vehicle's mass row; (0, 0): not randomised (wheels counted in chassis_mass) */
 } WlStartupParams;
 int wl_startup_randomize(const WlStartupParams* su, const WlEnvBuffers* b, uint64_t seed, void* stream);
 

@@ -11,7 +11,7 @@ import numpy as np
 from . import philox
 from .mathlib import F
 
-S_STARTUP, S_STARTUP_BUCKET = 8, 9
+S_STARTUP, S_STARTUP_BUCKET, S_STARTUP_WHEELS = 8, 9, 10
 DRIFT = dict(wheel_mu_s=(0.3, 0.5), wheel_mu_d=(0.3, 0.5), mu_buckets=20, mu_consistent=True, damping=(10.0, 50.0),
              chassis_mass=3.0, mass_add=(0.3, 0.5))
 ELEV = dict(wheel_mu_s=(2.0, 2.0), wheel_mu_d=(1.0, 1.0), mu_buckets=5, mu_consistent=False, damping=(1000.0, 1000.0),
@@ -22,7 +22,8 @@ def _lerp(r, u):
     return (F(r[0]) + u * (F(r[1]) - F(r[0]))).astype(F)   # the kernel's fmaf differs by <= 1 ulp
 
 
-def draw(n, seed, env_offset=0, *, wheel_mu_s, wheel_mu_d, mu_buckets, mu_consistent, damping, chassis_mass, mass_add):
+def draw(n, seed, env_offset=0, *, wheel_mu_s, wheel_mu_d, mu_buckets, mu_consistent, damping, chassis_mass, mass_add,
+         wheel_mass=(0.0, 0.0)):
     """-> mu_s, mu_d, damp, mass, bucket: float32 [n] each (bucket int32) for global envs env_offset .. env_offset + n"""
     gid = np.arange(n, dtype=np.uint64) + np.uint64(env_offset)
     u = philox.uniform4(gid, 0, S_STARTUP, seed)
@@ -33,4 +34,8 @@ def draw(n, seed, env_offset=0, *, wheel_mu_s, wheel_mu_d, mu_buckets, mu_consis
     mu_d = _lerp(wheel_mu_d, m[1])
     if mu_consistent:
         mu_d = np.minimum(mu_d, mu_s)
-    return mu_s, mu_d, _lerp(damping, u[1]), (F(chassis_mass) + _lerp(mass_add, u[2])).astype(F), bucket
+    mass = (F(chassis_mass) + _lerp(mass_add, u[2])).astype(F)
+    if wheel_mass[1] > 0:      # the four wheel links' masses ("abs", visual cfg :289-298) add to the vehicle's
+        w = philox.uniform4(gid, 0, S_STARTUP_WHEELS, seed)
+        mass = (mass + ((_lerp(wheel_mass, w[0]) + _lerp(wheel_mass, w[1])) + (_lerp(wheel_mass, w[2]) + _lerp(wheel_mass, w[3])))).astype(F)
+    return mu_s, mu_d, _lerp(damping, u[1]), mass, bucket

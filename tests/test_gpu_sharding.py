@@ -59,6 +59,27 @@ def test_startup_randomisation_matches_the_keyed_restatement(lib):
     np.testing.assert_allclose(f[23:27, :64], np.array([[0.4], [0.4], [30.0], [3.4]], np.float32) * np.ones((1, 64), np.float32), rtol=1e-6)
 
 
+def test_wheel_mass_randomisation_matches_the_keyed_restatement(lib):
+    """VisualEventsRandomCfg's three startup terms through the registry's flattening -> wl_startup_randomize vs oracle/startup.py"""
+    from oracle import startup as OSU
+    from wheeledlab_amd import _abi as A
+    from wheeledlab_amd.core import VisualBatch
+    from wheeledlab_amd.envs.flatten import flatten_visual_cfg
+    from wheeledlab_amd.tasks.visual import MushrVisualRLRandomEnvCfg
+    flat = flatten_visual_cfg(MushrVisualRLRandomEnvCfg())
+    su = flat.startup
+    n, off = 2048 + 5, 4096
+    env = VisualBatch(n, device=DEV, seed=19, env_offset=off, params=flat.params, startup=su)
+    torch.cuda.synchronize()
+    st = env.state.cpu().numpy()
+    mu_s, mu_d, damp, mass, _ = OSU.draw(n, 19, off, wheel_mu_s=su.wheel_mu_s, wheel_mu_d=su.wheel_mu_d, mu_buckets=su.mu_buckets,
+                                         mu_consistent=su.mu_consistent, damping=su.damping, chassis_mass=su.chassis_mass,
+                                         mass_add=su.mass_add, wheel_mass=su.wheel_mass)
+    for row, want in ((A.S_MU_S, mu_s), (A.S_MU_D, mu_d), (A.S_DAMP, damp), (A.S_MASS, mass)):
+        np.testing.assert_allclose(st[row, :n], want, rtol=6e-7, atol=0)
+    assert 1.04 <= st[A.S_MASS, :n].min() and st[A.S_MASS, :n].max() <= 4.2 and abs(st[A.S_MASS, :n].mean() - 2.62) < 0.05
+
+
 def _shard_check(make, n, K, act_scale=1.0, extra=()):
     """big batch vs two halves built independently (same seed, env_offset): bitwise equal after K steps"""
     big = make(n, 0)

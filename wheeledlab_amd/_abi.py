@@ -155,7 +155,7 @@ class WlPpoParams(C.Structure):
 class WlStartupParams(C.Structure):
     _fields_ = [("wheel_mu_s", C.c_float * 2), ("wheel_mu_d", C.c_float * 2), ("mu_buckets", C.c_int32),
                 ("mu_consistent", C.c_int32), ("damping", C.c_float * 2), ("chassis_mass", C.c_float),
-                ("mass_add", C.c_float * 2), ("randomize", C.c_int32)]
+                ("mass_add", C.c_float * 2), ("randomize", C.c_int32), ("wheel_mass", C.c_float * 2)]
 
 
 class WlPpoState(C.Structure):

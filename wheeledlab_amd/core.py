@@ -42,7 +42,7 @@ def apply_startup_events(lib, bufs: "A.WlEnvBuffers", su, seed: int, stream, ran
     env id (bufs.env_offset + e), so a sharded run holds the same parameter sets as the one big batch."""
     sp = A.WlStartupParams((C.c_float * 2)(*su.wheel_mu_s), (C.c_float * 2)(*su.wheel_mu_d), int(su.mu_buckets),
                            int(bool(su.mu_consistent)), (C.c_float * 2)(*su.damping), float(su.chassis_mass),
-                           (C.c_float * 2)(*su.mass_add), int(bool(randomize)))
+                           (C.c_float * 2)(*su.mass_add), int(bool(randomize)), (C.c_float * 2)(*getattr(su, "wheel_mass", (0.0, 0.0))))
     A.check(lib.wl_startup_randomize(C.byref(sp), C.byref(bufs), int(seed), stream), "wl_startup_randomize")
 
 

@@ -4,7 +4,7 @@
 #include "wl_math.h"
 
 enum WlRngStream : uint32_t { WL_RS_RESET = 0, WL_RS_TIMERS = 1, WL_RS_PUSH_HF = 2, WL_RS_PUSH_LF = 3, WL_RS_NOISE0 = 4 /* ..6 */, WL_RS_POLICY = 7,
-                            WL_RS_STARTUP = 8, WL_RS_STARTUP_BUCKET = 9 };
+                            WL_RS_STARTUP = 8, WL_RS_STARTUP_BUCKET = 9, WL_RS_STARTUP_WHEELS = 10 };
 
 struct U4 {
     uint32_t x, y, z, w;

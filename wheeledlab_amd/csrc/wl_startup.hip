@@ -27,11 +27,15 @@ __global__ void __launch_bounds__(kBlock) startup_kernel(const WlStartupParams s
         if (su.mu_consistent) mu_d = fminf(mu_d, mu_s);
         damp = lerp_range(su.damping, u.y);
         mass = su.chassis_mass + lerp_range(su.mass_add, u.z);
+        if (su.wheel_mass[1] > 0.f) {    // randomize_rigid_body_mass on the four wheel links (visual cfg :289-298): link masses add up
+            const F4 w = philox_uniform4((uint32_t)(b.env_offset + e), 0, WL_RS_STARTUP_WHEELS, seed);
+            mass += (lerp_range(su.wheel_mass, w.x) + lerp_range(su.wheel_mass, w.y)) + (lerp_range(su.wheel_mass, w.z) + lerp_range(su.wheel_mass, w.w));
+        }
     } else {
         mu_s = 0.5f * (su.wheel_mu_s[0] + su.wheel_mu_s[1]);
         mu_d = fminf(0.5f * (su.wheel_mu_d[0] + su.wheel_mu_d[1]), mu_s);
         damp = 0.5f * (su.damping[0] + su.damping[1]);
-        mass = su.chassis_mass + 0.5f * (su.mass_add[0] + su.mass_add[1]);
+        mass = su.chassis_mass + 0.5f * (su.mass_add[0] + su.mass_add[1]) + 2.f * (su.wheel_mass[0] + su.wheel_mass[1]);
     }
     S.st(WL_S_MU_S, e, mu_s);
     S.st(WL_S_MU_D, e, mu_d);

@@ -24,6 +24,7 @@ class StartupSpec:
     mu_consistent: bool = True
     damping: tuple = (30.0, 30.0)
     mass_add: tuple = (0.0, 0.0)
+    wheel_mass: tuple = (0.0, 0.0)      # each wheel link's mass ("abs"); (0, 0): wheels counted in chassis_mass
     chassis_mass: float = MUSHR_CHASSIS_MASS
     track_radius: float = 0.8
     track_straight: float = 0.8
@@ -284,6 +285,12 @@ def _startup_events(cfg, su, allowed_reset):
         elif ev == "wheel_friction" and term.mode == "startup":
             su.wheel_mu_s, su.wheel_mu_d = tuple(pr["static_friction_range"]), tuple(pr["dynamic_friction_range"])
             su.mu_buckets, su.mu_consistent = int(pr["num_buckets"]), bool(pr.get("make_consistent", False))
+        elif ev == "base_mass" and term.mode == "startup" and "wheel" in str(getattr(pr.get("asset_cfg"), "body_names", "")):
+            # randomize_rigid_body_mass on the wheel links (visual/mushr_visual_env_cfg.py:289-298): the four link masses add to the
+            # vehicle's mass row; the wheels' ROTATIONAL inertia stays the model's one `wheel_inertia` (not randomised per wheel)
+            if pr.get("operation", "add") != "abs":
+                raise NotImplementedError("randomize_rigid_body_mass on the wheel links: operation abs")
+            su.wheel_mass = tuple(pr["mass_distribution_params"])
         elif ev == "base_mass" and term.mode == "startup":
             if pr.get("operation", "add") == "add":
                 su.mass_add = tuple(pr["mass_distribution_params"])

@@ -85,6 +85,10 @@ class VisualEventsRandomCfg(VisualEventsCfg):
         func=mdp.randomize_rigid_body_mass, mode="startup",
         params=dict(asset_cfg=SceneEntityCfg("robot", body_names=["base_link"]), mass_distribution_params=(1.0, 3.0),
                     operation="abs"))
+    add_wheel_mass = EventTerm(
+        func=mdp.randomize_rigid_body_mass, mode="startup",
+        params=dict(asset_cfg=SceneEntityCfg("robot", body_names=".*wheel_.*link"), mass_distribution_params=(0.01, 0.3),
+                    operation="abs"))
 
 
 @configclass
