@@ -584,6 +584,8 @@ int wl_elev_collect_rollout(const WlElevParams* p, const WlEnvBuffers* b, const 
 #define WL_VIS_CROP 20                          /* rows dropped from the top: H // 3 (mdp_sensors/observations.py:79) */
 #define WL_VIS_NPIX ((WL_VIS_IMG_H - WL_VIS_CROP) * WL_VIS_IMG_W)   /* 3200                                        */
 #define WL_VIS_OBS_DIM (WL_VIS_NPIX + 8)        /* 3208 (mushr_visual_env_cfg.py:38-58)                               */
+#define WL_VISDEPTH_NPIX (WL_VIS_IMG_H * WL_VIS_IMG_W)   /* 4800: the uncropped depth image                              */
+#define WL_VISDEPTH_OBS_DIM (WL_VISDEPTH_NPIX + 8)       /* 4808: visual-depth extension task (BASELINE config 5)         */
 
 enum WlVisualRewTerm { WL_VR_TRAVERSABLE = 0, WL_VR_FORWARD_VEL, WL_VR_NTERMS };
 
@@ -672,6 +674,29 @@ int64_t wl_heightfield_pyramid_floats(int32_t nx, int32_t ny);
 int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* stream);
 int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid,
                     float max_depth, float* depth, void* stream);
+/* the same image into rows of `row_stride` floats (>= 4800): env e's image at rows + e * row_stride */
+int wl_visual_depth_rows(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid,
+                         float max_depth, float* rows, int64_t row_stride, void* stream);
+/*
+ * Visual-depth EXTENSION task (not a reference id; BASELINE.json configs[4] "Visual task, 4096 envs, depth raycast against
+ * heightfield"): the visual task's env.step() -- 4WD action term, traversable_reward / forward_vel, time_out / out_of_map, reset
+ * onto a random traversable cell (mushr_visual_env_cfg.py:309-312,370-371,390-398; visual/mdp/events.py:11-42) -- driven on a
+ * heightfield terrain (wheel contacts by bilinear gathers as in the elevation task; reset poses lifted onto the terrain), with
+ * the camera's depth image as the policy observation: obs [n][WL_VISDEPTH_OBS_DIM] = distance_to_image_plane 60 x 80
+ * (`raycast_depth`, mdp_sensors/observations.py:93-95) | base_lin_vel 3 | base_ang_vel 3 | last_action 2.
+ *   wl_visual_step_hf       the step launch: state, reward, flags, and columns 4800 .. 4807 of out->obs
+ *   wl_visual_reset_hf      reset (mask NULL = all envs)
+ *   wl_visual_depth_step    step launch + depth launch (columns 0 .. 4799): one env.step()
+ *   wl_visual_depth_observe columns 0 .. 4807 of the state as it stands (reset / first observation)
+ */
+int wl_visual_step_hf(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const WlHeightField* hf, const float* actions,
+                      const WlStepOut* out, uint64_t seed, uint64_t step, void* stream);
+int wl_visual_reset_hf(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const WlHeightField* hf, const uint8_t* mask,
+                       uint64_t seed, uint64_t step, void* stream);
+int wl_visual_depth_step(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const WlHeightField* hf, const float* pyramid,
+                         float max_depth, const float* actions, const WlStepOut* out, uint64_t seed, uint64_t step, void* stream);
+int wl_visual_depth_observe(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
+                            float* obs, void* stream);
 
 /*
  * Startup-mode events (domain randomisation applied ONCE per env, at construction): bucketed wheel friction

@@ -44,7 +44,8 @@ def spawn_cells(trav):
     return np.stack([ys, xs], -1).astype(np.int32)
 
 
-def reset_envs(p, state, episode_len, cells, ids, seed, step, env_offset=0):
+def reset_envs(p, state, episode_len, cells, ids, seed, step, env_offset=0, hf=None):
+    """hf: the visual-depth extension task's heightfield terrain -- the reset pose is lifted onto it (z 0.1 above the ground)"""
     if len(ids) == 0:
         return
     gid = np.asarray(ids) + env_offset
@@ -54,6 +55,10 @@ def reset_envs(p, state, episode_len, cells, ids, seed, step, env_offset=0):
     state[PX, ids] = (ix.astype(F) - F(p.map_cols // 2)) * F(p.row_spacing)          # generate_random_poses :198-199
     state[PX + 1, ids] = (iy.astype(F) - F(p.map_rows // 2)) * F(p.col_spacing)
     state[PX + 2, ids] = F(p.reset_z)
+    if hf is not None:
+        from . import heightfield as H
+        zt, _, _ = H.sample(hf[0], hf[1], hf[2], hf[3], state[PX, ids], state[PX + 1, ids], outside=0.0)
+        state[PX + 2, ids] = (F(p.reset_z) + zt.astype(F)).astype(F)
     yaw = u[1] * F(2.0 * math.pi)                                                     # U(0, 360) deg
     state[QW, ids], state[QW + 1, ids], state[QW + 2, ids], state[QW + 3, ids] = np.cos(yaw * F(.5)), 0, 0, np.sin(yaw * F(.5))
     state[VX:VX + 6, ids] = 0
@@ -120,7 +125,20 @@ def observe(p, state, trav):
     return np.concatenate([camera(p, state, trav), v_b, w_b, np.clip(state[ACT0:ACT0 + 2].T, F(-1), F(1))], -1).astype(F)
 
 
-def step(p, state, episode_len, trav, cells, actions, seed, step_count, metrics=None, env_offset=0):
+def observe_depth(p, state, hf, max_depth):
+    """observation of the visual-depth extension task (BASELINE config 5): distance_to_image_plane 60 x 80 against the heightfield
+    (oracle/depth.c) | base_lin_vel | base_ang_vel | last_action"""
+    from . import depth as D
+    R = matrix_from_quat(state[QW:QW + 4].T)
+    v_b = np.einsum("nji,nj->ni", R, state[VX:VX + 3].T).astype(F)
+    w_b = np.einsum("nji,nj->ni", R, state[WX:WX + 3].T).astype(F)
+    img = D.depth(p, state[PX:PX + 3].T.copy(), state[QW:QW + 4].T.copy(), hf, max_depth).reshape(state.shape[1], -1)
+    return np.concatenate([img, v_b, w_b, np.clip(state[ACT0:ACT0 + 2].T, F(-1), F(1))], -1).astype(F)
+
+
+def step(p, state, episode_len, trav, cells, actions, seed, step_count, metrics=None, env_offset=0, hf=None, max_depth=None):
+    """hf / max_depth: the visual-depth extension task -- the same step on the heightfield terrain `hf` (wheel contacts through
+    heightfield.sample, reset onto the terrain), observation = observe_depth"""
     n = state.shape[1]
     vp = p.vehicle
     a_raw = M.clip_action(actions) if p.action.clip_wrapper else f32(actions)
@@ -136,9 +154,13 @@ def step(p, state, episode_len, trav, cells, actions, seed, step_count, metrics=
     wheel = state[WHEEL:WHEEL + 4].T.copy()
     th, om = state[STEER_POS].copy(), state[STEER_VEL].copy()
     h = F(p.sim_dt) / F(vp.substeps)
+    ground = V.flat_ground
+    if hf is not None:
+        from .elev_step import ground_fn
+        ground = ground_fn(hf)
     for _ in range(p.decimation * vp.substeps):
         x, q, v, wb, wheel, th, om = V.substep(x, q, v, wb, wheel, th, om, steer2[:, 0], wheel_t.astype(F), state[MASS],
-                                               state[MU_S], state[MU_D], state[DAMP], vp, h)
+                                               state[MU_S], state[MU_D], state[DAMP], vp, h, ground)
     R = matrix_from_quat(q)
     ww = np.einsum("nij,nj->ni", R, wb).astype(F)
     pos = (x - R @ cvec).astype(F)
@@ -178,8 +200,9 @@ def step(p, state, episode_len, trav, cells, actions, seed, step_count, metrics=
         bad = np.nonzero(~finite)[0]
         state[:19, bad] = 0
         state[QW, bad] = 1
-    reset_envs(p, state, episode_len, cells, ids, seed, step_count, env_offset)
-    return observe(p, state, trav), reward.astype(F), terminated, truncated, dict(terms=terms, finite=finite)
+    reset_envs(p, state, episode_len, cells, ids, seed, step_count, env_offset, hf)
+    obs = observe(p, state, trav) if hf is None else observe_depth(p, state[:, :n], hf, max_depth)
+    return obs, reward.astype(F), terminated, truncated, dict(terms=terms, finite=finite)
 
 
 def init_state(p, n, seed=0, stride=None, wheel_mu=(0.5, 0.5), mass=3.0):

@@ -5,7 +5,10 @@ from wheeledlab_amd.configs.runs import apply_override, registered_runs, resolve
 
 
 def test_registered_runs_carry_the_reference_values():
-    assert registered_runs() == ["F1TENTH_DRIFT_CONFIG", "RSS_DRIFT_CONFIG", "RSS_ELEV_CONFIG", "RSS_VISUAL_CONFIG"]
+    # the reference's four + one clearly-labelled extension (the visual task on a heightfield with the depth image as observation)
+    assert registered_runs() == ["F1TENTH_DRIFT_CONFIG", "RSS_DRIFT_CONFIG", "RSS_ELEV_CONFIG", "RSS_VISUAL_CONFIG", "VISUAL_DEPTH_CONFIG"]
+    ext = resolve_run("VISUAL_DEPTH_CONFIG")
+    assert ext.env_setup.task_name == "Isaac-MushrVisualDepthRL-v0" and ext.env.wl_task == "visual_depth"
     want = {"RSS_DRIFT_CONFIG": ("Isaac-MushrDriftRL-v0", 1024), "RSS_VISUAL_CONFIG": ("Isaac-MushrVisualRL-v0", 512),
             "RSS_ELEV_CONFIG": ("Isaac-MushrElevationRL-v0", 1024), "F1TENTH_DRIFT_CONFIG": ("Isaac-F1TenthDriftRL-v0", 1024)}
     for name, (task, n) in want.items():                      # wheeledlab_rl/configs/runs/rss_cfgs.py, f1tenth_cfgs.py

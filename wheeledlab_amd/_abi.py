@@ -110,6 +110,8 @@ class WlVisualParams(C.Structure):
 
 VIS_NPIX = 40 * 80
 VIS_OBS_DIM = VIS_NPIX + 8
+VISDEPTH_NPIX = 60 * 80                 # visual-depth extension task (BASELINE config 5): the uncropped depth image ...
+VISDEPTH_OBS_DIM = VISDEPTH_NPIX + 8    # ... | base_lin_vel | base_ang_vel | last_action
 
 
 class WlEnvBuffers(C.Structure):
@@ -241,6 +243,12 @@ SIGNATURES = {
     "wl_heightfield_pyramid_floats": (C.c_int64, [_i32, _i32]),
     "wl_heightfield_build_pyramid": (C.c_int, [_P(WlHeightField), _vp, _vp]),
     "wl_visual_depth": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, C.c_float, _vp, _vp]),
+    "wl_visual_depth_rows": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, C.c_float, _vp, _i64, _vp]),
+    "wl_visual_step_hf": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _P(WlHeightField), _vp, _P(WlStepOut), _u64, _u64, _vp]),
+    "wl_visual_reset_hf": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _P(WlHeightField), _vp, _u64, _u64, _vp]),
+    "wl_visual_depth_step": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _P(WlHeightField), _vp, C.c_float, _vp,
+                                       _P(WlStepOut), _u64, _u64, _vp]),
+    "wl_visual_depth_observe": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, C.c_float, _vp, _vp]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwheeledlab_amd.so")

@@ -35,6 +35,14 @@ class F1TENTH_DRIFT_CONFIG(RslRlRunConfig):
     agent_setup = AgentSetup(entry_point="rsl_rl_cfg_entry_point")
 
 
+@configclass
+class VISUAL_DEPTH_CONFIG(RslRlRunConfig):
+    """EXTENSION (not a reference run): the visual task on a heightfield with the depth image as observation"""
+    env_setup = EnvSetup(num_envs=512, task_name="Isaac-MushrVisualDepthRL-v0")
+    train = RLTrainConfig(num_iterations=5000, rl_algo_lib="rsl", rl_algo_class="ppo")
+    agent_setup = AgentSetup(entry_point="rsl_rl_cfg_entry_point")
+
+
 _RUNS: dict[str, type] = {}
 
 
@@ -48,7 +56,8 @@ def registered_runs():
 
 
 for _n, _c in (("RSS_DRIFT_CONFIG", RSS_DRIFT_CONFIG), ("RSS_ELEV_CONFIG", RSS_ELEV_CONFIG),
-               ("RSS_VISUAL_CONFIG", RSS_VISUAL_CONFIG), ("F1TENTH_DRIFT_CONFIG", F1TENTH_DRIFT_CONFIG)):
+               ("RSS_VISUAL_CONFIG", RSS_VISUAL_CONFIG), ("F1TENTH_DRIFT_CONFIG", F1TENTH_DRIFT_CONFIG),
+               ("VISUAL_DEPTH_CONFIG", VISUAL_DEPTH_CONFIG)):
     register_run(_n, _c)
 
 

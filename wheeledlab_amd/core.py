@@ -486,6 +486,75 @@ class VisualBatch(_MetricsView):
         return cam.render(self, max_depth, out)
 
 
+class VisualDepthBatch(VisualBatch):
+    """n envs of the visual-DEPTH extension task (BASELINE.json configs[4]; not a reference id): the visual task's step driven on a
+    heightfield terrain with the camera's 60 x 80 depth image as the observation -- obs [n, 4808] = distance_to_image_plane |
+    base_lin_vel | base_ang_vel | last_action.  Two launches per env.step(): the step (wl_visual_step_hf: lane or quad of lanes
+    = env, HeightFieldGround contacts) and the depth ray-cast (wl_visual_depth_rows).  `heightfield`: (height [ny, nx], x0, y0,
+    cell), default the synthetic 800 x 800 terrain; the traversability map should cover it (default: an 80 x 80 map of 0.5 m
+    cells = the terrain's 40 m square, generated like the reference's from the seed)."""
+
+    OBS_DIM = A.VISDEPTH_OBS_DIM
+
+    def __init__(self, n_envs: int, device="cuda:0", params=None, seed: int = 42, env_offset: int = 0, trav_map=None,
+                 spacing=(0.5, 0.5), metrics_slots: int = 1, startup=None, map_kwargs=None, heightfield=None, max_depth: float = 20.0):
+        from .terrain import synthetic_heightfield
+        if trav_map is None and map_kwargs is None:
+            map_kwargs = dict(map_size=(80, 80), env_size=(40, 40), sub_group_size=(20, 20), num_walkers=1)
+        super().__init__(n_envs, device, params, seed, env_offset, trav_map, spacing, metrics_slots, startup, map_kwargs)
+        h, x0, y0, cell = heightfield if heightfield is not None else synthetic_heightfield()
+        self.height = torch.as_tensor(h, dtype=torch.float32).contiguous().to(self.device)
+        self.max_depth = float(max_depth)
+        self.camera = DepthCamera((self.height, float(x0), float(y0), float(cell)), self.device, self.p)
+        self._hf = self.camera._hf
+        self.obs = torch.zeros(self.n, self.OBS_DIM, dtype=torch.float32, device=self.device)
+        self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
+                                self.truncated.data_ptr(), self.dones.data_ptr())
+
+    def reset(self, mask: torch.Tensor | None = None):
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        A.check(self.lib.wl_visual_reset_hf(C.byref(self.p), C.byref(self._bufs), C.byref(self._map), C.byref(self._hf),
+                                            None if m is None else m.data_ptr(), self.seed, self.step_count, self._stream()),
+                "wl_visual_reset_hf")
+
+    def observe(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        out = self.obs if out is None else out
+        A.check(self.lib.wl_visual_depth_observe(C.byref(self.p), C.byref(self._bufs), C.byref(self._hf), self.camera.pyramid.data_ptr(),
+                                                 self.max_depth, out.data_ptr(), self._stream()), "wl_visual_depth_observe")
+        return out
+
+    def sample_augmentation(self, generator=None):
+        """the depth image is not augmented (mdp_sensors/observations.py:93-95 returns the raw distances)"""
+
+    def step(self, actions: torch.Tensor):
+        if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.shape != (self.n, 2):
+            actions = actions.to(torch.float32).reshape(self.n, 2).contiguous()
+        self._step_into(actions.data_ptr(), self._out)
+        return self.obs, self.reward, self.terminated, self.truncated
+
+    def _step_into(self, actions_ptr, out):
+        A.check(self.lib.wl_visual_depth_step(C.byref(self.p), C.byref(self._bufs), C.byref(self._map), C.byref(self._hf),
+                                              self.camera.pyramid.data_ptr(), self.max_depth, actions_ptr, C.byref(out), self.seed,
+                                              self.step_count, self._stream()), "wl_visual_depth_step")
+        self.step_count += 1
+
+    def rollout(self, actions: torch.Tensor, obs_out=None, rew_out=None, term_out=None, trunc_out=None, dones_out=None,
+                persistent: bool = False):
+        """K steps with pre-staged actions [K, n, 2]; optional [K, ...] output storage (else overwritten in place)"""
+        K = actions.shape[0]
+        assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous() and not persistent
+        for k in range(K):
+            out = self._out if obs_out is None else A.WlStepOut(obs_out[k].data_ptr(), rew_out[k].data_ptr(), term_out[k].data_ptr(),
+                                                                trunc_out[k].data_ptr(), None if dones_out is None else dones_out[k].data_ptr())
+            self._step_into(actions[k].data_ptr(), out)
+
+    def depth(self, heightfield=None, max_depth: float | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+        """the task's own terrain unless another heightfield is given"""
+        if heightfield is None:
+            return self.camera.render(self, self.max_depth if max_depth is None else max_depth, out)
+        return super().depth(heightfield, 20.0 if max_depth is None else max_depth, out)
+
+
 class DepthCamera:
     """The visual task's pinhole camera rendering distance_to_image_plane against a heightfield (wl_visual_depth): owns the
     device copy of the field and its max-pyramid (built once), renders the poses of ANY batch (rows WL_S_PX.. / WL_S_QW.. of
@@ -525,12 +594,16 @@ class DepthCamera:
 
 
 def _cached_depth_camera(batch, heightfield) -> DepthCamera:
-    """one DepthCamera per (batch, heightfield object): the pyramid is built on first use"""
+    """one DepthCamera per (batch, heightfield): the pyramid is a SNAPSHOT of the field, built on first use and rebuilt when the
+    array object, its placement (x0, y0, cell), its shape or -- for tensors -- its in-place version counter changes"""
     cache = batch.__dict__.setdefault("_depth_cameras", {})
-    key = id(heightfield[0])
+    h, x0, y0, cell = heightfield
+    key = (id(h), float(x0), float(y0), float(cell), tuple(h.shape), getattr(h, "_version", None))
     cam = cache.get(key)
-    if cam is None or cam._src is not heightfield[0]:
+    if cam is None or cam._src is not h:
+        for k in [k for k in cache if k[0] == id(h)]:      # an older snapshot of the same array
+            del cache[k]
         cam = DepthCamera(heightfield, batch.device, batch.p if isinstance(batch.p, A.WlVisualParams) else None)
-        cam._src = heightfield[0]    # keeps the key's object alive: an id is only unique among live objects
+        cam._src = h    # keeps the key's object alive: an id is only unique among live objects
         cache[key] = cam
     return cam

@@ -61,11 +61,11 @@ WL_DEV DepthCam depth_cam(const WlVisualParams& p, const WlEnvBuffers& b, int e)
     return c;
 }
 
-// one ray per lane, one 4 x 16 tile per wavefront: the wavefront lives as long as its longest ray (lanes busy 0.6 of the time on
-// the bench poses).  Kept as the A/B reference of the pool form below (-DWL_DEPTH_POOL_ROWS=0 builds the library with it).
+// one ray per lane, one 4 x 16 tile per wavefront: the wavefront lives as long as its longest ray (lanes busy 0.6 of the steps on
+// the bench poses) -- and is still the fastest form measured (the ray-pool form below: 1.3 - 2 x slower).
 __global__ void __launch_bounds__(64) visual_depth_tile_kernel(const WlVisualParams p, const WlEnvBuffers b, const DepthGrid g,
                                                                 const Pyramid py, const float* __restrict__ buf, const unsigned buf_bytes,
-                                                                const float max_depth, float* __restrict__ depth) {
+                                                                const float max_depth, float* __restrict__ depth, const int64_t row_stride) {
     const int e = blockIdx.x / kTiles, tile = blockIdx.x - e * kTiles;
     const int strip = tile / kTilesPerStrip;
     const DepthCam cam = depth_cam(p, b, e);
@@ -74,18 +74,22 @@ __global__ void __launch_bounds__(64) visual_depth_tile_kernel(const WlVisualPar
     const V3 d = mul(cam.R, depth_pixel_ray_body(p, row, col));
     const FieldMem mem{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(buf), 0, (int)buf_bytes, 0x00020000)};
     const float t = cast_ray(g, py, mem, clear_height(g, py, mem), cam.o, d, max_depth);
-    depth[(int64_t)e * (WL_VIS_IMG_H * WL_VIS_IMG_W) + row * WL_VIS_IMG_W + col] = t;
+    depth[(int64_t)e * row_stride + row * WL_VIS_IMG_W + col] = t;
 }
 
-// Ray POOL per wavefront (round 4).  A tile's walk lengths differ 5 x between lanes (sky 2 - 3 steps, near ground 8 - 10, the rows
-// below the horizon 15 - 20, grazing rays 100 +): with one ray per lane 40 % of the lane-steps are idle lanes waiting for the
-// tile's longest ray.  Here a wavefront owns POOL_ROWS image rows of one env (POOL_ROWS x 80 rays, in 4 x 16 tile order so that
-// the lanes start as neighbours) and a lane whose ray is done takes the next ray of the pool: whenever at least THRESH lanes are
-// idle they are refilled in ONE pass of the set-up code (ballot + prefix count give each idle lane its pool index; the set-up costs
-// about as much as a step, so it has to be shared by many lanes).  On the bench poses the lanes are busy 0.80 of the steps instead
-// of 0.60 (host simulation of the same walk, tests/host_sim): 11.8 wave-steps per 64 rays against 15.2.
+// Ray POOL per wavefront (round 4; MEASURED SLOWER, not the default: -DWL_DEPTH_POOL_ROWS=4 | 12 | 20 | 60 builds it).  A tile's
+// walk lengths differ 5 x between lanes (sky 2 - 3 steps, near ground 8 - 10, the rows below the horizon 15 - 20, grazing rays
+// 100 +): with one ray per lane 40 % of the lane-steps are idle lanes waiting for the tile's longest ray.  Here a wavefront owns
+// POOL_ROWS image rows of one env (in 4 x 16 tile order, so that the lanes start as neighbours) and a lane whose ray is done takes
+// the next ray of the pool: whenever at least THRESH lanes are idle they are refilled in ONE pass of the set-up code (ballot +
+// prefix count give each idle lane its pool index).  The host simulation of the same walk (tests/host_sim) promised 11.8
+// wave-steps per 64 rays against 15.2 (lanes busy 0.80 instead of 0.60).  On the device, 4096 cameras, us per render: tile form
+// 545; pools of 4 rows 718, 12 rows 839 (THRESH 12 / 20 / 32: 849 / 839 / 893; non-temporal stores 802), 20 rows 890, 60 rows
+// 1083.  What the simulation does not see: lanes that hold rays from different tiles at different depths of their walks gather
+// from 64 unrelated places per step (the tile form's neighbours share their cache lines), and the fewer, longer wavefronts
+// balance worse over the chip.  Idle lanes are the cheaper evil.
 #ifndef WL_DEPTH_POOL_ROWS
-#define WL_DEPTH_POOL_ROWS 12
+#define WL_DEPTH_POOL_ROWS 0     // 0: the tile form
 #endif
 #ifndef WL_DEPTH_POOL_THRESH
 #define WL_DEPTH_POOL_THRESH 20
@@ -93,14 +97,14 @@ __global__ void __launch_bounds__(64) visual_depth_tile_kernel(const WlVisualPar
 template <int POOL_ROWS, int THRESH>
 __global__ void __launch_bounds__(64) visual_depth_pool_kernel(const WlVisualParams p, const WlEnvBuffers b, const DepthGrid g,
                                                                 const Pyramid py, const float* __restrict__ buf, const unsigned buf_bytes,
-                                                                const float max_depth, float* __restrict__ depth) {
+                                                                const float max_depth, float* __restrict__ depth, const int64_t row_stride) {
     static_assert(POOL_ROWS % kStripRows == 0 && WL_VIS_IMG_H % POOL_ROWS == 0, "whole strips per pool, whole pools per image");
     constexpr int kPools = WL_VIS_IMG_H / POOL_ROWS, kPool = POOL_ROWS * WL_VIS_IMG_W;
     const int e = blockIdx.x / kPools, r0 = (blockIdx.x - e * kPools) * POOL_ROWS;
     const DepthCam cam = depth_cam(p, b, e);
     const FieldMem mem{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(buf), 0, (int)buf_bytes, 0x00020000)};
     const float zclear = clear_height(g, py, mem);
-    float* img = depth + (int64_t)e * (WL_VIS_IMG_H * WL_VIS_IMG_W) + r0 * WL_VIS_IMG_W;
+    float* img = depth + (int64_t)e * row_stride + r0 * WL_VIS_IMG_W;
     const int lane = threadIdx.x;
     const int max_walk = max_walk_steps(g);
     // pool index -> pixel of the pool's rows: tile (q >> 6) = strip-major 4 x 16 tiles, (q & 63) = row-major inside the tile
@@ -156,6 +160,20 @@ __global__ void __launch_bounds__(64) visual_depth_pool_kernel(const WlVisualPar
     }
 }
 
+// the 8 proprioceptive columns of the visual-depth observation (base_lin_vel | base_ang_vel | last_action clipped) of the state as it
+// stands: lane = env (the step launch writes them itself; this is the reset / first-observation path)
+__global__ void __launch_bounds__(kBlock) visual_depth_prop_kernel(const WlEnvBuffers b, float* __restrict__ obs) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= b.n_envs) return;
+    const Rows S = make_rows(b.state, b.stride);
+    const Quat q{S.ld(WL_S_QW, e), S.ld(WL_S_QX, e), S.ld(WL_S_QY, e), S.ld(WL_S_QZ, e)};
+    const Mat3 R = mat_from_quat(q);
+    const V3 vb = mul_t(R, ld3(S, WL_S_VX, e)), wb = mul_t(R, ld3(S, WL_S_WX, e));
+    float* t = obs + (int64_t)e * WL_VISDEPTH_OBS_DIM + WL_VISDEPTH_NPIX;
+    t[0] = vb.x, t[1] = vb.y, t[2] = vb.z, t[3] = wb.x, t[4] = wb.y, t[5] = wb.z;
+    t[6] = clampf(S.ld(WL_S_ACT0, e), -1.f, 1.f), t[7] = clampf(S.ld(WL_S_ACT1, e), -1.f, 1.f);
+}
+
 }  // namespace
 
 extern "C" {
@@ -177,11 +195,11 @@ int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* 
     return launch_status();
 }
 
-int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
-                    float* depth, void* stream) {
-    if (!p || !b || !hf || !b->state || !hf->height || !pyramid || !depth || b->n_envs <= 0 || !(max_depth > 0.f)) return WL_EINVAL;
+int wl_visual_depth_rows(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
+                         float* rows, int64_t row_stride, void* stream) {
+    if (!p || !b || !hf || !b->state || !hf->height || !pyramid || !rows || b->n_envs <= 0 || !(max_depth > 0.f)) return WL_EINVAL;
     if (hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || b->stride < b->n_envs || !(p->fx > 0.f) ||
-        !(p->fy > 0.f))
+        !(p->fy > 0.f) || row_stride < WL_VISDEPTH_NPIX)
         return WL_EINVAL;
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (int64_t)b->n_envs * kTiles > 0x7fffffffLL) return WL_EINVAL;
     const Pyramid py = make_pyramid(hf->nx, hf->ny);
@@ -189,10 +207,31 @@ int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeig
     clear_error();
 #if WL_DEPTH_POOL_ROWS > 0
     visual_depth_pool_kernel<WL_DEPTH_POOL_ROWS, WL_DEPTH_POOL_THRESH><<<b->n_envs * (WL_VIS_IMG_H / WL_DEPTH_POOL_ROWS), 64, 0, (hipStream_t)stream>>>(
-        *p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, depth);
+        *p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, rows, row_stride);
 #else
-    visual_depth_tile_kernel<<<b->n_envs * kTiles, 64, 0, (hipStream_t)stream>>>(*p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, depth);
+    visual_depth_tile_kernel<<<b->n_envs * kTiles, 64, 0, (hipStream_t)stream>>>(*p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, rows, row_stride);
 #endif
+    return launch_status();
+}
+
+int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
+                    float* depth, void* stream) {
+    return wl_visual_depth_rows(p, b, hf, pyramid, max_depth, depth, WL_VISDEPTH_NPIX, stream);
+}
+
+int wl_visual_depth_step(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const WlHeightField* hf, const float* pyramid,
+                         float max_depth, const float* actions, const WlStepOut* out, uint64_t seed, uint64_t step, void* stream) {
+    if (!pyramid || !(max_depth > 0.f)) return WL_EINVAL;
+    const int rc = wl_visual_step_hf(p, b, m, hf, actions, out, seed, step, stream);     // validates the rest
+    if (rc != WL_OK) return rc;
+    return wl_visual_depth_rows(p, b, hf, pyramid, max_depth, out->obs, WL_VISDEPTH_OBS_DIM, stream);
+}
+
+int wl_visual_depth_observe(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
+                            float* obs, void* stream) {
+    const int rc = wl_visual_depth_rows(p, b, hf, pyramid, max_depth, obs, WL_VISDEPTH_OBS_DIM, stream);
+    if (rc != WL_OK) return rc;
+    visual_depth_prop_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*b, obs);
     return launch_status();
 }
 

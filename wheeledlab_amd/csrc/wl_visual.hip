@@ -14,6 +14,7 @@
 #include "wl_drift_terms.h"
 #include "wl_rng.h"
 #include "wl_vehicle.h"
+#include "wl_heightfield.h"
 
 namespace {
 
@@ -82,11 +83,14 @@ struct CamPose {
     float px, py, pz, qw, qx, qy, qz, vx, vy, vz, wx, wy, wz, a0, a1;
 };
 
-// one env.step() of env e (lane form: one lane; quad form: the four lanes of a quad, wid = wheel)
-template <int LANES>
+// one env.step() of env e (lane form: one lane; quad form: the four lanes of a quad, wid = wheel).  Ground: the flat plane of the
+// reference's task, or a heightfield (the visual-depth extension task, BASELINE config 5: wheel contacts by bilinear gathers as in
+// the elevation task, reset poses lifted onto the terrain; `prop`: the env's 8 proprioceptive observation values are written
+// there -- the depth image next to them comes from wl_depth.hip)
+template <int LANES, class Ground = FlatGround>
 WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, const WlEnvBuffers& b, const WlTravMap& m, float2 a,
                                const WlStepOut& out, const uint64_t seed, const uint64_t step, const Rows& S, const int e, const int wid,
-                               const bool lead, float* blk_metrics) {
+                               const bool lead, float* blk_metrics, const Ground ground = Ground{}, float* __restrict__ prop = nullptr) {
     const WlVehicleParams& vp = p.vehicle;
     {
         const uint32_t gid = (uint32_t)(b.env_offset + e);
@@ -114,7 +118,6 @@ WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, co
             s.x = pos + vp.cg_z * v3(R.r0.z, R.r1.z, R.r2.z);
             s.wb = mul_t(R, ww);
         }
-        const FlatGround ground{};
         // bookkeeping rows: the quad form (one wavefront per SIMD, registers to spare) requests them BEFORE the physics loop
         // and finds them landed behind it; the lane form fetches them after it (registers are worth more there)
         int ep_len_in = 0;
@@ -129,7 +132,7 @@ WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, co
             }
         };
         if constexpr (LANES == 4) fetch_bookkeeping();
-        vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
+        vehicle_integrate<LANES, Ground>(vp, vd, ec, s, ground, wid);
         if constexpr (LANES != 4) {
             asm volatile("" ::: "memory");
             fetch_bookkeeping();
@@ -187,6 +190,12 @@ WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, co
             }
             const VisReset rd = draw_visual_reset(p, m, gid, step, seed);
             pos = rd.pos;
+            if constexpr (!Ground::kFlat) {     // z 0.1 above the plane -> 0.1 above the terrain under the spawn cell
+                float zt;
+                V3 nt;
+                ground.sample(pos.x, pos.y, zt, nt);
+                pos.z += zt;
+            }
             s.q = rd.q;
             s.v = v3(0.f, 0.f, 0.f);
             ww = v3(0.f, 0.f, 0.f);
@@ -216,15 +225,22 @@ WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, co
                 for (int i = 0; i < WL_VR_NTERMS; ++i) S.st(WL_S_EPSUM0 + i, e, epsum[i]);
             }
             b.episode_len[e] = ep_len;
+            if (prop) {     // base_lin_vel | base_ang_vel | last_action (clipped) of the post-reset state
+                const Mat3 R2 = mat_from_quat(s.q);
+                const V3 vb2 = mul_t(R2, s.v), wb2 = mul_t(R2, ww);
+                prop[0] = vb2.x, prop[1] = vb2.y, prop[2] = vb2.z, prop[3] = wb2.x, prop[4] = wb2.y, prop[5] = wb2.z;
+                prop[6] = clampf(a0, -1.f, 1.f), prop[7] = clampf(a1, -1.f, 1.f);
+            }
         }
         return CamPose{pos.x, pos.y, pos.z, s.q.w, s.q.x, s.q.y, s.q.z, s.v.x, s.v.y, s.v.z, ww.x, ww.y, ww.z, a0, a1};
     }
 }
 
-template <int LANES, int QB = kBlock /* quad form: threads per block (see drift_step_kernel) */>
+template <int LANES, int QB = kBlock /* quad form: threads per block (see drift_step_kernel) */, class Ground = FlatGround>
 __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b,
                                                              const WlTravMap m, const float2* __restrict__ actions,
-                                                             const WlStepOut out, const uint64_t seed, const uint64_t step) {
+                                                             const WlStepOut out, const uint64_t seed, const uint64_t step,
+                                                             const Ground ground = Ground{}, const int prop_stride = 0, const int prop_offset = 0) {
     __shared__ float blk_metrics[WL_M_COUNT];
     WlVisualParams p = p_arg;
     VehDerived vd = vd_arg;
@@ -242,7 +258,9 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
     if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
     __syncthreads();
     const Rows S = make_rows(b.state, b.stride);
-    if (e < b.n_envs) visual_env_step<LANES>(p, vd, b, m, actions[e], out, seed, step, S, e, wid, lead, blk_metrics);
+    if (e < b.n_envs)
+        visual_env_step<LANES, Ground>(p, vd, b, m, actions[e], out, seed, step, S, e, wid, lead, blk_metrics, ground,
+                                       prop_stride > 0 ? out.obs + (int64_t)e * prop_stride + prop_offset : nullptr);
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
         const float v = blk_metrics[threadIdx.x];
@@ -568,13 +586,21 @@ __global__ void __launch_bounds__(kPersistThreads) visual_rollout_persistent_ker
     }
 }
 
+template <class Ground = FlatGround>
 __global__ void __launch_bounds__(kBlock) visual_reset_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
-                                                              const uint8_t* __restrict__ mask, uint64_t seed, uint64_t step) {
+                                                              const uint8_t* __restrict__ mask, uint64_t seed, uint64_t step,
+                                                              const Ground ground = Ground{}) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= b.n_envs) return;
     if (mask && !mask[e]) return;
     const Rows S = make_rows(b.state, b.stride);
-    const VisReset rd = draw_visual_reset(p, m, (uint32_t)(b.env_offset + e), step, seed);
+    VisReset rd = draw_visual_reset(p, m, (uint32_t)(b.env_offset + e), step, seed);
+    if constexpr (!Ground::kFlat) {
+        float zt;
+        V3 nt;
+        ground.sample(rd.pos.x, rd.pos.y, zt, nt);
+        rd.pos.z += zt;
+    }
     st3(S, WL_S_PX, e, rd.pos);
     S.st(WL_S_QW, e, rd.q.w);
     S.st(WL_S_QX, e, rd.q.x);
@@ -691,7 +717,7 @@ int wl_visual_reset(const WlVisualParams* p, const WlEnvBuffers* b, const WlTrav
     int rc = check_visual(p, b, m);
     if (rc != WL_OK) return rc;
     clear_error();
-    visual_reset_kernel<<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, mask, seed, step);
+    visual_reset_kernel<FlatGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, mask, seed, step, FlatGround{});
     return launch_status();
 }
 
@@ -701,6 +727,40 @@ int wl_visual_observe(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
     if (!obs) return WL_EINVAL;
     clear_error();
     launch_visual_obs(p, b, m, obs, (hipStream_t)stream);
+    return launch_status();
+}
+
+/* ---- the visual-depth extension task (BASELINE config 5): the visual task's step on a heightfield terrain; the observation row is
+ * [ depth image 4800 | base_lin_vel 3 | base_ang_vel 3 | last_action 2 ]: this launch writes the last 8, wl_depth.hip the image ---- */
+int wl_visual_step_hf(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const WlHeightField* hf, const float* actions,
+                      const WlStepOut* out, uint64_t seed, uint64_t step, void* stream) {
+    int rc = check_visual(p, b, m);
+    if (rc != WL_OK) return rc;
+    if (!hf || !hf->height || hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f)) return WL_EINVAL;
+    if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated) return WL_EINVAL;
+    const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
+    const HeightFieldGround g = make_ground(hf);
+    const float2* a = (const float2*)actions;
+    const hipStream_t hs = (hipStream_t)stream;
+    const int n = b->n_envs;
+    clear_error();
+    if (use_quad(b)) {
+        const int lanes = n * 4;
+        if (n <= 8192) visual_step_kernel<4, 128, HeightFieldGround><<<(lanes + 127) / 128, 128, 0, hs>>>(*p, vd, *b, *m, a, *out, seed, step, g, WL_VISDEPTH_OBS_DIM, WL_VISDEPTH_NPIX);
+        else visual_step_kernel<4, kBlock, HeightFieldGround><<<grid_for(lanes), kBlock, 0, hs>>>(*p, vd, *b, *m, a, *out, seed, step, g, WL_VISDEPTH_OBS_DIM, WL_VISDEPTH_NPIX);
+    } else {
+        visual_step_kernel<1, kBlock, HeightFieldGround><<<grid_for(n), kBlock, 0, hs>>>(*p, vd, *b, *m, a, *out, seed, step, g, WL_VISDEPTH_OBS_DIM, WL_VISDEPTH_NPIX);
+    }
+    return launch_status();
+}
+
+int wl_visual_reset_hf(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const WlHeightField* hf, const uint8_t* mask,
+                       uint64_t seed, uint64_t step, void* stream) {
+    int rc = check_visual(p, b, m);
+    if (rc != WL_OK) return rc;
+    if (!hf || !hf->height || hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f)) return WL_EINVAL;
+    clear_error();
+    visual_reset_kernel<HeightFieldGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, mask, seed, step, make_ground(hf));
     return launch_status();
 }
 

@@ -429,7 +429,8 @@ def flatten_visual_cfg(cfg) -> FlatTaskCfg:
     if not has_timeout:
         p.max_episode_length = INT_MAX
     flat.extra["out_of_map"] = has_oom
-    want = ["camera_data_rgb_flattened_aug", "base_lin_vel", "base_ang_vel", "last_action"]
+    depth_task = getattr(cfg, "wl_task", "visual") == "visual_depth"
+    want = ["raycast_depth" if depth_task else "camera_data_rgb_flattened_aug", "base_lin_vel", "base_ang_vel", "last_action"]
     vis_obs = _terms(cfg.observations.policy)
     got = [getattr(t.func, "__name__", str(t.func)) for _, t in vis_obs]
     if got[:len(want)] != want or cfg.observations.policy.enable_corruption:
@@ -448,6 +449,10 @@ def flatten_visual_cfg(cfg) -> FlatTaskCfg:
     flat.extra.update(map=t.traversability_hashmap, map_size=(t.num_rows, t.num_cols), env_size=(t.env_num_rows, t.env_num_cols),
                       group=(t.group_num_rows, t.group_num_cols), walkers=t.num_walkers, spacing=(t.row_spacing, t.col_spacing),
                       augment=bool(getattr(cfg, "augment_camera", True)))
+    if depth_task:      # extension task: heightfield terrain + the depth image as observation (tasks/visual_depth)
+        flat.task, flat.obs_dim = "visual_depth", A.VISDEPTH_OBS_DIM
+        clip = getattr(cam.spawn, "clipping_range", None) or (0.01, 20.0)
+        flat.extra.update(heightfield=getattr(t, "heightfield", None), max_depth=float(clip[1]), augment=False)
     return flat
 
 
@@ -455,7 +460,7 @@ def flatten_cfg(cfg):
     task = getattr(cfg, "wl_task", "drift")
     if task == "elevation":
         return flatten_elev_cfg(cfg)
-    if task == "visual":
+    if task in ("visual", "visual_depth"):
         return flatten_visual_cfg(cfg)
     f = flatten_drift_cfg(cfg)
     f.task, f.extra = "drift", {}

@@ -17,7 +17,7 @@ import math
 import torch
 
 from .. import _abi as A
-from ..core import DriftBatch, ElevBatch, VisualBatch
+from ..core import DriftBatch, ElevBatch, VisualBatch, VisualDepthBatch
 from .configclass import fields_of
 from .flatten import flatten_cfg
 from .scene import SceneView
@@ -229,11 +229,14 @@ class ManagerBasedRLEnv:
                       metrics_slots=int(cfg.metrics_slots), startup=flat.startup)
         if flat.task == "elevation":
             self._batch = ElevBatch(self.num_envs, heightfield=flat.extra.get("heightfield"), **common)
-        elif flat.task == "visual":
+        elif flat.task in ("visual", "visual_depth"):
             x = flat.extra
-            self._batch = VisualBatch(self.num_envs, trav_map=x["map"], spacing=x["spacing"],
-                                      map_kwargs=dict(map_size=x["map_size"], env_size=x["env_size"],
-                                                      sub_group_size=x["group"], num_walkers=x["walkers"]), **common)
+            kw = dict(trav_map=x["map"], spacing=x["spacing"], map_kwargs=dict(map_size=x["map_size"], env_size=x["env_size"],
+                                                                              sub_group_size=x["group"], num_walkers=x["walkers"]))
+            if flat.task == "visual_depth":
+                self._batch = VisualDepthBatch(self.num_envs, heightfield=x.get("heightfield"), max_depth=x["max_depth"], **kw, **common)
+            else:
+                self._batch = VisualBatch(self.num_envs, **kw, **common)
         else:
             self._batch = DriftBatch(self.num_envs, **common)
         self.scene = SceneView(self._batch, cfg.scene, task=flat.task)

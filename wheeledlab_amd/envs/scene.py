@@ -179,6 +179,9 @@ class CameraData:
         if self._cam is None:
             from ..core import DepthCamera
             b = self._b
+            if getattr(b, "camera", None) is not None:      # visual-depth task: the batch's own camera (its terrain, its pyramid)
+                self._cam = b.camera
+                return self._cam
             if hasattr(b, "height"):        # elevation task: its own heightfield (already on the device)
                 hf = (b.height, float(b._hf.x0), float(b._hf.y0), float(b._hf.cell))
             else:                           # flat ground: any grid at z = 0 (beyond it the outside plane is z = 0 as well)
