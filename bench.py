@@ -41,7 +41,8 @@ BYTES_PER_ENV_STEP = BYTES_READ + BYTES_WRITE
 
 # algorithmic HBM bytes per unit of the other hot kernels: elevation 270 + 676 x 4
 # (height map) + 8 (goal); visual 270 + 3200 x 4 (image); depth ray-cast: the 60 x 80 fp32 image + the camera pose (7 fp32)
-ALGO_BYTES = {"drift": BYTES_PER_ENV_STEP, "elev": 2982, "visual": 13070, "depth": 60 * 80 * 4 + 28}
+ALGO_BYTES = {"drift": BYTES_PER_ENV_STEP, "elev": 2982, "visual": 13070, "depth": 60 * 80 * 4 + 28,
+              "visual_depth": 270 + (60 * 80 + 8) * 4}     # the visual-depth task step: state rows + the 4808-float observation row
 
 
 _SHARED_SRC = ["wl_kernel_common.h", "wl_math.h", "wl_rng.h", "wl_vehicle.h", "wl_drift_terms.h"]
@@ -49,6 +50,7 @@ TASK_SOURCES = {"drift": ["wl_drift.hip", "wl_drift_env.h"] + _SHARED_SRC,
                 "elev": ["wl_elev.hip", "wl_heightfield.h", "wl_actor_dev.h", "wl_mlp.h"] + _SHARED_SRC,
                 "visual": ["wl_visual.hip"] + _SHARED_SRC,
                 "depth": ["wl_depth.hip", "wl_depth_dev.h", "wl_heightfield.h", "wl_kernel_common.h", "wl_math.h"]}
+TASK_SOURCES["visual_depth"] = sorted(set(TASK_SOURCES["visual"] + TASK_SOURCES["depth"]))
 
 
 def csrc_fingerprint(task: str):
@@ -101,7 +103,7 @@ def rocprof_avg_us(kernel_substr):
             for nm in names:
                 best = None
                 for r in rows:
-                    if nm + "<" in r.get("Name", "") + "<" and nm in r.get("Name", "") and (best is None or int(r["Calls"]) > best[0]):
+                    if nm in r.get("Name", "") and (best is None or int(r["Calls"]) > best[0]):
                         best = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
                 if best is None:
                     tot = None
@@ -351,7 +353,7 @@ def other_tasks_sweep(dev):
                 s1.record()
                 torch.cuda.synchronize()
                 dus = s0.elapsed_time(s1) * 1e3 / 3
-                blk = roofline_block("depth", big, dus, "visual_depth_kernel", "valu+latency")
+                blk = roofline_block("depth", big, dus, "visual_depth_tile_kernel", "valu+latency")
                 out.append({"task": "depth", "n_envs": big, "us_per_render": round(dus, 2), "rays_per_s": big * 4800 / (dus * 1e-6),
                             "achieved_GBs": blk["achieved"], "frac_of_8TBs": blk["frac"], "bytes_per_image": ALGO_BYTES["depth"]})
                 del cam, img
@@ -753,11 +755,11 @@ def main():
         other["visual_depth"] = {"us_per_render": dus, "images_per_s": n / (dus * 1e-6), "rays_per_s": n * 4800 / (dus * 1e-6),
                                  "image": "60 x 80 fp32 distance_to_image_plane", "hit_fraction": hit,
                                  "workload": f"{n} elevation-task cars on the synthetic 800 x 800 heightfield (0.05 m), max depth 100 m",
-                                 "roofline": roofline_block("depth", n, dus, "visual_depth_kernel",
+                                 "roofline": roofline_block("depth", n, dus, "visual_depth_tile_kernel",
                                                             "valu issue + divergence (max-pyramid walk; the image write is the only HBM stream)",
-                                                            profile_kernels=["visual_depth_kernel"] if n == ENVS_PER_GPU else None)}
+                                                            profile_kernels=["visual_depth_tile_kernel"] if n == ENVS_PER_GPU else None)}
         # this kernel's governing roofline is the VALU pipe, not HBM: instructions issued x 2 cycles / (1024 SIMDs x shader cycles)
-        dc = (other["visual_depth"]["roofline"].get("counters") or {}).get("visual_depth_kernel") or {}
+        dc = (other["visual_depth"]["roofline"].get("counters") or {}).get("visual_depth_tile_kernel") or {}
         other["visual_depth"]["roofline"]["valu_frac"] = dc.get("valu_pipe_frac")
         other["visual_depth"]["roofline"]["governing"] = "valu_frac (HBM fraction reported for the contract; the walk is instruction-bound)"
         if not args.no_cpu_baseline:
@@ -779,6 +781,47 @@ def main():
             except Exception as ex:   # noqa: BLE001 -- building / loading oracle/depth.c needs make + gcc + OpenMP on the box: a
                 other["visual_depth"]["cpu_baseline"] = {"error": repr(ex)}   # secondary figure must never cost the headline line
         del t, cam, img
+
+    # secondary: BASELINE.json configs[4] AS A TASK -- the visual task stepped on the heightfield terrain with the depth image as the
+    # policy observation (extension id Isaac-MushrVisualDepthRL-v0): two launches per env.step() (step on the heightfield, depth
+    # ray-cast into the observation rows), far plane 20 m as the task's camera is configured
+    if rank == 0 and world == 1 and not args.headline_only:
+        from wheeledlab_amd.core import VisualDepthBatch
+        t = VisualDepthBatch(n, device=dev, seed=42)
+        t.reset()
+        k = 16
+        a = torch.rand(k, n, 2, device=dev) * 2 - 1
+        a[:, :, 0] = a[:, :, 0].abs()
+        for _ in range(3):
+            t.rollout(a)
+        torch.cuda.synchronize()
+        q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        us = 1e30
+        for _ in range(3):
+            q0.record()
+            for _ in range(4):
+                t.rollout(a)
+            q1.record()
+            torch.cuda.synchronize()
+            us = min(us, q0.elapsed_time(q1) * 1e3 / (4 * k))
+        t.observe()
+        torch.cuda.synchronize()
+        q0.record()
+        for _ in range(16):
+            t.observe()
+        q1.record()
+        torch.cuda.synchronize()
+        obs_us = q0.elapsed_time(q1) * 1e3 / 16
+        other["visual_depth_task"] = {
+            "us_per_step": us, "env_steps_per_s": n / (us * 1e-6), "obs_dim": t.OBS_DIM, "render_us": obs_us, "step_launch_us": us - obs_us,
+            "launches": "two per env.step() (visual_step_kernel<HeightFieldGround>, visual_depth_tile_kernel)",
+            "workload": f"Isaac-MushrVisualDepthRL-v0 (extension): {n} envs on the synthetic 800 x 800 heightfield, 80 x 80 traversability map, "
+                        f"depth image 60 x 80 clipped at {t.max_depth:g} m as observation",
+            "hit_fraction": float((t.obs[:, :4800] < t.max_depth).float().mean()),
+            "roofline": roofline_block("visual_depth", n, us, "visual_step_kernel<HeightFieldGround> + visual_depth_tile_kernel",
+                                       "valu issue + divergence (the depth walk) + latency (40 dependent sub-steps with terrain gathers)"),
+            "test": "tests/test_gpu_visual_depth_task.py"}
+        del t, a
 
     # secondary: the same workload driven step by step through the drop-in Python surface
     # (registry.make -> ClipAction -> RslRlVecEnvWrapper.step), i.e. what a Python RL loop sees per env.step() call

@@ -41,6 +41,13 @@ elif task in ("elev", "visual"):
         env.sample_augmentation(torch.Generator().manual_seed(0))
     a = torch.rand(K, n, 2, device=dev) * 2 - 1
     env.rollout(a)
+elif task == "visual_depth":      # round 4: the visual-depth extension task (step on the heightfield + depth image observation)
+    from wheeledlab_amd.core import VisualDepthBatch
+    env = VisualDepthBatch(n, device=dev, seed=42)
+    env.reset()
+    a = torch.rand(K, n, 2, device=dev) * 2 - 1
+    a[:, :, 0] = a[:, :, 0].abs()
+    env.rollout(a)
 elif task == "depth":
     env = ElevBatch(n, device=dev, seed=42)
     env.reset()

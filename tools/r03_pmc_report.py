@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 from bench import ALGO_BYTES, csrc_fingerprint  # noqa: E402
 
 KERNELS = {"drift": ["drift_step_kernel"], "elev": ["elev_step_scan_kernel", "elev_step_kernel", "elev_scan_kernel", "elev_scan_lds_kernel"],
-           "visual": ["visual_step_kernel", "visual_obs_kernel"], "depth": ["visual_depth_kernel"]}
+           "visual": ["visual_step_kernel", "visual_obs_kernel"], "depth": ["visual_depth_kernel", "visual_depth_tile_kernel"],
+           "visual_depth": ["visual_step_kernel", "visual_depth_tile_kernel"]}
 
 
 def rows(d):

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-r03}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-pm() { d=$1; shift; c=$1; shift; timeout 300 rocprofv3 --output-format csv --pmc $c -d $O/$d -- "$@" > $O/$d.log 2>&1; }
+pm() { d=$1; shift; c=$1; shift; timeout ${WL_PMC_TIMEOUT:-240} rocprofv3 --output-format csv --pmc $c -d $O/$d -- "$@" > $O/$d.log 2>&1; }
 SQA="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
 SQB="GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"
 WORK=${WL_PMC_WORK:-"drift:4096:64 drift:4194304:4 elev:4096:32 elev:262144:4 visual:4096:16 visual:262144:2 depth:4096:8 depth:32768:2"}
