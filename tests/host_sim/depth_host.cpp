@@ -16,12 +16,19 @@ int hs_depth(const WlVisualParams* p, const WlHeightField* hf, int n, const floa
     const Pyramid py = make_pyramid(hf->nx, hf->ny);
     const int P = 1 << py.lp;
     std::vector<float> buf((size_t)pyramid_total_floats(hf->nx, hf->ny), -INFINITY);
-    for (int J = 0; J < (P >> 1); ++J)
-        for (int I = 0; I < (P >> 1); ++I) buf[(size_t)pyramid_level_offset(py.lp, 1) + (size_t)J * (P >> 1) + I] = pyramid_level1_value(*hf, I, J);
-    for (int L = 2; L <= py.lp; ++L)
+    float hmax = -INFINITY;
+    for (size_t k = 0; k < (size_t)hf->nx * hf->ny; ++k) hmax = fmaxf(hmax, hf->height[k]);
+    buf[0] = hmax;
+    for (int L = 1; L <= py.lp; ++L)
         for (int J = 0; J < (P >> L); ++J)
-            for (int I = 0; I < (P >> L); ++I)
-                buf[(size_t)pyramid_level_offset(py.lp, L) + (size_t)J * (P >> L) + I] = pyramid_reduce_value(buf.data(), py.lp, L, I, J);
+            for (int I = 0; I < (P >> L); ++I) {
+                uint32_t w0;
+                float c;
+                plane_cell_serial(*hf, L, I, J, w0, c);
+                float* e = buf.data() + 2 * ((size_t)pyramid_level_offset(py.lp, L) + (size_t)J * (P >> L) + I);
+                e[0] = __builtin_bit_cast(float, w0);
+                e[1] = c;
+            }
     std::copy(hf->height, hf->height + (size_t)hf->nx * hf->ny, buf.begin() + py.h0);
     const DepthGrid g = make_depth_grid(hf);
     const FieldMem mem{buf.data()};

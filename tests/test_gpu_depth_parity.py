@@ -33,29 +33,46 @@ def _posed_batch(pos, quat):
     return env
 
 
-def test_pyramid_levels_are_the_block_maxima(hf):
+def test_pyramid_planes_bound_every_grid_point_of_their_cells(hf):
+    """the bound pyramid (round 4): entry (J, I) of level L = { fp16 slopes a | b, float c }; the plane a (i - I 2^L) + b (j - J 2^L)
+    + c lies on or above EVERY grid point of its 2^L x 2^L block of cells (that is all the walk's skips rely on), tightly (the
+    largest residual of the block, a rounding hair above), and never looser at the block's centre than the block's maximum;
+    float 0 = the field's maximum; blocks that cover no cell: c = -inf; behind the entries the walk's copy of the heights"""
     from wheeledlab_amd.core import DepthCamera
-    for field in (hf, (hf[0][:613, :349].copy(), hf[1], hf[2], hf[3])):
+    rough = np.random.RandomState(5).uniform(0.0, 1.5, (97, 131)).astype(np.float32)       # nothing smooth about it
+    for field in (hf, (hf[0][:613, :349].copy(), hf[1], hf[2], hf[3]), (rough, -3.0, -2.0, 0.05)):
         cam = DepthCamera(field, DEV)
         torch.cuda.synchronize()
-        h = field[0]
+        h = np.asarray(field[0], np.float32)
         ny, nx = h.shape
         Pw = 2
         while Pw < nx - 1 or Pw < ny - 1:
             Pw *= 2
         pyr = cam.pyramid.cpu().numpy()
         lp = int(np.log2(Pw))
-        assert len(pyr) == Pw * Pw // 2 + nx * ny
-        np.testing.assert_array_equal(pyr[Pw * Pw // 2:].reshape(ny, nx), h)       # the walk's copy of the heights
+        assert len(pyr) == Pw * Pw + nx * ny and pyr[0] == h.max()
+        np.testing.assert_array_equal(pyr[Pw * Pw:].reshape(ny, nx), h)             # the walk's copy of the heights
+        hd = h.astype(np.float64)
         for L in range(1, lp + 1):
             W, s = Pw >> L, 1 << L
-            off = (Pw * Pw) >> (2 * L)
-            got = pyr[off: off + W * W].reshape(W, W)
-            want = np.full((W, W), -np.inf, np.float32)
-            for J in range(min(W, (ny - 1 + s - 1) // s)):
-                for I in range(min(W, (nx - 1 + s - 1) // s)):
-                    want[J, I] = h[J * s: min((J + 1) * s, ny - 1) + 1, I * s: min((I + 1) * s, nx - 1) + 1].max()
-            np.testing.assert_array_equal(got, want, err_msg=f"level {L}")
+            off = 2 * ((Pw * Pw) >> (2 * L))
+            ent = pyr[off: off + 2 * W * W].reshape(W, W, 2)
+            slopes = ent[:, :, 0].copy().view(np.uint32)
+            a = (slopes & 0xffff).astype(np.uint16).view(np.float16).astype(np.float64)
+            b = (slopes >> 16).astype(np.uint16).view(np.float16).astype(np.float64)
+            c = ent[:, :, 1].astype(np.float64)
+            nJ, nI = min(W, (ny - 1 + s - 1) // s), min(W, (nx - 1 + s - 1) // s)
+            assert np.isneginf(c[nJ:]).all() and np.isneginf(c[:, nI:]).all()         # blocks that cover no cell
+            step = max(1, (nJ * nI) // 4000)                                            # every block of the coarse levels, a sample of the fine
+            for k in range(0, nJ * nI, step):
+                J, I = divmod(k, nI)
+                blk = hd[J * s: min((J + 1) * s, ny - 1) + 1, I * s: min((I + 1) * s, nx - 1) + 1]
+                jj, ii = np.mgrid[0:blk.shape[0], 0:blk.shape[1]]
+                slack = c[J, I] + a[J, I] * ii + b[J, I] * jj - blk
+                assert slack.min() >= 0.0, (L, J, I, slack.min())
+                assert slack.min() < 1e-5 * (1 + abs(c[J, I])), (L, J, I, slack.min())                 # tight: it touches a point
+                centre = c[J, I] + 0.5 * (a[J, I] * (blk.shape[1] - 1) + b[J, I] * (blk.shape[0] - 1))
+                assert centre <= blk.max() + 1e-5 * (1 + abs(blk.max())), (L, J, I)
 
 
 @pytest.mark.parametrize("max_depth", [100.0, 20.0])
@@ -136,7 +153,7 @@ def test_invalid_arguments_are_refused(hf):
     assert lib.wl_visual_depth(*args(md=0.0)) == -1
     bad_hf = A.WlHeightField(cam._hf.height, 1, 800, 0.0, 0.0, 0.05, 0.0)
     assert lib.wl_visual_depth(*args(hf=bad_hf)) == -1
-    assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800
+    assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 + 800 * 800
     assert lib.wl_heightfield_build_pyramid(C.byref(bad_hf), cam.pyramid.data_ptr(), None) == -1
     torch.cuda.synchronize()
 

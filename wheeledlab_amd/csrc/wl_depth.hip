@@ -31,15 +31,51 @@ constexpr int kStripRows = 4, kStrips = WL_VIS_IMG_H / kStripRows;
 constexpr int kTileCols = 16, kTilesPerStrip = WL_VIS_IMG_W / kTileCols, kTiles = kStrips * kTilesPerStrip;   // 75 tiles per image
 static_assert(WL_VIS_IMG_H % kStripRows == 0 && WL_VIS_IMG_W % kTileCols == 0 && kStripRows * kTileCols == 64, "one wavefront per tile");
 
-__global__ void __launch_bounds__(kBlock) pyramid_level1_kernel(const WlHeightField f, float* __restrict__ buf, const int lp) {
-    const int W = (1 << lp) >> 1;
-    const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k < W * W) buf[pyramid_level_offset(lp, 1) + k] = pyramid_level1_value(f, k % W, k / W);
-}
-__global__ void __launch_bounds__(kBlock) pyramid_reduce_kernel(float* __restrict__ buf, const int lp, const int L) {
+// the bound pyramid, level by level straight from the heights (exact residuals: every grid point of a cell is visited).
+// Small cells (L <= 4: at most 17 x 17 points): one thread per cell.
+__global__ void __launch_bounds__(kBlock) pyramid_planes_small_kernel(const WlHeightField f, float* __restrict__ buf, const int lp, const int L) {
     const int W = (1 << lp) >> L;
     const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k < W * W) buf[pyramid_level_offset(lp, L) + k] = pyramid_reduce_value(buf, lp, L, k % W, k / W);
+    if (k >= W * W) return;
+    uint32_t w0;
+    float c;
+    plane_cell_serial(f, L, k % W, k / W, w0, c);
+    float* e = buf + 2 * (pyramid_level_offset(lp, L) + k);
+    e[0] = __builtin_bit_cast(float, w0);
+    e[1] = c;
+}
+// Large cells: one block per cell, its points strided over the threads, maxima folded through LDS.  The top level's block also
+// leaves the field's maximum in float 0 (clear_height).
+__global__ void __launch_bounds__(kBlock) pyramid_planes_large_kernel(const WlHeightField f, float* __restrict__ buf, const int lp, const int L) {
+    __shared__ float red[2][kBlock / 64];
+    const int W = (1 << lp) >> L;
+    const int I = blockIdx.x % W, J = blockIdx.x / W;
+    float* e = buf + 2 * (pyramid_level_offset(lp, L) + blockIdx.x);
+    int i0, i1, j0, j1;
+    if (!plane_cell_range(f, L, I, J, i0, i1, j0, j1)) {     // block-uniform
+        if (threadIdx.x == 0) e[0] = 0.f, e[1] = -INFINITY;
+        return;
+    }
+    float a, b, resid = -INFINITY, hmax = -INFINITY;
+    plane_cell_slopes(f, i0, i1, j0, j1, a, b);
+    const int wpts = i1 - i0 + 1, npts = wpts * (j1 - j0 + 1);
+    for (int k = threadIdx.x; k < npts; k += kBlock) plane_point(f, i0, j0, i0 + k % wpts, j0 + k / wpts, a, b, resid, hmax);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        resid = fmaxf(resid, __shfl_xor(resid, off, 64));
+        hmax = fmaxf(hmax, __shfl_xor(hmax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = resid, red[1][threadIdx.x >> 6] = hmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) resid = fmaxf(resid, red[0][w]), hmax = fmaxf(hmax, red[1][w]);
+        uint32_t w0;
+        float c;
+        plane_entry(i0, i1, j0, j1, a, b, resid, hmax, w0, c);
+        e[0] = __builtin_bit_cast(float, w0);
+        e[1] = c;
+        if (L == lp) buf[0] = hmax;
+    }
 }
 __global__ void __launch_bounds__(kBlock) pyramid_copy_heights_kernel(const float* __restrict__ h, float* __restrict__ dst, const int n) {
     const int k = blockIdx.x * kBlock + threadIdx.x;
@@ -189,8 +225,11 @@ int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* 
     clear_error();
     const hipStream_t hs = (hipStream_t)stream;
     const int P = 1 << py.lp;
-    pyramid_level1_kernel<<<grid_for((P >> 1) * (P >> 1)), kBlock, 0, hs>>>(*hf, pyramid, py.lp);
-    for (int L = 2; L <= py.lp; ++L) pyramid_reduce_kernel<<<grid_for((P >> L) * (P >> L)), kBlock, 0, hs>>>(pyramid, py.lp, L);
+    for (int L = 1; L <= py.lp; ++L) {
+        const int cells = (P >> L) * (P >> L);
+        if (L <= 4 && L < py.lp) pyramid_planes_small_kernel<<<grid_for(cells), kBlock, 0, hs>>>(*hf, pyramid, py.lp, L);
+        else pyramid_planes_large_kernel<<<cells, kBlock, 0, hs>>>(*hf, pyramid, py.lp, L);
+    }
     pyramid_copy_heights_kernel<<<grid_for(hf->nx * hf->ny), kBlock, 0, hs>>>(hf->height, pyramid + py.h0, hf->nx * hf->ny);
     return launch_status();
 }

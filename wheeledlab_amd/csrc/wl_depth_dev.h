@@ -7,43 +7,91 @@
 namespace {
 
 // ONE device buffer holds everything the walk gathers, so that every access is a 32-bit offset from one base:
-//   floats [PP >> 2L, 2 (PP >> 2L))  level L of the max-pyramid, 1 <= L <= lp: a (P >> L) x (P >> L) array (P = 2^lp = the
-//                                    power of two >= the cell count of the longer side, PP = P^2); entry (J, I) = the highest
-//                                    grid corner inside the 2^L x 2^L block of cells (J, I); blocks that cover no cell: -inf
-//   floats [PP / 2, PP / 2 + ny nx)  a copy of the heights [ny][nx] (level 0 is not stored: a cell's maximum is the largest
-//                                    of the four corners the intersection needs anyway)
-// The level offsets are shifts (no table, no division); the price is PP / 6 floats of padding.
+//   float  [0]                       the field's maximum (clear_height)
+//   entries [PP >> 2L, 2 (PP >> 2L)) level L of the BOUND pyramid, 1 <= L <= lp: a (P >> L) x (P >> L) array (P = 2^lp = the
+//                                    power of two >= the cell count of the longer side, PP = P^2) of 8-byte entries
+//                                    { half a | half b, float c } (entry e = floats 2 e, 2 e + 1): inside the 2^L x 2^L block of
+//                                    cells (J, I) the terrain stays below the PLANE  a (u - I 2^L) + b (v - J 2^L) + c  (u, v in
+//                                    grid units); blocks that cover no cell: c = -inf
+//   floats [PP, PP + ny nx)          a copy of the heights [ny][nx] (level 0 is not stored: the intersection needs the four
+//                                    corners of a cell anyway)
+// The level offsets are shifts (no table, no division); the price is PP / 3 floats of padding.
+//
+// Round 4: bounding PLANES instead of the round-3 maxima.  Under a maximum a cell on a slope is "as high as its highest corner":
+// a ray skimming 10 - 20 cm above a hillside cannot skip cells larger than ~0.2 m and walks them one by one.  A plane fitted to
+// the cell (slopes from its corner heights, rounded to fp16; c = the largest residual of ANY grid point of the cell against the
+// ROUNDED slopes, so the bound is exact whatever the fit is worth) is loose only by the cell's curvature; the ray clears it over
+// its whole stay in the cell iff it clears it at both ends (ray and plane are both linear).  Same answers bit for bit (a skip is
+// only ever conservative); host simulation on the bench poses: 8.15 -> 6.49 steps per ray, 13.9 -> 9.1 wave-steps per tile.
+// Where the flat bound (a = b = 0, c = the cell's maximum) is the lower one at the cell's centre it is stored instead.
 struct Pyramid {
     int lp;        // log2 P = the top level (one entry)
-    int h0;        // float offset of the height copy = PP / 2
+    int h0;        // float offset of the height copy = PP
 };
 inline int pyramid_log2(int nx, int ny) {
     int lp = 1;
     while ((1 << lp) < nx - 1 || (1 << lp) < ny - 1) ++lp;
     return lp;
 }
-__host__ __device__ inline int pyramid_level_offset(int lp, int L) { return (1 << (2 * lp)) >> (2 * L); }
+__host__ __device__ inline int pyramid_level_offset(int lp, int L) { return (1 << (2 * lp)) >> (2 * L); }   // in ENTRIES
 inline Pyramid make_pyramid(int nx, int ny) {
     const int lp = pyramid_log2(nx, ny);
-    return Pyramid{lp, (1 << (2 * lp)) >> 1};
+    return Pyramid{lp, 1 << (2 * lp)};
 }
 inline int64_t pyramid_total_floats(int nx, int ny) { return (int64_t)make_pyramid(nx, ny).h0 + (int64_t)nx * ny; }
 
-// level 1 from the heights: cell (I, J) covers grid cells (2I .. 2I+1, 2J .. 2J+1), i.e. corners (2I .. 2I+2, 2J .. 2J+2)
-WL_DEV float pyramid_level1_value(const WlHeightField& f, int I, int J) {
-    float m = -INFINITY;
-    if (2 * I < f.nx - 1 && 2 * J < f.ny - 1) {
-        const int i1 = min(2 * I + 2, f.nx - 1), j1 = min(2 * J + 2, f.ny - 1);
-        for (int j = 2 * J; j <= j1; ++j)
-            for (int i = 2 * I; i <= i1; ++i) m = fmaxf(m, f.height[(int64_t)j * f.nx + i]);
-    }
-    return m;
+// two fp16 slopes in one 32-bit word
+WL_DEV uint32_t pack_slopes(float a, float b) {
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
 }
-// level L >= 2 from level L - 1
-WL_DEV float pyramid_reduce_value(const float* buf, int lp, int L, int I, int J) {
-    const int W = (1 << lp) >> L;
-    const float* src = buf + pyramid_level_offset(lp, L - 1) + (2 * J) * (2 * W) + 2 * I;
-    return fmaxf(fmaxf(src[0], src[1]), fmaxf(src[2 * W], src[2 * W + 1]));
+WL_DEV void unpack_slopes(uint32_t w, float& a, float& b) {
+    a = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
+    b = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+}
+// the grid points of cell (I, J) of level L: [i0, i1] x [j0, j1] (clipped to the field); false: the block covers no cell
+WL_DEV bool plane_cell_range(const WlHeightField& f, int L, int I, int J, int& i0, int& i1, int& j0, int& j1) {
+    i0 = I << L, j0 = J << L;
+    if (i0 >= f.nx - 1 || j0 >= f.ny - 1) return false;
+    i1 = min(i0 + (1 << L), f.nx - 1), j1 = min(j0 + (1 << L), f.ny - 1);
+    return true;
+}
+// the fitted slopes of a cell: mean slope between its opposite edges' corner heights, as fp16 will hold them (clamped into fp16's
+// range: any slopes give a valid bound, the residual below makes it exact)
+WL_DEV void plane_cell_slopes(const WlHeightField& f, int i0, int i1, int j0, int j1, float& a, float& b) {
+    const float h00 = f.height[(int64_t)j0 * f.nx + i0], h10 = f.height[(int64_t)j0 * f.nx + i1];
+    const float h01 = f.height[(int64_t)j1 * f.nx + i0], h11 = f.height[(int64_t)j1 * f.nx + i1];
+    const float fa = ((h10 + h11) - (h00 + h01)) / (2.f * (float)(i1 - i0)), fb = ((h01 + h11) - (h00 + h10)) / (2.f * (float)(j1 - j0));
+    unpack_slopes(pack_slopes(fminf(fmaxf(fa, -6e4f), 6e4f), fminf(fmaxf(fb, -6e4f), 6e4f)), a, b);
+    if (!(a == a)) a = 0.f;      // NaN heights: flat
+    if (!(b == b)) b = 0.f;
+}
+// residual and height of ONE grid point against the cell's slopes (the reductions over a cell's points take the max of both)
+WL_DEV void plane_point(const WlHeightField& f, int i0, int j0, int i, int j, float a, float b, float& resid, float& hmax) {
+    const float h = f.height[(int64_t)j * f.nx + i];
+    resid = fmaxf(resid, h - fmaf(a, (float)(i - i0), b * (float)(j - j0)));
+    hmax = fmaxf(hmax, h);
+}
+// the entry to store: the fitted plane, or the flat bound where that is the lower one at the cell's centre; a hair of slack
+// covers the rounding of the walk's own evaluation of the plane
+WL_DEV void plane_entry(int i0, int i1, int j0, int j1, float a, float b, float resid, float hmax, uint32_t& w0, float& c) {
+    const float centre = resid + 0.5f * fmaf(a, (float)(i1 - i0), b * (float)(j1 - j0));
+    const bool fitted = centre < hmax;
+    w0 = fitted ? pack_slopes(a, b) : 0u;
+    c = (fitted ? resid : hmax) + 2e-6f * (1.f + fabsf(fitted ? resid : hmax));
+}
+// one cell, serially (small cells on the device; every cell in the host simulation)
+WL_DEV void plane_cell_serial(const WlHeightField& f, int L, int I, int J, uint32_t& w0, float& c) {
+    int i0, i1, j0, j1;
+    if (!plane_cell_range(f, L, I, J, i0, i1, j0, j1)) {
+        w0 = 0u, c = -INFINITY;
+        return;
+    }
+    float a, b, resid = -INFINITY, hmax = -INFINITY;
+    plane_cell_slopes(f, i0, i1, j0, j1, a, b);
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) plane_point(f, i0, j0, i, j, a, b, resid, hmax);
+    plane_entry(i0, i1, j0, j1, a, b, resid, hmax, w0, c);
 }
 
 // the walk's view of that buffer: 4- and 8-byte gathers at float offsets
@@ -210,16 +258,26 @@ WL_DEV void ray_step(const DepthGrid& g, const Pyramid& py, const FieldMem& mem,
     const float z_t = fmaf(t, dz, oz);
     const float zmin = dz < 0.f ? fmaf(te, dz, oz) : z_t;
     const bool fine = L == 0;
-    float h00, h10, h01, h11, m;
+    float h00, h10, h01, h11;
+    bool clear;      // the ray stays above everything in this cell over [t, te]
     if (fine) {
         const int k = py.h0 + (int)__umul24((unsigned)j, (unsigned)g.nx) + i;   // j, nx < 2^24: the full-rate multiply
         mem.ld2(k, h00, h10);
         mem.ld2(k + g.nx, h01, h11);
-        m = fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
+        clear = zmin > fmaxf(fmaxf(h00, h10), fmaxf(h01, h11)) + 1e-6f;
     } else {
-        m = mem.ld(pyramid_level_offset(py.lp, L) + (jL << (py.lp - L)) + iL);
+        // the cell's bounding plane, one 8-byte gather: above it at both ends of the stay = above it throughout
+        float sw, c;
+        mem.ld2(2 * (pyramid_level_offset(py.lp, L) + (jL << (py.lp - L)) + iL), sw, c);
+        float a, b;
+        unpack_slopes(__builtin_bit_cast(uint32_t, sw), a, b);
+        const float u0 = ou - (float)(iL << L), v0 = ov - (float)(jL << L);
+        const float au = a * u0, bv = b * v0;
+        const float g0 = (oz - c) - (au + bv), g1 = dz - fmaf(a, du, b * dv);      // height above the plane: g(t) = g0 + t g1
+        // margin: the rounding of g itself (the products can be hundreds of times the ray's clearance on steep, far cells)
+        clear = fminf(fmaf(t, g1, g0), fmaf(te, g1, g0)) > fmaf(4e-7f, fabsf(au) + fabsf(bv), 1e-5f);
     }
-    if (!(zmin > m + 1e-6f)) {      // the ray may touch something in this cell
+    if (!clear) {      // the ray may touch something in this cell
         if (!fine) {
             w.L = L - 1;
             return;
@@ -293,9 +351,7 @@ WL_DEV float cast_ray(const DepthGrid& g, const Pyramid& py, const FieldMem& mem
     return ray_result(g, w);
 }
 // the height nothing of the terrain solid rises above: the pyramid's top entry (the field's maximum) or the outside plane
-WL_DEV float clear_height(const DepthGrid& g, const Pyramid& py, const FieldMem& mem) {
-    return fmaxf(mem.ld(pyramid_level_offset(py.lp, py.lp)), g.outside_z);
-}
+WL_DEV float clear_height(const DepthGrid& g, const Pyramid& py, const FieldMem& mem) { return fmaxf(mem.ld(0), g.outside_z); }
 
 // camera ray of pixel (row, col) of the FULL 60 x 80 image in the body frame: optical axis = body +x, image right = body -y,
 // image down = body -z (the visual camera's convention, wl_visual.hip).  Body x component 1: the ray parameter IS the
