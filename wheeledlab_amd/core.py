@@ -68,6 +68,14 @@ class _MetricsView:
         first step's counts (a ring of R slots holds R - 1 steps)."""
         return self.metrics_slots > 1 and n_steps > 1 and n_steps % self.metrics_slots == 0
 
+    def _warn_ring_alias(self, n_steps: int):
+        if not getattr(self, "_ring_alias_warned", False):
+            import warnings
+            warnings.warn(f"a persistent rollout of {n_steps} steps with a metric ring of {self.metrics_slots} slots is run as 1 + "
+                          f"{n_steps - 1} steps: the ring then misses the first step's episode counts (choose a rollout length that is "
+                          "not a multiple of metrics_slots to keep them)", stacklevel=3)
+            self._ring_alias_warned = True
+
 
 class DriftBatch(_MetricsView):
     """n drift envs resident on one GPU as a SoA state matrix [S_COUNT, stride] (fp32)."""
@@ -160,6 +168,7 @@ class DriftBatch(_MetricsView):
         K = actions.shape[0]
         assert actions.shape == (K, self.n, 2) and actions.dtype == torch.float32 and actions.is_contiguous()
         if persistent and self._ring_aliases(K):
+            self._warn_ring_alias(K)
             cut = lambda t, a, b: None if t is None else t[a:b]
             for a, b in ((0, 1), (1, K)):
                 self.rollout(actions[a:b], cut(obs_out, a, b), cut(rew_out, a, b), cut(term_out, a, b), cut(trunc_out, a, b), True,

@@ -460,8 +460,15 @@ class ManagerBasedRLEnv:
         out = {}
         for key, (kind, i) in self._log_keys.items():
             out[key] = m[i] if kind == "c" else m[A.M_EPSUM0 + i] / resets / self.max_episode_length_s
-        for key, v in self._custom_log.items():      # terms that run as torch behind the kernel: their latest episode means / counts
-            out[key] = float(v)
+        if self._custom_log:      # terms that run as torch behind the kernel: their latest episode means / counts -- ONE stacked copy
+            keys = list(self._custom_log)
+            vals = torch.stack([torch.as_tensor(self._custom_log[k], dtype=torch.float32, device=self.device).reshape(()) for k in keys])
+            if reduce_ranks and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                # rank-local means / counts -> the mean over ranks (counts: the sum), like the kernel's keys above
+                counts = torch.tensor([k.startswith("Episode_Termination/") for k in keys], device=self.device)
+                torch.distributed.all_reduce(vals)
+                vals = torch.where(counts, vals, vals / torch.distributed.get_world_size())
+            out.update(zip(keys, vals.tolist()))
         return out
 
     def _episode_log(self, slot):

@@ -416,7 +416,8 @@ def raycast_depth(env, sensor_cfg=_CAMERA, heightfield=None, max_depth: float | 
     far = env.scene.sensors[sensor_cfg.name].data.far if max_depth is None else max_depth
     if heightfield is None:
         return env.scene.sensors[sensor_cfg.name].data._camera().render(env._batch, far).unsqueeze(-1)
-    return env._batch.depth(heightfield, far).unsqueeze(-1)
+    from ..core import _cached_depth_camera          # any task's batch: the camera is built on (and cached with) the batch
+    return _cached_depth_camera(env._batch, heightfield).render(env._batch, far).unsqueeze(-1)
 
 
 @_event("reset_traversable")

@@ -170,7 +170,8 @@ class CameraData:
     heightfield of the elevation task, the z = 0 plane of the others -- and clipped at the camera's far plane."""
 
     def __init__(self, batch, cfg):
-        self._b, self._cam = batch, None
+        self._b, self._cam, self._cfg = batch, None, cfg
+        self._cached = (None, None)      # (batch.step_count it was rendered at, image): one render per env.step(), however often read
         clip = getattr(getattr(cfg, "spawn", None), "clipping_range", None) or (0.01, 100.0)
         self.far = float(clip[1])
         self.beyond = {"max": None, "zero": 0.0, "none": float("inf")}[getattr(cfg, "depth_clipping_behavior", "max")]
@@ -186,8 +187,21 @@ class CameraData:
                 hf = (b.height, float(b._hf.x0), float(b._hf.y0), float(b._hf.cell))
             else:                           # flat ground: any grid at z = 0 (beyond it the outside plane is z = 0 as well)
                 hf = (torch.zeros(3, 3, dtype=torch.float32, device=b.device), -1.0, -1.0, 1.0)
-            self._cam = DepthCamera(hf, b.device, b.p if isinstance(b.p, A.WlVisualParams) else None)
+            self._cam = DepthCamera(hf, b.device, b.p if isinstance(b.p, A.WlVisualParams) else self._params_from_cfg())
         return self._cam
+
+    def _params_from_cfg(self):
+        """tasks whose batch carries no camera parameters (drift, elevation): intrinsics and mounting pose from the sensor's cfg"""
+        from ..params import visual_params
+        p, c = visual_params(), self._cfg
+        sp = getattr(c, "spawn", None)
+        if sp is not None and getattr(sp, "focal_length", None):
+            p.fx = c.width * sp.focal_length / sp.horizontal_aperture
+            p.fy = c.height * sp.focal_length / sp.vertical_aperture
+            p.cx, p.cy = c.width / 2, c.height / 2
+        if getattr(c, "body_pos", None) is not None:
+            p.cam_pos[0], p.cam_pos[1], p.cam_pos[2] = c.body_pos
+        return p
 
     @property
     def output(self):
@@ -202,10 +216,13 @@ class _CameraOutputs:
         if key != "distance_to_image_plane":
             raise KeyError(f"camera data type {key!r} is not rendered here (the fused observation carries the grey image)")
         d = self._d
-        img = d._camera().render(d._b, d.far)
-        if d.beyond is not None:
-            img = torch.where(img >= d.far, torch.full_like(img, d.beyond), img)
-        return img.unsqueeze(-1)
+        stamp = getattr(d._b, "step_count", None)
+        if d._cached[0] != stamp or stamp is None:
+            img = d._camera().render(d._b, d.far)
+            if d.beyond is not None:
+                img = torch.where(img >= d.far, torch.full_like(img, d.beyond), img)
+            d._cached = (stamp, img.unsqueeze(-1))
+        return d._cached[1]
 
     def keys(self):
         return ["distance_to_image_plane"]
