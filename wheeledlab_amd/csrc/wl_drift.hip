@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? 
                                                             const VehDerived vd_arg, const WlEnvBuffers b_arg,
                                                             const float* __restrict__ noise, const WlStepOut out,
                                                             const Ground ground, const MetricSlots slots) {
-    constexpr int kEnvs = (LANES == 4 ? QB : kBlock) / LANES;   // envs per block
+    constexpr int kEnvs = QB / LANES;   // envs per block (QB threads per block in both forms)
     // quad (latency) form: parameters by one batch of vector loads from the kernarg segment (p_arg right behind the
     // hot arguments, vd_arg behind it); lane (throughput) form: the compiler's scalar loads -- latency is hidden by
     // occupancy there and the VGPRs are needed for the env
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? 
     b.env_offset = env_offset;
     // lane form only: per-WAVEFRONT obs transposing tile and metric accumulators (no block barrier anywhere)
     __shared__ float tile[LANES == 1 ? kEnvs * kObsPad : 1];
-    __shared__ float wave_metrics[LANES == 1 ? (kBlock / 64) * WL_M_COUNT : 1];
+    __shared__ float wave_metrics[LANES == 1 ? (QB / 64) * WL_M_COUNT : 1];
     const int wave = threadIdx.x >> 6;
     const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);   // this lane's wheel (quad form)
     const bool lead = LANES == 1 || wid == 0;       // the lane that writes the env's shared rows / outputs
@@ -278,7 +278,13 @@ static void launch_step(const WlDriftParams* p, const WlEnvBuffers* b, const Veh
                         const WlStepOut& out, uint64_t seed, uint64_t step, hipStream_t stream) {
     const MetricSlots slots = metric_slots(b, step);
 #define WL_STEP_ARGS b->state, b->episode_len, actions, (int)b->stride, b->n_envs, b->env_offset, seed, step, *p, vd, *b, noise, out, FlatGround{}, slots
-    const int grid = grid_for(b->n_envs);
+#ifndef WL_LANE_BLOCK
+#define WL_LANE_BLOCK 256     // threads per block of the lane forms (whole wavefronts; the kernel has no block-level barrier).
+                              // Round 4, us per step at 1 M / 2 M / 4 M envs: 256 threads 79.2 / 151.0 / 290.1, 128: 81.5 / 155.1 / 291.6,
+                              // 64: 82.1 / 153.1 / 292.0 -- finer blocks do not even out the last round of the launch
+#endif
+    constexpr int LB = WL_LANE_BLOCK;
+    const int grid = (b->n_envs + LB - 1) / LB;
     const bool awd = p->vehicle.drive == 1;
     // WL_FLAG_STREAM selects the streaming instantiation at any size (it is a lane form with the scalar wheel loop)
     const bool streaming = use_streaming(b, (int64_t)b->stride * 4 * WL_S_COUNT, kStreamingStateBytes);
@@ -290,14 +296,14 @@ static void launch_step(const WlDriftParams* p, const WlEnvBuffers* b, const Veh
         else drift_step_kernel<4, FlatGround><<<grid_for(lanes), kBlock, 0, stream>>>(WL_STEP_ARGS);
     }
     else if (!forced_stream && use_unrolled(b)) {
-        if (awd) drift_step_kernel<1, FlatGround, true, 1><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
-        else drift_step_kernel<1, FlatGround, true, 0><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
+        if (awd) drift_step_kernel<1, FlatGround, true, 1, LB><<<grid, LB, 0, stream>>>(WL_STEP_ARGS);
+        else drift_step_kernel<1, FlatGround, true, 0, LB><<<grid, LB, 0, stream>>>(WL_STEP_ARGS);
     } else if (!streaming) {
-        if (awd) drift_step_kernel<1, FlatGround, false, 1><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
-        else drift_step_kernel<1, FlatGround, false, 0><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
+        if (awd) drift_step_kernel<1, FlatGround, false, 1, LB><<<grid, LB, 0, stream>>>(WL_STEP_ARGS);
+        else drift_step_kernel<1, FlatGround, false, 0, LB><<<grid, LB, 0, stream>>>(WL_STEP_ARGS);
     } else {
-        if (awd) drift_step_kernel<1, FlatGround, false, 1, kBlock, true><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
-        else drift_step_kernel<1, FlatGround, false, 0, kBlock, true><<<grid, kBlock, 0, stream>>>(WL_STEP_ARGS);
+        if (awd) drift_step_kernel<1, FlatGround, false, 1, LB, true><<<grid, LB, 0, stream>>>(WL_STEP_ARGS);
+        else drift_step_kernel<1, FlatGround, false, 0, LB, true><<<grid, LB, 0, stream>>>(WL_STEP_ARGS);
     }
 #undef WL_STEP_ARGS
 }

@@ -147,7 +147,7 @@ WL_DEV void keep_scalar_common(P& v, const P& s) {   // from the scalar copy of 
 // Metric accumulators: [slot][WL_M_SHARDS][WL_M_COUNT] (include/wheeledlab_amd.h).
 constexpr int kMetricSlotFloats = WL_M_SHARDS * WL_M_COUNT;
 WL_DEV float* metric_shard(const WlEnvBuffers& b, int slot) {   // this wavefront's shard of `slot`
-    const int wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int wave = blockIdx.x * ((int)blockDim.x >> 6) + (threadIdx.x >> 6);
     return b.metrics + (int64_t)slot * kMetricSlotFloats + (wave & (WL_M_SHARDS - 1)) * WL_M_COUNT;
 }
 WL_DEV void clear_metric_slot(const WlEnvBuffers& b, int slot) {   // block 0 zeroes all shards of `slot`
