@@ -397,7 +397,15 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
         tgt_in[3] = S.ld(WL_S_CMD_TIMER, e);
     };
     if constexpr (LANES == 4) fetch_bookkeeping();
-    vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
+#ifndef WL_WHEEL_CORNER_CACHE
+#define WL_WHEEL_CORNER_CACHE 1
+#endif
+    if constexpr (LANES == 1 && WL_WHEEL_CORNER_CACHE) {      // lane form: each wheel's cell corners stay in registers between sub-steps
+        const HeightFieldGroundCached cached(ground);
+        vehicle_integrate<LANES, HeightFieldGroundCached>(vp, vd, ec, s, cached, wid);
+    } else {
+        vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
+    }
     if constexpr (LANES != 4) {
         asm volatile("" ::: "memory");
         fetch_bookkeeping();
@@ -508,8 +516,11 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
 
 // (lane form: 110 VGPRs = 4 wavefronts per SIMD.  Squeezed to 96 / 80 registers for 5 / 6 wavefronts the kernel spills 60 / 128 bytes
 // of scratch per lane and the step at 262 144 envs goes from 650 to 664 / 782 us: round 3.)
+#ifndef WL_ELEV_LANE_WAVES
+#define WL_ELEV_LANE_WAVES 1
+#endif
 template <int LANES>
-__global__ void __launch_bounds__(kBlock) elev_step_kernel(const WlElevParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b,
+__global__ void __launch_bounds__(kBlock, LANES == 1 ? WL_ELEV_LANE_WAVES : 1) elev_step_kernel(const WlElevParams p_arg, const VehDerived vd_arg, const WlEnvBuffers b,
                                                            const HeightFieldGround ground, const float2* __restrict__ actions,
                                                            const WlStepOut out, const uint64_t seed, const uint64_t step) {
     __shared__ float blk_metrics[WL_M_COUNT];

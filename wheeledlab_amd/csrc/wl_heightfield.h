@@ -36,6 +36,8 @@ struct HeightFieldGround {
         return inside;
     }
     WL_DEV void sample(float x, float y, float& z, V3& n) const { (void)sample_full(x, y, z, n); }
+    template <int W>
+    WL_DEV void sample_wheel(float x, float y, float& z, V3& n) const { (void)sample_full(x, y, z, n); }
     // split form of sample_height for software pipelining: `corners` issues the two 8-byte gathers, `blend` consumes them
     struct Corners {
         wl_float2_u lo, hi;
@@ -88,6 +90,47 @@ struct HeightFieldGround {
         const float a = fmaf(fu, lo.y - lo.x, lo.x), b = fmaf(fu, hi.y - hi.x, hi.x);
         z = inside ? fmaf(fv, b - a, a) : f.outside_z;
         return inside;
+    }
+};
+
+// The same sampler with the four corner heights of each WHEEL's current cell kept in registers (lane form of the step kernels: one
+// lane = one env = four wheels).  A wheel moves <= 1.5 cm per 5 ms sub-step over 5 cm cells: its cell changes every few sub-steps,
+// so the two 8-byte gathers are re-issued only for the lanes whose wheel crossed a cell line -- a quarter of the lane addresses.
+// At large batches the lane-form step is bound by exactly those addresses (160 divergent gather instructions per env-step, each
+// 64 envs = 64 unrelated cache lines).  Same arithmetic on the same corners: bit-identical to HeightFieldGround.
+struct HeightFieldGroundCached {
+    static constexpr bool kFlat = false;
+    HeightFieldGround g;
+    mutable int cell[4];
+    mutable float h00[4], h10[4], h01[4], h11[4];
+    WL_DEV explicit HeightFieldGroundCached(const HeightFieldGround& g_) : g(g_) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) cell[w] = -1, h00[w] = h10[w] = h01[w] = h11[w] = 0.f;
+    }
+    template <int W>
+    WL_DEV void sample_wheel(float x, float y, float& z, V3& n) const {
+        const WlHeightField& f = g.f;
+        const float u = (x - f.x0) * g.inv_cell, v = (y - f.y0) * g.inv_cell;
+        const bool inside = u >= 0.f && v >= 0.f && u < (float)(f.nx - 1) && v < (float)(f.ny - 1);
+        const float uc = fminf(fmaxf(u, 0.f), (float)(f.nx - 1) - 1e-3f), vc = fminf(fmaxf(v, 0.f), (float)(f.ny - 1) - 1e-3f);
+        const float fi = floorf(uc), fj = floorf(vc);
+        const int k = (int)fj * f.nx + (int)fi;
+        const float fu = uc - fi, fv = vc - fj;
+        if (k != cell[W]) {       // per lane: only the lanes whose wheel changed cells gather
+            const float* row0 = f.height + k;
+            const wl_float2_u lo = *reinterpret_cast<const wl_float2_u*>(row0);
+            const wl_float2_u hi = *reinterpret_cast<const wl_float2_u*>(row0 + f.nx);
+            h00[W] = lo.x, h10[W] = lo.y, h01[W] = hi.x, h11[W] = hi.y;
+            cell[W] = k;
+        }
+        const float a00 = h00[W], a10 = h10[W], a01 = h01[W], a11 = h11[W];
+        const float a = fmaf(fu, a10 - a00, a00), b = fmaf(fu, a11 - a01, a01);
+        const float zz = fmaf(fv, b - a, a);
+        const float dzdx = fmaf(fv, (a11 - a01) - (a10 - a00), a10 - a00) * g.inv_cell;
+        const float dzdy = (b - a) * g.inv_cell;
+        const float inv_len = rsq(fmaf(dzdx, dzdx, fmaf(dzdy, dzdy, 1.f)));
+        z = inside ? zz : f.outside_z;
+        n = inside ? v3(-dzdx * inv_len, -dzdy * inv_len, inv_len) : v3(0.f, 0.f, 1.f);
     }
 };
 

@@ -92,6 +92,8 @@ struct FlatGround {
         zg = 0.f;
         n = v3(0.f, 0.f, 1.f);
     }
+    template <int W>     // W: the wheel slot of a lane (samplers that keep per-wheel state, wl_heightfield.h)
+    WL_DEV void sample_wheel(float x, float y, float& zg, V3& n) const { sample(x, y, zg, n); }
 };
 
 // by-value pick of this lane's element: the operands are SSA values, so the selection is three v_cndmask.  (Written as
@@ -218,7 +220,7 @@ struct Contact {
 };
 // On flat ground the sub-expressions shared by the wheels of an axle / a side (arm components, the partial sums of
 // vb + w_b x arm, the penetration) are written so that the compiler's CSE merges them across the inlined calls.
-template <class Ground>
+template <class Ground, int W = 0>
 WL_DEV Contact wheel_contact(const WlVehicleParams& vp, const VehDerived& vd, const Ground& ground, const Mat3& R, const VehState& s,
                              V3 vb, float bx, float by) {
     const float r = vp.wheel_radius;
@@ -232,7 +234,7 @@ WL_DEV Contact wheel_contact(const WlVehicleParams& vp, const VehDerived& vd, co
         const float cz = s.x.z + fmaf(R.r2.x, bx, fmaf(R.r2.y, by, R.r2.z * vd.zrel));
         float zg;
         V3 nw;
-        ground.sample(cx, cy, zg, nw);
+        ground.template sample_wheel<W>(cx, cy, zg, nw);
         c.pen = r - (cz - zg) * nw.z;
         c.n = mul_t(R, nw);
     }
@@ -247,11 +249,11 @@ struct Wrench {
     V3 F, T;
     float Fz;
 };
-template <class Ground, bool STEER, bool MOTOR, bool FIRST>
+template <class Ground, bool STEER, bool MOTOR, bool FIRST, int W = 0>
 WL_DEV void wheel_step(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Ground& ground, const Mat3& R,
                        const VehState& s, V3 vb, float bx, float by, float hc, float hs, float d, float inv_A0d, float wt,
                        float& w_spin, Wrench& w) {
-    const Contact c = wheel_contact(vp, vd, ground, R, s, vb, bx, by);
+    const Contact c = wheel_contact<Ground, W>(vp, vd, ground, R, s, vb, bx, by);
     const TyreCoef o = wheel_tyre<STEER, MOTOR>(vp, vd, ec, c.n, c.vc, c.pen, hc, hs, d, inv_A0d, wt, w_spin);
     const V3 F = tyre_force<STEER>(o.fx, o.fy, o.kz, c.n, hc, hs);
     const V3 t = cross(c.arm, F);
@@ -378,18 +380,18 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
         w.Fz = ar.Fz + af.Fz;
     } else if constexpr (LANES == 1) {
         const float ht = vp.half_track, bxr = -vp.half_wheelbase_r, bxf = vp.half_wheelbase_f;
-        wheel_step<Ground, false, true, true>(vp, vd, ec, ground, R, s, vb, bxr, ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
-                                              ec.wheel_target[0], s.wheel[0], w);
-        wheel_step<Ground, false, true, false>(vp, vd, ec, ground, R, s, vb, bxr, -ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
-                                               ec.wheel_target[1], s.wheel[1], w);
+        wheel_step<Ground, false, true, true, 0>(vp, vd, ec, ground, R, s, vb, bxr, ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
+                                                 ec.wheel_target[0], s.wheel[0], w);
+        wheel_step<Ground, false, true, false, 1>(vp, vd, ec, ground, R, s, vb, bxr, -ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
+                                                  ec.wheel_target[1], s.wheel[1], w);
         if (DRIVE == 1 || (DRIVE < 0 && vp.drive == 1)) {
-            wheel_step<Ground, true, true, false>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, ec.damp, ec.inv_A0_damp,
-                                                  ec.wheel_target[2], s.wheel[2], w);
-            wheel_step<Ground, true, true, false>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, ec.damp, ec.inv_A0_damp,
-                                                  ec.wheel_target[3], s.wheel[3], w);
+            wheel_step<Ground, true, true, false, 2>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, ec.damp, ec.inv_A0_damp,
+                                                     ec.wheel_target[2], s.wheel[2], w);
+            wheel_step<Ground, true, true, false, 3>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, ec.damp, ec.inv_A0_damp,
+                                                     ec.wheel_target[3], s.wheel[3], w);
         } else {
-            wheel_step<Ground, true, false, false>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[2], w);
-            wheel_step<Ground, true, false, false>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[3], w);
+            wheel_step<Ground, true, false, false, 2>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[2], w);
+            wheel_step<Ground, true, false, false, 3>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[3], w);
         }
     } else {
         const bool front = wid >= 2;

@@ -132,7 +132,15 @@ WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, co
             }
         };
         if constexpr (LANES == 4) fetch_bookkeeping();
-        vehicle_integrate<LANES, Ground>(vp, vd, ec, s, ground, wid);
+#ifndef WL_WHEEL_CORNER_CACHE
+#define WL_WHEEL_CORNER_CACHE 1
+#endif
+        if constexpr (LANES == 1 && !Ground::kFlat && WL_WHEEL_CORNER_CACHE) {   // lane form on a heightfield: see HeightFieldGroundCached
+            const HeightFieldGroundCached cached(ground);
+            vehicle_integrate<LANES, HeightFieldGroundCached>(vp, vd, ec, s, cached, wid);
+        } else {
+            vehicle_integrate<LANES, Ground>(vp, vd, ec, s, ground, wid);
+        }
         if constexpr (LANES != 4) {
             asm volatile("" ::: "memory");
             fetch_bookkeeping();
