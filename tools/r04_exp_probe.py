@@ -9,7 +9,7 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_variants", "lib_e*.so"))
     for n in (65536, 262144):
         env = ElevBatch(n, device="cuda:0", seed=42); env.reset(); env.set_lanes(1)
         res = {"build": os.path.basename(path), "n": n}
-        for name, fl in (("gather_stream", 8 | 1), ("gather_nostream", 8 | 2)):
+        for name, fl in (("lds_stream", 4 | 1), ("gather_stream", 8 | 1)):
             env.set_flags(fl)
             for _ in range(3): env.observe()
             torch.cuda.synchronize()

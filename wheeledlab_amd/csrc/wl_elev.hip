@@ -583,113 +583,95 @@ __global__ void __launch_bounds__(kScanThreads) elev_scan_kernel(const WlElevPar
 // branches -- 245 VALU + 216 SALU per wavefront, four wavefronts per env: SLOWER than the gathers at every size, 597 against
 // 502 us per observation launch at 262 144 envs: the scan is instruction-bound before it is address-rate-bound.)
 constexpr int kPatch = 74;               // grid points per side the bounding box can need (scan_size * sqrt 2 / cell + 3 must fit)
-constexpr int kPatchPitch = 80, kPatchRowsLds = 76;   // LDS: pitch 80 floats; 19 passes x 4 rows
-constexpr int kLdsScanThreads = 4 * kPatchPitch;
-// (Round 4, persistent blocks software-pipelined over their envs -- the patch rows of env k + 1 requested before the rays of env k
-// are evaluated: 746 us per launch at 262 144 envs against 483 for this block-per-env form.  1536 resident blocks fall into lock
-// step -- every block requests its rows at once, then every block computes -- and a fresh block per env desynchronises the CU's
-// six blocks for free.  Kept out.)
-// kLdsScanEnvs envs per block through the one LDS patch (the rows of all of them requested up front, the rays of env k evaluated
-// while the rows of env k + 1 are still landing).  Measured at 262 144 envs, us per observation launch: 1 env per block 483,
-// 2 envs per block 497, persistent blocks software-pipelined over ~170 envs 746 (1536 resident blocks fall into lock step), the
-// gather form 510 - 520; the launch without its stores 500, the stores alone 124.  Every form of the read side lands at ~1.9 ns per
-// env: what they share is ~20 KB per env (patch rows, or the cache lines under 1352 gathers) crossing from L2 to a CU -- 5 GB per
-// launch, 11 TB/s -- with a fresh, never re-used working set per block.  The LDS form is the cheapest way through that (7 - 10 %
-// under the gathers from 65 536 envs up) and stays the default there.
-constexpr int kLdsScanEnvs = 1;
+// LDS: pitch 80 floats = 20 sixteen-byte words per patch row; 320 threads = 16 patch rows per pass of 16-byte loads; 5 passes
+constexpr int kPatchPitch = 80, kPatchRowsLds = 80;
+constexpr int kLdsScanThreads = 320, kPatchRowsPerPass = kLdsScanThreads / (kPatchPitch / 4);
+static_assert(kPatchRowsPerPass * (kPatchPitch / 4) == kLdsScanThreads && kPatchRowsLds % kPatchRowsPerPass == 0, "whole rows per pass");
+// the 7 pose rows of env e (block-uniform address) by ONE lane per wavefront, broadcast with v_readfirstlane: the texture unit is
+// charged per lane address, and with five wavefronts per env the pose loads were 35 of the block's 133 full-width vector-memory
+// instructions.  (Through the scalar cache instead -- s_load_dword x 7 -- the launch is faster up to 16 384 envs, 12.6 against
+// 13.9 us at 4096, and TWICE as slow beyond, 911 against 483 us at 262 144: every block's seven lines miss the small scalar cache.)
+WL_DEV void load_pose_lane0(const Rows& S, int e, float (&v)[7]) {
+    float r[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    static_assert(WL_S_PX == 0 && WL_S_QZ == 6, "pose = rows 0 .. 6");
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) r[k] = S.ld(k, e);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r[k])));
+}
+// Block = one env.  Measured at 262 144 envs, us per observation launch (profiles/r04_scan_experiments.txt): dword staging (19
+// requests per thread) + pose rows by every lane 483; 16-byte staging (5 requests) + pose rows by one lane per wavefront 430
+// (133 -> 33 full-width vector-memory instructions per env); 2 envs per block 497; persistent blocks software-pipelined over ~170
+// envs 746 (1536 resident blocks fall into lock step); the gather form 510 - 520; the launch without its stores 500, the stores
+// alone 124; HALF of the staging lanes switched off (wrong results, probe only) 522 against 538: the L2 -> CU volume is not what
+// binds either.  What is left is occupancy x latency: a wavefront lives 1.9 us (0.47 of it waiting for its two dependent round
+// trips, pose rows then patch rows), 21 of them are resident per CU (LDS allows 30; short blocks leave slots idle between
+// launches), 30 % of its cycles issue instructions (the pose / frame / patch set-up is repeated by all five wavefronts).
 template <bool STREAM>
 __global__ void __launch_bounds__(kLdsScanThreads) elev_scan_lds_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
                                                                         float* __restrict__ obs) {
-    __shared__ float patch[kPatchPitch * kPatchRowsLds];
-    const int tid = threadIdx.x, n = b.n_envs;
-    const int e0 = blockIdx.x * kLdsScanEnvs;
-    const Rows S = make_rows(b.state, b.stride);
+    __shared__ __attribute__((aligned(16))) float patch[kPatchPitch * kPatchRowsLds];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    float pose[7];
+    load_pose_lane0(make_rows(b.state, b.stride), e, pose);
+    const float pz = pose[2];
+    float c, s;
+    yaw_cs(Quat{pose[3], pose[4], pose[5], pose[6]}, c, s);
     const WlHeightField& f = ground.f;
+    const ScanFrame fr = scan_frame(p, ground, ScanPose{pose[0], pose[1], pz, c, s});
+    // the patch: the lattice's bounding box in grid units (its corners are rays (0,0), (25,0), (0,25), (25,25)), the +1 corner
+    // of the last cell, a little slack for rounding.  Block-uniform values, kept in scalar registers.
+    constexpr float kSpan = (float)(WL_ELEV_SCAN_N - 1);
+    const float u_lo = fr.u0 + fminf(kSpan * fr.ux, 0.f) + fminf(kSpan * fr.uy, 0.f), v_lo = fr.v0 + fminf(kSpan * fr.vx, 0.f) + fminf(kSpan * fr.vy, 0.f);
+    const float v_hi = fr.v0 + fmaxf(kSpan * fr.vx, 0.f) + fmaxf(kSpan * fr.vy, 0.f);
+    const int i0 = __builtin_amdgcn_readfirstlane(min(max((int)floorf(u_lo - 0.02f), 0), f.nx - kPatchPitch));
+    const int j0 = __builtin_amdgcn_readfirstlane(min(max((int)floorf(v_lo - 0.02f), 0), f.ny - kPatch));
+    const int rows = __builtin_amdgcn_readfirstlane(min(max((int)floorf(v_hi + 0.02f) + 2 - j0, 1), kPatch));
+    // staging: 16 bytes per lane and request (4-byte aligned is enough), 16 patch rows per pass: a thread's 4-column group never
+    // changes and its row advances by 16 -- global offset = constant lane offset + a SCALAR pass offset, LDS address = constant +
+    // an immediate: no vector arithmetic per staged element.  Rows past the field's end read 0 through the buffer resource's
+    // bounds check (never used: rays there are misses).
     const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f.height), 0, f.nx * f.ny * 4, 0x00020000);
-    const int r0 = (int)(__umul24((unsigned)tid, 205u) >> 14);      // tid / 80 (tid < 320)
-    const int col = tid - r0 * kPatchPitch;
-    const int lane_off = ((int)__umul24((unsigned)r0, (unsigned)f.nx) + min(col, kPatch - 1)) * 4;   // columns 74 .. 79 duplicate column 73
-    const int pass_bytes = 4 * f.nx * 4;
-    constexpr int kPasses = kPatchRowsLds / 4;      // 19
-    constexpr int kAlways = 13;                     // 52 rows: the footprint itself at yaw 0
-    // pose rows of both envs first (one round trip for the block)
-    float pose[kLdsScanEnvs][7];
+    const int r0 = (int)(__umul24((unsigned)tid, 3277u) >> 16);      // tid / 20 (tid < 320)
+    const int c4 = tid - r0 * (kPatchPitch / 4);
+    const int lane_off = ((int)__umul24((unsigned)r0, (unsigned)f.nx) + 4 * c4) * 4;
+    const int origin = (j0 * f.nx + i0) * 4, pass_bytes = kPatchRowsPerPass * f.nx * 4;
+    constexpr int kPasses = kPatchRowsLds / kPatchRowsPerPass;      // 5
+    constexpr int kAlways = 4;                                      // 64 rows: the footprint at yaw 0 (52 rows) and a little beyond
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 stage[kPasses];
 #pragma unroll
-    for (int k = 0; k < kLdsScanEnvs; ++k) {
-        const int e = min(e0 + k, n - 1);
-        pose[k][0] = S.ld(WL_S_PX, e), pose[k][1] = S.ld(WL_S_PY, e), pose[k][2] = S.ld(WL_S_PZ, e);
-        pose[k][3] = S.ld(WL_S_QW, e), pose[k][4] = S.ld(WL_S_QX, e), pose[k][5] = S.ld(WL_S_QY, e), pose[k][6] = S.ld(WL_S_QZ, e);
-    }
-    ScanFrame fr[kLdsScanEnvs];
-    int i0[kLdsScanEnvs], j0[kLdsScanEnvs], rows[kLdsScanEnvs];
-    float stage[kLdsScanEnvs][kPasses];
+    for (int it = 0; it < kAlways; ++it) stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hr, lane_off, origin + it * pass_bytes, 0));
+    if (rows > kAlways * kPatchRowsPerPass)
+        stage[kAlways] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hr, lane_off, origin + kAlways * pass_bytes, 0));
+    f32x4* patch4 = reinterpret_cast<f32x4*>(patch);
 #pragma unroll
-    for (int k = 0; k < kLdsScanEnvs; ++k) {
-        float c, s;
-        yaw_cs(Quat{pose[k][3], pose[k][4], pose[k][5], pose[k][6]}, c, s);
-        fr[k] = scan_frame(p, ground, ScanPose{pose[k][0], pose[k][1], pose[k][2], c, s});
-        // the patch: the lattice's bounding box in grid units (its corners are rays (0,0), (25,0), (0,25), (25,25)), the +1 corner
-        // of the last cell, a little slack for rounding.  Block-uniform values, kept in scalar registers.
-        constexpr float kSpan = (float)(WL_ELEV_SCAN_N - 1);
-        const float u_lo = fr[k].u0 + fminf(kSpan * fr[k].ux, 0.f) + fminf(kSpan * fr[k].uy, 0.f);
-        const float v_lo = fr[k].v0 + fminf(kSpan * fr[k].vx, 0.f) + fminf(kSpan * fr[k].vy, 0.f);
-        const float v_hi = fr[k].v0 + fmaxf(kSpan * fr[k].vx, 0.f) + fmaxf(kSpan * fr[k].vy, 0.f);
-        i0[k] = __builtin_amdgcn_readfirstlane(min(max((int)floorf(u_lo - 0.02f), 0), f.nx - kPatch));
-        j0[k] = __builtin_amdgcn_readfirstlane(min(max((int)floorf(v_lo - 0.02f), 0), f.ny - kPatch));
-        rows[k] = __builtin_amdgcn_readfirstlane(min(max((int)floorf(v_hi + 0.02f) + 2 - j0[k], 1), kPatch));
-        // all requests of the patch at once; the pass count in three scalar steps (13 / 16 / 19 passes = 52 / 64 / 76 rows).  No
-        // vector arithmetic per element: the lane offset is constant, the pass goes into the scalar offset.
-        const int origin = (j0[k] * f.nx + i0[k]) * 4;
+    for (int it = 0; it < kAlways; ++it) patch4[tid + it * kLdsScanThreads] = stage[it];
+    if (rows > kAlways * kPatchRowsPerPass) patch4[tid + kAlways * kLdsScanThreads] = stage[kAlways];
+    __syncthreads();
+    if (tid < kScanQuads) {     // the first three wavefronts: one quad of rays per lane
+        float fx[4], fy[4];
+        scan_ray_xy(4 * tid, fx[0], fy[0]);
+        scan_ray_xy(4 * tid + 2, fx[2], fy[2]);
+        fx[1] = fx[0] + 1.f, fy[1] = fy[0], fx[3] = fx[2] + 1.f, fy[3] = fy[2];
+        ScanRay cr[4];
 #pragma unroll
-        for (int it = 0; it < kAlways; ++it) stage[k][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr, lane_off, origin + it * pass_bytes, 0));
-        if (rows[k] > 4 * kAlways) {
-#pragma unroll
-            for (int it = kAlways; it < 16; ++it) stage[k][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr, lane_off, origin + it * pass_bytes, 0));
-            if (rows[k] > 64) {
-#pragma unroll
-                for (int it = 16; it < kPasses; ++it) stage[k][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hr, lane_off, origin + it * pass_bytes, 0));
-            }
+        for (int m = 0; m < 4; ++m) {
+            const ScanCell cell = scan_cell(fr, f, fx[m], fy[m]);
+            // clamped (unsigned minimum: a negative offset wraps to the top and is clamped with everything else): a point the
+            // bounding box missed would read a wrong corner (the parity tests would show it), never out of bounds
+            const float* h = patch + min((unsigned)(cell.j - j0), (unsigned)(kPatchRowsLds - 2)) * kPatchPitch + min((unsigned)(cell.i - i0), (unsigned)(kPatchPitch - 2));
+            cr[m].lo.x = h[0], cr[m].lo.y = h[1], cr[m].hi.x = h[kPatchPitch], cr[m].hi.y = h[kPatchPitch + 1];
+            cr[m].fu = cell.fu, cr[m].fv = cell.fv, cr[m].inside = cell.inside;
         }
-    }
-    // this lane's quad of rays (the first three wavefronts evaluate rays): the same lattice coordinates for both envs
-    float fx[4], fy[4];
-    scan_ray_xy(4 * min(tid, kScanQuads - 1), fx[0], fy[0]);
-    scan_ray_xy(4 * min(tid, kScanQuads - 1) + 2, fx[2], fy[2]);
-    fx[1] = fx[0] + 1.f, fy[1] = fy[0], fx[3] = fx[2] + 1.f, fy[3] = fy[2];
-#pragma unroll
-    for (int k = 0; k < kLdsScanEnvs; ++k) {
-        if (k > 0) __syncthreads();       // every ray of the previous env has read the patch
-        // registers -> LDS: address = the thread's constant + an immediate
-#pragma unroll
-        for (int it = 0; it < kAlways; ++it) patch[tid + it * kLdsScanThreads] = stage[k][it];
-        if (rows[k] > 4 * kAlways) {
-#pragma unroll
-            for (int it = kAlways; it < 16; ++it) patch[tid + it * kLdsScanThreads] = stage[k][it];
-            if (rows[k] > 64) {
-#pragma unroll
-                for (int it = 16; it < kPasses; ++it) patch[tid + it * kLdsScanThreads] = stage[k][it];
-            }
-        }
-        __syncthreads();
-        if (tid < kScanQuads && e0 + k < n) {
-            ScanRay cr[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const ScanCell cell = scan_cell(fr[k], f, fx[m], fy[m]);
-                // clamped (unsigned minimum: a negative offset wraps to the top and is clamped with everything else): a point the
-                // bounding box missed would read a wrong corner (the parity tests would show it), never out of bounds
-                const float* h = patch + min((unsigned)(cell.j - j0[k]), (unsigned)(kPatchRowsLds - 2)) * kPatchPitch +
-                                 min((unsigned)(cell.i - i0[k]), (unsigned)(kPatchPitch - 2));
-                cr[m].lo.x = h[0], cr[m].lo.y = h[1], cr[m].hi.x = h[kPatchPitch], cr[m].hi.y = h[kPatchPitch + 1];
-                cr[m].fu = cell.fu, cr[m].fv = cell.fv, cr[m].inside = cell.inside;
-            }
-            scan_quad_store<STREAM>(obs + (int64_t)(e0 + k) * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, fr[k].pz));
-        }
+        scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, pz));
     }
 }
 // the staged patch must hold the footprint's bounding box at any yaw
 inline bool scan_patch_fits(const WlElevParams* p, const WlHeightField* hf) {
-    return hf->nx >= kPatch && hf->ny >= kPatch && p->scan_size * 1.41422f / hf->cell + 3.2f <= (float)kPatch;
+    return hf->nx >= kPatchPitch && hf->ny >= kPatch && p->scan_size * 1.41422f / hf->cell + 3.2f <= (float)kPatch;
 }
 // gather form while the chip is not full (every env's 128 lanes in flight at once: latency, not address rate, is what counts
 // there), LDS patches beyond; WL_FLAG_SCAN_LDS / WL_FLAG_SCAN_GATHER force one
@@ -700,9 +682,8 @@ inline void launch_elev_scan(const WlElevParams* p, const WlEnvBuffers* b, const
     const bool stream = use_streaming(b, (int64_t)b->n_envs * WL_ELEV_OBS_DIM * 4, 256ll << 20);
     const bool lds = scan_patch_fits(p, &g.f) && ((b->flags & WL_FLAG_SCAN_LDS) || (!(b->flags & WL_FLAG_SCAN_GATHER) && b->n_envs >= WL_SCAN_LDS_MIN_ENVS));
     if (lds) {
-        const int grid = (b->n_envs + kLdsScanEnvs - 1) / kLdsScanEnvs;
-        if (stream) elev_scan_lds_kernel<true><<<grid, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
-        else elev_scan_lds_kernel<false><<<grid, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
+        if (stream) elev_scan_lds_kernel<true><<<b->n_envs, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
+        else elev_scan_lds_kernel<false><<<b->n_envs, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
         return;
     }
     if (stream) elev_scan_kernel<true><<<b->n_envs, kScanThreads, 0, hs>>>(*p, *b, g, obs);

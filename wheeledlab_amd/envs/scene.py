@@ -217,12 +217,12 @@ class _CameraOutputs:
             raise KeyError(f"camera data type {key!r} is not rendered here (the fused observation carries the grey image)")
         d = self._d
         stamp = getattr(d._b, "step_count", None)
-        if d._cached[0] != stamp or stamp is None:
-            img = d._camera().render(d._b, d.far)
-            if d.beyond is not None:
-                img = torch.where(img >= d.far, torch.full_like(img, d.beyond), img)
-            d._cached = (stamp, img.unsqueeze(-1))
-        return d._cached[1]
+        if d._cached[0] != stamp or stamp is None:       # the render is cached per env step; what lies beyond the far plane is applied per read
+            d._cached = (stamp, d._camera().render(d._b, d.far))
+        img = d._cached[1]
+        if d.beyond is not None:
+            img = torch.where(img >= d.far, torch.full_like(img, d.beyond), img)
+        return img.unsqueeze(-1)
 
     def keys(self):
         return ["distance_to_image_plane"]
