@@ -601,34 +601,43 @@ WL_DEV void load_pose_lane0(const Rows& S, int e, float (&v)[7]) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r[k])));
 }
-// Block = one env.  Measured at 262 144 envs, us per observation launch (profiles/r04_scan_experiments.txt): dword staging (19
-// requests per thread) + pose rows by every lane 483; 16-byte staging (5 requests) + pose rows by one lane per wavefront 430
-// (133 -> 33 full-width vector-memory instructions per env); 2 envs per block 497; persistent blocks software-pipelined over ~170
-// envs 746 (1536 resident blocks fall into lock step); the gather form 510 - 520; the launch without its stores 500, the stores
-// alone 124; HALF of the staging lanes switched off (wrong results, probe only) 522 against 538: the L2 -> CU volume is not what
-// binds either.  What is left is occupancy x latency: a wavefront lives 1.9 us (0.47 of it waiting for its two dependent round
-// trips, pose rows then patch rows), 21 of them are resident per CU (LDS allows 30; short blocks leave slots idle between
-// launches), 30 % of its cycles issue instructions (the pose / frame / patch set-up is repeated by all five wavefronts).
+// Block = one env, five wavefronts.  Wavefront 0 alone fetches the pose rows and sets the env up (yaw, lattice frame, the patch's
+// origin and row count) and hands 10 words to the others through LDS: the launch is bound by the INSTRUCTIONS it issues, not by
+// what it moves or waits for (measured at 262 144 envs, us per observation launch, profiles/r04_scan_experiments.txt: half of the
+// staging lanes switched off 522 against 538; two / three envs per block with all their requests overlapped 442 / 572 against
+// 418), and with the set-up repeated by all five wavefronts it was a third of them.
+struct ScanSetup {      // what wavefront 0 publishes (40 bytes)
+    ScanFrame fr;
+    int origin, i0j0, rows;      // byte offset of the patch origin in the field; i0 | j0 << 16; patch rows needed
+};
 template <bool STREAM>
 __global__ void __launch_bounds__(kLdsScanThreads) elev_scan_lds_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
                                                                         float* __restrict__ obs) {
     __shared__ __attribute__((aligned(16))) float patch[kPatchPitch * kPatchRowsLds];
+    __shared__ __attribute__((aligned(16))) ScanSetup setup;
     const int e = blockIdx.x, tid = threadIdx.x;
-    float pose[7];
-    load_pose_lane0(make_rows(b.state, b.stride), e, pose);
-    const float pz = pose[2];
-    float c, s;
-    yaw_cs(Quat{pose[3], pose[4], pose[5], pose[6]}, c, s);
     const WlHeightField& f = ground.f;
-    const ScanFrame fr = scan_frame(p, ground, ScanPose{pose[0], pose[1], pz, c, s});
-    // the patch: the lattice's bounding box in grid units (its corners are rays (0,0), (25,0), (0,25), (25,25)), the +1 corner
-    // of the last cell, a little slack for rounding.  Block-uniform values, kept in scalar registers.
-    constexpr float kSpan = (float)(WL_ELEV_SCAN_N - 1);
-    const float u_lo = fr.u0 + fminf(kSpan * fr.ux, 0.f) + fminf(kSpan * fr.uy, 0.f), v_lo = fr.v0 + fminf(kSpan * fr.vx, 0.f) + fminf(kSpan * fr.vy, 0.f);
-    const float v_hi = fr.v0 + fmaxf(kSpan * fr.vx, 0.f) + fmaxf(kSpan * fr.vy, 0.f);
-    const int i0 = __builtin_amdgcn_readfirstlane(min(max((int)floorf(u_lo - 0.02f), 0), f.nx - kPatchPitch));
-    const int j0 = __builtin_amdgcn_readfirstlane(min(max((int)floorf(v_lo - 0.02f), 0), f.ny - kPatch));
-    const int rows = __builtin_amdgcn_readfirstlane(min(max((int)floorf(v_hi + 0.02f) + 2 - j0, 1), kPatch));
+    if (tid < 64) {
+        float pose[7];
+        load_pose_lane0(make_rows(b.state, b.stride), e, pose);
+        float c, s;
+        yaw_cs(Quat{pose[3], pose[4], pose[5], pose[6]}, c, s);
+        const ScanFrame fr = scan_frame(p, ground, ScanPose{pose[0], pose[1], pose[2], c, s});
+        // the patch: the lattice's bounding box in grid units (its corners are rays (0,0), (25,0), (0,25), (25,25)), the +1 corner
+        // of the last cell, a little slack for rounding
+        constexpr float kSpan = (float)(WL_ELEV_SCAN_N - 1);
+        const float u_lo = fr.u0 + fminf(kSpan * fr.ux, 0.f) + fminf(kSpan * fr.uy, 0.f), v_lo = fr.v0 + fminf(kSpan * fr.vx, 0.f) + fminf(kSpan * fr.vy, 0.f);
+        const float v_hi = fr.v0 + fmaxf(kSpan * fr.vx, 0.f) + fmaxf(kSpan * fr.vy, 0.f);
+        const int i0 = min(max((int)floorf(u_lo - 0.02f), 0), f.nx - kPatchPitch), j0 = min(max((int)floorf(v_lo - 0.02f), 0), f.ny - kPatch);
+        if (tid == 0) {
+            setup.fr = fr;
+            setup.origin = (j0 * f.nx + i0) * 4;
+            setup.i0j0 = i0 | (j0 << 16);
+            setup.rows = min(max((int)floorf(v_hi + 0.02f) + 2 - j0, 1), kPatch);
+        }
+    }
+    __syncthreads();
+    const int origin = __builtin_amdgcn_readfirstlane(setup.origin), rows = __builtin_amdgcn_readfirstlane(setup.rows);
     // staging: 16 bytes per lane and request (4-byte aligned is enough), 16 patch rows per pass: a thread's 4-column group never
     // changes and its row advances by 16 -- global offset = constant lane offset + a SCALAR pass offset, LDS address = constant +
     // an immediate: no vector arithmetic per staged element.  Rows past the field's end read 0 through the buffer resource's
@@ -637,9 +646,28 @@ __global__ void __launch_bounds__(kLdsScanThreads) elev_scan_lds_kernel(const Wl
     const int r0 = (int)(__umul24((unsigned)tid, 3277u) >> 16);      // tid / 20 (tid < 320)
     const int c4 = tid - r0 * (kPatchPitch / 4);
     const int lane_off = ((int)__umul24((unsigned)r0, (unsigned)f.nx) + 4 * c4) * 4;
-    const int origin = (j0 * f.nx + i0) * 4, pass_bytes = kPatchRowsPerPass * f.nx * 4;
+    const int pass_bytes = kPatchRowsPerPass * f.nx * 4;
     constexpr int kPasses = kPatchRowsLds / kPatchRowsPerPass;      // 5
     constexpr int kAlways = 4;                                      // 64 rows: the footprint at yaw 0 (52 rows) and a little beyond
+#ifndef WL_SCAN_LDS_DMA
+#define WL_SCAN_LDS_DMA 1
+#endif
+#if WL_SCAN_LDS_DMA
+    // straight into LDS (buffer_load_dwordx4 ... lds): a wavefront's 64 lanes land as 1 KB at its M0 base -- exactly this layout
+    // (consecutive threads = consecutive 16-byte words) -- with no staging registers and no ds_write (whose VGPR -> LDS transfer,
+    // 13 LDS cycles per 16-byte wave-instruction, was a quarter of the block's LDS time).  The compiler does not wait for LDS-DMA:
+    // vmcnt(0) by hand before the barrier that publishes the patch.
+    {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        float* wave_base = patch + (tid >> 6) * 256;
+#pragma unroll
+        for (int it = 0; it < kAlways; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(wave_base + it * kLdsScanThreads * 4), 16, lane_off, origin + it * pass_bytes, 0, 0);
+        if (rows > kAlways * kPatchRowsPerPass)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(wave_base + kAlways * kLdsScanThreads * 4), 16, lane_off, origin + kAlways * pass_bytes, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+    }
+#else
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 stage[kPasses];
 #pragma unroll
@@ -650,8 +678,11 @@ __global__ void __launch_bounds__(kLdsScanThreads) elev_scan_lds_kernel(const Wl
 #pragma unroll
     for (int it = 0; it < kAlways; ++it) patch4[tid + it * kLdsScanThreads] = stage[it];
     if (rows > kAlways * kPatchRowsPerPass) patch4[tid + kAlways * kLdsScanThreads] = stage[kAlways];
+#endif
     __syncthreads();
     if (tid < kScanQuads) {     // the first three wavefronts: one quad of rays per lane
+        const ScanFrame fr = setup.fr;
+        const int i0 = setup.i0j0 & 0xffff, j0 = setup.i0j0 >> 16;
         float fx[4], fy[4];
         scan_ray_xy(4 * tid, fx[0], fy[0]);
         scan_ray_xy(4 * tid + 2, fx[2], fy[2]);
@@ -666,7 +697,7 @@ __global__ void __launch_bounds__(kLdsScanThreads) elev_scan_lds_kernel(const Wl
             cr[m].lo.x = h[0], cr[m].lo.y = h[1], cr[m].hi.x = h[kPatchPitch], cr[m].hi.y = h[kPatchPitch + 1];
             cr[m].fu = cell.fu, cr[m].fv = cell.fv, cr[m].inside = cell.inside;
         }
-        scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, pz));
+        scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, fr.pz));
     }
 }
 // the staged patch must hold the footprint's bounding box at any yaw
