@@ -189,7 +189,7 @@ const char* wl_strerror(int code);
  *      4 tyre contacts (replaces PhysX)] -> time_out + cart_off_track (mushr_drift_env_cfg.py:343-362)
  *   -> 7 reward terms x weight x step_dt (:160-299) -> in-kernel reset along the track (drifting/mdp/events.py:102-133)
  *   -> interval pushes (:121-143) -> 14-dim noisy observation (common/observations.py:24-54).
- * `actions` is [n][2] row-major (device).  `noise` is NULL (in-kernel Philox4x32-10 keyed by (seed, env, step))
+ * `actions` is [n][2] row-major (device).  `noise` is NULL (in-kernel Philox4x32, 7 rounds (csrc/wl_rng.h), keyed by (seed, env, step))
  * or a device float[12][stride] of standard normals used instead (parity mode).
  * `step` is IsaacLab's common_step_counter BEFORE this step.
  */
@@ -722,7 +722,7 @@ typedef struct WlStartupParams {
 } WlStartupParams;
 int wl_startup_randomize(const WlStartupParams* su, const WlEnvBuffers* b, uint64_t seed, void* stream);
 
-/* Raw Philox4x32-10 uniforms as used in-kernel: out[4][n] for counter (env, step, stream_id). Test hook. */
+/* Raw Philox4x32 (7 rounds) uniforms, 24 bits of each word, as used in-kernel: out[4][n] for counter (env, step, stream_id). Test hook. */
 int wl_philox_uniform(int32_t n, uint64_t seed, uint64_t step, uint32_t stream_id, float* out, void* stream);
 
 #ifdef __cplusplus

@@ -29,7 +29,7 @@ def reset_envs(p, state, episode_len, ref_table, ids, seed, step, env_offset=0):
     if len(ids) == 0:
         return
     gid = np.asarray(ids) + env_offset
-    u = PH.uniform4(gid, step, PH.S_RESET, seed)
+    u = PH.uniform8(gid, step, PH.S_DRIFT_EVENTS, seed)    # [0..3] index, x, y, yaw | [4..5] timers | [6..7] the lf push's (step)
     n_ref = p.num_ref_points
     idx = np.minimum((u[0] * F(n_ref)).astype(np.int32), n_ref - 1)
     state[PX + 0, ids] = ref_table[0, idx] + (F(2) * u[1] - F(1)) * F(p.pos_noise)
@@ -44,9 +44,8 @@ def reset_envs(p, state, episode_len, ref_table, ids, seed, step, env_offset=0):
     state[ACT0:ACT0 + 2, ids] = 0
     state[EPSUM0:EPSUM0 + 8, ids] = 0
     episode_len[ids] = 0
-    t = PH.uniform4(gid, step, PH.S_TIMERS, seed)
-    state[TIMER_HF, ids] = F(p.hf_interval[0]) + t[0] * (F(p.hf_interval[1]) - F(p.hf_interval[0]))
-    state[TIMER_LF, ids] = F(p.lf_interval[0]) + t[1] * (F(p.lf_interval[1]) - F(p.lf_interval[0]))
+    state[TIMER_HF, ids] = F(p.hf_interval[0]) + u[4] * (F(p.hf_interval[1]) - F(p.hf_interval[0]))
+    state[TIMER_LF, ids] = F(p.lf_interval[0]) + u[5] * (F(p.lf_interval[1]) - F(p.lf_interval[0]))
 
 
 def observe(p, state, normals):
@@ -124,7 +123,7 @@ def step(p, state, episode_len, ref_table, actions, seed, step_count, metrics=No
         gid = np.arange(n) + env_offset
         state[TIMER_HF] -= step_dt
         fire = state[TIMER_HF] < F(1e-6)
-        u = PH.uniform4(gid, step_count, PH.S_PUSH_HF, seed)
+        u = PH.uniform8(gid, step_count, PH.S_NOISE1, seed)[4:]       # words z, w of the block whose x, y are normals 8..11
         sym = lambda uu, a: (F(2) * uu - F(1)) * F(a)
         state[VX] += np.where(fire, sym(u[0], p.hf_vel_x), F(0))
         state[VX + 1] += np.where(fire, sym(u[1], p.hf_vel_y), F(0))
@@ -133,7 +132,7 @@ def step(p, state, episode_len, ref_table, actions, seed, step_count, metrics=No
                                    state[TIMER_HF])
         state[TIMER_LF] -= step_dt
         fire = state[TIMER_LF] < F(1e-6)
-        u = PH.uniform4(gid, step_count, PH.S_PUSH_LF, seed)
+        u = PH.uniform8(gid, step_count, PH.S_DRIFT_EVENTS, seed)[6:]  # word w of the event block
         state[WX + 2] += np.where(fire, sym(u[0], p.lf_vel_yaw), F(0))
         state[TIMER_LF] = np.where(fire, F(p.lf_interval[0]) + u[1] * (F(p.lf_interval[1]) - F(p.lf_interval[0])),
                                    state[TIMER_LF])

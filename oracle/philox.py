@@ -1,5 +1,7 @@
-"""Philox4x32-10 counter RNG (Salmon et al., SC'11), numpy.  Mirrors the in-kernel generator bit for bit so that
-fused-step parity tests can include resets, pushes and observation noise.
+"""Philox4x32 counter RNG (Salmon et al., SC'11), numpy, ROUNDS rounds (7: the smallest Crush-resistant round count the paper
+reports for this width; wheeledlab_amd/csrc/wl_rng.h says why).  Mirrors the in-kernel generator bit for bit so that fused-step
+parity tests can include resets, pushes and observation noise.  The round function and key schedule are pinned against the
+published 10-round known answers through `rounds=10` (tests/test_oracle_golden_drift.py).
 key = (seed_lo, seed_hi); counter = (env_id, step_lo, step_hi, stream_id)."""
 import numpy as np
 
@@ -7,17 +9,18 @@ M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 W0, W1 = 0x9E3779B9, 0xBB67AE85
 MASK = np.uint64(0xFFFFFFFF)
 
-# stream ids (must match wl_rng.h)
-S_RESET, S_TIMERS, S_PUSH_HF, S_PUSH_LF, S_NOISE0 = 0, 1, 2, 3, 4
+ROUNDS = 7
+# stream ids (must match wl_rng.h); the drift step draws from S_DRIFT_EVENTS, S_NOISE0 and S_NOISE1 (layout: drift_draws below)
+S_RESET, S_DRIFT_EVENTS, S_TIMERS, S_PUSH_HF, S_PUSH_LF, S_NOISE0, S_NOISE1 = 0, 0, 1, 2, 3, 4, 5
 
 
-def philox4x32(env_ids, step, stream_id, seed):
+def philox4x32(env_ids, step, stream_id, seed, rounds=ROUNDS):
     c0 = np.asarray(env_ids, dtype=np.uint64) & MASK
     c1 = np.full_like(c0, np.uint64(step & 0xFFFFFFFF))
     c2 = np.full_like(c0, np.uint64((step >> 32) & 0xFFFFFFFF))
     c3 = np.full_like(c0, np.uint64(stream_id))
     k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = M0 * c0
         p1 = M1 * c2
         hi0, lo0 = p0 >> np.uint64(32), p0 & MASK
@@ -34,13 +37,28 @@ def uniform4(env_ids, step, stream_id, seed):
     return ((x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
 
 
+def uniform8(env_ids, step, stream_id, seed):
+    """eight 16-bit uniforms per block, (h + 1/2) / 65536 in (0, 1): index 2k = low half of word k, 2k + 1 = its high half
+    (wl_rng.h u16_lo / u16_hi) -> float32 [8, n]"""
+    x = philox4x32(env_ids, step, stream_id, seed)
+    lo, hi = (x & np.uint32(0xFFFF)).astype(np.float32), (x >> np.uint32(16)).astype(np.float32)
+    h = np.stack([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]])
+    return (h * np.float32(2.0 ** -16) + np.float32(2.0 ** -17)).astype(np.float32)
+
+
+def _pair(u0, u1):
+    r = np.sqrt(np.float32(-2.0) * np.log(u0)).astype(np.float32)
+    th = np.float32(2.0 * np.pi) * u1
+    return [r * np.cos(th), r * np.sin(th)]
+
+
 def normal12(env_ids, step, seed):
-    """12 standard normals per env from streams S_NOISE0..+2 via Box-Muller -> float32 [12, n]"""
+    """12 standard normals per env: one Box-Muller pair per word (radius from the low half, angle from the high half) of the four
+    words of stream S_NOISE0 and the first two of S_NOISE1 (wl_drift_env.h obs_noise) -> float32 [12, n]"""
+    a, b = uniform8(env_ids, step, S_NOISE0, seed), uniform8(env_ids, step, S_NOISE1, seed)
     out = []
-    for s in range(3):
-        u = uniform4(env_ids, step, S_NOISE0 + s, seed)
-        for j in (0, 2):
-            r = np.sqrt(np.float32(-2.0) * np.log(np.float32(1.0) - u[j])).astype(np.float32)
-            th = np.float32(2.0 * np.pi) * u[j + 1]
-            out += [r * np.cos(th), r * np.sin(th)]
+    for k in range(4):
+        out += _pair(a[2 * k], a[2 * k + 1])
+    for k in range(2):
+        out += _pair(b[2 * k], b[2 * k + 1])
     return np.stack(out).astype(np.float32)

@@ -109,13 +109,15 @@ def test_math_self_consistency():
 
 
 def test_philox_known_answers():
-    """Philox4x32-10 (the keyed generator of every random draw; the HIP kernels are bit-exact to this oracle,
-    tests/test_gpu_drift_parity.py::test_philox_bit_exact) against the three known-answer vectors of the Random123
-    distribution (kat_vectors: counter / key all zero, all ones, and the digits of pi)"""
+    """Philox4x32 (the keyed generator of every random draw; the HIP kernels are bit-exact to this oracle,
+    tests/test_gpu_drift_parity.py::test_philox_bit_exact): the round function and the key schedule at TEN rounds against the three
+    known-answer vectors of the Random123 distribution (kat_vectors: counter / key all zero, all ones, and the digits of pi).  The
+    draws use the first ROUNDS = 7 of the same rounds (the paper's smallest Crush-resistant count for this width)."""
     from oracle import philox as PH
+    assert PH.ROUNDS == 7
 
     def run(c, k):   # counter = (env, step low, step high, stream), key = (seed low, seed high)
-        out = PH.philox4x32(np.array([c[0]]), c[1] | (c[2] << 32), c[3], k[0] | (k[1] << 32))
+        out = PH.philox4x32(np.array([c[0]]), c[1] | (c[2] << 32), c[3], k[0] | (k[1] << 32), rounds=10)
         return [int(v) for v in out[:, 0]]
     assert run((0, 0, 0, 0), (0, 0)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
     assert run((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
@@ -132,6 +134,9 @@ def test_noise_draws_are_uniform_and_standard_normal():
     from oracle import philox as PH
     u = PH.uniform4(np.arange(50000), 5, 0, 42).reshape(-1)
     assert u.min() >= 0.0 and u.max() < 1.0 and stats.kstest(u, "uniform").pvalue > 1e-3
+    u8 = PH.uniform8(np.arange(25000), 5, 0, 42)                   # the 16-bit draws of the drift step: open interval, halves independent
+    assert u8.min() >= 2.0 ** -17 and u8.max() <= 1.0 - 2.0 ** -17 and stats.kstest(u8.reshape(-1), "uniform").pvalue > 1e-3
+    assert np.abs(np.corrcoef(u8) - np.eye(8)).max() < 0.03
     z = PH.normal12(np.arange(20000), 7, 42)                       # [12, n]: the 12 observation-noise normals per env
     assert stats.kstest(z.reshape(-1), "norm").pvalue > 1e-3
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01

@@ -25,10 +25,13 @@ struct ResetDraw {
     float timer_hf, timer_lf;
 };
 
-// reset_root_state_along_track.__call__ (drifting/mdp/events.py:119-133) + EventManager.reset interval re-arm
-WL_DEV ResetDraw draw_reset(const WlDriftParams& p, const float* __restrict__ ref, uint32_t gid, uint64_t step,
-                            uint64_t seed) {
-    const F4 u = philox_uniform4(gid, step, WL_RS_RESET, seed);
+// The drift step's draws, three Philox blocks of eight 16-bit uniforms each (wl_rng.h; round 3: six blocks of four 24-bit ones):
+//   WL_RS_DRIFT_EVENTS  x: reference-pose index | x offset   y: y offset | yaw offset   z: re-armed hf | lf timer   w: lf push yaw kick | lf timer
+//   WL_RS_NOISE0        x y z w: observation normals 0..7 (one Box-Muller pair per word: radius from the low half, angle from the high half)
+//   WL_RS_NOISE1        x y: normals 8..11                                                 z: hf push dvx | dvy   w: hf push yaw kick | hf timer
+// reset_root_state_along_track.__call__ (drifting/mdp/events.py:119-133) + EventManager.reset interval re-arm, from the event block's
+// words x, y, z
+WL_DEV ResetDraw reset_from_uniforms(const WlDriftParams& p, const float* __restrict__ ref, F4 u /* halves of x, y */, float t_hf, float t_lf) {
     const int idx = min((int)(u.x * (float)p.num_ref_points), p.num_ref_points - 1);
     ResetDraw r;
     r.pos = v3(fmaf(2.f * u.y - 1.f, p.pos_noise, ref[idx]), fmaf(2.f * u.z - 1.f, p.pos_noise, ref[32 + idx]), 0.f);
@@ -37,10 +40,15 @@ WL_DEV ResetDraw draw_reset(const WlDriftParams& p, const float* __restrict__ re
     sincos_fast(0.5f * yaw, s, c);
     r.q = Quat{c, 0.f, 0.f, s};
     r.yaw = yaw;
-    const F4 t = philox_uniform4(gid, step, WL_RS_TIMERS, seed);
-    r.timer_hf = fmaf(t.x, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
-    r.timer_lf = fmaf(t.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
+    r.timer_hf = fmaf(t_hf, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
+    r.timer_lf = fmaf(t_lf, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
     return r;
+}
+WL_DEV ResetDraw reset_from_block(const WlDriftParams& p, const float* __restrict__ ref, const U4& ev) {
+    return reset_from_uniforms(p, ref, u16x4(ev.x, ev.y), u16_lo(ev.z), u16_hi(ev.z));
+}
+WL_DEV ResetDraw draw_reset(const WlDriftParams& p, const float* __restrict__ ref, uint32_t gid, uint64_t step, uint64_t seed) {
+    return reset_from_block(p, ref, philox_block(gid, step, WL_RS_DRIFT_EVENTS, seed));
 }
 
 // BlindObsCfg.PolicyCfg (wheeledlab_tasks/common/observations.py:24-54) into this wave's LDS tile
@@ -74,20 +82,24 @@ WL_DEV void write_obs_row(float* row, const WlDriftParams& p, V3 pos, V3 e /* eu
     row[13] = clampf(a1, -1.f, 1.f);
 }
 
-// quad form: lane w < 3 holds normals 4w .. 4w+3; every lane of the quad gets all twelve via DPP quad broadcasts
+// quad form: lanes 0, 3, 1 hold normals 0..3, 4..7, 8..11 (draw_step_raw); every lane of the quad gets all twelve via DPP quad broadcasts
 WL_DEV Noise12 gather_quad_noise(const float z[4]) {
     Noise12 nz;
     nz.z[0] = quad_bcast<0>(z[0]); nz.z[1] = quad_bcast<0>(z[1]); nz.z[2] = quad_bcast<0>(z[2]); nz.z[3] = quad_bcast<0>(z[3]);
-    nz.z[4] = quad_bcast<1>(z[0]); nz.z[5] = quad_bcast<1>(z[1]); nz.z[6] = quad_bcast<1>(z[2]); nz.z[7] = quad_bcast<1>(z[3]);
-    nz.z[8] = quad_bcast<2>(z[0]); nz.z[9] = quad_bcast<2>(z[1]); nz.z[10] = quad_bcast<2>(z[2]); nz.z[11] = quad_bcast<2>(z[3]);
+    nz.z[4] = quad_bcast<3>(z[0]); nz.z[5] = quad_bcast<3>(z[1]); nz.z[6] = quad_bcast<3>(z[2]); nz.z[7] = quad_bcast<3>(z[3]);
+    nz.z[8] = quad_bcast<1>(z[0]); nz.z[9] = quad_bcast<1>(z[1]); nz.z[10] = quad_bcast<1>(z[2]); nz.z[11] = quad_bcast<1>(z[3]);
     return nz;
 }
 
-// observation noise: off, the caller's parity tensor, or (lane form) three Philox blocks -> 12 normals.  The quad form
-// draws its normals in draw_step (one block per lane) and gathers them with gather_quad_noise.
+// one word -> two standard normals
+WL_DEV void normals_of_word(uint32_t w, float& z0, float& z1) { box_muller_open(u16_lo(w), u16_hi(w), z0, z1); }
+
+// observation noise: off, the caller's parity tensor, or (lane form) two Philox blocks -> 12 normals; `nb` = the WL_RS_NOISE1 block when
+// the caller has drawn it already (the step draws it once for the hf push and the noise).  The quad form draws its normals in
+// draw_step (one block per lane) and gathers them with gather_quad_noise.
 template <int LANES>
 WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise, int64_t stride, int e, uint32_t gid,
-                         uint64_t step, uint64_t seed, int wid = 0) {
+                         uint64_t step, uint64_t seed, const U4* nb = nullptr) {
     Noise12 nz;
     if (!p.enable_corruption) {
 #pragma unroll
@@ -96,12 +108,14 @@ WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise
 #pragma unroll
         for (int k = 0; k < 12; ++k) nz.z[k] = noise[k * stride + e];
     } else {
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const F4 u = philox_uniform4(gid, step, WL_RS_NOISE0 + s, seed);
-            box_muller(u.x, u.y, nz.z[4 * s + 0], nz.z[4 * s + 1]);
-            box_muller(u.z, u.w, nz.z[4 * s + 2], nz.z[4 * s + 3]);
-        }
+        const U4 na = philox_block(gid, step, WL_RS_NOISE0, seed);
+        const U4 n1 = nb ? *nb : philox_block(gid, step, WL_RS_NOISE1, seed);
+        normals_of_word(na.x, nz.z[0], nz.z[1]);
+        normals_of_word(na.y, nz.z[2], nz.z[3]);
+        normals_of_word(na.z, nz.z[4], nz.z[5]);
+        normals_of_word(na.w, nz.z[6], nz.z[7]);
+        normals_of_word(n1.x, nz.z[8], nz.z[9]);
+        normals_of_word(n1.y, nz.z[10], nz.z[11]);
     }
     return nz;
 }
@@ -111,34 +125,38 @@ WL_DEV Noise12 obs_noise(const WlDriftParams& p, const float* __restrict__ noise
 // matrix -- instead of lazily in the reset / push branches on the tail, where each draw is a dependent chain of ~100
 // instructions on the kernel's critical path (the kernel ends with its slowest wavefront, and with 16 envs per
 // wavefront nearly every step some wavefront resets and most have a push).  The draws are SPREAD over the quad: lane w
-// computes ONE event block, Philox stream w (WL_RS_RESET, WL_RS_TIMERS, WL_RS_PUSH_HF, WL_RS_PUSH_LF == 0 .. 3), and
-// one observation-noise block (stream 4 + min(w, 2)) -- two Philox blocks per lane where round 1 had five -- and the
-// branch that needs an event pulls it from its lane with DPP quad broadcasts (the branch conditions are functions of
-// the replicated env state, so a quad is always wholly inside or outside a branch).
+// computes ONE Philox block -- lane 0 WL_RS_NOISE0, lane 1 WL_RS_NOISE1, lane 2 WL_RS_DRIFT_EVENTS, lane 3 WL_RS_NOISE0 again (its
+// words z, w become normals 4..7) -- where round 3 had two per lane and round 1 five, and the branch that needs an event pulls it
+// from its lane with DPP quad broadcasts (the branch conditions are functions of the replicated env state, so a quad is always
+// wholly inside or outside a branch).
 struct StepDraws {
-    F4 ev;               // this lane's event block: lane 0 reset pose, lane 1 re-armed timers, lane 2 hf push, lane 3 lf push
-    float ref[3];        // the reference pose (x, y, yaw) lane 0's reset would start from (ref_pose_request)
-    float z[4];          // this lane's four observation-noise normals (lanes 0..2 of the quad; see gather_quad_noise)
+    F4 e0, e1;           // the halves of this lane's words (x, y) and (z, w) as uniforms: lane 1's e1 = hf push, lane 2's e0 / e1 = reset / timers + lf push
+    float ref[3];        // the reference pose (x, y, yaw) lane 2's reset would start from (ref_pose_request)
+    float z[4];          // this lane's four observation-noise normals (lanes 0, 3, 1 of the quad; see gather_quad_noise)
 };
 
 // first half: needs nothing but the key (preloaded kernel arguments): it runs while BOTH the state rows and the parameter
 // block are still in flight
 WL_DEV StepDraws draw_step_raw(uint32_t gid, uint64_t step, uint64_t seed, int wid) {
     StepDraws d;
-    d.ev = philox_uniform4(gid, step, (uint32_t)wid, seed);
-    const F4 n = philox_uniform4(gid, step, WL_RS_NOISE0 + (uint32_t)min(wid, 2), seed);
-    box_muller(n.x, n.y, d.z[0], d.z[1]);
-    box_muller(n.z, n.w, d.z[2], d.z[3]);
+    const uint32_t stream = wid == 1 ? (uint32_t)WL_RS_NOISE1 : wid == 2 ? (uint32_t)WL_RS_DRIFT_EVENTS : (uint32_t)WL_RS_NOISE0;
+    const U4 w = philox_block(gid, step, stream, seed);
+    d.e0 = u16x4(w.x, w.y);
+    d.e1 = u16x4(w.z, w.w);
+    const bool hi = wid == 3;
+    box_muller_open(hi ? d.e1.x : d.e0.x, hi ? d.e1.y : d.e0.y, d.z[0], d.z[1]);
+    box_muller_open(hi ? d.e1.z : d.e0.z, hi ? d.e1.w : d.e0.w, d.z[2], d.z[3]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) d.z[k] = opaque(d.z[k]);   // computed HERE, not sunk to the observation code on the tail
-    d.ev.x = opaque(d.ev.x), d.ev.y = opaque(d.ev.y), d.ev.z = opaque(d.ev.z), d.ev.w = opaque(d.ev.w);
+    d.e0.x = opaque(d.e0.x), d.e0.y = opaque(d.e0.y), d.e0.z = opaque(d.e0.z), d.e0.w = opaque(d.e0.w);
+    d.e1.x = opaque(d.e1.x), d.e1.y = opaque(d.e1.y), d.e1.z = opaque(d.e1.z), d.e1.w = opaque(d.e1.w);
     d.ref[0] = d.ref[1] = d.ref[2] = 0.f;
     return d;
 }
 // the reference-pose lookup is a dependent memory round trip: requested as soon as the pose count is known, consumed
-// only inside the reset branch (every lane looks up ITS block's index; lane 0's is the one that counts)
+// only inside the reset branch (every lane looks up ITS block's index; lane 2's is the one that counts)
 WL_DEV void ref_pose_request(StepDraws& d, const float* __restrict__ ref, int num_ref) {
-    const int idx = min((int)(d.ev.x * (float)num_ref), num_ref - 1);
+    const int idx = min((int)(d.e0.x * (float)num_ref), num_ref - 1);
     d.ref[0] = ref[idx], d.ref[1] = ref[32 + idx], d.ref[2] = ref[64 + idx];
 }
 WL_DEV StepDraws draw_step(const WlDriftParams& p, const float* __restrict__ ref, uint32_t gid, uint64_t step, uint64_t seed,
@@ -147,24 +165,23 @@ WL_DEV StepDraws draw_step(const WlDriftParams& p, const float* __restrict__ ref
     ref_pose_request(d, ref, p.num_ref_points);
     return d;
 }
-// the events of the quad, pulled from the lanes that drew them (called inside the reset branch: a quad is always wholly
+// the events of the quad, pulled from the lane that drew them (called inside the reset branch: a quad is always wholly
 // inside or outside it, the branch conditions being functions of the replicated env state)
 WL_DEV ResetDraw quad_reset_draw(const WlDriftParams& p, const StepDraws& d) {
     ResetDraw r;
-    // reset_root_state_along_track.__call__ (drifting/mdp/events.py:119-133) on lane 0's block, timers on lane 1's
-    r.pos = v3(quad_bcast<0>(fmaf(2.f * d.ev.y - 1.f, p.pos_noise, d.ref[0])), quad_bcast<0>(fmaf(2.f * d.ev.z - 1.f, p.pos_noise, d.ref[1])), 0.f);
-    r.yaw = quad_bcast<0>(fmaf(2.f * d.ev.w - 1.f, p.yaw_noise, d.ref[2]));
+    // reset_root_state_along_track.__call__ (drifting/mdp/events.py:119-133) on lane 2's block (same arithmetic as reset_from_uniforms)
+    r.pos = v3(quad_bcast<2>(fmaf(2.f * d.e0.y - 1.f, p.pos_noise, d.ref[0])), quad_bcast<2>(fmaf(2.f * d.e0.z - 1.f, p.pos_noise, d.ref[1])), 0.f);
+    r.yaw = quad_bcast<2>(fmaf(2.f * d.e0.w - 1.f, p.yaw_noise, d.ref[2]));
     float s, c;
     sincos_fast(0.5f * r.yaw, s, c);
     r.q = Quat{c, 0.f, 0.f, s};
-    r.timer_hf = quad_bcast<1>(fmaf(d.ev.x, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]));
-    r.timer_lf = quad_bcast<1>(fmaf(d.ev.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]));
+    r.timer_hf = quad_bcast<2>(fmaf(d.e1.x, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]));
+    r.timer_lf = quad_bcast<2>(fmaf(d.e1.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]));
     return r;
 }
-template <int K>
-WL_DEV F4 quad_event(const StepDraws& d) {
-    return F4{quad_bcast<K>(d.ev.x), quad_bcast<K>(d.ev.y), quad_bcast<K>(d.ev.z), quad_bcast<K>(d.ev.w)};
-}
+// the hf push's four uniforms (lane 1, words z w) / the lf push's two (lane 2, word w)
+WL_DEV F4 quad_hf_draw(const StepDraws& d) { return F4{quad_bcast<1>(d.e1.x), quad_bcast<1>(d.e1.y), quad_bcast<1>(d.e1.z), quad_bcast<1>(d.e1.w)}; }
+WL_DEV void quad_lf_draw(const StepDraws& d, float& kick, float& timer) { kick = quad_bcast<2>(d.e1.z), timer = quad_bcast<2>(d.e1.w); }
 
 // flush a tile of `n_slots` obs rows ([slot][kObsPad], row-padded) to obs[n][14]: contiguous dword stores
 WL_DEV void flush_obs(const float* tile, float* __restrict__ obs, int block_env0, int n, int envs_per_block = kBlock) {
@@ -430,7 +447,15 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
     Mat3 Ro = R;
     V3 wb_o = s.wb;
     float a0 = a.x, a1 = a.y, timer_hf = r.timer_hf, timer_lf = r.timer_lf;
-    if (terminated || truncated) {
+    // lane form: the event block serves the reset (words x, y, z) and the lf push (w): drawn once, by the wavefronts with a lane that
+    // needs either (a lane that resets re-arms its lf timer from the same block, so `lf_due` on the old timer covers every use)
+    U4 ev = U4{0u, 0u, 0u, 0u};
+    const float lf_next = timer_lf - step_dt;     // ONE value for the draw condition and the push below (a re-contracted copy could differ in the last bit)
+    const bool done = terminated || truncated;
+    if constexpr (LANES == 1) {
+        if (done || (p.enable_pushes && lf_next < 1e-6f)) ev = philox_block(gid, step, WL_RS_DRIFT_EVENTS, seed);
+    }
+    if (done) {
         if (lead) {
 #pragma unroll
             for (int i = 0; i < WL_DR_NTERMS; ++i) ms.add(WL_M_EPSUM0 + i, epsum[i]);
@@ -449,7 +474,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         }
         ResetDraw rd;
         if constexpr (LANES == 4) rd = quad_reset_draw(p, *pre);
-        else rd = draw_reset(p, b.ref_poses, gid, step, seed);
+        else rd = reset_from_block(p, b.ref_poses, ev);
         pos = rd.pos;
         s.q = rd.q;
         if constexpr (LANES == 4) euler = v3(0.f, 0.f, rd.yaw - WL_TWO_PI * floorf(rd.yaw * WL_INV_TWO_PI));
@@ -466,12 +491,22 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
         a0 = a1 = 0.f;  // ActionManager.reset zeroes `action` (last_action) of reset envs
     }
     // ---- interval events: push_by_setting_velocity (mushr_drift_env_cfg.py:121-143) ----
+    bool hf_due = false;
     if (p.enable_pushes) {
         timer_hf -= step_dt;
-        if (timer_hf < 1e-6f) {
+        hf_due = timer_hf < 1e-6f;
+    }
+    // lane form: the WL_RS_NOISE1 block serves the hf push (words z, w) and the last four observation normals (x, y): drawn once, here
+    U4 nb = U4{0u, 0u, 0u, 0u};
+    const bool draw_noise = p.enable_corruption && !noise;
+    if constexpr (LANES == 1) {
+        if (draw_noise || hf_due) nb = philox_block(gid, step, WL_RS_NOISE1, seed);
+    }
+    if (p.enable_pushes) {
+        if (hf_due) {
             F4 u;
-            if constexpr (LANES == 4) u = quad_event<2>(*pre);
-            else u = philox_uniform4(gid, step, WL_RS_PUSH_HF, seed);
+            if constexpr (LANES == 4) u = quad_hf_draw(*pre);
+            else u = u16x4(nb.z, nb.w);
             const float dvx = (2.f * u.x - 1.f) * p.hf_vel_x, dvy = (2.f * u.y - 1.f) * p.hf_vel_y, dwz = (2.f * u.z - 1.f) * p.hf_vel_yaw;
             s.v.x += dvx;
             s.v.y += dvy;
@@ -481,15 +516,15 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
             wb_o = fma3(dwz, Ro.r2, wb_o);
             timer_hf = fmaf(u.w, p.hf_interval[1] - p.hf_interval[0], p.hf_interval[0]);
         }
-        timer_lf -= step_dt;
-        if (timer_lf < 1e-6f) {
-            F4 u;
-            if constexpr (LANES == 4) u = quad_event<3>(*pre);
-            else u = philox_uniform4(gid, step, WL_RS_PUSH_LF, seed);
-            const float dwz = (2.f * u.x - 1.f) * p.lf_vel_yaw;
+        timer_lf = done ? timer_lf - step_dt : lf_next;
+        if (timer_lf < 1e-6f) {     // (lane form: `ev` was drawn for this lane -- it reset, or the condition above saw the same value)
+            float uk, ut;
+            if constexpr (LANES == 4) quad_lf_draw(*pre, uk, ut);
+            else uk = u16_lo(ev.w), ut = u16_hi(ev.w);
+            const float dwz = (2.f * uk - 1.f) * p.lf_vel_yaw;
             ww.z += dwz;
             wb_o = fma3(dwz, Ro.r2, wb_o);
-            timer_lf = fmaf(u.y, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
+            timer_lf = fmaf(ut, p.lf_interval[1] - p.lf_interval[0], p.lf_interval[0]);
         }
     }
     // ---- back to memory form ----
@@ -525,7 +560,7 @@ WL_DEV void drift_env_step(const WlDriftParams& p, const WlEnvBuffers& b, const 
             drawn = true;
         }
     }
-    if (!drawn) nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, wid);   // off / parity tensor / lane form
+    if (!drawn) nz = obs_noise<LANES>(p, noise, b.stride, e, gid, step, seed, LANES == 1 ? &nb : nullptr);   // off / parity tensor / lane form
     if constexpr (LANES == 1) euler = euler_xyz_from_quat(s.q);
     if constexpr (LANES == 4) {
         // quad form: the 14 values are replicated on the quad's lanes; a caller that feeds them to a policy in the
