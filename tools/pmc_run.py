@@ -17,6 +17,9 @@ n, K = int(argv[0]), int(argv[1])
 lanes = int(argv[2]) if len(argv) > 2 else 0
 flags = int(os.environ.get("WL_FLAGS", "0"))     # WlEnvBuffers.flags: force an instantiation (round 4: scan forms, streaming)
 dev = "cuda:0"
+if os.environ.get("WL_LIB"):     # a variant build of the library (tools/build_variants.sh)
+    from wheeledlab_amd import _abi as _A
+    _A.load(os.environ["WL_LIB"])
 if task == "drift":
     env = DriftBatch(n, device=dev, seed=42)
     env.reset()

@@ -244,6 +244,9 @@ WL_DEV wl_float4_u scan_quad_value(const WlElevParams& p, const ScanRay (&r)[4],
     v.x = scan_value(p, r[0], pz), v.y = scan_value(p, r[1], pz), v.z = scan_value(p, r[2], pz), v.w = scan_value(p, r[3], pz);
     return v;
 }
+#ifndef WL_FUSED_SCAN_NT
+#define WL_FUSED_SCAN_NT true     // the fused step + scan launches' map rows as non-temporal stores (round 4, 4096 envs: 25.6 -> 24.7 us per step)
+#endif
 template <bool STREAM>
 WL_DEV void scan_quad_store(float* __restrict__ row_map /* obs row + 13 */, int q, wl_float4_u v) {
     wl_float4_u* dst = reinterpret_cast<wl_float4_u*>(row_map + 4 * q);
@@ -709,8 +712,16 @@ inline bool scan_patch_fits(const WlElevParams* p, const WlHeightField* hf) {
 #ifndef WL_SCAN_LDS_MIN_ENVS
 #define WL_SCAN_LDS_MIN_ENVS 16384
 #endif
+#ifndef WL_ELEV_FUSED_MAX_ENVS
+#define WL_ELEV_FUSED_MAX_ENVS 8192
+#endif
+#ifndef WL_ELEV_STREAM_BYTES
+#define WL_ELEV_STREAM_BYTES 0ll
+#endif
 inline void launch_elev_scan(const WlElevParams* p, const WlEnvBuffers* b, const HeightFieldGround& g, float* obs, hipStream_t hs) {
-    const bool stream = use_streaming(b, (int64_t)b->n_envs * WL_ELEV_OBS_DIM * 4, 256ll << 20);
+    // non-temporal map rows at every size unless WL_FLAG_NO_STREAM asks otherwise (round 4: 2 - 3 % of the step from 4096 envs up; the rows
+    // are not read again by this launch, and an XCD's L2 does not survive the launch boundary anyway)
+    const bool stream = use_streaming(b, (int64_t)b->n_envs * WL_ELEV_OBS_DIM * 4, WL_ELEV_STREAM_BYTES);
     const bool lds = scan_patch_fits(p, &g.f) && ((b->flags & WL_FLAG_SCAN_LDS) || (!(b->flags & WL_FLAG_SCAN_GATHER) && b->n_envs >= WL_SCAN_LDS_MIN_ENVS));
     if (lds) {
         if (stream) elev_scan_lds_kernel<true><<<b->n_envs, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
@@ -926,7 +937,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
             const int idx = tid + (half * kBatch + i) * kFusedThreads;
             int j, q;
             scan_quad_slot(idx, j, q);
-            if (idx < kAll && j < n_here) scan_quad_store<false>(out.obs + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], pz[i]));
+            if (idx < kAll && j < n_here) scan_quad_store<WL_FUSED_SCAN_NT>(out.obs + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], pz[i]));
         }
     }
 }
@@ -1016,7 +1027,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_rollout_persistent_kernel(
                 const int idx = t7 + (part * kBatch + i) * kScanLanes;
                 int j, q;
                 scan_quad_slot(idx, j, q);
-                if (idx < kAll && j < n_here) scan_quad_store<false>(obs_k + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], pz[i]));
+                if (idx < kAll && j < n_here) scan_quad_store<WL_FUSED_SCAN_NT>(obs_k + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], pz[i]));
             }
         }
     }
@@ -1250,7 +1261,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_collect_rollout_kernel(con
                     scan_quad_slot(idx, j, q);
                     if (idx < kAll && j < n_here) {
                         const wl_float4_u v = scan_quad_value(p, cr[i], pz[i]);
-                        scan_quad_store<false>(obs_k + (int64_t)(e0 + j) * D + 13, q, v);
+                        scan_quad_store<WL_FUSED_SCAN_NT>(obs_k + (int64_t)(e0 + j) * D + 13, q, v);
                         float* t4 = obs_tile + j * kTilePitch + 13 + 4 * q;
                         t4[0] = v.x, t4[1] = v.y, t4[2] = v.z, t4[3] = v.w;
                     }
@@ -1374,7 +1385,9 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
     const HeightFieldGround g = make_ground(hf);
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
-    const bool quad = use_quad(b);
+    // step + scan in one launch while its 16-env blocks fit the chip twice over (256 CUs); beyond, the lane-form step + the scan launch
+    // (round 4, us per step: 8192 envs 48.5 fused; 16 384 envs 92.5 fused / 75.4 two launches; 32 768 envs 180.6 / 100.2)
+    const bool quad = use_quad(b) && (b->lanes == 4 || b->n_envs <= WL_ELEV_FUSED_MAX_ENVS);
     clear_error();
     for (int k = 0; k < n_steps; ++k) {
         WlStepOut o = *out;

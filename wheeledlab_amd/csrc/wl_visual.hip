@@ -500,9 +500,13 @@ __global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p
 // augmented.  The gathers were not what bound it: 52.6 MB of observation rows in 18 us are 2.9 TB/s of stores, and the LDS form
 // gives up a quarter of the resident wavefronts for its 32 KB.  In the persistent rollout below, where the blocks are resident
 // for the whole rollout anyway, the LDS map does pay: 29.0 -> 26.0 us per step plain, 37.5 -> 35.9 augmented.)
+#ifndef WL_VIS_STREAM_BYTES
+#define WL_VIS_STREAM_BYTES 0ll
+#endif
 inline void launch_visual_obs(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, float* obs, hipStream_t hs) {
-    // rows of one launch beyond the 256 MB Infinity Cache (> 20 000 envs): stream them past the caches
-    if (use_streaming(b, (int64_t)b->n_envs * WL_VIS_OBS_DIM * 4, 256ll << 20)) visual_obs_kernel<true><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
+    // non-temporal rows at every size unless WL_FLAG_NO_STREAM asks otherwise (rounds 1-3: only beyond the 256 MB Infinity Cache, > 20 000
+    // envs, where they are worth 12 %; round 4, env.step() in us with / without: 4096 envs 49.2 / 50.7, 8192: 72.2 / 73.5, 16 384: 117.6 / 119.8)
+    if (use_streaming(b, (int64_t)b->n_envs * WL_VIS_OBS_DIM * 4, WL_VIS_STREAM_BYTES)) visual_obs_kernel<true><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
     else visual_obs_kernel<false><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
 }
 
