@@ -1,7 +1,7 @@
 """Philox4x32 counter RNG (Salmon et al., SC'11), numpy, ROUNDS rounds (7: the smallest Crush-resistant round count the paper
 reports for this width; wheeledlab_amd/csrc/wl_rng.h says why).  Mirrors the in-kernel generator bit for bit so that fused-step
-parity tests can include resets, pushes and observation noise.  The round function and key schedule are pinned against the
-published 10-round known answers through `rounds=10` (tests/test_oracle_golden_drift.py).
+parity tests can include resets, pushes and observation noise.  Pinned against the Random123 distribution's known answers
+for 7 rounds and (through `rounds=10`) for 10 (tests/test_oracle_golden_drift.py).
 key = (seed_lo, seed_hi); counter = (env_id, step_lo, step_hi, stream_id)."""
 import numpy as np
 

@@ -48,6 +48,17 @@ def test_philox_bit_exact(lib):
         torch.cuda.synchronize()
         want = PH.uniform4(np.arange(n), step, stream, seed)
         np.testing.assert_array_equal(out.cpu().numpy(), want)
+    # the device against the Random123 distribution's 7-round vectors (counter 0 / key 0; all ones): u01 keeps the top 24 bits of a word
+    for env, step, stream, seed, words in ((0, 0, 0, 0, (0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48)),
+                                           (0xFFFFFFFF, 2 ** 64 - 1, 0xFFFFFFFF, 2 ** 64 - 1, (0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662))):
+        want = [np.float32((w >> 8) * 2.0 ** -24) for w in words]
+        if env == 0:
+            assert lib.wl_philox_uniform(1, seed, step, stream, out.data_ptr(), None) == 0
+            torch.cuda.synchronize()
+            got = out.cpu().numpy().reshape(-1)[[0, 1, 2, 3]]
+            assert [float(g) for g in got] == [float(w) for w in want]
+        u = PH.uniform4(np.array([env]), step, stream, seed)[:, 0]
+        assert [float(g) for g in u] == [float(w) for w in want]
     # known-answer test from the Random123 distribution (ten rounds of the round function the draws use seven of): counter 0, key 0
     x = PH.philox4x32(np.array([0]), 0, 0, 0, rounds=10)[:, 0]
     assert [hex(int(v)) for v in x] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]

@@ -112,13 +112,20 @@ def test_philox_known_answers():
     """Philox4x32 (the keyed generator of every random draw; the HIP kernels are bit-exact to this oracle,
     tests/test_gpu_drift_parity.py::test_philox_bit_exact): the round function and the key schedule at TEN rounds against the three
     known-answer vectors of the Random123 distribution (kat_vectors: counter / key all zero, all ones, and the digits of pi).  The
-    draws use the first ROUNDS = 7 of the same rounds (the paper's smallest Crush-resistant count for this width)."""
+    draws use the first ROUNDS = 7 of the same rounds (the paper's smallest Crush-resistant count for this width), pinned by the
+    distribution's 7-round vectors."""
     from oracle import philox as PH
     assert PH.ROUNDS == 7
 
     def run(c, k):   # counter = (env, step low, step high, stream), key = (seed low, seed high)
         out = PH.philox4x32(np.array([c[0]]), c[1] | (c[2] << 32), c[3], k[0] | (k[1] << 32), rounds=10)
         return [int(v) for v in out[:, 0]]
+    def run7(c, k):
+        out = PH.philox4x32(np.array([c[0]]), c[1] | (c[2] << 32), c[3], k[0] | (k[1] << 32))
+        return [int(v) for v in out[:, 0]]
+    # the seven-round generator the draws use: kat_vectors' `philox4x32 7` lines for the all-zero and the all-ones counter / key
+    assert run7((0, 0, 0, 0), (0, 0)) == [0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48]
+    assert run7((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2) == [0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662]
     assert run((0, 0, 0, 0), (0, 0)) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
     assert run((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
     assert run((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == [0xD16CFE09, 0x94FDCCEB, 0x5001E420,

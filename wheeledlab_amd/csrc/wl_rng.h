@@ -2,8 +2,8 @@
 // counter = (global env id, step_lo, step_hi, stream id).  Stateless: no RNG state lives in HBM.
 // Rounds: 7 -- the smallest round count of Philox4x32 the paper reports Crush-resistant (its Table 2; 10 is the library's default with
 // a safety margin).  32 x 32 -> 64-bit multiplies are quarter-rate on gfx950 and the generator was ~25 % of the drift step's vector
-// instruction slots at large N: 10 -> 7 rounds is worth 3 - 4 % of the launch there (profiles/r04_rng_probe.jsonl).  The round function and
-// the key schedule are pinned against the published 10-round known answers (tests/test_oracle_golden_drift.py, rounds=10 on the oracle).
+// instruction slots at large N: 10 -> 7 rounds is worth 3 - 4 % of the launch there (profiles/r04_rng_probe.jsonl).  Pinned against the
+// Random123 distribution's known answers for 7 AND 10 rounds (tests/test_oracle_golden_drift.py; the device: tests/test_gpu_drift_parity.py).
 #pragma once
 #include "wl_math.h"
 
