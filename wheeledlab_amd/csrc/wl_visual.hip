@@ -485,7 +485,12 @@ WL_DEV CamPose load_cam_pose(const Rows& S, const int e) {
 // block = env: the observation of the state as it stands (reset / first observation / lane-form steps); map cells by byte
 // gathers from global memory (maps too large for LDS, or no bit map supplied)
 template <bool STREAM>
-__global__ void __launch_bounds__(kCam) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
+// seven wavefronts per SIMD (72 VGPRs + 24 bytes of scratch) instead of the six that the free allocation (73 -> 80 VGPRs) allows: round 4,
+// env.step() in us at 4096 / 65 536 / 262 144 envs: 49.2 -> 49.0 / 415.5 -> 400 / 1606 -> 1543; eight (64 VGPRs, 40 bytes): 49.6 / 408 / 1614
+#ifndef WL_CAM_MIN_WAVES
+#define WL_CAM_MIN_WAVES 7
+#endif
+__global__ void __launch_bounds__(kCam, WL_CAM_MIN_WAVES) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
                                                           float* __restrict__ obs) {
     __shared__ __attribute__((aligned(16))) float img[kImgFloats];
     __shared__ float red[kCam / 64];
