@@ -484,14 +484,19 @@ WL_DEV CamPose load_cam_pose(const Rows& S, const int e) {
 
 // block = env: the observation of the state as it stands (reset / first observation / lane-form steps); map cells by byte
 // gathers from global memory (maps too large for LDS, or no bit map supplied)
-template <bool STREAM>
-// seven wavefronts per SIMD (72 VGPRs + 24 bytes of scratch) instead of the six that the free allocation (73 -> 80 VGPRs) allows: round 4,
-// env.step() in us at 4096 / 65 536 / 262 144 envs: 49.2 -> 49.0 / 415.5 -> 400 / 1606 -> 1543; eight (64 VGPRs, 40 bytes): 49.6 / 408 / 1614
+// MINW = 7: seven wavefronts per SIMD (72 VGPRs + 24 bytes of scratch) instead of the six that the free allocation (73 -> 80 VGPRs)
+// allows -- round 4, env.step() in us at 4096 / 65 536 / 262 144 envs: 49.2 -> 49.0 / 415.5 -> 400 / 1606 -> 1543 (eight, 64 VGPRs + 40
+// bytes: 49.6 / 408 / 1614).  The small launches keep the free allocation: nothing to win there, and their scratch rows reach the fabric
+// (counter traffic of the 4096-env step 1.19 -> 1.40 x algorithmic).
 #ifndef WL_CAM_MIN_WAVES
 #define WL_CAM_MIN_WAVES 7
 #endif
-__global__ void __launch_bounds__(kCam, WL_CAM_MIN_WAVES) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
-                                                          float* __restrict__ obs) {
+#ifndef WL_CAM_MIN_WAVES_ENVS
+#define WL_CAM_MIN_WAVES_ENVS 32768
+#endif
+template <bool STREAM, int MINW = 1>
+__global__ void __launch_bounds__(kCam, MINW) visual_obs_kernel(const WlVisualParams p, const WlEnvBuffers b, const WlTravMap m,
+                                                                float* __restrict__ obs) {
     __shared__ __attribute__((aligned(16))) float img[kImgFloats];
     __shared__ float red[kCam / 64];
     const int e = blockIdx.x;
@@ -511,8 +516,14 @@ __global__ void __launch_bounds__(kCam, WL_CAM_MIN_WAVES) visual_obs_kernel(cons
 inline void launch_visual_obs(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, float* obs, hipStream_t hs) {
     // non-temporal rows at every size unless WL_FLAG_NO_STREAM asks otherwise (rounds 1-3: only beyond the 256 MB Infinity Cache, > 20 000
     // envs, where they are worth 12 %; round 4, env.step() in us with / without: 4096 envs 49.2 / 50.7, 8192: 72.2 / 73.5, 16 384: 117.6 / 119.8)
-    if (use_streaming(b, (int64_t)b->n_envs * WL_VIS_OBS_DIM * 4, WL_VIS_STREAM_BYTES)) visual_obs_kernel<true><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
-    else visual_obs_kernel<false><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
+    const bool dense = b->n_envs > WL_CAM_MIN_WAVES_ENVS;
+    if (use_streaming(b, (int64_t)b->n_envs * WL_VIS_OBS_DIM * 4, WL_VIS_STREAM_BYTES)) {
+        if (dense) visual_obs_kernel<true, WL_CAM_MIN_WAVES><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
+        else visual_obs_kernel<true><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
+    } else {
+        if (dense) visual_obs_kernel<false, WL_CAM_MIN_WAVES><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
+        else visual_obs_kernel<false><<<b->n_envs, kCam, 0, hs>>>(*p, *b, *m, obs);
+    }
 }
 
 // K env.step()s in ONE launch with pre-staged actions [K][n][2] (open-loop rollouts; quad form, n <= 32 768), the visual
