@@ -11,7 +11,7 @@ MASK = np.uint64(0xFFFFFFFF)
 
 ROUNDS = 7
 # stream ids (must match wl_rng.h); the drift step draws from S_DRIFT_EVENTS, S_NOISE0 and S_NOISE1 (layout: drift_draws below)
-S_RESET, S_DRIFT_EVENTS, S_TIMERS, S_PUSH_HF, S_PUSH_LF, S_NOISE0, S_NOISE1 = 0, 0, 1, 2, 3, 4, 5
+S_RESET, S_DRIFT_EVENTS, S_NOISE0, S_NOISE1 = 0, 0, 4, 5
 
 
 def philox4x32(env_ids, step, stream_id, seed, rounds=ROUNDS):

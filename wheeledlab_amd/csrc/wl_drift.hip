@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(kBlock, LANES == 4 ? WL_MIN_WAVES : (UNROLL ? 
             int go = 1;
             asm volatile("" : "+s"(go) : : "memory");
             if (go) {
-                // the step's random draws need only (seed, gid, step) -- preloaded arguments: two Philox blocks and two
+                // the step's random draws need only (seed, gid, step) -- preloaded arguments: one Philox block and two
                 // Box-Muller pairs per lane before the first instruction that waits for anything
                 StepDraws pre = draw_step_raw(gid, step, seed, wid);
                 kernarg_words_landed(kw);            // the first instruction that waits for the parameter block
