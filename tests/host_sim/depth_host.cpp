@@ -16,30 +16,24 @@ int hs_depth(const WlVisualParams* p, const WlHeightField* hf, int n, const floa
     const Pyramid py = make_pyramid(hf->nx, hf->ny);
     const int P = 1 << py.lp;
     std::vector<float> buf((size_t)pyramid_total_floats(hf->nx, hf->ny), -INFINITY);
-    float hmax = -INFINITY;
-    for (size_t k = 0; k < (size_t)hf->nx * hf->ny; ++k) hmax = fmaxf(hmax, hf->height[k]);
-    buf[0] = hmax;
+    pyramid_header_serial(*hf, buf.data() + py.hdr);
+    buf[0] = buf[py.hdr + kPyrMax];
+    uint32_t* words = reinterpret_cast<uint32_t*>(buf.data());
     for (int L = 1; L <= py.lp; ++L)
         for (int J = 0; J < (P >> L); ++J)
-            for (int I = 0; I < (P >> L); ++I) {
-                uint32_t w0;
-                float c;
-                plane_cell_serial(*hf, L, I, J, w0, c);
-                float* e = buf.data() + 2 * ((size_t)pyramid_level_offset(py.lp, L) + (size_t)J * (P >> L) + I);
-                e[0] = __builtin_bit_cast(float, w0);
-                e[1] = c;
-            }
+            for (int I = 0; I < (P >> L); ++I)
+                words[(size_t)pyramid_level_offset(py.lp, L) + (size_t)J * (P >> L) + I] = plane_cell_serial(*hf, L, I, J, buf.data() + py.hdr);
     std::copy(hf->height, hf->height + (size_t)hf->nx * hf->ny, buf.begin() + py.h0);
     const DepthGrid g = make_depth_grid(hf);
     const FieldMem mem{buf.data()};
-    const float zclear = clear_height(g, py, mem);
+    const PyrHead hd = pyramid_head(g, py, mem);
     for (int e = 0; e < n; ++e) {
         const Quat q{quat[4 * e], quat[4 * e + 1], quat[4 * e + 2], quat[4 * e + 3]};
         const Mat3 R = mat_from_quat(q);
         const V3 o = v3(pos[3 * e], pos[3 * e + 1], pos[3 * e + 2]) + mul(R, v3(p->cam_pos[0], p->cam_pos[1], p->cam_pos[2]));
         for (int r = 0; r < WL_VIS_IMG_H; ++r)
             for (int c = 0; c < WL_VIS_IMG_W; ++c)
-                depth[((size_t)e * WL_VIS_IMG_H + r) * WL_VIS_IMG_W + c] = cast_ray(g, py, mem, zclear, o, mul(R, depth_pixel_ray_body(*p, r, c)), max_depth);
+                depth[((size_t)e * WL_VIS_IMG_H + r) * WL_VIS_IMG_W + c] = cast_ray(g, py, hd, mem, o, mul(R, depth_pixel_ray_body(*p, r, c)), max_depth);
     }
     return 0;
 }

@@ -95,8 +95,8 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.wl_ppo_apply(C.byref(small_a), C.byref(small_c), base, 0, C.byref(hp), C.byref(st), 0, 1, None) == -1           # empty batch
     assert lib.wl_ppo_apply(C.byref(actor), C.byref(critic), base, 64, C.byref(hp), C.byref(st), 0, 1, None) == -1             # not the 14-wide nets
     # depth ray-cast: pyramid sizing is host arithmetic; every malformed call is refused before a launch
-    assert lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 + 800 * 800      # bound pyramid (8-byte entries) + heights
-    assert lib.wl_heightfield_pyramid_floats(3, 3) == 2 * 2 + 9 and lib.wl_heightfield_pyramid_floats(349, 613) == 1024 * 1024 + 349 * 613
+    assert lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800 + 4      # bound pyramid (4-byte entries) + heights + header
+    assert lib.wl_heightfield_pyramid_floats(3, 3) == 4 + 9 + 4 and lib.wl_heightfield_pyramid_floats(349, 613) == 1024 * 1024 // 2 + 349 * 613 + 4
     assert lib.wl_heightfield_pyramid_floats(1, 9) == 0 and lib.wl_heightfield_pyramid_floats(9, 16386) == 0
     vp = PP.visual_params()
     hf = A.WlHeightField(base, 16, 16, 0.0, 0.0, 0.5, 0.0)

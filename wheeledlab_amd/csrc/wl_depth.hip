@@ -17,8 +17,8 @@
 // nearly the same walk, so the lanes stay together and their gathers hit the same cache lines; a tile's walk length varies
 // 5 x over the image (sky / near ground short, the rows at the horizon long), and single-wavefront blocks let the dispatcher
 // refill a slot the moment its tile is done (five-wavefront strip blocks held four finished wavefronts' slots until the
-// slowest one ended: 716 against 611 us at 4096 cameras, same walk).  The field (2.56 MB) and the pyramid (0.85 MB touched)
-// are L2-resident.  Output is the only HBM stream: 19 200 B per env, 64 B segments per tile row.
+// slowest one ended: 716 against 611 us at 4096 cameras, same walk).  The field's copy (2.56 MB) and the pyramid (0.85 MB touched:
+// 4-byte entries) fit an XCD's L2.  Output is the only HBM stream: 19 200 B per env, 64 B segments per tile row.
 #include <hip/hip_runtime.h>
 
 #include "../../include/wheeledlab_amd.h"
@@ -31,33 +31,56 @@ constexpr int kStripRows = 4, kStrips = WL_VIS_IMG_H / kStripRows;
 constexpr int kTileCols = 16, kTilesPerStrip = WL_VIS_IMG_W / kTileCols, kTiles = kStrips * kTilesPerStrip;   // 75 tiles per image
 static_assert(WL_VIS_IMG_H % kStripRows == 0 && WL_VIS_IMG_W % kTileCols == 0 && kStripRows * kTileCols == 64, "one wavefront per tile");
 
+// the header: the field's range and its steepest cell edge (one block: this runs once per heightfield); the maximum also goes to float 0
+__global__ void __launch_bounds__(1024) pyramid_header_kernel(const WlHeightField f, float* __restrict__ buf, const int hdr) {
+    __shared__ float red[3][16];
+    __shared__ int bad;
+    float hmin = INFINITY, hmax = -INFINITY, smax = 0.f;
+    bool finite = true;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    const int64_t n = (int64_t)f.nx * f.ny;
+    for (int64_t k = threadIdx.x; k < n; k += 1024) {
+        const int j = (int)(k / f.nx);
+        header_point(f, (int)(k - (int64_t)j * f.nx), j, hmin, hmax, smax, finite);
+    }
+    if (!finite) bad = 1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        hmin = fminf(hmin, __shfl_xor(hmin, off, 64));
+        hmax = fmaxf(hmax, __shfl_xor(hmax, off, 64));
+        smax = fmaxf(smax, __shfl_xor(smax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = hmin, red[1][threadIdx.x >> 6] = hmax, red[2][threadIdx.x >> 6] = smax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) hmin = fminf(hmin, red[0][w]), hmax = fmaxf(hmax, red[1][w]), smax = fmaxf(smax, red[2][w]);
+        pyramid_header_values(hmin, hmax, smax, bad == 0, buf + hdr);
+        buf[0] = hmax;
+    }
+}
 // the bound pyramid, level by level straight from the heights (exact residuals: every grid point of a cell is visited).
 // Small cells (L <= 4: at most 17 x 17 points): one thread per cell.
-__global__ void __launch_bounds__(kBlock) pyramid_planes_small_kernel(const WlHeightField f, float* __restrict__ buf, const int lp, const int L) {
+__global__ void __launch_bounds__(kBlock) pyramid_planes_small_kernel(const WlHeightField f, float* __restrict__ buf, const int lp, const int L, const int hdr) {
     const int W = (1 << lp) >> L;
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= W * W) return;
-    uint32_t w0;
-    float c;
-    plane_cell_serial(f, L, k % W, k / W, w0, c);
-    float* e = buf + 2 * (pyramid_level_offset(lp, L) + k);
-    e[0] = __builtin_bit_cast(float, w0);
-    e[1] = c;
+    reinterpret_cast<uint32_t*>(buf)[pyramid_level_offset(lp, L) + k] = plane_cell_serial(f, L, k % W, k / W, buf + hdr);
 }
-// Large cells: one block per cell, its points strided over the threads, maxima folded through LDS.  The top level's block also
-// leaves the field's maximum in float 0 (clear_height).
-__global__ void __launch_bounds__(kBlock) pyramid_planes_large_kernel(const WlHeightField f, float* __restrict__ buf, const int lp, const int L) {
+// Large cells: one block per cell, its points strided over the threads, maxima folded through LDS.
+__global__ void __launch_bounds__(kBlock) pyramid_planes_large_kernel(const WlHeightField f, float* __restrict__ buf, const int lp, const int L, const int hdr) {
     __shared__ float red[2][kBlock / 64];
     const int W = (1 << lp) >> L;
     const int I = blockIdx.x % W, J = blockIdx.x / W;
-    float* e = buf + 2 * (pyramid_level_offset(lp, L) + blockIdx.x);
+    uint32_t* e = reinterpret_cast<uint32_t*>(buf) + pyramid_level_offset(lp, L) + blockIdx.x;
     int i0, i1, j0, j1;
     if (!plane_cell_range(f, L, I, J, i0, i1, j0, j1)) {     // block-uniform
-        if (threadIdx.x == 0) e[0] = 0.f, e[1] = -INFINITY;
+        if (threadIdx.x == 0) *e = kEmptyEntry;
         return;
     }
+    int a8, b8;
     float a, b, resid = -INFINITY, hmax = -INFINITY;
-    plane_cell_slopes(f, i0, i1, j0, j1, a, b);
+    plane_cell_slopes(f, i0, i1, j0, j1, buf[hdr + kPyrSlopeQ], a8, b8, a, b);
     const int wpts = i1 - i0 + 1, npts = wpts * (j1 - j0 + 1);
     for (int k = threadIdx.x; k < npts; k += kBlock) plane_point(f, i0, j0, i0 + k % wpts, j0 + k / wpts, a, b, resid, hmax);
 #pragma unroll
@@ -69,12 +92,7 @@ __global__ void __launch_bounds__(kBlock) pyramid_planes_large_kernel(const WlHe
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < kBlock / 64; ++w) resid = fmaxf(resid, red[0][w]), hmax = fmaxf(hmax, red[1][w]);
-        uint32_t w0;
-        float c;
-        plane_entry(i0, i1, j0, j1, a, b, resid, hmax, w0, c);
-        e[0] = __builtin_bit_cast(float, w0);
-        e[1] = c;
-        if (L == lp) buf[0] = hmax;
+        *e = plane_entry(i0, i1, j0, j1, a8, b8, a, b, resid, hmax, buf + hdr);
     }
 }
 __global__ void __launch_bounds__(kBlock) pyramid_copy_heights_kernel(const float* __restrict__ h, float* __restrict__ dst, const int n) {
@@ -109,7 +127,7 @@ __global__ void __launch_bounds__(64) visual_depth_tile_kernel(const WlVisualPar
     const int row = strip * kStripRows + (lane >> 4), col = (tile - strip * kTilesPerStrip) * kTileCols + (lane & 15);
     const V3 d = mul(cam.R, depth_pixel_ray_body(p, row, col));
     const FieldMem mem{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(buf), 0, (int)buf_bytes, 0x00020000)};
-    const float t = cast_ray(g, py, mem, clear_height(g, py, mem), cam.o, d, max_depth);
+    const float t = cast_ray(g, py, pyramid_head(g, py, mem), mem, cam.o, d, max_depth);
     // non-temporal: the image rows must not push the pyramid and the heights (4.3 MB for the 800 x 800 field, an XCD's L2 holds 4 MB)
     // out of L2 -- round 4, 4096 images: counter reads 176 -> 69 MB per render (the compulsory fill is 8 XCDs x 4.3 MB), 380 -> 372 us
     __builtin_nontemporal_store(t, depth + (int64_t)e * row_stride + row * WL_VIS_IMG_W + col);
@@ -141,7 +159,8 @@ __global__ void __launch_bounds__(64) visual_depth_pool_kernel(const WlVisualPar
     const int e = blockIdx.x / kPools, r0 = (blockIdx.x - e * kPools) * POOL_ROWS;
     const DepthCam cam = depth_cam(p, b, e);
     const FieldMem mem{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(buf), 0, (int)buf_bytes, 0x00020000)};
-    const float zclear = clear_height(g, py, mem);
+    const PyrHead hd = pyramid_head(g, py, mem);
+    const float zclear = hd.zclear;
     float* img = depth + (int64_t)e * row_stride + r0 * WL_VIS_IMG_W;
     const int lane = threadIdx.x;
     const int max_walk = max_walk_steps(g);
@@ -166,7 +185,7 @@ __global__ void __launch_bounds__(64) visual_depth_pool_kernel(const WlVisualPar
     for (;;) {
         if (have) {
             if (w.live && steps < max_walk) {
-                ray_step(g, py, mem, w);
+                ray_step(g, py, hd, mem, w);
                 ++steps;
             } else {
 #ifdef WL_DEPTH_NT
@@ -227,10 +246,11 @@ int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* 
     clear_error();
     const hipStream_t hs = (hipStream_t)stream;
     const int P = 1 << py.lp;
+    pyramid_header_kernel<<<1, 1024, 0, hs>>>(*hf, pyramid, py.hdr);
     for (int L = 1; L <= py.lp; ++L) {
         const int cells = (P >> L) * (P >> L);
-        if (L <= 4 && L < py.lp) pyramid_planes_small_kernel<<<grid_for(cells), kBlock, 0, hs>>>(*hf, pyramid, py.lp, L);
-        else pyramid_planes_large_kernel<<<cells, kBlock, 0, hs>>>(*hf, pyramid, py.lp, L);
+        if (L <= 4 && L < py.lp) pyramid_planes_small_kernel<<<grid_for(cells), kBlock, 0, hs>>>(*hf, pyramid, py.lp, L, py.hdr);
+        else pyramid_planes_large_kernel<<<cells, kBlock, 0, hs>>>(*hf, pyramid, py.lp, L, py.hdr);
     }
     pyramid_copy_heights_kernel<<<grid_for(hf->nx * hf->ny), kBlock, 0, hs>>>(hf->height, pyramid + py.h0, hf->nx * hf->ny);
     return launch_status();

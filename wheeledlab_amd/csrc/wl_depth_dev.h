@@ -7,47 +7,82 @@
 namespace {
 
 // ONE device buffer holds everything the walk gathers, so that every access is a 32-bit offset from one base:
-//   float  [0]                       the field's maximum (clear_height)
-//   entries [PP >> 2L, 2 (PP >> 2L)) level L of the BOUND pyramid, 1 <= L <= lp: a (P >> L) x (P >> L) array (P = 2^lp = the
-//                                    power of two >= the cell count of the longer side, PP = P^2) of 8-byte entries
-//                                    { half a | half b, float c } (entry e = floats 2 e, 2 e + 1): inside the 2^L x 2^L block of
-//                                    cells (J, I) the terrain stays below the PLANE  a (u - I 2^L) + b (v - J 2^L) + c  (u, v in
-//                                    grid units); blocks that cover no cell: c = -inf
-//   floats [PP, PP + ny nx)          a copy of the heights [ny][nx] (level 0 is not stored: the intersection needs the four
-//                                    corners of a cell anyway)
-// The level offsets are shifts (no table, no division); the price is PP / 3 floats of padding.
+//   float  [0]                       the field's maximum (also in the header)
+//   words  [PP >> 2L, 2 (PP >> 2L))  level L of the BOUND pyramid, 1 <= L <= lp: a (P >> L) x (P >> L) array (P = 2^lp = the
+//                                    power of two >= the cell count of the longer side, PP = P^2) of 4-byte entries
+//                                    { uint16 c' | int8 a' | int8 b' }: inside the 2^L x 2^L block of cells (J, I) the terrain stays
+//                                    below the PLANE  a (u - I 2^L) + b (v - J 2^L) + c  (u, v in grid units) with a = a' qs,
+//                                    b = b' qs, c = c0 + c' qc; blocks that cover no cell: the word 0 (never read by the walk)
+//   floats [h0, h0 + ny nx)          a copy of the heights [ny][nx], h0 = max(PP / 2, 4) (level 0 is not stored: the intersection
+//                                    needs the four corners of a cell anyway)
+//   floats [h0 + ny nx, + 4)         the header: field maximum, slope quantum qs, offset base c0, offset quantum qc
+// The level offsets are shifts (no table, no division); the price is PP / 6 floats of padding.
 //
 // Round 4: bounding PLANES instead of the round-3 maxima.  Under a maximum a cell on a slope is "as high as its highest corner":
 // a ray skimming 10 - 20 cm above a hillside cannot skip cells larger than ~0.2 m and walks them one by one.  A plane fitted to
-// the cell (slopes from its corner heights, rounded to fp16; c = the largest residual of ANY grid point of the cell against the
-// ROUNDED slopes, so the bound is exact whatever the fit is worth) is loose only by the cell's curvature; the ray clears it over
-// its whole stay in the cell iff it clears it at both ends (ray and plane are both linear).  Same answers bit for bit (a skip is
-// only ever conservative); host simulation on the bench poses: 8.15 -> 6.49 steps per ray, 13.9 -> 9.1 wave-steps per tile.
-// Where the flat bound (a = b = 0, c = the cell's maximum) is the lower one at the cell's centre it is stored instead.
+// the cell (slopes from its corner heights, quantised; c = the largest residual of ANY grid point of the cell against the
+// QUANTISED slopes, rounded UP, so the bound is exact whatever the fit is worth) is loose only by the cell's curvature; the ray
+// clears it over its whole stay in the cell iff it clears it at both ends (ray and plane are both linear).  Same answers bit for
+// bit (a skip is only ever conservative); host simulation on the bench poses: 8.15 -> 6.49 steps per ray, 13.9 -> 9.1 wave-steps
+// per tile.  Where the flat bound (a = b = 0, c = the cell's maximum) is the lower one at the cell's centre it is stored instead.
+// Entries of FOUR bytes (first version: fp16 slopes + float c = eight): the 800 x 800 bench field's entries + heights are 3.4 MB
+// instead of 4.3 MB -- under the 4 MB of L2 an XCD has.  What the quantisation costs the bound: int8 slopes with ONE quantum per
+// field (its steepest cell edge / 127) are off by at most qs / 2 per cell of the block's extent (bench field: 0.1 mm per cell);
+// 16-bit fixed-point offsets over twice the field's relief are off by at most qc (bench field: 0.03 mm -- fp16 offsets, 0.25 - 0.5 mm
+// there, cost 2 % more wave-steps: the rays that matter pass the last cells before their hit within a millimetre of the surface).
 struct Pyramid {
     int lp;        // log2 P = the top level (one entry)
-    int h0;        // float offset of the height copy = PP
+    int h0;        // float offset of the height copy
+    int hdr;       // float offset of the header
 };
+constexpr int kPyrMax = 0, kPyrSlopeQ = 1, kPyrBase = 2, kPyrOffsetQ = 3, kPyrHeader = 4;   // header floats
 inline int pyramid_log2(int nx, int ny) {
     int lp = 1;
     while ((1 << lp) < nx - 1 || (1 << lp) < ny - 1) ++lp;
     return lp;
 }
-__host__ __device__ inline int pyramid_level_offset(int lp, int L) { return (1 << (2 * lp)) >> (2 * L); }   // in ENTRIES
+__host__ __device__ inline int pyramid_level_offset(int lp, int L) { return (1 << (2 * lp)) >> (2 * L); }   // in ENTRIES = words
 inline Pyramid make_pyramid(int nx, int ny) {
     const int lp = pyramid_log2(nx, ny);
-    return Pyramid{lp, 1 << (2 * lp)};
+    const int h0 = max((1 << (2 * lp)) >> 1, 4);
+    return Pyramid{lp, h0, h0 + nx * ny};
 }
-inline int64_t pyramid_total_floats(int nx, int ny) { return (int64_t)make_pyramid(nx, ny).h0 + (int64_t)nx * ny; }
+inline int64_t pyramid_total_floats(int nx, int ny) { return (int64_t)make_pyramid(nx, ny).hdr + kPyrHeader; }
 
-// two fp16 slopes in one 32-bit word
-WL_DEV uint32_t pack_slopes(float a, float b) {
-    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-    return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+// what every launch reads once from the header
+struct PyrHead {
+    float zclear;       // the highest height of the field or the outside plane, whichever is higher (rising rays end above it)
+    float qs, c0, qc;   // slope quantum, offset base, offset quantum
+};
+// the header of a field with heights in [hmin, hmax] (finite: `finite`) whose steepest cell edge rises smax per cell.  Offsets cover
+// [hmin, hmin + 2 relief]: every block maximum (the flat bound) fits, a fitted plane whose corner offset does not falls back to it.
+// A field with a non-finite height gets qc = +inf: every bound is +inf, nothing is ever skipped, the walk visits every cell.
+__host__ __device__ inline void pyramid_header_values(float hmin, float hmax, float smax, bool finite, float* hd) {
+    hd[kPyrMax] = hmax;
+    hd[kPyrSlopeQ] = (finite && smax > 0.f) ? smax * (1.f / 127.f) : 1.f;
+    const float span = fmaxf(2.f * (hmax - hmin), 1e-3f * (1.f + fabsf(hmax)));
+    hd[kPyrBase] = finite ? hmin : 0.f;
+    hd[kPyrOffsetQ] = finite ? span * (1.f / 65534.f) : INFINITY;
 }
-WL_DEV void unpack_slopes(uint32_t w, float& a, float& b) {
-    a = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu));
-    b = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+// a slope as a multiple of the quantum
+WL_DEV int slope_steps(float s, float q) {
+    const float r = rintf(s / q);
+    return (r == r) ? (int)fminf(fmaxf(r, -127.f), 127.f) : 0;      // NaN heights: flat
+}
+// the smallest offset code whose value c0 + code qc is >= c (may exceed 65535: the caller falls back to the flat bound)
+WL_DEV int offset_code(float c, float c0, float qc) {
+    if (!(qc < 1e30f)) return 1;                        // qc = +inf: any non-zero code decodes to +inf
+    float u = ceilf((c - c0) / qc);
+    if (!(u == u) || u > 1e6f) return 1 << 20;
+    u = fmaxf(u, 1.f);
+    if (fmaf(u, qc, c0) < c) u += 1.f;                  // the division rounded down across an integer
+    return (int)u;
+}
+WL_DEV uint32_t pack_entry(int a8, int b8, int code) { return ((uint32_t)code << 16) | ((uint32_t)(a8 & 0xff) << 8) | (uint32_t)(b8 & 0xff); }
+WL_DEV void unpack_entry(uint32_t w, const PyrHead& hd, float& a, float& b, float& c) {
+    a = (float)(int)(int8_t)(w >> 8) * hd.qs;
+    b = (float)(int)(int8_t)w * hd.qs;
+    c = fmaf((float)(w >> 16), hd.qc, hd.c0);
 }
 // the grid points of cell (I, J) of level L: [i0, i1] x [j0, j1] (clipped to the field); false: the block covers no cell
 WL_DEV bool plane_cell_range(const WlHeightField& f, int L, int I, int J, int& i0, int& i1, int& j0, int& j1) {
@@ -56,15 +91,14 @@ WL_DEV bool plane_cell_range(const WlHeightField& f, int L, int I, int J, int& i
     i1 = min(i0 + (1 << L), f.nx - 1), j1 = min(j0 + (1 << L), f.ny - 1);
     return true;
 }
-// the fitted slopes of a cell: mean slope between its opposite edges' corner heights, as fp16 will hold them (clamped into fp16's
-// range: any slopes give a valid bound, the residual below makes it exact)
-WL_DEV void plane_cell_slopes(const WlHeightField& f, int i0, int i1, int j0, int j1, float& a, float& b) {
+// the fitted slopes of a cell: mean slope between its opposite edges' corner heights, as the entry will hold them (whole steps of the
+// quantum: any slopes give a valid bound, the residual below makes it exact)
+WL_DEV void plane_cell_slopes(const WlHeightField& f, int i0, int i1, int j0, int j1, float q, int& a8, int& b8, float& a, float& b) {
     const float h00 = f.height[(int64_t)j0 * f.nx + i0], h10 = f.height[(int64_t)j0 * f.nx + i1];
     const float h01 = f.height[(int64_t)j1 * f.nx + i0], h11 = f.height[(int64_t)j1 * f.nx + i1];
     const float fa = ((h10 + h11) - (h00 + h01)) / (2.f * (float)(i1 - i0)), fb = ((h01 + h11) - (h00 + h10)) / (2.f * (float)(j1 - j0));
-    unpack_slopes(pack_slopes(fminf(fmaxf(fa, -6e4f), 6e4f), fminf(fmaxf(fb, -6e4f), 6e4f)), a, b);
-    if (!(a == a)) a = 0.f;      // NaN heights: flat
-    if (!(b == b)) b = 0.f;
+    a8 = slope_steps(fa, q), b8 = slope_steps(fb, q);
+    a = (float)a8 * q, b = (float)b8 * q;        // exactly what unpack_entry returns
 }
 // residual and height of ONE grid point against the cell's slopes (the reductions over a cell's points take the max of both)
 WL_DEV void plane_point(const WlHeightField& f, int i0, int j0, int i, int j, float a, float b, float& resid, float& hmax) {
@@ -73,36 +107,56 @@ WL_DEV void plane_point(const WlHeightField& f, int i0, int j0, int i, int j, fl
     hmax = fmaxf(hmax, h);
 }
 // the entry to store: the fitted plane, or the flat bound where that is the lower one at the cell's centre; a hair of slack
-// covers the rounding of the walk's own evaluation of the plane
-WL_DEV void plane_entry(int i0, int i1, int j0, int j1, float a, float b, float resid, float hmax, uint32_t& w0, float& c) {
+// covers the rounding of the walk's own evaluation of the plane (and of base + c')
+WL_DEV uint32_t plane_entry(int i0, int i1, int j0, int j1, int a8, int b8, float a, float b, float resid, float hmax, const float* hd) {
     const float centre = resid + 0.5f * fmaf(a, (float)(i1 - i0), b * (float)(j1 - j0));
-    const bool fitted = centre < hmax;
-    w0 = fitted ? pack_slopes(a, b) : 0u;
-    c = (fitted ? resid : hmax) + 2e-6f * (1.f + fabsf(fitted ? resid : hmax));
+    const float c0 = hd[kPyrBase], qc = hd[kPyrOffsetQ];
+    const int fit = offset_code(resid + 2e-6f * (1.f + fabsf(resid)), c0, qc);
+    if (centre < hmax && fit <= 65535) return pack_entry(a8, b8, fit);
+    return pack_entry(0, 0, min(offset_code(hmax + 2e-6f * (1.f + fabsf(hmax)), c0, qc), 65535));
 }
+constexpr uint32_t kEmptyEntry = 0u;     // the block covers no cell (the walk never asks for it)
 // one cell, serially (small cells on the device; every cell in the host simulation)
-WL_DEV void plane_cell_serial(const WlHeightField& f, int L, int I, int J, uint32_t& w0, float& c) {
+WL_DEV uint32_t plane_cell_serial(const WlHeightField& f, int L, int I, int J, const float* hd) {
     int i0, i1, j0, j1;
-    if (!plane_cell_range(f, L, I, J, i0, i1, j0, j1)) {
-        w0 = 0u, c = -INFINITY;
-        return;
-    }
+    if (!plane_cell_range(f, L, I, J, i0, i1, j0, j1)) return kEmptyEntry;
+    int a8, b8;
     float a, b, resid = -INFINITY, hmax = -INFINITY;
-    plane_cell_slopes(f, i0, i1, j0, j1, a, b);
+    plane_cell_slopes(f, i0, i1, j0, j1, hd[kPyrSlopeQ], a8, b8, a, b);
     for (int j = j0; j <= j1; ++j)
         for (int i = i0; i <= i1; ++i) plane_point(f, i0, j0, i, j, a, b, resid, hmax);
-    plane_entry(i0, i1, j0, j1, a, b, resid, hmax, w0, c);
+    return plane_entry(i0, i1, j0, j1, a8, b8, a, b, resid, hmax, hd);
 }
+// one height's share of the header's reductions
+WL_DEV void header_point(const WlHeightField& f, int i, int j, float& hmin, float& hmax, float& smax, bool& finite) {
+    const float h = f.height[(int64_t)j * f.nx + i];
+    hmin = fminf(hmin, h), hmax = fmaxf(hmax, h);
+    finite = finite && (h - h == 0.f);
+    if (i + 1 < f.nx) smax = fmaxf(smax, fabsf(f.height[(int64_t)j * f.nx + i + 1] - h));
+    if (j + 1 < f.ny) smax = fmaxf(smax, fabsf(f.height[(int64_t)(j + 1) * f.nx + i] - h));
+}
+// the header of a field, serially (the host simulation; the device has pyramid_header_kernel)
+#ifdef WL_HOST_SIM
+inline void pyramid_header_serial(const WlHeightField& f, float* hd) {
+    float hmin = INFINITY, hmax = -INFINITY, smax = 0.f;
+    bool finite = true;
+    for (int j = 0; j < f.ny; ++j)
+        for (int i = 0; i < f.nx; ++i) header_point(f, i, j, hmin, hmax, smax, finite);
+    pyramid_header_values(hmin, hmax, smax, finite, hd);
+}
+#endif
 
 // the walk's view of that buffer: 4- and 8-byte gathers at float offsets
 struct FieldMem {
 #ifdef WL_HOST_SIM
     const float* base;
     WL_DEV float ld(int idx) const { return base[idx]; }
+    WL_DEV uint32_t ldw(int idx) const { return __builtin_bit_cast(uint32_t, base[idx]); }
     WL_DEV void ld2(int idx, float& a, float& b) const { a = base[idx], b = base[idx + 1]; }
 #else
     __amdgpu_buffer_rsrc_t rsrc;   // buffer loads: ONE 32-bit VGPR offset per gather, no 64-bit address arithmetic
     WL_DEV float ld(int idx) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, idx * 4, 0, 0)); }
+    WL_DEV uint32_t ldw(int idx) const { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, idx * 4, 0, 0); }
     WL_DEV void ld2(int idx, float& a, float& b) const {
         // 4-byte aligned is enough.  The WHOLE result is bit-cast: indexing the builtin's own return type (v[0], v[1]) is folded
         // to element 0 twice by this compiler (ROCm 7.2 clang, -O3: the load is narrowed to one dword).
@@ -241,7 +295,7 @@ WL_DEV RayWalk ray_begin(const DepthGrid& g, const Pyramid& py, const float zcle
 }
 
 // one step of the walk: test the level-L cell of (i, j); hit, descend, or leave it through its nearer line
-WL_DEV void ray_step(const DepthGrid& g, const Pyramid& py, const FieldMem& mem, RayWalk& w) {
+WL_DEV void ray_step(const DepthGrid& g, const Pyramid& py, const PyrHead& hd, const FieldMem& mem, RayWalk& w) {
     const int NX = g.NX, NY = g.NY;
     const float ou = w.ou, ov = w.ov, du = w.du, dv = w.dv, oz = w.oz, dz = w.dz, idu = w.idu, idv = w.idv, t = w.t, t_stop = w.t_stop;
     const int su = w.su, sv = w.sv, i = w.i, j = w.j, L = w.L;
@@ -266,11 +320,9 @@ WL_DEV void ray_step(const DepthGrid& g, const Pyramid& py, const FieldMem& mem,
         mem.ld2(k + g.nx, h01, h11);
         clear = zmin > fmaxf(fmaxf(h00, h10), fmaxf(h01, h11)) + 1e-6f;
     } else {
-        // the cell's bounding plane, one 8-byte gather: above it at both ends of the stay = above it throughout
-        float sw, c;
-        mem.ld2(2 * (pyramid_level_offset(py.lp, L) + (jL << (py.lp - L)) + iL), sw, c);
-        float a, b;
-        unpack_slopes(__builtin_bit_cast(uint32_t, sw), a, b);
+        // the cell's bounding plane, one 4-byte gather: above it at both ends of the stay = above it throughout
+        float a, b, c;
+        unpack_entry(mem.ldw(pyramid_level_offset(py.lp, L) + (jL << (py.lp - L)) + iL), hd, a, b, c);
         const float u0 = ou - (float)(iL << L), v0 = ov - (float)(jL << L);
         const float au = a * u0, bv = b * v0;
         const float g0 = (oz - c) - (au + bv), g1 = dz - fmaf(a, du, b * dv);      // height above the plane: g(t) = g0 + t g1
@@ -343,15 +395,18 @@ WL_DEV float ray_result(const DepthGrid& g, const RayWalk& w) {
 WL_DEV int max_walk_steps(const DepthGrid& g) { return 4 * (g.NX + g.NY) + 64; }
 
 // one ray from start to end (the host simulation and the one-ray-per-lane kernel form)
-WL_DEV float cast_ray(const DepthGrid& g, const Pyramid& py, const FieldMem& mem, const float zclear, const V3 o, const V3 d, const float tmax) {
-    RayWalk w = ray_begin(g, py, zclear, o, d, tmax);
+WL_DEV float cast_ray(const DepthGrid& g, const Pyramid& py, const PyrHead& hd, const FieldMem& mem, const V3 o, const V3 d, const float tmax) {
+    RayWalk w = ray_begin(g, py, hd.zclear, o, d, tmax);
     const int max_walk = max_walk_steps(g);
 #pragma unroll 1
-    for (int it = 0; it < max_walk && w.live; ++it) ray_step(g, py, mem, w);
+    for (int it = 0; it < max_walk && w.live; ++it) ray_step(g, py, hd, mem, w);
     return ray_result(g, w);
 }
-// the height nothing of the terrain solid rises above: the pyramid's top entry (the field's maximum) or the outside plane
-WL_DEV float clear_height(const DepthGrid& g, const Pyramid& py, const FieldMem& mem) { return fmaxf(mem.ld(0), g.outside_z); }
+// the pyramid's header: the height nothing of the terrain solid rises above (the field's maximum or the outside plane), the quanta and
+// the base of the entries
+WL_DEV PyrHead pyramid_head(const DepthGrid& g, const Pyramid& py, const FieldMem& mem) {
+    return PyrHead{fmaxf(mem.ld(py.hdr + kPyrMax), g.outside_z), mem.ld(py.hdr + kPyrSlopeQ), mem.ld(py.hdr + kPyrBase), mem.ld(py.hdr + kPyrOffsetQ)};
+}
 
 // camera ray of pixel (row, col) of the FULL 60 x 80 image in the body frame: optical axis = body +x, image right = body -y,
 // image down = body -z (the visual camera's convention, wl_visual.hip).  Body x component 1: the ray parameter IS the
