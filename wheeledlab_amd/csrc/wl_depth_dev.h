@@ -179,17 +179,18 @@ WL_DEV float plane_hit(float oz, float dz, float zp, float ta, float tb) {
 }
 
 // where a ray enters the pyramid: rays that rise can only meet terrain above the camera and start high (a few large cells and
-// out); rays that fall start near the level at which the ground in front of the car stops being skippable.  Same-box A/B at
-// 4096 cameras (us per render at 100 / 20 / 5 m range): 4 / 4: 694 / 665 / 566, 3 / 7: 694 / 673 / 565, 2 / 6: 685 / 683 / 563,
-// 4 / 8: 712 / 689 / 577 -- flat; the walk finds its level within two or three steps wherever it starts.
+// out); rays that fall start near the level at which the ground in front of the car stops being skippable.  Round 3 (block maxima),
+// same-box A/B at 4096 cameras (us per render at 100 / 20 / 5 m range): 4 / 4: 694 / 665 / 566, 3 / 7: 694 / 673 / 565, 2 / 6:
+// 685 / 683 / 563, 4 / 8: 712 / 689 / 577 -- flat.  Round 4 (bounding planes skip further): host simulation on the bench poses,
+// wave-steps per tile: 3 / 7: 9.48, 4 / 6: 9.25, 4 / 5: 9.44, 5 / 6: 9.36; on the device 3 / 7: 374.8, 4 / 6: 369.8 us per render.
 #ifndef WL_DEPTH_STEP_HOOK
 #define WL_DEPTH_STEP_HOOK(L)       // host instrumentation (walk steps per ray): nothing in the device build
 #endif
 #ifndef WL_DEPTH_START_LEVEL
-#define WL_DEPTH_START_LEVEL 3      // falling rays
+#define WL_DEPTH_START_LEVEL 4      // falling rays
 #endif
 #ifndef WL_DEPTH_START_LEVEL_UP
-#define WL_DEPTH_START_LEVEL_UP 7   // rising rays
+#define WL_DEPTH_START_LEVEL_UP 6   // rising rays
 #endif
 
 // the grid the walk runs on: cells, not metres (u = (x - x0) / cell, integer cell lines)
