@@ -10,12 +10,11 @@ using std::min;
 
 #include "wl_depth_dev.h"
 
-extern "C" {
-// pos [n][3], quat [n][4]; depth [n][60][80]; steps (optional) [n][60][80]: unused, reserved
-int hs_depth(const WlVisualParams* p, const WlHeightField* hf, int n, const float* pos, const float* quat, float max_depth, float* depth) {
+// the pyramid buffer of a field exactly as wl_heightfield_build_pyramid lays it out (header, entries, copy of the heights)
+static std::vector<float> host_pyramid(const WlHeightField* hf) {
     const Pyramid py = make_pyramid(hf->nx, hf->ny);
     const int P = 1 << py.lp;
-    std::vector<float> buf((size_t)pyramid_total_floats(hf->nx, hf->ny), -INFINITY);
+    std::vector<float> buf((size_t)pyramid_total_floats(hf->nx, hf->ny), 0.f);
     pyramid_header_serial(*hf, buf.data() + py.hdr);
     buf[0] = buf[py.hdr + kPyrMax];
     uint32_t* words = reinterpret_cast<uint32_t*>(buf.data());
@@ -24,6 +23,20 @@ int hs_depth(const WlVisualParams* p, const WlHeightField* hf, int n, const floa
             for (int I = 0; I < (P >> L); ++I)
                 words[(size_t)pyramid_level_offset(py.lp, L) + (size_t)J * (P >> L) + I] = plane_cell_serial(*hf, L, I, J, buf.data() + py.hdr);
     std::copy(hf->height, hf->height + (size_t)hf->nx * hf->ny, buf.begin() + py.h0);
+    return buf;
+}
+
+extern "C" {
+// -> number of floats; fills `out` (capacity `cap` floats) when it is large enough
+long long hs_pyramid(const WlHeightField* hf, float* out, long long cap) {
+    const std::vector<float> buf = host_pyramid(hf);
+    if (out && cap >= (long long)buf.size()) std::copy(buf.begin(), buf.end(), out);
+    return (long long)buf.size();
+}
+// pos [n][3], quat [n][4]; depth [n][60][80]
+int hs_depth(const WlVisualParams* p, const WlHeightField* hf, int n, const float* pos, const float* quat, float max_depth, float* depth) {
+    const Pyramid py = make_pyramid(hf->nx, hf->ny);
+    const std::vector<float> buf = host_pyramid(hf);
     const DepthGrid g = make_depth_grid(hf);
     const FieldMem mem{buf.data()};
     const PyrHead hd = pyramid_head(g, py, mem);

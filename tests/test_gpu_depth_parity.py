@@ -34,52 +34,13 @@ def _posed_batch(pos, quat):
 
 
 def test_pyramid_planes_bound_every_grid_point_of_their_cells(hf):
-    """the bound pyramid (round 4): entry (J, I) of level L = { uint16 c' | int8 a' | int8 b' } with a = a' qs, b = b' qs, c = c0 + c' qc
-    (header behind the heights: field maximum, qs, c0, qc); the plane a (i - I 2^L) + b (j - J 2^L) + c lies on or above EVERY grid point
-    of its 2^L x 2^L block of cells (that is all the walk's skips rely on), tightly (the largest residual of the block, one offset step
-    and a rounding hair above), and never looser at the block's centre than the block's maximum; float 0 = the field's maximum; blocks
-    that cover no cell: the word 0; behind the entries the walk's copy of the heights"""
+    """the bound pyramid as the device builds it (wl_heightfield_build_pyramid) keeps its contract: tests/depth_cases.py::check_pyramid"""
     from wheeledlab_amd.core import DepthCamera
     rough = np.random.RandomState(5).uniform(0.0, 1.5, (97, 131)).astype(np.float32)       # nothing smooth about it
     for field in (hf, (hf[0][:613, :349].copy(), hf[1], hf[2], hf[3]), (rough, -3.0, -2.0, 0.05)):
         cam = DepthCamera(field, DEV)
         torch.cuda.synchronize()
-        h = np.asarray(field[0], np.float32)
-        ny, nx = h.shape
-        Pw = 2
-        while Pw < nx - 1 or Pw < ny - 1:
-            Pw *= 2
-        pyr = cam.pyramid.cpu().numpy()
-        lp = int(np.log2(Pw))
-        h0 = max(Pw * Pw // 2, 4)
-        assert len(pyr) == h0 + nx * ny + 4 and pyr[0] == h.max()
-        np.testing.assert_array_equal(pyr[h0: h0 + nx * ny].reshape(ny, nx), h)      # the walk's copy of the heights
-        fmax, qs, c0, qc = (float(v) for v in pyr[h0 + nx * ny:])
-        steepest = max(np.abs(np.diff(h, axis=0)).max(), np.abs(np.diff(h, axis=1)).max())
-        assert fmax == h.max() and c0 == h.min() and abs(qs * 127 - steepest) <= 1e-6 * steepest   # one slope quantum per field: its steepest cell edge / 127
-        assert abs(qc * 65534 - 2 * (h.max() - h.min())) <= 1e-5 * (h.max() - h.min())                # offsets: 16 bits over twice the relief
-        words = pyr.view(np.uint32)
-        hd = h.astype(np.float64)
-        for L in range(1, lp + 1):
-            W, s = Pw >> L, 1 << L
-            off = (Pw * Pw) >> (2 * L)
-            ent = words[off: off + W * W].reshape(W, W)
-            a = (ent >> 8).astype(np.uint8).view(np.int8).astype(np.float64) * qs
-            b = ent.astype(np.uint8).view(np.int8).astype(np.float64) * qs
-            c = c0 + (ent >> 16).astype(np.float64) * qc
-            nJ, nI = min(W, (ny - 1 + s - 1) // s), min(W, (nx - 1 + s - 1) // s)
-            assert (ent[nJ:] == 0).all() and (ent[:, nI:] == 0).all() and (ent[:nJ, :nI] >> 16 > 0).all()   # blocks that cover no cell
-            step = max(1, (nJ * nI) // 4000)                                            # every block of the coarse levels, a sample of the fine
-            for k in range(0, nJ * nI, step):
-                J, I = divmod(k, nI)
-                blk = hd[J * s: min((J + 1) * s, ny - 1) + 1, I * s: min((I + 1) * s, nx - 1) + 1]
-                jj, ii = np.mgrid[0:blk.shape[0], 0:blk.shape[1]]
-                slack = c[J, I] + a[J, I] * ii + b[J, I] * jj - blk
-                half_step = 1.01 * qc                                                # the offset is rounded UP to a whole step
-                assert slack.min() >= 0.0, (L, J, I, slack.min())
-                assert slack.min() < abs(half_step) + 1e-5 * (1 + abs(c[J, I])), (L, J, I, slack.min())   # tight: it (nearly) touches a point
-                centre = c[J, I] + 0.5 * (a[J, I] * (blk.shape[1] - 1) + b[J, I] * (blk.shape[0] - 1))
-                assert centre <= blk.max() + abs(half_step) + 1e-5 * (1 + abs(blk.max())), (L, J, I)
+        DC.check_pyramid(cam.pyramid.cpu().numpy(), field[0])
 
 
 @pytest.mark.parametrize("max_depth", [100.0, 20.0])

@@ -83,6 +83,8 @@ def hostlib(tmp_path_factory):
                     os.path.join(ROOT, "tests", "host_sim", "depth_host.cpp"), "-o", str(out)], check=True)
     lib = C.CDLL(str(out))
     lib.hs_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    lib.hs_pyramid.argtypes = [C.c_void_p, C.c_void_p, C.c_longlong]
+    lib.hs_pyramid.restype = C.c_longlong
     return lib
 
 
@@ -146,3 +148,29 @@ def test_device_walk_on_rough_terrain(hostlib):
         want = D.depth(P, pos, quat, field, 50.0)
         bad, err = DC.mismatch(got, want, 50.0)
         assert bad.mean() < 5e-5, (name, int(bad.sum()), float(err.max()))
+
+
+def test_host_built_pyramid_keeps_the_bound_contract(hostlib, hf):
+    """the pyramid's entry encoding (int8 slopes, 16-bit fixed-point offsets, header) as the device functions build it, compiled for the
+    host: every plane bounds every grid point of its block, tightly (tests/depth_cases.py::check_pyramid); sized as the ABI says"""
+    from wheeledlab_amd import _abi as A
+    lib = A.load() if os.path.exists(A.LIB_PATH) else None
+    rough = np.random.RandomState(5).uniform(0.0, 1.5, (97, 131)).astype(np.float32)
+    flat = np.full((9, 17), 0.25, np.float32)                      # no relief, no slope: the header's guards
+    for field in (hf, (hf[0][:613, :349].copy(), hf[1], hf[2], hf[3]), (rough, -3.0, -2.0, 0.05)):
+        h = np.ascontiguousarray(field[0], np.float32)
+        hfs = _abi.WlHeightField(h.ctypes.data, h.shape[1], h.shape[0], float(field[1]), float(field[2]), float(field[3]), 0.0)
+        n = hostlib.hs_pyramid(C.byref(hfs), None, 0)
+        if lib is not None:
+            assert n == lib.wl_heightfield_pyramid_floats(h.shape[1], h.shape[0])
+        pyr = np.zeros(n, np.float32)
+        assert hostlib.hs_pyramid(C.byref(hfs), pyr.ctypes.data, n) == n
+        DC.check_pyramid(pyr, h)
+    hfs = _abi.WlHeightField(flat.ctypes.data, 17, 9, 0.0, 0.0, 0.05, 0.0)
+    n = hostlib.hs_pyramid(C.byref(hfs), None, 0)
+    pyr = np.zeros(n, np.float32)
+    hostlib.hs_pyramid(C.byref(hfs), pyr.ctypes.data, n)
+    fmax, qs, c0, qc = pyr[-4:]
+    assert fmax == 0.25 and qs == 1.0 and c0 == 0.25 and 0 < qc < 1e-6          # flat field: unit slope quantum, a sliver of offset range
+    words = pyr.view(np.uint32)
+    assert ((words[1:2] >> 16) > 0).all() and (words[1] & 0xffff) == 0          # the top entry: flat, just above the field
