@@ -89,27 +89,30 @@ def pmc_entry(task: str, n_envs: int):
     return None
 
 
-def rocprof_avg_us(kernel_substr):
+def rocprof_avg_us(kernels):
     """average duration of a kernel (or the sum over a list of kernels: the launches of one step) in the newest committed
     `rocprofv3 --kernel-trace --stats` summary of bench.py itself (profiles/r*_bench_kernel_stats.csv), for the reader who
-    recomputes `frac` from profiles/.  Of several instantiations of a kernel the most-called one counts."""
+    recomputes `frac` from profiles/.  A kernel is named by the substrings its row's Name must ALL contain -- a string, or a
+    tuple such as ("visual_step_kernel<", "FlatGround>") that pins the exact instantiation a section timed (the flat-ground
+    visual step, not the heightfield one of the depth task).  A tuple that still matches several rows is ambiguous: None."""
     import csv
     import glob
-    names = [kernel_substr] if isinstance(kernel_substr, str) else list(kernel_substr)
+    names = [kernels] if isinstance(kernels, (str, tuple)) else list(kernels)
+    names = [(k,) if isinstance(k, str) else tuple(k) for k in names]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")), reverse=True):
         try:
             rows = list(csv.DictReader(open(f)))
             tot, calls = 0.0, None
-            for nm in names:
-                best = None
-                for r in rows:
-                    if nm in r.get("Name", "") and (best is None or int(r["Calls"]) > best[0]):
-                        best = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
-                if best is None:
+            for subs in names:
+                hits = [r for r in rows if all(sub in r.get("Name", "") for sub in subs)]
+                if len(hits) > 1 and len(subs) == 1:      # a bare name: the most-called instantiation (the headline's 10^4 launches)
+                    hits = sorted(hits, key=lambda r: -int(r["Calls"]))[:1]
+                if len(hits) != 1:
                     tot = None
                     break
-                tot += best[1]
-                calls = best[0] if calls is None else min(calls, best[0])
+                tot += float(hits[0]["AverageNs"]) / 1e3
+                c = int(hits[0]["Calls"])
+                calls = c if calls is None else min(calls, c)
             if tot is not None:
                 return {"avg_us": tot, "calls": calls, "source": os.path.relpath(f, ROOT)}
         except (KeyError, ValueError):
@@ -362,6 +365,105 @@ def other_tasks_sweep(dev):
     return out
 
 
+MAX_LINE_BYTES = 6144     # the driver's parser lost round 4's 21.9 KB line: the final stdout line stays under this
+
+
+def _r(x, sig=4):
+    """floats to `sig` significant digits (the compact line; the side file keeps full precision)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d.get(k) for k in keys} if d else None
+
+
+def write_detail(detail, path=None):
+    """everything bench.py measured, with the per-kernel counter dicts and the prose, as a side file (default
+    gpurun_out/bench_detail.json: gpurun merges that directory back); returns the path relative to the repo, or None"""
+    path = path or os.environ.get("WL_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(detail, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as ex:     # a read-only checkout must not cost the line
+        print(f"[bench] could not write {path}: {ex!r}", file=sys.stderr, flush=True)
+        return None
+
+
+_ROOF_KEYS = ("bound", "regime", "achieved", "peak", "unit", "frac", "traffic", "frac_profile", "frac_counters", "wasted_traffic", "valu_frac",
+              "kernel", "launch_us", "bytes_per_env_step", "envs_per_launch")
+_TASK_ROOF_KEYS = ("frac", "frac_profile", "frac_counters", "wasted_traffic", "valu_frac")
+
+
+def _task_valu_frac(roof):
+    """VALU-pipe share of the task's dominant kernel from the committed counter digest (the largest over the step's kernels)"""
+    if not roof:
+        return None
+    if roof.get("valu_frac") is not None:
+        return roof["valu_frac"]
+    v = [k.get("valu_pipe_frac") for k in (roof.get("counters") or {}).values() if k.get("valu_pipe_frac") is not None]
+    return max(v) if v else None
+
+
+def compact_line(d, detail_path):
+    """the ONE JSON line the driver parses: contract keys + config + roofline + cpu_baseline + per-task / per-size digests;
+    no prose beyond the workload name, no counter dicts (those are in the side file `detail`)"""
+    line = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                               "vs_baseline", "dtype", "data")}
+    c = d["config"]
+    line["config"] = {"workload": f"drift task, {c['envs_per_gpu']} envs/GPU, flat terrain, fused step kernel, synthetic actions in HBM",
+                      "envs_per_gpu": c["envs_per_gpu"], "total_envs": c["total_envs"], "parallelism": f"env-shard x{d['n_gpus']}"}
+    line["roofline"] = _pick(d["roofline"], _ROOF_KEYS)
+    cb = d.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {**_pick(cb, ("value", "unit", "cores", "kind", "host_cores")),
+                                "sample": f"{cb['sample'].split(' ')[0]} drift mdp passes (no physics), {c['envs_per_gpu']} envs, torch-CPU"[:80],
+                                "full_step_oracle": _pick(cb.get("full_step_oracle"), ("value", "cores"))}
+    if d.get("rccl"):
+        rc = d["rccl"]
+        line["rccl"] = {**_pick(rc, ("backend", "world", "ranks_seen", "allreduce_every", "launch_us_min_over_ranks", "launch_us_max_over_ranks")),
+                        "metric_allreduce_us": (rc.get("metric_allreduce_us") or {}).get("median_max_over_ranks")}
+    else:
+        line["rccl"] = None
+    line["episode_metrics"] = d["episode_metrics"]
+    line["gpu_event_ms_per_step"] = d["gpu_event_ms_per_step"]
+    ot = {}
+    for name, o in (d.get("other_tasks") or {}).items():
+        roof = o.get("roofline") or {}
+        e = {"us": o.get("us_per_step", o.get("us_per_render")), **_pick(roof, _TASK_ROOF_KEYS)}
+        e["valu_frac"] = _task_valu_frac(roof)
+        ot[name] = e
+    if ot:
+        line["other_tasks"] = ot
+    if d.get("large_n_sweep"):
+        line["large_n_sweep"] = [{"n": r["n_envs"], "us": r["us_per_step"], "frac": r["frac_of_8TBs"], "frac_counters": r.get("frac_counters"),
+                                  "valu_frac": r.get("valu_frac"), "test": r["test"].split("::")[-1].split(" ")[0]} for r in d["large_n_sweep"]]
+    if d.get("other_tasks_large_n"):
+        line["other_tasks_large_n"] = [{"task": r["task"], "n": r["n_envs"], "us": r.get("us_per_step", r.get("us_per_render")),
+                                        "frac": r["frac_of_8TBs"], "frac_counters": r.get("frac_counters")} for r in d["other_tasks_large_n"]]
+    for k, sub in (("persistent_rollout", "env_steps_per_s"), ("policy_rollout", "env_steps_per_s"), ("training_iteration", "env_steps_per_s")):
+        if d.get(k):
+            line[k + "_env_steps_per_s"] = d[k][sub]
+    if d.get("python_surface_env_steps_per_s"):
+        line["python_surface_env_steps_per_s"] = d["python_surface_env_steps_per_s"]
+    line["detail"] = detail_path
+    out = _r(line)
+    # the contract's own figures keep full precision: the driver recomputes value from ms_per_step
+    for k in ("value", "ms_per_step"):
+        out[k] = d[k]
+    out["roofline"]["achieved"], out["roofline"]["frac"] = d["roofline"]["achieved"], d["roofline"]["frac"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -376,6 +478,8 @@ def main():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--sweep-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--headline-only", action="store_true", help="only the timed headline workload: no secondary sections, no CPU baseline")
+    ap.add_argument("--detail-out", default=None, help="side file for everything measured (default gpurun_out/bench_detail.json)")
+    ap.add_argument("--print-detail", action="store_true", help="also print the full detail as an earlier stdout line prefixed `[bench detail] `")
     args = ap.parse_args()
     if args.sweep_child:
         assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
@@ -546,7 +650,7 @@ def main():
     # which roofline binds: at the BASELINE size the state is L2 / Infinity-Cache resident and one wavefront per SIMD
     # issues dependent instructions -- launch floor + instruction latency, not bandwidth; the HBM fraction is reported
     # regardless (the contract's metric) and the sweep below shows the regime where bandwidth and the VALU pipe bind
-    bound = "latency" if n <= 32768 else "valu+hbm"
+    regime = "latency" if n <= 32768 else "valu+hbm"
 
     # secondary: the same K-step rollouts as ONE persistent launch each (state in registers across steps; only possible
     # with pre-staged actions, so it is NOT the headline; the policy-in-the-loop form follows)
@@ -661,7 +765,7 @@ def main():
                                                          profile_kernels=["elev_step_scan_kernel"] if n == ENVS_PER_GPU else None)
             else:
                 other[name]["roofline"] = roofline_block("visual", n, us, "visual_step_kernel + visual_obs_kernel", "hbm+lds",
-                                                         profile_kernels=["visual_step_kernel", "visual_obs_kernel"] if n == ENVS_PER_GPU else None)
+                                                         profile_kernels=[("visual_step_kernel<", "FlatGround>("), "visual_obs_kernel"] if n == ENVS_PER_GPU else None)
                 t.observe()
                 torch.cuda.synchronize()
                 q0.record()
@@ -757,7 +861,7 @@ def main():
                                  "workload": f"{n} elevation-task cars on the synthetic 800 x 800 heightfield (0.05 m), max depth 100 m",
                                  "roofline": roofline_block("depth", n, dus, "visual_depth_tile_kernel",
                                                             "valu issue + divergence (max-pyramid walk; the image write is the only HBM stream)",
-                                                            profile_kernels=["visual_depth_tile_kernel"] if n == ENVS_PER_GPU else None)}
+                                                            profile_kernels=[("visual_depth_tile_kernel<0>",)] if n == ENVS_PER_GPU else None)}
         # this kernel's governing roofline is the VALU pipe, not HBM: instructions issued x 2 cycles / (1024 SIMDs x shader cycles)
         dc = (other["visual_depth"]["roofline"].get("counters") or {}).get("visual_depth_tile_kernel") or {}
         other["visual_depth"]["roofline"]["valu_frac"] = dc.get("valu_pipe_frac")
@@ -819,7 +923,9 @@ def main():
                         f"depth image 60 x 80 clipped at {t.max_depth:g} m as observation",
             "hit_fraction": float((t.obs[:, :4800] < t.max_depth).float().mean()),
             "roofline": roofline_block("visual_depth", n, us, "visual_step_kernel<HeightFieldGround> + visual_depth_tile_kernel",
-                                       "valu issue + divergence (the depth walk) + latency (40 dependent sub-steps with terrain gathers)"),
+                                       "valu issue + divergence (the depth walk) + latency (40 dependent sub-steps with terrain gathers)",
+                                       profile_kernels=[("visual_step_kernel<", "HeightFieldGround>("), ("visual_depth_tile_kernel<1>",)]
+                                       if n == ENVS_PER_GPU else None),
             "test": "tests/test_gpu_visual_depth_task.py"}
         del t, a
 
@@ -868,7 +974,7 @@ def main():
         frac_profile = BYTES_PER_ENV_STEP * n / (prof["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS if prof and n == ENVS_PER_GPU else None
         pe = pmc_entry("drift", n)
         frac_counters = pe.get("frac_counters") if pe and not pe["stale"] else None
-        line = {
+        detail = {
             "metric": "env steps/sec (whole node), drift task @ 4096 envs/GPU",
             "value": total_envs * args.steps / wall,
             "unit": "env-steps/s",
@@ -887,7 +993,9 @@ def main():
                        "mean_value": total_envs * args.steps / wall_mean, "mean_ms_per_step": wall_mean * 1e3 / args.steps,
                        "metric_reductions_in_timed_blocks": reductions_in_timed_blocks, "allreduce_every": every},
             "rccl": rccl,
-            "roofline": {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound` names the roofline `peak` belongs to (the contract: "hbm" | "mfma"); `regime` says what actually limits the
+            # launch at this size
+            "roofline": {"bound": "hbm", "regime": regime, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
                          "valu_frac": sq.get("valu_pipe_frac") if sq else None, "sq_counters": sq,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
@@ -899,18 +1007,27 @@ def main():
             "episode_metrics": {"resets": float(metric_sum[8]), "timeouts": float(metric_sum[9]),
                                 "out_of_bounds": float(metric_sum[10]), "nonfinite": float(metric_sum[14])},
         }
-        line["python_surface_env_steps_per_s"] = py_rate
-        line["persistent_rollout"] = persistent
-        line["policy_rollout"] = policy
-        line["training_iteration"] = train
-        line["other_tasks"] = other
+        detail["python_surface_env_steps_per_s"] = py_rate
+        detail["persistent_rollout"] = persistent
+        detail["policy_rollout"] = policy
+        detail["training_iteration"] = train
+        detail["other_tasks"] = other
         if sweep:
-            line["large_n_sweep"] = sweep
+            detail["large_n_sweep"] = sweep
         if other_sweep:
-            line["other_tasks_large_n"] = other_sweep
+            detail["other_tasks_large_n"] = other_sweep
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n)
-        print(json.dumps(line), flush=True)
+            detail["cpu_baseline"] = cpu_baseline(n)
+        # The driver parses the LAST stdout line; round 4's grew to 21.9 KB and was not parsed.  Everything measured goes to a
+        # side file (and, on request, to an earlier stdout line that does not start with `{`); the one JSON line is the compact
+        # digest of it, asserted below to stay under 6 KB.
+        detail_path = write_detail(detail, args.detail_out)
+        line = compact_line(detail, detail_path)
+        text = json.dumps(line, separators=(",", ":"))
+        assert len(text) < MAX_LINE_BYTES, f"bench line grew to {len(text)} bytes (limit {MAX_LINE_BYTES}): trim compact_line()"
+        if args.print_detail:
+            print("[bench detail] " + json.dumps(detail), flush=True)
+        print(text, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

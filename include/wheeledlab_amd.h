@@ -110,7 +110,8 @@ typedef struct WlActionParams {
     int32_t bounding;         /* 0 none, 1 clip(-1,1), 2 tanh                                                 */
     int32_t no_reverse;       /* clamp processed throttle >= 0                                                */
     int32_t clip_wrapper;     /* 1: apply the ClipAction wrapper (clip_action.py:27) before everything        */
-    int32_t map;              /* 0 RCCarRWDAction, 1 RCCar4WDAction (rc_car_actions.py:12-29 / 36-64)         */
+    int32_t map;              /* 0 RCCarRWDAction, 1 RCCar4WDAction (rc_car_actions.py:12-29 / 36-64), 2 the base
+                               * class AckermannAction: true Ackermann angles (ackermann_actions.py:150-201)   */
     float base_length, base_width, wheel_radius;
 } WlActionParams;
 

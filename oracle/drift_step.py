@@ -21,6 +21,8 @@ def targets(p, a_raw):
         wheel = np.concatenate([wr, np.zeros_like(wr)], -1)
     else:
         steer, wheel = M.fwd_targets(proc[:, 0], proc[:, 1], p.action)
+        if p.action.map == 2:   # base-class AckermannAction: the joints take angles; the single-track model steers by their
+            steer = np.stack([proc[:, 1], proc[:, 1]], -1)   # centre-line equivalent atan(L / R) = delta
     return steer[:, 0].astype(F), wheel.astype(F)
 
 

@@ -119,6 +119,12 @@ class SceneEntityCfg:
         self.joint_ids = joint_ids
         self.body_ids = body_ids
 
+    def resolve(self, scene):       # isaaclab: names -> indices on the scene entity
+        if self.body_names is not None:
+            self.body_ids = scene[self.name].find_bodies(self.body_names)[0]
+        if self.joint_names is not None:
+            self.joint_ids = scene[self.name].find_joints(self.joint_names)[0]
+
 
 # ---- published IsaacLab 2.0.2 math (restated; NOT reference-owned -> parity unpinned) ------------
 
@@ -186,6 +192,14 @@ class FakeAsset:
                 ids.append(i)
                 names.append(n)
         return ids, names
+
+    body_names = ["base_link", "back_left_wheel_link", "back_right_wheel_link", "front_left_wheel_link", "front_right_wheel_link"]
+
+    def find_bodies(self, name_keys):
+        if isinstance(name_keys, str):
+            name_keys = [name_keys]
+        ids = [i for i, n in enumerate(self.body_names) if any(re.fullmatch(k, n) for k in name_keys)]
+        return ids, [self.body_names[i] for i in ids]
 
     def set_joint_velocity_target(self, t, joint_ids=None):
         self.vel_target = (t.clone(), list(joint_ids))
@@ -702,6 +716,69 @@ def gen_visual_terms(st_seed=8):
     res["out_of_map"] = npy(V.out_of_map(env))
     res["weights"] = np.array([V.VisualRewardsCfg.traversablility.weight, V.VisualRewardsCfg.vel_rew.weight], np.float32)
     np.savez_compressed(os.path.join(OUT, "visual_mdp.npz"), **res)
+    gen_visual_unwired(V, st, env)
+
+
+def gen_visual_unwired(V, st, env):
+    """the term functions the visual cfg module DEFINES but does not register (mushr_visual_env_cfg.py:314-368,400-403): their
+    outputs on 512 states spread over the 250 m map (+ wheel-link positions as an independent input, roll angles over the whole
+    circle for roll_over, a second position set on the drift-track scale for off_track), so that the build's torch restatements
+    (wheeledlab_amd/envs/mdp.py) are pinned to the reference too"""
+    n = st["pos"].shape[0]
+    rng = np.random.RandomState(11 + SEED_OFFSET)
+    # half of the cars near the paths (a random traversable cell + up to 0.4 m: wheels on and off the path), half anywhere
+    TU = importlib.import_module("wheeledlab_tasks.visual.utils.traversability_utils")
+    util = TU.TraversabilityHashmapUtil()
+    m = np.asarray(torch.as_tensor(util.traversability_hashmap).cpu().numpy(), bool)
+    cells = np.argwhere(m)                         # (y_idx, x_idx)
+    pick = cells[rng.randint(0, len(cells), n // 2)]
+    st = {k: v.copy() for k, v in st.items()}
+    st["pos"][: n // 2, 0] = pick[:, 1] * 0.5 - 125.0 + rng.uniform(-0.4, 0.4, n // 2)
+    st["pos"][: n // 2, 1] = pick[:, 0] * 0.5 - 125.0 + rng.uniform(-0.4, 0.4, n // 2)
+    terrain = env.scene["terrain"]
+    env = env_from_state(st)
+    env.scene["terrain"] = terrain
+    # wheel links: the root position + a body-frame offset per wheel, + the root link itself as body 0 (what `.*wheel_link` must skip)
+    off = np.array([[0.0, 0.0], [-0.16, 0.1], [-0.16, -0.1], [0.16, 0.1], [0.16, -0.1]], np.float32)
+    yaw = rng.uniform(0, 2 * math.pi, n).astype(np.float32)
+    c, s_ = np.cos(yaw), np.sin(yaw)
+    body = np.zeros((n, 5, 3), np.float32)
+    body[:, :, 0] = st["pos"][:, None, 0] + c[:, None] * off[None, :, 0] - s_[:, None] * off[None, :, 1]
+    body[:, :, 1] = st["pos"][:, None, 1] + s_[:, None] * off[None, :, 0] + c[:, None] * off[None, :, 1]
+    body[:, :, 2] = 0.05
+    # a quarter of the cars straddle a cell line (cells of 0.5 m): wheels on both sides of it
+    k = np.arange(0, n, 4)
+    body[k, :, 0] += (np.round(body[k, 0, 0] / 0.5) * 0.5 - 0.25 - body[k, 0, 0])[:, None]
+    env.scene["robot"].data.body_pos_w = torch.from_numpy(body.copy())
+    # roll over the whole circle (the function subtracts pi from an angle wrapped to [0, 2 pi))
+    roll = rng.uniform(-math.pi, math.pi, n)
+    quat = quat_from_euler_xyz(torch.tensor(roll, dtype=torch.float32), torch.zeros(n), torch.tensor(yaw)).numpy().astype(np.float32)
+    env.scene["robot"].data.root_quat_w = torch.from_numpy(quat.copy())
+    out = dict(pos=st["pos"], quat=quat, lin_vel_b=st["lin_vel_b"], body_pos_w=body)
+    env.common_step_counter, env.max_episode_length = 999 * 50 + 49, 50
+    out["bool_is_not_traversable_early"] = npy(V.bool_is_not_traversable(env))
+    env.common_step_counter = 1000 * 50
+    out["bool_is_not_traversable_late"] = npy(V.bool_is_not_traversable(env))
+    out["counters"] = np.array([999 * 50 + 49, 1000 * 50, 50], np.int64)
+    out["is_traversable"] = npy(V.is_traversable(env))
+    out["is_traversable_speed_scaled"] = npy(V.is_traversable_speed_scaled(env))
+    out["is_traversable_wheels"] = npy(V.is_traversable_wheels(env))
+    out["binary_is_traversable_wheels"] = npy(V.binary_is_traversable_wheels(env))
+    out["vel_rew_trav"] = npy(V.vel_rew_trav(env))
+    out["vel_rew_trav_2_3"] = npy(V.vel_rew_trav(env, 2.0, 3.0))
+    out["low_speed_penalty"] = npy(V.low_speed_penalty(env))
+    out["low_speed_penalty_2"] = npy(V.low_speed_penalty(env, 2.0))
+    out["roll_over"] = npy(V.roll_over(env))
+    # off_track on the drift track's scale (the function is the drift cfg's, copied into the visual module)
+    st2 = make_state(n, 12)
+    env2 = env_from_state(st2)
+    out["pos_track"] = st2["pos"]
+    out["off_track"] = npy(V.off_track(env2, 0.8, 2.0))
+    out["off_track_1"] = npy(V.off_track(env2, 0.8, 1.0))
+    # the map the reference's singleton holds (what the terms above looked up)
+    out["map_packed"], out["map_shape"] = np.packbits(m), np.array(m.shape, np.int64)
+    out["spacing"] = np.array([util.row_spacing, util.col_spacing], np.float64)
+    np.savez_compressed(os.path.join(OUT, "visual_unwired.npz"), **out)
 
 
 def main():

@@ -125,6 +125,19 @@ def test_action_map_matches_reference_golden(lib, golden):
             assert (w[:, 2:] == 0).all()
         else:
             np.testing.assert_allclose(w, g[f"{tag}_wheel_vel_target"], rtol=2e-5, atol=1e-3)
+    # map 2: the base class AckermannAction (ackermann_actions.py:150-201; tanh bounding, reverse allowed): the steer joints take
+    # the true Ackermann angles atan(L / (R -+ W / 2)), the wheels the 4WD speeds -- against the reference's own outputs
+    ap = PP.mushr_action(2)
+    ap.clip_wrapper, ap.bounding, ap.no_reverse = 0, 2, 0
+    proc, st, wh = torch.zeros(n, 2, device=DEV), torch.zeros(n, 2, device=DEV), torch.zeros(n, 4, device=DEV)
+    assert lib.wl_action_map(C.byref(ap), n, a.data_ptr(), proc.data_ptr(), st.data_ptr(), wh.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(proc.cpu().numpy(), g["base_processed"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(st.cpu().numpy(), g["base_steer_pos_target"], rtol=1e-5, atol=2e-6)
+    assert (np.abs(g["base_steer_pos_target"][:, 0] - g["base_steer_pos_target"][:, 1]) > 1e-3).any()      # left != right: not the tan map
+    np.testing.assert_allclose(wh.cpu().numpy(), g["base_wheel_vel_target"], rtol=2e-5, atol=1e-3)
+    ap.map = 3
+    assert lib.wl_action_map(C.byref(ap), n, a.data_ptr(), proc.data_ptr(), st.data_ptr(), wh.data_ptr(), None) == -1      # WL_EINVAL
 
 
 def _fresh(n, seed=3, **kw):

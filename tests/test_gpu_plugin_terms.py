@@ -188,7 +188,30 @@ def test_visual_depth_observation_term_through_the_scene_camera():
     cfg.observations.policy.depth = ObsTerm(func=ref_style, params=dict(sensor_cfg=SceneEntityCfg("camera")), clip=(0.0, 20.0))
     env = registry.make("Isaac-MushrVisualRL-v0", cfg=cfg)
     assert env.observation_manager.group_obs_dim["policy"] == (3208 + 4800,)
+    # the constructor's shape probe ran the term on the un-reset state (all cars at the origin): nothing of it may survive into the
+    # first observation -- the scene camera caches one render per (step, pose epoch), and reset() starts a new epoch
+    cam = env.scene.sensors["camera"].data
+    assert cam._cached == (None, None)
     obs, _ = env.reset()
+    fresh = cam._camera().render(env._batch, cam.far)
+    assert torch.equal(obs["policy"][:, 3208:], fresh.reshape(n, -1).clamp(0.0, 20.0))
+    assert (fresh[1:] != fresh[:1]).any()                                  # spawned at different cells: not the probe's image
+    # a second reset without a step in between moves the cars again: again a fresh render
+    obs, _ = env.reset()
+    again = cam._camera().render(env._batch, cam.far)
+    assert torch.equal(obs["policy"][:, 3208:], again.reshape(n, -1).clamp(0.0, 20.0))
+    # a plugin's pose write (what a user reset event does) invalidates the cached image as well
+    before = mdp.camera_data_depth(env).clone()
+    robot = env.scene["robot"]
+    pose = torch.cat([robot.data.root_pos_w, robot.data.root_quat_w], 1)
+    pose[:, 2] += 0.5
+    robot.write_root_pose_to_sim(pose)
+    lifted = mdp.camera_data_depth(env)
+    assert not torch.equal(lifted, before)
+    assert torch.equal(lifted[..., 0], cam._camera().render(env._batch, cam.far))
+    pose[:, 2] -= 0.5
+    robot.write_root_pose_to_sim(pose)
+    assert torch.equal(mdp.camera_data_depth(env), before)
     for _ in range(5):
         obs, *_ = env.step(torch.rand(n, 2, device=DEV) * 2 - 1)
     d = mdp.raycast_depth(env)
@@ -212,3 +235,82 @@ def test_visual_depth_observation_term_through_the_scene_camera():
         dm = mdp.camera_data_depth(env)[..., 0]
         assert torch.equal(dm == val, d[..., 0] >= 100.0) and torch.equal(dm[d[..., 0] < 100.0], d[..., 0][d[..., 0] < 100.0]), mode
     cam.beyond = None
+
+
+def test_visual_unwired_terms_wired_through_a_config_override():
+    """the term functions the reference's visual cfg module defines without registering them (mushr_visual_env_cfg.py:314-368,
+    400-403; pinned to the reference's outputs on CPU: tests/test_plugin_terms_cpu.py) wired in as the reference's users would --
+    `is_traversable_wheels` / `vel_rew_trav` as rewards, `binary_is_traversable_wheels` as a termination, `roll_over` and
+    `low_speed_penalty` read directly -- run as torch terms behind the fused kernel.  Checked against a twin batch stepped with the
+    same kernel and the formulas written out on the twin's post-step state (wheel centres from the oracle's rotation matrix, the map
+    lookup from the reference's index arithmetic)."""
+    from oracle.mathlib import matrix_from_quat
+    from wheeledlab_amd.core import VisualBatch
+    from wheeledlab_amd.envs import mdp
+    from wheeledlab_amd.envs.managers_cfg import RewardTermCfg as RewTerm
+    from wheeledlab_amd.envs.managers_cfg import TerminationTermCfg as DoneTerm
+    n = 256
+    registry, cfg = _cfg("Isaac-MushrVisualRL-v0", n)
+    cfg.rewards.wheels = RewTerm(func=mdp.is_traversable_wheels, weight=0.5)
+    cfg.rewards.speed = RewTerm(func=mdp.vel_rew_trav, weight=2.0, params=dict(speed_target_on_trav=1.0, speed_target_on_non_trav=2.0))
+    cfg.terminations.all_wheels_off = DoneTerm(func=mdp.binary_is_traversable_wheels)
+    env = registry.make("Isaac-MushrVisualRL-v0", cfg=cfg)
+    b = env._batch
+    assert env._has_custom_rewards and "all_wheels_off" in env.termination_manager.active_terms
+    tmap, (rs, cs) = env.traversability
+    tm = tmap.cpu().numpy().astype(bool)
+    rows, cols = tm.shape
+    v = b.p.vehicle
+    local = np.array([[-v.half_wheelbase_r, v.half_track, v.wheel_z], [-v.half_wheelbase_r, -v.half_track, v.wheel_z],
+                      [v.half_wheelbase_f, v.half_track, v.wheel_z], [v.half_wheelbase_f, -v.half_track, v.wheel_z]], np.float32)
+
+    def lookup(xy):
+        xi = np.clip(((xy[..., 0] + np.float32(rows * rs / 2.0) + np.float32(rs / 2.0)) / np.float32(rs)).astype(np.int64), 0, rows - 1)
+        yi = np.clip(((xy[..., 1] + np.float32(cols * cs / 2) + np.float32(cs / 2)) / np.float32(cs)).astype(np.int64), 0, cols - 1)
+        return tm[yi, xi]
+
+    env.reset()
+    # the scene view of the wheel links against the geometry written out
+    st = b.state[:, :n].cpu().numpy()
+    want_body = st[0:3].T[:, None, :] + np.einsum("nij,bj->nbi", matrix_from_quat(st[3:7].T), local)
+    cfgw = mdp.SceneEntityCfg("robot", body_names=".*wheel_link").resolve(env.scene)
+    got_body = env.scene["robot"].data.body_pos_w[:, cfgw.body_ids].cpu().numpy()
+    np.testing.assert_allclose(got_body, want_body, rtol=1e-5, atol=1e-5)
+    assert mdp.roll_over(env).dtype == torch.bool and mdp.low_speed_penalty(env).shape == (n,)
+    assert not mdp.bool_is_not_traversable(env).any()                   # fewer than 1000 episodes so far: the delayed term is off
+    twin = VisualBatch(n, device=DEV, seed=b.seed, params=b.p, startup=env._flat.startup, trav_map=tm,
+                       spacing=(rs, cs))
+    g = torch.Generator(device=DEV).manual_seed(4)
+    dt = cfg.sim.dt * cfg.decimation
+    ended = 0
+    for k in range(12):
+        twin.state.copy_(b.state)
+        twin.episode_len.copy_(b.episode_len)
+        twin.step_count = b.step_count
+        a = torch.rand(n, 2, device=DEV, generator=g) * 2 - 1
+        a[:, 0] = a[:, 0].abs()
+        o, rew, term, trunc, extras = env.step(a)
+        rew, term = rew.clone(), term.clone()
+        _, r2, t2, u2 = twin.step(a)
+        live = ~(t2 | u2).cpu().numpy()
+        s = twin.state[:, :n].cpu().numpy()
+        R = matrix_from_quat(s[3:7].T)
+        wheels = s[0:3].T[:, None, :] + np.einsum("nij,bj->nbi", R, local)
+        on = lookup(wheels[..., :2])                                              # [n, 4]
+        r_wheels = np.where(on, 1.0, -5.0).sum(-1)
+        vb = np.einsum("nji,nj->ni", R, s[7:10].T)
+        target = np.where(lookup(s[0:2].T), 1.0, 2.0)
+        sd = -((np.linalg.norm(vb, axis=-1) - target) ** 2) + target ** 2
+        r_speed = np.where(sd > 0, sd, 0.0)
+        extra = np.where(live, (0.5 * r_wheels + 2.0 * r_speed) * dt, 0.0)
+        # a wheel within a hair of a cell line may round to the other cell: those envs are excused from the reward comparison
+        frac = (wheels[..., :2] + 125.25) / 0.5
+        near = (np.abs(frac - np.round(frac)) < 1e-3).any(axis=(1, 2))
+        d = np.abs(rew.cpu().numpy() - (r2.cpu().numpy() + extra))
+        assert (d[~near] < 2e-4 + 2e-4 * np.abs(extra[~near])).all(), (k, d[~near].max())
+        off = (~on).all(-1) & live
+        assert np.array_equal(term.cpu().numpy()[~near], (t2.cpu().numpy() | off)[~near])
+        ended += int(off.sum())
+        assert "Episode_Reward/wheels" in extras["log"] and "Episode_Termination/all_wheels_off" in extras["log"]
+    assert ended > 0                                                             # cars do leave the paths within 12 steps
+    env.close()

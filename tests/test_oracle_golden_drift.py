@@ -187,7 +187,7 @@ def test_committed_vectors_regenerate_from_the_reference(tmp_path):
     env = dict(os.environ, WL_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
     subprocess.run([sys.executable, os.path.join(here, "gen_golden.py")], check=True, env=env, capture_output=True, timeout=600)
     names = sorted(f for f in os.listdir(here) if f.endswith(".npz"))
-    assert names == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) and len(names) == 9
+    assert names == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) and len(names) == 10
     for f in names:
         a, b = np.load(os.path.join(here, f)), np.load(tmp_path / f)
         assert set(a.files) == set(b.files), f
@@ -207,6 +207,7 @@ def test_oracle_matches_the_reference_on_fresh_seeds(tmp_path, offset):
     subprocess.run([sys.executable, os.path.join(here, "golden", "gen_golden.py")], check=True, env=env, capture_output=True, timeout=600)
     env = dict(os.environ, WL_GOLDEN_DIR=str(tmp_path))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.join(here, "test_oracle_golden_drift.py"),
-                        os.path.join(here, "test_oracle_golden_elev_visual.py"), "-k", "not regenerate and not fresh_seeds"],
+                        os.path.join(here, "test_oracle_golden_elev_visual.py"), os.path.join(here, "test_plugin_terms_cpu.py"),
+                        "-k", "not regenerate and not fresh_seeds"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]

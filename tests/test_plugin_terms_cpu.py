@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from wheeledlab_amd.envs import mdp
-from wheeledlab_amd.envs.scene import MUSHR_JOINT_NAMES, ArticulationView
+from wheeledlab_amd.envs.scene import MUSHR_BODY_NAMES, MUSHR_JOINT_NAMES, ArticulationView
 
 
 class _Data:
@@ -59,3 +59,86 @@ def test_unwired_elevation_reward_functions_match_the_reference(golden):
     second = mdp.elevation_continuity(env2, 0.1)
     np.testing.assert_allclose(second.numpy(), g["elevation_continuity_second"], rtol=1e-4, atol=1e-5)
     assert np.abs(g["elevation_continuity_second"]).max() > 0
+
+
+# ---- the visual cfg module's unwired terms (mushr_visual_env_cfg.py:314-368,400-403) against the reference's own outputs --------
+
+def _make_visual_env(g, pos_key="pos"):
+    """a fake env over the golden inputs: state views, wheel-link positions as the reference's test input gave them, and the
+    reference singleton's map as `env.traversability`"""
+    n = g["pos"].shape[0]
+    t = lambda k: torch.from_numpy(g[k].copy())   # noqa: E731
+    data = types.SimpleNamespace(root_pos_w=t(pos_key), root_quat_w=t("quat"), root_lin_vel_b=t("lin_vel_b"), body_pos_w=t("body_pos_w"))
+    robot = types.SimpleNamespace(data=data, body_names=list(MUSHR_BODY_NAMES))
+    robot.find_bodies = types.MethodType(ArticulationView.find_bodies, robot)
+    rows, cols = (int(v) for v in g["map_shape"])
+    tmap = torch.from_numpy(np.unpackbits(g["map_packed"])[: rows * cols].reshape(rows, cols).astype(np.uint8))
+    return types.SimpleNamespace(scene=_Scene(robot, n), num_envs=n, device="cpu", traversability=(tmap, tuple(float(v) for v in g["spacing"])),
+                                 common_step_counter=0, max_episode_length=50)
+
+
+def test_unwired_visual_terms_match_the_reference(golden):
+    g = golden("visual_unwired")
+    env = _make_visual_env(g)
+    env.common_step_counter, env.max_episode_length = int(g["counters"][0]), int(g["counters"][2])
+    early = mdp.bool_is_not_traversable(env)
+    env.common_step_counter = int(g["counters"][1])
+    cases = {
+        "bool_is_not_traversable_early": early,
+        "bool_is_not_traversable_late": mdp.bool_is_not_traversable(env),
+        "is_traversable_speed_scaled": mdp.is_traversable_speed_scaled(env),
+        "is_traversable_wheels": mdp.is_traversable_wheels(env),
+        "binary_is_traversable_wheels": mdp.binary_is_traversable_wheels(env),
+        "vel_rew_trav": mdp.vel_rew_trav(env),
+        "vel_rew_trav_2_3": mdp.vel_rew_trav(env, 2.0, 3.0),
+        "low_speed_penalty": mdp.low_speed_penalty(env),
+        "low_speed_penalty_2": mdp.low_speed_penalty(env, 2.0),
+        "roll_over": mdp.roll_over(env),
+    }
+    for name, got in cases.items():
+        want = g[name]
+        assert tuple(got.shape) == want.shape, name
+        if want.dtype == bool:
+            assert got.dtype == torch.bool, name
+            np.testing.assert_array_equal(got.numpy(), want, err_msg=name)
+        else:
+            np.testing.assert_allclose(got.numpy(), want, rtol=1e-6, atol=1e-6, err_msg=name)
+    assert not g["bool_is_not_traversable_early"].any() and g["bool_is_not_traversable_late"].any()      # the 1000-episode delay
+    assert len(np.unique(g["is_traversable_wheels"])) == 5                  # 0 .. 4 wheels on the path: every mix occurs
+    assert 0.2 < g["roll_over"].mean() < 0.8
+    # off_track: the drift cfg's function, defined again in the visual module -- here the torch form (non-drift envs)
+    env2 = _make_visual_env(g, "pos_track")
+    for name, r_out in (("off_track", 2.0), ("off_track_1", 1.0)):
+        got = mdp.off_track(env2, 0.8, r_out)
+        assert got.dtype == torch.int64
+        np.testing.assert_array_equal(got.numpy(), g[name], err_msg=name)
+        assert 0 < g[name].mean() < 1
+
+
+def test_wheel_link_positions_follow_the_vehicle_geometry():
+    """ArticulationData.body_pos_w: root pose (+) the wheel-centre offsets the step kernels use (wl_vehicle.h::wheel_contact),
+    held against the oracle's rotation matrix; `.*wheel_link` selects bodies 1..4"""
+    from oracle.mathlib import matrix_from_quat
+    from wheeledlab_amd.envs.managers_cfg import SceneEntityCfg
+    from wheeledlab_amd.envs.scene import ArticulationData
+    from wheeledlab_amd.params import visual_params
+    rng = np.random.RandomState(0)
+    n = 64
+    q = rng.normal(size=(n, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    pos = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    state = torch.zeros(41, n)
+    state[0:3], state[3:7] = torch.from_numpy(pos.T), torch.from_numpy(q.T)
+    p = visual_params()
+    batch = types.SimpleNamespace(state=state, n=n, device="cpu", p=p)
+    body = ArticulationData(batch).body_pos_w
+    assert body.shape == (n, 5, 3)
+    v = p.vehicle
+    local = np.array([[0, 0, 0], [-v.half_wheelbase_r, v.half_track, v.wheel_z], [-v.half_wheelbase_r, -v.half_track, v.wheel_z],
+                      [v.half_wheelbase_f, v.half_track, v.wheel_z], [v.half_wheelbase_f, -v.half_track, v.wheel_z]], np.float32)
+    want = pos[:, None, :] + np.einsum("nij,bj->nbi", matrix_from_quat(q), local)
+    np.testing.assert_allclose(body.numpy(), want, rtol=1e-5, atol=1e-5)
+    robot = types.SimpleNamespace(body_names=list(MUSHR_BODY_NAMES))
+    robot.find_bodies = types.MethodType(ArticulationView.find_bodies, robot)
+    cfg = SceneEntityCfg("robot", body_names=".*wheel_link").resolve({"robot": robot})
+    assert cfg.body_ids == [1, 2, 3, 4]

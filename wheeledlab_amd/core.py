@@ -55,6 +55,12 @@ class _MetricsView:
         m = self.metrics_raw.sum(1)
         return m[0] if self.metrics_slots == 1 else m
 
+    pose_epoch = 0       # bumped by everything that moves cars WITHOUT advancing step_count (resets, plugin pose writes)
+
+    def touch_pose(self):
+        """anything cached per env.step() from the poses (the scene camera's render) is stale after this"""
+        self.pose_epoch = self.pose_epoch + 1
+
     def set_flags(self, flags: int = 0):
         """WlEnvBuffers.flags (_abi.FLAG_*): force an instantiation the launchers otherwise pick from the batch size -- the
         streaming (non-temporal store) forms, the cache-allocating forms, the height scan through LDS patches or through
@@ -140,6 +146,7 @@ class DriftBatch(_MetricsView):
         self._out.dones = self.dones.data_ptr() if on else None
 
     def reset(self, mask: torch.Tensor | None = None):
+        self.touch_pose()
         m = None if mask is None else mask.to(torch.uint8).contiguous()
         A.check(self.lib.wl_drift_reset(C.byref(self.p), C.byref(self._bufs), None if m is None else m.data_ptr(),
                                         self.seed, self.step_count, self._stream()), "wl_drift_reset")
@@ -277,6 +284,7 @@ class ElevBatch(_MetricsView):
         self._bufs.lanes = lanes
 
     def reset(self, mask: torch.Tensor | None = None):
+        self.touch_pose()
         m = None if mask is None else mask.to(torch.uint8).contiguous()
         A.check(self.lib.wl_elev_reset(C.byref(self.p), C.byref(self._bufs), C.byref(self._hf),
                                        None if m is None else m.data_ptr(), self.seed, self.step_count, self._stream()),
@@ -443,6 +451,7 @@ class VisualBatch(_MetricsView):
         self.p.contrast_first = int(order.index(1) < order.index(0))
 
     def reset(self, mask: torch.Tensor | None = None):
+        self.touch_pose()
         m = None if mask is None else mask.to(torch.uint8).contiguous()
         A.check(self.lib.wl_visual_reset(C.byref(self.p), C.byref(self._bufs), C.byref(self._map),
                                          None if m is None else m.data_ptr(), self.seed, self.step_count, self._stream()),
@@ -521,6 +530,7 @@ class VisualDepthBatch(VisualBatch):
                                 self.truncated.data_ptr(), self.dones.data_ptr())
 
     def reset(self, mask: torch.Tensor | None = None):
+        self.touch_pose()
         m = None if mask is None else mask.to(torch.uint8).contiguous()
         A.check(self.lib.wl_visual_reset_hf(C.byref(self.p), C.byref(self._bufs), C.byref(self._map), C.byref(self._hf),
                                             None if m is None else m.data_ptr(), self.seed, self.step_count, self._stream()),

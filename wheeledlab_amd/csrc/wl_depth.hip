@@ -117,6 +117,9 @@ WL_DEV DepthCam depth_cam(const WlVisualParams& p, const WlEnvBuffers& b, int e)
 
 // one ray per lane, one 4 x 16 tile per wavefront: the wavefront lives as long as its longest ray (lanes busy 0.6 of the steps on
 // the bench poses) -- and is still the fastest form measured (the ray-pool form below: 1.3 - 2 x slower).
+// ROWS names what the launch writes -- 0: the 60 x 80 image of wl_visual_depth, 1: the observation rows of the visual-depth task
+// (stride 4808) -- same code; two instantiations so that a kernel-statistics summary keeps the two workloads apart.
+template <int ROWS>
 __global__ void __launch_bounds__(64) visual_depth_tile_kernel(const WlVisualParams p, const WlEnvBuffers b, const DepthGrid g,
                                                                 const Pyramid py, const float* __restrict__ buf, const unsigned buf_bytes,
                                                                 const float max_depth, float* __restrict__ depth, const int64_t row_stride) {
@@ -256,13 +259,21 @@ int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* 
     return launch_status();
 }
 
-int wl_visual_depth_rows(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
-                         float* rows, int64_t row_stride, void* stream) {
-    if (!p || !b || !hf || !b->state || !hf->height || !pyramid || !rows || b->n_envs <= 0 || !(max_depth > 0.f)) return WL_EINVAL;
+// every argument check of the depth launch, so that callers that launch something in front of it (wl_visual_depth_step: the step
+// kernel advances state, episode_len and metrics) can refuse the WHOLE call before anything has run
+static int depth_rows_args_ok(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
+                              const float* rows, int64_t row_stride) {
+    if (!p || !b || !hf || !b->state || !hf->height || !pyramid || !rows || b->n_envs <= 0 || !(max_depth > 0.f)) return 0;
     if (hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || b->stride < b->n_envs || !(p->fx > 0.f) ||
         !(p->fy > 0.f) || row_stride < WL_VISDEPTH_NPIX)
-        return WL_EINVAL;
-    if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (int64_t)b->n_envs * kTiles > 0x7fffffffLL) return WL_EINVAL;
+        return 0;
+    if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (int64_t)b->n_envs * kTiles > 0x7fffffffLL) return 0;
+    return 1;
+}
+
+int wl_visual_depth_rows(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
+                         float* rows, int64_t row_stride, void* stream) {
+    if (!depth_rows_args_ok(p, b, hf, pyramid, max_depth, rows, row_stride)) return WL_EINVAL;
     const Pyramid py = make_pyramid(hf->nx, hf->ny);
     const unsigned bytes = (unsigned)(pyramid_total_floats(hf->nx, hf->ny) * 4);
     clear_error();
@@ -270,7 +281,10 @@ int wl_visual_depth_rows(const WlVisualParams* p, const WlEnvBuffers* b, const W
     visual_depth_pool_kernel<WL_DEPTH_POOL_ROWS, WL_DEPTH_POOL_THRESH><<<b->n_envs * (WL_VIS_IMG_H / WL_DEPTH_POOL_ROWS), 64, 0, (hipStream_t)stream>>>(
         *p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, rows, row_stride);
 #else
-    visual_depth_tile_kernel<<<b->n_envs * kTiles, 64, 0, (hipStream_t)stream>>>(*p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, rows, row_stride);
+    if (row_stride == WL_VISDEPTH_NPIX)
+        visual_depth_tile_kernel<0><<<b->n_envs * kTiles, 64, 0, (hipStream_t)stream>>>(*p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, rows, row_stride);
+    else
+        visual_depth_tile_kernel<1><<<b->n_envs * kTiles, 64, 0, (hipStream_t)stream>>>(*p, *b, make_depth_grid(hf), py, pyramid, bytes, max_depth, rows, row_stride);
 #endif
     return launch_status();
 }
@@ -282,7 +296,9 @@ int wl_visual_depth(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeig
 
 int wl_visual_depth_step(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap* m, const WlHeightField* hf, const float* pyramid,
                          float max_depth, const float* actions, const WlStepOut* out, uint64_t seed, uint64_t step, void* stream) {
-    if (!pyramid || !(max_depth > 0.f)) return WL_EINVAL;
+    // all-or-nothing: the depth launch's own checks run BEFORE the step kernel advances the state (a refused call must leave the
+    // batch and the caller's step counter where they were)
+    if (!out || !depth_rows_args_ok(p, b, hf, pyramid, max_depth, out->obs, WL_VISDEPTH_OBS_DIM)) return WL_EINVAL;
     const int rc = wl_visual_step_hf(p, b, m, hf, actions, out, seed, step, stream);     // validates the rest
     if (rc != WL_OK) return rc;
     return wl_visual_depth_rows(p, b, hf, pyramid, max_depth, out->obs, WL_VISDEPTH_OBS_DIM, stream);

@@ -191,8 +191,10 @@ __global__ void __launch_bounds__(kBlock) action_map_kernel(const WlActionParams
     float v, delta, st, w[4];
     process_action(ap, a.x, a.y, v, delta);
     joint_targets(ap, v, delta, st, w);
+    float sl, sr;
+    steer_pair(ap, delta, st, sl, sr);
     processed[e] = make_float2(v, delta);
-    steer_target[e] = make_float2(st, st);
+    steer_target[e] = make_float2(sl, sr);
     wheel_target[e] = make_float4(w[0], w[1], w[2], w[3]);
 }
 
@@ -373,7 +375,7 @@ int wl_drift_mdp(const WlDriftParams* p, int32_t n, int64_t stride, const float*
 
 int wl_action_map(const WlActionParams* a, int32_t n, const float* actions, float* processed, float* steer_target,
                   float* wheel_target, void* stream) {
-    if (!a || n <= 0 || !actions || !processed || !steer_target || !wheel_target) return WL_EINVAL;
+    if (!a || n <= 0 || !actions || !processed || !steer_target || !wheel_target || a->map < 0 || a->map > 2) return WL_EINVAL;
     if (((uintptr_t)wheel_target & 15u) || ((uintptr_t)actions & 7u)) return WL_EALIGN;
     clear_error();
     action_map_kernel<<<grid_for(n), kBlock, 0, (hipStream_t)stream>>>(*a, n, (const float2*)actions, (float2*)processed,

@@ -28,10 +28,12 @@ WL_DEV void process_action(const WlActionParams& ap, float& a0, float& a1, float
 
 // RCCarRWDAction / RCCar4WDAction._calculate_ackermann_angles_and_velocities
 // (wheeledlab/envs/mdp/actions/rc_car_actions.py:12-29, 36-64): steer joint target = tan(delta);
-// wheel velocity targets in order bl, br, fl, fr.
+// wheel velocity targets in order bl, br, fl, fr.  map 2 = the base class (ackermann_actions.py:150-201): the 4WD wheel
+// speeds; its two steer joints take the true Ackermann ANGLES (steer_pair below) -- the single-track vehicle model of the step
+// kernels steers by their centre-line equivalent atan(L / R) = delta itself.
 WL_DEV void joint_targets(const WlActionParams& ap, float v, float delta, float& steer, float w[4]) {
     const float t = tan_fast(delta);   // hardware sin/cos: |delta| <= scale[1] (0.488 rad), abs error ~1e-6
-    steer = t;
+    steer = ap.map == 2 ? delta : t;
     const float inv_r = 1.f / ap.wheel_radius;
     if (ap.map == 0) {
         w[0] = w[1] = v * inv_r;
@@ -45,6 +47,21 @@ WL_DEV void joint_targets(const WlActionParams& ap, float v, float delta, float&
         w[1] = v * fabsf((R + W2) * inv_Rr);
         w[2] = v * fabsf(rl * inv_Rr);
         w[3] = v * fabsf(rr * inv_Rr);
+    }
+}
+
+// the two steer-joint targets (left, right).  RC-car maps: both = tan(delta).  map 2, AckermannAction.
+// _calculate_ackermann_angles_and_velocities (ackermann_actions.py:178-186): R = L / tan(delta) (1e6 where tan(delta) == 0),
+// delta_left = atan(L / (R - W / 2)), delta_right = atan(L / (R + W / 2)).  Only the parity entry point wl_action_map uses it
+// (no registered task selects the base class), so the library tan / atan are affordable here.
+WL_DEV void steer_pair(const WlActionParams& ap, float delta, float steer, float& left, float& right) {
+    left = right = steer;
+    if (ap.map == 2) {
+        const float t = tanf(delta);
+        const float L = ap.base_length, W2 = 0.5f * ap.base_width;
+        const float R = (t == 0.f) ? 1e6f : L / t;
+        left = atanf(L / (R - W2));
+        right = atanf(L / (R + W2));
     }
 }
 

@@ -14,7 +14,9 @@ from .managers_cfg import ActionTermCfg
 
 
 class AckermannAction:
-    wl_map = None  # the base class' true-Ackermann steering map is not used by any registered task
+    # the base class' true-Ackermann map (ackermann_actions.py:150-201; no registered task selects it): steer joints take
+    # atan(L / (R -+ W / 2)), wheels the 4WD speeds
+    wl_map = 2
 
     def __init__(self, cfg, env):
         self.cfg, self._env = cfg, env

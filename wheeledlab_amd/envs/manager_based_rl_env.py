@@ -271,7 +271,13 @@ class ManagerBasedRLEnv:
         self._has_custom_rewards = bool(self._custom_rew or self._custom_term or self._custom_obs)
         self._obs_dim = self._batch.OBS_DIM
         if self._custom_obs:
+            # shape probe on the un-reset state: nothing it renders may be kept (the scene camera caches per step)
+            cams = [s.data for s in self.scene.sensors.values() if hasattr(s.data, "caching")]
+            for c in cams:
+                c.caching = False
             self._obs_dim += sum(self._eval_obs_term(t).shape[1] for _, t in self._custom_obs)
+            for c in cams:
+                c.caching = True
             self.observation_manager.group_obs_dim["policy"] = (self._obs_dim,)
             self.single_observation_space = {"policy": Box(-math.inf, math.inf, (self._obs_dim,))}
             self.observation_space = {"policy": Box(-math.inf, math.inf, (self.num_envs, self._obs_dim))}
@@ -291,6 +297,15 @@ class ManagerBasedRLEnv:
     @episode_length_buf.setter
     def episode_length_buf(self, value):  # the RSL-RL runner assigns it for init_at_random_ep_len
         self._batch.episode_len[: self.num_envs] = value.to(torch.int32)
+
+    @property
+    def traversability(self):
+        """(map [rows, cols] uint8 on the device, (row_spacing, col_spacing)) of the visual tasks -- what the reference keeps in
+        its TraversabilityHashmapUtil singleton (visual/utils/traversability_utils.py:57-63); read by the torch terms of mdp.py"""
+        b = self._batch
+        if not hasattr(b, "trav_map"):
+            raise AttributeError(f"the {self._task} task has no traversability map")
+        return b.trav_map, (float(b._map.row_spacing), float(b._map.col_spacing))
 
     @property
     def reward_buf(self):

@@ -13,6 +13,8 @@ class SceneEntityCfg:
     def resolve(self, scene):
         if self.joint_names is not None:
             self.joint_ids = scene[self.name].find_joints(self.joint_names)[0]
+        if self.body_names is not None:
+            self.body_ids = scene[self.name].find_bodies(self.body_names)[0]
         return self
 
 

@@ -142,8 +142,14 @@ def cart_off_track(env, straight: float, corner_in_radius: float, corner_out_rad
 
 
 def off_track(env, straight, corner_out_radius):
-    """mushr_drift_env_cfg.py:210-217 -- int 0/1; only the outer bound (inner radius disabled)"""
-    return env._eval_drift_terms(dict(straight=straight, r_in=0.0, r_out=corner_out_radius))[1].long()
+    """mushr_drift_env_cfg.py:210-217 -- int 0/1; only the outer bound (inner radius disabled).  The visual cfg module
+    defines the same function (visual/mushr_visual_env_cfg.py:352-359): on a non-drift env it is evaluated with torch."""
+    if getattr(env, "_task", None) == "drift":
+        return env._eval_drift_terms(dict(straight=straight, r_in=0.0, r_out=corner_out_radius))[1].long()
+    pos = root_pos_w(env)
+    x, y = pos[..., 0], pos[..., 1]
+    corner = (y - torch.where(y > 0, straight, -straight)) ** 2 + x ** 2 > corner_out_radius ** 2
+    return torch.where(y.abs() < straight, x.abs() > corner_out_radius, corner).long()
 
 
 def in_range(env, straight, corner_in_radius):
@@ -386,6 +392,64 @@ def is_traversable(env):                                        # :304-307
 @_kernel_term("termination", 0)
 def out_of_map(env):                                            # :390-398
     return env._eval_visual_terms()["out_of_map"]
+
+
+# ---- terms the visual cfg module DEFINES but does not register (visual/mushr_visual_env_cfg.py:314-368,400-403): torch terms
+# on the state views, so that a config override can wire them in (the elevation twin: forward_wheel_spin ... low_vel_penalty above)
+
+def _traversability_at(env, xy):
+    """TraversabilityHashmapUtil.get_traversability / get_map_id (visual/utils/traversability_utils.py:68-88) for arbitrary
+    points [M, 2]: x_idx = clamp(trunc((x + W / 2 + dx / 2) / dx), 0, rows - 1), likewise y; map[y_idx, x_idx].
+    `env.traversability` -> (bool / uint8 map [rows, cols] on the env's device, (row_spacing, col_spacing))."""
+    tmap, (rs, cs) = env.traversability
+    rows, cols = tmap.shape
+    width, height = rows * rs, cols * cs
+    x_idx = ((xy[:, 0] + width / 2.0 + rs / 2.0) / rs).long().clamp(0, rows - 1)
+    y_idx = ((xy[:, 1] + height / 2 + cs / 2) / cs).long().clamp(0, cols - 1)
+    return tmap[y_idx, x_idx].bool()
+
+
+def bool_is_not_traversable(env):                               # :314-322: off until 1000 episodes have passed
+    if env.common_step_counter // env.max_episode_length < 1000:
+        return torch.zeros(env.num_envs, dtype=torch.bool, device=env.device)
+    return ~_traversability_at(env, root_pos_w(env)[..., :2])
+
+
+def is_traversable_speed_scaled(env):                           # :324-325
+    return _traversability_at(env, root_pos_w(env)[..., :2]).float() * base_lin_vel(env)[:, 0]
+
+
+def _wheels_traversable(env):
+    """[N, 4] bool: the four wheel links' xy on the map (:327-333)"""
+    cfg = SceneEntityCfg("robot", body_names=".*wheel_link").resolve(env.scene)
+    xy = env.scene[cfg.name].data.body_pos_w[:, cfg.body_ids][:, :, :2]
+    B, nb = xy.shape[:2]
+    return _traversability_at(env, xy.reshape(-1, 2)).reshape(B, nb)
+
+
+def is_traversable_wheels(env):                                 # :327-334: +1 per wheel on the path, -5 per wheel off it
+    t = _wheels_traversable(env)
+    return torch.where(t, 1.0, -5.0).sum(dim=-1)
+
+
+def binary_is_traversable_wheels(env):                          # :336-344: True when NO wheel is on the path
+    return _wheels_traversable(env).float().sum(dim=-1) == 0
+
+
+def vel_rew_trav(env, speed_target_on_trav: float = 1.0, speed_target_on_non_trav: float = 2.0):   # :346-354
+    trav = _traversability_at(env, root_pos_w(env)[..., :2])
+    target = torch.where(trav, speed_target_on_trav, speed_target_on_non_trav)
+    d = -((torch.norm(base_lin_vel(env), dim=-1) - target) ** 2) + target ** 2
+    return torch.where(d > 0.0, d, torch.zeros_like(d))
+
+
+def low_speed_penalty(env, low_speed_thresh: float = 0.3):      # :361-364
+    return (torch.norm(base_lin_vel(env), dim=-1) < low_speed_thresh).float()
+
+
+def roll_over(env):                                             # :400-403: roll (wrapped to [0, 2 pi)) - pi inside (-pi/2, pi/2)
+    roll = euler_xyz_from_quat(root_quat_w(env))[0] - math.pi
+    return (roll < math.pi / 2) & (roll > -math.pi / 2)
 
 
 _CAMERA = SceneEntityCfg("camera")

@@ -17,6 +17,9 @@ MUSHR_JOINT_NAMES = [
     "front_left_wheel_suspension", "front_right_wheel_suspension",
     "back_left_wheel_suspension", "back_right_wheel_suspension",
 ]
+# rigid bodies of the articulation as far as the reference's terms select them (`body_names=".*wheel_link"`,
+# visual/mushr_visual_env_cfg.py:326,336): the root link and the four wheel links, wheels in the state rows' order (bl, br, fl, fr)
+MUSHR_BODY_NAMES = ["base_link", "back_left_wheel_link", "back_right_wheel_link", "front_left_wheel_link", "front_right_wheel_link"]
 
 
 def quat_rotate_inverse(q: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
@@ -76,6 +79,24 @@ class ArticulationData:
         return self._rows(A.S_VX, 6)
 
     @property
+    def body_pos_w(self):
+        """[N, 5, 3]: the root link and the four wheel centres = root pose (+) the vehicle geometry the step kernels use
+        (wl_vehicle.h::wheel_contact: wheel centre = root + R (+-half_wheelbase, +-half_track, wheel_z))"""
+        v = self._b.p.vehicle
+        local = torch.tensor([[0.0, 0.0, 0.0],
+                              [-v.half_wheelbase_r, v.half_track, v.wheel_z], [-v.half_wheelbase_r, -v.half_track, v.wheel_z],
+                              [v.half_wheelbase_f, v.half_track, v.wheel_z], [v.half_wheelbase_f, -v.half_track, v.wheel_z]],
+                             dtype=torch.float32, device=self._b.device)
+        q = self.root_quat_w
+        w, u = q[:, None, 0:1], q[:, None, 1:4].expand(-1, local.shape[0], -1)
+        lv = local[None].expand(q.shape[0], -1, -1)
+        # R(q) v = v + 2 w (u x v) + 2 u x (u x v)
+        c1 = torch.cross(u, lv, dim=-1)
+        return self.root_pos_w[:, None, :] + lv + 2.0 * (w * c1 + torch.cross(u, c1, dim=-1))
+
+    body_link_pos_w = body_pos_w
+
+    @property
     def default_root_state(self):
         d = torch.zeros(self._b.n, 13, device=self._b.device)
         d[:, 3] = 1.0
@@ -102,8 +123,14 @@ class ArticulationView:
     def __init__(self, batch, joint_names=MUSHR_JOINT_NAMES):
         self._b = batch
         self.joint_names = list(joint_names)   # layout: [steer L, steer R, rear L, rear R, front L, front R, (suspension x4)]
+        self.body_names = list(MUSHR_BODY_NAMES)
         self.data = ArticulationData(batch, len(self.joint_names))
         self.num_instances = batch.n
+
+    def find_bodies(self, name_keys, preserve_order=False):
+        keys = [name_keys] if isinstance(name_keys, str) else list(name_keys)
+        ids = [i for i, n in enumerate(self.body_names) if any(re.fullmatch(k, n) for k in keys)]
+        return ids, [self.body_names[i] for i in ids]
 
     def find_joints(self, name_keys, joint_subset=None, preserve_order=False):
         keys = [name_keys] if isinstance(name_keys, str) else list(name_keys)
@@ -118,10 +145,12 @@ class ArticulationView:
     def write_root_pose_to_sim(self, pose, env_ids=None):
         ids = slice(None) if env_ids is None else env_ids
         self._b.state[A.S_PX:A.S_PX + 7, ids] = pose.T.to(torch.float32)
+        self._b.touch_pose()
 
     def write_root_velocity_to_sim(self, vel, env_ids=None):
         ids = slice(None) if env_ids is None else env_ids
         self._b.state[A.S_VX:A.S_VX + 6, ids] = vel.T.to(torch.float32)
+        self._b.touch_pose()
 
 
 class RayCasterData:
@@ -171,7 +200,11 @@ class CameraData:
 
     def __init__(self, batch, cfg):
         self._b, self._cam, self._cfg = batch, None, cfg
-        self._cached = (None, None)      # (batch.step_count it was rendered at, image): one render per env.step(), however often read
+        # ((batch.step_count, batch.pose_epoch) it was rendered at, image): one render per env.step(), however often read --
+        # and a new one after anything that moved cars without a step (reset(), the masked in-step resets of custom
+        # terminations, a plugin's write_root_pose_to_sim: they bump pose_epoch)
+        self._cached = (None, None)
+        self.caching = True              # the env's constructor switches it off around its shape probe of the custom terms
         clip = getattr(getattr(cfg, "spawn", None), "clipping_range", None) or (0.01, 100.0)
         self.far = float(clip[1])
         self.beyond = {"max": None, "zero": 0.0, "none": float("inf")}[getattr(cfg, "depth_clipping_behavior", "max")]
@@ -216,10 +249,13 @@ class _CameraOutputs:
         if key != "distance_to_image_plane":
             raise KeyError(f"camera data type {key!r} is not rendered here (the fused observation carries the grey image)")
         d = self._d
-        stamp = getattr(d._b, "step_count", None)
-        if d._cached[0] != stamp or stamp is None:       # the render is cached per env step; what lies beyond the far plane is applied per read
-            d._cached = (stamp, d._camera().render(d._b, d.far))
-        img = d._cached[1]
+        stamp = (getattr(d._b, "step_count", None), getattr(d._b, "pose_epoch", None))
+        if not d.caching or None in stamp:
+            img = d._camera().render(d._b, d.far)
+        else:
+            if d._cached[0] != stamp:       # the render is cached per env step; what lies beyond the far plane is applied per read
+                d._cached = (stamp, d._camera().render(d._b, d.far))
+            img = d._cached[1]
         if d.beyond is not None:
             img = torch.where(img >= d.far, torch.full_like(img, d.beyond), img)
         return img.unsqueeze(-1)
