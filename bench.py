@@ -345,7 +345,7 @@ def other_tasks_sweep(dev):
                         "frac_counters": blk.get("frac_counters"), "wasted_traffic": blk.get("wasted_traffic"),
                         "test": OTHER_SWEEP_TESTS.get((task, big))})
             if task == "elev" and big == 65536:
-                cam = DepthCamera((e2.height, float(e2._hf.x0), float(e2._hf.y0), float(e2._hf.cell)), dev)
+                cam = DepthCamera(e2.hf, dev)
                 img = torch.empty(big, 60, 80, device=dev)
                 cam.render(e2, 100.0, img)
                 torch.cuda.synchronize()
@@ -841,7 +841,7 @@ def main():
         t = ElevBatch(n, device=dev, seed=42)
         t.reset()
         t.rollout(torch.rand(8, n, 2, device=dev) * 2 - 1)
-        cam = DepthCamera((t.height, float(t._hf.x0), float(t._hf.y0), float(t._hf.cell)), dev)
+        cam = DepthCamera(t.hf, dev)
         img = torch.empty(n, 60, 80, device=dev)
         for _ in range(3):
             cam.render(t, 100.0, img)

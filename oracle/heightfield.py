@@ -1,16 +1,30 @@
 """Heightfield terrain: bilinear height + normal sampling, and a synthetic terrain generator.
 DESIGNED (the reference's terrain mesh `Terrains/huge_compact.usd` is missing, .MISSING_LARGE_BLOBS): SURVEY.md 8d
-config 3 prescribes a synthetic 800 x 800 fp32 grid at 0.05 m (40 x 40 m, ramps + sine hills, seed 0)."""
+config 3 prescribes a synthetic 800 x 800 grid at 0.05 m (40 x 40 m, ramps + sine hills, seed 0).
+Round 5: the terrain is DEFINED as 16-bit height codes x a vertical scale (IsaacLab's own height-field terrains are int16 x
+vertical_scale): `quantize` / `decode` restate the product's representation (wheeledlab_amd/terrain.py), every sampler below
+works on the DECODED float32 grid -- exactly the values the kernels decode (one fp32 multiply per grid point)."""
 import numpy as np
 
 from .mathlib import F, f32
 
 BASE_Z = 0.19   # root height on the flat base: `plane_init_value` of the reference's height map (elevation cfg :79)
+Z_SCALE = 2.0 ** -13   # metres per height code of the synthetic terrain (0.122 mm; +-4 m of range)
+
+
+def quantize(h, z_scale=Z_SCALE):
+    """float heights -> int16 codes: rint(h / z_scale), clipped to +-32767"""
+    return np.clip(np.rint(np.asarray(h, np.float64) / float(z_scale)), -32767, 32767).astype(np.int16)
+
+
+def decode(codes, z_scale=Z_SCALE):
+    """int16 codes -> the float32 heights the kernels see: (float) code * (float) z_scale"""
+    return np.asarray(codes, np.int16).astype(F) * F(z_scale)
 
 
 def make_terrain(n=800, cell=0.05, seed=0):
     """-> (height [n, n] float32 indexed [iy, ix], x0, y0, cell): flat base at BASE_Z with smooth hills, ramps and
-    plateaus; slopes stay below ~25 deg so the 4WD car can climb them."""
+    plateaus; slopes stay below ~25 deg so the 4WD car can climb them.  Heights on the code lattice: code * 2^-13 exactly."""
     rng = np.random.RandomState(seed)
     half = 0.5 * n * cell
     xs = (np.arange(n) * cell - half).astype(np.float64)
@@ -29,7 +43,7 @@ def make_terrain(n=800, cell=0.05, seed=0):
     h += 0.04 * np.sin(0.9 * X) * np.sin(1.1 * Y)          # gentle undulation
     edge = np.clip((half - np.maximum(np.abs(X), np.abs(Y))) / 1.0, 0, 1)   # fade to the flat base at the border
     h = BASE_Z + np.maximum(h, 0) * edge
-    return h.astype(F), F(-half), F(-half), F(cell)
+    return decode(quantize(h)), F(-half), F(-half), F(cell)
 
 
 def sample(hf, x0, y0, cell, x, y, outside=0.0):

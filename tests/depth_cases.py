@@ -31,6 +31,25 @@ def terrain():
     return HF.make_terrain()
 
 
+def on_lattice(field, z_scale=None):
+    """the same field with its heights on the 16-bit code lattice -- code * z_scale exactly, what the product's quantisation
+    (wheeledlab_amd/terrain.py::quantize_heights, its default scale unless one is given) leaves of it: the ORACLE is handed these
+    floats, the product re-quantises them without loss, so both sides see one terrain"""
+    from wheeledlab_amd.terrain import decode_heights, quantize_heights
+    codes, zs = quantize_heights(field[0], z_scale)
+    return (decode_heights(codes, zs),) + tuple(field[1:4])
+
+
+def hf_struct(field, outside_z=0.0, z_scale=None):
+    """-> (WlHeightField over the field's height codes, the codes array that must stay alive while the struct is used)"""
+    from wheeledlab_amd import _abi
+    from wheeledlab_amd.terrain import quantize_heights
+    codes, zs = quantize_heights(field[0], z_scale)
+    codes = np.ascontiguousarray(codes)
+    return _abi.WlHeightField(codes.ctypes.data, codes.shape[1], codes.shape[0], float(field[1]), float(field[2]), float(field[3]),
+                              float(outside_z), zs), codes
+
+
 def poses(n, seed, hf=None, span=17.5, tilt=0.15, edge=True):
     """-> pos [n,3], quat [n,4] float32.  Roots 0.04-0.3 m above the terrain with N(0, tilt) roll / pitch and uniform yaw; the
     first len(EDGE) are the edge cases (when n allows and `edge`)."""
@@ -61,7 +80,7 @@ def rough_fields(seed=3):
     on them, steeply tilted: (name, field, pos, quat) tuples"""
     rng = np.random.RandomState(seed)
     out = []
-    for name, h, cell in (("white noise", rng.uniform(0, 2, (256, 256)).astype(np.float32), 0.1),
+    for name, h, cell in (("white noise", on_lattice((rng.uniform(0, 2, (256, 256)),))[0], 0.1),
                           ("spikes", np.where(rng.rand(300, 200) < 0.02, 3.0, 0.0).astype(np.float32), 0.07),
                           ("steps", (np.floor(np.arange(512)[None, :] / 32) * 0.25 + np.zeros((512, 1))).astype(np.float32), 0.05)):
         ny, nx = h.shape
@@ -76,12 +95,13 @@ def rough_fields(seed=3):
     return out
 
 
-def check_pyramid(pyr, h):
+def check_pyramid(pyr, h, z_scale=2.0 ** -13):
     """the bound pyramid's contract (wheeledlab_amd/csrc/wl_depth_dev.h): entry (J, I) of level L = { uint16 c' | int8 a' | int8 b' } with
     a = a' qs, b = b' qs, c = c0 + c' qc (header behind the heights: field maximum, qs, c0, qc); the plane a (i - I 2^L) + b (j - J 2^L)
     + c lies on or above EVERY grid point of its 2^L x 2^L block of cells (that is all the walk's skips rely on), tightly (the largest
     residual of the block, one offset step and a rounding hair above), and never looser at the block's centre than the block's
-    maximum; float 0 = the field's maximum; blocks that cover no cell: the word 0; behind the entries the walk's copy of the heights"""
+    maximum; float 0 = the field's maximum; blocks that cover no cell: the word 0; behind the entries the walk's copy of the 16-bit
+    height codes (h = code * z_scale)"""
     h = np.asarray(h, np.float32)
     pyr = np.asarray(pyr, np.float32)
     ny, nx = h.shape
@@ -90,9 +110,11 @@ def check_pyramid(pyr, h):
         Pw *= 2
     lp = int(np.log2(Pw))
     h0 = max(Pw * Pw // 2, 4)
-    assert len(pyr) == h0 + nx * ny + 4 and pyr[0] == h.max()
-    np.testing.assert_array_equal(pyr[h0: h0 + nx * ny].reshape(ny, nx), h)      # the walk's copy of the heights
-    fmax, qs, c0, qc = (float(v) for v in pyr[h0 + nx * ny:])
+    nw = (nx * ny + 1) // 2
+    assert len(pyr) == h0 + nw + 4 and pyr[0] == h.max()
+    codes = pyr[h0: h0 + nw].view(np.int16)[: nx * ny].reshape(ny, nx)
+    np.testing.assert_array_equal(codes.astype(np.float32) * np.float32(z_scale), h)      # the walk's copy of the height codes
+    fmax, qs, c0, qc = (float(v) for v in pyr[h0 + nw:])
     steepest = max(np.abs(np.diff(h, axis=0)).max(), np.abs(np.diff(h, axis=1)).max())
     assert fmax == h.max() and c0 == h.min() and abs(qs * 127 - steepest) <= 1e-6 * steepest   # one slope quantum per field: its steepest cell edge / 127
     assert abs(qc * 65534 - 2 * (h.max() - h.min())) <= 1e-5 * (h.max() - h.min())                # offsets: 16 bits over twice the relief
@@ -115,6 +137,8 @@ def check_pyramid(pyr, h):
             slack = c[J, I] + a[J, I] * ii + b[J, I] * jj - blk
             one_step = 1.01 * qc                                                 # the offset is rounded UP to a whole step
             assert slack.min() >= 0.0, (L, J, I, slack.min())
-            assert slack.min() < one_step + 1e-5 * (1 + abs(c[J, I])), (L, J, I, slack.min())   # tight: it (nearly) touches a point
+            # tight: it (nearly) touches a point -- up to the rounding allowance of the walk's travelled extent (plane_entry)
+            travel = 4.1e-7 * (abs(a[J, I]) * (blk.shape[1] - 1) + abs(b[J, I]) * (blk.shape[0] - 1))
+            assert slack.min() < one_step + travel + 1e-5 * (1 + abs(c[J, I])), (L, J, I, slack.min())
             centre = c[J, I] + 0.5 * (a[J, I] * (blk.shape[1] - 1) + b[J, I] * (blk.shape[0] - 1))
-            assert centre <= blk.max() + one_step + 1e-5 * (1 + abs(blk.max())), (L, J, I)
+            assert centre <= blk.max() + one_step + travel + 1e-5 * (1 + abs(blk.max())), (L, J, I)

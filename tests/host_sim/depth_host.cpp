@@ -22,7 +22,7 @@ static std::vector<float> host_pyramid(const WlHeightField* hf) {
         for (int J = 0; J < (P >> L); ++J)
             for (int I = 0; I < (P >> L); ++I)
                 words[(size_t)pyramid_level_offset(py.lp, L) + (size_t)J * (P >> L) + I] = plane_cell_serial(*hf, L, I, J, buf.data() + py.hdr);
-    std::copy(hf->height, hf->height + (size_t)hf->nx * hf->ny, buf.begin() + py.h0);
+    std::copy(hf->height, hf->height + (size_t)hf->nx * hf->ny, reinterpret_cast<int16_t*>(buf.data() + py.h0));
     return buf;
 }
 

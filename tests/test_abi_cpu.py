@@ -95,20 +95,21 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.wl_ppo_apply(C.byref(small_a), C.byref(small_c), base, 0, C.byref(hp), C.byref(st), 0, 1, None) == -1           # empty batch
     assert lib.wl_ppo_apply(C.byref(actor), C.byref(critic), base, 64, C.byref(hp), C.byref(st), 0, 1, None) == -1             # not the 14-wide nets
     # depth ray-cast: pyramid sizing is host arithmetic; every malformed call is refused before a launch
-    assert lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800 + 4      # bound pyramid (4-byte entries) + heights + header
-    assert lib.wl_heightfield_pyramid_floats(3, 3) == 4 + 9 + 4 and lib.wl_heightfield_pyramid_floats(349, 613) == 1024 * 1024 // 2 + 349 * 613 + 4
+    assert lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800 // 2 + 4      # bound pyramid (4-byte entries) + 16-bit height codes + header
+    assert lib.wl_heightfield_pyramid_floats(3, 3) == 4 + 5 + 4 and lib.wl_heightfield_pyramid_floats(349, 613) == 1024 * 1024 // 2 + (349 * 613 + 1) // 2 + 4
     assert lib.wl_heightfield_pyramid_floats(1, 9) == 0 and lib.wl_heightfield_pyramid_floats(9, 16386) == 0
     vp = PP.visual_params()
-    hf = A.WlHeightField(base, 16, 16, 0.0, 0.0, 0.5, 0.0)
+    hf = A.WlHeightField(base, 16, 16, 0.0, 0.0, 0.5, 0.0, 2.0 ** -13)
     good_b = A.WlEnvBuffers(base, base, None, base, 64, 40, 0, 1, 0, 0)
     dep = lib.wl_visual_depth
     assert dep(C.byref(vp), C.byref(good_b), C.byref(hf), None, 10.0, base, None) == -1               # no pyramid
     assert dep(C.byref(vp), C.byref(good_b), C.byref(hf), base, 0.0, base, None) == -1                # range
     assert dep(C.byref(vp), C.byref(good_b), C.byref(hf), base, 10.0, None, None) == -1               # no output
     assert dep(C.byref(vp), C.byref(b), C.byref(hf), base, 10.0, base, None) == -1                    # null state
-    assert dep(C.byref(vp), C.byref(good_b), C.byref(A.WlHeightField(base, 1, 16, 0.0, 0.0, 0.5, 0.0)), base, 10.0, base, None) == -1
-    assert dep(C.byref(vp), C.byref(good_b), C.byref(A.WlHeightField(base, 16, 16, 0.0, 0.0, 0.0, 0.0)), base, 10.0, base, None) == -1   # cell 0
-    assert lib.wl_heightfield_build_pyramid(C.byref(A.WlHeightField(None, 16, 16, 0.0, 0.0, 0.5, 0.0)), base, None) == -1
+    assert dep(C.byref(vp), C.byref(good_b), C.byref(A.WlHeightField(base, 1, 16, 0.0, 0.0, 0.5, 0.0, 2.0 ** -13)), base, 10.0, base, None) == -1
+    assert dep(C.byref(vp), C.byref(good_b), C.byref(A.WlHeightField(base, 16, 16, 0.0, 0.0, 0.0, 0.0, 2.0 ** -13)), base, 10.0, base, None) == -1   # cell 0
+    assert dep(C.byref(vp), C.byref(good_b), C.byref(A.WlHeightField(base, 16, 16, 0.0, 0.0, 0.5, 0.0, 0.0)), base, 10.0, base, None) == -1   # z_scale 0
+    assert lib.wl_heightfield_build_pyramid(C.byref(A.WlHeightField(None, 16, 16, 0.0, 0.0, 0.5, 0.0, 2.0 ** -13)), base, None) == -1
     assert lib.wl_heightfield_build_pyramid(C.byref(hf), None, None) == -1
 
 
@@ -146,8 +147,10 @@ def test_layout_of_task_structs_and_misuse_codes(tmp_path):
     assert lib.wl_drift_step(C.byref(p), C.byref(good), base, None, C.byref(out), 0, 0, None) == -1      # > 32 ref poses
     ep = PP.elev_params()
     assert lib.wl_elev_step(C.byref(ep), C.byref(good), None, base, C.byref(out), 0, 0, None) == -1      # no heightfield
+    no_scale = A.WlHeightField(base, 8, 8, 0.0, 0.0, 1.0, 0.0, 0.0)
+    assert lib.wl_elev_step(C.byref(ep), C.byref(good), C.byref(no_scale), base, C.byref(out), 0, 0, None) == -1      # z_scale 0
     # persistent elevation collector: observation rows k + 1 must be where the policy of step k + 1 reads them; quad form only
-    hfb = A.WlHeightField(base, 8, 8, 0.0, 0.0, 1.0, 0.0)
+    hfb = A.WlHeightField(base, 8, 8, 0.0, 0.0, 1.0, 0.0, 2.0 ** -13)
     net = lambda o: A.WlMlp(base, base, base, base, base, base, A.ELEV_OBS_DIM, o, 64, A.ACT_ELU)
     na, nc = net(2), net(1)
     io = A.WlCollectIo(base, base, base, base, base)

@@ -95,7 +95,7 @@ def test_depth_of_driving_elevation_cars(hf):
     g = torch.Generator(device=DEV).manual_seed(0)
     for _ in range(30):
         env.step(torch.rand(n, 2, device=DEV, generator=g) * 2 - 1)
-    cam = DepthCamera((env.height, float(env._hf.x0), float(env._hf.y0), float(env._hf.cell)), DEV)
+    cam = DepthCamera(env.hf, DEV)
     got = cam.render(env, 30.0)
     torch.cuda.synchronize()
     st = env.state[:, :n].cpu().numpy()
@@ -119,7 +119,7 @@ def test_invalid_arguments_are_refused(hf):
     assert lib.wl_visual_depth(*args(pyr=None)) == -1
     assert lib.wl_visual_depth(*args(out=None)) == -1
     assert lib.wl_visual_depth(*args(md=0.0)) == -1
-    bad_hf = A.WlHeightField(cam._hf.height, 1, 800, 0.0, 0.0, 0.05, 0.0)
+    bad_hf = A.WlHeightField(cam._hf.height, 1, 800, 0.0, 0.0, 0.05, 0.0, cam._hf.z_scale)
     assert lib.wl_visual_depth(*args(hf=bad_hf)) == -1
     assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800 + 4
     assert lib.wl_heightfield_build_pyramid(C.byref(bad_hf), cam.pyramid.data_ptr(), None) == -1

@@ -215,8 +215,9 @@ def test_settled_cars_need_no_contact_excuse(lanes, terrain):
     n = 512
     xs = (np.arange(800) * 0.05 - 20.0).astype(np.float64)
     X, Y = np.meshgrid(xs, xs, indexing="xy")
-    hf = ((0.19 + 2.5 + 0.10 * X + 0.05 * Y + 0.02 * np.sin(0.5 * X) * np.cos(0.4 * Y)).astype(np.float32), np.float32(-20.0),
-          np.float32(-20.0), np.float32(0.05))
+    from tests.depth_cases import on_lattice
+    hf = on_lattice(((0.19 + 2.5 + 0.10 * X + 0.05 * Y + 0.02 * np.sin(0.5 * X) * np.cos(0.4 * Y)).astype(np.float32), np.float32(-20.0),
+                     np.float32(-20.0), np.float32(0.05)))      # heights up to 5.7 m: codes of 2^-12 m
     if terrain == "bench":
         hf = OH.make_terrain()
     env = ElevBatch(n, device=DEV, seed=8, heightfield=hf)

@@ -122,12 +122,22 @@ def _elev(n, seed, flags=0, lanes=0, off=0, params=None, hf=None):
     return env
 
 
-def test_height_scan_forms_are_bit_identical(A):
+@pytest.mark.parametrize("z_scale", [None, 0.005])
+def test_height_scan_forms_are_bit_identical(A, z_scale):
     """gather / LDS-patch x cache-allocating / non-temporal: the four scan instantiations write the same 676 values per env --
     cars anywhere on the terrain at any yaw, incl. on and beyond its border (rays that miss: +inf clipped to 10; a patch origin
-    clamped to the grid) and tilted"""
+    clamped to the grid) and tilted.  z_scale 0.005: the terrain's codes at IsaacLab's default vertical_scale (not a power of two:
+    the decode's product is rounded; every form must round it the same way) -- and the scan against the oracle on those codes."""
     n = 3000 + 11
-    env = _elev(n, 31, flags=A.FLAG_SCAN_GATHER | A.FLAG_NO_STREAM)
+    hf = None
+    if z_scale is not None:
+        from oracle import elev_step as OE
+        from oracle import heightfield as OH
+        from tests.depth_cases import on_lattice
+        hf = on_lattice(OH.make_terrain(), z_scale)
+    env = _elev(n, 31, flags=A.FLAG_SCAN_GATHER | A.FLAG_NO_STREAM, hf=None if hf is None else hf + (z_scale,))
+    if hf is not None:
+        assert env.hf.z_scale == z_scale and torch.equal(env.height.cpu(), torch.from_numpy(hf[0]))        # decoded = the oracle's grid
     g = torch.Generator(device=DEV).manual_seed(2)
     st = env.state
     half = 20.0
@@ -145,6 +155,11 @@ def test_height_scan_forms_are_bit_identical(A):
     torch.cuda.synchronize()
     assert torch.isfinite(ref).all() and (ref[:, 13:].abs() <= 10.0).all()
     assert (ref[:, 13:] == 10.0).any() and (ref[:, 13:].abs() < 5.0).any()           # misses and hits both present
+    if hf is not None:
+        want = OE.height_map(OE.elev_params(), env.state[:, :n].cpu().numpy(), hf)
+        d = np.abs(ref[:, 13:].cpu().numpy() - want)
+        # a ray within 1e-4 cell of a cell line or the border may fall on the other side in the other arithmetic (counted)
+        assert (d > 2e-5).mean() < 2e-4 and np.median(d) < 1e-6, (float((d > 2e-5).mean()), float(d.max()))
     for flags in (A.FLAG_SCAN_GATHER | A.FLAG_STREAM, A.FLAG_SCAN_LDS | A.FLAG_NO_STREAM, A.FLAG_SCAN_LDS | A.FLAG_STREAM,
                   A.FLAG_SCAN_LDS, A.FLAG_STREAM):
         env.set_flags(flags)

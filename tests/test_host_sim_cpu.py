@@ -125,8 +125,8 @@ def test_body_frame_substeps_equal_the_spec_on_the_heightfield(hostlib):
     hf = OH.make_terrain()
     st = _states(2048, seed=11, z0=0.06 - 0.0028, hf=hf)
     want = _oracle(p.vehicle, p.sim_dt, p.decimation, st, OE.ground_fn(hf))
-    h = np.ascontiguousarray(hf[0])
-    hs = _abi.WlHeightField(h.ctypes.data, h.shape[1], h.shape[0], float(hf[1]), float(hf[2]), float(hf[3]), 0.0)
+    from tests.depth_cases import hf_struct
+    hs, _keep = hf_struct(hf)
     got = _host(hostlib, p.vehicle, p.sim_dt, p.decimation, st, hs, 1)
     # 20 sub-steps with contact make-or-break: a wheel that touches down in one build and not yet in the other puts the
     # env on a different branch for a sub-step; those (a handful) are held to a loose bound, the rest to fp32 noise

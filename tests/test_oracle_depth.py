@@ -95,8 +95,7 @@ def test_device_walk_on_the_host_matches_the_oracle(hostlib, hf, max_depth):
     vp = visual_params()
     for field, seed in ((hf, 11), ((hf[0][:613, :349].copy(), hf[1], hf[2], hf[3]), 12)):
         pos, quat = DC.poses(96, seed=seed, hf=field, span=0.5 * min(field[0].shape) * float(field[3]) - 1.5)
-        h = np.ascontiguousarray(field[0])
-        hfs = _abi.WlHeightField(h.ctypes.data, h.shape[1], h.shape[0], float(field[1]), float(field[2]), float(field[3]), 0.0)
+        hfs, _keep = DC.hf_struct(field)
         got = np.zeros((len(pos), 60, 80), np.float32)
         assert hostlib.hs_depth(C.byref(vp), C.byref(hfs), len(pos), pos.ctypes.data, quat.ctypes.data, max_depth, got.ctypes.data) == 0
         want = D.depth(P, pos, quat, field, max_depth)
@@ -107,8 +106,7 @@ def test_device_walk_on_the_host_matches_the_oracle(hostlib, hf, max_depth):
 
 def _host_depth(hostlib, field, pos, quat, max_depth):
     vp = visual_params()
-    h = np.ascontiguousarray(field[0])
-    hfs = _abi.WlHeightField(h.ctypes.data, h.shape[1], h.shape[0], float(field[1]), float(field[2]), float(field[3]), 0.0)
+    hfs, _keep = DC.hf_struct(field)
     got = np.zeros((len(pos), 60, 80), np.float32)
     assert hostlib.hs_depth(C.byref(vp), C.byref(hfs), len(pos), pos.ctypes.data, quat.ctypes.data, max_depth, got.ctypes.data) == 0
     return got
@@ -132,7 +130,7 @@ def test_size_independent_properties_of_oracle_and_device_walk(hostlib, hf):
         # rays that leave the grid meet the outside plane (z = 0) 0.5 m lower relative to the lifted camera: exclude those that end there
         on_grid = hit & (np.abs(up - near) < 1e-3)
         assert on_grid.sum() > 0.5 * hit.sum()
-    flat = (np.full((128, 128), 0.19, np.float32), np.float32(-32.0), np.float32(-32.0), np.float32(0.5))
+    flat = DC.on_lattice((np.full((128, 128), 0.19, np.float32), np.float32(-32.0), np.float32(-32.0), np.float32(0.5)))
     p0 = np.array([[0.0, 0.0, 0.25]], np.float32)
     q0 = np.array([[1.0, 0.0, 0.0, 0.0]], np.float32)
     for img in (D.depth(P, p0, q0, flat, 30.0)[0], _host_depth(hostlib, flat, p0, q0, 30.0)[0]):
@@ -155,18 +153,18 @@ def test_host_built_pyramid_keeps_the_bound_contract(hostlib, hf):
     host: every plane bounds every grid point of its block, tightly (tests/depth_cases.py::check_pyramid); sized as the ABI says"""
     from wheeledlab_amd import _abi as A
     lib = A.load() if os.path.exists(A.LIB_PATH) else None
-    rough = np.random.RandomState(5).uniform(0.0, 1.5, (97, 131)).astype(np.float32)
+    rough = DC.on_lattice((np.random.RandomState(5).uniform(0.0, 1.5, (97, 131)),))[0]
     flat = np.full((9, 17), 0.25, np.float32)                      # no relief, no slope: the header's guards
     for field in (hf, (hf[0][:613, :349].copy(), hf[1], hf[2], hf[3]), (rough, -3.0, -2.0, 0.05)):
         h = np.ascontiguousarray(field[0], np.float32)
-        hfs = _abi.WlHeightField(h.ctypes.data, h.shape[1], h.shape[0], float(field[1]), float(field[2]), float(field[3]), 0.0)
+        hfs, _keep = DC.hf_struct(field)
         n = hostlib.hs_pyramid(C.byref(hfs), None, 0)
         if lib is not None:
             assert n == lib.wl_heightfield_pyramid_floats(h.shape[1], h.shape[0])
         pyr = np.zeros(n, np.float32)
         assert hostlib.hs_pyramid(C.byref(hfs), pyr.ctypes.data, n) == n
         DC.check_pyramid(pyr, h)
-    hfs = _abi.WlHeightField(flat.ctypes.data, 17, 9, 0.0, 0.0, 0.05, 0.0)
+    hfs, _keep = DC.hf_struct((flat, 0.0, 0.0, 0.05))
     n = hostlib.hs_pyramid(C.byref(hfs), None, 0)
     pyr = np.zeros(n, np.float32)
     hostlib.hs_pyramid(C.byref(hfs), pyr.ctypes.data, n)

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 20
+WL_ABI_VERSION = 21
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -76,7 +76,7 @@ class WlDriftParams(C.Structure):
 
 class WlHeightField(C.Structure):
     _fields_ = [("height", C.c_void_p), ("nx", C.c_int32), ("ny", C.c_int32), ("x0", C.c_float), ("y0", C.c_float),
-                ("cell", C.c_float), ("outside_z", C.c_float)]
+                ("cell", C.c_float), ("outside_z", C.c_float), ("z_scale", C.c_float)]
 
 
 class WlElevParams(C.Structure):

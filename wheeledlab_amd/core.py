@@ -46,6 +46,47 @@ def apply_startup_events(lib, bufs: "A.WlEnvBuffers", su, seed: int, stream, ran
     A.check(lib.wl_startup_randomize(C.byref(sp), C.byref(bufs), int(seed), stream), "wl_startup_randomize")
 
 
+class DeviceHeightField:
+    """A heightfield resident on the device as the kernels read it (WlHeightField, ABI 21): 16-bit height codes [ny, nx] and the
+    vertical scale, z = code * z_scale.  `heightfield` is `(height, x0, y0, cell)` with float heights (quantised: terrain.
+    quantize_heights' rule, z_scale 2^-13 m unless the range needs more) or `(codes int16, x0, y0, cell, z_scale)`, arrays or
+    tensors; or another DeviceHeightField on the same device (shared).  `.heights`: the decoded fp32 grid -- exactly the values
+    every kernel sees (what tests hand to the oracle)."""
+
+    def __init__(self, heightfield, device, outside_z: float = 0.0):
+        from .terrain import default_z_scale
+        self.device = torch.device(device)
+        if isinstance(heightfield, DeviceHeightField):
+            src = heightfield
+            assert src.device == self.device
+            self.codes, self.z_scale, self.heights = src.codes, src.z_scale, src.heights
+            self.x0, self.y0, self.cell = src.x0, src.y0, src.cell
+        else:
+            h, x0, y0, cell, *rest = heightfield
+            h = torch.as_tensor(h)
+            if h.dtype == torch.int16:
+                if not rest:
+                    raise ValueError("int16 height codes need their z_scale: (codes, x0, y0, cell, z_scale)")
+                self.codes, self.z_scale = h.contiguous().to(self.device), float(rest[0])
+            else:
+                h = h.to(self.device, torch.float64)
+                if not bool(torch.isfinite(h).all()):
+                    raise ValueError("heightfield with non-finite heights")
+                self.z_scale = float(rest[0]) if rest else default_z_scale(float(h.abs().max()) if h.numel() else 0.0)
+                self.codes = torch.clamp(torch.round(h / self.z_scale), -32767, 32767).to(torch.int16).contiguous()
+            if not self.z_scale > 0 or self.codes.dim() != 2:
+                raise ValueError("heightfield: a [ny, nx] grid and a positive z_scale")
+            self.heights = self.codes.to(torch.float32) * torch.tensor(self.z_scale, dtype=torch.float32, device=self.device)
+            self.x0, self.y0, self.cell = float(x0), float(y0), float(cell)
+        self.outside_z = float(outside_z)
+        ny, nx = self.codes.shape
+        self.struct = A.WlHeightField(self.codes.data_ptr(), nx, ny, self.x0, self.y0, self.cell, self.outside_z, self.z_scale)
+
+    def as_tuple(self):
+        """(decoded heights, x0, y0, cell): the form the oracle's functions take"""
+        return self.heights, self.x0, self.y0, self.cell
+
+
 class _MetricsView:
     """`metrics_raw` is what the kernels add into: [slots][WL_M_SHARDS][WL_M_COUNT].  `metrics` is the logical value
     (sum over the shards): [WL_M_COUNT] for one accumulator, [slots][WL_M_COUNT] for a ring; a fresh tensor per read."""
@@ -260,10 +301,8 @@ class ElevBatch(_MetricsView):
         self.terminated = torch.zeros(self.n, dtype=torch.bool, device=dev)
         self.truncated = torch.zeros(self.n, dtype=torch.bool, device=dev)
         self.dones = torch.zeros(self.n, dtype=torch.long, device=dev)   # terminated | truncated, as RSL-RL consumes it
-        h, x0, y0, cell = heightfield if heightfield is not None else synthetic_heightfield()
-        self.height = torch.as_tensor(h, dtype=torch.float32).contiguous().to(dev)
-        self._hf = A.WlHeightField(self.height.data_ptr(), self.height.shape[1], self.height.shape[0], float(x0), float(y0),
-                                   float(cell), 0.0)
+        self.hf = DeviceHeightField(heightfield if heightfield is not None else synthetic_heightfield(), dev)
+        self.height, self._hf = self.hf.heights, self.hf.struct       # the DECODED fp32 grid (what the kernels see); the ABI struct
         # startup events (elevation cfg :387-407): wheel friction fixed (2.0, 1.0), base mass += U(0.2, 0.5)
         if startup is None:
             from .envs.flatten import StartupSpec
@@ -520,10 +559,10 @@ class VisualDepthBatch(VisualBatch):
         if trav_map is None and map_kwargs is None:
             map_kwargs = dict(map_size=(80, 80), env_size=(40, 40), sub_group_size=(20, 20), num_walkers=1)
         super().__init__(n_envs, device, params, seed, env_offset, trav_map, spacing, metrics_slots, startup, map_kwargs)
-        h, x0, y0, cell = heightfield if heightfield is not None else synthetic_heightfield()
-        self.height = torch.as_tensor(h, dtype=torch.float32).contiguous().to(self.device)
+        self.hf = DeviceHeightField(heightfield if heightfield is not None else synthetic_heightfield(), self.device)
+        self.height = self.hf.heights
         self.max_depth = float(max_depth)
-        self.camera = DepthCamera((self.height, float(x0), float(y0), float(cell)), self.device, self.p)
+        self.camera = DepthCamera(self.hf, self.device, self.p)
         self._hf = self.camera._hf
         self.obs = torch.zeros(self.n, self.OBS_DIM, dtype=torch.float32, device=self.device)
         self._out = A.WlStepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.terminated.data_ptr(),
@@ -588,11 +627,9 @@ class DepthCamera:
         if self.device.type != "cuda":
             raise A.HipExtensionMissing("DepthCamera needs a HIP device; there is no CPU path")
         self.p = params if params is not None else visual_params()
-        h, x0, y0, cell = heightfield
-        self.height = h if isinstance(h, torch.Tensor) and h.device == self.device and h.dtype == torch.float32 and h.is_contiguous() \
-            else torch.as_tensor(h, dtype=torch.float32).contiguous().to(self.device)
-        ny, nx = self.height.shape
-        self._hf = A.WlHeightField(self.height.data_ptr(), nx, ny, float(x0), float(y0), float(cell), float(outside_z))
+        self.hf = DeviceHeightField(heightfield, self.device, outside_z)     # a tuple (quantised here) or a batch's own `.hf` (shared)
+        self.height, self._hf = self.hf.heights, self.hf.struct
+        ny, nx = self.hf.codes.shape
         n_f = int(self.lib.wl_heightfield_pyramid_floats(nx, ny))
         if n_f <= 0:
             raise A.WlError(f"heightfield of {nx} x {ny} points is outside the pyramid's range")
@@ -616,7 +653,10 @@ def _cached_depth_camera(batch, heightfield) -> DepthCamera:
     """one DepthCamera per (batch, heightfield): the pyramid is a SNAPSHOT of the field, built on first use and rebuilt when the
     array object, its placement (x0, y0, cell), its shape or -- for tensors -- its in-place version counter changes"""
     cache = batch.__dict__.setdefault("_depth_cameras", {})
-    h, x0, y0, cell = heightfield
+    if isinstance(heightfield, DeviceHeightField):
+        h, x0, y0, cell = heightfield.codes, heightfield.x0, heightfield.y0, heightfield.cell
+    else:
+        h, x0, y0, cell = heightfield[:4]
     key = (id(h), float(x0), float(y0), float(cell), tuple(h.shape), getattr(h, "_version", None))
     cam = cache.get(key)
     if cam is None or cam._src is not h:

@@ -17,8 +17,8 @@
 // nearly the same walk, so the lanes stay together and their gathers hit the same cache lines; a tile's walk length varies
 // 5 x over the image (sky / near ground short, the rows at the horizon long), and single-wavefront blocks let the dispatcher
 // refill a slot the moment its tile is done (five-wavefront strip blocks held four finished wavefronts' slots until the
-// slowest one ended: 716 against 611 us at 4096 cameras, same walk).  The field's copy (2.56 MB) and the pyramid (0.85 MB touched:
-// 4-byte entries) fit an XCD's L2.  Output is the only HBM stream: 19 200 B per env, 64 B segments per tile row.
+// slowest one ended: 716 against 611 us at 4096 cameras, same walk).  The field's copy (16-bit codes: 1.28 MB) and the pyramid
+// (0.85 MB touched: 4-byte entries) fit an XCD's L2 twice over.  Output is the only HBM stream: 19 200 B per env, 64 B segments per tile row.
 #include <hip/hip_runtime.h>
 
 #include "../../include/wheeledlab_amd.h"
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(kBlock) pyramid_planes_large_kernel(const WlHe
         *e = plane_entry(i0, i1, j0, j1, a8, b8, a, b, resid, hmax, buf + hdr);
     }
 }
-__global__ void __launch_bounds__(kBlock) pyramid_copy_heights_kernel(const float* __restrict__ h, float* __restrict__ dst, const int n) {
+__global__ void __launch_bounds__(kBlock) pyramid_copy_heights_kernel(const int16_t* __restrict__ h, int16_t* __restrict__ dst, const int n) {
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k < n) dst[k] = h[k];
 }
@@ -244,7 +244,7 @@ int64_t wl_heightfield_pyramid_floats(int32_t nx, int32_t ny) {
 }
 
 int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* stream) {
-    if (!hf || !hf->height || !pyramid || hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f)) return WL_EINVAL;
+    if (!hf || !hf->height || !pyramid || hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f)) return WL_EINVAL;
     const Pyramid py = make_pyramid(hf->nx, hf->ny);
     clear_error();
     const hipStream_t hs = (hipStream_t)stream;
@@ -255,7 +255,7 @@ int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* 
         if (L <= 4 && L < py.lp) pyramid_planes_small_kernel<<<grid_for(cells), kBlock, 0, hs>>>(*hf, pyramid, py.lp, L, py.hdr);
         else pyramid_planes_large_kernel<<<cells, kBlock, 0, hs>>>(*hf, pyramid, py.lp, L, py.hdr);
     }
-    pyramid_copy_heights_kernel<<<grid_for(hf->nx * hf->ny), kBlock, 0, hs>>>(hf->height, pyramid + py.h0, hf->nx * hf->ny);
+    pyramid_copy_heights_kernel<<<grid_for(hf->nx * hf->ny), kBlock, 0, hs>>>(hf->height, reinterpret_cast<int16_t*>(pyramid + py.h0), hf->nx * hf->ny);
     return launch_status();
 }
 
@@ -264,7 +264,7 @@ int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* 
 static int depth_rows_args_ok(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
                               const float* rows, int64_t row_stride) {
     if (!p || !b || !hf || !b->state || !hf->height || !pyramid || !rows || b->n_envs <= 0 || !(max_depth > 0.f)) return 0;
-    if (hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || b->stride < b->n_envs || !(p->fx > 0.f) ||
+    if (hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f) || b->stride < b->n_envs || !(p->fx > 0.f) ||
         !(p->fy > 0.f) || row_stride < WL_VISDEPTH_NPIX)
         return 0;
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (int64_t)b->n_envs * kTiles > 0x7fffffffLL) return 0;

@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/wheeledlab_amd.h"
 #include "wl_math.h"
+#include "wl_heightfield.h"      // hf_at / hf_decode_pair: the one decoding of the 16-bit height codes
 
 namespace {
 
@@ -13,9 +14,10 @@ namespace {
 //                                    { uint16 c' | int8 a' | int8 b' }: inside the 2^L x 2^L block of cells (J, I) the terrain stays
 //                                    below the PLANE  a (u - I 2^L) + b (v - J 2^L) + c  (u, v in grid units) with a = a' qs,
 //                                    b = b' qs, c = c0 + c' qc; blocks that cover no cell: the word 0 (never read by the walk)
-//   floats [h0, h0 + ny nx)          a copy of the heights [ny][nx], h0 = max(PP / 2, 4) (level 0 is not stored: the intersection
-//                                    needs the four corners of a cell anyway)
-//   floats [h0 + ny nx, + 4)         the header: field maximum, slope quantum qs, offset base c0, offset quantum qc
+//   words  [h0, h0 + ceil(ny nx / 2)) a copy of the 16-bit height CODES [ny][nx] (round 5; fp32 heights before: 2.56 MB of the bench
+//                                    field's 3.4 MB), h0 = max(PP / 2, 4) (level 0 is not stored: the intersection needs the
+//                                    four corners of a cell anyway -- two 4-byte gathers of two codes each)
+//   floats [hdr, hdr + 4)            the header: field maximum, slope quantum qs, offset base c0, offset quantum qc
 // The level offsets are shifts (no table, no division); the price is PP / 6 floats of padding.
 //
 // Round 4: bounding PLANES instead of the round-3 maxima.  Under a maximum a cell on a slope is "as high as its highest corner":
@@ -32,8 +34,8 @@ namespace {
 // there, cost 2 % more wave-steps: the rays that matter pass the last cells before their hit within a millimetre of the surface).
 struct Pyramid {
     int lp;        // log2 P = the top level (one entry)
-    int h0;        // float offset of the height copy
-    int hdr;       // float offset of the header
+    int h0;        // word (4-byte) offset of the copy of the height codes
+    int hdr;       // word offset of the header
 };
 constexpr int kPyrMax = 0, kPyrSlopeQ = 1, kPyrBase = 2, kPyrOffsetQ = 3, kPyrHeader = 4;   // header floats
 inline int pyramid_log2(int nx, int ny) {
@@ -45,7 +47,7 @@ __host__ __device__ inline int pyramid_level_offset(int lp, int L) { return (1 <
 inline Pyramid make_pyramid(int nx, int ny) {
     const int lp = pyramid_log2(nx, ny);
     const int h0 = max((1 << (2 * lp)) >> 1, 4);
-    return Pyramid{lp, h0, h0 + nx * ny};
+    return Pyramid{lp, h0, h0 + (nx * ny + 1) / 2};
 }
 inline int64_t pyramid_total_floats(int nx, int ny) { return (int64_t)make_pyramid(nx, ny).hdr + kPyrHeader; }
 
@@ -94,15 +96,15 @@ WL_DEV bool plane_cell_range(const WlHeightField& f, int L, int I, int J, int& i
 // the fitted slopes of a cell: mean slope between its opposite edges' corner heights, as the entry will hold them (whole steps of the
 // quantum: any slopes give a valid bound, the residual below makes it exact)
 WL_DEV void plane_cell_slopes(const WlHeightField& f, int i0, int i1, int j0, int j1, float q, int& a8, int& b8, float& a, float& b) {
-    const float h00 = f.height[(int64_t)j0 * f.nx + i0], h10 = f.height[(int64_t)j0 * f.nx + i1];
-    const float h01 = f.height[(int64_t)j1 * f.nx + i0], h11 = f.height[(int64_t)j1 * f.nx + i1];
+    const float h00 = hf_at(f, (int64_t)j0 * f.nx + i0), h10 = hf_at(f, (int64_t)j0 * f.nx + i1);
+    const float h01 = hf_at(f, (int64_t)j1 * f.nx + i0), h11 = hf_at(f, (int64_t)j1 * f.nx + i1);
     const float fa = ((h10 + h11) - (h00 + h01)) / (2.f * (float)(i1 - i0)), fb = ((h01 + h11) - (h00 + h10)) / (2.f * (float)(j1 - j0));
     a8 = slope_steps(fa, q), b8 = slope_steps(fb, q);
     a = (float)a8 * q, b = (float)b8 * q;        // exactly what unpack_entry returns
 }
 // residual and height of ONE grid point against the cell's slopes (the reductions over a cell's points take the max of both)
 WL_DEV void plane_point(const WlHeightField& f, int i0, int j0, int i, int j, float a, float b, float& resid, float& hmax) {
-    const float h = f.height[(int64_t)j * f.nx + i];
+    const float h = hf_at(f, (int64_t)j * f.nx + i);
     resid = fmaxf(resid, h - fmaf(a, (float)(i - i0), b * (float)(j - j0)));
     hmax = fmaxf(hmax, h);
 }
@@ -111,7 +113,12 @@ WL_DEV void plane_point(const WlHeightField& f, int i0, int j0, int i, int j, fl
 WL_DEV uint32_t plane_entry(int i0, int i1, int j0, int j1, int a8, int b8, float a, float b, float resid, float hmax, const float* hd) {
     const float centre = resid + 0.5f * fmaf(a, (float)(i1 - i0), b * (float)(j1 - j0));
     const float c0 = hd[kPyrBase], qc = hd[kPyrOffsetQ];
-    const int fit = offset_code(resid + 2e-6f * (1.f + fabsf(resid)), c0, qc);
+    // + the rounding of the walk's t g1 term: |t du| is the distance travelled from the ray's origin, at most |u0| + the block's
+    // extent -- the walk's own margin covers the |a u0| + |b v0| part, the extent part is paid here once per entry instead of per
+    // walk step (a ray that starts at a block's corner and crosses a large steep block: 1.2e-7 |a| 2^L, beyond the walk's fixed
+    // 1e-5 from |a| ~ 0.7 m per cell at level 7)
+    const float travel = 4e-7f * fmaf(fabsf(a), (float)(i1 - i0), fabsf(b) * (float)(j1 - j0));
+    const int fit = offset_code(resid + 2e-6f * (1.f + fabsf(resid)) + travel, c0, qc);
     if (centre < hmax && fit <= 65535) return pack_entry(a8, b8, fit);
     return pack_entry(0, 0, min(offset_code(hmax + 2e-6f * (1.f + fabsf(hmax)), c0, qc), 65535));
 }
@@ -129,11 +136,11 @@ WL_DEV uint32_t plane_cell_serial(const WlHeightField& f, int L, int I, int J, c
 }
 // one height's share of the header's reductions
 WL_DEV void header_point(const WlHeightField& f, int i, int j, float& hmin, float& hmax, float& smax, bool& finite) {
-    const float h = f.height[(int64_t)j * f.nx + i];
+    const float h = hf_at(f, (int64_t)j * f.nx + i);
     hmin = fminf(hmin, h), hmax = fmaxf(hmax, h);
-    finite = finite && (h - h == 0.f);
-    if (i + 1 < f.nx) smax = fmaxf(smax, fabsf(f.height[(int64_t)j * f.nx + i + 1] - h));
-    if (j + 1 < f.ny) smax = fmaxf(smax, fabsf(f.height[(int64_t)(j + 1) * f.nx + i] - h));
+    finite = finite && (h - h == 0.f);      // codes are finite; a non-finite z_scale is refused at the ABI -- kept for the bound's contract
+    if (i + 1 < f.nx) smax = fmaxf(smax, fabsf(hf_at(f, (int64_t)j * f.nx + i + 1) - h));
+    if (j + 1 < f.ny) smax = fmaxf(smax, fabsf(hf_at(f, (int64_t)(j + 1) * f.nx + i) - h));
 }
 // the header of a field, serially (the host simulation; the device has pyramid_header_kernel)
 #ifdef WL_HOST_SIM
@@ -152,17 +159,18 @@ struct FieldMem {
     const float* base;
     WL_DEV float ld(int idx) const { return base[idx]; }
     WL_DEV uint32_t ldw(int idx) const { return __builtin_bit_cast(uint32_t, base[idx]); }
-    WL_DEV void ld2(int idx, float& a, float& b) const { a = base[idx], b = base[idx + 1]; }
+    // two adjacent height codes at HALFWORD index hidx of the buffer, decoded
+    WL_DEV void ldh2(int hidx, float zs, float& a, float& b) const {
+        const int16_t* c = reinterpret_cast<const int16_t*>(base) + hidx;
+        hf_decode_pair((uint32_t)(uint16_t)c[0] | ((uint32_t)(uint16_t)c[1] << 16), zs, a, b);
+    }
 #else
     __amdgpu_buffer_rsrc_t rsrc;   // buffer loads: ONE 32-bit VGPR offset per gather, no 64-bit address arithmetic
     WL_DEV float ld(int idx) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, idx * 4, 0, 0)); }
     WL_DEV uint32_t ldw(int idx) const { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, idx * 4, 0, 0); }
-    WL_DEV void ld2(int idx, float& a, float& b) const {
-        // 4-byte aligned is enough.  The WHOLE result is bit-cast: indexing the builtin's own return type (v[0], v[1]) is folded
-        // to element 0 twice by this compiler (ROCm 7.2 clang, -O3: the load is narrowed to one dword).
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, idx * 4, 0, 0));
-        a = v.x, b = v.y;
+    // two adjacent height codes at HALFWORD index hidx of the buffer (one 4-byte gather, 2-byte aligned), decoded
+    WL_DEV void ldh2(int hidx, float zs, float& a, float& b) const {
+        hf_decode_pair((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, hidx * 2, 0, 0), zs, a, b);
     }
 #endif
 };
@@ -197,9 +205,10 @@ WL_DEV float plane_hit(float oz, float dz, float zp, float ta, float tb) {
 struct DepthGrid {
     int nx, NX, NY;            // row pitch of the heights; cells per side
     float x0, y0, inv_cell, outside_z;
+    float zs;                  // metres per height code
 };
 inline DepthGrid make_depth_grid(const WlHeightField* hf) {
-    return DepthGrid{hf->nx, hf->nx - 1, hf->ny - 1, hf->x0, hf->y0, 1.f / hf->cell, hf->outside_z};
+    return DepthGrid{hf->nx, hf->nx - 1, hf->ny - 1, hf->x0, hf->y0, 1.f / hf->cell, hf->outside_z, hf->z_scale};
 }
 
 // The walk of ONE ray as a state machine, so that a wavefront can keep its lanes busy: ray_begin() sets a ray up (or answers it
@@ -316,9 +325,9 @@ WL_DEV void ray_step(const DepthGrid& g, const Pyramid& py, const PyrHead& hd, c
     float h00, h10, h01, h11;
     bool clear;      // the ray stays above everything in this cell over [t, te]
     if (fine) {
-        const int k = py.h0 + (int)__umul24((unsigned)j, (unsigned)g.nx) + i;   // j, nx < 2^24: the full-rate multiply
-        mem.ld2(k, h00, h10);
-        mem.ld2(k + g.nx, h01, h11);
+        const int k = 2 * py.h0 + (int)__umul24((unsigned)j, (unsigned)g.nx) + i;   // halfword index; j, nx < 2^24: the full-rate multiply
+        mem.ldh2(k, g.zs, h00, h10);
+        mem.ldh2(k + g.nx, g.zs, h01, h11);
         clear = zmin > fmaxf(fmaxf(h00, h10), fmaxf(h01, h11)) + 1e-6f;
     } else {
         // the cell's bounding plane, one 4-byte gather: above it at both ends of the stay = above it throughout

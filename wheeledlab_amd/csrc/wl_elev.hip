@@ -180,31 +180,30 @@ WL_DEV ScanCell scan_cell(const ScanFrame& f, const WlHeightField& hf, float fix
     c.i = i, c.j = j;
     return c;
 }
-// a ray in flight: the two 8-byte gathers of its cell's corners (issued by scan_request), consumed by scan_value
+// a ray in flight: the two 4-byte gathers of its cell's corners (issued by scan_request: two 16-bit height codes each), decoded
+// and consumed by scan_value
 struct ScanRay {
-    wl_float2_u lo, hi;
+    uint32_t lo, hi;      // codes (i, i + 1) of rows j and j + 1: low half = the first
     float fu, fv;
     bool inside;
 };
 struct ScanField {   // the heightfield through a buffer resource: one 32-bit lane offset per gather
     __amdgpu_buffer_rsrc_t rsrc;
     int row_bytes;
+    float z_scale;
 };
 WL_DEV ScanField scan_field(const WlHeightField& hf) {
-    return ScanField{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hf.height), 0, hf.nx * hf.ny * 4, 0x00020000), hf.nx * 4};
+    return ScanField{__builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(hf.height), 0, hf.nx * hf.ny * 2, 0x00020000), hf.nx * 2, hf.z_scale};
 }
 WL_DEV ScanRay scan_request(const ScanFrame& f, const WlHeightField& hf, const ScanField& sf, float fix, float fiy) {
     const ScanCell c = scan_cell(f, hf, fix, fiy);
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     ScanRay r;
     r.fu = c.fu, r.fv = c.fv, r.inside = c.inside;
     // a ray outside the field asks for whatever address its cell index wraps to: inside the buffer it reads a value nobody uses
     // (the ray is a miss), outside it the resource's bounds check returns 0 -- four clamps per ray saved
-    const int idx4 = (c.j * hf.nx + c.i) * 4;
-    // (whole-result bit casts: see FieldMem::ld2 in wl_depth_dev.h)
-    const f32x2 lo = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(sf.rsrc, idx4, 0, 0));
-    const f32x2 hi = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(sf.rsrc, idx4, sf.row_bytes, 0));
-    r.lo.x = lo.x, r.lo.y = lo.y, r.hi.x = hi.x, r.hi.y = hi.y;
+    const int idx2 = (c.j * hf.nx + c.i) * 2;       // 2-byte aligned dword requests: see wl_heightfield.h
+    r.lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sf.rsrc, idx2, 0, 0);
+    r.hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sf.rsrc, idx2, sf.row_bytes, 0);
     return r;
 }
 // FOUR consecutive rays per lane, stored as ONE 16-byte word (round 4).  The scan's 676 four-byte stores per env were what bound
@@ -222,8 +221,11 @@ WL_DEV void scan_quad_slot(int idx, int& j, int& q) {
 }
 // bilinear height under the ray -> the observation value: -(sensor_z - hit_z - offset) + (root_z - plane_init_value), +inf on a
 // miss, clipped to +- obs_clip
-WL_DEV float scan_value(const WlElevParams& p, const ScanRay& r, float pz) {
-    const float a = fmaf(r.fu, r.lo.y - r.lo.x, r.lo.x), b = fmaf(r.fu, r.hi.y - r.hi.x, r.hi.x);
+WL_DEV float scan_value(const WlElevParams& p, const ScanRay& r, float z_scale, float pz) {
+    float h00, h10, h01, h11;
+    hf_decode_pair(r.lo, z_scale, h00, h10);
+    hf_decode_pair(r.hi, z_scale, h01, h11);
+    const float a = fmaf(r.fu, h10 - h00, h00), b = fmaf(r.fu, h11 - h01, h01);
     const float hz = fmaf(r.fv, b - a, a);
     const float val = r.inside ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
     return clampf(val, -p.obs_clip, p.obs_clip);
@@ -239,9 +241,10 @@ WL_DEV void scan_quad_request(const ScanFrame& f, const WlHeightField& hf, const
     r[3] = scan_request(f, hf, sf, fx2 + 1.f, fy2);
 }
 // ... and their four values as one 16-byte word
-WL_DEV wl_float4_u scan_quad_value(const WlElevParams& p, const ScanRay (&r)[4], float pz) {
+WL_DEV wl_float4_u scan_quad_value(const WlElevParams& p, const ScanRay (&r)[4], float z_scale, float pz) {
     wl_float4_u v;
-    v.x = scan_value(p, r[0], pz), v.y = scan_value(p, r[1], pz), v.z = scan_value(p, r[2], pz), v.w = scan_value(p, r[3], pz);
+    v.x = scan_value(p, r[0], z_scale, pz), v.y = scan_value(p, r[1], z_scale, pz), v.z = scan_value(p, r[2], z_scale, pz);
+    v.w = scan_value(p, r[3], z_scale, pz);
     return v;
 }
 #ifndef WL_FUSED_SCAN_NT
@@ -572,24 +575,32 @@ __global__ void __launch_bounds__(kScanThreads) elev_scan_kernel(const WlElevPar
     const ScanField sf = scan_field(ground.f);
     ScanRay cr[4];
     scan_quad_request(fr, ground.f, sf, tid, cr);     // this lane's four rays: their 8 gathers in flight together
-    scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, pz));
+    scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, sf.z_scale, pz));
 }
 // The same scan with the env's terrain patch staged in LDS (BASELINE config 3: "heightfield gather ... in LDS").  One block =
-// one env.  The bounding box of the yaw-rotated 2.5 m footprint -- at most 73 x 73 grid points of the 0.05 m field -- is fetched
-// as whole rows (consecutive lanes = consecutive floats: full-rate coalesced requests, against two divergent 8-byte gathers per
-// ray) and the 676 rays read their four corners from LDS (two ds_read2_b32 each) with the arithmetic of scan_cell / scan_value:
-// the rows are bit-identical to the gather form's.  The staging costs NO vector arithmetic per element: 320 threads = 4 patch rows
-// of pitch 80 per pass, so a thread's column never changes and its row advances by 4 -- the global offset of pass `it` is the
-// thread's constant lane offset + a SCALAR offset (it x 4 field rows), its LDS address the thread's constant + an immediate.
-// Rows past the field's end read 0 through the buffer resource's bounds check (never used: rays there are misses).
+// one env.  The bounding box of the yaw-rotated 2.5 m footprint -- at most 74 x 74 grid points of the 0.05 m field -- is fetched
+// as whole rows (consecutive lanes = consecutive 16-byte words: full-rate coalesced requests, against two divergent 4-byte
+// gathers per ray) and the 676 rays read their four corners from LDS (two 2-byte-aligned ds_read_b32 each: a pair of codes) with
+// the arithmetic of scan_cell / scan_value: the rows are bit-identical to the gather form's.  The staging costs NO vector
+// arithmetic per element: THREADS lanes x 16 bytes = a whole number of patch rows of PITCH codes per pass, so a thread's column
+// group never changes and its row advances by a constant -- the global offset of pass `it` is the thread's constant lane offset
+// + a SCALAR offset, its LDS address the wavefront's M0 base + an immediate.  Rows past the field's end read 0 through the buffer
+// resource's bounds check (never used: rays there are misses).
+// Round 5: 16-bit codes -- a patch row is 160 B instead of 320, the block stages <= 12.8 KB instead of 25.6 KB (the L2 -> LDS
+// volume was the scan's largest stream: ~6 GB per launch at 262 144 envs) in 3 requests per thread instead of 5.  The patch origin
+// is an EVEN column (16-byte requests from 4-byte aligned addresses need an even code index; the row pitch nx must be even too:
+// scan_patch_fits), one column of the 80 - 74 spare.
 // (Round 4, first version: 256 threads, pitch 74, flat index split by multiply-shift per element, pass count by a chain of scalar
 // branches -- 245 VALU + 216 SALU per wavefront, four wavefronts per env: SLOWER than the gathers at every size, 597 against
 // 502 us per observation launch at 262 144 envs: the scan is instruction-bound before it is address-rate-bound.)
 constexpr int kPatch = 74;               // grid points per side the bounding box can need (scan_size * sqrt 2 / cell + 3 must fit)
-// LDS: pitch 80 floats = 20 sixteen-byte words per patch row; 320 threads = 16 patch rows per pass of 16-byte loads; 5 passes
-constexpr int kPatchPitch = 80, kPatchRowsLds = 80;
-constexpr int kLdsScanThreads = 320, kPatchRowsPerPass = kLdsScanThreads / (kPatchPitch / 4);
-static_assert(kPatchRowsPerPass * (kPatchPitch / 4) == kLdsScanThreads && kPatchRowsLds % kPatchRowsPerPass == 0, "whole rows per pass");
+constexpr int kPatchRows = 80;           // patch rows staged at most (kPatch + slack, a multiple of 16)
+#ifndef WL_SCAN_LDS_THREADS
+#define WL_SCAN_LDS_THREADS 320
+#endif
+#ifndef WL_SCAN_LDS_PITCH
+#define WL_SCAN_LDS_PITCH 80             // codes per LDS row (>= kPatch + 2: an even origin costs one column)
+#endif
 // the 7 pose rows of env e (block-uniform address) by ONE lane per wavefront, broadcast with v_readfirstlane: the texture unit is
 // charged per lane address, and with five wavefronts per env the pose loads were 35 of the block's 133 full-width vector-memory
 // instructions.  (Through the scalar cache instead -- s_load_dword x 7 -- the launch is faster up to 16 384 envs, 12.6 against
@@ -604,19 +615,25 @@ WL_DEV void load_pose_lane0(const Rows& S, int e, float (&v)[7]) {
 #pragma unroll
     for (int k = 0; k < 7; ++k) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r[k])));
 }
-// Block = one env, five wavefronts.  Wavefront 0 alone fetches the pose rows and sets the env up (yaw, lattice frame, the patch's
-// origin and row count) and hands 10 words to the others through LDS: the launch is bound by the INSTRUCTIONS it issues, not by
+// Block = one env.  Wavefront 0 alone fetches the pose rows and sets the env up (yaw, lattice frame, the patch's
+// origin and row count) and hands 11 words to the others through LDS: the launch is bound by the INSTRUCTIONS it issues, not by
 // what it moves or waits for (measured at 262 144 envs, us per observation launch, profiles/r04_scan_experiments.txt: half of the
 // staging lanes switched off 522 against 538; two / three envs per block with all their requests overlapped 442 / 572 against
 // 418), and with the set-up repeated by all five wavefronts it was a third of them.
-struct ScanSetup {      // what wavefront 0 publishes (40 bytes)
+struct ScanSetup {      // what wavefront 0 publishes (44 bytes)
     ScanFrame fr;
-    int origin, i0j0, rows;      // byte offset of the patch origin in the field; i0 | j0 << 16; patch rows needed
+    int origin, i0, j0, rows;      // byte offset of the patch origin in the field; its column and row; patch rows needed
 };
-template <bool STREAM>
-__global__ void __launch_bounds__(kLdsScanThreads) elev_scan_lds_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
-                                                                        float* __restrict__ obs) {
-    __shared__ __attribute__((aligned(16))) float patch[kPatchPitch * kPatchRowsLds];
+template <bool STREAM, int THREADS, int PITCH>
+__global__ void __launch_bounds__(THREADS) elev_scan_lds_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
+                                                                float* __restrict__ obs) {
+    constexpr int kWordsPerRow = PITCH / 8;                          // 16-byte words per patch row
+    constexpr int kRowsPerPass = THREADS / kWordsPerRow;
+    constexpr int kPasses = (kPatchRows + kRowsPerPass - 1) / kRowsPerPass;
+    constexpr int kAlways = 64 / kRowsPerPass;                      // 64 rows: the footprint at yaw 0 (52 rows) and a little beyond
+    static_assert(PITCH % 8 == 0 && PITCH >= kPatch + 2 && THREADS % 64 == 0 && THREADS >= 192, "whole 16-byte words per row; three ray wavefronts");
+    static_assert(kRowsPerPass * kWordsPerRow == THREADS && 64 % kRowsPerPass == 0 && kAlways >= 1 && kAlways <= kPasses, "whole rows per pass");
+    __shared__ __attribute__((aligned(16))) int16_t patch[PITCH * kRowsPerPass * kPasses];
     __shared__ __attribute__((aligned(16))) ScanSetup setup;
     const int e = blockIdx.x, tid = threadIdx.x;
     const WlHeightField& f = ground.f;
@@ -627,65 +644,46 @@ __global__ void __launch_bounds__(kLdsScanThreads) elev_scan_lds_kernel(const Wl
         yaw_cs(Quat{pose[3], pose[4], pose[5], pose[6]}, c, s);
         const ScanFrame fr = scan_frame(p, ground, ScanPose{pose[0], pose[1], pose[2], c, s});
         // the patch: the lattice's bounding box in grid units (its corners are rays (0,0), (25,0), (0,25), (25,25)), the +1 corner
-        // of the last cell, a little slack for rounding
+        // of the last cell, a little slack for rounding; the origin column rounded down to an even one
         constexpr float kSpan = (float)(WL_ELEV_SCAN_N - 1);
         const float u_lo = fr.u0 + fminf(kSpan * fr.ux, 0.f) + fminf(kSpan * fr.uy, 0.f), v_lo = fr.v0 + fminf(kSpan * fr.vx, 0.f) + fminf(kSpan * fr.vy, 0.f);
         const float v_hi = fr.v0 + fmaxf(kSpan * fr.vx, 0.f) + fmaxf(kSpan * fr.vy, 0.f);
-        const int i0 = min(max((int)floorf(u_lo - 0.02f), 0), f.nx - kPatchPitch), j0 = min(max((int)floorf(v_lo - 0.02f), 0), f.ny - kPatch);
+        const int i0 = min(max((int)floorf(u_lo - 0.02f), 0) & ~1, f.nx - PITCH), j0 = min(max((int)floorf(v_lo - 0.02f), 0), f.ny - kPatch);
         if (tid == 0) {
             setup.fr = fr;
-            setup.origin = (j0 * f.nx + i0) * 4;
-            setup.i0j0 = i0 | (j0 << 16);
+            setup.origin = (j0 * f.nx + i0) * 2;
+            setup.i0 = i0, setup.j0 = j0;
             setup.rows = min(max((int)floorf(v_hi + 0.02f) + 2 - j0, 1), kPatch);
         }
     }
     __syncthreads();
     const int origin = __builtin_amdgcn_readfirstlane(setup.origin), rows = __builtin_amdgcn_readfirstlane(setup.rows);
-    // staging: 16 bytes per lane and request (4-byte aligned is enough), 16 patch rows per pass: a thread's 4-column group never
-    // changes and its row advances by 16 -- global offset = constant lane offset + a SCALAR pass offset, LDS address = constant +
-    // an immediate: no vector arithmetic per staged element.  Rows past the field's end read 0 through the buffer resource's
-    // bounds check (never used: rays there are misses).
-    const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f.height), 0, f.nx * f.ny * 4, 0x00020000);
-    const int r0 = (int)(__umul24((unsigned)tid, 3277u) >> 16);      // tid / 20 (tid < 320)
-    const int c4 = tid - r0 * (kPatchPitch / 4);
-    const int lane_off = ((int)__umul24((unsigned)r0, (unsigned)f.nx) + 4 * c4) * 4;
-    const int pass_bytes = kPatchRowsPerPass * f.nx * 4;
-    constexpr int kPasses = kPatchRowsLds / kPatchRowsPerPass;      // 5
-    constexpr int kAlways = 4;                                      // 64 rows: the footprint at yaw 0 (52 rows) and a little beyond
-#ifndef WL_SCAN_LDS_DMA
-#define WL_SCAN_LDS_DMA 1
-#endif
-#if WL_SCAN_LDS_DMA
-    // straight into LDS (buffer_load_dwordx4 ... lds): a wavefront's 64 lanes land as 1 KB at its M0 base -- exactly this layout
-    // (consecutive threads = consecutive 16-byte words) -- with no staging registers and no ds_write (whose VGPR -> LDS transfer,
-    // 13 LDS cycles per 16-byte wave-instruction, was a quarter of the block's LDS time).  The compiler does not wait for LDS-DMA:
+    // staging: 16 bytes (8 codes) per lane and request, kRowsPerPass patch rows per pass: a thread's column group never changes and
+    // its row advances by kRowsPerPass -- global offset = constant lane offset + a SCALAR pass offset.  Straight into LDS
+    // (buffer_load_dwordx4 ... lds): a wavefront's 64 lanes land as 1 KB at its M0 base -- exactly this layout (consecutive
+    // threads = consecutive 16-byte words) -- with no staging registers and no ds_write.  The compiler does not wait for LDS-DMA:
     // vmcnt(0) by hand before the barrier that publishes the patch.
+    const __amdgpu_buffer_rsrc_t hr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(f.height), 0, f.nx * f.ny * 2, 0x00020000);
+    const int r0 = tid / kWordsPerRow;                               // compile-time divisor: multiply-shift
+    const int c8 = tid - r0 * kWordsPerRow;
+    const int lane_off = ((int)__umul24((unsigned)r0, (unsigned)f.nx) + 8 * c8) * 2;
+    const int pass_bytes = kRowsPerPass * f.nx * 2;
     {
         typedef __attribute__((address_space(3))) void* lds_ptr;
-        float* wave_base = patch + (tid >> 6) * 256;
+        int16_t* wave_base = patch + (tid >> 6) * 512;              // 64 lanes x 16 B = 512 codes
 #pragma unroll
         for (int it = 0; it < kAlways; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(wave_base + it * kLdsScanThreads * 4), 16, lane_off, origin + it * pass_bytes, 0, 0);
-        if (rows > kAlways * kPatchRowsPerPass)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(wave_base + kAlways * kLdsScanThreads * 4), 16, lane_off, origin + kAlways * pass_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(wave_base + it * THREADS * 8), 16, lane_off, origin + it * pass_bytes, 0, 0);
+#pragma unroll
+        for (int it = kAlways; it < kPasses; ++it)
+            if (rows > it * kRowsPerPass)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(wave_base + it * THREADS * 8), 16, lane_off, origin + it * pass_bytes, 0, 0);
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
     }
-#else
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 stage[kPasses];
-#pragma unroll
-    for (int it = 0; it < kAlways; ++it) stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hr, lane_off, origin + it * pass_bytes, 0));
-    if (rows > kAlways * kPatchRowsPerPass)
-        stage[kAlways] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hr, lane_off, origin + kAlways * pass_bytes, 0));
-    f32x4* patch4 = reinterpret_cast<f32x4*>(patch);
-#pragma unroll
-    for (int it = 0; it < kAlways; ++it) patch4[tid + it * kLdsScanThreads] = stage[it];
-    if (rows > kAlways * kPatchRowsPerPass) patch4[tid + kAlways * kLdsScanThreads] = stage[kAlways];
-#endif
     __syncthreads();
     if (tid < kScanQuads) {     // the first three wavefronts: one quad of rays per lane
         const ScanFrame fr = setup.fr;
-        const int i0 = setup.i0j0 & 0xffff, j0 = setup.i0j0 >> 16;
+        const int i0 = setup.i0, j0 = setup.j0;
         float fx[4], fy[4];
         scan_ray_xy(4 * tid, fx[0], fy[0]);
         scan_ray_xy(4 * tid + 2, fx[2], fy[2]);
@@ -696,16 +694,17 @@ __global__ void __launch_bounds__(kLdsScanThreads) elev_scan_lds_kernel(const Wl
             const ScanCell cell = scan_cell(fr, f, fx[m], fy[m]);
             // clamped (unsigned minimum: a negative offset wraps to the top and is clamped with everything else): a point the
             // bounding box missed would read a wrong corner (the parity tests would show it), never out of bounds
-            const float* h = patch + min((unsigned)(cell.j - j0), (unsigned)(kPatchRowsLds - 2)) * kPatchPitch + min((unsigned)(cell.i - i0), (unsigned)(kPatchPitch - 2));
-            cr[m].lo.x = h[0], cr[m].lo.y = h[1], cr[m].hi.x = h[kPatchPitch], cr[m].hi.y = h[kPatchPitch + 1];
+            const int16_t* h = patch + min((unsigned)(cell.j - j0), (unsigned)(kRowsPerPass * kPasses - 2)) * PITCH + min((unsigned)(cell.i - i0), (unsigned)(PITCH - 2));
+            cr[m].lo = *reinterpret_cast<const wl_u32_u2*>(h), cr[m].hi = *reinterpret_cast<const wl_u32_u2*>(h + PITCH);
             cr[m].fu = cell.fu, cr[m].fv = cell.fv, cr[m].inside = cell.inside;
         }
-        scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, fr.pz));
+        scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, f.z_scale, fr.pz));
     }
 }
-// the staged patch must hold the footprint's bounding box at any yaw
+// the staged patch must hold the footprint's bounding box at any yaw; 16-byte staging requests need an even row pitch (and the
+// even origin column one spare code)
 inline bool scan_patch_fits(const WlElevParams* p, const WlHeightField* hf) {
-    return hf->nx >= kPatchPitch && hf->ny >= kPatch && p->scan_size * 1.41422f / hf->cell + 3.2f <= (float)kPatch;
+    return hf->nx >= WL_SCAN_LDS_PITCH && hf->ny >= kPatch && (hf->nx & 1) == 0 && p->scan_size * 1.41422f / hf->cell + 3.2f <= (float)kPatch;
 }
 // gather form while the chip is not full (every env's 128 lanes in flight at once: latency, not address rate, is what counts
 // there), LDS patches beyond; WL_FLAG_SCAN_LDS / WL_FLAG_SCAN_GATHER force one
@@ -724,8 +723,8 @@ inline void launch_elev_scan(const WlElevParams* p, const WlEnvBuffers* b, const
     const bool stream = use_streaming(b, (int64_t)b->n_envs * WL_ELEV_OBS_DIM * 4, WL_ELEV_STREAM_BYTES);
     const bool lds = scan_patch_fits(p, &g.f) && ((b->flags & WL_FLAG_SCAN_LDS) || (!(b->flags & WL_FLAG_SCAN_GATHER) && b->n_envs >= WL_SCAN_LDS_MIN_ENVS));
     if (lds) {
-        if (stream) elev_scan_lds_kernel<true><<<b->n_envs, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
-        else elev_scan_lds_kernel<false><<<b->n_envs, kLdsScanThreads, 0, hs>>>(*p, *b, g, obs);
+        if (stream) elev_scan_lds_kernel<true, WL_SCAN_LDS_THREADS, WL_SCAN_LDS_PITCH><<<b->n_envs, WL_SCAN_LDS_THREADS, 0, hs>>>(*p, *b, g, obs);
+        else elev_scan_lds_kernel<false, WL_SCAN_LDS_THREADS, WL_SCAN_LDS_PITCH><<<b->n_envs, WL_SCAN_LDS_THREADS, 0, hs>>>(*p, *b, g, obs);
         return;
     }
     if (stream) elev_scan_kernel<true><<<b->n_envs, kScanThreads, 0, hs>>>(*p, *b, g, obs);
@@ -937,7 +936,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
             const int idx = tid + (half * kBatch + i) * kFusedThreads;
             int j, q;
             scan_quad_slot(idx, j, q);
-            if (idx < kAll && j < n_here) scan_quad_store<WL_FUSED_SCAN_NT>(out.obs + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], pz[i]));
+            if (idx < kAll && j < n_here) scan_quad_store<WL_FUSED_SCAN_NT>(out.obs + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], sf.z_scale, pz[i]));
         }
     }
 }
@@ -1027,7 +1026,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_rollout_persistent_kernel(
                 const int idx = t7 + (part * kBatch + i) * kScanLanes;
                 int j, q;
                 scan_quad_slot(idx, j, q);
-                if (idx < kAll && j < n_here) scan_quad_store<WL_FUSED_SCAN_NT>(obs_k + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], pz[i]));
+                if (idx < kAll && j < n_here) scan_quad_store<WL_FUSED_SCAN_NT>(obs_k + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], sf.z_scale, pz[i]));
             }
         }
     }
@@ -1260,7 +1259,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_collect_rollout_kernel(con
                     int j, q;
                     scan_quad_slot(idx, j, q);
                     if (idx < kAll && j < n_here) {
-                        const wl_float4_u v = scan_quad_value(p, cr[i], pz[i]);
+                        const wl_float4_u v = scan_quad_value(p, cr[i], sf.z_scale, pz[i]);
                         scan_quad_store<WL_FUSED_SCAN_NT>(obs_k + (int64_t)(e0 + j) * D + 13, q, v);
                         float* t4 = obs_tile + j * kTilePitch + 13 + 4 * q;
                         t4[0] = v.x, t4[1] = v.y, t4[2] = v.z, t4[3] = v.w;
@@ -1363,7 +1362,7 @@ int check_elev(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
     if (!flags_ok(b)) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f)) return WL_EINVAL;
-    if (hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f)) return WL_EINVAL;
+    if (hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f)) return WL_EINVAL;
     return WL_OK;
 }
 

@@ -8,9 +8,29 @@ namespace {
 // (Round 3: a pair layout -- every grid point stored next to its +y neighbour, so that a cell's four corners are ONE 16-byte
 // gather -- was measured: elevation step at 4096 envs 29.2 vs 26.2 us (the 5.1 MB table no longer fits an XCD's 4 MB L2), at
 // 262 144 envs 668 vs 685, at 1 M envs 2572 vs 2503: no gain where nothing fits, a loss where the plain field does.  Reverted.)
-// two horizontally adjacent cells as ONE 8-byte gather (the address is only 4-byte aligned: fine for global loads on
-// gfx9+); halves the number of gather instructions per bilinear sample
-typedef float wl_float2_u __attribute__((ext_vector_type(2), aligned(4)));
+// Round 5: the grid holds 16-bit height CODES (z = code * z_scale, WlHeightField): two horizontally adjacent grid points are ONE
+// 4-byte gather (the address is only 2-byte aligned: gfx950 takes unaligned dword loads from global memory, buffers and LDS --
+// the compiler emits global_load_dword / ds_read_b32 for them), a cell's four corners two of them; decoding is one conversion
+// (SDWA: sign-extended half -> float) and one multiply per corner, the same on every path, so that all samplers of a field see
+// exactly the floats the oracle's decoded grid holds.
+typedef uint32_t wl_u32_u2 __attribute__((aligned(2)));
+// a dword of two adjacent codes (low half = the first) -> their heights.  The multiply is kept a multiply (contract off): under
+// -ffp-contract=fast the compiler would otherwise fuse it into whichever add consumes the height at each inlining site, and two
+// samplers of one field would disagree in the last bit for scales that are not a power of two.
+WL_DEV void hf_decode_pair(uint32_t w, float z_scale, float& a, float& b) {
+#pragma clang fp contract(off)
+    a = (float)(int)(int16_t)(w & 0xffffu) * z_scale;
+    b = (float)((int)w >> 16) * z_scale;
+}
+// two adjacent codes at grid index k (row-major), decoded
+WL_DEV void hf_pair(const WlHeightField& f, int64_t k, float& a, float& b) {
+    hf_decode_pair(*reinterpret_cast<const wl_u32_u2*>(f.height + k), f.z_scale, a, b);
+}
+// one grid point, decoded (table builders: the depth pyramid)
+WL_DEV float hf_at(const WlHeightField& f, int64_t k) {
+#pragma clang fp contract(off)
+    return (float)(int)f.height[k] * f.z_scale;
+}
 
 // bilinear heightfield sampler (spec: oracle/heightfield.py::sample)
 struct HeightFieldGround {
@@ -24,8 +44,10 @@ struct HeightFieldGround {
         const float fi = floorf(uc), fj = floorf(vc);
         const int i = (int)fi, j = (int)fj;
         const float fu = uc - fi, fv = vc - fj;
-        const float* row0 = f.height + (int64_t)j * f.nx + i;
-        const float h00 = row0[0], h10 = row0[1], h01 = row0[f.nx], h11 = row0[f.nx + 1];
+        const int64_t k = (int64_t)j * f.nx + i;
+        float h00, h10, h01, h11;
+        hf_pair(f, k, h00, h10);
+        hf_pair(f, k + f.nx, h01, h11);
         const float a = fmaf(fu, h10 - h00, h00), b = fmaf(fu, h11 - h01, h01);
         const float zz = fmaf(fv, b - a, a);
         const float dzdx = fmaf(fv, (h11 - h01) - (h10 - h00), h10 - h00) * inv_cell;
@@ -38,9 +60,9 @@ struct HeightFieldGround {
     WL_DEV void sample(float x, float y, float& z, V3& n) const { (void)sample_full(x, y, z, n); }
     template <int W>
     WL_DEV void sample_wheel(float x, float y, float& z, V3& n) const { (void)sample_full(x, y, z, n); }
-    // split form of sample_height for software pipelining: `corners` issues the two 8-byte gathers, `blend` consumes them
+    // split form of sample_height for software pipelining: `corners` issues the two 4-byte gathers, `blend` consumes them
     struct Corners {
-        wl_float2_u lo, hi;
+        float h00, h10, h01, h11;
         float fu, fv;
         bool inside;
     };
@@ -68,34 +90,26 @@ struct HeightFieldGround {
         c.inside = k.inside;
         c.fu = k.fu;
         c.fv = k.fv;
-        const float* row0 = f.height + k.j * f.nx + k.i;
-        c.lo = *reinterpret_cast<const wl_float2_u*>(row0);
-        c.hi = *reinterpret_cast<const wl_float2_u*>(row0 + f.nx);
+        const int idx = k.j * f.nx + k.i;
+        hf_pair(f, idx, c.h00, c.h10);
+        hf_pair(f, idx + f.nx, c.h01, c.h11);
         return c;
     }
     WL_DEV float blend(const Corners& c) const {
-        const float a = fmaf(c.fu, c.lo.y - c.lo.x, c.lo.x), b = fmaf(c.fu, c.hi.y - c.hi.x, c.hi.x);
+        const float a = fmaf(c.fu, c.h10 - c.h00, c.h00), b = fmaf(c.fu, c.h11 - c.h01, c.h01);
         return c.inside ? fmaf(c.fv, b - a, a) : f.outside_z;
     }
     // height only (ray casting: no normal needed) -- same arithmetic as sample_full for z
     WL_DEV bool sample_height(float x, float y, float& z) const {
-        const float u = (x - f.x0) * inv_cell, v = (y - f.y0) * inv_cell;
-        const bool inside = u >= 0.f && v >= 0.f && u < (float)(f.nx - 1) && v < (float)(f.ny - 1);
-        const float uc = fminf(fmaxf(u, 0.f), (float)(f.nx - 1) - 1e-3f), vc = fminf(fmaxf(v, 0.f), (float)(f.ny - 1) - 1e-3f);
-        const float fi = floorf(uc), fj = floorf(vc);
-        const float fu = uc - fi, fv = vc - fj;
-        const float* row0 = f.height + (int64_t)(int)fj * f.nx + (int)fi;
-        const wl_float2_u lo = *reinterpret_cast<const wl_float2_u*>(row0);
-        const wl_float2_u hi = *reinterpret_cast<const wl_float2_u*>(row0 + f.nx);
-        const float a = fmaf(fu, lo.y - lo.x, lo.x), b = fmaf(fu, hi.y - hi.x, hi.x);
-        z = inside ? fmaf(fv, b - a, a) : f.outside_z;
-        return inside;
+        const Corners c = corners(x, y);
+        z = blend(c);
+        return c.inside;
     }
 };
 
 // The same sampler with the four corner heights of each WHEEL's current cell kept in registers (lane form of the step kernels: one
 // lane = one env = four wheels).  A wheel moves <= 1.5 cm per 5 ms sub-step over 5 cm cells: its cell changes every few sub-steps,
-// so the two 8-byte gathers are re-issued only for the lanes whose wheel crossed a cell line -- a quarter of the lane addresses.
+// so the two 4-byte gathers are re-issued only for the lanes whose wheel crossed a cell line -- a quarter of the lane addresses.
 // At large batches the lane-form step is bound by exactly those addresses (160 divergent gather instructions per env-step, each
 // 64 envs = 64 unrelated cache lines).  Same arithmetic on the same corners: bit-identical to HeightFieldGround.
 struct HeightFieldGroundCached {
@@ -116,11 +130,9 @@ struct HeightFieldGroundCached {
         const float fi = floorf(uc), fj = floorf(vc);
         const int k = (int)fj * f.nx + (int)fi;
         const float fu = uc - fi, fv = vc - fj;
-        if (k != cell[W]) {       // per lane: only the lanes whose wheel changed cells gather
-            const float* row0 = f.height + k;
-            const wl_float2_u lo = *reinterpret_cast<const wl_float2_u*>(row0);
-            const wl_float2_u hi = *reinterpret_cast<const wl_float2_u*>(row0 + f.nx);
-            h00[W] = lo.x, h10[W] = lo.y, h01[W] = hi.x, h11[W] = hi.y;
+        if (k != cell[W]) {       // per lane: only the lanes whose wheel changed cells gather (and decode)
+            hf_pair(f, k, h00[W], h10[W]);
+            hf_pair(f, k + f.nx, h01[W], h11[W]);
             cell[W] = k;
         }
         const float a00 = h00[W], a10 = h10[W], a01 = h01[W], a11 = h11[W];

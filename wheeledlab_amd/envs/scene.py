@@ -216,8 +216,8 @@ class CameraData:
             if getattr(b, "camera", None) is not None:      # visual-depth task: the batch's own camera (its terrain, its pyramid)
                 self._cam = b.camera
                 return self._cam
-            if hasattr(b, "height"):        # elevation task: its own heightfield (already on the device)
-                hf = (b.height, float(b._hf.x0), float(b._hf.y0), float(b._hf.cell))
+            if hasattr(b, "hf"):            # elevation task: its own heightfield (already on the device: shared, not re-quantised)
+                hf = b.hf
             else:                           # flat ground: any grid at z = 0 (beyond it the outside plane is z = 0 as well)
                 hf = (torch.zeros(3, 3, dtype=torch.float32, device=b.device), -1.0, -1.0, 1.0)
             self._cam = DepthCamera(hf, b.device, b.p if isinstance(b.p, A.WlVisualParams) else self._params_from_cfg())
