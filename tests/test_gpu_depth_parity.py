@@ -121,7 +121,7 @@ def test_invalid_arguments_are_refused(hf):
     assert lib.wl_visual_depth(*args(md=0.0)) == -1
     bad_hf = A.WlHeightField(cam._hf.height, 1, 800, 0.0, 0.0, 0.05, 0.0, cam._hf.z_scale)
     assert lib.wl_visual_depth(*args(hf=bad_hf)) == -1
-    assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800 + 4
+    assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800 // 2 + 4
     assert lib.wl_heightfield_build_pyramid(C.byref(bad_hf), cam.pyramid.data_ptr(), None) == -1
     torch.cuda.synchronize()
 

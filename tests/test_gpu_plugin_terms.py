@@ -204,14 +204,14 @@ def test_visual_depth_observation_term_through_the_scene_camera():
     # a plugin's pose write (what a user reset event does) invalidates the cached image as well
     before = mdp.camera_data_depth(env).clone()
     robot = env.scene["robot"]
-    pose = torch.cat([robot.data.root_pos_w, robot.data.root_quat_w], 1)
+    pose0 = torch.cat([robot.data.root_pos_w, robot.data.root_quat_w], 1)
+    pose = pose0.clone()
     pose[:, 2] += 0.5
     robot.write_root_pose_to_sim(pose)
     lifted = mdp.camera_data_depth(env)
     assert not torch.equal(lifted, before)
     assert torch.equal(lifted[..., 0], cam._camera().render(env._batch, cam.far))
-    pose[:, 2] -= 0.5
-    robot.write_root_pose_to_sim(pose)
+    robot.write_root_pose_to_sim(pose0)
     assert torch.equal(mdp.camera_data_depth(env), before)
     for _ in range(5):
         obs, *_ = env.step(torch.rand(n, 2, device=DEV) * 2 - 1)

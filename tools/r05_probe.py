@@ -1,6 +1,6 @@
 """Round-5 same-box A/B: us per launch / step of the named workloads for the in-tree library and every build in
 gpurun_variants/lib_*.so (tools/build_variants.sh).   usage: r05_probe.py workload[,workload...] [repeat]
-workloads: drift4096 drift65536 drift1m elev4096 elevobs262144 elevstep262144 elevstep1m visual4096 depth4096 vdtask4096"""
+workloads: drift4096 drift65536 drift1m elev4096 elevobs262144 elevobsg262144 (gather form) elevstep262144 elevstep1m visual4096 depth4096 vdtask4096"""
 import glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -39,8 +39,10 @@ def run(name):
         a = torch.rand(K, n, 2, device=dev) * 2 - 1
         return timed(lambda: env.rollout(a), 8 if n <= 65536 else 6, K, warm=3)
     if name.startswith("elev"):
-        n = int(name.replace("elevobs", "").replace("elevstep", "").replace("elev", "").replace("1m", "1048576"))
+        n = int(name.replace("elevobsg", "").replace("elevobs", "").replace("elevstep", "").replace("elev", "").replace("1m", "1048576"))
         env = ElevBatch(n, device=dev, seed=42)
+        if name.startswith("elevobsg"):
+            env.set_flags(A.FLAG_SCAN_GATHER)
         env.reset()
         K = 32 if n <= 32768 else 4
         a = torch.rand(K, n, 2, device=dev) * 2 - 1

@@ -202,8 +202,16 @@ WL_DEV ScanRay scan_request(const ScanFrame& f, const WlHeightField& hf, const S
     // a ray outside the field asks for whatever address its cell index wraps to: inside the buffer it reads a value nobody uses
     // (the ray is a miss), outside it the resource's bounds check returns 0 -- four clamps per ray saved
     const int idx2 = (c.j * hf.nx + c.i) * 2;       // 2-byte aligned dword requests: see wl_heightfield.h
+#if WL_HF_ALIGNED_PAIRS
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(sf.rsrc, idx2 & ~3, 0, 0));
+    const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(sf.rsrc, idx2 & ~3, sf.row_bytes, 0));
+    const unsigned sh = ((unsigned)idx2 & 2u) * 8u;
+    r.lo = __builtin_amdgcn_alignbit(lo.y, lo.x, sh), r.hi = __builtin_amdgcn_alignbit(hi.y, hi.x, sh);
+#else
     r.lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sf.rsrc, idx2, 0, 0);
     r.hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sf.rsrc, idx2, sf.row_bytes, 0);
+#endif
     return r;
 }
 // FOUR consecutive rays per lane, stored as ONE 16-byte word (round 4).  The scan's 676 four-byte stores per env were what bound
@@ -580,7 +588,7 @@ __global__ void __launch_bounds__(kScanThreads) elev_scan_kernel(const WlElevPar
 // The same scan with the env's terrain patch staged in LDS (BASELINE config 3: "heightfield gather ... in LDS").  One block =
 // one env.  The bounding box of the yaw-rotated 2.5 m footprint -- at most 74 x 74 grid points of the 0.05 m field -- is fetched
 // as whole rows (consecutive lanes = consecutive 16-byte words: full-rate coalesced requests, against two divergent 4-byte
-// gathers per ray) and the 676 rays read their four corners from LDS (two 2-byte-aligned ds_read_b32 each: a pair of codes) with
+// gathers per ray) and the 676 rays read their four corners from LDS (two aligned dword pairs each, the code pair cut out with v_alignbit) with
 // the arithmetic of scan_cell / scan_value: the rows are bit-identical to the gather form's.  The staging costs NO vector
 // arithmetic per element: THREADS lanes x 16 bytes = a whole number of patch rows of PITCH codes per pass, so a thread's column
 // group never changes and its row advances by a constant -- the global offset of pass `it` is the thread's constant lane offset
@@ -633,7 +641,7 @@ __global__ void __launch_bounds__(THREADS) elev_scan_lds_kernel(const WlElevPara
     constexpr int kAlways = 64 / kRowsPerPass;                      // 64 rows: the footprint at yaw 0 (52 rows) and a little beyond
     static_assert(PITCH % 8 == 0 && PITCH >= kPatch + 2 && THREADS % 64 == 0 && THREADS >= 192, "whole 16-byte words per row; three ray wavefronts");
     static_assert(kRowsPerPass * kWordsPerRow == THREADS && 64 % kRowsPerPass == 0 && kAlways >= 1 && kAlways <= kPasses, "whole rows per pass");
-    __shared__ __attribute__((aligned(16))) int16_t patch[PITCH * kRowsPerPass * kPasses];
+    __shared__ __attribute__((aligned(16))) int16_t patch[PITCH * kRowsPerPass * kPasses + 8];   // + the dword past the last pair read
     __shared__ __attribute__((aligned(16))) ScanSetup setup;
     const int e = blockIdx.x, tid = threadIdx.x;
     const WlHeightField& f = ground.f;
@@ -694,8 +702,14 @@ __global__ void __launch_bounds__(THREADS) elev_scan_lds_kernel(const WlElevPara
             const ScanCell cell = scan_cell(fr, f, fx[m], fy[m]);
             // clamped (unsigned minimum: a negative offset wraps to the top and is clamped with everything else): a point the
             // bounding box missed would read a wrong corner (the parity tests would show it), never out of bounds
-            const int16_t* h = patch + min((unsigned)(cell.j - j0), (unsigned)(kRowsPerPass * kPasses - 2)) * PITCH + min((unsigned)(cell.i - i0), (unsigned)(PITCH - 2));
-            cr[m].lo = *reinterpret_cast<const wl_u32_u2*>(h), cr[m].hi = *reinterpret_cast<const wl_u32_u2*>(h + PITCH);
+            // ALIGNED dword pairs + v_alignbit: a code pair at an odd column straddles two LDS dwords, and a misaligned ds_read_b32
+            // is served lane by lane (measured: the scan launch at 262 144 envs 698 us with 2-byte aligned reads against 404 us for
+            // the fp32 patch of round 4)
+            const unsigned rj = min((unsigned)(cell.j - j0), (unsigned)(kRowsPerPass * kPasses - 2)), ri = min((unsigned)(cell.i - i0), (unsigned)(PITCH - 2));
+            const uint32_t* h = reinterpret_cast<const uint32_t*>(patch) + rj * (PITCH / 2) + (ri >> 1);
+            const unsigned sh = (ri & 1u) * 16u;
+            cr[m].lo = __builtin_amdgcn_alignbit(h[1], h[0], sh);
+            cr[m].hi = __builtin_amdgcn_alignbit(h[PITCH / 2 + 1], h[PITCH / 2], sh);
             cr[m].fu = cell.fu, cr[m].fv = cell.fv, cr[m].inside = cell.inside;
         }
         scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, f.z_scale, fr.pz));

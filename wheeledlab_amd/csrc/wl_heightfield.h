@@ -22,9 +22,20 @@ WL_DEV void hf_decode_pair(uint32_t w, float z_scale, float& a, float& b) {
     a = (float)(int)(int16_t)(w & 0xffffu) * z_scale;
     b = (float)((int)w >> 16) * z_scale;
 }
-// two adjacent codes at grid index k (row-major), decoded
+// two adjacent codes at grid index k (row-major), decoded.  WL_HF_ALIGNED_PAIRS (probe build): the aligned 8 bytes around the pair
+// + v_alignbit instead of one 2-byte aligned dword -- what the LDS patch reads need (wl_elev.hip); global memory takes the
+// misaligned dword at full rate (round 5, same box: see DESIGN.md section 7)
+#ifndef WL_HF_ALIGNED_PAIRS
+#define WL_HF_ALIGNED_PAIRS 0
+#endif
 WL_DEV void hf_pair(const WlHeightField& f, int64_t k, float& a, float& b) {
+#if WL_HF_ALIGNED_PAIRS
+    typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+    const u32x2_a4 w = *reinterpret_cast<const u32x2_a4*>(f.height + (k & ~(int64_t)1));
+    hf_decode_pair(__builtin_amdgcn_alignbit(w.y, w.x, ((unsigned)k & 1u) * 16u), f.z_scale, a, b);
+#else
     hf_decode_pair(*reinterpret_cast<const wl_u32_u2*>(f.height + k), f.z_scale, a, b);
+#endif
 }
 // one grid point, decoded (table builders: the depth pyramid)
 WL_DEV float hf_at(const WlHeightField& f, int64_t k) {
