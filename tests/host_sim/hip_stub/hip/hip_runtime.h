@@ -22,6 +22,9 @@ static inline float __builtin_amdgcn_cosf(float rev) { return (float)std::cos(6.
 static inline float __builtin_amdgcn_logf(float x) { return std::log2(x); }                                         // v_log_f32 is log2
 static inline int __builtin_amdgcn_update_dpp(int, int v, int, int, int, bool) { return v; }   // quad forms are not simulated
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {     // v_alignbit_b32: ({hi, lo} >> sh[4:0])[31:0]
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31u));
+}
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }

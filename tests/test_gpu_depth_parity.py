@@ -36,11 +36,13 @@ def _posed_batch(pos, quat):
 def test_pyramid_planes_bound_every_grid_point_of_their_cells(hf):
     """the bound pyramid as the device builds it (wl_heightfield_build_pyramid) keeps its contract: tests/depth_cases.py::check_pyramid"""
     from wheeledlab_amd.core import DepthCamera
-    rough = np.random.RandomState(5).uniform(0.0, 1.5, (97, 131)).astype(np.float32)       # nothing smooth about it
-    for field in (hf, (hf[0][:613, :349].copy(), hf[1], hf[2], hf[3]), (rough, -3.0, -2.0, 0.05)):
-        cam = DepthCamera(field, DEV)
+    rough = DC.on_lattice((np.random.RandomState(5).uniform(0.0, 1.5, (97, 131)), -3.0, -2.0, 0.05))       # nothing smooth about it
+    coarse = DC.on_lattice((np.random.RandomState(6).uniform(-0.5, 1.0, (40, 56)), -1.0, -1.4, 0.05), z_scale=0.005)   # IsaacLab's default vertical_scale
+    for field, zs in ((hf, None), ((hf[0][:613, :349].copy(), hf[1], hf[2], hf[3]), None), (rough, None), (coarse, 0.005)):
+        cam = DepthCamera(field if zs is None else field + (zs,), DEV)
         torch.cuda.synchronize()
-        DC.check_pyramid(cam.pyramid.cpu().numpy(), field[0])
+        assert cam.hf.codes.dtype == torch.int16 and torch.equal(cam.height.cpu(), torch.from_numpy(np.asarray(field[0], np.float32)))   # lossless
+        DC.check_pyramid(cam.pyramid.cpu().numpy(), field[0], cam.hf.z_scale)
 
 
 @pytest.mark.parametrize("max_depth", [100.0, 20.0])

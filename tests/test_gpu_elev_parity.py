@@ -201,7 +201,7 @@ def test_persistent_rollout_equals_stepping(n, K, slots):
     assert torch.equal(ma[8:12], mb[8:12]) and float(ma[8]) == float(outs[0][4].sum())      # resets, time-outs, first two terminations
 
 
-@pytest.mark.parametrize("terrain", ["tilted", "bench"])
+@pytest.mark.parametrize("terrain", ["plane", "tilted", "bench"])
 @pytest.mark.parametrize("lanes", [4, 1])
 def test_settled_cars_need_no_contact_excuse(lanes, terrain):
     """Companion of test_elev_fused_step_matches_oracle_single_steps: that test excuses up to 1 % of envs per step as contact
@@ -210,7 +210,12 @@ def test_settled_cars_need_no_contact_excuse(lanes, terrain):
     long swell (all four wheels stay loaded; normals still vary), every termination is switched off on BOTH sides, the cars
     settle for 12 steps and then crawl -- the excused set must be EMPTY for 24 steps, in both forms of the kernel.
     terrain "bench" (round 4): the same on the synthetic 800 x 800 terrain bench.py and the step test run on (hills, ramps up to
-    plateaus, the 4 cm undulation): settled, gently driven cars keep all four wheels loaded there too."""
+    plateaus, the 4 cm undulation): settled, gently driven cars keep all four wheels loaded there too.
+    Round 5 (16-bit height codes): a CURVED surface on the code lattice carries +-0.06 mm of rounding per grid point -- slope noise of
+    0.24 % between neighbouring cells, a kink in the ground normal at every cell line -- so "tilted" (plane + swell) now behaves like
+    "bench": now and then ONE car's wheel sits on a cell line in one arithmetic and beside it in the other (measured: 1 env of 512 in
+    1 - 2 of the 24 steps, 2 - 4 x the bound).  The EMPTY excuse set is held on terrain "plane": a tilted plane that IS on the lattice
+    (41 and 20 codes of rise per cell: 10 % and 4.9 % grade), all four wheels loaded, the body rolled and pitched against gravity."""
     from wheeledlab_amd.core import ElevBatch
     n = 512
     xs = (np.arange(800) * 0.05 - 20.0).astype(np.float64)
@@ -222,6 +227,11 @@ def test_settled_cars_need_no_contact_excuse(lanes, terrain):
                      np.float32(-20.0), np.float32(0.05)))
     if terrain == "bench":
         hf = OH.make_terrain()
+    if terrain == "plane":
+        ii, jj = np.meshgrid(np.arange(800) - 400, np.arange(800) - 400, indexing="xy")
+        codes = (1556 + 41 * ii + 20 * jj).astype(np.int16)
+        hf = (OH.decode(codes), np.float32(-20.0), np.float32(-20.0), np.float32(0.05))
+        assert np.abs(np.diff(hf[0], 2, axis=1)).max() == 0 and np.abs(np.diff(hf[0], 2, axis=0)).max() == 0     # exactly flat: no lattice noise
     env = ElevBatch(n, device=DEV, seed=8, heightfield=hf)
     env.set_lanes(lanes)
     p = OS.elev_params()
@@ -248,7 +258,7 @@ def test_settled_cars_need_no_contact_excuse(lanes, terrain):
         assert not term.any() and not trunc.any() and not o_term.any() and not o_trunc.any()
         err = np.abs(got[:21, :n] - st[:21, :n]) / (5e-4 + 5e-4 * np.abs(st[:21, :n]))
         touchy = err.max(0) > 1.0
-        if terrain == "tilted":
+        if terrain == "plane":
             assert touchy.sum() == 0, (k, int(touchy.sum()), float(err.max()))
         else:
             # the bench terrain has crests (plateau rims, hill tops) where ONE wheel of a crawling car unloads within a step: measured

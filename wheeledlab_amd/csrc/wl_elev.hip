@@ -417,6 +417,9 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
     if constexpr (LANES == 1 && WL_WHEEL_CORNER_CACHE) {      // lane form: each wheel's cell corners stay in registers between sub-steps
         const HeightFieldGroundCached cached(ground);
         vehicle_integrate<LANES, HeightFieldGroundCached>(vp, vd, ec, s, cached, wid);
+    } else if constexpr (LANES == 4 && WL_HF_AHEAD) {          // quad form: the next sub-step's codes requested one sub-step ahead
+        const HeightFieldGroundAhead ahead(ground);
+        vehicle_integrate<LANES, HeightFieldGroundAhead>(vp, vd, ec, s, ahead, wid);
     } else {
         vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
     }
@@ -594,8 +597,8 @@ __global__ void __launch_bounds__(kScanThreads) elev_scan_kernel(const WlElevPar
 // group never changes and its row advances by a constant -- the global offset of pass `it` is the thread's constant lane offset
 // + a SCALAR offset, its LDS address the wavefront's M0 base + an immediate.  Rows past the field's end read 0 through the buffer
 // resource's bounds check (never used: rays there are misses).
-// Round 5: 16-bit codes -- a patch row is 160 B instead of 320, the block stages <= 12.8 KB instead of 25.6 KB (the L2 -> LDS
-// volume was the scan's largest stream: ~6 GB per launch at 262 144 envs) in 3 requests per thread instead of 5.  The patch origin
+// Round 5: 16-bit codes -- a patch row of 80 codes is 160 B instead of 320, the block stages half of round 4's 25.6 KB (the L2 -> LDS
+// volume was the scan's largest stream: ~6 GB per launch at 262 144 envs).  The patch origin
 // is an EVEN column (16-byte requests from 4-byte aligned addresses need an even code index; the row pitch nx must be even too:
 // scan_patch_fits), one column of the 80 - 74 spare.
 // (Round 4, first version: 256 threads, pitch 74, flat index split by multiply-shift per element, pass count by a chain of scalar
@@ -603,11 +606,17 @@ __global__ void __launch_bounds__(kScanThreads) elev_scan_kernel(const WlElevPar
 // 502 us per observation launch at 262 144 envs: the scan is instruction-bound before it is address-rate-bound.)
 constexpr int kPatch = 74;               // grid points per side the bounding box can need (scan_size * sqrt 2 / cell + 3 must fit)
 constexpr int kPatchRows = 80;           // patch rows staged at most (kPatch + slack, a multiple of 16)
+// Block shape (round 5, us per observation launch at 262 144 envs, same box): 320 threads / pitch 80 (round 4's shape, three
+// requests per thread) 411 - 414; 256 / 128: the same; 192 / 96 (the three wavefronts that cast the rays also stage, five requests
+// per thread, 15.4 KB per env) 355 - 357 -- fewer, fuller wavefronts per env; shipped.
 #ifndef WL_SCAN_LDS_THREADS
-#define WL_SCAN_LDS_THREADS 320
+#define WL_SCAN_LDS_THREADS 192
 #endif
 #ifndef WL_SCAN_LDS_PITCH
-#define WL_SCAN_LDS_PITCH 80             // codes per LDS row (>= kPatch + 2: an even origin costs one column)
+#define WL_SCAN_LDS_PITCH 96             // codes per LDS row (>= kPatch + 2: an even origin costs one column)
+#endif
+#ifndef WL_SCAN_LDS_STAGERS
+#define WL_SCAN_LDS_STAGERS WL_SCAN_LDS_THREADS      // threads that issue staging requests (a whole number of patch rows per pass)
 #endif
 // the 7 pose rows of env e (block-uniform address) by ONE lane per wavefront, broadcast with v_readfirstlane: the texture unit is
 // charged per lane address, and with five wavefronts per env the pose loads were 35 of the block's 133 full-width vector-memory
@@ -632,15 +641,15 @@ struct ScanSetup {      // what wavefront 0 publishes (44 bytes)
     ScanFrame fr;
     int origin, i0, j0, rows;      // byte offset of the patch origin in the field; its column and row; patch rows needed
 };
-template <bool STREAM, int THREADS, int PITCH>
+template <bool STREAM, int THREADS, int PITCH, int STAGERS = THREADS>
 __global__ void __launch_bounds__(THREADS) elev_scan_lds_kernel(const WlElevParams p, const WlEnvBuffers b, const HeightFieldGround ground,
                                                                 float* __restrict__ obs) {
     constexpr int kWordsPerRow = PITCH / 8;                          // 16-byte words per patch row
-    constexpr int kRowsPerPass = THREADS / kWordsPerRow;
+    constexpr int kRowsPerPass = STAGERS / kWordsPerRow;
     constexpr int kPasses = (kPatchRows + kRowsPerPass - 1) / kRowsPerPass;
     constexpr int kAlways = 64 / kRowsPerPass;                      // 64 rows: the footprint at yaw 0 (52 rows) and a little beyond
     static_assert(PITCH % 8 == 0 && PITCH >= kPatch + 2 && THREADS % 64 == 0 && THREADS >= 192, "whole 16-byte words per row; three ray wavefronts");
-    static_assert(kRowsPerPass * kWordsPerRow == THREADS && 64 % kRowsPerPass == 0 && kAlways >= 1 && kAlways <= kPasses, "whole rows per pass");
+    static_assert(kRowsPerPass * kWordsPerRow == STAGERS && STAGERS <= THREADS && 64 % kRowsPerPass == 0 && kAlways >= 1 && kAlways <= kPasses, "whole rows per pass");
     __shared__ __attribute__((aligned(16))) int16_t patch[PITCH * kRowsPerPass * kPasses + 8];   // + the dword past the last pair read
     __shared__ __attribute__((aligned(16))) ScanSetup setup;
     const int e = blockIdx.x, tid = threadIdx.x;
@@ -676,16 +685,16 @@ __global__ void __launch_bounds__(THREADS) elev_scan_lds_kernel(const WlElevPara
     const int c8 = tid - r0 * kWordsPerRow;
     const int lane_off = ((int)__umul24((unsigned)r0, (unsigned)f.nx) + 8 * c8) * 2;
     const int pass_bytes = kRowsPerPass * f.nx * 2;
-    {
+    if (STAGERS == THREADS || tid < STAGERS) {
         typedef __attribute__((address_space(3))) void* lds_ptr;
         int16_t* wave_base = patch + (tid >> 6) * 512;              // 64 lanes x 16 B = 512 codes
 #pragma unroll
         for (int it = 0; it < kAlways; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(wave_base + it * THREADS * 8), 16, lane_off, origin + it * pass_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(wave_base + it * STAGERS * 8), 16, lane_off, origin + it * pass_bytes, 0, 0);
 #pragma unroll
         for (int it = kAlways; it < kPasses; ++it)
             if (rows > it * kRowsPerPass)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(wave_base + it * THREADS * 8), 16, lane_off, origin + it * pass_bytes, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(hr, (lds_ptr)(wave_base + it * STAGERS * 8), 16, lane_off, origin + it * pass_bytes, 0, 0);
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
     }
     __syncthreads();
@@ -737,8 +746,8 @@ inline void launch_elev_scan(const WlElevParams* p, const WlEnvBuffers* b, const
     const bool stream = use_streaming(b, (int64_t)b->n_envs * WL_ELEV_OBS_DIM * 4, WL_ELEV_STREAM_BYTES);
     const bool lds = scan_patch_fits(p, &g.f) && ((b->flags & WL_FLAG_SCAN_LDS) || (!(b->flags & WL_FLAG_SCAN_GATHER) && b->n_envs >= WL_SCAN_LDS_MIN_ENVS));
     if (lds) {
-        if (stream) elev_scan_lds_kernel<true, WL_SCAN_LDS_THREADS, WL_SCAN_LDS_PITCH><<<b->n_envs, WL_SCAN_LDS_THREADS, 0, hs>>>(*p, *b, g, obs);
-        else elev_scan_lds_kernel<false, WL_SCAN_LDS_THREADS, WL_SCAN_LDS_PITCH><<<b->n_envs, WL_SCAN_LDS_THREADS, 0, hs>>>(*p, *b, g, obs);
+        if (stream) elev_scan_lds_kernel<true, WL_SCAN_LDS_THREADS, WL_SCAN_LDS_PITCH, WL_SCAN_LDS_STAGERS><<<b->n_envs, WL_SCAN_LDS_THREADS, 0, hs>>>(*p, *b, g, obs);
+        else elev_scan_lds_kernel<false, WL_SCAN_LDS_THREADS, WL_SCAN_LDS_PITCH, WL_SCAN_LDS_STAGERS><<<b->n_envs, WL_SCAN_LDS_THREADS, 0, hs>>>(*p, *b, g, obs);
         return;
     }
     if (stream) elev_scan_kernel<true><<<b->n_envs, kScanThreads, 0, hs>>>(*p, *b, g, obs);
