@@ -38,21 +38,6 @@ void run(const WlVehicleParams& vp, float sim_dt, int decimation, int n, float* 
 }  // namespace
 
 extern "C" {
-// The quad form's look-ahead sampler (HeightFieldGroundAhead: lane = one wheel) fed a PATH of n contact points, one object per path
-// as one lane would hold it; next to it the plain sampler on the same points.  z / nrm: [n] / [n][3] of the look-ahead sampler,
-// z_ref / nrm_ref of HeightFieldGround; returns how many samples were served from the block requested by the sample before.
-int hs_ahead_path(const WlHeightField* hf, int n, const float* xs, const float* ys, float* z, float* nrm, float* z_ref, float* nrm_ref) {
-    const HeightFieldGround g = make_ground(hf);
-    const HeightFieldGroundAhead ahead(g);
-    for (int k = 0; k < n; ++k) {
-        V3 a, b;
-        ahead.sample_wheel<0>(xs[k], ys[k], z[k], a);
-        g.sample_wheel<0>(xs[k], ys[k], z_ref[k], b);
-        nrm[3 * k] = a.x, nrm[3 * k + 1] = a.y, nrm[3 * k + 2] = a.z;
-        nrm_ref[3 * k] = b.x, nrm_ref[3 * k + 1] = b.y, nrm_ref[3 * k + 2] = b.z;
-    }
-    return ahead.hits;
-}
 // decimation x substeps integrator sub-steps of n envs, in place; arrays are [n][k] row-major float32.
 // hf == NULL: flat ground (the drift / visual tasks); else the bilinear heightfield (elevation task).
 void hs_vehicle_integrate(const WlVehicleParams* vp, float sim_dt, int decimation, int n, float* x, float* q, float* v, float* wb,

@@ -157,44 +157,3 @@ def test_long_horizon_drift_rollout_stays_close_to_the_spec(hostlib):
     d = np.abs(a[2] - b[2]).max(-1)   # velocity difference per env
     assert np.median(d) < 1e-3 and (d > 5e-2).mean() < 0.05, (float(np.median(d)), float((d > 5e-2).mean()))
 
-
-def test_look_ahead_sampler_equals_the_plain_sampler_bit_for_bit(hostlib):
-    """HeightFieldGroundAhead (the quad form's sampler: the codes of the NEXT sub-step's cell requested one sub-step ahead, picked out
-    of a 4 x 3 block of codes) against HeightFieldGround on the same contact points, compiled for the host: identical bits whether
-    a sample is served from the pending block or gathers afresh -- along slow paths (every sample but the first from the block), with
-    jumps (fallback), across the field's border rows (no block requested there) and outside the field."""
-    from tests.depth_cases import hf_struct
-    hf = OH.make_terrain()
-    hs, _keep = hf_struct(hf)
-    lib = hostlib
-    lib.hs_ahead_path.restype = C.c_int
-    rng = np.random.RandomState(4)
-
-    def run(xs, ys):
-        n = len(xs)
-        xs, ys = np.ascontiguousarray(xs, np.float32), np.ascontiguousarray(ys, np.float32)
-        z, zr, nr, nrr = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
-        p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
-        hits = lib.hs_ahead_path(C.byref(hs), C.c_int(n), p(xs), p(ys), p(z), p(nr), p(zr), p(nrr))
-        assert np.array_equal(z.view(np.uint32), zr.view(np.uint32)) and np.array_equal(nr.view(np.uint32), nrr.view(np.uint32))
-        return hits, z
-    # slow paths in every direction: up to 1.5 cm per sample over 5 cm cells (3 m/s at 5 ms), 400 samples each
-    for heading in np.linspace(0, 2 * np.pi, 16, endpoint=False):
-        step = rng.uniform(0.002, 0.015)
-        t = np.arange(400) * step
-        x0, y0 = rng.uniform(-10, 10, 2)
-        hits, z = run(x0 + t * np.cos(heading), y0 + t * np.sin(heading))
-        assert hits == 399 and z.std() > 0                               # every sample but the first came from the block
-    # jumps of several cells between samples: the block is useless, every sample gathers -- same bits
-    hits, _ = run(rng.uniform(-19, 19, 300), rng.uniform(-19, 19, 300))
-    assert hits < 10
-    # along and across the border: the outermost cells request no block (it would leave the field), outside there is no terrain
-    t = np.arange(600) * 0.01
-    for xs, ys in ((-20.0 + 0.02 + 0 * t, -3.0 + t), (19.93 + 0 * t, -3.0 + t), (-3.0 + t, 19.92 + 0 * t), (-20.2 + 0.002 * np.arange(600), 0 * t),
-                   (17.0 + t, 17.0 + 0.9 * t)):
-        hits, z = run(xs, ys)
-        assert 0 <= hits < 600
-    # half-cell moves (5 m/s at 5 ms: the design limit of the block's reach) are still served from the block
-    t = np.arange(200) * 0.0245
-    hits, _ = run(-4.0 + t, 2.0 + 0.3 * t)
-    assert hits == 199

@@ -136,15 +136,11 @@ struct StepDraws {
 };
 
 // first half: needs nothing but the key (preloaded kernel arguments): it runs while BOTH the state rows and the parameter
-// block are still in flight
+// block are still in flight.  (Round 5 probe: with this function returning constants -- no Philox block, no Box-Muller -- the 4096-env
+// launch takes 5.95 - 5.98 us against 6.05: where they stand the draws cost <= 0.1 us, so handing them to a sibling wavefront
+// through LDS + an s_barrier has nothing to win.)
 WL_DEV StepDraws draw_step_raw(uint32_t gid, uint64_t step, uint64_t seed, int wid) {
     StepDraws d;
-#ifdef WL_PROBE_NO_DRAWS   // probe build (NOT a product form): no Philox block, no Box-Muller -- what the draws cost the launch where they stand
-    d.e0 = d.e1 = F4{0.5f, 0.5f, 0.5f, 0.5f};
-    d.z[0] = d.z[1] = d.z[2] = d.z[3] = opaque(0.f);
-    d.ref[0] = d.ref[1] = d.ref[2] = 0.f;
-    return d;
-#endif
     const uint32_t stream = wid == 1 ? (uint32_t)WL_RS_NOISE1 : wid == 2 ? (uint32_t)WL_RS_DRIFT_EVENTS : (uint32_t)WL_RS_NOISE0;
     const U4 w = philox_block(gid, step, stream, seed);
     d.e0 = u16x4(w.x, w.y);

@@ -202,16 +202,8 @@ WL_DEV ScanRay scan_request(const ScanFrame& f, const WlHeightField& hf, const S
     // a ray outside the field asks for whatever address its cell index wraps to: inside the buffer it reads a value nobody uses
     // (the ray is a miss), outside it the resource's bounds check returns 0 -- four clamps per ray saved
     const int idx2 = (c.j * hf.nx + c.i) * 2;       // 2-byte aligned dword requests: see wl_heightfield.h
-#if WL_HF_ALIGNED_PAIRS
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(sf.rsrc, idx2 & ~3, 0, 0));
-    const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(sf.rsrc, idx2 & ~3, sf.row_bytes, 0));
-    const unsigned sh = ((unsigned)idx2 & 2u) * 8u;
-    r.lo = __builtin_amdgcn_alignbit(lo.y, lo.x, sh), r.hi = __builtin_amdgcn_alignbit(hi.y, hi.x, sh);
-#else
     r.lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sf.rsrc, idx2, 0, 0);
     r.hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sf.rsrc, idx2, sf.row_bytes, 0);
-#endif
     return r;
 }
 // FOUR consecutive rays per lane, stored as ONE 16-byte word (round 4).  The scan's 676 four-byte stores per env were what bound
@@ -417,9 +409,6 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
     if constexpr (LANES == 1 && WL_WHEEL_CORNER_CACHE) {      // lane form: each wheel's cell corners stay in registers between sub-steps
         const HeightFieldGroundCached cached(ground);
         vehicle_integrate<LANES, HeightFieldGroundCached>(vp, vd, ec, s, cached, wid);
-    } else if constexpr (LANES == 4 && WL_HF_AHEAD) {          // quad form: the next sub-step's codes requested one sub-step ahead
-        const HeightFieldGroundAhead ahead(ground);
-        vehicle_integrate<LANES, HeightFieldGroundAhead>(vp, vd, ec, s, ahead, wid);
     } else {
         vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
     }

@@ -22,20 +22,11 @@ WL_DEV void hf_decode_pair(uint32_t w, float z_scale, float& a, float& b) {
     a = (float)(int)(int16_t)(w & 0xffffu) * z_scale;
     b = (float)((int)w >> 16) * z_scale;
 }
-// two adjacent codes at grid index k (row-major), decoded.  WL_HF_ALIGNED_PAIRS (probe build): the aligned 8 bytes around the pair
-// + v_alignbit instead of one 2-byte aligned dword -- what the LDS patch reads need (wl_elev.hip); global memory takes the
-// misaligned dword at full rate (round 5, same box: see DESIGN.md section 7)
-#ifndef WL_HF_ALIGNED_PAIRS
-#define WL_HF_ALIGNED_PAIRS 0
-#endif
+// two adjacent codes at grid index k (row-major), decoded: ONE 2-byte aligned dword gather.  (Round 5, same box: the aligned 8 bytes
+// around the pair + v_alignbit instead -- what the LDS patch reads need, wl_elev.hip -- is slower from global memory: the gather-form
+// scan at 262 144 envs 504 against 482 us per launch, the fused 4096-env step 25.2 against 25.0 us.)
 WL_DEV void hf_pair(const WlHeightField& f, int64_t k, float& a, float& b) {
-#if WL_HF_ALIGNED_PAIRS
-    typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-    const u32x2_a4 w = *reinterpret_cast<const u32x2_a4*>(f.height + (k & ~(int64_t)1));
-    hf_decode_pair(__builtin_amdgcn_alignbit(w.y, w.x, ((unsigned)k & 1u) * 16u), f.z_scale, a, b);
-#else
     hf_decode_pair(*reinterpret_cast<const wl_u32_u2*>(f.height + k), f.z_scale, a, b);
-#endif
 }
 // one grid point, decoded (table builders: the depth pyramid)
 WL_DEV float hf_at(const WlHeightField& f, int64_t k) {
@@ -157,83 +148,12 @@ struct HeightFieldGroundCached {
     }
 };
 
-// The same sampler for the QUAD form of the step kernels (lane = one wheel; latency form: one wavefront alone on its SIMD walks 20 - 40
-// dependent sub-steps): the terrain gathers of a sub-step are taken OFF the dependent chain.  A wheel moves <= 1.5 cm per 5 ms
-// sub-step over 5 cm cells, so the codes the NEXT sub-step will blend are among the 4 x 3 grid points around the current contact
-// point: every sample requests that block (three 8-byte gathers: rows j0 .. j0 + 2 of codes i0 .. i0 + 3, placed so that the cells a
-// half-cell move can reach are inside) and the next sample picks its two code pairs out of the rows that have landed meanwhile --
-// ~250 instructions of cover for a round trip to L2.  A sample whose cell is not inside the pending block (the first of a launch,
-// a car flung more than half a cell per sub-step, the field's border rows) gathers as HeightFieldGround does.  Same codes, same
-// arithmetic: bit-identical to HeightFieldGround.
-#ifndef WL_HF_AHEAD
-#define WL_HF_AHEAD 1
-#endif
-struct HeightFieldGroundAhead {
-    static constexpr bool kFlat = false;
-    HeightFieldGround g;
-    mutable int i0, j0;                 // origin of the pending block of codes (i0 = kNone: nothing pending)
-    mutable uint32_t lo[3], hi[3];      // rows j0 .. j0 + 2: codes (i0, i0 + 1) | (i0 + 2, i0 + 3)
-    static constexpr int kNone = -(1 << 30);
-#ifdef WL_HOST_SIM
-    mutable int hits = 0;               // samples served from the pending block (tests/host_sim)
-#endif
-    WL_DEV explicit HeightFieldGroundAhead(const HeightFieldGround& g_) : g(g_), i0(kNone), j0(kNone) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) lo[r] = hi[r] = 0u;
-    }
-    template <int W>
-    WL_DEV void sample_wheel(float x, float y, float& z, V3& n) const {
-        const WlHeightField& f = g.f;
-        const float u = (x - f.x0) * g.inv_cell, v = (y - f.y0) * g.inv_cell;
-        const bool inside = u >= 0.f && v >= 0.f && u < (float)(f.nx - 1) && v < (float)(f.ny - 1);
-        const float uc = fminf(fmaxf(u, 0.f), (float)(f.nx - 1) - 1e-3f), vc = fminf(fmaxf(v, 0.f), (float)(f.ny - 1) - 1e-3f);
-        const float fi = floorf(uc), fj = floorf(vc);
-        const int i = (int)fi, j = (int)fj;
-        const float fu = uc - fi, fv = vc - fj;
-        const unsigned di = (unsigned)(i - i0), dj = (unsigned)(j - j0);
-        uint32_t a, b;       // the code pairs (i, i + 1) of rows j and j + 1
-        if (di <= 2u && dj <= 1u) {      // the cell is inside the block requested one sub-step ago
-            const uint32_t alo = dj ? lo[1] : lo[0], ahi = dj ? hi[1] : hi[0];
-            const uint32_t blo = dj ? lo[2] : lo[1], bhi = dj ? hi[2] : hi[1];
-            const unsigned sh = (di & 1u) * 16u;
-            a = di == 2u ? ahi : __builtin_amdgcn_alignbit(ahi, alo, sh);
-            b = di == 2u ? bhi : __builtin_amdgcn_alignbit(bhi, blo, sh);
-#ifdef WL_HOST_SIM
-            ++hits;
-#endif
-        } else {
-            const int64_t k = (int64_t)j * f.nx + i;
-            a = *reinterpret_cast<const wl_u32_u2*>(f.height + k);
-            b = *reinterpret_cast<const wl_u32_u2*>(f.height + k + f.nx);
-        }
-        // the block for the next sample, around THIS contact point: columns i - 1 .. i + 2 (left half of the cell) or i .. i + 3,
-        // rows j - 1 .. j + 1 (lower half) or j .. j + 2 -- the cells within half a cell of the point.  At the border the block would
-        // leave the field: nothing is requested there (the next sample gathers)
-        const int ni = i - (fu < 0.5f ? 1 : 0), nj = j - (fv < 0.5f ? 1 : 0);
-        if (ni >= 0 && nj >= 0 && ni + 3 < f.nx && nj + 2 < f.ny) {
-            typedef uint32_t u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
-            const int16_t* p0 = f.height + (int64_t)nj * f.nx + ni;
-            const u32x2_a2 q0 = *reinterpret_cast<const u32x2_a2*>(p0);
-            const u32x2_a2 q1 = *reinterpret_cast<const u32x2_a2*>(p0 + f.nx);
-            const u32x2_a2 q2 = *reinterpret_cast<const u32x2_a2*>(p0 + 2 * f.nx);
-            lo[0] = q0.x, hi[0] = q0.y, lo[1] = q1.x, hi[1] = q1.y, lo[2] = q2.x, hi[2] = q2.y;
-            i0 = ni, j0 = nj;
-        } else {
-            i0 = kNone;
-        }
-        float h00, h10, h01, h11;
-        hf_decode_pair(a, f.z_scale, h00, h10);
-        hf_decode_pair(b, f.z_scale, h01, h11);
-        const float ea = fmaf(fu, h10 - h00, h00), eb = fmaf(fu, h11 - h01, h01);
-        const float zz = fmaf(fv, eb - ea, ea);
-        const float dzdx = fmaf(fv, (h11 - h01) - (h10 - h00), h10 - h00) * g.inv_cell;
-        const float dzdy = (eb - ea) * g.inv_cell;
-        const float inv_len = rsq(fmaf(dzdx, dzdx, fmaf(dzdy, dzdy, 1.f)));
-        z = inside ? zz : f.outside_z;
-        n = inside ? v3(-dzdx * inv_len, -dzdy * inv_len, inv_len) : v3(0.f, 0.f, 1.f);
-    }
-};
-
+// (Round 5, quad form: a sampler that requested the NEXT sub-step's codes one sub-step ahead -- a 4 x 3 block of codes around the contact
+// point, three 8-byte gathers, the two code pairs picked out of the landed rows with v_cndmask / v_alignbit -- took the gathers off the
+// dependent chain and made the launch SLOWER: fused elevation step at 4096 envs 29.6 against 25.1 us, the visual-depth task's step 411
+// against 399 us.  The lone wavefront of the latency forms pays ~3 ns per instruction whatever it waits for; the ~35 instructions of
+// block selection and address arithmetic per sub-step cost more than the round trip to L2 they hide.  profiles/r05_hf_look_ahead.diff,
+// r05_hf_look_ahead_probe.jsonl.)
 inline HeightFieldGround make_ground(const WlHeightField* hf) { return HeightFieldGround{*hf, 1.f / hf->cell}; }
 
 }  // namespace

@@ -10,7 +10,7 @@
 // drift task: WL_RS_DRIFT_EVENTS (reset pose + re-armed timers + low-frequency push), WL_RS_NOISE0 (observation normals 0..7),
 // WL_RS_NOISE1 (normals 8..11 + high-frequency push): layout in wl_drift_env.h.  The other tasks' reset draws use streams 0..2 of their own
 // enums (wl_elev.hip ES_*, wl_visual.hip).  Ids 1..3 and 6 are free since the drift draws were packed (round 4).
-enum WlRngStream : uint32_t { WL_RS_RESET = 0, WL_RS_DRIFT_EVENTS = 0, WL_RS_NOISE0 = 4, WL_RS_NOISE1 = 5, WL_RS_POLICY = 7, WL_RS_STARTUP = 8,
+enum WlRngStream : uint32_t { WL_RS_DRIFT_EVENTS = 0, WL_RS_NOISE0 = 4, WL_RS_NOISE1 = 5, WL_RS_POLICY = 7, WL_RS_STARTUP = 8,
                             WL_RS_STARTUP_BUCKET = 9, WL_RS_STARTUP_WHEELS = 10 };
 
 struct U4 {

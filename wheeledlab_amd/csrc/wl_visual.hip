@@ -138,9 +138,6 @@ WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, co
         if constexpr (LANES == 1 && !Ground::kFlat && WL_WHEEL_CORNER_CACHE) {   // lane form on a heightfield: see HeightFieldGroundCached
             const HeightFieldGroundCached cached(ground);
             vehicle_integrate<LANES, HeightFieldGroundCached>(vp, vd, ec, s, cached, wid);
-        } else if constexpr (LANES == 4 && !Ground::kFlat && WL_HF_AHEAD) {      // quad form on a heightfield: see HeightFieldGroundAhead
-            const HeightFieldGroundAhead ahead(ground);
-            vehicle_integrate<LANES, HeightFieldGroundAhead>(vp, vd, ec, s, ahead, wid);
         } else {
             vehicle_integrate<LANES, Ground>(vp, vd, ec, s, ground, wid);
         }
