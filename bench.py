@@ -75,7 +75,7 @@ def csrc_fingerprint(task: str):
 
 
 def pmc_entry(task: str, n_envs: int):
-    """the newest committed counter digest (profiles/r*_pmc.json, tools/r03_pmc_report.py) for (task, env count), or None;
+    """the newest committed counter digest (profiles/r*_pmc.json, tools/pmc_report.py) for (task, env count), or None;
     `stale` when the kernels have changed since it was measured"""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
@@ -159,7 +159,7 @@ def pmc_traffic(n_envs: int):
 
 def pmc_sq(n_envs: int):
     """SQ-counter view of the same kernel and env count from the committed rocprofv3 --pmc passes
-    (profiles/r*_pmc_sq.json, made by tools/pmc_sq_profile.sh): VALU instructions per wavefront, the fractions of a
+    (profiles/r*_pmc.json, made by tools/profile_pmc.sh): VALU instructions per wavefront, the fractions of a
     wavefront's life spent issuing VALU / parked in s_waitcnt / stalled at issue, and the share of the VALU pipe's time
     the instruction mix occupies -- the second roofline of this kernel (it is not bandwidth-shaped at 4096 envs)."""
     e = pmc_entry("drift", n_envs)
@@ -954,7 +954,7 @@ def main():
 
     # secondary: the SAME fused step at env counts where it is throughput- rather than launch-bound (SURVEY 8(d) config 2:
     # "also sweep N ... to expose the bandwidth-bound regime").  Run in a fresh process: with the GB-sized buffers carved
-    # out of this process's caching-allocator leftovers the same launches measured 12-15 % slower (tools/lanes_probe.py)
+    # out of this process's caching-allocator leftovers the same launches measured 12-15 % slower (round 2, docs/HISTORY.md)
     sweep, other_sweep = [], []
     if rank == 0 and world == 1 and not args.no_sweep:
         try:

@@ -175,3 +175,51 @@ def test_visual_random_events_carry_the_wheel_mass_term():
     import pytest
     with pytest.raises(NotImplementedError):
         flatten_visual_cfg(cfg)
+
+
+def test_device_heightfield_forms_and_quantisation():
+    """core.DeviceHeightField (the WlHeightField of ABI 21: int16 codes x z_scale): float heights are quantised with the documented
+    rule, codes + scale are taken as they are, a decoded grid re-quantises without loss, the struct carries what the kernels read"""
+    import numpy as np
+    import pytest
+    import torch
+
+    from oracle import heightfield as OH
+    from wheeledlab_amd import terrain as T
+    from wheeledlab_amd.core import DeviceHeightField
+    h, x0, y0, cell = T.synthetic_heightfield(64, 0.05, seed=3)
+    ho = OH.make_terrain(64, 0.05, seed=3)
+    assert np.array_equal(h, ho[0]) and h.dtype == np.float32                      # product and oracle generate one terrain
+    d = DeviceHeightField((h, x0, y0, cell), "cpu")
+    assert d.codes.dtype == torch.int16 and d.z_scale == 2.0 ** -13 and d.struct.nx == 64 and d.struct.ny == 64
+    assert torch.equal(d.heights, torch.from_numpy(h)) and abs(d.struct.z_scale - 2.0 ** -13) == 0     # on the lattice: lossless
+    assert d.struct.height == d.codes.data_ptr() and d.struct.outside_z == 0.0
+    # arbitrary floats: rounded to the nearest code; the error is at most half a code
+    rng = np.random.RandomState(0)
+    r = rng.uniform(-2, 3, (17, 23)).astype(np.float32)
+    dr = DeviceHeightField((r, 0.0, 0.0, 0.1), "cpu")
+    assert np.abs(dr.heights.numpy() - r).max() <= 0.5 * 2.0 ** -13 + 1e-7
+    codes, zs = T.quantize_heights(r)
+    assert zs == 2.0 ** -13 and np.array_equal(dr.codes.numpy(), codes) and np.array_equal(OH.quantize(r), codes)
+    assert np.array_equal(T.decode_heights(codes, zs), OH.decode(codes, zs)) and np.array_equal(dr.heights.numpy(), OH.decode(codes))
+    # a range beyond +-4 m: the scale doubles until the codes fit
+    tall = DeviceHeightField((r * 4.0, 0.0, 0.0, 0.1), "cpu")
+    assert tall.z_scale == 2.0 ** -11 and int(tall.codes.abs().max()) <= 32767
+    # IsaacLab's form: int16 codes with their vertical_scale, taken as they are (and required)
+    isaac = DeviceHeightField((codes, 0.0, 0.0, 0.1, 0.005), "cpu")
+    assert isaac.z_scale == 0.005 and torch.equal(isaac.codes, torch.from_numpy(codes))
+    assert torch.equal(isaac.heights, torch.from_numpy(codes.astype(np.float32) * np.float32(0.005)))
+    with pytest.raises(ValueError):
+        DeviceHeightField((codes, 0.0, 0.0, 0.1), "cpu")
+    # float heights with an explicit scale; the decoded grid goes through again unchanged; sharing another field's codes
+    coarse = DeviceHeightField((r, 0.0, 0.0, 0.1, 0.005), "cpu")
+    again = DeviceHeightField((coarse.heights, 0.0, 0.0, 0.1, 0.005), "cpu")
+    assert torch.equal(again.codes, coarse.codes)
+    shared = DeviceHeightField(coarse, "cpu", outside_z=-1.0)
+    assert shared.codes is coarse.codes and shared.struct.outside_z == -1.0 and coarse.struct.outside_z == 0.0
+    bad = r.copy()
+    bad[3, 4] = np.nan
+    with pytest.raises(ValueError):
+        DeviceHeightField((bad, 0.0, 0.0, 0.1), "cpu")
+    with pytest.raises(ValueError):
+        T.quantize_heights(bad)

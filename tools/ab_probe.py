@@ -1,5 +1,5 @@
 """Round-5 same-box A/B: us per launch / step of the named workloads for the in-tree library and every build in
-gpurun_variants/lib_*.so (tools/build_variants.sh).   usage: r05_probe.py workload[,workload...] [repeat]
+gpurun_variants/lib_*.so (tools/build_variants.sh).   usage: ab_probe.py workload[,workload...] [repeat]
 workloads: drift4096 drift65536 drift1m elev4096 elevobs262144 elevobsg262144 (gather form) elevstep262144 elevstep1m visual4096 depth4096 vdtask4096"""
 import glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,13 +1,13 @@
-"""Digest of tools/r03_profile.sh -> <out>/<tag>_pmc.json: per (task, env count) and kernel the HBM bytes per launch (FETCH_SIZE /
+"""Digest of tools/profile_pmc.sh -> <out>/<tag>_pmc.json: per (task, env count) and kernel the HBM bytes per launch (FETCH_SIZE /
 WRITE_SIZE passes, factors calibrated on known bytes in the same pass where tools/microbench/layout_bw is present, else the
 guide's: FETCH x2, WRITE x1), the kernel's duration under the counters, and the SQ view (VALU instructions per wavefront, wait /
 issue-stall / active shares, VALU-pipe occupancy).  Stamped with the fingerprint of csrc/ + the header so that bench.py can
-tell whether the counters belong to the library it loaded.    usage: r03_pmc_report.py <gpurun_out/r03> [tag]"""
+tell whether the counters belong to the library it loaded.    usage: pmc_report.py <gpurun_out/tag> <tag>"""
 import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 O = sys.argv[1]
-TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"
+TAG = sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import ALGO_BYTES, csrc_fingerprint  # noqa: E402
@@ -122,5 +122,12 @@ for tag in tags:
 json.dump(out, open(os.path.join(O, f"{TAG}_pmc.json"), "w"), indent=1)
 fs = glob.glob(f"{O}/bench_stats/**/*kernel_stats.csv", recursive=True)
 if fs:
+    # rocprofv3 writes one summary per process (bench.py's sweep runs in a child): the bench process itself is the one with the
+    # headline kernel's thousands of launches; the sweep child's summary is kept beside it
+    def headline_calls(path):
+        return sum(int(r["Calls"]) for r in csv.DictReader(open(path)) if "drift_step_kernel" in r.get("Name", ""))
+    fs.sort(key=headline_calls, reverse=True)
     shutil.copy(fs[0], os.path.join(O, f"{TAG}_bench_kernel_stats.csv"))
+    if len(fs) > 1:
+        shutil.copy(fs[1], os.path.join(O, f"{TAG}_bench_sweep_kernel_stats.csv"))
 print(json.dumps(out, indent=1))

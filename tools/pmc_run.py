@@ -56,7 +56,7 @@ elif task == "depth":
     env.reset()
     a = torch.rand(8, n, 2, device=dev) * 2 - 1
     env.rollout(a)
-    cam = DepthCamera((env.height, float(env._hf.x0), float(env._hf.y0), float(env._hf.cell)), dev)
+    cam = DepthCamera(env.hf, dev)
     out = torch.empty(n, 60, 80, device=dev)
     for _ in range(K):
         cam.render(env, 100.0, out)
