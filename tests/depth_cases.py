@@ -81,6 +81,7 @@ def rough_fields(seed=3):
     rng = np.random.RandomState(seed)
     out = []
     for name, h, cell in (("white noise", on_lattice((rng.uniform(0, 2, (256, 256)),))[0], 0.1),
+                          ("steep noise", on_lattice((np.random.RandomState(5).uniform(0.0, 1.5, (97, 131)),))[0], 0.05),   # check_pyramid's field: up to 30 m / m
                           ("spikes", np.where(rng.rand(300, 200) < 0.02, 3.0, 0.0).astype(np.float32), 0.07),
                           ("steps", (np.floor(np.arange(512)[None, :] / 32) * 0.25 + np.zeros((512, 1))).astype(np.float32), 0.05)):
         ny, nx = h.shape

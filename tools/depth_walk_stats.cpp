@@ -31,6 +31,35 @@ static std::vector<float> host_pyramid(const WlHeightField* hf) {
 }
 
 extern "C" {
+// the raw traces, for scheduling experiments: trace_out[((e * 75 + tile) * 64 + lane) * max_len + k] = 0 past the ray's end, 1 a coarse
+// step, 2 a fine step; returns the longest ray
+int dws_traces(const WlVisualParams* p, const WlHeightField* hf, int n, const float* pos, const float* quat, float max_depth, uint8_t* trace_out,
+               int max_len) {
+    const Pyramid py = make_pyramid(hf->nx, hf->ny);
+    const std::vector<float> buf = host_pyramid(hf);
+    const DepthGrid g = make_depth_grid(hf);
+    const FieldMem mem{buf.data()};
+    const PyrHead hd = pyramid_head(g, py, mem);
+    std::vector<uint8_t> tr;
+    size_t longest = 0;
+    for (int e = 0; e < n; ++e) {
+        const Quat q{quat[4 * e], quat[4 * e + 1], quat[4 * e + 2], quat[4 * e + 3]};
+        const Mat3 R = mat_from_quat(q);
+        const V3 o = v3(pos[3 * e], pos[3 * e + 1], pos[3 * e + 2]) + mul(R, v3(p->cam_pos[0], p->cam_pos[1], p->cam_pos[2]));
+        for (int tile = 0; tile < 75; ++tile) {
+            const int strip = tile / 5, tc = tile % 5;
+            for (int lane = 0; lane < 64; ++lane) {
+                tr.clear();
+                g_trace = &tr;
+                (void)cast_ray(g, py, hd, mem, o, mul(R, depth_pixel_ray_body(*p, strip * 4 + (lane >> 4), tc * 16 + (lane & 15))), max_depth);
+                longest = std::max(longest, tr.size());
+                uint8_t* dst = trace_out + (((size_t)e * 75 + tile) * 64 + lane) * max_len;
+                for (size_t k = 0; k < tr.size() && k < (size_t)max_len; ++k) dst[k] = tr[k] ? 2 : 1;
+            }
+        }
+    }
+    return (int)longest;
+}
 // out[0..5]: rays, ray-steps, tiles, wave-steps (sum of per-tile maxima), wave-steps with >= 1 lane in a fine cell, fine ray-steps
 int dws_stats(const WlVisualParams* p, const WlHeightField* hf, int n, const float* pos, const float* quat, float max_depth, double* out) {
     const Pyramid py = make_pyramid(hf->nx, hf->ny);
