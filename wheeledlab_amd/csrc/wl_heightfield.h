@@ -152,8 +152,8 @@ struct HeightFieldGroundCached {
 // point, three 8-byte gathers, the two code pairs picked out of the landed rows with v_cndmask / v_alignbit -- took the gathers off the
 // dependent chain and made the launch SLOWER: fused elevation step at 4096 envs 29.6 against 25.1 us, the visual-depth task's step 411
 // against 399 us.  The lone wavefront of the latency forms pays ~3 ns per instruction whatever it waits for; the ~35 instructions of
-// block selection and address arithmetic per sub-step cost more than the round trip to L2 they hide.  profiles/r05_hf_look_ahead.diff,
-// r05_hf_look_ahead_probe.jsonl.)
+// block selection and address arithmetic per sub-step cost more than the round trip to L2 they hide.  profiles/r05_probes/hf_look_ahead.diff,
+// hf_look_ahead_scan_stagers.jsonl.)
 inline HeightFieldGround make_ground(const WlHeightField* hf) { return HeightFieldGround{*hf, 1.f / hf->cell}; }
 
 }  // namespace
