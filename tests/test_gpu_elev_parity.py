@@ -58,10 +58,18 @@ def test_elev_mdp_kernel_matches_reference_golden(golden):
     np.testing.assert_allclose(hmap.cpu().numpy()[:, :n].T, g["world_height_map"], rtol=1e-6, atol=4e-6)
 
 
-def _fresh(n, seed=3):
+def _fresh(n, seed=3, z_scale=None):
+    """z_scale: the bench terrain re-quantised to another vertical scale (not a power of two: the decode is a ROUNDED product, the
+    same on the device and in the oracle's decoded grid), passed as IsaacLab passes its terrains: codes + scale"""
     from wheeledlab_amd.core import ElevBatch
     hf = OH.make_terrain()
-    env = ElevBatch(n, device=DEV, seed=seed, heightfield=hf)
+    if z_scale is not None:
+        codes = OH.quantize(hf[0], z_scale)
+        hf = (OH.decode(codes, z_scale),) + hf[1:]
+        env = ElevBatch(n, device=DEV, seed=seed, heightfield=(codes,) + hf[1:] + (z_scale,))
+        assert env.hf.z_scale == z_scale and torch.equal(env.height.cpu(), torch.from_numpy(hf[0]))
+    else:
+        env = ElevBatch(n, device=DEV, seed=seed, heightfield=hf)
     env.reset()
     torch.cuda.synchronize()
     return env, hf
@@ -87,10 +95,10 @@ def test_elev_reset_and_observation_match_oracle():
     assert obs.shape == (200, 689)
 
 
-@pytest.mark.parametrize("lanes", [4, 1])
-def test_elev_fused_step_matches_oracle_single_steps(lanes):
+@pytest.mark.parametrize("lanes,z_scale", [(4, None), (1, None), (4, 1e-4), (1, 1e-4)])
+def test_elev_fused_step_matches_oracle_single_steps(lanes, z_scale):
     n = 512
-    env, hf = _fresh(n, seed=5)
+    env, hf = _fresh(n, seed=5, z_scale=z_scale)
     env.set_lanes(lanes)
     p = OS.elev_params()
     rng = np.random.RandomState(0)

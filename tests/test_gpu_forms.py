@@ -170,6 +170,33 @@ def test_height_scan_forms_are_bit_identical(A, z_scale):
         assert not bad.any(), (flags, int(bad.sum()), bad.nonzero()[:5].tolist(), float((got - ref).abs().max()))
 
 
+def test_a_field_the_lds_patch_cannot_take_falls_back_to_the_gather_scan(A):
+    """the LDS form stages 16-byte words from 4-byte aligned addresses: a field with an ODD row pitch (or narrower than a patch row)
+    is scanned by the gather form whatever the flags ask for -- same observation rows, and right against the oracle"""
+    from oracle import elev_step as OE
+    from oracle import heightfield as OH
+    full = OH.make_terrain()
+    for ny, nx in ((613, 349), (200, 90)):
+        hf = (np.ascontiguousarray(full[0][:ny, :nx]), full[1], full[2], full[3])
+        n = 777
+        env = _elev(n, 23, flags=A.FLAG_SCAN_GATHER | A.FLAG_NO_STREAM, hf=hf)
+        g = torch.Generator(device=DEV).manual_seed(3)
+        st = env.state
+        st[0, :n] = float(hf[1]) + torch.rand(n, device=DEV, generator=g) * (nx - 1) * 0.05
+        st[1, :n] = float(hf[2]) + torch.rand(n, device=DEV, generator=g) * (ny - 1) * 0.05
+        q = torch.randn(4, n, device=DEV, generator=g)
+        q[1:3] *= 0.1
+        st[3:7, :n] = q / q.norm(dim=0, keepdim=True)
+        ref = env.observe().clone()
+        for flags in (A.FLAG_SCAN_LDS, A.FLAG_SCAN_LDS | A.FLAG_STREAM):
+            env.set_flags(flags)
+            env.obs.fill_(-77.0)
+            assert torch.equal(env.observe(), ref), (nx, flags)
+        want = OE.height_map(OE.elev_params(), env.state[:, :n].cpu().numpy(), hf)
+        d = np.abs(ref[:, 13:].cpu().numpy() - want)
+        assert (d > 2e-5).mean() < 2e-4 and (np.abs(want) < 5).any() and (want == 10.0).any(), (nx, float(d.max()))
+
+
 def test_elevation_lane_form_steps_are_bit_identical_across_scan_forms(A):
     """the two-launch lane form (what runs beyond 32 768 envs) with the scan through LDS / with streaming rows == the same form
     with gathers, through resets and command resamples"""
