@@ -153,7 +153,7 @@ inline void pyramid_header_serial(const WlHeightField& f, float* hd) {
 }
 #endif
 
-// the walk's view of that buffer: 4- and 8-byte gathers at float offsets
+// the walk's view of that buffer: 4-byte gathers (an entry, or two height codes) at word / halfword offsets
 struct FieldMem {
 #ifdef WL_HOST_SIM
     const float* base;

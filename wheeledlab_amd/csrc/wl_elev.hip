@@ -10,8 +10,10 @@
 //   lane form: TWO --
 //   1. elev_step_kernel  (lane = env): the same step; state is read once / written once, sub-steps stay in VGPRs; also
 //      writes the 13 proprioceptive values of the observation row.
-//   2. elev_scan_kernel  (block = env): the 26 x 26 yaw-aligned height rays (4 L2-resident gathers each), written with
-//      contiguous dword stores -- this launch carries ~90 % of the task's HBM bytes (2.7 KB / env).  (Staging the env's
+//   2. elev_scan_kernel / elev_scan_lds_kernel (block = env): the 26 x 26 yaw-aligned height rays, four per lane, written as
+//      16-byte words -- this launch carries ~90 % of the task's HBM bytes (2.7 KB / env).  Gather form (two 4-byte gathers of
+//      two height codes per ray) below 16 384 envs, LDS-patch form (the footprint's codes staged by LDS-DMA) beyond; the terrain
+//      is 16-bit codes x z_scale since round 5 (wl_heightfield.h).  (Round 2 history: staging the env's
 //      terrain patch in LDS -- its bounding box fetched row by row with coalesced 8-byte requests, corners read from
 //      the tile -- was measured slower in every form tried: block per env 15.8 us, persistent blocks with the next
 //      env's pose prefetched 18 us, against 11.3 us for the gathers; round 2, DESIGN.md section 6.  Round 3: the same for the
@@ -236,7 +238,7 @@ WL_DEV float scan_value(const WlElevParams& p, const ScanRay& r, float z_scale, 
     const float val = r.inside ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
     return clampf(val, -p.obs_clip, p.obs_clip);
 }
-// the gathers of the four rays of quad q (8 x 8 B in flight per lane) ...
+// the gathers of the four rays of quad q (8 x 4 B in flight per lane) ...
 WL_DEV void scan_quad_request(const ScanFrame& f, const WlHeightField& hf, const ScanField& sf, int q, ScanRay (&r)[4]) {
     float fx0, fy0, fx2, fy2;
     scan_ray_xy(4 * q, fx0, fy0);
