@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WL_ABI_VERSION 21
+#define WL_ABI_VERSION 22
 
 enum WlStatus { WL_OK = 0, WL_EINVAL = -1, WL_ELAUNCH = -2, WL_EALIGN = -3, WL_ENODEV = -4 };
 
@@ -101,7 +101,14 @@ typedef struct WlVehicleParams {
     int32_t drive;            /* 0 = rear wheel drive (front passive, hound.py:44-51), 1 = 4WD               */
     /* implicit PD on the steer joints (hound.py:5-12)                                                        */
     float steer_kp, steer_kd, steer_effort, steer_vel_limit, steer_inertia;
-    int32_t substeps;         /* integrator sub-steps per sim.dt (1 for dt<=0.01)                             */
+    int32_t substeps;         /* integrator sub-steps per sim.dt: h = sim.dt / substeps                       */
+    /* ABI 22: which integrator steps the force laws above (wl_vehicle.h, spec oracle/vehicle.py).
+     * 0 = explicit (h <= 5 ms, tyre stiffness capped): what the drift / F1Tenth entry points take (sim.dt = 5 ms,
+     *     mushr_drift_env_cfg.py:393-394) -- they refuse 1;
+     * 1 = linearly implicit (Rosenbrock-W; stable and steady-state-exact up to h = 20 ms): what the elevation / visual /
+     *     visual-depth entry points take -- ONE sub-step per sim.dt, the reference's own physics rate
+     *     (mushr_elevation_env_cfg.py:461-462, mushr_visual_env_cfg.py:435-436) -- they refuse 0.                      */
+    int32_t implicit;
 } WlVehicleParams;
 
 /* ---- action term (AckermannAction.process_actions, ackermann_actions.py:119-133) ---------------------- */

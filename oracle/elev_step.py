@@ -24,7 +24,7 @@ def elev_params():
     import math
     return NS(
         sim_dt=0.01, decimation=10, max_episode_length=math.ceil(20.0 / (0.01 * 10)),          # :461-465
-        action=mushr_action(1), vehicle=mushr_vehicle(drive=1, motor_limit=0.25, substeps=2, ground_mu=(1.0, 1.0)),
+        action=mushr_action(1), vehicle=mushr_vehicle(drive=1, motor_limit=0.25, substeps=1, ground_mu=(1.0, 1.0), implicit=1),
         weight=[200.0, 5000.0, 0.0, -200.0, 0.0, 0.0, 0.0, 0.0],                                # :286-305
         min_height=0.15, stuck_min_vel=0.02, stuck_wheel_spin=5.0, stuck_vel_cap=1.2,           # :356-366, :155-157
         upright_cos=math.cos(math.radians(60.0)), goal_dist=0.5,                                # :368-376

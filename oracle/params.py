@@ -5,7 +5,7 @@ import math
 from types import SimpleNamespace as NS
 
 
-def mushr_vehicle(drive=0, motor_limit=0.5, substeps=1, ground_mu=(1.1, 1.0)):
+def mushr_vehicle(drive=0, motor_limit=0.5, substeps=1, ground_mu=(1.1, 1.0), implicit=0):
     k = 3000.0
     m_nom = 3.4                       # 3.0 kg chassis + mean of the U(0.3,0.5) added mass (mushr_drift_env_cfg.py:145-154)
     g = 9.81
@@ -18,7 +18,7 @@ def mushr_vehicle(drive=0, motor_limit=0.5, substeps=1, ground_mu=(1.1, 1.0)):
         motor_sat=1.05, motor_limit=motor_limit, motor_vel_limit=450.0,   # hound.py:13-21,40-43
         drive=drive,
         steer_kp=100.0, steer_kd=10.0, steer_effort=3.2, steer_vel_limit=10.0, steer_inertia=2e-4,  # hound.py:5-12
-        substeps=substeps,
+        substeps=substeps, implicit=implicit,   # integrator: oracle/vehicle.py
     )
 
 

@@ -9,6 +9,19 @@ geometry (wheeledlab_tasks/common/actions.py:17-20), friction + "multiply" combi
 
 State per env: x (CoM, world), q (wxyz), v (CoM lin vel, world), w_b (ang vel, body), wheel spin [4] in order
 bl, br, fl, fr, steer angle + rate.
+
+Two integrators of the SAME force laws (vp.implicit):
+  0  explicit: semi-implicit Euler of the body under the wheel forces evaluated at the current state (wheel spin and steering
+     joint implicit).  Stable for K h / m <~ 1: h <= 5 ms and a cap on the tyre's secant stiffness.  The drift tasks
+     (sim.dt = 5 ms, mushr_drift_env_cfg.py:393) step with it.
+  1  linearly implicit (round 6): the body's velocity increment solves  (M + h G^) du = h r(u_n)  with r the body-frame
+     residual (forces + gravity - frame rotation, torques - gyroscopic term) and G^ a structured approximation of the contact
+     forces' damping matrix -d r / d u: the exact 3 x 3 block of the in-plane motion (v_x, v_y, w_z) for the nominal wheel
+     positions, and the diagonal for heave / roll / pitch.  A Rosenbrock-W step: first-order consistent for ANY G^, every
+     steady state of the force laws (rest, steady cornering, constant creep on a slope) is a fixed point whatever h is, and
+     stable without a stiffness cap at the reference's own physics rate -- h = sim.dt = 10 ms (elevation,
+     mushr_elevation_env_cfg.py:461) and 20 ms (visual, mushr_visual_env_cfg.py:435), where PhysX runs its implicit TGS solver
+     (wheeledlab_assets/mushr.py:22-36).
 """
 import numpy as np
 
@@ -40,6 +53,55 @@ def flat_ground(xy):
     return np.zeros(n, F), np.tile(f32([0, 0, 1]), (n, 1))
 
 
+def solve_spd3(a11, a12, a13, a22, a23, a33, b1, b2, b3):
+    """LDL^T solve of a symmetric positive definite 3 x 3 system, elementwise over envs (no pivoting: the matrices here are
+    identity + positive semi-definite)"""
+    i1 = F(1) / a11
+    l21, l31 = a12 * i1, a13 * i1
+    d2 = a22 - l21 * a12
+    t32 = a23 - l31 * a12
+    i2 = F(1) / d2
+    l32 = t32 * i2
+    d3 = a33 - l31 * a13 - l32 * t32
+    y2 = b2 - l21 * b1
+    y3 = b3 - l31 * b1 - l32 * y2
+    x3 = y3 / d3
+    x2 = y2 * i2 - l32 * x3
+    x1 = b1 * i1 - l21 * x2 - l31 * x3
+    return x1.astype(F), x2.astype(F), x3.astype(F)
+
+
+def implicit_body_update(v, wb, R, Fw, Tb, Ib, mass, S, vp, h):
+    """(M + h G^) du = h r: the linearly implicit velocity update of the module docstring.  Fw: total force incl. gravity
+    (world), Tb: total contact torque about the CoM (body), S: the sums of the wheels' Jacobian pieces.
+    Unknowns in the body frame; the in-plane block is solved in (dv_x, dv_y, gyr_z dw_z), which makes it symmetric with the
+    mass divided out:  [1 + q Sxx, q Sxy, q Sxw / gz; ., 1 + q Syy, q Syw / gz; ., ., 1 + q Sww / gz^2],  q = h / m."""
+    q = (h / mass).astype(F)
+    gx, gy, gz = F(vp.gyr_x), F(vp.gyr_y), F(vp.gyr_z)
+    vb = np.einsum("nji,nj->ni", R, v).astype(F)
+    rot = np.cross(wb, vb).astype(F)                       # d/dt of a world-constant vector seen from the body frame is -w x v
+    ab = (np.einsum("nji,nj->ni", R, Fw) / mass[:, None] - rot).astype(F)
+    alpha = ((Tb - np.cross(wb, Ib * wb)) / Ib).astype(F)
+    igz = F(1) / gz
+    dvx, dvy, dwz_g = solve_spd3(F(1) + q * S["xx"], q * S["xy"], q * S["xw"] * igz, F(1) + q * S["yy"], q * S["yw"] * igz,
+                                 F(1) + q * S["ww"] * igz * igz, h * ab[:, 0], h * ab[:, 1], h * alpha[:, 2] * gz)
+    # heave / roll / pitch: diagonal.  Normal direction: the spring-damper's damping with the position update folded in,
+    # c + h k, for every wheel in contact at its nominal lever (half track / half wheelbase); the tyres act on roll and pitch
+    # through the height of the CoM above the contact patches.
+    Dn = F(vp.susp_c) + h * F(vp.susp_k)
+    az = (F(vp.wheel_z) - F(vp.cg_z)) - F(vp.wheel_radius)
+    by2 = F(vp.half_track) * F(vp.half_track)
+    bx2 = F(0.5) * (F(vp.half_wheelbase_f) * F(vp.half_wheelbase_f) + F(vp.half_wheelbase_r) * F(vp.half_wheelbase_r))
+    nD = S["nc"] * Dn
+    dvz = h * ab[:, 2] / (F(1) + q * nD)
+    dwx = h * alpha[:, 0] / (F(1) + q * (az * az * S["yy"] + by2 * nD) / (gx * gx))
+    dwy = h * alpha[:, 1] / (F(1) + q * (az * az * S["xx"] + bx2 * nD) / (gy * gy))
+    dvb = np.stack([dvx, dvy, dvz], -1).astype(F) + h * rot
+    v = (v + np.einsum("nij,nj->ni", R, dvb)).astype(F)
+    wb = (wb + np.stack([dwx, dwy, dwz_g * igz], -1)).astype(F)
+    return v, wb
+
+
 def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w, mu_d_w, damp, vp, h, ground=flat_ground):
     """one integrator sub-step of length h.  Arrays are [N,...] float32.  Returns the new state tuple."""
     h = F(h)
@@ -55,6 +117,8 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
     new_wheel = np.empty_like(wheel)
     Iw, bw = F(vp.wheel_inertia), F(vp.wheel_damping)
     zrel = F(vp.wheel_z) - F(vp.cg_z)
+    implicit = bool(getattr(vp, "implicit", 0))
+    S = {k: np.zeros(x.shape[0], F) for k in ("xx", "yy", "xy", "xw", "yw", "ww", "nc")}
     for i, name in enumerate(WHEELS):
         front = name[0] == "f"
         px = F(vp.half_wheelbase_f) if front else -F(vp.half_wheelbase_r)
@@ -88,18 +152,19 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
         K = Fz * gq / vden
         # explicit-stepping stability cap: the tyre may not take out more than half of this wheel's share of the
         # body's momentum per sub-step (binds only for high-friction tasks at low speed; never in the drift task)
-        K = np.minimum(K, F(0.125) * mass / h).astype(F)
+        if not implicit:
+            K = np.minimum(K, F(0.125) * mass / h).astype(F)
         driven = (vp.drive == 1) or (not front)
         d = damp if driven else np.zeros_like(damp)
         wt = wheel_target[:, i]
         lo, hi = dc_motor_limits(w_i, vp)
         A = Iw / h + bw + K * r * r
         rhs0 = Iw * w_i / h + r * K * vcx
+        # tau = clip(d (wt - w'), lo, hi) is non-increasing in w': the solution is the unclipped root w_u clamped to the roots of the
+        # two constant-torque equations -- a median, never the difference d (wt - w_u) itself, whose rounding the wheel equation
+        # amplifies by d / A (3e3 in the drift task, 1e5 with the elevation task's servo damping of 1000)
         w_u = (rhs0 + d * wt) / (A + d)
-        # unclipped motor: take w_u itself (tau = d (wt - w_u) cancels catastrophically near the target)
-        tau_u = d * (wt - w_u)
-        tau = np.clip(tau_u, lo, hi)
-        w_n = np.where(tau == tau_u, w_u, (rhs0 + tau) / A)
+        w_n = np.clip(w_u, (rhs0 + lo) / A, (rhs0 + hi) / A)
         Fx = K * (w_n * r - vcx)
         Fy = -K * vcy
         Fmax = mu_s * Fz
@@ -111,18 +176,43 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
         A2 = Iw / h + bw
         rhs2 = Iw * w_i / h - r * Fx
         w_u2 = (rhs2 + d * wt) / (A2 + d)
-        tau_u2 = d * (wt - w_u2)
-        tau2 = np.clip(tau_u2, lo, hi)
-        w_n = np.where(over, np.where(tau2 == tau_u2, w_u2, (rhs2 + tau2) / A2), w_n)
+        w_n = np.where(over, np.clip(w_u2, (rhs2 + lo) / A2, (rhs2 + hi) / A2), w_n)
         new_wheel[:, i] = w_n
+        if implicit:
+            # damping of this wheel's force against the contact-point velocity (secant): K_s = K * scale (on the friction
+            # circle the force no longer grows with the slip) laterally; longitudinally K_s with the wheel spin eliminated,
+            # K_s (A0 + d') / (A0 + d' + K r^2): d' = the motor's damping while its torque is inside the DC-motor window (the
+            # spin solve's unclipped root), 0 while it is clipped -- a free-spinning wheel follows the ground, a velocity-servoed
+            # one resists.  Rotated into the body axes by the wheel's heading (hc, hs) and moved to the CoM by the wheel's
+            # NOMINAL position (px, py): the in-plane Jacobian of a car standing on its wheels.
+            unclipped = (w_u >= (rhs0 + lo) / A) & (w_u <= (rhs0 + hi) / A)    # the median above returned w_u itself
+            dm = np.where(unclipped, d, F(0)).astype(F)
+            ky = (K * scale).astype(F)
+            kx = (ky * (A2 + dm) / (A + dm)).astype(F)
+            hc, hs = hb[:, 0], hb[:, 1]
+            kxb = kx * hc * hc + ky * hs * hs
+            kyb = kx * hs * hs + ky * hc * hc
+            kxy = (kx - ky) * hc * hs
+            gxw = -py * kxb + px * kxy
+            gyw = px * kyb - py * kxy
+            S["xx"] += kxb
+            S["yy"] += kyb
+            S["xy"] += kxy
+            S["xw"] += gxw
+            S["yw"] += gyw
+            S["ww"] += -py * gxw + px * gyw
+            S["nc"] += (Fz > 0).astype(F)
         Fi = Fz[:, None] * nrm + Fx[:, None] * tx + Fy[:, None] * ty
         Ftot += Fi
         Ttot += np.cross(arm, Fi)
     Ftot[:, 2] -= mass * F(vp.gravity)
-    v = (v + h * Ftot / mass[:, None]).astype(F)
     Ib = mass[:, None] * f32([vp.gyr_x ** 2, vp.gyr_y ** 2, vp.gyr_z ** 2])[None, :]
     Tb = np.einsum("nji,nj->ni", R, Ttot).astype(F)
-    wb = (wb + h * (Tb - np.cross(wb, Ib * wb)) / Ib).astype(F)
+    if implicit:
+        v, wb = implicit_body_update(v, wb, R, Ftot, Tb, Ib, mass, S, vp, h)
+    else:
+        v = (v + h * Ftot / mass[:, None]).astype(F)
+        wb = (wb + h * (Tb - np.cross(wb, Ib * wb)) / Ib).astype(F)
     ww = np.einsum("nij,nj->ni", R, wb).astype(F)
     x = (x + h * v).astype(F)
     qw, qx, qy, qz = q[:, 0], q[:, 1], q[:, 2], q[:, 3]

@@ -27,7 +27,7 @@ def visual_params():
     """MushrVisualRLEnvCfg (:412-444)"""
     return NS(
         sim_dt=0.02, decimation=10, max_episode_length=math.ceil(10.0 / (0.02 * 10)),           # :435-439
-        action=mushr_action(1), vehicle=mushr_vehicle(drive=1, motor_limit=0.25, substeps=4, ground_mu=(2.0, 2.0)),   # h = 0.005
+        action=mushr_action(1), vehicle=mushr_vehicle(drive=1, motor_limit=0.25, substeps=1, ground_mu=(2.0, 2.0), implicit=1),   # h = sim.dt
         weight=[5.0, 7.0, 0, 0, 0, 0, 0, 0],                                                    # :375-385
         map_rows=500, map_cols=500, row_spacing=0.5, col_spacing=0.5,                          # :70-76
         reset_z=0.1,                                                                            # :203

@@ -7,7 +7,7 @@
 #include "wl_heightfield.h"
 
 namespace {
-template <class Ground, bool UNROLL>
+template <class Ground, bool UNROLL, bool IMPL>
 void run(const WlVehicleParams& vp, float sim_dt, int decimation, int n, float* x, float* q, float* v, float* wb, float* wheel,
          float* steer, const float* steer_target, const float* wheel_target, const float* mass, const float* mu_s,
          const float* mu_d, const float* damp, const Ground& ground) {
@@ -25,7 +25,7 @@ void run(const WlVehicleParams& vp, float sim_dt, int decimation, int n, float* 
         for (int i = 0; i < 4; ++i) s.wheel[i] = wheel[4 * e + i];
         s.th = steer[2 * e];
         s.om = steer[2 * e + 1];
-        vehicle_integrate<1, Ground, UNROLL>(vp, vd, ec, s, ground, 0);
+        vehicle_integrate<1, Ground, UNROLL, -1, IMPL>(vp, vd, ec, s, ground, 0);
         x[3 * e] = s.x.x, x[3 * e + 1] = s.x.y, x[3 * e + 2] = s.x.z;
         q[4 * e] = s.q.w, q[4 * e + 1] = s.q.x, q[4 * e + 2] = s.q.y, q[4 * e + 3] = s.q.z;
         v[3 * e] = s.v.x, v[3 * e + 1] = s.v.y, v[3 * e + 2] = s.v.z;
@@ -43,13 +43,16 @@ extern "C" {
 void hs_vehicle_integrate(const WlVehicleParams* vp, float sim_dt, int decimation, int n, float* x, float* q, float* v, float* wb,
                           float* wheel, float* steer, const float* steer_target, const float* wheel_target, const float* mass,
                           const float* mu_s, const float* mu_d, const float* damp, const WlHeightField* hf, int unroll) {
+#define RUN(G, U, I, g) run<G, U, I>(*vp, sim_dt, decimation, n, x, q, v, wb, wheel, steer, steer_target, wheel_target, mass, mu_s, mu_d, damp, g)
+    // vp->implicit picks the integrator (wl_vehicle.h): 0 explicit, 1 linearly implicit
     if (hf) {
         const HeightFieldGround g = make_ground(hf);
-        if (unroll) run<HeightFieldGround, true>(*vp, sim_dt, decimation, n, x, q, v, wb, wheel, steer, steer_target, wheel_target, mass, mu_s, mu_d, damp, g);
-        else run<HeightFieldGround, false>(*vp, sim_dt, decimation, n, x, q, v, wb, wheel, steer, steer_target, wheel_target, mass, mu_s, mu_d, damp, g);
+        if (vp->implicit) unroll ? RUN(HeightFieldGround, true, true, g) : RUN(HeightFieldGround, false, true, g);
+        else unroll ? RUN(HeightFieldGround, true, false, g) : RUN(HeightFieldGround, false, false, g);
     } else {
-        if (unroll) run<FlatGround, true>(*vp, sim_dt, decimation, n, x, q, v, wb, wheel, steer, steer_target, wheel_target, mass, mu_s, mu_d, damp, FlatGround{});
-        else run<FlatGround, false>(*vp, sim_dt, decimation, n, x, q, v, wb, wheel, steer, steer_target, wheel_target, mass, mu_s, mu_d, damp, FlatGround{});
+        if (vp->implicit) unroll ? RUN(FlatGround, true, true, FlatGround{}) : RUN(FlatGround, false, true, FlatGround{});
+        else unroll ? RUN(FlatGround, true, false, FlatGround{}) : RUN(FlatGround, false, false, FlatGround{});
     }
+#undef RUN
 }
 }

@@ -119,8 +119,29 @@ def test_body_frame_substeps_equal_the_world_frame_spec_on_flat_ground(hostlib, 
     _compare(got, want, 5e-5)
 
 
+@pytest.mark.parametrize("unroll", [1, 0])
+@pytest.mark.parametrize("h_ms", [10, 20])
+def test_implicit_substeps_equal_the_spec_on_flat_ground(hostlib, h_ms, unroll):
+    """the linearly implicit integrator (vp.implicit = 1): the visual task's 10 x 20 ms and the elevation task's 10 x 10 ms on the
+    plane, 4WD at mu up to 2 -- the device's body-frame LDL^T against the oracle's, 4096 states"""
+    vp = OP.mushr_vehicle(drive=1, motor_limit=0.25, ground_mu=(2.0, 2.0), implicit=1)
+    st = list(_states(4096, seed=21 + h_ms, z0=0.06 - 0.0028))
+    st[9], st[10], st[11] = f32(np.full(4096, 1.0)), f32(np.full(4096, 1.0)), f32(np.full(4096, 1000.0))   # wheel mu 1 x ground 2; servo damping
+    st[9][::3] = F(0.4)
+    want = _oracle(vp, h_ms * 1e-3, 10, st, OV.flat_ground)
+    got = _host(hostlib, vp, h_ms * 1e-3, 10, st, None, unroll)
+    # every seventh state starts airborne and touches down inside the step: a wheel that makes contact a sub-step earlier in one
+    # arithmetic than in the other is a different branch for that sub-step (measured: max 4e-5 at 10 ms, 3e-4 at 20 ms)
+    per_env = np.max([np.abs(g - w).reshape(len(g), -1).max(-1) / (1 + np.abs(w).reshape(len(w), -1).max(-1))
+                      for g, w in zip(got, want)], axis=0)
+    assert np.isfinite(per_env).all()
+    assert np.median(per_env) < 5e-6 and (per_env > 5e-5).mean() < 0.01 and per_env.max() < 2e-3, (
+        float(np.median(per_env)), float((per_env > 5e-5).mean()), float(per_env.max()))
+
+
 def test_body_frame_substeps_equal_the_spec_on_the_heightfield(hostlib):
-    """elevation: 4WD, dt 0.01 x 2 sub-steps, bilinear heightfield with per-wheel normals; one control step of 20"""
+    """elevation: 4WD, ONE linearly implicit sub-step per sim.dt = 10 ms, bilinear heightfield with per-wheel normals; one control
+    step of 10"""
     p = OE.elev_params()
     hf = OH.make_terrain()
     st = _states(2048, seed=11, z0=0.06 - 0.0028, hf=hf)
@@ -128,7 +149,8 @@ def test_body_frame_substeps_equal_the_spec_on_the_heightfield(hostlib):
     from tests.depth_cases import hf_struct
     hs, _keep = hf_struct(hf)
     got = _host(hostlib, p.vehicle, p.sim_dt, p.decimation, st, hs, 1)
-    # 20 sub-steps with contact make-or-break: a wheel that touches down in one build and not yet in the other puts the
+    assert p.vehicle.implicit == 1 and p.vehicle.substeps == 1
+    # 10 sub-steps with contact make-or-break: a wheel that touches down in one build and not yet in the other puts the
     # env on a different branch for a sub-step; those (a handful) are held to a loose bound, the rest to fp32 noise
     err = max(float((np.abs(g - w) / (1 + np.abs(w))).max()) for g, w in zip(got, want))
     per_env = np.max([np.abs(g - w).reshape(len(g), -1).max(-1) / (1 + np.abs(w).reshape(len(w), -1).max(-1))

@@ -626,6 +626,7 @@ inline int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
     if (!flags_ok(b) || ((b->flags & WL_FLAG_STREAM) && b->lanes == 4)) return WL_EINVAL;   // the streaming form is a lane form
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL) return WL_EINVAL;   // buffer-resource offsets are 32-bit (~13 M envs)
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || p->num_ref_points <= 0 || p->num_ref_points > 32) return WL_EINVAL;
+    if (p->vehicle.implicit != 0) return WL_EINVAL;   // the drift kernels step the explicit integrator (wl_vehicle.h)
     if (!(p->sim_dt > 0.f)) return WL_EINVAL;
     return WL_OK;
 }

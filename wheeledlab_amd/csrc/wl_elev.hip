@@ -416,9 +416,9 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
 #endif
     if constexpr (LANES == 1 && WL_WHEEL_CORNER_CACHE) {      // lane form: each wheel's cell corners stay in registers between sub-steps
         const HeightFieldGroundCached cached(ground);
-        vehicle_integrate<LANES, HeightFieldGroundCached>(vp, vd, ec, s, cached, wid);
+        vehicle_integrate<LANES, HeightFieldGroundCached, true, -1, true>(vp, vd, ec, s, cached, wid);
     } else {
-        vehicle_integrate<LANES>(vp, vd, ec, s, ground, wid);
+        vehicle_integrate<LANES, HeightFieldGround, true, -1, true>(vp, vd, ec, s, ground, wid);
     }
     if constexpr (LANES != 4) {
         asm volatile("" ::: "memory");
@@ -1382,6 +1382,7 @@ int check_elev(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
     if (!flags_ok(b)) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f)) return WL_EINVAL;
+    if (p->vehicle.implicit != 1) return WL_EINVAL;   // these kernels step the linearly implicit integrator (wl_vehicle.h)
     if (hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f)) return WL_EINVAL;
     return WL_OK;
 }

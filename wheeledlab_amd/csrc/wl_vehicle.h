@@ -1,6 +1,16 @@
 // wl_vehicle.h -- rigid body + 4 tyre contacts, one integrator sub-step, all state in registers.
 // Replaces the PhysX articulation step of the reference (mushr_drift_env_cfg.py:393-394); model derivation in
 // DESIGN.md section 4, executable spec in oracle/vehicle.py.  Actuator constants: wheeledlab_assets/hound.py:4-52.
+//
+// Two integrators of the same force laws (template parameter IMPL, WlVehicleParams.implicit):
+//   explicit  -- semi-implicit Euler of the body under the wheel forces at the current state; h <= 5 ms and a cap on the tyre's
+//                secant stiffness.  The drift tasks (sim.dt = 5 ms, mushr_drift_env_cfg.py:393-394).
+//   implicit  -- round 6: linearly implicit (Rosenbrock-W).  The body's velocity increment solves (M + h G^) du = h r(u_n):
+//                r the body-frame residual, G^ the contact forces' damping matrix approximated by its exact in-plane 3 x 3 block
+//                (v_x, v_y, w_z) for the nominal wheel positions and its diagonal for heave / roll / pitch.  First-order
+//                consistent for any G^, every steady state of the force laws is a fixed point whatever h is, no stiffness cap:
+//                ONE sub-step per sim.dt at the reference's own physics rate -- 10 ms elevation, 20 ms visual
+//                (mushr_elevation_env_cfg.py:461-462, mushr_visual_env_cfg.py:435-436; PhysX: implicit TGS, mushr.py:22-36).
 #pragma once
 #include "../../include/wheeledlab_amd.h"
 #include "wl_math.h"
@@ -25,6 +35,8 @@ struct EnvConst {   // per-env constants hoisted out of the sub-step loop (VGPRs
     // quad form: THIS lane's wheel (picked once per env-step, not per sub-step): velocity target, body position,
     // throttle damping (0: undriven), 1 / (A0 + that damping)
     float wt_lane, bx_lane, by_lane, d_lane, inv_A0d_lane;
+    float A0d_lane;            // A0 + d_lane (implicit integrator: the longitudinal damping of a servoed wheel)
+    float lx_lane, ly_lane;    // (bx_lane, by_lane) / gyr_z
 };
 
 
@@ -42,6 +54,11 @@ struct VehDerived {
     float cgx, cgy, cgz;                    // gyroscopic coefficients h (Iz - Iy) / Ix, ... : the mass cancels
     float inv_wlim, mot_b;                  // 1 / motor_vel_limit ; motor_sat / motor_vel_limit
     float r2;                               // wheel radius squared
+    // implicit integrator (oracle/vehicle.py::implicit_body_update)
+    float Dn;                               // c + h k: the normal spring-damper's damping with the position update folded in
+    float az2, bx2, by2;                    // squared nominal levers: CoM height above the contact patches, half wheelbase, half track
+    float gz, inv_gz;                       // gyr_z: the in-plane block is solved in (dv_x, dv_y, gz dw_z) -- symmetric, mass-free
+    float lxf, lxr, ly;                     // nominal wheel positions / gz: front x, rear x (negative), left y
     int32_t n_sub;                          // decimation * substeps
 };
 
@@ -70,6 +87,16 @@ inline VehDerived derive_vehicle(const WlVehicleParams& vp, float sim_dt, int de
     d.inv_wlim = 1.f / vp.motor_vel_limit;
     d.mot_b = vp.motor_sat / vp.motor_vel_limit;
     d.r2 = vp.wheel_radius * vp.wheel_radius;
+    d.Dn = vp.susp_c + d.h * vp.susp_k;
+    const float az = d.zrel - vp.wheel_radius;
+    d.az2 = az * az;
+    d.bx2 = 0.5f * (vp.half_wheelbase_f * vp.half_wheelbase_f + vp.half_wheelbase_r * vp.half_wheelbase_r);
+    d.by2 = vp.half_track * vp.half_track;
+    d.gz = vp.gyr_z;
+    d.inv_gz = 1.f / vp.gyr_z;
+    d.lxf = vp.half_wheelbase_f * d.inv_gz;
+    d.lxr = -vp.half_wheelbase_r * d.inv_gz;
+    d.ly = vp.half_track * d.inv_gz;
     d.n_sub = decimation * vp.substeps;
     return d;
 }
@@ -110,6 +137,9 @@ WL_DEV void env_const_lane(EnvConst& ec, const WlVehicleParams& vp, const VehDer
     ec.by_lane = left ? vp.half_track : -vp.half_track;
     ec.d_lane = driven ? ec.damp : 0.f;
     ec.inv_A0d_lane = driven ? ec.inv_A0_damp : vd.inv_A0;
+    ec.A0d_lane = vd.A0 + ec.d_lane;
+    ec.lx_lane = front ? vd.lxf : vd.lxr;
+    ec.ly_lane = left ? vd.ly : -vd.ly;
 }
 
 // ---- one wheel: contact + tyre + wheel-spin solve, everything in the BODY frame ------------------------------------------
@@ -132,6 +162,7 @@ WL_DEV void env_const_lane(EnvConst& ec, const WlVehicleParams& vp, const VehDer
 struct TyreCoef {   // the contact force on the body (body frame) is F = fx h + fy (n x h) + kz n
     float fx, fy, kz;
     float Fz;       // normal load
+    float kx, ky;   // IMPL: the force's damping against the contact-point velocity, along / across the wheel (secant)
 };
 // F for coefficients c -- LINEAR in (fx, fy, kz): the axle form below maps the sum and the difference of its two wheels
 template <bool STEER>
@@ -141,9 +172,12 @@ WL_DEV V3 tyre_force(float fx, float fy, float kz, V3 n, float hc, float hs) {
                                    fmaf(kz, n.z, fy * fmaf(n.x, hs, -n.y * hc)));
     else return v3(fmaf(kz, n.x, fx), fmaf(kz, n.y, fyz), fmaf(kz, n.z, -fy * n.y));
 }
-template <bool STEER, bool MOTOR>
+//   IMPL:  no stiffness cap; also returns the damping (kx, ky) of the force against the contact-point velocity: ky = K * scale
+//          (scale: the friction circle's), kx = ky (A0 + d') / (A0 + d' + K r^2) -- the wheel spin eliminated, d' = the motor's
+//          damping while the spin solve took its unclipped root, 0 while the DC-motor window clips the torque
+template <bool STEER, bool MOTOR, bool IMPL = false>
 WL_DEV TyreCoef wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, V3 n, V3 vc, float pen, float hc,
-                           float hs, float d, float inv_A0d, float wt, float& w_spin) {
+                           float hs, float d, float inv_A0d, float wt, float& w_spin, float A0d = 0.f) {
     const float r = vp.wheel_radius;
     const float vn = dot(n, vc);
     const float Fz = pen > 0.f ? fmaxf(fmaf(vp.susp_k, pen, -vp.susp_c * vn), 0.f) : 0.f;
@@ -170,7 +204,7 @@ WL_DEV TyreCoef wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, cons
     const float inv_sig = fminf(rs, 1.f);
     const float gq = fmaf(ec.mu_s, fmaxf(1.f - sig, 0.f), fmaf(ec.mu_sd, inv_sig, ec.mu_d) * inv_sig);
     // explicit-stepping stability cap: at most half of this wheel's share of the body momentum per sub-step
-    const float K = fminf(Fz * gq * inv_vden, ec.K_cap);
+    const float K = IMPL ? Fz * gq * inv_vden : fminf(Fz * gq * inv_vden, ec.K_cap);
     // implicit spin update with the tyre's secant stiffness (unconditionally stable): A w = rhs0 + tau(w) with the
     // DC-motor torque tau = clamp(d (wt - w), lo, hi), window [lo, hi] taken at the current spin (IsaacLab DCMotor,
     // hound.py:13-21).  tau is non-increasing in w, so the solution is the unclipped root w_u = (rhs0 + d wt) / (A + d)
@@ -181,14 +215,18 @@ WL_DEV TyreCoef wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, cons
     const float rhs0 = fmaf(vd.Iw_h, w_i, rK * vcx);
     const float inv_A = rcp(A);
     float w_n, tau_lo = 0.f, tau_hi = 0.f;
+    float kxr = vd.A0 * inv_A;   // IMPL: kx / ky
     if constexpr (MOTOR) {
         tau_hi = clampf(fmaf(-vd.mot_b, w_i, vp.motor_sat), 0.f, vp.motor_limit);     // sat (1 - w / w_lim)
         tau_lo = clampf(fmaf(-vd.mot_b, w_i, -vp.motor_sat), -vp.motor_limit, 0.f);   // sat (-1 - w / w_lim)
-        const float w_u = fmaf(d, wt, rhs0) * rcp(A + d);
+        const float inv_Ad = rcp(A + d);
+        const float w_u = fmaf(d, wt, rhs0) * inv_Ad;
         w_n = clampf(w_u, (rhs0 + tau_lo) * inv_A, (rhs0 + tau_hi) * inv_A);
+        if constexpr (IMPL) kxr = w_n == w_u ? A0d * inv_Ad : kxr;
     } else {
         w_n = rhs0 * inv_A;
     }
+    float ks = K;
     float Fx = fmaf(w_n, rK, -K * vcx);
     float Fy = -K * vcy;
     const float Fmax = ec.mu_s * Fz;
@@ -197,6 +235,7 @@ WL_DEV TyreCoef wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, cons
         const float scale = Fmax * rsq(fmaxf(mag2, 1e-30f));
         Fx *= scale;
         Fy *= scale;
+        if constexpr (IMPL) ks = K * scale;
         const float rhs2 = fmaf(vd.Iw_h, w_i, -r * Fx);
         if constexpr (MOTOR) {
             const float w_u2 = fmaf(d, wt, rhs2) * inv_A0d;   // 1 / (A0 + d): per-env constant
@@ -208,7 +247,7 @@ WL_DEV TyreCoef wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, cons
     w_spin = w_n;
     // F = fx h + fy (n x h) + (Fz - fx g) n  with fx = Fx it, fy = Fy it
     const float fx = Fx * it;
-    return TyreCoef{fx, Fy * it, fmaf(-fx, g, Fz), Fz};
+    return TyreCoef{fx, Fy * it, fmaf(-fx, g, Fz), Fz, ks * kxr, ks};
 }
 
 // contact kinematics of one wheel at body position (bx, by, zrel)
@@ -249,14 +288,42 @@ struct Wrench {
     V3 F, T;
     float Fz;
 };
-template <class Ground, bool STEER, bool MOTOR, bool FIRST, int W = 0>
+// IMPL: the in-plane damping matrix of the wheels' forces about the CoM, in (v_x, v_y, gz w_z) -- sums over the wheels of
+// [kxb, kxy; kxy, kyb] (a wheel's (kx, ky) rotated into the body axes by its heading) moved to the CoM by the wheel's NOMINAL
+// position (lx, ly) = (x, y) / gz -- and the number of wheels in contact (oracle/vehicle.py::substep, the S sums)
+struct Jac {
+    float xx, yy, xy, xw, yw, ww, nc;
+};
+template <bool STEER, bool FIRST>
+WL_DEV void jac_add(Jac& J, const TyreCoef& o, float hc, float hs, float lx, float ly) {
+    float kxb, kyb, kxy;
+    if constexpr (STEER) {
+        const float c2 = hc * hc, s2 = hs * hs, dk = o.kx - o.ky;
+        kxb = fmaf(o.kx, c2, o.ky * s2);
+        kyb = fmaf(o.kx, s2, o.ky * c2);
+        kxy = dk * (hc * hs);
+    } else {
+        kxb = o.kx, kyb = o.ky, kxy = 0.f;
+    }
+    const float gxw = STEER ? fmaf(lx, kxy, -ly * kxb) : -ly * kxb;
+    const float gyw = STEER ? fmaf(lx, kyb, -ly * kxy) : lx * kyb;
+    const float gww = fmaf(lx, gyw, -ly * gxw);
+    const float c = o.Fz > 0.f ? 1.f : 0.f;
+    if constexpr (FIRST) {
+        J = Jac{kxb, kyb, kxy, gxw, gyw, gww, c};
+    } else {
+        J.xx += kxb, J.yy += kyb, J.xy += kxy, J.xw += gxw, J.yw += gyw, J.ww += gww, J.nc += c;
+    }
+}
+template <class Ground, bool STEER, bool MOTOR, bool FIRST, int W = 0, bool IMPL = false>
 WL_DEV void wheel_step(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Ground& ground, const Mat3& R,
                        const VehState& s, V3 vb, float bx, float by, float hc, float hs, float d, float inv_A0d, float wt,
-                       float& w_spin, Wrench& w) {
+                       float& w_spin, Wrench& w, Jac* J = nullptr, float A0d = 0.f, float lx = 0.f, float ly = 0.f) {
     const Contact c = wheel_contact<Ground, W>(vp, vd, ground, R, s, vb, bx, by);
-    const TyreCoef o = wheel_tyre<STEER, MOTOR>(vp, vd, ec, c.n, c.vc, c.pen, hc, hs, d, inv_A0d, wt, w_spin);
+    const TyreCoef o = wheel_tyre<STEER, MOTOR, IMPL>(vp, vd, ec, c.n, c.vc, c.pen, hc, hs, d, inv_A0d, wt, w_spin, A0d);
     const V3 F = tyre_force<STEER>(o.fx, o.fy, o.kz, c.n, hc, hs);
     const V3 t = cross(c.arm, F);
+    if constexpr (IMPL) jac_add<STEER, FIRST>(*J, o, hc, hs, lx, ly);
     if constexpr (FIRST) {   // plain assignment: `0 + x` cannot be folded (-0), it would cost an instruction per component
         w.F = F;
         w.T = t;
@@ -277,14 +344,19 @@ struct AxleOut {
     float ax;      // arm.x of the axle
     float Fz;      // load of both wheels
 };
-template <bool STEER, bool MOTOR>
+template <bool STEER, bool MOTOR, bool IMPL = false, bool FIRST = true>
 WL_DEV AxleOut axle_step(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Mat3& R, const VehState& s, V3 vb,
-                         float bx, float hc, float hs, float d, float inv_A0d, float wt_l, float wt_r, float& w_l, float& w_r) {
+                         float bx, float hc, float hs, float d, float inv_A0d, float wt_l, float wt_r, float& w_l, float& w_r,
+                         Jac* J = nullptr, float A0d = 0.f, float lx = 0.f) {
     const FlatGround flat{};
     const Contact cl = wheel_contact(vp, vd, flat, R, s, vb, bx, vp.half_track);
     const Contact cr = wheel_contact(vp, vd, flat, R, s, vb, bx, -vp.half_track);
-    const TyreCoef a = wheel_tyre<STEER, MOTOR>(vp, vd, ec, cl.n, cl.vc, cl.pen, hc, hs, d, inv_A0d, wt_l, w_l);
-    const TyreCoef b = wheel_tyre<STEER, MOTOR>(vp, vd, ec, cr.n, cr.vc, cr.pen, hc, hs, d, inv_A0d, wt_r, w_r);
+    const TyreCoef a = wheel_tyre<STEER, MOTOR, IMPL>(vp, vd, ec, cl.n, cl.vc, cl.pen, hc, hs, d, inv_A0d, wt_l, w_l, A0d);
+    const TyreCoef b = wheel_tyre<STEER, MOTOR, IMPL>(vp, vd, ec, cr.n, cr.vc, cr.pen, hc, hs, d, inv_A0d, wt_r, w_r, A0d);
+    if constexpr (IMPL) {
+        jac_add<STEER, FIRST>(*J, a, hc, hs, lx, vd.ly);
+        jac_add<STEER, false>(*J, b, hc, hs, lx, -vd.ly);
+    }
     AxleOut o;
     o.F = tyre_force<STEER>(a.fx + b.fx, a.fy + b.fy, a.kz + b.kz, cl.n, hc, hs);
     const V3 D = tyre_force<STEER>(a.fx - b.fx, a.fy - b.fy, a.kz - b.kz, cl.n, hc, hs);   // (the y component is dead code)
@@ -305,6 +377,20 @@ WL_DEV void steer_update(const WlVehicleParams& vp, const VehDerived& vd, const 
     s.om = om_n;
 }
 
+// the pose half of a sub-step: x <- x + h v, q <- q + (h / 2) q (0, w_b) renormalised, both with the NEW velocities
+WL_DEV void pose_integrate(const VehDerived& vd, VehState& s) {
+    s.x = fma3(vd.h, s.v, s.x);
+    // q <- q + (h / 2) q (0, w_b)   [== (h / 2) (0, R w_b) q, the world-rate form of the spec], then renormalise
+    const V3 u = vd.half_h * s.wb;
+    Quat q = s.q;
+    const float nw = fmaf(-q.x, u.x, fmaf(-q.y, u.y, fmaf(-q.z, u.z, q.w)));
+    const float nx = fmaf(q.w, u.x, fmaf(q.y, u.z, fmaf(-q.z, u.y, q.x)));
+    const float ny = fmaf(q.w, u.y, fmaf(q.z, u.x, fmaf(-q.x, u.z, q.y)));
+    const float nz = fmaf(q.w, u.z, fmaf(q.x, u.y, fmaf(-q.y, u.x, q.z)));
+    const float inv_n = rsq(fmaf(nw, nw, fmaf(nx, nx, fmaf(ny, ny, nz * nz))));
+    s.q = Quat{nw * inv_n, nx * inv_n, ny * inv_n, nz * inv_n};
+}
+
 // semi-implicit Euler of the rigid body under the summed contact force Fb / torque Tb about the CoM (BODY frame);
 // Fz_w: world z component of the contact force where the caller knows it without R (flat ground: the sum of the loads).
 // The inertia tensor is m diag(gyr^2): h / I = (h / m) / gyr^2 and the gyroscopic term w x (I w) / I has the mass
@@ -318,16 +404,51 @@ WL_DEV void body_integrate(const VehDerived& vd, const EnvConst& ec, VehState& s
     const V3 w = s.wb;
     s.wb = v3(fmaf(vd.inv_g2x, t.x, fmaf(-vd.cgx, w.y * w.z, w.x)), fmaf(vd.inv_g2y, t.y, fmaf(-vd.cgy, w.z * w.x, w.y)),
               fmaf(vd.inv_g2z, t.z, fmaf(-vd.cgz, w.x * w.y, w.z)));
-    s.x = fma3(vd.h, s.v, s.x);
-    // q <- q + (h / 2) q (0, w_b)   [== (h / 2) (0, R w_b) q, the world-rate form of the spec], then renormalise
-    const V3 u = vd.half_h * s.wb;
-    Quat q = s.q;
-    const float nw = fmaf(-q.x, u.x, fmaf(-q.y, u.y, fmaf(-q.z, u.z, q.w)));
-    const float nx = fmaf(q.w, u.x, fmaf(q.y, u.z, fmaf(-q.z, u.y, q.x)));
-    const float ny = fmaf(q.w, u.y, fmaf(q.z, u.x, fmaf(-q.x, u.z, q.y)));
-    const float nz = fmaf(q.w, u.z, fmaf(q.x, u.y, fmaf(-q.y, u.x, q.z)));
-    const float inv_n = rsq(fmaf(nw, nw, fmaf(nx, nx, fmaf(ny, ny, nz * nz))));
-    s.q = Quat{nw * inv_n, nx * inv_n, ny * inv_n, nz * inv_n};
+    pose_integrate(vd, s);
+}
+
+// The linearly implicit velocity update (oracle/vehicle.py::implicit_body_update): (M + h G^) du = h r in the body frame.
+//   r: Fb + m g_b - m w x v_b  (g_b = -g R.r2: gravity in body coordinates; -w x v_b: a world-constant velocity seen from the
+//      turning body, so that steady cornering is a fixed point), Tb - w x (I w);
+//   G^: J (the in-plane 3 x 3 block, solved by LDL^T in (dv_x, dv_y, gz dw_z) with the mass divided out) and the diagonal for
+//      heave / roll / pitch: Dn = c + h k per wheel in contact at its nominal lever, the tyres through the CoM height.
+// The world velocity takes R (dv_b + h w x v_b): in free flight (J = 0) exactly the explicit update.
+WL_DEV void body_integrate_implicit(const VehDerived& vd, const EnvConst& ec, VehState& s, const Mat3& R, V3 vb, V3 Fb, V3 Tb,
+                                    const Jac& J) {
+    const float q = ec.h_inv_mass;
+    const V3 w = s.wb;
+    const V3 hrot = vd.h * cross(w, vb);
+    // h a_b = q Fb - h g R.r2 - h w x v_b ;  h alpha = q Tb / gyr^2 - h (gyroscopic)
+    const V3 ha = v3(fmaf(q, Fb.x, fmaf(-vd.hg, R.r2.x, -hrot.x)), fmaf(q, Fb.y, fmaf(-vd.hg, R.r2.y, -hrot.y)),
+                     fmaf(q, Fb.z, fmaf(-vd.hg, R.r2.z, -hrot.z)));
+    const V3 t = q * Tb;
+    const V3 hal = v3(fmaf(vd.inv_g2x, t.x, -vd.cgx * (w.y * w.z)), fmaf(vd.inv_g2y, t.y, -vd.cgy * (w.z * w.x)),
+                      fmaf(vd.inv_g2z, t.z, -vd.cgz * (w.x * w.y)));
+    // in-plane: LDL^T of [1 + q Jxx, q Jxy, q Jxw; ., 1 + q Jyy, q Jyw; ., ., 1 + q Jww] (identity + PSD: no pivoting)
+    const float a11 = fmaf(q, J.xx, 1.f), a12 = q * J.xy, a13 = q * J.xw, a22 = fmaf(q, J.yy, 1.f), a23 = q * J.yw,
+                a33 = fmaf(q, J.ww, 1.f);
+    const float b1 = ha.x, b2 = ha.y, b3 = hal.z * vd.gz;
+    const float i1 = rcp(a11);
+    const float l21 = a12 * i1, l31 = a13 * i1;
+    const float d2 = fmaf(-l21, a12, a22);
+    const float t32 = fmaf(-l31, a12, a23);
+    const float i2 = rcp(d2);
+    const float l32 = t32 * i2;
+    const float d3 = fmaf(-l32, t32, fmaf(-l31, a13, a33));
+    const float y2 = fmaf(-l21, b1, b2);
+    const float y3 = fmaf(-l32, y2, fmaf(-l31, b1, b3));
+    const float x3 = y3 * rcp(d3);
+    const float x2 = fmaf(y2, i2, -l32 * x3);
+    const float x1 = fmaf(b1, i1, fmaf(-l21, x2, -l31 * x3));
+    // heave / roll / pitch: diagonal
+    const float nD = J.nc * vd.Dn;
+    const float dvz = ha.z * rcp(fmaf(q, nD, 1.f));
+    const float dwx = hal.x * rcp(fmaf(q * vd.inv_g2x, fmaf(vd.az2, J.yy, vd.by2 * nD), 1.f));
+    const float dwy = hal.y * rcp(fmaf(q * vd.inv_g2y, fmaf(vd.az2, J.xx, vd.bx2 * nD), 1.f));
+    const V3 dv = v3(x1 + hrot.x, x2 + hrot.y, dvz + hrot.z);
+    s.v = v3(s.v.x + dot(R.r0, dv), s.v.y + dot(R.r1, dv), s.v.z + dot(R.r2, dv));
+    s.wb = v3(w.x + dwx, w.y + dwy, fmaf(x3, vd.inv_gz, w.z));
+    pose_integrate(vd, s);
 }
 
 // sum over the 4 lanes of a quad with DPP quad_perm swaps (no LDS traffic); every lane gets the SAME bits
@@ -352,23 +473,26 @@ WL_DEV V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)
 //               the critical path per sub-step drops from 4 wheels to 1.
 //   DRIVE (lane form): 0 rear-wheel drive, 1 four-wheel drive: compiled in -- the other drive's front-axle code, its
 //               branch and its live values (two wheel targets) leave the loop; -1: decided at run time (vp.drive)
-template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1>
+template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1, bool IMPL = false>
 WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
                             const Ground& ground, int wid, float sn, float cs /* sin / cos of the steer angle in force */) {
     const Mat3 R = mat_from_quat(s.q);
     const V3 vb = mul_t(R, s.v);
     Wrench w;
+    Jac J;
     if constexpr (LANES == 1 && Ground::kFlat) {
         const bool awd = DRIVE == 1 || (DRIVE < 0 && vp.drive == 1);
         // rear axle: always driven, never steered; front axle: steered, driven only with 4WD (the undriven wheel has no
         // motor arithmetic at all)
-        const AxleOut ar = axle_step<false, true>(vp, vd, ec, R, s, vb, -vp.half_wheelbase_r, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
-                                                  ec.wheel_target[0], ec.wheel_target[1], s.wheel[0], s.wheel[1]);
+        const float A0d = vd.A0 + ec.damp;
+        const AxleOut ar = axle_step<false, true, IMPL, true>(vp, vd, ec, R, s, vb, -vp.half_wheelbase_r, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
+                                                              ec.wheel_target[0], ec.wheel_target[1], s.wheel[0], s.wheel[1], &J, A0d, vd.lxr);
         if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
         AxleOut af;
-        if (awd) af = axle_step<true, true>(vp, vd, ec, R, s, vb, vp.half_wheelbase_f, cs, sn, ec.damp, ec.inv_A0_damp, ec.wheel_target[2],
-                                            ec.wheel_target[3], s.wheel[2], s.wheel[3]);
-        else af = axle_step<true, false>(vp, vd, ec, R, s, vb, vp.half_wheelbase_f, cs, sn, 0.f, vd.inv_A0, 0.f, 0.f, s.wheel[2], s.wheel[3]);
+        if (awd) af = axle_step<true, true, IMPL, false>(vp, vd, ec, R, s, vb, vp.half_wheelbase_f, cs, sn, ec.damp, ec.inv_A0_damp, ec.wheel_target[2],
+                                                         ec.wheel_target[3], s.wheel[2], s.wheel[3], &J, A0d, vd.lxf);
+        else af = axle_step<true, false, IMPL, false>(vp, vd, ec, R, s, vb, vp.half_wheelbase_f, cs, sn, 0.f, vd.inv_A0, 0.f, 0.f, s.wheel[2], s.wheel[3],
+                                                      &J, vd.A0, vd.lxf);
         if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
         const V3 n = R.r2;
         const float r = vp.wheel_radius, ht = vp.half_track;
@@ -380,42 +504,50 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
         w.Fz = ar.Fz + af.Fz;
     } else if constexpr (LANES == 1) {
         const float ht = vp.half_track, bxr = -vp.half_wheelbase_r, bxf = vp.half_wheelbase_f;
-        wheel_step<Ground, false, true, true, 0>(vp, vd, ec, ground, R, s, vb, bxr, ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
-                                                 ec.wheel_target[0], s.wheel[0], w);
-        wheel_step<Ground, false, true, false, 1>(vp, vd, ec, ground, R, s, vb, bxr, -ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
-                                                  ec.wheel_target[1], s.wheel[1], w);
+        const float A0d = vd.A0 + ec.damp;
+        wheel_step<Ground, false, true, true, 0, IMPL>(vp, vd, ec, ground, R, s, vb, bxr, ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
+                                                       ec.wheel_target[0], s.wheel[0], w, &J, A0d, vd.lxr, vd.ly);
+        wheel_step<Ground, false, true, false, 1, IMPL>(vp, vd, ec, ground, R, s, vb, bxr, -ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
+                                                        ec.wheel_target[1], s.wheel[1], w, &J, A0d, vd.lxr, -vd.ly);
         if (DRIVE == 1 || (DRIVE < 0 && vp.drive == 1)) {
-            wheel_step<Ground, true, true, false, 2>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, ec.damp, ec.inv_A0_damp,
-                                                     ec.wheel_target[2], s.wheel[2], w);
-            wheel_step<Ground, true, true, false, 3>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, ec.damp, ec.inv_A0_damp,
-                                                     ec.wheel_target[3], s.wheel[3], w);
+            wheel_step<Ground, true, true, false, 2, IMPL>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, ec.damp, ec.inv_A0_damp,
+                                                           ec.wheel_target[2], s.wheel[2], w, &J, A0d, vd.lxf, vd.ly);
+            wheel_step<Ground, true, true, false, 3, IMPL>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, ec.damp, ec.inv_A0_damp,
+                                                           ec.wheel_target[3], s.wheel[3], w, &J, A0d, vd.lxf, -vd.ly);
         } else {
-            wheel_step<Ground, true, false, false, 2>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[2], w);
-            wheel_step<Ground, true, false, false, 3>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[3], w);
+            wheel_step<Ground, true, false, false, 2, IMPL>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[2], w,
+                                                            &J, vd.A0, vd.lxf, vd.ly);
+            wheel_step<Ground, true, false, false, 3, IMPL>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[3], w,
+                                                            &J, vd.A0, vd.lxf, -vd.ly);
         }
     } else {
         const bool front = wid >= 2;
         const float hc = front ? cs : 1.f, hs = front ? sn : 0.f;
-        wheel_step<Ground, true, true, true>(vp, vd, ec, ground, R, s, vb, ec.bx_lane, ec.by_lane, hc, hs, ec.d_lane, ec.inv_A0d_lane,
-                                             ec.wt_lane, s.wheel[0], w);
+        wheel_step<Ground, true, true, true, 0, IMPL>(vp, vd, ec, ground, R, s, vb, ec.bx_lane, ec.by_lane, hc, hs, ec.d_lane, ec.inv_A0d_lane,
+                                                      ec.wt_lane, s.wheel[0], w, &J, ec.A0d_lane, ec.lx_lane, ec.ly_lane);
         w.F = quad_sum(w.F);
         w.T = quad_sum(w.T);
-        if constexpr (Ground::kFlat) w.Fz = quad_sum(w.Fz);
+        if constexpr (Ground::kFlat && !IMPL) w.Fz = quad_sum(w.Fz);
+        if constexpr (IMPL) {
+            J.xx = quad_sum(J.xx), J.yy = quad_sum(J.yy), J.xy = quad_sum(J.xy), J.xw = quad_sum(J.xw), J.yw = quad_sum(J.yw);
+            J.ww = quad_sum(J.ww), J.nc = quad_sum(J.nc);
+        }
     }
     if constexpr (LANES == 1 && !UNROLL) __builtin_amdgcn_sched_barrier(0);
-    body_integrate<Ground::kFlat>(vd, ec, s, R, w.F, w.T, w.Fz);
+    if constexpr (IMPL) body_integrate_implicit(vd, ec, s, R, vb, w.F, w.T, J);
+    else body_integrate<Ground::kFlat>(vd, ec, s, R, w.F, w.T, w.Fz);
 }
 
 // decimation x substeps integrator sub-steps (everything in registers).  A variant that software-pipelined the steering
 // joint one sub-step ahead measured no gain: a wavefront alone on its SIMD pays ~3 ns per instruction whatever the
 // chain looks like (tools/microbench/valu_issue.hip), so only fewer instructions on the critical lane help.
-template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1>
+template <int LANES, class Ground, bool UNROLL = true, int DRIVE = -1, bool IMPL = false>
 WL_DEV void vehicle_integrate(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, VehState& s,
                               const Ground& ground, int wid = 0) {
     for (int k = 0; k < vd.n_sub; ++k) {
         steer_update(vp, vd, ec, s);
         float sn, cs;
         sincos_fast(s.th, sn, cs);   // |th| <= tan(0.488) rad: hardware sin/cos, ~1e-6 abs
-        vehicle_substep<LANES, Ground, UNROLL, DRIVE>(vp, vd, ec, s, ground, wid, sn, cs);
+        vehicle_substep<LANES, Ground, UNROLL, DRIVE, IMPL>(vp, vd, ec, s, ground, wid, sn, cs);
     }
 }

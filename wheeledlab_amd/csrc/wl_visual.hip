@@ -137,9 +137,9 @@ WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, co
 #endif
         if constexpr (LANES == 1 && !Ground::kFlat && WL_WHEEL_CORNER_CACHE) {   // lane form on a heightfield: see HeightFieldGroundCached
             const HeightFieldGroundCached cached(ground);
-            vehicle_integrate<LANES, HeightFieldGroundCached>(vp, vd, ec, s, cached, wid);
+            vehicle_integrate<LANES, HeightFieldGroundCached, true, -1, true>(vp, vd, ec, s, cached, wid);
         } else {
-            vehicle_integrate<LANES, Ground>(vp, vd, ec, s, ground, wid);
+            vehicle_integrate<LANES, Ground, true, -1, true>(vp, vd, ec, s, ground, wid);
         }
         if constexpr (LANES != 4) {
             asm volatile("" ::: "memory");
@@ -666,6 +666,7 @@ int check_visual(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
     if (!flags_ok(b)) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f) || m->rows <= 0 || m->cols <= 0) return WL_EINVAL;
+    if (p->vehicle.implicit != 1) return WL_EINVAL;   // these kernels step the linearly implicit integrator (wl_vehicle.h)
     return WL_OK;
 }
 

@@ -248,9 +248,10 @@ def _common_vehicle(cfg, p, acfg):
     mat = cfg.scene.terrain.physics_material
     if mat.friction_combine_mode != "multiply":
         raise NotImplementedError("only the 'multiply' friction combine mode is modelled")
-    substeps = max(1, math.ceil(float(cfg.sim.dt) / 0.00501))      # integrator step h <= 5 ms (validated range)
+    # the linearly implicit integrator steps once per sim.dt (the reference's physics rate) up to h = 20 ms, its validated range
+    substeps = max(1, math.ceil(float(cfg.sim.dt) / 0.0201))
     p.vehicle = mushr_vehicle(drive=0 if rwd else 1, motor_limit=float(thr.effort_limit), substeps=substeps,
-                              ground_mu=(mat.static_friction, mat.dynamic_friction))
+                              ground_mu=(mat.static_friction, mat.dynamic_friction), implicit=1)
     v = p.vehicle
     v.motor_sat, v.motor_vel_limit = float(thr.saturation_effort), float(thr.velocity_limit)
     st = acts["steering_joints"]

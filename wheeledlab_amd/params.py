@@ -11,7 +11,7 @@ MUSHR_CHASSIS_MASS = 3.0
 
 
 def mushr_vehicle(drive: int = 0, motor_limit: float = 0.5, substeps: int = 1,
-                  ground_mu: tuple[float, float] = (1.1, 1.0)) -> WlVehicleParams:
+                  ground_mu: tuple[float, float] = (1.1, 1.0), implicit: int = 0) -> WlVehicleParams:
     """MuSHR-class 1/10 car.  Geometry: wheeledlab_tasks/common/actions.py:17-20 (L 0.325, W 0.2, r 0.05).
     Actuators: wheeledlab_assets/wheeledlab_assets/hound.py:4-52.  Mass / inertia / compliance: designed (USD missing)."""
     v = WlVehicleParams()
@@ -31,6 +31,7 @@ def mushr_vehicle(drive: int = 0, motor_limit: float = 0.5, substeps: int = 1,
     v.drive = drive                                  # hound.py:44-51: front throttle joints passive in 2WD
     v.steer_kp, v.steer_kd, v.steer_effort, v.steer_vel_limit, v.steer_inertia = 100.0, 10.0, 3.2, 10.0, 2e-4
     v.substeps = substeps
+    v.implicit = implicit                            # integrator: csrc/wl_vehicle.h (0 explicit h <= 5 ms, 1 linearly implicit)
     return v
 
 
@@ -78,7 +79,7 @@ def elev_params() -> WlElevParams:
     p.sim_dt, p.decimation = 0.01, 10                                   # :461-462
     p.max_episode_length = math.ceil(20.0 / (0.01 * 10))                # :465
     p.action = mushr_action(1)                                          # :446 Mushr4WDActionCfg
-    p.vehicle = mushr_vehicle(drive=1, motor_limit=0.25, substeps=2, ground_mu=(1.0, 1.0))   # :130, :102-107
+    p.vehicle = mushr_vehicle(drive=1, motor_limit=0.25, substeps=1, ground_mu=(1.0, 1.0), implicit=1)   # :130, :102-107; h = sim.dt
     for i, w in enumerate((200.0, 5000.0, 0.0, -200.0, 0.0, 0.0, 0.0, 0.0)):                  # :286-305
         p.weight[i] = w
     p.min_height = 0.15                                                 # :356-359
@@ -116,7 +117,7 @@ def visual_params():
     p.sim_dt, p.decimation = 0.02, 10                                   # :435-436
     p.max_episode_length = math.ceil(10.0 / (0.02 * 10))                # :439
     p.action = mushr_action(1)
-    p.vehicle = mushr_vehicle(drive=1, motor_limit=0.25, substeps=4, ground_mu=(2.0, 2.0))   # :130-135; h = 0.005
+    p.vehicle = mushr_vehicle(drive=1, motor_limit=0.25, substeps=1, ground_mu=(2.0, 2.0), implicit=1)   # :130-135; h = sim.dt
     for i, w in enumerate((5.0, 7.0, 0, 0, 0, 0, 0, 0)):                # :375-385
         p.weight[i] = w
     p.reset_z = 0.1                                                     # :203
