@@ -180,15 +180,19 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
         new_wheel[:, i] = w_n
         if implicit:
             # damping of this wheel's force against the contact-point velocity (secant): K_s = K * scale (on the friction
-            # circle the force no longer grows with the slip) laterally; longitudinally K_s with the wheel spin eliminated,
-            # K_s (A0 + d') / (A0 + d' + K r^2): d' = the motor's damping while its torque is inside the DC-motor window (the
-            # spin solve's unclipped root), 0 while it is clipped -- a free-spinning wheel follows the ground, a velocity-servoed
-            # one resists.  Rotated into the body axes by the wheel's heading (hc, hs) and moved to the CoM by the wheel's
-            # NOMINAL position (px, py): the in-plane Jacobian of a car standing on its wheels.
-            unclipped = (w_u >= (rhs0 + lo) / A) & (w_u <= (rhs0 + hi) / A)    # the median above returned w_u itself
-            dm = np.where(unclipped, d, F(0)).astype(F)
+            # circle the force no longer grows with the slip) laterally; longitudinally K_s with the wheel spin eliminated:
+            # K_s A0 / (A0 + K r^2) for a free-spinning wheel (it follows the ground), K_s (A0 + d) / (A0 + d + K r^2) for a
+            # velocity-servoed one (it resists).  Between the two by s: 1 while the torque the unclipped root asks for,
+            # t_eq = A w_u - rhs0, is inside the DC-motor window, fading to 0 over the last tenth of motor_limit before the
+            # window clips it.  The RATIO kx / ky is blended, not the damping d: with d ~ 1000 >> A a blend of d is a 0 / 1
+            # switch in all but name, and two arithmetics that disagree in the last bit at the window's edge would take
+            # different Jacobians.  Rotated into the body axes by the wheel's heading (hc, hs) and moved to the CoM by the
+            # wheel's NOMINAL position (px, py): the in-plane Jacobian of a car standing on its wheels.
+            t_eq = A * w_u - rhs0
+            s_m = np.clip(np.minimum(hi - t_eq, t_eq - lo) * (F(10) / F(vp.motor_limit)), F(0), F(1))
             ky = (K * scale).astype(F)
-            kx = (ky * (A2 + dm) / (A + dm)).astype(F)
+            Kr2 = K * r * r
+            kx = (ky * (F(1) - Kr2 * (F(1) / A + s_m * (F(1) / (A + d) - F(1) / A)))).astype(F)
             hc, hs = hb[:, 0], hb[:, 1]
             kxb = kx * hc * hc + ky * hs * hs
             kyb = kx * hs * hs + ky * hc * hc

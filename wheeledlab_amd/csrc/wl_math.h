@@ -13,7 +13,11 @@ WL_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 WL_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 WL_DEV V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
 WL_DEV float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
-WL_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// (sums of two products are spelled out as fma(a, b, -(c * d)): under -ffp-contract=fast the compiler otherwise picks WHICH product
+// it fuses per inlining site, and kernels that must agree bit for bit -- the persistent rollouts with the stepping launches -- do not)
+WL_DEV V3 cross(V3 a, V3 b) {
+    return V3{fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+}
 WL_DEV V3 fma3(float s, V3 a, V3 b) { return V3{fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)}; }
 
 // hardware reciprocal / rsqrt / sqrt (1 ulp class): the path is not IEEE-division sensitive, parity budget is 1e-5
@@ -47,13 +51,13 @@ struct Mat3 {
     V3 r0, r1, r2;
 };
 WL_DEV Mat3 mat_from_quat(Quat q) {
-    float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z;
-    float xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z;
-    float wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+    const float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+    const float wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+    const float dz = 1.f - q.z * z2, dy = 1.f - q.y * y2;   // (one product each: nothing to choose)
     Mat3 m;
-    m.r0 = v3(1.f - 2.f * (yy + zz), 2.f * (xy - wz), 2.f * (xz + wy));
-    m.r1 = v3(2.f * (xy + wz), 1.f - 2.f * (xx + zz), 2.f * (yz - wx));
-    m.r2 = v3(2.f * (xz - wy), 2.f * (yz + wx), 1.f - 2.f * (xx + yy));
+    m.r0 = v3(fmaf(-q.y, y2, dz), fmaf(q.x, y2, -wz), fmaf(q.x, z2, wy));
+    m.r1 = v3(fmaf(q.x, y2, wz), fmaf(-q.x, x2, dz), fmaf(q.y, z2, -wx));
+    m.r2 = v3(fmaf(q.x, z2, -wy), fmaf(q.y, z2, wx), fmaf(-q.x, x2, dy));
     return m;
 }
 WL_DEV V3 mul(const Mat3& m, V3 v) { return v3(dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)); }

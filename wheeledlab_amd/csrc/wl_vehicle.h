@@ -35,7 +35,6 @@ struct EnvConst {   // per-env constants hoisted out of the sub-step loop (VGPRs
     // quad form: THIS lane's wheel (picked once per env-step, not per sub-step): velocity target, body position,
     // throttle damping (0: undriven), 1 / (A0 + that damping)
     float wt_lane, bx_lane, by_lane, d_lane, inv_A0d_lane;
-    float A0d_lane;            // A0 + d_lane (implicit integrator: the longitudinal damping of a servoed wheel)
     float lx_lane, ly_lane;    // (bx_lane, by_lane) / gyr_z
 };
 
@@ -53,6 +52,7 @@ struct VehDerived {
     float inv_g2x, inv_g2y, inv_g2z;        // 1 / gyr^2: h / I = (h / m) * inv_g2
     float cgx, cgy, cgz;                    // gyroscopic coefficients h (Iz - Iy) / Ix, ... : the mass cancels
     float inv_wlim, mot_b;                  // 1 / motor_vel_limit ; motor_sat / motor_vel_limit
+    float mot_g;                            // 10 / motor_limit: the implicit integrator's fade of the motor damping at the window's edge
     float r2;                               // wheel radius squared
     // implicit integrator (oracle/vehicle.py::implicit_body_update)
     float Dn;                               // c + h k: the normal spring-damper's damping with the position update folded in
@@ -86,6 +86,7 @@ inline VehDerived derive_vehicle(const WlVehicleParams& vp, float sim_dt, int de
     d.cgz = d.h * (gy2 - gx2) / gz2;
     d.inv_wlim = 1.f / vp.motor_vel_limit;
     d.mot_b = vp.motor_sat / vp.motor_vel_limit;
+    d.mot_g = 10.f / vp.motor_limit;
     d.r2 = vp.wheel_radius * vp.wheel_radius;
     d.Dn = vp.susp_c + d.h * vp.susp_k;
     const float az = d.zrel - vp.wheel_radius;
@@ -137,7 +138,6 @@ WL_DEV void env_const_lane(EnvConst& ec, const WlVehicleParams& vp, const VehDer
     ec.by_lane = left ? vp.half_track : -vp.half_track;
     ec.d_lane = driven ? ec.damp : 0.f;
     ec.inv_A0d_lane = driven ? ec.inv_A0_damp : vd.inv_A0;
-    ec.A0d_lane = vd.A0 + ec.d_lane;
     ec.lx_lane = front ? vd.lxf : vd.lxr;
     ec.ly_lane = left ? vd.ly : -vd.ly;
 }
@@ -163,6 +163,7 @@ struct TyreCoef {   // the contact force on the body (body frame) is F = fx h + 
     float fx, fy, kz;
     float Fz;       // normal load
     float kx, ky;   // IMPL: the force's damping against the contact-point velocity, along / across the wheel (secant)
+    float dk;       // kx - ky
 };
 // F for coefficients c -- LINEAR in (fx, fy, kz): the axle form below maps the sum and the difference of its two wheels
 template <bool STEER>
@@ -173,11 +174,12 @@ WL_DEV V3 tyre_force(float fx, float fy, float kz, V3 n, float hc, float hs) {
     else return v3(fmaf(kz, n.x, fx), fmaf(kz, n.y, fyz), fmaf(kz, n.z, -fy * n.y));
 }
 //   IMPL:  no stiffness cap; also returns the damping (kx, ky) of the force against the contact-point velocity: ky = K * scale
-//          (scale: the friction circle's), kx = ky (A0 + d') / (A0 + d' + K r^2) -- the wheel spin eliminated, d' = the motor's
-//          damping while the spin solve took its unclipped root, 0 while the DC-motor window clips the torque
+//          (scale: the friction circle's), kx = ky (1 - K r^2 cw) -- the wheel spin eliminated; cw the wheel's compliance,
+//          1 / (A + d) while the motor servoes it, 1 / A while the DC-motor window clips the torque, blended over the last tenth
+//          of motor_limit before the clip (continuous: a 0 / 1 switch would hand two arithmetics different Jacobians at the edge)
 template <bool STEER, bool MOTOR, bool IMPL = false>
 WL_DEV TyreCoef wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, V3 n, V3 vc, float pen, float hc,
-                           float hs, float d, float inv_A0d, float wt, float& w_spin, float A0d = 0.f) {
+                           float hs, float d, float inv_A0d, float wt, float& w_spin) {
     const float r = vp.wheel_radius;
     const float vn = dot(n, vc);
     const float Fz = pen > 0.f ? fmaxf(fmaf(vp.susp_k, pen, -vp.susp_c * vn), 0.f) : 0.f;
@@ -215,14 +217,17 @@ WL_DEV TyreCoef wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, cons
     const float rhs0 = fmaf(vd.Iw_h, w_i, rK * vcx);
     const float inv_A = rcp(A);
     float w_n, tau_lo = 0.f, tau_hi = 0.f;
-    float kxr = vd.A0 * inv_A;   // IMPL: kx / ky
+    float cw = inv_A;   // IMPL: the wheel's compliance 1 / (A + d'): inv_A free-spinning, 1 / (A + d) servoed, blended by the window's fade
     if constexpr (MOTOR) {
         tau_hi = clampf(fmaf(-vd.mot_b, w_i, vp.motor_sat), 0.f, vp.motor_limit);     // sat (1 - w / w_lim)
         tau_lo = clampf(fmaf(-vd.mot_b, w_i, -vp.motor_sat), -vp.motor_limit, 0.f);   // sat (-1 - w / w_lim)
         const float inv_Ad = rcp(A + d);
         const float w_u = fmaf(d, wt, rhs0) * inv_Ad;
         w_n = clampf(w_u, (rhs0 + tau_lo) * inv_A, (rhs0 + tau_hi) * inv_A);
-        if constexpr (IMPL) kxr = w_n == w_u ? A0d * inv_Ad : kxr;
+        if constexpr (IMPL) {   // s = clamp(min(hi - t_eq, t_eq - lo) * 10 / motor_limit, 0, 1), t_eq = A w_u - rhs0
+            const float m_hi = fmaf(-A, w_u, rhs0 + tau_hi), m_lo = fmaf(A, w_u, -(rhs0 + tau_lo));
+            cw = fmaf(clampf(fminf(m_hi, m_lo) * vd.mot_g, 0.f, 1.f), inv_Ad - inv_A, inv_A);
+        }
     } else {
         w_n = rhs0 * inv_A;
     }
@@ -247,7 +252,9 @@ WL_DEV TyreCoef wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, cons
     w_spin = w_n;
     // F = fx h + fy (n x h) + (Fz - fx g) n  with fx = Fx it, fy = Fy it
     const float fx = Fx * it;
-    return TyreCoef{fx, Fy * it, fmaf(-fx, g, Fz), Fz, ks * kxr, ks};
+    // kx / ky - 1 = -K r^2 x (the wheel's compliance)
+    const float kxr1 = IMPL ? -(K * vd.r2) * cw : 0.f;
+    return TyreCoef{fx, Fy * it, fmaf(-fx, g, Fz), Fz, fmaf(ks, kxr1, ks), ks, ks * kxr1};
 }
 
 // contact kinematics of one wheel at body position (bx, by, zrel)
@@ -298,10 +305,12 @@ template <bool STEER, bool FIRST>
 WL_DEV void jac_add(Jac& J, const TyreCoef& o, float hc, float hs, float lx, float ly) {
     float kxb, kyb, kxy;
     if constexpr (STEER) {
-        const float c2 = hc * hc, s2 = hs * hs, dk = o.kx - o.ky;
+        const float c2 = hc * hc, s2 = hs * hs;
         kxb = fmaf(o.kx, c2, o.ky * s2);
         kyb = fmaf(o.kx, s2, o.ky * c2);
-        kxy = dk * (hc * hs);
+        // (an fma, not a product: a bare product feeding quad_sum's first add is contracted into it at some inlining sites and not
+        // at others -- measured as last-bit differences between the persistent and the stepping kernels)
+        kxy = fmaf(o.dk, hc * hs, 0.f);
     } else {
         kxb = o.kx, kyb = o.ky, kxy = 0.f;
     }
@@ -318,9 +327,9 @@ WL_DEV void jac_add(Jac& J, const TyreCoef& o, float hc, float hs, float lx, flo
 template <class Ground, bool STEER, bool MOTOR, bool FIRST, int W = 0, bool IMPL = false>
 WL_DEV void wheel_step(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Ground& ground, const Mat3& R,
                        const VehState& s, V3 vb, float bx, float by, float hc, float hs, float d, float inv_A0d, float wt,
-                       float& w_spin, Wrench& w, Jac* J = nullptr, float A0d = 0.f, float lx = 0.f, float ly = 0.f) {
+                       float& w_spin, Wrench& w, Jac* J = nullptr, float lx = 0.f, float ly = 0.f) {
     const Contact c = wheel_contact<Ground, W>(vp, vd, ground, R, s, vb, bx, by);
-    const TyreCoef o = wheel_tyre<STEER, MOTOR, IMPL>(vp, vd, ec, c.n, c.vc, c.pen, hc, hs, d, inv_A0d, wt, w_spin, A0d);
+    const TyreCoef o = wheel_tyre<STEER, MOTOR, IMPL>(vp, vd, ec, c.n, c.vc, c.pen, hc, hs, d, inv_A0d, wt, w_spin);
     const V3 F = tyre_force<STEER>(o.fx, o.fy, o.kz, c.n, hc, hs);
     const V3 t = cross(c.arm, F);
     if constexpr (IMPL) jac_add<STEER, FIRST>(*J, o, hc, hs, lx, ly);
@@ -347,12 +356,12 @@ struct AxleOut {
 template <bool STEER, bool MOTOR, bool IMPL = false, bool FIRST = true>
 WL_DEV AxleOut axle_step(const WlVehicleParams& vp, const VehDerived& vd, const EnvConst& ec, const Mat3& R, const VehState& s, V3 vb,
                          float bx, float hc, float hs, float d, float inv_A0d, float wt_l, float wt_r, float& w_l, float& w_r,
-                         Jac* J = nullptr, float A0d = 0.f, float lx = 0.f) {
+                         Jac* J = nullptr, float lx = 0.f) {
     const FlatGround flat{};
     const Contact cl = wheel_contact(vp, vd, flat, R, s, vb, bx, vp.half_track);
     const Contact cr = wheel_contact(vp, vd, flat, R, s, vb, bx, -vp.half_track);
-    const TyreCoef a = wheel_tyre<STEER, MOTOR, IMPL>(vp, vd, ec, cl.n, cl.vc, cl.pen, hc, hs, d, inv_A0d, wt_l, w_l, A0d);
-    const TyreCoef b = wheel_tyre<STEER, MOTOR, IMPL>(vp, vd, ec, cr.n, cr.vc, cr.pen, hc, hs, d, inv_A0d, wt_r, w_r, A0d);
+    const TyreCoef a = wheel_tyre<STEER, MOTOR, IMPL>(vp, vd, ec, cl.n, cl.vc, cl.pen, hc, hs, d, inv_A0d, wt_l, w_l);
+    const TyreCoef b = wheel_tyre<STEER, MOTOR, IMPL>(vp, vd, ec, cr.n, cr.vc, cr.pen, hc, hs, d, inv_A0d, wt_r, w_r);
     if constexpr (IMPL) {
         jac_add<STEER, FIRST>(*J, a, hc, hs, lx, vd.ly);
         jac_add<STEER, false>(*J, b, hc, hs, lx, -vd.ly);
@@ -415,9 +424,12 @@ WL_DEV void body_integrate(const VehDerived& vd, const EnvConst& ec, VehState& s
 // The world velocity takes R (dv_b + h w x v_b): in free flight (J = 0) exactly the explicit update.
 WL_DEV void body_integrate_implicit(const VehDerived& vd, const EnvConst& ec, VehState& s, const Mat3& R, V3 vb, V3 Fb, V3 Tb,
                                     const Jac& J) {
+    // (every multiply-add spelled out: under -ffp-contract=fast the compiler picks which product of a sum it fuses per inlining
+    // site, and the persistent kernels must reproduce the stepping kernels bit for bit)
     const float q = ec.h_inv_mass;
     const V3 w = s.wb;
-    const V3 hrot = vd.h * cross(w, vb);
+    const V3 c = v3(fmaf(w.y, vb.z, -(w.z * vb.y)), fmaf(w.z, vb.x, -(w.x * vb.z)), fmaf(w.x, vb.y, -(w.y * vb.x)));   // w x v_b
+    const V3 hrot = vd.h * c;
     // h a_b = q Fb - h g R.r2 - h w x v_b ;  h alpha = q Tb / gyr^2 - h (gyroscopic)
     const V3 ha = v3(fmaf(q, Fb.x, fmaf(-vd.hg, R.r2.x, -hrot.x)), fmaf(q, Fb.y, fmaf(-vd.hg, R.r2.y, -hrot.y)),
                      fmaf(q, Fb.z, fmaf(-vd.hg, R.r2.z, -hrot.z)));
@@ -438,16 +450,18 @@ WL_DEV void body_integrate_implicit(const VehDerived& vd, const EnvConst& ec, Ve
     const float y2 = fmaf(-l21, b1, b2);
     const float y3 = fmaf(-l32, y2, fmaf(-l31, b1, b3));
     const float x3 = y3 * rcp(d3);
-    const float x2 = fmaf(y2, i2, -l32 * x3);
-    const float x1 = fmaf(b1, i1, fmaf(-l21, x2, -l31 * x3));
+    const float x2 = fmaf(y2, i2, -(l32 * x3));
+    const float x1 = fmaf(b1, i1, fmaf(-l21, x2, -(l31 * x3)));
     // heave / roll / pitch: diagonal
     const float nD = J.nc * vd.Dn;
-    const float dvz = ha.z * rcp(fmaf(q, nD, 1.f));
-    const float dwx = hal.x * rcp(fmaf(q * vd.inv_g2x, fmaf(vd.az2, J.yy, vd.by2 * nD), 1.f));
-    const float dwy = hal.y * rcp(fmaf(q * vd.inv_g2y, fmaf(vd.az2, J.xx, vd.bx2 * nD), 1.f));
-    const V3 dv = v3(x1 + hrot.x, x2 + hrot.y, dvz + hrot.z);
-    s.v = v3(s.v.x + dot(R.r0, dv), s.v.y + dot(R.r1, dv), s.v.z + dot(R.r2, dv));
-    s.wb = v3(w.x + dwx, w.y + dwy, fmaf(x3, vd.inv_gz, w.z));
+    const float rz = rcp(fmaf(q, nD, 1.f));
+    const float rx = rcp(fmaf(q * vd.inv_g2x, fmaf(vd.az2, J.yy, vd.by2 * nD), 1.f));
+    const float ry = rcp(fmaf(q * vd.inv_g2y, fmaf(vd.az2, J.xx, vd.bx2 * nD), 1.f));
+    // world velocity += R (dv_b + h w x v_b)
+    const V3 dv = v3(fmaf(vd.h, c.x, x1), fmaf(vd.h, c.y, x2), fmaf(ha.z, rz, hrot.z));
+    s.v = v3(fmaf(R.r0.x, dv.x, fmaf(R.r0.y, dv.y, fmaf(R.r0.z, dv.z, s.v.x))), fmaf(R.r1.x, dv.x, fmaf(R.r1.y, dv.y, fmaf(R.r1.z, dv.z, s.v.y))),
+             fmaf(R.r2.x, dv.x, fmaf(R.r2.y, dv.y, fmaf(R.r2.z, dv.z, s.v.z))));
+    s.wb = v3(fmaf(hal.x, rx, w.x), fmaf(hal.y, ry, w.y), fmaf(x3, vd.inv_gz, w.z));
     pose_integrate(vd, s);
 }
 
@@ -484,15 +498,14 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
         const bool awd = DRIVE == 1 || (DRIVE < 0 && vp.drive == 1);
         // rear axle: always driven, never steered; front axle: steered, driven only with 4WD (the undriven wheel has no
         // motor arithmetic at all)
-        const float A0d = vd.A0 + ec.damp;
         const AxleOut ar = axle_step<false, true, IMPL, true>(vp, vd, ec, R, s, vb, -vp.half_wheelbase_r, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
-                                                              ec.wheel_target[0], ec.wheel_target[1], s.wheel[0], s.wheel[1], &J, A0d, vd.lxr);
+                                                              ec.wheel_target[0], ec.wheel_target[1], s.wheel[0], s.wheel[1], &J, vd.lxr);
         if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
         AxleOut af;
         if (awd) af = axle_step<true, true, IMPL, false>(vp, vd, ec, R, s, vb, vp.half_wheelbase_f, cs, sn, ec.damp, ec.inv_A0_damp, ec.wheel_target[2],
-                                                         ec.wheel_target[3], s.wheel[2], s.wheel[3], &J, A0d, vd.lxf);
+                                                         ec.wheel_target[3], s.wheel[2], s.wheel[3], &J, vd.lxf);
         else af = axle_step<true, false, IMPL, false>(vp, vd, ec, R, s, vb, vp.half_wheelbase_f, cs, sn, 0.f, vd.inv_A0, 0.f, 0.f, s.wheel[2], s.wheel[3],
-                                                      &J, vd.A0, vd.lxf);
+                                                      &J, vd.lxf);
         if constexpr (!UNROLL) __builtin_amdgcn_sched_barrier(0);
         const V3 n = R.r2;
         const float r = vp.wheel_radius, ht = vp.half_track;
@@ -504,27 +517,26 @@ WL_DEV void vehicle_substep(const WlVehicleParams& vp, const VehDerived& vd, con
         w.Fz = ar.Fz + af.Fz;
     } else if constexpr (LANES == 1) {
         const float ht = vp.half_track, bxr = -vp.half_wheelbase_r, bxf = vp.half_wheelbase_f;
-        const float A0d = vd.A0 + ec.damp;
         wheel_step<Ground, false, true, true, 0, IMPL>(vp, vd, ec, ground, R, s, vb, bxr, ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
-                                                       ec.wheel_target[0], s.wheel[0], w, &J, A0d, vd.lxr, vd.ly);
+                                                       ec.wheel_target[0], s.wheel[0], w, &J, vd.lxr, vd.ly);
         wheel_step<Ground, false, true, false, 1, IMPL>(vp, vd, ec, ground, R, s, vb, bxr, -ht, 1.f, 0.f, ec.damp, ec.inv_A0_damp,
-                                                        ec.wheel_target[1], s.wheel[1], w, &J, A0d, vd.lxr, -vd.ly);
+                                                        ec.wheel_target[1], s.wheel[1], w, &J, vd.lxr, -vd.ly);
         if (DRIVE == 1 || (DRIVE < 0 && vp.drive == 1)) {
             wheel_step<Ground, true, true, false, 2, IMPL>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, ec.damp, ec.inv_A0_damp,
-                                                           ec.wheel_target[2], s.wheel[2], w, &J, A0d, vd.lxf, vd.ly);
+                                                           ec.wheel_target[2], s.wheel[2], w, &J, vd.lxf, vd.ly);
             wheel_step<Ground, true, true, false, 3, IMPL>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, ec.damp, ec.inv_A0_damp,
-                                                           ec.wheel_target[3], s.wheel[3], w, &J, A0d, vd.lxf, -vd.ly);
+                                                           ec.wheel_target[3], s.wheel[3], w, &J, vd.lxf, -vd.ly);
         } else {
             wheel_step<Ground, true, false, false, 2, IMPL>(vp, vd, ec, ground, R, s, vb, bxf, ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[2], w,
-                                                            &J, vd.A0, vd.lxf, vd.ly);
+                                                            &J, vd.lxf, vd.ly);
             wheel_step<Ground, true, false, false, 3, IMPL>(vp, vd, ec, ground, R, s, vb, bxf, -ht, cs, sn, 0.f, vd.inv_A0, 0.f, s.wheel[3], w,
-                                                            &J, vd.A0, vd.lxf, -vd.ly);
+                                                            &J, vd.lxf, -vd.ly);
         }
     } else {
         const bool front = wid >= 2;
         const float hc = front ? cs : 1.f, hs = front ? sn : 0.f;
         wheel_step<Ground, true, true, true, 0, IMPL>(vp, vd, ec, ground, R, s, vb, ec.bx_lane, ec.by_lane, hc, hs, ec.d_lane, ec.inv_A0d_lane,
-                                                      ec.wt_lane, s.wheel[0], w, &J, ec.A0d_lane, ec.lx_lane, ec.ly_lane);
+                                                      ec.wt_lane, s.wheel[0], w, &J, ec.lx_lane, ec.ly_lane);
         w.F = quad_sum(w.F);
         w.T = quad_sum(w.T);
         if constexpr (Ground::kFlat && !IMPL) w.Fz = quad_sum(w.Fz);
