@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievab
 BYTES_READ = (23 + 4 + 7) * 4 + 4 + 8
 BYTES_WRITE = (23 + 7) * 4 + 4 + 14 * 4 + 4 + 2
 BYTES_PER_ENV_STEP = BYTES_READ + BYTES_WRITE
+BYTES_PER_ENV_STEP_SURVEY = 270      # the per-unit figure the survey states for the fused drift step
 
 
 # algorithmic HBM bytes per unit of the other hot kernels: elevation 270 + 676 x 4
@@ -94,18 +95,20 @@ def rocprof_avg_us(kernels):
     `rocprofv3 --kernel-trace --stats` summary of bench.py itself (profiles/r*_bench_kernel_stats.csv), for the reader who
     recomputes `frac` from profiles/.  A kernel is named by the substrings its row's Name must ALL contain -- a string, or a
     tuple such as ("visual_step_kernel<", "FlatGround>") that pins the exact instantiation a section timed (the flat-ground
-    visual step, not the heightfield one of the depth task).  A tuple that still matches several rows is ambiguous: None."""
+    visual step, not the heightfield one of the depth task).  A tuple -- of any length, one element included -- that still matches
+    several rows is ambiguous: None."""
     import csv
     import glob
     names = [kernels] if isinstance(kernels, (str, tuple)) else list(kernels)
+    bare = [isinstance(k, str) for k in names]       # only a BARE string may fall back to its most-called instantiation
     names = [(k,) if isinstance(k, str) else tuple(k) for k in names]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")), reverse=True):
         try:
             rows = list(csv.DictReader(open(f)))
             tot, calls = 0.0, None
-            for subs in names:
+            for subs, is_bare in zip(names, bare):
                 hits = [r for r in rows if all(sub in r.get("Name", "") for sub in subs)]
-                if len(hits) > 1 and len(subs) == 1:      # a bare name: the most-called instantiation (the headline's 10^4 launches)
+                if len(hits) > 1 and is_bare:      # a bare name: the most-called instantiation (the headline's 10^4 launches)
                     hits = sorted(hits, key=lambda r: -int(r["Calls"]))[:1]
                 if len(hits) != 1:
                     tot = None
@@ -399,8 +402,9 @@ def write_detail(detail, path=None):
         return None
 
 
-_ROOF_KEYS = ("bound", "regime", "achieved", "peak", "unit", "frac", "traffic", "frac_profile", "frac_counters", "wasted_traffic", "valu_frac",
-              "kernel", "launch_us", "bytes_per_env_step", "envs_per_launch")
+_ROOF_KEYS = ("bound", "regime", "achieved", "peak", "unit", "frac", "traffic", "frac_launch", "frac_profile", "frac_counters", "frac_survey",
+              "wasted_traffic", "valu_frac", "kernel", "launch_us", "profile_us", "bytes_per_env_step", "bytes_per_env_step_survey",
+              "envs_per_launch", "frac_is")
 _TASK_ROOF_KEYS = ("frac", "frac_profile", "frac_counters", "wasted_traffic", "valu_frac")
 
 
@@ -576,6 +580,12 @@ def main():
         dist.all_reduce(ones)
         rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks_seen": int(ones.item()),
                 "allreduce_every": every}
+        if rccl["ranks_seen"] != world or rccl["world"] != world:
+            # a collective that does not span the job would make `value` a lie: fail the run instead of printing a line
+            print(f"[bench] rank {rank}: the all-reduce saw {rccl['ranks_seen']} ranks in a world of {rccl['world']}, launched as {world}",
+                  file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            sys.exit(3)
     run(args.warmup)
     # EXACTLY --steps steps per timed block, bracketed by barrier + synchronize, max over ranks -- and REPEATS such blocks:
     # at the driver's K = 20 one block is 0.15 ms, a single sample of which is launch-queue noise (round 1 reported
@@ -644,7 +654,12 @@ def main():
                      "metric_allreduce_us": {"median_max_over_ranks": float(lt.item()), "min_this_rank": lat[0], "max_this_rank": lat[-1],
                                              "bytes": int(m.numel() * m.element_size()), "samples": len(lat),
                                              "timing": "HIP events around one blocking all_reduce of the [16] metric vector on an idle stream"}})
-    achieved = BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
+    # The line's own fraction follows from the line's own clock: algorithmic bytes of one launch / ms_per_step (the wall time per
+    # step of the timed blocks, barrier + synchronise bracket included) / peak.  The same bytes over the kernel's duration between
+    # two events on the launch stream are `frac_launch`; over its average in the committed rocprofv3 summary `frac_profile`.
+    step_us = wall * 1e6 / args.steps
+    achieved = BYTES_PER_ENV_STEP * n / (step_us * 1e-6) / 1e9
+    achieved_launch = BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
     traffic, traffic_src, traffic_stale = pmc_traffic(n)
     sq = pmc_sq(n)
     # which roofline binds: at the BASELINE size the state is L2 / Infinity-Cache resident and one wavefront per SIMD
@@ -997,10 +1012,17 @@ def main():
             # launch at this size
             "roofline": {"bound": "hbm", "regime": regime, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
+                         "frac_is": "bytes_per_env_step x envs_per_launch / ms_per_step / peak",
+                         "frac_launch": achieved_launch / HBM_PEAK_GBS,
+                         # SURVEY.md 8(d)'s own per-unit figure (270 B: it leaves out the episode-sum rows and the flag bytes the
+                         # kernel also moves) beside the 334 B this file counts row by row
+                         "bytes_per_env_step_survey": BYTES_PER_ENV_STEP_SURVEY,
+                         "frac_survey": BYTES_PER_ENV_STEP_SURVEY * n / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "profile_us": prof["avg_us"] if prof else None,
                          "valu_frac": sq.get("valu_pipe_frac") if sq else None, "sq_counters": sq,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "kernel": "drift_step_kernel<FlatGround>", "launch_us": launch_us,
-                         "frac_uses": "launch_us (HIP events on the launch stream, live in this run)",
+                         "frac_uses": "ms_per_step (wall clock of the timed blocks); frac_launch: launch_us (HIP events on the launch stream)",
                          "rocprof_kernel_stats": prof, "frac_profile": frac_profile, "frac_counters": frac_counters,
                          "wasted_traffic": traffic / (BYTES_PER_ENV_STEP * n) if traffic else None,
                          "bytes_per_env_step": BYTES_PER_ENV_STEP, "envs_per_launch": n},

@@ -478,14 +478,15 @@ int wl_drift_observe(const WlDriftParams* p, const WlEnvBuffers* b, const float*
 /* terrain: regular-grid heightfield, height[iy][ix] row-major, world x = x0 + ix*cell. Replaces the terrain mesh
  * `Terrains/huge_compact.usd` (:95-108) for BOTH wheel contact and the ray-caster (:132-142). Outside the grid the
  * ground is the extra plane at z = outside_z (:120-128) and height-scan rays miss.
- * ABI 21: the grid holds 16-bit height CODES, z = code * z_scale (one fp32 multiply per grid point, the same on every path) --
+ * ABI 21: the grid holds 16-bit height CODES, z = code * z_scale (one fp32 multiply per grid point on the contact and depth paths;
+ * the height scan blends four codes and scales once: the same value for a power-of-two scale, else within 2e-5 m of it) --
  * IsaacLab's own height-field terrains are int16 x vertical_scale (isaaclab.terrains.height_field).  Half the bytes of the fp32
  * grid of ABI <= 20: the 800 x 800 bench terrain is 1.28 MB instead of 2.56 MB per XCD's L2. */
 typedef struct WlHeightField {
     const int16_t* height;
     int32_t nx, ny;
     float x0, y0, cell, outside_z;
-    float z_scale;            /* metres per code, > 0 (terrain.py default 2^-13 m = 0.122 mm: +-4 m of range)     */
+    float z_scale;            /* metres per code, > 0 and finite (terrain.py default 2^-13 m = 0.122 mm: +-4 m)  */
 } WlHeightField;
 
 enum WlElevRewTerm { WL_ER_GOAL_PROGRESS = 0, WL_ER_HIGHER_ELEVATION, WL_ER_FALLING, WL_ER_STUCK_PENALTY, WL_ER_NTERMS };

@@ -43,9 +43,17 @@ def test_the_drivers_own_command_prints_one_short_line_with_roofline_and_cpu_bas
               "kernel", "launch_us", "bytes_per_env_step"):
         assert k in r, k
     assert r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["bound"] == "hbm" and r["regime"] == "latency"
-    # the line's own figures agree with each other: bytes per launch / launch time = achieved; the kernel fits in the step
-    assert abs(r["achieved"] - r["bytes_per_env_step"] * 4096 / (r["launch_us"] * 1e-6) / 1e9) < 2e-3 * r["achieved"]
-    assert r["launch_us"] * 1e-3 <= line["ms_per_step"] * 1.05
+    # every fraction on the line follows from numbers on the line: `frac` from the line's own clock (bytes per launch / ms_per_step /
+    # peak), `frac_launch` from the event-timed launch, `frac_survey` from SURVEY 8(d)'s 270 B, `frac_profile` from `profile_us`
+    # (= one row of the committed kernel summary); the kernel fits in the step
+    per_step = r["bytes_per_env_step"] * r["envs_per_launch"] / (line["ms_per_step"] * 1e-3) / 1e9
+    assert abs(r["achieved"] - per_step) < 1e-6 * per_step and abs(r["frac"] - per_step / 8000.0) < 1e-9
+    assert abs(r["frac_launch"] - r["bytes_per_env_step"] * 4096 / (r["launch_us"] * 1e-6) / 1e9 / 8000.0) < 2e-3 * r["frac_launch"]
+    assert r["bytes_per_env_step"] == 334 and r["bytes_per_env_step_survey"] == 270
+    assert abs(r["frac_survey"] - r["frac"] * 270 / 334) < 2e-3 * r["frac"]
+    if r["frac_profile"] is not None:
+        assert abs(r["frac_profile"] - 334 * 4096 / (r["profile_us"] * 1e-6) / 1e9 / 8000.0) < 2e-3 * r["frac_profile"]
+    assert r["launch_us"] * 1e-3 <= line["ms_per_step"] * 1.05 and r["frac"] <= r["frac_launch"] * 1.05
     assert abs(line["value"] - 4096 * 20 / (line["ms_per_step"] * 20e-3)) < 1e-6 * line["value"]
     c = line["cpu_baseline"]
     assert c["value"] > 0 and c["unit"] == "env-steps/s" and c["kind"] == "port" and c["cores"] >= 1 and len(c["sample"]) <= 80
@@ -98,3 +106,17 @@ def test_two_ranks_reduce_their_metrics_every_step(tmp_path):
     for k in ("persistent_rollout", "policy_rollout", "training_iteration"):
         assert line.get(k) is None                    # secondary sections are skipped when world > 1
     assert not line.get("other_tasks")
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_share_the_gpu_through_the_drivers_launcher(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 ...` -- the command of the driver's 8-GPU lease, which no
+    box of this pool has run -- with eight gloo ranks on the one GPU: rank 0 alone prints the one JSON line, the attested world is 8,
+    the job is SURVEY 8(d) config 4's 32 768 envs.  (The rate itself says nothing here: eight ranks time-share one device.)"""
+    line = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                 "--master-port", "29548", "bench.py", "--gpus", "8", *ARGS], env={"WL_BENCH_BACKEND": "gloo"}, detail=tmp_path / "w8.json")
+    assert line["n_gpus"] == 8 and line["config"]["total_envs"] == 32768 and line["config"]["envs_per_gpu"] == 4096
+    assert line["rccl"]["world"] == 8 and line["rccl"]["ranks_seen"] == 8 and line["scaling"] == "weak"
+    assert abs(line["value"] - 32768 * 20 / (line["ms_per_step"] * 20e-3)) < 1e-6 * line["value"]
+    assert line["roofline"]["envs_per_launch"] == 4096          # the roofline stays per GPU: one rank's launch
+    assert line["episode_metrics"]["resets"] > 0

@@ -125,7 +125,23 @@ def test_invalid_arguments_are_refused(hf):
     assert lib.wl_visual_depth(*args(hf=bad_hf)) == -1
     assert lib.wl_heightfield_pyramid_floats(1, 5) == 0 and lib.wl_heightfield_pyramid_floats(800, 800) == 1024 * 1024 // 2 + 800 * 800 // 2 + 4
     assert lib.wl_heightfield_build_pyramid(C.byref(bad_hf), cam.pyramid.data_ptr(), None) == -1
+    for zs in (float("inf"), float("nan"), 0.0):      # a vertical scale that is not a positive finite number is refused at the ABI
+        inf_hf = A.WlHeightField(cam._hf.height, 800, 800, -20.0, -20.0, 0.05, 0.0, zs)
+        assert lib.wl_visual_depth(*args(hf=inf_hf)) == -1
+        assert lib.wl_heightfield_build_pyramid(C.byref(inf_hf), cam.pyramid.data_ptr(), None) == -1
     torch.cuda.synchronize()
+
+
+def test_the_scene_camera_cache_tells_vertical_scales_apart():
+    """the same int16 codes tensor handed over with another z_scale is another terrain -- the cached DepthCamera
+    (its pyramid is built from decoded heights) must not be reused"""
+    from wheeledlab_amd.core import VisualBatch, _cached_depth_camera
+    codes = torch.randint(-200, 200, (128, 128), dtype=torch.int16, device=DEV)
+    env = VisualBatch(64, device=DEV, seed=1, trav_map=np.ones((500, 500), bool))
+    a = _cached_depth_camera(env, (codes, -3.2, -3.2, 0.05, 2.0 ** -13))
+    assert _cached_depth_camera(env, (codes, -3.2, -3.2, 0.05, 2.0 ** -13)) is a
+    b = _cached_depth_camera(env, (codes, -3.2, -3.2, 0.05, 2.0 ** -11))
+    assert b is not a and b._hf.z_scale == 2.0 ** -11 and float((b.height - 4 * a.height).abs().max()) == 0.0
 
 
 def test_rough_terrain(hf):

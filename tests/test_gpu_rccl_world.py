@@ -97,3 +97,10 @@ def test_the_same_worker_over_gloo_with_two_ranks_sharing_one_gpu():
     """the one-GPU box's stand-in: the identical worker (shards by env_offset, metric all-reduce, gather, comparison with the big
     batch) with the gloo backend, so that the test above is known to be right before the first multi-GPU lease runs it"""
     mp.start_processes(_worker, args=(2, _free_port(), "gloo"), nprocs=2, join=True, start_method="spawn")
+
+
+@pytest.mark.timeout(900)
+def test_eight_gloo_ranks_sharing_one_gpu():
+    """world = 8 (8 x 4096 envs), the size of the driver's multi-GPU lease: shard k of eight == slice k of ONE
+    32 768-env batch bit for bit, the all-reduced metric vector == the big batch's"""
+    mp.start_processes(_worker, args=(8, _free_port(), "gloo"), nprocs=8, join=True, start_method="spawn")

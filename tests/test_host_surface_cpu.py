@@ -223,3 +223,37 @@ def test_device_heightfield_forms_and_quantisation():
         DeviceHeightField((bad, 0.0, 0.0, 0.1), "cpu")
     with pytest.raises(ValueError):
         T.quantize_heights(bad)
+
+
+def test_device_heightfield_refuses_scales_that_cannot_hold_the_heights_and_shares_across_device_spellings():
+    """an explicit z_scale too small for the height range used to clip the codes silently (heights up to 4 m at
+    z_scale 1e-4 were flattened at 3.28 m); a non-finite scale passed the `> 0` check; two spellings of one device failed a bare
+    assert; the depth-camera cache ignored the vertical scale of a (codes, ..., z_scale) tuple."""
+    import torch
+
+    from wheeledlab_amd import terrain
+    from wheeledlab_amd.core import DeviceHeightField, _cached_depth_camera, _canonical_device
+    h = np.linspace(0.0, 4.0, 64 * 64, dtype=np.float32).reshape(64, 64)
+    with pytest.raises(ValueError, match="do not fit"):
+        DeviceHeightField((h, 0.0, 0.0, 0.1, 1e-4), "cpu")
+    with pytest.raises(ValueError, match="do not fit"):
+        terrain.quantize_heights(h, 1e-4)
+    assert DeviceHeightField((h, 0.0, 0.0, 0.1, 2e-4), "cpu").heights.max() == pytest.approx(4.0, abs=2e-4)     # 6.55 m of range: fits
+    for bad in (float("inf"), float("nan"), 0.0, -1.0):
+        with pytest.raises(ValueError):
+            DeviceHeightField((h, 0.0, 0.0, 0.1, bad), "cpu")
+        with pytest.raises(ValueError):
+            terrain.quantize_heights(h, bad)
+        with pytest.raises(ValueError):
+            DeviceHeightField((np.zeros((4, 4), np.int16), 0.0, 0.0, 0.1, bad), "cpu")
+    assert _canonical_device("cpu") == torch.device("cpu")
+    assert _canonical_device("cuda").index is not None and _canonical_device("cuda:0") == torch.device("cuda", 0)
+    a = DeviceHeightField((h, 0.0, 0.0, 0.1), "cpu")
+    assert DeviceHeightField(a, torch.device("cpu")).codes is a.codes
+    a.device = torch.device("cuda", 1)                                                   # (a field that lives elsewhere)
+    with pytest.raises(ValueError, match="cannot be shared"):
+        DeviceHeightField(a, "cpu")
+    # the cache key of the scene's depth camera: the same codes under another vertical scale are another field
+    import inspect
+    src = inspect.getsource(_cached_depth_camera)
+    assert "zs)" in src and "heightfield.z_scale" in src and "heightfield[4]" in src

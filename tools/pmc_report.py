@@ -1,6 +1,6 @@
 """Digest of tools/profile_pmc.sh -> <out>/<tag>_pmc.json: per (task, env count) and kernel the HBM bytes per launch (FETCH_SIZE /
-WRITE_SIZE passes, factors calibrated on known bytes in the same pass where tools/microbench/layout_bw is present, else the
-guide's: FETCH x2, WRITE x1), the kernel's duration under the counters, and the SQ view (VALU instructions per wavefront, wait /
+WRITE_SIZE passes, factors calibrated on the known bytes of tools/microbench/pmc_calib.hip in the same pass -- `factors_from` says
+whether that happened -- else the guide's: FETCH x2, WRITE x1), the kernel's duration under the counters, and the SQ view (VALU instructions per wavefront, wait /
 issue-stall / active shares, VALU-pipe occupancy).  Stamped with the fingerprint of csrc/ + the header so that bench.py can
 tell whether the counters belong to the library it loaded.    usage: pmc_report.py <gpurun_out/tag> <tag>"""
 import csv, glob, json, os, re, shutil, sys
@@ -48,35 +48,33 @@ def counters(d, kernel):
 
 
 def calibration():
+    """FETCH_SIZE / WRITE_SIZE (KiB) against the known bytes of tools/microbench/pmc_calib.hip's two kernels, each counter in its own
+    pass: fetch_factor = known read bytes / (FETCH_SIZE x 1024), write_factor likewise.  The guide's figures are x2 and x1 (gfx950
+    counts 64-byte fetch units in a counter documented in 32-byte units); round 2 measured 1.9999 / 1.000."""
     cal = {}
     if not os.path.isdir(f"{O}/calib_FETCH"):
         return cal
-    for name, sub, rd, wr in (("soa_dword_4M", "stream_kernel", 34 * 4 * 4194304, 30 * 4 * 4194304),
-                              ("float4_copy", "copy4_kernel", 20 * 4 * 4194304, 20 * 4 * 4194304)):
-        def big(d, key):
-            vals = [float(r["Counter_Value"]) for r in rows(d) if base_name(r["Kernel_Name"]) == sub and r["Counter_Name"] == key
-                    and ("<34, 30, false>" in r["Kernel_Name"] or sub != "stream_kernel")]
-            if not vals:
-                return None
-            m = max(vals)
-            sel = [v for v in vals if v > 0.6 * m]
-            return sum(sel) / len(sel)
-        fk, wk = big("calib_FETCH", "FETCH_SIZE"), big("calib_WRITE", "WRITE_SIZE")
-        if fk and wk:
-            cal[name] = {"known_read_bytes": rd, "known_write_bytes": wr, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
-                         "fetch_factor": rd / (fk * 1024), "write_factor": wr / (wk * 1024)}
+    for name, kernel, rd, wr in (("soa_dword_4M", "calib_soa_dword_kernel", 34 * 4 * 4194304, 30 * 4 * 4194304),
+                                 ("float4_copy_1GiB", "calib_copy4_kernel", 1 << 30, 1 << 30)):
+        f, _, nf = counters("calib_FETCH", kernel)
+        w, _, nw = counters("calib_WRITE", kernel)
+        if f.get("FETCH_SIZE") and w.get("WRITE_SIZE"):
+            cal[name] = {"known_read_bytes": rd, "known_write_bytes": wr, "FETCH_SIZE_KiB": f["FETCH_SIZE"], "WRITE_SIZE_KiB": w["WRITE_SIZE"],
+                         "dispatches": min(nf, nw), "fetch_factor": rd / (f["FETCH_SIZE"] * 1024), "write_factor": wr / (w["WRITE_SIZE"] * 1024)}
     return cal
 
 
 cal = calibration()
+# the factors applied below: the measured ones of the drift step's own access shape when this pass calibrated, else the guide's
 ff = cal.get("soa_dword_4M", {}).get("fetch_factor", 2.0)
 wf = cal.get("soa_dword_4M", {}).get("write_factor", 1.0)
+factors_from = "calibration.soa_dword_4M (measured in this pass)" if "soa_dword_4M" in cal else "MI355X_MICROARCH.md (x2 / x1): no calibration in this pass"
 out = {"_doc": "rocprofv3 --pmc digests per (task:envs) and kernel, per launch.  traffic = FETCH_SIZE KiB x 1024 x fetch_factor + "
                "WRITE_SIZE KiB x 1024 x write_factor (separate passes).  SQ_* time counters are quad-cycles per wavefront summed "
                "over wavefronts; valu_pipe_frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x shader cycles of the launch, "
                "GRBM_GUI_ACTIVE / 8 XCDs): a lower bound (transcendentals take 4+).  duration_ns is the kernel's mean duration "
                "with counters attached (slower than untraced).  Workload: tools/pmc_run.py.",
-       "csrc_fingerprints": {t: csrc_fingerprint(t) for t in KERNELS}, "calibration": cal, "fetch_factor_used": ff, "write_factor_used": wf, "entries": {}}
+       "csrc_fingerprints": {t: csrc_fingerprint(t) for t in KERNELS}, "calibration": cal, "fetch_factor_used": ff, "write_factor_used": wf, "factors_from": factors_from, "entries": {}}
 tags = sorted({os.path.basename(p)[len("FETCH_"):] for p in glob.glob(f"{O}/FETCH_*") if os.path.isdir(p)})
 for tag in tags:
     task, n = tag.rsplit("_", 1)

@@ -21,9 +21,10 @@ for w in $WORK; do
   pm sqa_${task}_$n "$SQA" python $R/tools/pmc_run.py $task $n $k
   pm sqb_${task}_$n "$SQB" python $R/tools/pmc_run.py $task $n $k
 done
-if [ -x $R/tools/microbench/layout_bw ]; then
-  pm calib_FETCH FETCH_SIZE $R/tools/microbench/layout_bw
-  pm calib_WRITE WRITE_SIZE $R/tools/microbench/layout_bw
+# calibration of the two traffic counters on known bytes (built here: the binary is not in the tree)
+if timeout 120 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/microbench/pmc_calib.hip -o $O/pmc_calib > $O/pmc_calib_build.log 2>&1; then
+  pm calib_FETCH FETCH_SIZE $O/pmc_calib
+  pm calib_WRITE WRITE_SIZE $O/pmc_calib
 fi
 if [ -z "$WL_PMC_NO_STATS" ]; then
   # the SAME command the driver runs (sweep children and CPU baseline included: their kernels land in their own process's summary)

@@ -46,6 +46,14 @@ def apply_startup_events(lib, bufs: "A.WlEnvBuffers", su, seed: int, stream, ran
     A.check(lib.wl_startup_randomize(C.byref(sp), C.byref(bufs), int(seed), stream), "wl_startup_randomize")
 
 
+def _canonical_device(device) -> torch.device:
+    """torch.device with its index filled in: 'cuda' and 'cuda:0' name the same GPU but compare unequal"""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return d
+
+
 class DeviceHeightField:
     """A heightfield resident on the device as the kernels read it (WlHeightField, ABI 21): 16-bit height codes [ny, nx] and the
     vertical scale, z = code * z_scale.  `heightfield` is `(height, x0, y0, cell)` with float heights (quantised: terrain.
@@ -55,10 +63,11 @@ class DeviceHeightField:
 
     def __init__(self, heightfield, device, outside_z: float = 0.0):
         from .terrain import default_z_scale
-        self.device = torch.device(device)
+        self.device = _canonical_device(device)
         if isinstance(heightfield, DeviceHeightField):
             src = heightfield
-            assert src.device == self.device
+            if src.device != self.device:
+                raise ValueError(f"a DeviceHeightField lives on {src.device}; it cannot be shared with {self.device}")
             self.codes, self.z_scale, self.heights = src.codes, src.z_scale, src.heights
             self.x0, self.y0, self.cell = src.x0, src.y0, src.cell
         else:
@@ -72,10 +81,16 @@ class DeviceHeightField:
                 h = h.to(self.device, torch.float64)
                 if not bool(torch.isfinite(h).all()):
                     raise ValueError("heightfield with non-finite heights")
-                self.z_scale = float(rest[0]) if rest else default_z_scale(float(h.abs().max()) if h.numel() else 0.0)
-                self.codes = torch.clamp(torch.round(h / self.z_scale), -32767, 32767).to(torch.int16).contiguous()
-            if not self.z_scale > 0 or self.codes.dim() != 2:
-                raise ValueError("heightfield: a [ny, nx] grid and a positive z_scale")
+                hmax = float(h.abs().max()) if h.numel() else 0.0
+                self.z_scale = float(rest[0]) if rest else default_z_scale(hmax)
+                if rest and math.isfinite(self.z_scale) and self.z_scale > 0 and hmax > 32767 * self.z_scale:
+                    # (the default scale widens itself; an explicit one that cannot hold the heights would flatten them silently)
+                    raise ValueError(f"heights up to {hmax:g} m do not fit 16-bit codes of z_scale {self.z_scale:g} m "
+                                     f"(+-{32767 * self.z_scale:g} m): pass a larger z_scale or none")
+                self.codes = torch.clamp(torch.round(h / self.z_scale), -32767, 32767).to(torch.int16).contiguous() if (
+                    math.isfinite(self.z_scale) and self.z_scale > 0) else torch.zeros((0,), dtype=torch.int16)
+            if not (math.isfinite(self.z_scale) and self.z_scale > 0) or self.codes.dim() != 2:
+                raise ValueError("heightfield: a [ny, nx] grid and a positive, finite z_scale")
             self.heights = self.codes.to(torch.float32) * torch.tensor(self.z_scale, dtype=torch.float32, device=self.device)
             self.x0, self.y0, self.cell = float(x0), float(y0), float(cell)
         self.outside_z = float(outside_z)
@@ -654,10 +669,11 @@ def _cached_depth_camera(batch, heightfield) -> DepthCamera:
     array object, its placement (x0, y0, cell), its shape or -- for tensors -- its in-place version counter changes"""
     cache = batch.__dict__.setdefault("_depth_cameras", {})
     if isinstance(heightfield, DeviceHeightField):
-        h, x0, y0, cell = heightfield.codes, heightfield.x0, heightfield.y0, heightfield.cell
+        h, x0, y0, cell, zs = heightfield.codes, heightfield.x0, heightfield.y0, heightfield.cell, heightfield.z_scale
     else:
         h, x0, y0, cell = heightfield[:4]
-    key = (id(h), float(x0), float(y0), float(cell), tuple(h.shape), getattr(h, "_version", None))
+        zs = float(heightfield[4]) if len(heightfield) > 4 else None       # the same codes under another vertical scale: another field
+    key = (id(h), float(x0), float(y0), float(cell), tuple(h.shape), getattr(h, "_version", None), zs)
     cam = cache.get(key)
     if cam is None or cam._src is not h:
         for k in [k for k in cache if k[0] == id(h)]:      # an older snapshot of the same array

@@ -244,7 +244,7 @@ int64_t wl_heightfield_pyramid_floats(int32_t nx, int32_t ny) {
 }
 
 int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* stream) {
-    if (!hf || !hf->height || !pyramid || hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f)) return WL_EINVAL;
+    if (!hf || !hf->height || !pyramid || hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f && hf->z_scale < INFINITY)) return WL_EINVAL;
     const Pyramid py = make_pyramid(hf->nx, hf->ny);
     clear_error();
     const hipStream_t hs = (hipStream_t)stream;
@@ -264,7 +264,7 @@ int wl_heightfield_build_pyramid(const WlHeightField* hf, float* pyramid, void* 
 static int depth_rows_args_ok(const WlVisualParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* pyramid, float max_depth,
                               const float* rows, int64_t row_stride) {
     if (!p || !b || !hf || !b->state || !hf->height || !pyramid || !rows || b->n_envs <= 0 || !(max_depth > 0.f)) return 0;
-    if (hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f) || b->stride < b->n_envs || !(p->fx > 0.f) ||
+    if (hf->nx < 2 || hf->ny < 2 || hf->nx > 16385 || hf->ny > 16385 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f && hf->z_scale < INFINITY) || b->stride < b->n_envs || !(p->fx > 0.f) ||
         !(p->fy > 0.f) || row_stride < WL_VISDEPTH_NPIX)
         return 0;
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (int64_t)b->n_envs * kTiles > 0x7fffffffLL) return 0;

@@ -932,10 +932,16 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     }
     // ---- the scan ----
     const WlElevParams& p = p_arg;
-    // flat index over (env, quad of rays): 16 x 169 quads / 512 lanes = 5.3 per lane, in three batches of two (16 gathers in flight)
-    // (rounds 2 - 3, single rays: 1 / 2 / 3 batches of gathers 28.4 / 26.2 / 25.9 us per step at 4096 envs -- one batch needs 256 VGPRs)
+    // flat index over (env, quad of rays): 16 x 169 quads / 512 lanes = 5.3 per lane, ONE quad (8 gathers) per batch: request,
+    // blend, store, next.  (Rounds 2 - 3, single rays: 1 / 2 / 3 batches of gathers 28.4 / 26.2 / 25.9 us per step at 4096 envs.
+    // Round 6, after the physics went to 10 sub-steps, same box: 1 / 2 / 3 / 6 batches 21.4 / 21.3 / 21.3 / 20.2 us -- the phase is
+    // bound by the rate at which the CU's texture path takes scattered lines and by its stores, not by round trips: the sooner the
+    // first rows are written the better.)
     constexpr int kAll = kFusedEnvs * kScanQuads;
-    constexpr int kScanBatches = 3;
+#ifndef WL_FUSED_SCAN_BATCHES
+#define WL_FUSED_SCAN_BATCHES 6
+#endif
+    constexpr int kScanBatches = WL_FUSED_SCAN_BATCHES;
     constexpr int kSlots = (kAll + kFusedThreads - 1) / kFusedThreads, kBatch = (kSlots + kScanBatches - 1) / kScanBatches;
     const int n_here = min(kFusedEnvs, b.n_envs - e0);
     const ScanField sf = scan_field(ground.f);
@@ -1383,7 +1389,7 @@ int check_elev(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField
     if (!flags_ok(b)) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f)) return WL_EINVAL;
     if (p->vehicle.implicit != 1) return WL_EINVAL;   // these kernels step the linearly implicit integrator (wl_vehicle.h)
-    if (hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f)) return WL_EINVAL;
+    if (hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f && hf->z_scale < INFINITY)) return WL_EINVAL;
     return WL_OK;
 }
 

@@ -11,8 +11,11 @@ namespace {
 // Round 5: the grid holds 16-bit height CODES (z = code * z_scale, WlHeightField): two horizontally adjacent grid points are ONE
 // 4-byte gather (the address is only 2-byte aligned: gfx950 takes unaligned dword loads from global memory, buffers and LDS --
 // the compiler emits global_load_dword / ds_read_b32 for them), a cell's four corners two of them; decoding is one conversion
-// (SDWA: sign-extended half -> float) and one multiply per corner, the same on every path, so that all samplers of a field see
-// exactly the floats the oracle's decoded grid holds.
+// (SDWA: sign-extended half -> float) and one multiply per corner, the same on every CONTACT and DEPTH path, so that those samplers
+// of a field see exactly the floats the oracle's decoded grid holds.  The one exception is the height SCAN (wl_elev.hip::scan_value,
+// shared by all four scan forms): it blends the four corner codes and scales once -- identical when z_scale is a power of two
+// (terrain.py's default 2^-13; scaling by 2^k commutes with every rounding), different in the last bit otherwise (IsaacLab's
+// vertical_scale 0.005): the scan's parity bound is 2e-5 m (tests/test_gpu_elev_parity.py), not bit equality with the decoded grid.
 typedef uint32_t wl_u32_u2 __attribute__((aligned(2)));
 // a dword of two adjacent codes (low half = the first) -> their heights.  The multiply is kept a multiply (contract off): under
 // -ffp-contract=fast the compiler would otherwise fuse it into whichever add consumes the height at each inlining site, and two

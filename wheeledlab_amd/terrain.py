@@ -25,9 +25,12 @@ def quantize_heights(height, z_scale: float | None = None):
     h = np.asarray(height, dtype=np.float64)
     if not np.isfinite(h).all():
         raise ValueError("heightfield with non-finite heights")
-    zs = float(default_z_scale(float(np.abs(h).max(initial=0.0))) if z_scale is None else z_scale)
-    if not zs > 0:
-        raise ValueError("z_scale must be positive")
+    hmax = float(np.abs(h).max(initial=0.0))
+    zs = float(default_z_scale(hmax) if z_scale is None else z_scale)
+    if not (np.isfinite(zs) and zs > 0):
+        raise ValueError("z_scale must be positive and finite")
+    if hmax > 32767 * zs:
+        raise ValueError(f"heights up to {hmax:g} m do not fit 16-bit codes of z_scale {zs:g} m (+-{32767 * zs:g} m)")
     return np.clip(np.rint(h / zs), -32767, 32767).astype(np.int16), zs
 
 
