@@ -36,11 +36,18 @@ def elev_params():
     )
 
 
-def ground_fn(hf):
+def ground_fn(hf, probe=None):
+    """probe (see vehicle.substep): `cell_margin` -- per env the smallest distance, in cells, of a wheel's sample point from a
+    cell line of the grid (where the bilinear surface's normal jumps), minimised over every call"""
     h, x0, y0, cell = hf
 
     def g(xy):
         z, n, _ = H.sample(h, x0, y0, cell, xy[:, 0], xy[:, 1], outside=0.0)
+        if probe is not None:
+            u = (f32(xy[:, 0]) - F(x0)) / F(cell)
+            v = (f32(xy[:, 1]) - F(y0)) / F(cell)
+            d = np.minimum(np.abs(u - np.rint(u)), np.abs(v - np.rint(v)))
+            probe["cell_margin"] = np.minimum(probe.get("cell_margin", np.inf), d)
         return z, n
     return g
 
@@ -120,7 +127,7 @@ def observe(p, state, hf):
                            np.clip(state[ACT0:ACT0 + 2].T, F(-1), F(1)), height_map(p, state, hf)], -1).astype(F)
 
 
-def step(p, state, episode_len, hf, actions, seed, step_count, metrics=None, env_offset=0):
+def step(p, state, episode_len, hf, actions, seed, step_count, metrics=None, env_offset=0, probe=None):
     n = state.shape[1]
     vp = p.vehicle
     a_raw = M.clip_action(actions) if p.action.clip_wrapper else f32(actions)
@@ -137,10 +144,10 @@ def step(p, state, episode_len, hf, actions, seed, step_count, metrics=None, env
     wheel = state[WHEEL:WHEEL + 4].T.copy()
     th, om = state[STEER_POS].copy(), state[STEER_VEL].copy()
     h = F(p.sim_dt) / F(vp.substeps)
-    g = ground_fn(hf)
+    g = ground_fn(hf, probe)
     for _ in range(p.decimation * vp.substeps):
         x, q, v, wb, wheel, th, om = V.substep(x, q, v, wb, wheel, th, om, steer_t, wheel_t.astype(F), state[MASS],
-                                               state[MU_S], state[MU_D], state[DAMP], vp, h, g)
+                                               state[MU_S], state[MU_D], state[DAMP], vp, h, g, probe)
     R = matrix_from_quat(q)
     ww = np.einsum("nij,nj->ni", R, wb).astype(F)
     pos = (x - R @ cvec).astype(F)

@@ -102,8 +102,12 @@ def implicit_body_update(v, wb, R, Fw, Tb, Ib, mass, S, vp, h):
     return v, wb
 
 
-def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w, mu_d_w, damp, vp, h, ground=flat_ground):
-    """one integrator sub-step of length h.  Arrays are [N,...] float32.  Returns the new state tuple."""
+def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w, mu_d_w, damp, vp, h, ground=flat_ground, probe=None):
+    """one integrator sub-step of length h.  Arrays are [N,...] float32.  Returns the new state tuple.
+    probe: a dict the parity tests pass to learn which envs sit on one of the model's discontinuities during this sub-step (the
+    causes a HIP-vs-oracle difference beyond rounding can have): per env, `contact` -- the in-contact pattern of the four wheels as
+    a bit mask, appended per sub-step -- and `fz_margin` -- the smallest distance of a wheel from making or breaking contact, in
+    newtons of normal force (|k pen - c v_n| in contact, k |pen| above the ground), minimised over the sub-steps"""
     h = F(h)
     r = F(vp.wheel_radius)
     th, om = steer_update(th, om, steer_target, vp, h)
@@ -132,6 +136,10 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
         vcp = v + np.cross(ww, arm)
         vn = (vcp * nrm).sum(-1)
         Fz = np.where(pen > 0, np.maximum(F(vp.susp_k) * pen - F(vp.susp_c) * vn, F(0)), F(0)).astype(F)
+        if probe is not None:
+            m_i = np.where(pen > 0, np.abs(F(vp.susp_k) * pen - F(vp.susp_c) * vn), F(vp.susp_k) * np.abs(pen))
+            probe["_margin"] = np.minimum(probe.get("_margin", np.inf), m_i)
+            probe["_mask"] = probe.get("_mask", 0) + (Fz > 0).astype(np.int32) * (1 << i)
         if front:
             hb = np.stack([cs, sn, np.zeros_like(cs)], -1)
         else:
@@ -228,4 +236,7 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
         ww[:, 0] * qy - ww[:, 1] * qx + ww[:, 2] * qw], -1)
     q = q + hh * dq
     q = (q / np.sqrt((q * q).sum(-1, keepdims=True))).astype(F)
+    if probe is not None:
+        probe.setdefault("contact", []).append(probe.pop("_mask"))
+        probe["fz_margin"] = np.minimum(probe.get("fz_margin", np.inf), probe.pop("_margin"))
     return x, q, v, wb, new_wheel.astype(F), th, om

@@ -136,7 +136,7 @@ def observe_depth(p, state, hf, max_depth):
     return np.concatenate([img, v_b, w_b, np.clip(state[ACT0:ACT0 + 2].T, F(-1), F(1))], -1).astype(F)
 
 
-def step(p, state, episode_len, trav, cells, actions, seed, step_count, metrics=None, env_offset=0, hf=None, max_depth=None):
+def step(p, state, episode_len, trav, cells, actions, seed, step_count, metrics=None, env_offset=0, hf=None, max_depth=None, probe=None):
     """hf / max_depth: the visual-depth extension task -- the same step on the heightfield terrain `hf` (wheel contacts through
     heightfield.sample, reset onto the terrain), observation = observe_depth"""
     n = state.shape[1]
@@ -157,10 +157,10 @@ def step(p, state, episode_len, trav, cells, actions, seed, step_count, metrics=
     ground = V.flat_ground
     if hf is not None:
         from .elev_step import ground_fn
-        ground = ground_fn(hf)
+        ground = ground_fn(hf, probe)
     for _ in range(p.decimation * vp.substeps):
         x, q, v, wb, wheel, th, om = V.substep(x, q, v, wb, wheel, th, om, steer2[:, 0], wheel_t.astype(F), state[MASS],
-                                               state[MU_S], state[MU_D], state[DAMP], vp, h, ground)
+                                               state[MU_S], state[MU_D], state[DAMP], vp, h, ground, probe)
     R = matrix_from_quat(q)
     ww = np.einsum("nij,nj->ni", R, wb).astype(F)
     pos = (x - R @ cvec).astype(F)

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from tests import parity_predicates as PRED
 from oracle import elev_step as OS
 from oracle import heightfield as OH
 
@@ -102,7 +103,7 @@ def test_elev_fused_step_matches_oracle_single_steps(lanes, z_scale):
     env.set_lanes(lanes)
     p = OS.elev_params()
     rng = np.random.RandomState(0)
-    flips = 0
+    flips = excused = reach = 0
     for k in range(24):
         st = env.state.cpu().numpy().copy()
         ep = env.episode_len.cpu().numpy().copy()
@@ -117,21 +118,20 @@ def test_elev_fused_step_matches_oracle_single_steps(lanes, z_scale):
         obs, rew, term, trunc = env.step(torch.from_numpy(a).to(DEV))
         torch.cuda.synchronize()
         met = np.zeros(16)
-        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, hf, a, 5, k, met)
+        probe = {}
+        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, hf, a, 5, k, met, probe=probe)
         got = env.state.cpu().numpy()
         np.testing.assert_array_equal(trunc.cpu().numpy(), o_trunc)
         bad = term.cpu().numpy() != o_term
         flips += int(bad.sum())
         ok = ~bad
-        # 20 sub-steps over a bilinear heightfield: 5e-4 abs/rel on the dynamic state.  Contact make/break (a wheel
-        # touching down within the step) is a discontinuity that amplifies fp32 rounding: such envs (< 1 %) are held
-        # to a loose bound instead, and must re-converge (each step restarts from the device state).
-        err = np.abs(got[:21, :n] - st[:21, :n]) / (5e-4 + 5e-4 * np.abs(st[:21, :n]))
-        touchy = (err.max(0) > 1.0) & ok
-        assert touchy.sum() <= max(2, n // 100), (k, int(touchy.sum()))
-        assert err[:, touchy].max(initial=0) < 400, (k, err[:, touchy].max())      # i.e. < 0.2 abs on O(1) values
-        ok &= ~touchy
-        np.testing.assert_allclose(got[:21, :n][:, ok], st[:21, :n][:, ok], rtol=5e-4, atol=5e-4, err_msg=f"step {k}")
+        # 10 sub-steps over a bilinear heightfield: 5e-4 abs/rel on the dynamic state.  An env may miss it only if the ORACLE's own step
+        # shows the cause -- a wheel within reach of making / breaking contact or of a cell line (tests/parity_predicates.py) -- is then
+        # held to a loose bound, and must re-converge (each step restarts from the device state)
+        ok, n_ex = PRED.check_state(got, st, probe, n, ok, where=f"step {k}")
+        excused += n_ex
+        reach += int(PRED.explainable(probe, n).sum())
+        assert PRED.state_error(got, st, n)[:, ok].max() <= 1.0, k
         np.testing.assert_allclose(got[35:41, :n][:, ok], st[35:41, :n][:, ok], rtol=5e-4, atol=2e-3)
         np.testing.assert_allclose(rew.cpu().numpy()[ok], o_rew[ok], rtol=2e-3, atol=5e-2)   # weights 5000*0.1 amplify z
         d = np.abs(obs.cpu().numpy() - o_obs)[ok]
@@ -145,6 +145,10 @@ def test_elev_fused_step_matches_oracle_single_steps(lanes, z_scale):
             dm = env.metrics.cpu().numpy().astype(np.float64) - met0
             np.testing.assert_allclose(dm[8:16], met[8:16], atol=1e-3)
     assert flips <= 3
+    # measured (round 6, all four variants): NO env needs the excuse -- 0 of 12 288 env-steps, spawn drops included (until round 5, with
+    # 20 explicit sub-steps, up to 1 % of the envs per step did, by a count).  A handful stays allowed for other seeds / compilers, each
+    # one explained by the predicate.
+    assert excused <= 3, (excused, reach)
 
 
 @pytest.mark.parametrize("n", [4096])
@@ -216,7 +220,7 @@ def test_settled_cars_need_no_contact_excuse(lanes, terrain):
     make / break discontinuities (the spawn drop; on the rough synthetic terrain also a wheel unloading over a crest -- the
     suspension's static deflection is 2.8 mm).  Here nothing makes or breaks contact: the terrain is a tilted plane with a faint
     long swell (all four wheels stay loaded; normals still vary), every termination is switched off on BOTH sides, the cars
-    settle for 12 steps and then crawl -- the excused set must be EMPTY for 24 steps, in both forms of the kernel.
+    settle for 18 steps and then crawl -- the excused set must be EMPTY for 24 steps, in both forms of the kernel.
     terrain "bench" (round 4): the same on the synthetic 800 x 800 terrain bench.py and the step test run on (hills, ramps up to
     plateaus, the 4 cm undulation): settled, gently driven cars keep all four wheels loaded there too.
     Round 5 (16-bit height codes): a CURVED surface on the code lattice carries +-0.06 mm of rounding per grid point -- slope noise of
@@ -250,36 +254,41 @@ def test_settled_cars_need_no_contact_excuse(lanes, terrain):
     env.reset()
     rng = np.random.RandomState(1)
     gentle = lambda: np.stack([rng.uniform(0.1, 0.3, n), rng.uniform(-0.3, 0.3, n)], -1).astype(np.float32)
-    for _ in range(12):
+    SETTLE = 18      # the spawn drop is up to 0.7 m on these planes (reset_z = 0.25 over terrain down to -0.5): 1.2 s to ring out
+    for _ in range(SETTLE):
         env.step(torch.from_numpy(gentle()).to(DEV))
     torch.cuda.synchronize()
     assert int(env.metrics[8]) == 0
     excused = 0
     for k in range(24):
         st = env.state.cpu().numpy().copy()
+        pre = st.copy()
         ep = env.episode_len.cpu().numpy().copy()
         a = gentle()
         obs, rew, term, trunc = env.step(torch.from_numpy(a).to(DEV))
         torch.cuda.synchronize()
-        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, hf, a, 8, 12 + k)
+        probe = {}
+        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, hf, a, 8, SETTLE + k, probe=probe)
         got = env.state.cpu().numpy()
         assert not term.any() and not trunc.any() and not o_term.any() and not o_trunc.any()
-        err = np.abs(got[:21, :n] - st[:21, :n]) / (5e-4 + 5e-4 * np.abs(st[:21, :n]))
-        touchy = err.max(0) > 1.0
+        err = PRED.state_error(got, st, n)
+        # the cars this test is about: upright ones.  (All terminations are off: on the curved terrains a few of the 512 came to rest on
+        # their side or roof after the spawn drop -- up to 0.7 m here -- and keep touching down with one wheel; the single-step test above
+        # covers such states with the same predicate.)
+        q0 = pre[3:7, :n]
+        upright = (1.0 - 2.0 * (q0[1] ** 2 + q0[2] ** 2)) > 0.8
+        assert upright.mean() > 0.9, (k, float(upright.mean()))
+        # (on the curved terrains a crawling car keeps 3 - 5 % of the env-steps busy with a wheel touching down or lifting off: the chassis is
+        # rigid and the suspension's static deflection 2.8 mm, so over uneven ground it rocks on a diagonal pair of wheels.)
+        # every upright car to the tight bound; on the curved terrains ("tilted", "bench") one may miss it only with a wheel on a cell line
+        # of the 16-bit lattice (the predicate of tests/parity_predicates.py) -- on the exact plane not at all
+        ok, n_ex = PRED.check_state(got, st, probe, n, upright, loose=60.0, where=f"{terrain} step {k}")
         if terrain == "plane":
-            r_, e_ = np.unravel_index(int(np.argmax(err)), err.shape)
-            assert touchy.sum() == 0, (k, int(touchy.sum()), float(err.max()), "row", int(r_), "env", int(e_), "got", got[:21, e_].tolist(),
-                                       "want", st[:21, e_].tolist())
-        else:
-            # the bench terrain has crests (plateau rims, hill tops) where ONE wheel of a crawling car unloads within a step: measured
-            # 1 env of 512 in 1 - 2 of the 24 steps, 12 x the bound (6e-3 abs).  Held to: <= 2 envs per step, < 60 x the bound (3e-2 abs;
-            # the main step test's excuse is 1 % of the envs at 400 x), <= 0.1 % of all env-steps, and every other env to the bound.
-            assert touchy.sum() <= 2 and err.max() < 60.0, (k, int(touchy.sum()), float(err.max()))
-            excused += int(touchy.sum())
-        ok = ~touchy
+            assert n_ex == 0, (k, n_ex, float(err.max()))
+        excused += n_ex
         np.testing.assert_allclose(rew.cpu().numpy()[ok], o_rew[ok], rtol=2e-3, atol=5e-2)
         d = np.abs(obs.cpu().numpy() - o_obs)[ok]
         d[:, 2:5] = np.minimum(d[:, 2:5], np.abs(2 * np.pi - d[:, 2:5]))
         assert d[:, :13].max() < 3e-3 and (d[:, 13:] > 2e-3).sum() <= 4
-    assert excused <= 12, excused                                             # 0.1 % of 24 x 512 env-steps
+    assert excused <= 6, excused                                              # 0.05 % of the 24 x 512 env-steps; each one explained (round 5: up to 12, by a count)
     assert float(np.abs(env.state[7:9, :n].cpu().numpy()).mean()) > 0.05     # they do drive

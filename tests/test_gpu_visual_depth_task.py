@@ -8,6 +8,7 @@ import torch
 
 from oracle import heightfield as OH
 from oracle import visual_step as OS
+from tests import parity_predicates as PRED
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -62,7 +63,7 @@ def test_visual_depth_step_matches_oracle_single_steps(lanes):
     cells = OS.spawn_cells(trav)
     p = _oracle_params(env)
     rng = np.random.RandomState(0)
-    img_bad_total = 0
+    img_bad_total = excused = 0
     for k in range(10):
         st = env.state.cpu().numpy().copy()
         ep = env.episode_len.cpu().numpy().copy()
@@ -79,19 +80,18 @@ def test_visual_depth_step_matches_oracle_single_steps(lanes):
         obs, rew, term, trunc = env.step(torch.from_numpy(a).to(DEV))
         torch.cuda.synchronize()
         met = np.zeros(16)
-        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, trav, cells, a, 5, k, met, hf=hf, max_depth=MAX_DEPTH)
+        probe = {}
+        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, trav, cells, a, 5, k, met, hf=hf, max_depth=MAX_DEPTH, probe=probe)
         got = env.state.cpu().numpy()
         np.testing.assert_array_equal(trunc.cpu().numpy(), o_trunc)
         bad = term.cpu().numpy() != o_term
         assert bad.sum() <= 1
         ok = ~bad
-        # 40 sub-steps over the heightfield with contact make / break (the 10 cm spawn drop): as the elevation / visual step tests
-        err = np.abs(got[:21, :n] - st[:21, :n]) / (5e-4 + 5e-4 * np.abs(st[:21, :n]))
-        touchy = (err.max(0) > 1.0) & ok
-        assert touchy.sum() <= max(3, n // 25), (k, int(touchy.sum()))
-        assert err[:, touchy].max(initial=0) < 600, (k, err[:, touchy].max())
-        ok &= ~touchy
-        np.testing.assert_allclose(got[:21, :n][:, ok], st[:21, :n][:, ok], rtol=5e-4, atol=5e-4, err_msg=f"step {k}")
+        # 10 sub-steps of 20 ms over the heightfield with contact make / break (the 10 cm spawn drop): an env may miss the tight bound only
+        # if the ORACLE's step had a wheel within reach of a discontinuity (tests/parity_predicates.py), as in the elevation step test
+        ok, n_ex = PRED.check_state(got, st, probe, n, ok, where=f"step {k}")
+        excused += n_ex
+        assert PRED.state_error(got, st, n)[:, ok].max() <= 1.0, k
         cell_flip = np.abs(rew.cpu().numpy() - o_rew) > 0.5     # +-1 traversability flips exactly on a cell edge
         assert (cell_flip & ok).sum() <= 1
         sel = ok & ~cell_flip
@@ -108,6 +108,7 @@ def test_visual_depth_step_matches_oracle_single_steps(lanes):
             dm = env.metrics.cpu().numpy().astype(np.float64) - met0
             np.testing.assert_allclose(dm[8:16], met[8:16], atol=1e-3)
     assert img_bad_total < 1e-3 * 10 * n * 4800, img_bad_total
+    assert excused <= 3, excused                                # (round 5: max(3, n / 25) envs PER STEP at 600 x the bound, by a count)
     assert env.metrics[10] > 0 and env.metrics[9] > 0           # both out_of_map and time_out were exercised
 
 
@@ -150,21 +151,21 @@ def test_settled_cars_need_no_contact_excuse(lanes):
         obs, rew, term, trunc = env.step(torch.from_numpy(a).to(DEV))
         torch.cuda.synchronize()
         met = np.zeros(16)
-        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, trav, cells, a, 21, 6 + k, met, hf=hf, max_depth=MAX_DEPTH)
+        probe = {}
+        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, trav, cells, a, 21, 6 + k, met, hf=hf, max_depth=MAX_DEPTH, probe=probe)
         got = env.state.cpu().numpy()
         assert not term.any() and not trunc.any() and not o_term.any() and not o_trunc.any()
-        err = np.abs(got[:21, :n] - st[:21, :n]) / (5e-4 + 5e-4 * np.abs(st[:21, :n]))
-        touchy = err.max(0) > 1.0
-        assert touchy.sum() <= 2 and err.max() < 60.0, (k, int(touchy.sum()), float(err.max()))
-        excused += int(touchy.sum())
-        ok = ~touchy
+        # every env to the tight bound unless the oracle's step shows a wheel within reach of a discontinuity (a wheel unloading over a
+        # crest, a cell line of the lattice: tests/parity_predicates.py)
+        ok, n_ex = PRED.check_state(got, st, probe, n, np.ones(n, bool), loose=60.0, where=f"step {k}")
+        excused += n_ex
         cell_flip = np.abs(rew.cpu().numpy() - o_rew) > 0.5      # +-1 traversability flips exactly on a cell edge
         assert (cell_flip & ok).sum() <= 1
         sel = ok & ~cell_flip
         np.testing.assert_allclose(rew.cpu().numpy()[sel], o_rew[sel], rtol=2e-3, atol=3e-3)
         assert np.abs(obs.cpu().numpy()[sel, 4800:] - o_obs[sel, 4800:]).max() < 3e-3
     print(f"visual-depth settled cars, lanes {lanes}: {excused} excused env-steps of {12 * n}")
-    assert excused <= max(1, int(0.002 * 12 * n)), excused
+    assert excused <= 2, excused
 
 
 def test_a_refused_depth_step_leaves_the_batch_untouched():

@@ -8,6 +8,7 @@ import torch
 
 from oracle import visual_mdp as VM
 from oracle import visual_step as OS
+from tests import parity_predicates as PRED
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -102,6 +103,7 @@ def test_visual_fused_step_matches_oracle_single_steps(trav, lanes):
     p = OS.visual_params()
     cells = OS.spawn_cells(trav)
     rng = np.random.RandomState(0)
+    excused = 0
     for k in range(12):
         st = env.state.cpu().numpy().copy()
         ep = env.episode_len.cpu().numpy().copy()
@@ -116,17 +118,18 @@ def test_visual_fused_step_matches_oracle_single_steps(trav, lanes):
         obs, rew, term, trunc = env.step(torch.from_numpy(a).to(DEV))
         torch.cuda.synchronize()
         met = np.zeros(16)
-        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, trav, cells, a, 5, k, met)
+        probe = {}
+        o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, trav, cells, a, 5, k, met, probe=probe)
         got = env.state.cpu().numpy()
         np.testing.assert_array_equal(trunc.cpu().numpy(), o_trunc)
         bad = term.cpu().numpy() != o_term
         assert bad.sum() <= 1
         ok = ~bad
-        err = np.abs(got[:21, :n] - st[:21, :n]) / (5e-4 + 5e-4 * np.abs(st[:21, :n]))
-        touchy = (err.max(0) > 1.0) & ok                       # wheel touch-down within the step (10 cm spawn drop)
-        assert touchy.sum() <= max(2, n // 50), (k, int(touchy.sum()))
-        ok &= ~touchy
-        np.testing.assert_allclose(got[:21, :n][:, ok], st[:21, :n][:, ok], rtol=5e-4, atol=5e-4, err_msg=f"step {k}")
+        # an env may miss the tight bound only if the ORACLE's step had a wheel within reach of making / breaking contact (the 10 cm spawn
+        # drop; tests/parity_predicates.py) -- measured in round 6: none does
+        ok, n_ex = PRED.check_state(got, st, probe, n, ok, where=f"step {k}")
+        excused += n_ex
+        assert PRED.state_error(got, st, n)[:, ok].max() <= 1.0, k
         cell_flip = np.abs(rew.cpu().numpy() - o_rew) > 0.5    # +-1 traversability flips exactly on a cell edge
         assert (cell_flip & ok).sum() <= 1
         sel = ok & ~cell_flip
@@ -137,6 +140,7 @@ def test_visual_fused_step_matches_oracle_single_steps(trav, lanes):
             dm = env.metrics.cpu().numpy().astype(np.float64) - met0
             np.testing.assert_allclose(dm[8:16], met[8:16], atol=1e-3)
     assert env.metrics[10] > 0 and env.metrics[9] > 0          # both out_of_map and time_out were exercised
+    assert excused <= 2, excused                               # (until round 5, 40 explicit sub-steps: up to 2 % of the envs per step, by a count)
 
 
 def test_visual_full_size_properties_and_depth(trav):
@@ -274,7 +278,7 @@ def test_settled_cars_need_no_contact_excuse(trav, lanes):
         o_obs, o_rew, o_term, o_trunc, info = OS.step(p, st, ep, trav, cells, a, 8, 6 + k)
         got = env.state.cpu().numpy()
         assert not term.any() and not trunc.any() and not o_term.any() and not o_trunc.any()
-        err = np.abs(got[:21, :n] - st[:21, :n]) / (5e-4 + 5e-4 * np.abs(st[:21, :n]))
+        err = PRED.state_error(got, st, n)
         touchy = err.max(0) > 1.0
         assert touchy.sum() == 0, (k, int(touchy.sum()), float(err.max()))
         cell_flip = np.abs(rew.cpu().numpy() - o_rew) > 0.5    # +-1 traversability flips exactly on a cell edge
