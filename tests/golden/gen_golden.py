@@ -775,6 +775,15 @@ def gen_visual_unwired(V, st, env):
     out["pos_track"] = st2["pos"]
     out["off_track"] = npy(V.off_track(env2, 0.8, 2.0))
     out["off_track_1"] = npy(V.off_track(env2, 0.8, 1.0))
+    # the cfg CLASS's own lookup (:188-208 get_traversability / get_map_id: floor, [x_idx, y_idx] order -- not the singleton's rule the
+    # terms above use): points all over the map and beyond its edge, some exactly on cell lines
+    cfg = object.__new__(V.VisualTerrainImporterCfg)
+    pts = rng.uniform(-130.0, 130.0, (n, 2)).astype(np.float32)
+    pts[:32] = (np.round(pts[:32] / 0.5) * 0.5 + 0.25).astype(np.float32)          # on the lines of the floor rule
+    pts[32:40] = [[-125.0, 125.0], [125.0, -125.0], [-124.75, -124.75], [124.75, 124.75], [0.0, 0.0], [0.25, -0.25], [-0.25, 0.25], [124.9, 0.1]]
+    xi, yi = cfg.get_map_id(torch.from_numpy(pts[:, 0].copy()), torch.from_numpy(pts[:, 1].copy()))
+    out["cfg_points"], out["cfg_map_id_x"], out["cfg_map_id_y"] = pts, npy(xi), npy(yi)
+    out["cfg_traversability"] = npy(torch.as_tensor(cfg.get_traversability(torch.from_numpy(pts.copy()))))
     # the map the reference's singleton holds (what the terms above looked up)
     out["map_packed"], out["map_shape"] = np.packbits(m), np.array(m.shape, np.int64)
     out["spacing"] = np.array([util.row_spacing, util.col_spacing], np.float64)

@@ -315,3 +315,29 @@ def test_visual_unwired_terms_wired_through_a_config_override():
         assert "Episode_Reward/wheels" in extras["log"] and "Episode_Termination/all_wheels_off" in extras["log"]
     assert ended > 0                                                             # cars do leave the paths within 12 steps
     env.close()
+
+
+def test_camera_data_rgb_is_what_the_fused_grey_image_is_made_of():
+    """`camera_data_rgb` (visual/mdp_sensors/observations.py:60-62): the un-flattened [N, 60, 80, 3] uint8 image of the scene's camera.
+    Pushed through the reference's own chain for the flattened term (:64-73: drop the top third, grey = 0.2989 R + 0.587 G + 0.114 B
+    of the image / 255, normalise with mean 0.5 / std 0.5) it is the fused kernel's un-augmented observation -- up to the uint8 rounding
+    of the sky's 0.5 and the pixels whose ray lands within rounding of a cell edge of the map"""
+    from wheeledlab_amd.envs import mdp
+    n = 64
+    registry, cfg = _cfg("Isaac-MushrVisualRL-v0", n)
+    env = registry.make("Isaac-MushrVisualRL-v0", cfg=cfg)
+    env.reset()
+    for _ in range(3):
+        env.step(torch.rand(n, 2, device=env.device) * 2 - 1)
+    rgb = mdp.camera_data_rgb(env)
+    assert rgb.shape == (n, 60, 80, 3) and rgb.dtype == torch.uint8
+    assert torch.equal(rgb[..., 0], rgb[..., 1]) and torch.equal(rgb[..., 1], rgb[..., 2])
+    assert set(torch.unique(rgb).tolist()) <= {0, 127, 255} and (rgb == 255).any() and (rgb == 0).any()
+    img = rgb[:, 20:].permute(0, 3, 1, 2).float() / 255.0
+    grey = 0.2989 * img[:, 0] + 0.587 * img[:, 1] + 0.114 * img[:, 2]
+    want = ((grey - 0.5) / 0.5).reshape(n, -1)
+    got = mdp.camera_data_rgb_flattened(env)
+    assert got.shape == want.shape == (n, 3200)
+    off = (got - want).abs() > 0.01
+    assert off.float().mean() < 5e-3, float(off.float().mean())
+    env.close()

@@ -5,6 +5,7 @@ reference's own functions (tests/golden*/elevation_unwired.npz, made by tests/go
 import types
 
 import numpy as np
+import pytest
 import torch
 
 from wheeledlab_amd.envs import mdp
@@ -142,3 +143,46 @@ def test_wheel_link_positions_follow_the_vehicle_geometry():
     robot.find_bodies = types.MethodType(ArticulationView.find_bodies, robot)
     cfg = SceneEntityCfg("robot", body_names=".*wheel_link").resolve({"robot": robot})
     assert cfg.body_ids == [1, 2, 3, 4]
+
+
+def test_cfg_class_lookups_match_the_reference(golden):
+    """VisualTerrainImporterCfg.get_map_id / get_traversability (visual/mushr_visual_env_cfg.py:188-208): the cfg class's OWN lookup --
+    floor((x + width / 2 - spacing / 2) / spacing), clamped, map[x_idx, y_idx] -- which is NOT the rule of the reward terms' singleton
+    (truncation of (x + width / 2 + spacing / 2) / spacing, map[y_idx, x_idx]); against the reference class's outputs on points over
+    the whole map, beyond its edge and exactly on the rule's cell lines"""
+    from wheeledlab_amd.tasks.visual.mushr_visual_env_cfg import VisualTerrainImporterCfg
+    g = golden("visual_unwired")
+    m = np.unpackbits(g["map_packed"])[: int(np.prod(g["map_shape"]))].reshape(tuple(g["map_shape"])).astype(bool)
+    cfg = VisualTerrainImporterCfg()
+    with pytest.raises(ValueError):
+        cfg.get_traversability(torch.zeros(1, 2))                     # no map yet: generated when the env is built
+    cfg.traversability_hashmap = m.tolist()                           # the reference holds a nested list
+    pts = torch.from_numpy(g["cfg_points"].copy())
+    xi, yi = cfg.get_map_id(pts[:, 0], pts[:, 1])
+    assert xi.dtype == torch.int64
+    np.testing.assert_array_equal(xi.numpy(), g["cfg_map_id_x"])
+    np.testing.assert_array_equal(yi.numpy(), g["cfg_map_id_y"])
+    np.testing.assert_array_equal(np.asarray(cfg.get_traversability(pts)), g["cfg_traversability"])
+    assert 0 < g["cfg_traversability"].mean() < 1 and g["cfg_map_id_x"].min() == 0 and g["cfg_map_id_x"].max() == 499
+    # and it is a different rule from the singleton's: the two disagree on a good share of the points
+    from oracle import visual_mdp as VM
+    other = VM.get_traversability(m, g["cfg_points"])
+    assert (other != g["cfg_traversability"]).mean() > 0.05
+
+
+def test_lidar_terms_read_any_sensor_with_linear_depth():
+    """lidar_ranges / lidar_ranges_normalized (mdp_sensors/observations.py:25-58): the sensor's `linear_depth` as is; with N(0, 0.1)
+    noise, clipped to [min_range, max_range] and mapped to [0, 1]"""
+    from wheeledlab_amd.envs.managers_cfg import SceneEntityCfg
+    r = torch.rand(256, 360) * 12.0
+    sensor = types.SimpleNamespace(data=types.SimpleNamespace(output={"linear_depth": r}), cfg=types.SimpleNamespace(min_range=0.4, max_range=10.0))
+    env = types.SimpleNamespace(scene=types.SimpleNamespace(sensors={"lidar": sensor}))
+    cfg = SceneEntityCfg("lidar")
+    assert mdp.lidar_ranges(env, cfg) is r
+    torch.manual_seed(0)
+    got = mdp.lidar_ranges_normalized(env, cfg)
+    torch.manual_seed(0)
+    want = (torch.clip(r + torch.normal(mean=0.0, std=0.1, size=r.shape), min=0.4, max=10.0) - 0.4) / 9.6
+    assert torch.equal(got, want) and got.min() == 0.0 and got.max() == 1.0
+    inner = (r > 1.0) & (r < 9.0)
+    assert abs(float(((got * 9.6 + 0.4) - r)[inner].std()) - 0.1) < 0.005          # the noise is there, at its sigma

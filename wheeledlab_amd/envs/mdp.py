@@ -468,6 +468,27 @@ def camera_data_rgb_flattened(env, sensor_cfg=None):            # mdp_sensors/ob
     return out
 
 
+def camera_data_rgb(env, sensor_cfg=_CAMERA):                   # mdp_sensors/observations.py:60-62
+    """the camera's un-flattened image [N, 60, 80, 3] uint8: what `camera_data_rgb_flattened` crops, greys and normalises (the designed
+    camera renders the black / white traversability plane, sky grey: the three channels are equal)"""
+    return env.scene.sensors[sensor_cfg.name].data.output["rgb"]
+
+
+def lidar_ranges(env, sensor_cfg):                              # mdp_sensors/observations.py:25-30
+    """`linear_depth` of a lidar-like sensor of the scene, as is.  (No registered scene carries one -- the reference's F1Tenth task
+    switches its RTX lidars off, drifting/disable_lidar.py -- the term works with any sensor whose data exposes that output.)"""
+    return env.scene.sensors[sensor_cfg.name].data.output["linear_depth"]
+
+
+def lidar_ranges_normalized(env, sensor_cfg):                   # mdp_sensors/observations.py:32-58
+    """ranges + N(0, 0.1) noise, clipped to the sensor's [min_range, max_range], mapped to [0, 1]"""
+    sensor = env.scene.sensors[sensor_cfg.name]
+    r = sensor.data.output["linear_depth"]
+    lo, hi = sensor.cfg.min_range, sensor.cfg.max_range
+    noisy = r + torch.normal(mean=0.0, std=0.1, size=r.shape, device=r.device)
+    return (torch.clip(noisy, min=lo, max=hi) - lo) / (hi - lo)
+
+
 def camera_data_depth(env, sensor_cfg=_CAMERA):                 # mdp_sensors/observations.py:89-91
     """distance_to_image_plane of the robot's camera [N, 60, 80, 1] (defined but unwired in the reference's VisualObsCfg)"""
     return env.scene.sensors[sensor_cfg.name].data.output["distance_to_image_plane"]

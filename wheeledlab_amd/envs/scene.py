@@ -240,12 +240,51 @@ class CameraData:
     def output(self):
         return _CameraOutputs(self)
 
+    def rgb(self):
+        """`output["rgb"]` [N, 60, 80, 3] uint8 (mdp_sensors/observations.py:60-62 `camera_data_rgb`): the designed camera's view of the
+        black / white traversability plane, all 60 rows, no augmentation -- each pixel one ray against the z = 0 plane with a map lookup
+        (white 255 on a traversable cell, black 0 off it or off the map, grey 127 where the ray misses the plane), the model the fused
+        observation kernel evaluates for the lower 40 rows (csrc/wl_visual.hip, oracle/visual_step.py::camera).  Plain torch: this is
+        the un-wired debugging / logging path, not env.step()."""
+        b = self._b
+        if not hasattr(b, "trav_map"):
+            raise KeyError("camera data type 'rgb' needs the visual task's traversability map")
+        n, p = b.n, b.p
+        q = b.state[A.S_QW:A.S_QW + 4, :n]
+        w, x, y, z = q[0], q[1], q[2], q[3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                         2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).view(n, 3, 3)
+        cam = torch.tensor(list(p.cam_pos), dtype=torch.float32, device=b.device)
+        o = b.state[A.S_PX:A.S_PX + 3, :n].T + R @ cam
+        rows = torch.arange(60, dtype=torch.float32, device=b.device)
+        cols = torch.arange(80, dtype=torch.float32, device=b.device)
+        dy = -((cols + 0.5 - p.cx) / p.fx)
+        dz = -((rows + 0.5 - p.cy) / p.fy)
+        db = torch.stack([torch.ones(60, 80, device=b.device), dy[None, :].expand(60, 80), dz[:, None].expand(60, 80)], -1).view(-1, 3)
+        dw = torch.einsum("nij,pj->npi", R, db)
+        hit = dw[..., 2] < -1e-6
+        t = torch.where(hit, -o[:, None, 2] / torch.where(hit, dw[..., 2], torch.full_like(dw[..., 2], -1.0)), torch.zeros_like(dw[..., 2]))
+        hx, hy = o[:, None, 0] + t * dw[..., 0], o[:, None, 1] + t * dw[..., 1]
+        m = b.trav_map
+        nr, nc = m.shape
+        rs, cs = float(b._map.row_spacing), float(b._map.col_spacing)
+        on_map = hit & (hx.abs() <= nr * rs / 2) & (hy.abs() <= nc * cs / 2)
+        # the reward terms' lookup (visual/utils/traversability_utils.py:68-88): (x + width / 2 + spacing / 2) / spacing truncated towards
+        # zero, clamped, map[y, x]
+        ix = torch.clamp(((hx + (nr * rs / 2 + rs / 2)) / rs).long(), 0, nr - 1)
+        iy = torch.clamp(((hy + (nc * cs / 2 + cs / 2)) / cs).long(), 0, nc - 1)
+        white = on_map & m.bool()[iy, ix]
+        grey = torch.where(hit, torch.where(white, 255, 0), 127).to(torch.uint8)
+        return grey.view(n, 60, 80, 1).expand(n, 60, 80, 3).contiguous()
+
 
 class _CameraOutputs:
     def __init__(self, data):
         self._d = data
 
     def __getitem__(self, key):
+        if key == "rgb":
+            return self._d.rgb()
         if key != "distance_to_image_plane":
             raise KeyError(f"camera data type {key!r} is not rendered here (the fused observation carries the grey image)")
         d = self._d

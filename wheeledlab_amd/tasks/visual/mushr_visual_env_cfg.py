@@ -57,6 +57,23 @@ class VisualTerrainImporterCfg(TerrainImporterCfg):
     def height_m(self):
         return self.num_cols * self.col_spacing
 
+    def get_map_id(self, x, y):
+        """the cfg class's OWN cell lookup (reference :201-208) -- not the one the reward terms use
+        (visual/utils/traversability_utils.py: round, [y, x] order): here the index is floor((x + width / 2 - spacing / 2) / spacing),
+        clamped to the map, and the map is then indexed [x_idx, y_idx].  Torch tensors in, long tensors out."""
+        import torch
+        x_idx = torch.floor((x + self.width / 2 - self.row_spacing / 2) / self.row_spacing).long()
+        y_idx = torch.floor((y + self.height_m / 2 - self.col_spacing / 2) / self.col_spacing).long()
+        return torch.clamp(x_idx, 0, self.num_rows - 1), torch.clamp(y_idx, 0, self.num_cols - 1)
+
+    def get_traversability(self, poses):
+        """traversability of poses [N, >= 2] (x, y) through get_map_id (reference :190-196); needs `traversability_hashmap`"""
+        import torch
+        if self.traversability_hashmap is None:
+            raise ValueError("traversability_hashmap is generated when the env is constructed; set it (or build the env) first")
+        x_idx, y_idx = self.get_map_id(poses[:, 0], poses[:, 1])
+        return torch.as_tensor(self.traversability_hashmap).to(x_idx.device)[x_idx, y_idx]
+
 
 @configclass
 class MushrVisualSceneCfg(InteractiveSceneCfg):
