@@ -261,6 +261,7 @@ WL_DEV wl_float4_u scan_quad_value(const WlElevParams& p, const ScanRay (&r)[4],
 template <bool STREAM>
 WL_DEV void scan_quad_store(float* __restrict__ row_map /* obs row + 13 */, int q, wl_float4_u v) {
     wl_float4_u* dst = reinterpret_cast<wl_float4_u*>(row_map + 4 * q);
+
     if constexpr (STREAM) __builtin_nontemporal_store(v, dst);
     else *dst = v;
 }
@@ -932,19 +933,22 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     }
     // ---- the scan ----
     const WlElevParams& p = p_arg;
+    const int n_here = min(kFusedEnvs, b.n_envs - e0);
+    const ScanField sf = scan_field(ground.f);
     // flat index over (env, quad of rays): 16 x 169 quads / 512 lanes = 5.3 per lane, ONE quad (8 gathers) per batch: request,
     // blend, store, next.  (Rounds 2 - 3, single rays: 1 / 2 / 3 batches of gathers 28.4 / 26.2 / 25.9 us per step at 4096 envs.
-    // Round 6, after the physics went to 10 sub-steps, same box: 1 / 2 / 3 / 6 batches 21.4 / 21.3 / 21.3 / 20.2 us -- the phase is
-    // bound by the rate at which the CU's texture path takes scattered lines and by its stores, not by round trips: the sooner the
-    // first rows are written the better.)
+    // Round 6, after the physics went to 10 sub-steps, same box: 1 / 2 / 3 / 6 batches 21.4 / 21.3 / 21.3 / 20.2 us -- what the phase
+    // waits for is its STORES (the launch without them: 15.0 us; without the whole phase: 13.2): 11.3 MB leave all 256 CUs in one burst
+    // at the end of the launch and the launch ends when the last one is acknowledged, so the sooner the first rows are written the
+    // better.  Measured and dropped in round 6: a wavefront per env with the rays in 7 x 9 blocks of neighbours (40 % fewer distinct
+    // cache lines per gather instruction, values transposed through LDS into the same 16-byte stores): 21.1 us -- the gathers were
+    // never the cost.)
     constexpr int kAll = kFusedEnvs * kScanQuads;
 #ifndef WL_FUSED_SCAN_BATCHES
 #define WL_FUSED_SCAN_BATCHES 6
 #endif
     constexpr int kScanBatches = WL_FUSED_SCAN_BATCHES;
     constexpr int kSlots = (kAll + kFusedThreads - 1) / kFusedThreads, kBatch = (kSlots + kScanBatches - 1) / kScanBatches;
-    const int n_here = min(kFusedEnvs, b.n_envs - e0);
-    const ScanField sf = scan_field(ground.f);
 #pragma unroll
     for (int half = 0; half < kScanBatches; ++half) {
         ScanRay cr[kBatch][4];
