@@ -109,6 +109,12 @@ typedef struct WlVehicleParams {
      *     visual-depth entry points take -- ONE sub-step per sim.dt, the reference's own physics rate
      *     (mushr_elevation_env_cfg.py:461-462, mushr_visual_env_cfg.py:435-436) -- they refuse 0.                      */
     int32_t implicit;
+    /* ABI 22: the normal force of a wheel is max(min(k pen, susp_fmax) - c v_n, 0): the SPRING's force is capped.  The model has no
+     * chassis collision: a car that lands on its roof or tumbles meets the ground with its wheel spheres only, tens of centimetres
+     * deep, where a linear penalty spring would hand it hundreds of newtons per wheel.  24 x the static wheel load (6.7 cm of
+     * penetration: more than the wheel's radius) in the registered tasks: never reached in driving, nor by the 0.25 m spawn drop
+     * of the elevation task (2.4 cm).  Must be > 0.                                                                          */
+    float susp_fmax;
 } WlVehicleParams;
 
 /* ---- action term (AckermannAction.process_actions, ackermann_actions.py:119-133) ---------------------- */

@@ -13,7 +13,7 @@ def mushr_vehicle(drive=0, motor_limit=0.5, substeps=1, ground_mu=(1.1, 1.0), im
     return NS(
         gravity=g, half_wheelbase_f=0.1625, half_wheelbase_r=0.1625, half_track=0.1, wheel_radius=r,
         wheel_z=r - m_nom * g / (4 * k), cg_z=0.06, gyr_x=0.06, gyr_y=0.12, gyr_z=0.13,
-        wheel_inertia=8e-5, wheel_damping=1e-4, susp_k=k, susp_c=60.0,
+        wheel_inertia=8e-5, wheel_damping=1e-4, susp_k=k, susp_c=60.0, susp_fmax=24.0 * m_nom * g / 4.0,
         ground_mu_s=ground_mu[0], ground_mu_d=ground_mu[1], slip_peak=0.12, v_min=0.25,
         motor_sat=1.05, motor_limit=motor_limit, motor_vel_limit=450.0,   # hound.py:13-21,40-43
         drive=drive,

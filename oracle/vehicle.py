@@ -83,8 +83,6 @@ def implicit_body_update(v, wb, R, Fw, Tb, Ib, mass, S, vp, h):
     ab = (np.einsum("nji,nj->ni", R, Fw) / mass[:, None] - rot).astype(F)
     alpha = ((Tb - np.cross(wb, Ib * wb)) / Ib).astype(F)
     igz = F(1) / gz
-    dvx, dvy, dwz_g = solve_spd3(F(1) + q * S["xx"], q * S["xy"], q * S["xw"] * igz, F(1) + q * S["yy"], q * S["yw"] * igz,
-                                 F(1) + q * S["ww"] * igz * igz, h * ab[:, 0], h * ab[:, 1], h * alpha[:, 2] * gz)
     # heave / roll / pitch: diagonal.  Normal direction: the spring-damper's damping with the position update folded in,
     # c + h k, for every wheel in contact at its nominal lever (half track / half wheelbase); the tyres act on roll and pitch
     # through the height of the CoM above the contact patches.
@@ -93,9 +91,25 @@ def implicit_body_update(v, wb, R, Fw, Tb, Ib, mass, S, vp, h):
     by2 = F(vp.half_track) * F(vp.half_track)
     bx2 = F(0.5) * (F(vp.half_wheelbase_f) * F(vp.half_wheelbase_f) + F(vp.half_wheelbase_r) * F(vp.half_wheelbase_r))
     nD = S["nc"] * Dn
-    dvz = h * ab[:, 2] / (F(1) + q * nD)
-    dwx = h * alpha[:, 0] / (F(1) + q * (az * az * S["yy"] + by2 * nD) / (gx * gx))
-    dwy = h * alpha[:, 1] / (F(1) + q * (az * az * S["xx"] + bx2 * nD) / (gy * gy))
+    # The nominal geometry is that of a car standing on its wheels.  Tilted by more than ~40 degrees (world up in the body frame,
+    # R[2, 2] < 0.75: on its side, on its roof, tumbling -- the visual task has no rollover termination) the contact normals and
+    # levers are anywhere, and G^ falls back to an isotropic bound that over-estimates the damping matrix whatever the geometry
+    # (J^T D J <= 2 d_max blockdiag(I, |arm|^2 I) per wheel): g = 2 (sum of the wheels' kx + ky + contact damping) on every
+    # translation, g rho^2 on every rotation, rho the longest lever.  Over-estimating G^ only slows stiff modes down; an
+    # under-estimate at h = 20 ms let a car that had landed on its roof spin itself up to 300 rad/s and beyond fp32.
+    tilted = R[:, 2, 2] < F(0.75)
+    g_iso = F(2) * (S["xx"] + S["yy"] + nD)
+    rho2 = bx2 + by2 + az * az
+    one = np.ones_like(q)
+    a11 = np.where(tilted, one + q * g_iso, one + q * S["xx"])
+    a22 = np.where(tilted, one + q * g_iso, one + q * S["yy"])
+    a33 = np.where(tilted, one + q * g_iso * rho2 * igz * igz, one + q * S["ww"] * igz * igz)
+    off = np.where(tilted, F(0), F(1)).astype(F)
+    dvx, dvy, dwz_g = solve_spd3(a11, off * q * S["xy"], off * q * S["xw"] * igz, a22, off * q * S["yw"] * igz, a33,
+                                 h * ab[:, 0], h * ab[:, 1], h * alpha[:, 2] * gz)
+    dvz = h * ab[:, 2] / np.where(tilted, one + q * g_iso, one + q * nD)
+    dwx = h * alpha[:, 0] / np.where(tilted, one + q * g_iso * rho2 / (gx * gx), one + q * (az * az * S["yy"] + by2 * nD) / (gx * gx))
+    dwy = h * alpha[:, 1] / np.where(tilted, one + q * g_iso * rho2 / (gy * gy), one + q * (az * az * S["xx"] + bx2 * nD) / (gy * gy))
     dvb = np.stack([dvx, dvy, dvz], -1).astype(F) + h * rot
     v = (v + np.einsum("nij,nj->ni", R, dvb)).astype(F)
     wb = (wb + np.stack([dwx, dwy, dwz_g * igz], -1)).astype(F)
@@ -135,9 +149,11 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
         arm = arm_c - r * nrm                                       # CoM -> contact point
         vcp = v + np.cross(ww, arm)
         vn = (vcp * nrm).sum(-1)
-        Fz = np.where(pen > 0, np.maximum(F(vp.susp_k) * pen - F(vp.susp_c) * vn, F(0)), F(0)).astype(F)
+        # spring (its force capped at susp_fmax: a penalty spring is meaningless centimetres deep, where only tumbling cars get) + damper,
+        # no adhesion
+        Fz = np.where(pen > 0, np.maximum(np.minimum(F(vp.susp_k) * pen, F(getattr(vp, 'susp_fmax', 1e30))) - F(vp.susp_c) * vn, F(0)), F(0)).astype(F)
         if probe is not None:
-            m_i = np.where(pen > 0, np.abs(F(vp.susp_k) * pen - F(vp.susp_c) * vn), F(vp.susp_k) * np.abs(pen))
+            m_i = np.where(pen > 0, np.abs(np.minimum(F(vp.susp_k) * pen, F(getattr(vp, 'susp_fmax', 1e30))) - F(vp.susp_c) * vn), F(vp.susp_k) * np.abs(pen))
             probe["_margin"] = np.minimum(probe.get("_margin", np.inf), m_i)
             probe["_mask"] = probe.get("_mask", 0) + (Fz > 0).astype(np.int32) * (1 << i)
         if front:
@@ -146,7 +162,7 @@ def substep(x, q, v, wb, wheel, th, om, steer_target, wheel_target, mass, mu_s_w
             hb = np.tile(f32([1, 0, 0]), (x.shape[0], 1))
         hw = np.einsum("nij,nj->ni", R, hb).astype(F)
         t = hw - (hw * nrm).sum(-1, keepdims=True) * nrm
-        tx = t / np.sqrt((t * t).sum(-1, keepdims=True))
+        tx = t / np.sqrt(np.maximum((t * t).sum(-1, keepdims=True), F(1e-6)))      # floored: a heading parallel to the ground normal has no tangent
         ty = np.cross(nrm, tx)
         vcx = (vcp * tx).sum(-1)
         vcy = (vcp * ty).sum(-1)

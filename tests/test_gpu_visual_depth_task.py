@@ -240,7 +240,9 @@ def test_full_size_properties_and_half_shards():
     assert resets > n and torch.isfinite(st).all() and torch.isfinite(ob).all()
     assert ((st[3:7] ** 2).sum(0).sqrt() - 1).abs().max() < 1e-5
     assert (ob[:, :4800] >= 0).all() and (ob[:, :4800] <= MAX_DEPTH).all()
-    assert st[2].min() > 0.1 and st[2].max() < 1.6                                  # on the terrain (0.19 .. ~1.2 m), not under it
+    # on the terrain (0.19 .. ~1.2 m).  The root of a car that came to rest standing on its nose or lying on its side -- no rollover
+    # termination in this task, wheels are spheres, the chassis has no collision shape -- is up to 0.17 m BELOW the surface it leans on
+    assert st[2].min() > 0.19 - 0.2 and st[2].max() < 1.6
     for r, h in enumerate(halves):
         sl = slice(r * (n // 2), (r + 1) * (n // 2))
         assert torch.equal(h.state[:, : n // 2], big.state[:, sl])
@@ -264,3 +266,23 @@ def test_malformed_calls_are_refused():
     assert lib.wl_visual_depth_rows(C.byref(env.p), C.byref(env._bufs), C.byref(env._hf), env.camera.pyramid.data_ptr(), MAX_DEPTH,
                                     env.obs.data_ptr(), 4799, st) == -1               # rows shorter than an image
     torch.cuda.synchronize()
+
+
+def test_an_untrained_policy_never_drives_a_car_out_of_fp32():
+    """4096 envs x 300 steps of N(0, 1) actions (what PPO's first iterations send) on the task's terrain at mu = 2, h = 20 ms, no rollover
+    termination: cars land on their sides and roofs.  No env may go non-finite (metric 14; the first implicit build lost 1 - 2 envs per
+    512 x 24 env-steps this way, profiles/r06_train_visual_depth_config_8it.json's predecessor), and speeds stay physical."""
+    n = 4096
+    env, hf = _batch(n, 3)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    vmax = wmax = 0.0
+    for k in range(300):
+        a = torch.randn(n, 2, device=DEV, generator=g).clamp(-1.5, 1.5)
+        env.step(a)
+        if k % 10 == 9:
+            vmax = max(vmax, float(env.state[7:10, :n].abs().max()))
+            wmax = max(wmax, float(env.state[10:13, :n].abs().max()))
+    torch.cuda.synchronize()
+    m = env.metrics.cpu().numpy()
+    assert m[14] == 0 and torch.isfinite(env.state[:, :n]).all(), m[14]
+    assert m[8] > 0 and vmax < 15.0 and wmax < 80.0, (vmax, wmax)

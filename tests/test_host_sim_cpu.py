@@ -139,6 +139,29 @@ def test_implicit_substeps_equal_the_spec_on_flat_ground(hostlib, h_ms, unroll):
         float(np.median(per_env)), float((per_env > 5e-5).mean()), float(per_env.max()))
 
 
+def test_tilted_cars_take_the_isotropic_bound_in_both_statements(hostlib):
+    """cars in EVERY orientation just above the plane (on their side, on their roof: R[2, 2] < 0.75 switches the implicit update to its
+    isotropic over-estimate of the damping matrix) and hard landings that reach the normal-force cap: the device code against the spec"""
+    vp = OP.mushr_vehicle(drive=1, motor_limit=0.25, ground_mu=(2.0, 2.0), implicit=1)
+    n = 2048
+    st = list(_states(n, seed=77, z0=0.06 - 0.0028))
+    rng = np.random.RandomState(5)
+    q = rng.normal(size=(n, 4))
+    st[1] = f32(q / np.linalg.norm(q, axis=1, keepdims=True))
+    st[0][:, 2] = f32(rng.uniform(0.0, 0.15, n))
+    st[2][:, 2] = f32(rng.uniform(-3.0, 0.5, n))                # some slam into the ground: k pen - c v_n beyond susp_fmax
+    st[9], st[10], st[11] = f32(np.full(n, 1.0)), f32(np.full(n, 1.0)), f32(np.full(n, 1000.0))
+    R22 = 1.0 - 2.0 * (st[1][:, 1] ** 2 + st[1][:, 2] ** 2)
+    assert 0.3 < (R22 < 0.75).mean() < 0.95
+    want = _oracle(vp, 0.02, 3, st, OV.flat_ground)
+    got = _host(hostlib, vp, 0.02, 3, st, None, 1)
+    per_env = np.max([np.abs(g - w).reshape(len(g), -1).max(-1) / (1 + np.abs(w).reshape(len(w), -1).max(-1))
+                      for g, w in zip(got, want)], axis=0)
+    assert np.isfinite(per_env).all()
+    # (tumbling cars make and break contact every sub-step and cross the 0.75 threshold: the branchy states get the loose bound)
+    assert np.median(per_env) < 1e-5 and (per_env > 1e-3).mean() < 0.02, (float(np.median(per_env)), float((per_env > 1e-3).mean()))
+
+
 def test_body_frame_substeps_equal_the_spec_on_the_heightfield(hostlib):
     """elevation: 4WD, ONE linearly implicit sub-step per sim.dt = 10 ms, bilinear heightfield with per-wheel normals; one control
     step of 10"""

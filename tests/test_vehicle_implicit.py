@@ -208,3 +208,54 @@ def test_policy_like_driving_on_the_terrain_stays_bounded():
             wmax = max(wmax, float(np.abs(st[3]).max()))
         assert all(np.isfinite(a).all() for a in st)
         assert vmax < 4.5 and wmax < 30.0, (h_ms, vmax, wmax)
+
+
+def test_rolled_over_and_tumbling_cars_stay_bounded_at_20_ms():
+    """The visual tasks have no rollover termination and the model no chassis collision: a car on its side or roof meets the ground with
+    its wheel spheres only.  Two safeguards keep such states bounded at h = 20 ms (round 6: before them one car in ~10^5 env-steps spun
+    itself up to 300 rad/s and out of fp32): the normal spring's force is capped at susp_fmax (24 x the static wheel load) and the implicit
+    update of a car tilted by more than ~40 degrees uses an isotropic over-estimate of the damping matrix.  Here: cars thrown onto the
+    synthetic terrain in every orientation, spinning, driven with N(0, 1) actions at mu = 2 for 4 s."""
+    hf = H.make_terrain()
+    ground = ground_fn(hf)
+    vp, h = _vehicle(20)
+    n = 256
+    rng = np.random.RandomState(11)
+    xy = rng.uniform(-10, 10, (n, 2)).astype(F)
+    zt, _ = ground(xy)
+    st = _rest(n, vp)
+    st[0] = np.concatenate([xy, (zt + rng.uniform(0.05, 0.4, n))[:, None]], -1).astype(F)
+    q = rng.normal(size=(n, 4))
+    st[1] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F)           # every orientation
+    st[2] = rng.uniform(-2, 2, (n, 3)).astype(F)
+    st[3] = rng.uniform(-8, 8, (n, 3)).astype(F)
+    m, ms, md, dm = (np.full(n, v, F) for v in (3.4, 1.0, 1.0, 1000.0))
+    ap = P.mushr_action(1)
+    vmax = wmax = 0.0
+    for k in range(200):
+        if k % 10 == 0:
+            a = np.clip(rng.randn(n, 2), -1.5, 1.5).astype(F)
+            proc = M.process_actions(M.clip_action(a), ap)
+            steer2, wt = M.fwd_targets(proc[:, 0], proc[:, 1], ap)
+        st = list(V.substep(*st, steer2[:, 0].astype(F), wt.astype(F), m, ms, md, dm, vp, h, ground))
+        assert all(np.isfinite(a_).all() for a_ in st), k
+        if k >= 25:                                      # after the throw-in has landed
+            vmax, wmax = max(vmax, float(np.abs(st[2]).max())), max(wmax, float(np.abs(st[3]).max()))
+    assert vmax < 12.0 and wmax < 60.0, (vmax, wmax)
+
+
+def test_the_spring_cap_is_out_of_reach_of_driving_and_of_the_spawn_drop():
+    """susp_fmax (200 N = 6.7 cm of penetration, more than a wheel radius) against what the wheels' springs carry: 8.3 N at rest, and the
+    0.25 m spawn drop of the elevation task compresses them to 2.4 cm"""
+    vp, h = _vehicle(10)
+    assert vp.susp_fmax == pytest.approx(24 * 3.4 * G / 4)
+    zrel = vp.wheel_z - vp.cg_z
+    st = _rest(4, vp, z=vp.cg_z + 0.25)
+    m, ms, md, dm = (np.full(4, v, F) for v in (3.4, 1.0, 1.0, 1000.0))
+    z = np.zeros(4, F)
+    pen = 0.0
+    for k in range(80):
+        st = list(V.substep(*st, z, np.zeros((4, 4), F), m, ms, md, dm, vp, h))
+        pen = max(pen, float(vp.wheel_radius - (st[0][:, 2] + zrel).min()))
+    assert 0.006 < pen and 3000.0 * pen < 0.5 * vp.susp_fmax, pen            # a hard landing: 9 x the static 2.8 mm, far from 6.7 cm
+    assert abs(float(st[0][0, 2]) - vp.cg_z) < 1e-4 and np.abs(st[2]).max() < 1e-3      # and it comes to rest where it should

@@ -48,7 +48,7 @@ class WlVehicleParams(C.Structure):
         "gyr_y", "gyr_z", "wheel_inertia", "wheel_damping", "susp_k", "susp_c", "ground_mu_s", "ground_mu_d",
         "slip_peak", "v_min", "motor_sat", "motor_limit", "motor_vel_limit")] + [("drive", C.c_int32)] + [
         (n, C.c_float) for n in ("steer_kp", "steer_kd", "steer_effort", "steer_vel_limit", "steer_inertia")] + [
-        ("substeps", C.c_int32), ("implicit", C.c_int32)]
+        ("substeps", C.c_int32), ("implicit", C.c_int32), ("susp_fmax", C.c_float)]
 
 
 class WlActionParams(C.Structure):

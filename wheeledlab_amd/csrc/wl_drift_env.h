@@ -595,7 +595,7 @@ WL_DEV void pin_params_vgpr(WlDriftParams& p, VehDerived& d) {
     float* vf[] = {&v.gravity, &v.half_wheelbase_f, &v.half_wheelbase_r, &v.half_track, &v.wheel_radius, &v.wheel_z, &v.cg_z,
                    &v.gyr_x, &v.gyr_y, &v.gyr_z, &v.wheel_inertia, &v.wheel_damping, &v.susp_k, &v.susp_c, &v.ground_mu_s,
                    &v.ground_mu_d, &v.slip_peak, &v.v_min, &v.motor_sat, &v.motor_limit, &v.motor_vel_limit, &v.steer_kp,
-                   &v.steer_kd, &v.steer_effort, &v.steer_vel_limit, &v.steer_inertia};
+                   &v.steer_kd, &v.steer_effort, &v.steer_vel_limit, &v.steer_inertia, &v.susp_fmax};
 #pragma unroll
     for (float* f : vf) pin_vgpr(*f);
     float* pf[] = {&p.straight, &p.r_in, &p.r_out, &p.r_line, &p.slip_min, &p.slip_max, &p.slip_min_vx, &p.speed_target,
@@ -626,7 +626,7 @@ inline int check_buffers(const WlDriftParams* p, const WlEnvBuffers* b) {
     if (!flags_ok(b) || ((b->flags & WL_FLAG_STREAM) && b->lanes == 4)) return WL_EINVAL;   // the streaming form is a lane form
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL) return WL_EINVAL;   // buffer-resource offsets are 32-bit (~13 M envs)
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || p->num_ref_points <= 0 || p->num_ref_points > 32) return WL_EINVAL;
-    if (p->vehicle.implicit != 0) return WL_EINVAL;   // the drift kernels step the explicit integrator (wl_vehicle.h)
+    if (p->vehicle.implicit != 0 || !(p->vehicle.susp_fmax > 0.f)) return WL_EINVAL;   // the drift kernels step the explicit integrator (wl_vehicle.h)
     if (!(p->sim_dt > 0.f)) return WL_EINVAL;
     return WL_OK;
 }

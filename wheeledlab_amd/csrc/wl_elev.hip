@@ -1392,7 +1392,7 @@ int check_elev(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
     if (!flags_ok(b)) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f)) return WL_EINVAL;
-    if (p->vehicle.implicit != 1) return WL_EINVAL;   // these kernels step the linearly implicit integrator (wl_vehicle.h)
+    if (p->vehicle.implicit != 1 || !(p->vehicle.susp_fmax > 0.f)) return WL_EINVAL;   // these kernels step the linearly implicit integrator (wl_vehicle.h)
     if (hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f && hf->z_scale < INFINITY)) return WL_EINVAL;
     return WL_OK;
 }

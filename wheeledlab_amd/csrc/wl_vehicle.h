@@ -59,6 +59,7 @@ struct VehDerived {
     float az2, bx2, by2;                    // squared nominal levers: CoM height above the contact patches, half wheelbase, half track
     float gz, inv_gz;                       // gyr_z: the in-plane block is solved in (dv_x, dv_y, gz dw_z) -- symmetric, mass-free
     float lxf, lxr, ly;                     // nominal wheel positions / gz: front x, rear x (negative), left y
+    float iso_x, iso_y, iso_z;              // rho^2 / gyr^2 per axis, rho the longest lever: the tilted car's isotropic bound on the rotations
     int32_t n_sub;                          // decimation * substeps
 };
 
@@ -98,6 +99,8 @@ inline VehDerived derive_vehicle(const WlVehicleParams& vp, float sim_dt, int de
     d.lxf = vp.half_wheelbase_f * d.inv_gz;
     d.lxr = -vp.half_wheelbase_r * d.inv_gz;
     d.ly = vp.half_track * d.inv_gz;
+    const float rho2 = d.bx2 + d.by2 + d.az2;
+    d.iso_x = rho2 * d.inv_g2x, d.iso_y = rho2 * d.inv_g2y, d.iso_z = rho2 * d.inv_g2z;
     d.n_sub = decimation * vp.substeps;
     return d;
 }
@@ -182,13 +185,15 @@ WL_DEV TyreCoef wheel_tyre(const WlVehicleParams& vp, const VehDerived& vd, cons
                            float hs, float d, float inv_A0d, float wt, float& w_spin) {
     const float r = vp.wheel_radius;
     const float vn = dot(n, vc);
-    const float Fz = pen > 0.f ? fmaxf(fmaf(vp.susp_k, pen, -vp.susp_c * vn), 0.f) : 0.f;
+    const float Fz = pen > 0.f ? fmaxf(fmaf(-vp.susp_c, vn, fminf(vp.susp_k * pen, vp.susp_fmax)), 0.f) : 0.f;   // (spring capped: WlVehicleParams.susp_fmax)
     // g = n . h ; m = (n x h).z ; lx = h . vc ; ly = (hc vc.y - hs vc.x)  [(n x h).xy = n.z (-hs, hc)]
     const float g = STEER ? fmaf(n.x, hc, n.y * hs) : n.x;
     const float m = STEER ? fmaf(n.x, hs, -n.y * hc) : -n.y;
     const float lx = STEER ? fmaf(hc, vc.x, hs * vc.y) : vc.x;
     const float ly = STEER ? fmaf(hc, vc.y, -hs * vc.x) : vc.y;
-    const float it = rsq(fmaf(-g, g, 1.f));
+    // (floored: a wheel whose heading is parallel to the ground normal -- a car standing on its nose -- has 1 - g^2 = 0, or a rounding
+    // below it, and rsq of that is inf / NaN: one of the ways a tumbling car left fp32)
+    const float it = rsq(fmaxf(fmaf(-g, g, 1.f), 1e-6f));
     const float vcx = it * fmaf(-g, vn, lx);
     const float vcy = it * fmaf(n.z, ly, m * vc.z);
     const float w_i = w_spin;
@@ -436,9 +441,17 @@ WL_DEV void body_integrate_implicit(const VehDerived& vd, const EnvConst& ec, Ve
     const V3 t = q * Tb;
     const V3 hal = v3(fmaf(vd.inv_g2x, t.x, -vd.cgx * (w.y * w.z)), fmaf(vd.inv_g2y, t.y, -vd.cgy * (w.z * w.x)),
                       fmaf(vd.inv_g2z, t.z, -vd.cgz * (w.x * w.y)));
+    // The nominal geometry is that of a car standing on its wheels.  Tilted by more than ~40 degrees (world up in the body frame,
+    // R.r2.z < 0.75: on its side, on its roof, tumbling -- the visual task has no rollover termination) G^ falls back to an isotropic
+    // bound that over-estimates the damping matrix whatever the geometry: g = 2 (sum of kx + ky + contact damping) on every
+    // translation, g rho^2 on every rotation (oracle/vehicle.py::implicit_body_update).
+    const bool tilted = R.r2.z < 0.75f;
+    const float nD = J.nc * vd.Dn;
+    const float qg = q * (2.f * (J.xx + J.yy + nD));
     // in-plane: LDL^T of [1 + q Jxx, q Jxy, q Jxw; ., 1 + q Jyy, q Jyw; ., ., 1 + q Jww] (identity + PSD: no pivoting)
-    const float a11 = fmaf(q, J.xx, 1.f), a12 = q * J.xy, a13 = q * J.xw, a22 = fmaf(q, J.yy, 1.f), a23 = q * J.yw,
-                a33 = fmaf(q, J.ww, 1.f);
+    const float qo = tilted ? 0.f : q;
+    const float a11 = tilted ? 1.f + qg : fmaf(q, J.xx, 1.f), a12 = qo * J.xy, a13 = qo * J.xw, a22 = tilted ? 1.f + qg : fmaf(q, J.yy, 1.f),
+                a23 = qo * J.yw, a33 = tilted ? fmaf(qg, vd.iso_z, 1.f) : fmaf(q, J.ww, 1.f);
     const float b1 = ha.x, b2 = ha.y, b3 = hal.z * vd.gz;
     const float i1 = rcp(a11);
     const float l21 = a12 * i1, l31 = a13 * i1;
@@ -453,10 +466,9 @@ WL_DEV void body_integrate_implicit(const VehDerived& vd, const EnvConst& ec, Ve
     const float x2 = fmaf(y2, i2, -(l32 * x3));
     const float x1 = fmaf(b1, i1, fmaf(-l21, x2, -(l31 * x3)));
     // heave / roll / pitch: diagonal
-    const float nD = J.nc * vd.Dn;
-    const float rz = rcp(fmaf(q, nD, 1.f));
-    const float rx = rcp(fmaf(q * vd.inv_g2x, fmaf(vd.az2, J.yy, vd.by2 * nD), 1.f));
-    const float ry = rcp(fmaf(q * vd.inv_g2y, fmaf(vd.az2, J.xx, vd.bx2 * nD), 1.f));
+    const float rz = rcp(tilted ? 1.f + qg : fmaf(q, nD, 1.f));
+    const float rx = rcp(tilted ? fmaf(qg, vd.iso_x, 1.f) : fmaf(q * vd.inv_g2x, fmaf(vd.az2, J.yy, vd.by2 * nD), 1.f));
+    const float ry = rcp(tilted ? fmaf(qg, vd.iso_y, 1.f) : fmaf(q * vd.inv_g2y, fmaf(vd.az2, J.xx, vd.bx2 * nD), 1.f));
     // world velocity += R (dv_b + h w x v_b)
     const V3 dv = v3(fmaf(vd.h, c.x, x1), fmaf(vd.h, c.y, x2), fmaf(ha.z, rz, hrot.z));
     s.v = v3(fmaf(R.r0.x, dv.x, fmaf(R.r0.y, dv.y, fmaf(R.r0.z, dv.z, s.v.x))), fmaf(R.r1.x, dv.x, fmaf(R.r1.y, dv.y, fmaf(R.r1.z, dv.z, s.v.y))),

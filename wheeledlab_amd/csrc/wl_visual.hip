@@ -666,7 +666,7 @@ int check_visual(const WlVisualParams* p, const WlEnvBuffers* b, const WlTravMap
     if (b->stride * 4 * WL_S_COUNT > 0x7fffffffLL || (b->lanes != 0 && b->lanes != 1 && b->lanes != 4)) return WL_EINVAL;
     if (!flags_ok(b)) return WL_EINVAL;
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f) || m->rows <= 0 || m->cols <= 0) return WL_EINVAL;
-    if (p->vehicle.implicit != 1) return WL_EINVAL;   // these kernels step the linearly implicit integrator (wl_vehicle.h)
+    if (p->vehicle.implicit != 1 || !(p->vehicle.susp_fmax > 0.f)) return WL_EINVAL;   // these kernels step the linearly implicit integrator (wl_vehicle.h)
     return WL_OK;
 }
 

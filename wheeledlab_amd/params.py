@@ -25,6 +25,7 @@ def mushr_vehicle(drive: int = 0, motor_limit: float = 0.5, substeps: int = 1,
     v.gyr_x, v.gyr_y, v.gyr_z = 0.06, 0.12, 0.13
     v.wheel_inertia, v.wheel_damping = 8e-5, 1e-4
     v.susp_k, v.susp_c = k, 60.0
+    v.susp_fmax = 24.0 * MUSHR_NOMINAL_MASS * g / 4.0   # 200 N: 24 x the static wheel load = 6.7 cm of penetration, more than the wheel's radius (designed; see include/wheeledlab_amd.h)
     v.ground_mu_s, v.ground_mu_d = ground_mu        # mushr_drift_env_cfg.py:45-50 ("multiply" combine)
     v.slip_peak, v.v_min = 0.12, 0.25
     v.motor_sat, v.motor_limit, v.motor_vel_limit = 1.05, motor_limit, 450.0   # hound.py:13-21, 40-43
