@@ -22,6 +22,7 @@ static inline float __builtin_amdgcn_cosf(float rev) { return (float)std::cos(6.
 static inline float __builtin_amdgcn_logf(float x) { return std::log2(x); }                                         // v_log_f32 is log2
 static inline int __builtin_amdgcn_update_dpp(int, int v, int, int, int, bool) { return v; }   // quad forms are not simulated
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return p ? 1ull : 0ull; }   // a wavefront of one lane
 static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {     // v_alignbit_b32: ({hi, lo} >> sh[4:0])[31:0]
     return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31u));
 }

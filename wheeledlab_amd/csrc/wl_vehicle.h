@@ -405,6 +405,9 @@ WL_DEV void pose_integrate(const VehDerived& vd, VehState& s) {
     s.q = Quat{nw * inv_n, nx * inv_n, ny * inv_n, nz * inv_n};
 }
 
+// true for every lane if `p` holds in ANY lane of the wavefront (a scalar branch condition)
+WL_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
 // semi-implicit Euler of the rigid body under the summed contact force Fb / torque Tb about the CoM (BODY frame);
 // Fz_w: world z component of the contact force where the caller knows it without R (flat ground: the sum of the loads).
 // The inertia tensor is m diag(gyr^2): h / I = (h / m) / gyr^2 and the gyroscopic term w x (I w) / I has the mass
@@ -441,17 +444,25 @@ WL_DEV void body_integrate_implicit(const VehDerived& vd, const EnvConst& ec, Ve
     const V3 t = q * Tb;
     const V3 hal = v3(fmaf(vd.inv_g2x, t.x, -vd.cgx * (w.y * w.z)), fmaf(vd.inv_g2y, t.y, -vd.cgy * (w.z * w.x)),
                       fmaf(vd.inv_g2z, t.z, -vd.cgz * (w.x * w.y)));
+    const float nD = J.nc * vd.Dn;
+    // in-plane: LDL^T of [1 + q Jxx, q Jxy, q Jxw; ., 1 + q Jyy, q Jyw; ., ., 1 + q Jww] (identity + PSD: no pivoting); heave / roll /
+    // pitch: the diagonal
+    float a11 = fmaf(q, J.xx, 1.f), a12 = q * J.xy, a13 = q * J.xw, a22 = fmaf(q, J.yy, 1.f), a23 = q * J.yw, a33 = fmaf(q, J.ww, 1.f);
+    float dz = fmaf(q, nD, 1.f), dx = fmaf(q * vd.inv_g2x, fmaf(vd.az2, J.yy, vd.by2 * nD), 1.f),
+          dy = fmaf(q * vd.inv_g2y, fmaf(vd.az2, J.xx, vd.bx2 * nD), 1.f);
     // The nominal geometry is that of a car standing on its wheels.  Tilted by more than ~40 degrees (world up in the body frame,
     // R.r2.z < 0.75: on its side, on its roof, tumbling -- the visual task has no rollover termination) G^ falls back to an isotropic
     // bound that over-estimates the damping matrix whatever the geometry: g = 2 (sum of kx + ky + contact damping) on every
-    // translation, g rho^2 on every rotation (oracle/vehicle.py::implicit_body_update).
+    // translation, g rho^2 on every rotation (oracle/vehicle.py::implicit_body_update).  Behind a wavefront-uniform branch: no car of
+    // a wavefront is tilted in all but a few launches, and the 15 instructions of the fallback then cost one ballot.
     const bool tilted = R.r2.z < 0.75f;
-    const float nD = J.nc * vd.Dn;
-    const float qg = q * (2.f * (J.xx + J.yy + nD));
-    // in-plane: LDL^T of [1 + q Jxx, q Jxy, q Jxw; ., 1 + q Jyy, q Jyw; ., ., 1 + q Jww] (identity + PSD: no pivoting)
-    const float qo = tilted ? 0.f : q;
-    const float a11 = tilted ? 1.f + qg : fmaf(q, J.xx, 1.f), a12 = qo * J.xy, a13 = qo * J.xw, a22 = tilted ? 1.f + qg : fmaf(q, J.yy, 1.f),
-                a23 = qo * J.yw, a33 = tilted ? fmaf(qg, vd.iso_z, 1.f) : fmaf(q, J.ww, 1.f);
+    if (wave_any(tilted)) {
+        const float qg = q * (2.f * (J.xx + J.yy + nD));
+        const float iso = 1.f + qg;
+        a11 = tilted ? iso : a11, a22 = tilted ? iso : a22, a33 = tilted ? fmaf(qg, vd.iso_z, 1.f) : a33;
+        a12 = tilted ? 0.f : a12, a13 = tilted ? 0.f : a13, a23 = tilted ? 0.f : a23;
+        dz = tilted ? iso : dz, dx = tilted ? fmaf(qg, vd.iso_x, 1.f) : dx, dy = tilted ? fmaf(qg, vd.iso_y, 1.f) : dy;
+    }
     const float b1 = ha.x, b2 = ha.y, b3 = hal.z * vd.gz;
     const float i1 = rcp(a11);
     const float l21 = a12 * i1, l31 = a13 * i1;
@@ -466,9 +477,7 @@ WL_DEV void body_integrate_implicit(const VehDerived& vd, const EnvConst& ec, Ve
     const float x2 = fmaf(y2, i2, -(l32 * x3));
     const float x1 = fmaf(b1, i1, fmaf(-l21, x2, -(l31 * x3)));
     // heave / roll / pitch: diagonal
-    const float rz = rcp(tilted ? 1.f + qg : fmaf(q, nD, 1.f));
-    const float rx = rcp(tilted ? fmaf(qg, vd.iso_x, 1.f) : fmaf(q * vd.inv_g2x, fmaf(vd.az2, J.yy, vd.by2 * nD), 1.f));
-    const float ry = rcp(tilted ? fmaf(qg, vd.iso_y, 1.f) : fmaf(q * vd.inv_g2y, fmaf(vd.az2, J.xx, vd.bx2 * nD), 1.f));
+    const float rz = rcp(dz), rx = rcp(dx), ry = rcp(dy);
     // world velocity += R (dv_b + h w x v_b)
     const V3 dv = v3(fmaf(vd.h, c.x, x1), fmaf(vd.h, c.y, x2), fmaf(ha.z, rz, hrot.z));
     s.v = v3(fmaf(R.r0.x, dv.x, fmaf(R.r0.y, dv.y, fmaf(R.r0.z, dv.z, s.v.x))), fmaf(R.r1.x, dv.x, fmaf(R.r1.y, dv.y, fmaf(R.r1.z, dv.z, s.v.y))),
