@@ -13,6 +13,8 @@ using std::min;
 static thread_local int g_steps, g_fine_mask_step;
 static thread_local std::vector<uint8_t>* g_trace;       // per step of the current ray: 1 = fine cell
 #define WL_DEPTH_STEP_HOOK(L) (g_trace->push_back((L) == 0 ? 1 : 0))
+static thread_local int g_clear_prefix;            // leading steps of the current ray whose cell was cleared (-1 - count once one was not)
+#define WL_DEPTH_CLEAR_HOOK(clear, t, te) (g_clear_prefix = g_clear_prefix < 0 ? g_clear_prefix : ((clear) ? g_clear_prefix + 1 : -1 - g_clear_prefix))
 #include "wl_depth_dev.h"
 
 static std::vector<float> host_pyramid(const WlHeightField* hf) {
@@ -93,6 +95,38 @@ int dws_stats(const WlVisualParams* p, const WlHeightField* hf, int n, const flo
             }
     }
     out[0] = rays, out[1] = ray_steps, out[2] = tiles, out[3] = wave_steps, out[4] = fine_wave_steps, out[5] = fine_ray_steps;
+    return 0;
+}
+// round 6: what a tile-cooperative start could skip at most.  out[0..1]: the sum over the tiles of the number of leading CLEAR steps
+// every ray of the tile shares (the minimum over its rays of the steps before the ray's first not-clear test), the tiles' wave-steps
+int dws_shared_prefix(const WlVisualParams* p, const WlHeightField* hf, int n, const float* pos, const float* quat, float max_depth, double* out) {
+    const Pyramid py = make_pyramid(hf->nx, hf->ny);
+    const std::vector<float> buf = host_pyramid(hf);
+    const DepthGrid g = make_depth_grid(hf);
+    const FieldMem mem{buf.data()};
+    const PyrHead hd = pyramid_head(g, py, mem);
+    std::vector<uint8_t> tr;
+    double shared = 0, wave_steps = 0;
+    for (int e = 0; e < n; ++e) {
+        const Quat q{quat[4 * e], quat[4 * e + 1], quat[4 * e + 2], quat[4 * e + 3]};
+        const Mat3 R = mat_from_quat(q);
+        const V3 o = v3(pos[3 * e], pos[3 * e + 1], pos[3 * e + 2]) + mul(R, v3(p->cam_pos[0], p->cam_pos[1], p->cam_pos[2]));
+        for (int tile = 0; tile < 75; ++tile) {
+            const int strip = tile / 5, tc = tile % 5;
+            int longest = 0, prefix = 1 << 30;
+            for (int lane = 0; lane < 64; ++lane) {
+                tr.clear();
+                g_trace = &tr;
+                g_clear_prefix = 0;
+                (void)cast_ray(g, py, hd, mem, o, mul(R, depth_pixel_ray_body(*p, strip * 4 + (lane >> 4), tc * 16 + (lane & 15))), max_depth);
+                longest = std::max(longest, (int)tr.size());
+                if (!tr.empty()) prefix = std::min(prefix, g_clear_prefix < 0 ? -1 - g_clear_prefix : g_clear_prefix);
+            }
+            wave_steps += longest;
+            shared += longest ? std::min(prefix, longest) : 0;
+        }
+    }
+    out[0] = shared, out[1] = wave_steps;
     return 0;
 }
 }

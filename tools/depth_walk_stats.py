@@ -36,3 +36,8 @@ rays, ray_steps, tiles, wave_steps, fine_ws, fine_rs = list(out)
 print(f"images {len(pos)}  far {far:g} m   steps/ray {ray_steps / rays:.2f}   wave-steps/tile {wave_steps / tiles:.2f}   "
       f"lanes busy {ray_steps / (64 * wave_steps):.3f}   wave-steps with a fine lane {fine_ws / wave_steps:.3f}   "
       f"fine ray-steps {fine_rs / ray_steps:.3f} of ray-steps, lanes active in them {fine_rs / (64 * max(fine_ws, 1)):.3f}")
+sp = (C.c_double * 2)()
+lib.dws_shared_prefix.argtypes = lib.dws_stats.argtypes
+lib.dws_shared_prefix(C.byref(vp), C.byref(hfs), len(pos), pos.ctypes.data, quat.ctypes.data, far, sp)
+print(f"leading clear steps shared by ALL rays of a tile (what a tile-cooperative start could skip at most): {sp[0] / tiles:.2f} of {sp[1] / tiles:.2f} "
+      f"wave-steps per tile ({100 * sp[0] / sp[1]:.1f} %)")

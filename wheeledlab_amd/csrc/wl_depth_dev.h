@@ -194,6 +194,9 @@ WL_DEV float plane_hit(float oz, float dz, float zp, float ta, float tb) {
 #ifndef WL_DEPTH_STEP_HOOK
 #define WL_DEPTH_STEP_HOOK(L)       // host instrumentation (walk steps per ray): nothing in the device build
 #endif
+#ifndef WL_DEPTH_CLEAR_HOOK
+#define WL_DEPTH_CLEAR_HOOK(clear, t, te)   // host instrumentation: nothing in the device build
+#endif
 #ifndef WL_DEPTH_START_LEVEL
 #define WL_DEPTH_START_LEVEL 4      // falling rays
 #endif
@@ -339,6 +342,7 @@ WL_DEV void ray_step(const DepthGrid& g, const Pyramid& py, const PyrHead& hd, c
         // margin: the rounding of g itself (the products can be hundreds of times the ray's clearance on steep, far cells)
         clear = fminf(fmaf(t, g1, g0), fmaf(te, g1, g0)) > fmaf(4e-7f, fabsf(au) + fabsf(bv), 1e-5f);
     }
+    WL_DEPTH_CLEAR_HOOK(clear, t, te);
     if (!clear) {      // the ray may touch something in this cell
         if (!fine) {
             w.L = L - 1;
