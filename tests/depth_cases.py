@@ -41,13 +41,16 @@ def on_lattice(field, z_scale=None):
 
 
 def hf_struct(field, outside_z=0.0, z_scale=None):
-    """-> (WlHeightField over the field's height codes, the codes array that must stay alive while the struct is used)"""
+    """-> (WlHeightField over the field's height codes and row-pair table, the arrays that must stay alive while the struct is used)"""
     from wheeledlab_amd import _abi
     from wheeledlab_amd.terrain import quantize_heights
     codes, zs = quantize_heights(field[0], z_scale)
     codes = np.ascontiguousarray(codes)
+    # the row-pair table (ABI 23), the header's definition in numpy: pair[j][i] = code[j][i] | code[min(j + 1, ny - 1)][i] << 16
+    up = np.concatenate([codes[1:], codes[-1:]], 0)
+    pairs = np.ascontiguousarray(codes.astype(np.uint16).astype(np.uint32) | (up.astype(np.uint16).astype(np.uint32) << 16))
     return _abi.WlHeightField(codes.ctypes.data, codes.shape[1], codes.shape[0], float(field[1]), float(field[2]), float(field[3]),
-                              float(outside_z), zs), codes
+                              float(outside_z), zs, pairs.ctypes.data), (codes, pairs)
 
 
 def poses(n, seed, hf=None, span=17.5, tilt=0.15, edge=True):

@@ -292,3 +292,23 @@ def test_settled_cars_need_no_contact_excuse(lanes, terrain):
         assert d[:, :13].max() < 3e-3 and (d[:, 13:] > 2e-3).sum() <= 4
     assert excused <= 6, excused                                              # 0.05 % of the 24 x 512 env-steps; each one explained (round 5: up to 12, by a count)
     assert float(np.abs(env.state[7:9, :n].cpu().numpy()).mean()) > 0.05     # they do drive
+
+
+def test_row_pair_table_is_what_the_header_says():
+    """WlHeightField.pair (ABI 23): wl_heightfield_pairs on the device == the header's definition restated in torch (core.pair_table);
+    the elevation entry points refuse a field without it (the height scan gathers a cell's four corners from it in one request)."""
+    from wheeledlab_amd import _abi as A
+    from wheeledlab_amd.core import DeviceHeightField, ElevBatch, pair_table
+    g = torch.Generator().manual_seed(3)
+    codes = torch.randint(-32767, 32768, (37, 52), generator=g, dtype=torch.int32).to(torch.int16)
+    hf = DeviceHeightField((codes, -1.0, -1.0, 0.05, 2.0 ** -13), "cuda:0")
+    want = pair_table(codes)
+    assert torch.equal(hf.pairs.cpu(), want)
+    lo, hi = (want & 0xffff).to(torch.int16), (want >> 16).to(torch.int16)
+    assert torch.equal(lo, codes) and torch.equal(hi[:-1], codes[1:]) and torch.equal(hi[-1], codes[-1])
+    env = ElevBatch(64, device="cuda:0", seed=1)
+    env.reset()
+    bare = A.WlHeightField(env._hf.height, env._hf.nx, env._hf.ny, env._hf.x0, env._hf.y0, env._hf.cell, env._hf.outside_z, env._hf.z_scale)
+    out = torch.empty(64, 689, device="cuda:0")
+    rc = env.lib.wl_elev_observe(C.byref(env.p), C.byref(env._bufs), C.byref(bare), out.data_ptr(), None)
+    assert rc == -1      # WL_EINVAL

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-WL_ABI_VERSION = 22
+WL_ABI_VERSION = 23
 WL_MAX_REW_TERMS = 8
 
 # WlStateField
@@ -76,7 +76,7 @@ class WlDriftParams(C.Structure):
 
 class WlHeightField(C.Structure):
     _fields_ = [("height", C.c_void_p), ("nx", C.c_int32), ("ny", C.c_int32), ("x0", C.c_float), ("y0", C.c_float),
-                ("cell", C.c_float), ("outside_z", C.c_float), ("z_scale", C.c_float)]
+                ("cell", C.c_float), ("outside_z", C.c_float), ("z_scale", C.c_float), ("pair", C.c_void_p)]
 
 
 class WlElevParams(C.Structure):
@@ -240,6 +240,7 @@ SIGNATURES = {
     "wl_visual_reset": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _u64, _u64, _vp]),
     "wl_visual_observe": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlTravMap), _vp, _vp]),
     "wl_visual_mdp": (C.c_int, [_P(WlVisualParams), _P(WlTravMap), _i32, _i64] + [_vp] * 7),
+    "wl_heightfield_pairs": (C.c_int, [_P(WlHeightField), _vp, _vp]),
     "wl_heightfield_pyramid_floats": (C.c_int64, [_i32, _i32]),
     "wl_heightfield_build_pyramid": (C.c_int, [_P(WlHeightField), _vp, _vp]),
     "wl_visual_depth": (C.c_int, [_P(WlVisualParams), _P(WlEnvBuffers), _P(WlHeightField), _vp, C.c_float, _vp, _vp]),

@@ -54,6 +54,14 @@ def _canonical_device(device) -> torch.device:
     return d
 
 
+def pair_table(codes: torch.Tensor) -> torch.Tensor:
+    """WlHeightField.pair as the header defines it: pair[j][i] = code[j][i] (low half) | code[min(j + 1, ny - 1)][i] << 16, int32
+    [ny, nx] (what wl_heightfield_pairs builds on the device; here in torch, for host-side fields and as the test's definition)"""
+    c = codes.to(torch.int32)
+    up = torch.cat([c[1:], c[-1:]], 0)
+    return ((c & 0xffff) | (up << 16)).to(torch.int32).contiguous()
+
+
 class DeviceHeightField:
     """A heightfield resident on the device as the kernels read it (WlHeightField, ABI 21): 16-bit height codes [ny, nx] and the
     vertical scale, z = code * z_scale.  `heightfield` is `(height, x0, y0, cell)` with float heights (quantised: terrain.
@@ -68,7 +76,7 @@ class DeviceHeightField:
             src = heightfield
             if src.device != self.device:
                 raise ValueError(f"a DeviceHeightField lives on {src.device}; it cannot be shared with {self.device}")
-            self.codes, self.z_scale, self.heights = src.codes, src.z_scale, src.heights
+            self.codes, self.z_scale, self.heights, self.pairs = src.codes, src.z_scale, src.heights, src.pairs
             self.x0, self.y0, self.cell = src.x0, src.y0, src.cell
         else:
             h, x0, y0, cell, *rest = heightfield
@@ -93,9 +101,19 @@ class DeviceHeightField:
                 raise ValueError("heightfield: a [ny, nx] grid and a positive, finite z_scale")
             self.heights = self.codes.to(torch.float32) * torch.tensor(self.z_scale, dtype=torch.float32, device=self.device)
             self.x0, self.y0, self.cell = float(x0), float(y0), float(cell)
+            self.pairs = None
         self.outside_z = float(outside_z)
         ny, nx = self.codes.shape
-        self.struct = A.WlHeightField(self.codes.data_ptr(), nx, ny, self.x0, self.y0, self.cell, self.outside_z, self.z_scale)
+        self.struct = A.WlHeightField(self.codes.data_ptr(), nx, ny, self.x0, self.y0, self.cell, self.outside_z, self.z_scale, None)
+        if self.pairs is None:
+            # the row-pair table the height scan gathers from (WlHeightField.pair, ABI 23): built on the device by the library
+            if self.device.type == "cuda":
+                self.pairs = torch.empty((ny, nx), dtype=torch.int32, device=self.device)
+                A.check(A.load().wl_heightfield_pairs(C.byref(self.struct), self.pairs.data_ptr(),
+                                                      C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "wl_heightfield_pairs")
+            else:
+                self.pairs = pair_table(self.codes)
+        self.struct.pair = self.pairs.data_ptr()
 
     def as_tuple(self):
         """(decoded heights, x0, y0, cell): the form the oracle's functions take"""

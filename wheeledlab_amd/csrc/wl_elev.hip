@@ -23,6 +23,19 @@
 //      already hidden behind it.)
 #include <hip/hip_runtime.h>
 
+// Debug builds only (tools/build_variants.sh ... -DWL_FUSED_TIMELINE=1; tools/fused_timeline.py): lane 0 of a wavefront stamps
+// the 100 MHz wall clock into wl_timeline[block][slot] at the phase boundaries of the fused step + scan launch.
+#ifndef WL_FUSED_TIMELINE
+#define WL_FUSED_TIMELINE 0
+#endif
+#if WL_FUSED_TIMELINE
+__device__ unsigned long long wl_timeline[2048][16];
+#define WL_TL(slot) do { if ((threadIdx.x & 63) == 0) wl_timeline[blockIdx.x & 2047][slot] = wall_clock64(); } while (0)
+#else
+#define WL_TL(slot) do { } while (0)
+#endif
+
+
 #include "../../include/wheeledlab_amd.h"
 #include "wl_kernel_common.h"
 #include "wl_actor_dev.h"
@@ -182,30 +195,35 @@ WL_DEV ScanCell scan_cell(const ScanFrame& f, const WlHeightField& hf, float fix
     c.i = i, c.j = j;
     return c;
 }
-// a ray in flight: the two 4-byte gathers of its cell's corners (issued by scan_request: two 16-bit height codes each), decoded
-// and consumed by scan_value
+// a ray in flight: the gather(s) of its cell's four corner codes, decoded and consumed by scan_value.
+// PAIR (the gather forms, round 6): ONE 8-byte gather from the row-pair table (WlHeightField.pair): lo = (c00 | c01 << 16), hi = (c10 |
+// c11 << 16).  The gather forms were bound by the texture unit's address rate -- rocprofv3 on the fused launch at 4096 envs: TA busy
+// 16 000 cycles per CU = the whole scan phase, 57 cache accesses per 64-lane gather instruction, L1 hit rate 0.91 -- and a ray cost
+// two of them (rows j and j + 1 of the code field); with the pair table it costs one (measured: fused step 20.5 -> 17.5 us, gather-form
+// scan at 262 144 envs 484 -> 319 us).  !PAIR (the LDS patch form, which reads the code field's rows): lo = codes (i, i + 1) of row j,
+// hi = of row j + 1, low half = the first.
 struct ScanRay {
-    uint32_t lo, hi;      // codes (i, i + 1) of rows j and j + 1: low half = the first
+    uint32_t lo, hi;
     float fu, fv;
     bool inside;
 };
-struct ScanField {   // the heightfield through a buffer resource: one 32-bit lane offset per gather
+struct ScanField {   // the row-pair table through a buffer resource: one 32-bit lane offset per gather
     __amdgpu_buffer_rsrc_t rsrc;
-    int row_bytes;
     float z_scale;
 };
 WL_DEV ScanField scan_field(const WlHeightField& hf) {
-    return ScanField{__builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t*>(hf.height), 0, hf.nx * hf.ny * 2, 0x00020000), hf.nx * 2, hf.z_scale};
+    return ScanField{__builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(hf.pair), 0, hf.nx * hf.ny * 4, 0x00020000), hf.z_scale};
 }
 WL_DEV ScanRay scan_request(const ScanFrame& f, const WlHeightField& hf, const ScanField& sf, float fix, float fiy) {
+    typedef unsigned wl_u2 __attribute__((ext_vector_type(2)));
     const ScanCell c = scan_cell(f, hf, fix, fiy);
     ScanRay r;
     r.fu = c.fu, r.fv = c.fv, r.inside = c.inside;
     // a ray outside the field asks for whatever address its cell index wraps to: inside the buffer it reads a value nobody uses
-    // (the ray is a miss), outside it the resource's bounds check returns 0 -- four clamps per ray saved
-    const int idx2 = (c.j * hf.nx + c.i) * 2;       // 2-byte aligned dword requests: see wl_heightfield.h
-    r.lo = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sf.rsrc, idx2, 0, 0);
-    r.hi = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sf.rsrc, idx2, sf.row_bytes, 0);
+    // (the ray is a miss), outside it the resource's bounds check returns 0 -- four clamps per ray saved.  24-bit multiply (full
+    // rate; v_mul_lo_u32 is a quarter-rate instruction): exact for every ray inside the field (check_elev: nx, ny < 2^23)
+    const wl_u2 w = __builtin_amdgcn_raw_buffer_load_b64(sf.rsrc, (__mul24(c.j, hf.nx) + c.i) * 4, 0, 0);
+    r.lo = w.x, r.hi = w.y;
     return r;
 }
 // FOUR consecutive rays per lane, stored as ONE 16-byte word (round 4).  The scan's 676 four-byte stores per env were what bound
@@ -223,12 +241,15 @@ WL_DEV void scan_quad_slot(int idx, int& j, int& q) {
 }
 // bilinear height under the ray -> the observation value: -(sensor_z - hit_z - offset) + (root_z - plane_init_value), +inf on a
 // miss, clipped to +- obs_clip
+template <bool PAIR = true>
 WL_DEV float scan_value(const WlElevParams& p, const ScanRay& r, float z_scale, float pz) {
     // the blend runs on the CODES and is scaled once (3 instructions per ray fewer than decoding the four corners first; the large-batch
     // scan is VALU-bound since round 5).  Exactly the decode-first value when z_scale is a power of two (terrain.py's default: scaling
     // by 2^k commutes with every rounding); for other scales it differs from it in the last bit -- every scan form shares this function
-    const float c00 = (float)(int)(int16_t)(r.lo & 0xffffu), c10 = (float)((int)r.lo >> 16);
-    const float c01 = (float)(int)(int16_t)(r.hi & 0xffffu), c11 = (float)((int)r.hi >> 16);
+    // (codes are < 2^15 in magnitude: their differences are exact in either layout, so both give the same bits)
+    const float lo0 = (float)(int)(int16_t)(r.lo & 0xffffu), lo1 = (float)((int)r.lo >> 16);
+    const float hi0 = (float)(int)(int16_t)(r.hi & 0xffffu), hi1 = (float)((int)r.hi >> 16);
+    const float c00 = lo0, c10 = PAIR ? hi0 : lo1, c01 = PAIR ? lo1 : hi0, c11 = hi1;
     const float a = fmaf(r.fu, c10 - c00, c00), b = fmaf(r.fu, c11 - c01, c01);
     float hz;
     {
@@ -238,7 +259,7 @@ WL_DEV float scan_value(const WlElevParams& p, const ScanRay& r, float z_scale, 
     const float val = r.inside ? (-(pz - hz - p.scan_offset) + (pz - p.elev_z0)) : __builtin_inff();
     return clampf(val, -p.obs_clip, p.obs_clip);
 }
-// the gathers of the four rays of quad q (8 x 4 B in flight per lane) ...
+// the gathers of the four rays of quad q (4 x 8 B in flight per lane) ...
 WL_DEV void scan_quad_request(const ScanFrame& f, const WlHeightField& hf, const ScanField& sf, int q, ScanRay (&r)[4]) {
     float fx0, fy0, fx2, fy2;
     scan_ray_xy(4 * q, fx0, fy0);
@@ -249,10 +270,11 @@ WL_DEV void scan_quad_request(const ScanFrame& f, const WlHeightField& hf, const
     r[3] = scan_request(f, hf, sf, fx2 + 1.f, fy2);
 }
 // ... and their four values as one 16-byte word
+template <bool PAIR = true>
 WL_DEV wl_float4_u scan_quad_value(const WlElevParams& p, const ScanRay (&r)[4], float z_scale, float pz) {
     wl_float4_u v;
-    v.x = scan_value(p, r[0], z_scale, pz), v.y = scan_value(p, r[1], z_scale, pz), v.z = scan_value(p, r[2], z_scale, pz);
-    v.w = scan_value(p, r[3], z_scale, pz);
+    v.x = scan_value<PAIR>(p, r[0], z_scale, pz), v.y = scan_value<PAIR>(p, r[1], z_scale, pz), v.z = scan_value<PAIR>(p, r[2], z_scale, pz);
+    v.w = scan_value<PAIR>(p, r[3], z_scale, pz);
     return v;
 }
 #ifndef WL_FUSED_SCAN_NT
@@ -419,7 +441,9 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
         const HeightFieldGroundCached cached(ground);
         vehicle_integrate<LANES, HeightFieldGroundCached, true, -1, true>(vp, vd, ec, s, cached, wid);
     } else {
+        if constexpr (LANES == 4) WL_TL(1);
         vehicle_integrate<LANES, HeightFieldGround, true, -1, true>(vp, vd, ec, s, ground, wid);
+        if constexpr (LANES == 4) WL_TL(2);
     }
     if constexpr (LANES != 4) {
         asm volatile("" ::: "memory");
@@ -719,7 +743,7 @@ __global__ void __launch_bounds__(THREADS) elev_scan_lds_kernel(const WlElevPara
             cr[m].hi = __builtin_amdgcn_alignbit(h[PITCH / 2 + 1], h[PITCH / 2], sh);
             cr[m].fu = cell.fu, cr[m].fv = cell.fv, cr[m].inside = cell.inside;
         }
-        scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value(p, cr, f.z_scale, fr.pz));
+        scan_quad_store<STREAM>(obs + (int64_t)e * WL_ELEV_OBS_DIM + 13, tid, scan_quad_value<false>(p, cr, f.z_scale, fr.pz));
     }
 }
 // the staged patch must hold the footprint's bounding box at any yaw; 16-byte staging requests need an even row pitch (and the
@@ -790,6 +814,7 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     __shared__ __attribute__((aligned(16))) float hbuf[POLICY ? 2 * 3 * kMlpTiles * 64 * 4 : 4];   // partial accumulators [net][share - 1][tile][lane][4]
     __shared__ float2 act_lds[kFusedEnvs];
     const int tid = threadIdx.x;
+    if (tid < 64) WL_TL(0);
     if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
     if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
@@ -923,10 +948,13 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
                 vd.n_sub = vd_arg.n_sub;
                 const ScanPose sp = elev_env_step<4>(p, vd, b, ground, a, rows, out, seed, step, S, e, wid, wid == 0, blk_metrics);
                 if (wid == 0) frame[tid >> 2] = scan_frame(p, ground, sp);
+                WL_TL(3);
             }
         }
     }
     __syncthreads();
+    if (tid < 64) WL_TL(4);
+    if (tid >= kFusedThreads - 64) WL_TL(8);
     if (tid < WL_M_COUNT) {
         const float m = blk_metrics[tid];
         if (m != 0.f) atomicAdd(metric_shard(b, m_slot) + tid, m);
@@ -935,14 +963,19 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     const WlElevParams& p = p_arg;
     const int n_here = min(kFusedEnvs, b.n_envs - e0);
     const ScanField sf = scan_field(ground.f);
-    // flat index over (env, quad of rays): 16 x 169 quads / 512 lanes = 5.3 per lane, ONE quad (8 gathers) per batch: request,
-    // blend, store, next.  (Rounds 2 - 3, single rays: 1 / 2 / 3 batches of gathers 28.4 / 26.2 / 25.9 us per step at 4096 envs.
-    // Round 6, after the physics went to 10 sub-steps, same box: 1 / 2 / 3 / 6 batches 21.4 / 21.3 / 21.3 / 20.2 us -- what the phase
-    // waits for is its STORES (the launch without them: 15.0 us; without the whole phase: 13.2): 11.3 MB leave all 256 CUs in one burst
-    // at the end of the launch and the launch ends when the last one is acknowledged, so the sooner the first rows are written the
-    // better.  Measured and dropped in round 6: a wavefront per env with the rays in 7 x 9 blocks of neighbours (40 % fewer distinct
-    // cache lines per gather instruction, values transposed through LDS into the same 16-byte stores): 21.1 us -- the gathers were
-    // never the cost.)
+    // flat index over (env, quad of rays): 16 x 169 quads / 512 lanes = 5.3 per lane, ONE quad (4 eight-byte gathers) per batch:
+    // request, blend, store, next.  (Rounds 2 - 3, single rays: 1 / 2 / 3 batches of gathers 28.4 / 26.2 / 25.9 us per step at 4096
+    // envs; round 6, 10 sub-steps: 1 / 2 / 3 / 6 batches 21.4 / 21.3 / 21.3 / 20.2 us.)
+    // What bounds the phase (round 6, tools/fused_timeline.py: wall-clock stamps inside the launch; tools/tcp_pass.sh: TA / TCP
+    // counters): NOT its stores -- 0.2 - 0.4 us from a wavefront's last store to its acknowledgement; 11.3 MB written with nothing
+    // in front of them cost 1.8 - 2.9 us on top of an empty launch (tools/microbench/row_burst.hip), and that overlaps the phase --
+    // but the TEXTURE UNIT's address rate: with two 4-byte gathers per ray the phase took 6.1 - 6.8 us, the unit was busy 16 000
+    // cycles per CU (all of it), 57 cache accesses per 64-lane gather instruction, L1 hit rate 0.91.  One 8-byte gather per ray
+    // (the row-pair table): 4.2 - 4.4 us, what its ~1100 vector instructions per wavefront (two wavefronts per SIMD) cost to issue.
+    // Measured and dropped in round 6: the same loop software-pipelined (quad k + 1 requested before quad k is blended and stored:
+    // 21.0 against 20.5 us, and 19.1 against 18.6 with the pair table -- the older wavefronts of a SIMD run ahead and the younger
+    // ones finish alone); store cache policies sc1 / nt / write-through (equal); a wavefront per env with the rays in 7 x 9 blocks of
+    // neighbours (21.1 us).
     constexpr int kAll = kFusedEnvs * kScanQuads;
 #ifndef WL_FUSED_SCAN_BATCHES
 #define WL_FUSED_SCAN_BATCHES 6
@@ -969,6 +1002,13 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
             if (idx < kAll && j < n_here) scan_quad_store<WL_FUSED_SCAN_NT>(out.obs + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], sf.z_scale, pz[i]));
         }
     }
+#if WL_FUSED_TIMELINE
+    if (tid < 64) WL_TL(5);
+    if (tid >= kFusedThreads - 64) WL_TL(9);
+    __builtin_amdgcn_s_waitcnt(0);
+    if (tid < 64) WL_TL(6);
+    if (tid >= kFusedThreads - 64) WL_TL(10);
+#endif
 }
 
 // K env.step()s in ONE launch with pre-staged actions [K][n][2] (open-loop rollouts: sampling-based planners, system
@@ -1394,13 +1434,37 @@ int check_elev(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField
     if (p->decimation <= 0 || p->vehicle.substeps <= 0 || !(p->sim_dt > 0.f)) return WL_EINVAL;
     if (p->vehicle.implicit != 1 || !(p->vehicle.susp_fmax > 0.f)) return WL_EINVAL;   // these kernels step the linearly implicit integrator (wl_vehicle.h)
     if (hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f && hf->z_scale < INFINITY)) return WL_EINVAL;
+    if (!hf->pair || (int64_t)hf->nx * hf->ny * 4 > 0x7fffffffLL || hf->nx >= (1 << 23) || hf->ny >= (1 << 23)) return WL_EINVAL;   // wl_heightfield_pairs
+    if ((uintptr_t)hf->pair & 3u) return WL_EALIGN;
     return WL_OK;
+}
+
+// pair[j][i] = code[j][i] | code[min(j + 1, ny - 1)][i] << 16
+__global__ void __launch_bounds__(256) heightfield_pairs_kernel(const int16_t* __restrict__ height, uint32_t* __restrict__ pair, int nx, int ny) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= (int64_t)nx * ny) return;
+    const int64_t up = k + nx < (int64_t)nx * ny ? k + nx : k;
+    pair[k] = (uint32_t)(uint16_t)height[k] | (uint32_t)(uint16_t)height[up] << 16;
 }
 
 
 }  // namespace
 
 extern "C" {
+#if WL_FUSED_TIMELINE
+int wl_debug_fused_timeline(unsigned long long* host_dst /* [2048][16] */) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(wl_timeline), sizeof(unsigned long long) * 2048 * 16);
+}
+#endif
+
+int wl_heightfield_pairs(const WlHeightField* hf, uint32_t* pair_out, void* stream) {
+    if (!hf || !hf->height || !pair_out || hf->nx < 2 || hf->ny < 2) return WL_EINVAL;
+    if ((uintptr_t)pair_out & 3u) return WL_EALIGN;
+    clear_error();
+    const int64_t n = (int64_t)hf->nx * hf->ny;
+    heightfield_pairs_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(hf->height, pair_out, hf->nx, hf->ny);
+    return launch_status();
+}
 
 int wl_elev_step(const WlElevParams* p, const WlEnvBuffers* b, const WlHeightField* hf, const float* actions,
                  const WlStepOut* out, uint64_t seed, uint64_t step, void* stream) {

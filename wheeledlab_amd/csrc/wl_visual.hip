@@ -765,7 +765,7 @@ int wl_visual_step_hf(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
                       const WlStepOut* out, uint64_t seed, uint64_t step, void* stream) {
     int rc = check_visual(p, b, m);
     if (rc != WL_OK) return rc;
-    if (!hf || !hf->height || hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f && hf->z_scale < INFINITY)) return WL_EINVAL;
+    if (!hf || !hf->height || !hf->pair || hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f && hf->z_scale < INFINITY)) return WL_EINVAL;   // pair: the contact sampler's table (wl_heightfield_pairs)
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated) return WL_EINVAL;
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
     const HeightFieldGround g = make_ground(hf);
@@ -787,7 +787,7 @@ int wl_visual_reset_hf(const WlVisualParams* p, const WlEnvBuffers* b, const WlT
                        uint64_t seed, uint64_t step, void* stream) {
     int rc = check_visual(p, b, m);
     if (rc != WL_OK) return rc;
-    if (!hf || !hf->height || hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f && hf->z_scale < INFINITY)) return WL_EINVAL;
+    if (!hf || !hf->height || !hf->pair || hf->nx < 2 || hf->ny < 2 || !(hf->cell > 0.f) || !(hf->z_scale > 0.f && hf->z_scale < INFINITY)) return WL_EINVAL;   // pair: the contact sampler's table (wl_heightfield_pairs)
     clear_error();
     visual_reset_kernel<HeightFieldGround><<<grid_for(b->n_envs), kBlock, 0, (hipStream_t)stream>>>(*p, *b, *m, mask, seed, step, make_ground(hf));
     return launch_status();
