@@ -775,8 +775,8 @@ def main():
             # dominant kernel alone (the camera: 12 832 B of observation row per env)
             if name == "elevation":
                 other[name]["roofline"] = roofline_block("elev", n, us, "elev_step_scan_kernel" if n <= 32768 else
-                                                         "elev_step_kernel + elev_scan_lds_kernel",
-                                                         "latency (20 dependent integrator sub-steps with terrain gathers)" if n <= 32768 else "hbm+valu",
+                                                         "elev_step_kernel + elev_scan_kernel",
+                                                         "latency (10 dependent integrator sub-steps) + texture-unit address rate (height scan)" if n <= 32768 else "hbm+valu+texture-unit address rate",
                                                          profile_kernels=["elev_step_scan_kernel"] if n == ENVS_PER_GPU else None)
             else:
                 other[name]["roofline"] = roofline_block("visual", n, us, "visual_step_kernel + visual_obs_kernel", "hbm+lds",

@@ -2,7 +2,8 @@
 
 The step / scan / camera launchers switch forms by size: the streaming drift step beyond 1.22 M envs (`sc1 nt` row stores,
 csrc/wl_drift.hip launch_step), non-temporal observation rows of the height scan beyond 97 k envs and of the camera beyond
-20.9 k (wl_elev.hip launch_elev_scan, wl_visual.hip launch_visual_obs), the height scan through LDS patches from 16 384 envs.
+20.9 k (wl_elev.hip launch_elev_scan, wl_visual.hip launch_visual_obs); the height scan through LDS patches is a flag (round 6: with
+the row-pair table the gather form is the faster one at every size and the default).
 bench.py's `large_n_sweep` / `other_tasks_large_n` rows -- the 4 M-env row carries the north-star's HBM fraction -- are
 measured on exactly those forms.  Here:
 

@@ -1,26 +1,28 @@
+# Texture-unit / L1 counters of one workload's kernels (round 6: how the fused elevation launch's scan phase was found to be bound by
+# the texture unit's address rate).  usage (through gpurun): bash tools/tcp_pass.sh <tag> "task:envs:K ..."   e.g. "elev:4096:32 depth:4096:8"
+# Each rocprofv3 --pmc run is its own pass, under `timeout`; per kernel and counter the average over the later half of the dispatches.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06e/tcp; mkdir -p $O
-timeout 60 rocprofv3 -L > $O/avail.txt 2>&1
-grep -o "\bTCP_[A-Z0-9_]*\|\bTA_[A-Z0-9_]*\|\bTD_[A-Z0-9_]*\|\bTCC_[A-Z_]*HIT[A-Z_]*\|\bTCC_[A-Z_]*MISS[A-Z_]*\|\bTCC_REQ[A-Z_]*" $O/avail.txt | sort -u > $O/names.txt
-wc -l $O/names.txt
-pm() { d=$1; shift; c=$1; shift; timeout 120 rocprofv3 --output-format csv --pmc $c -d $O/$d -- "$@" > $O/$d.log 2>&1; echo "$d rc=$?"; }
-export WL_LIB=$R/gpurun_variants/lib_base.so
-pm p1 "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" python $R/tools/pmc_run.py elev 4096 32
-pm p2 "TA_BUSY_avr TA_TA_BUSY_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" python $R/tools/pmc_run.py elev 4096 32
-pm p3 "TCP_TA_TCP_STATE_READ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" python $R/tools/pmc_run.py elev 4096 32
-pm p4 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" python $R/tools/pmc_run.py elev 4096 32
-pm p5 "TA_BUFFER_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" python $R/tools/pmc_run.py elev 4096 32
-pm p6 "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum" python $R/tools/pmc_run.py elev 4096 32
-pm p7 "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD" python $R/tools/pmc_run.py elev 4096 32
-for d in p1 p2 p3 p4 p5 p6 p7; do f=$(find $O/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python3 - $f <<'PY'
-import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
-acc = collections.defaultdict(list)
-for r in rows:
-    if 'elev_step_scan' in r['Kernel_Name']:
-        acc[r['Counter_Name']].append(float(r['Counter_Value']))
-for k, v in acc.items():
-    v = v[len(v)//4:]
-    print(k, 'per launch', sum(v)/len(v), 'n', len(v))
+R=$GRAFT_REPO_ROOT; TAG=${1:-tcp}; O=$R/gpurun_out/$TAG; mkdir -p $O
+WORK=${2:-"elev:4096:32"}
+pm() { d=$1; shift; c=$1; shift; timeout 150 rocprofv3 --output-format csv --pmc $c -d $O/$d -- "$@" > $O/$d.log 2>&1; }
+for w in $WORK; do
+  IFS=: read task n k <<< "$w"
+  pm ${task}_${n}_a "TA_BUSY_avr TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" python $R/tools/pmc_run.py $task $n $k
+  pm ${task}_${n}_b "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" python $R/tools/pmc_run.py $task $n $k
+  pm ${task}_${n}_c "TD_TD_BUSY_sum TD_TC_STALL_sum TCP_PENDING_STALL_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" python $R/tools/pmc_run.py $task $n $k
+  python3 - $O ${task}_${n} <<'PY'
+import csv, sys, collections, glob, json
+O, key = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{O}/{key}_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, cs in acc.items():
+    if not any(s in k for s in ("elev_", "visual_", "drift_", "depth")):
+        continue
+    out[k] = {c: round(sum(v[len(v) // 2:]) / max(len(v[len(v) // 2:]), 1), 1) for c, v in cs.items()}
+    out[k]["dispatches"] = max(len(v) for v in cs.values())
+print(json.dumps({key: out}))
 PY
 done

@@ -376,11 +376,17 @@ WL_DEV ElevBook load_elev_book(const WlElevParams& p, const WlEnvBuffers& b, con
 // one env.step() of env `e` (all LANES lanes of the env take part): the body of the step kernels below.
 // PERSIST: the env's rows and bookkeeping live in `rows` / `*carry` across calls (persistent rollout): nothing is loaded
 // from or stored to the state matrix here, both are updated in place.
-template <int LANES, bool PERSIST = false>
+// POSE_HOOK: called with the env's pose as the step leaves it (AFTER a reset, if the env resets) as soon as that pose is known --
+// before the rewards are weighted, the outputs, the metrics and the state rows are written -- so that the fused launch can hand the
+// height scan its lattice frames and let the other wavefronts start while this one finishes its bookkeeping (round 6).
+struct NoPoseHook {
+    WL_DEV void operator()(const V3&, const Quat&) const {}
+};
+template <int LANES, bool PERSIST = false, class POSE_HOOK = NoPoseHook>
 WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const WlEnvBuffers& b, const HeightFieldGround& ground,
                               const float2 action, ElevRows<LANES>& rows, const WlStepOut& out, const uint64_t seed,
                               const uint64_t step, const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics,
-                              ElevBook* carry = nullptr, float* prop2 = nullptr) {
+                              ElevBook* carry = nullptr, float* prop2 = nullptr, const POSE_HOOK& pose_hook = POSE_HOOK()) {
     const WlVehicleParams& vp = p.vehicle;
     const uint32_t gid = (uint32_t)(b.env_offset + e);
     float2 a = action;
@@ -465,6 +471,14 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
     float cbx = cb_in[0], cby = cb_in[1];
     const ElevTerms tm = elev_terms(p, pos, R.r2.z, vb, s.v, wheel_sum, cbx, cby, truncated);
     const bool terminated = !finite || tm.flag[0] || tm.flag[1] || tm.flag[2] || tm.flag[3];
+    // the pose the step leaves behind first (a reset replaces it): whoever waits for it (pose_hook) is served before the bookkeeping
+    const bool reset_now = terminated || truncated;
+    ElevReset rd{};
+    if (reset_now) {
+        rd = draw_elev_reset(p, ground, gid, step, seed);
+        pos = rd.pos;
+    }
+    pose_hook(pos, reset_now ? rd.q : s.q);
     const float step_dt = p.sim_dt * (float)p.decimation;
     float reward = 0.f;
     float epsum[WL_ER_NTERMS];
@@ -479,11 +493,11 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
         out.reward[e] = reward;
         out.terminated[e] = terminated ? 1 : 0;
         out.truncated[e] = truncated ? 1 : 0;
-        if (out.dones) out.dones[e] = (terminated || truncated) ? 1 : 0;
+        if (out.dones) out.dones[e] = reset_now ? 1 : 0;
     }
     float a0 = a.x, a1 = a.y;
     float tgt_x = tgt_in[0], tgt_y = tgt_in[1], tgt_h = tgt_in[2], cmd_timer = tgt_in[3];
-    if (terminated || truncated) {
+    if (reset_now) {
         if (lead) {
 #pragma unroll
         for (int i = 0; i < WL_ER_NTERMS; ++i) atomicAdd(&blk_metrics[WL_M_EPSUM0 + i], epsum[i]);
@@ -502,8 +516,6 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
             for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
             s.th = s.om = 0.f;
         }
-        const ElevReset rd = draw_elev_reset(p, ground, gid, step, seed);
-        pos = rd.pos;
         s.q = rd.q;
         s.v = v3(rd.vx, rd.vy, 0.f);
         ww = v3(0.f, 0.f, 0.f);
@@ -751,10 +763,15 @@ __global__ void __launch_bounds__(THREADS) elev_scan_lds_kernel(const WlElevPara
 inline bool scan_patch_fits(const WlElevParams* p, const WlHeightField* hf) {
     return hf->nx >= WL_SCAN_LDS_PITCH && hf->ny >= kPatch && (hf->nx & 1) == 0 && p->scan_size * 1.41422f / hf->cell + 3.2f <= (float)kPatch;
 }
-// gather form while the chip is not full (every env's 128 lanes in flight at once: latency, not address rate, is what counts
-// there), LDS patches beyond; WL_FLAG_SCAN_LDS / WL_FLAG_SCAN_GATHER force one
+// Which form (round 6): the GATHER form at every size.  With the row-pair table a ray is one lane address instead of two and the
+// gather form passed the LDS form everywhere (us per observation launch, same box, gather / LDS: 16 384 envs 26.8 / 28.3, 65 536:
+// 94 / 95, 262 144: 345 / 356, 1 M: 1223 / 1252; rounds 4 - 5, two gathers per ray: 484 - 515 against 404 -> 334 at 262 144).  Both
+// are bound by the same unit from different sides -- the gather form by the texture unit's one lane address per cycle (676 per env),
+// the LDS form by the vector instructions its staging and unaligned LDS reads cost.  WL_FLAG_SCAN_LDS still selects the LDS form
+// (BASELINE config 3's "heightfield patch in LDS"; the parity tests run both), WL_SCAN_LDS_MIN_ENVS (default: never) a size from
+// which it is the default.
 #ifndef WL_SCAN_LDS_MIN_ENVS
-#define WL_SCAN_LDS_MIN_ENVS 16384
+#define WL_SCAN_LDS_MIN_ENVS 0x7fffffff
 #endif
 #ifndef WL_ELEV_FUSED_MAX_ENVS
 #define WL_ELEV_FUSED_MAX_ENVS 8192
@@ -946,18 +963,33 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
             if (go) {
                 keep_scalar_common(p, p_arg);
                 vd.n_sub = vd_arg.n_sub;
-                const ScanPose sp = elev_env_step<4>(p, vd, b, ground, a, rows, out, seed, step, S, e, wid, wid == 0, blk_metrics);
-                if (wid == 0) frame[tid >> 2] = scan_frame(p, ground, sp);
-                WL_TL(3);
+                // the block's ONE meeting point sits in the middle of this wavefront's step: as soon as the pose it leaves behind is
+                // known (after a reset's draw) the lattice frames go to LDS and the other seven wavefronts start casting rays, while
+                // this one weights its rewards, writes outputs, metrics and state rows and then joins them for a smaller share
+                // (fused_scan_share).  Round 6, tools/fused_timeline.py: the bookkeeping was 1.1 us of every launch with seven
+                // wavefronts waiting behind it.  (Every block has an env, so wavefront 0 always gets here: one s_barrier per wavefront.)
+                auto publish = [&](const V3& pos_out, const Quat& q_out) {
+                    float yc, ys;
+                    yaw_cs(q_out, yc, ys);
+                    if (wid == 0) frame[tid >> 2] = scan_frame(p, ground, ScanPose{pos_out.x, pos_out.y, pos_out.z, yc, ys});
+                    WL_TL(3);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                };
+                (void)elev_env_step<4, false, decltype(publish)>(p, vd, b, ground, a, rows, out, seed, step, S, e, wid, wid == 0, blk_metrics, nullptr, nullptr, publish);
             }
         }
-    }
-    __syncthreads();
-    if (tid < 64) WL_TL(4);
-    if (tid >= kFusedThreads - 64) WL_TL(8);
-    if (tid < WL_M_COUNT) {
-        const float m = blk_metrics[tid];
-        if (m != 0.f) atomicAdd(metric_shard(b, m_slot) + tid, m);
+        WL_TL(4);
+        if (tid < WL_M_COUNT) {
+            const float m = blk_metrics[tid];
+            if (m != 0.f) atomicAdd(metric_shard(b, m_slot) + tid, m);
+        }
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (tid >= kFusedThreads - 64) WL_TL(8);
     }
     // ---- the scan ----
     const WlElevParams& p = p_arg;
@@ -976,30 +1008,27 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     // 21.0 against 20.5 us, and 19.1 against 18.6 with the pair table -- the older wavefronts of a SIMD run ahead and the younger
     // ones finish alone); store cache policies sc1 / nt / write-through (equal); a wavefront per env with the rays in 7 x 9 blocks of
     // neighbours (21.1 us).
-    constexpr int kAll = kFusedEnvs * kScanQuads;
-#ifndef WL_FUSED_SCAN_BATCHES
-#define WL_FUSED_SCAN_BATCHES 6
-#endif
-    constexpr int kScanBatches = WL_FUSED_SCAN_BATCHES;
-    constexpr int kSlots = (kAll + kFusedThreads - 1) / kFusedThreads, kBatch = (kSlots + kScanBatches - 1) / kScanBatches;
+    // 43 chunks of 64 ray quads (the last one holds 16) in six rounds; the wavefronts of a round take NEIGHBOURING chunks (what is in
+    // flight on the CU at a time then covers ~3 envs' patches of the table; with a contiguous range per wavefront -- 16 envs' patches
+    // at once -- the phase took 4.8 instead of 4.2 us: L1).  Wavefront 0, busy with its bookkeeping, sits out the first two rounds:
+    // rounds 0 - 1: wavefronts 1 - 7 (7 chunks each), rounds 2 - 4: all eight, round 5: wavefronts 0 - 4 -- per SIMD (wavefronts s and
+    // s + 4) 11 chunks, or 10 + the bookkeeping.
+    constexpr int kAll = kFusedEnvs * kScanQuads, kChunks = (kAll + 63) / 64;
+    static_assert(kChunks == 43 && kFusedThreads == 512, "the shares below are for 16 envs x 169 quads on eight wavefronts");
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #pragma unroll
-    for (int half = 0; half < kScanBatches; ++half) {
-        ScanRay cr[kBatch][4];
-        float pz[kBatch];
-#pragma unroll
-        for (int i = 0; i < kBatch; ++i) {
+    for (int r = 0; r < 6; ++r) {
+        const bool mine = r < 2 ? wave != 0 : (r < 5 || wave <= 4);      // wavefront-uniform
+        if (mine) {
+            const int chunk = r < 2 ? 7 * r + wave - 1 : 14 + 8 * (r - 2) + wave;
+            const int idx = chunk * 64 + lane;
             int j, q;
-            scan_quad_slot(min(tid + (half * kBatch + i) * kFusedThreads, kAll - 1), j, q);
+            scan_quad_slot(min(idx, kAll - 1), j, q);
             const ScanFrame fr = frame[min(j, n_here - 1)];
-            pz[i] = fr.pz;
-            scan_quad_request(fr, ground.f, sf, q, cr[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < kBatch; ++i) {
-            const int idx = tid + (half * kBatch + i) * kFusedThreads;
-            int j, q;
-            scan_quad_slot(idx, j, q);
-            if (idx < kAll && j < n_here) scan_quad_store<WL_FUSED_SCAN_NT>(out.obs + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr[i], sf.z_scale, pz[i]));
+            ScanRay cr[4];
+            scan_quad_request(fr, ground.f, sf, q, cr);
+            if (idx < kAll && j < n_here)
+                scan_quad_store<WL_FUSED_SCAN_NT>(out.obs + (int64_t)(e0 + j) * WL_ELEV_OBS_DIM + 13, q, scan_quad_value(p, cr, sf.z_scale, fr.pz));
         }
     }
 #if WL_FUSED_TIMELINE
