@@ -300,13 +300,23 @@ WL_DEV float group_sum(float v, float* scratch /* [GT / 64], this group's */, in
 // how a pixel's map cell is read: a byte gather from the global map, or one bit of the LDS-resident copy of the whole map
 // (WlTravMap.bits: the camera's 3200 divergent byte gathers per image were what bound it -- one lane per cycle and CU through
 // the texture addresser; an LDS read costs a thirty-second of that)
+// `masked(k, on)`: the cell, or false for a pixel that is off the map.  Global form (round 6): the byte map through a buffer resource
+// -- a 32-bit lane offset instead of a 64-bit address (v_mad_u64_u32 + v_lshl_add_u64 per pixel went), and an off-map pixel asks for
+// an offset outside the buffer (the bounds check returns 0 = not traversable) instead of branching around its gather: with the branch
+// the compiler waited for every pixel's gather inside it (`s_waitcnt vmcnt(0)` fourteen times per lane), now a lane's fourteen are in
+// flight together as the loop was written for.
 struct GlobalMapLookup {
-    const uint8_t* map;
-    WL_DEV bool operator()(int k) const { return map[k] != 0; }
+    __amdgpu_buffer_rsrc_t rsrc;
+    WL_DEV explicit GlobalMapLookup(const WlTravMap& m)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(m.map), 0, m.rows * m.cols, 0x00020000)) {}
+    WL_DEV bool masked(int k, bool on) const { return __builtin_amdgcn_raw_buffer_load_b8(rsrc, on ? k : -1, 0, 0) != 0; }
 };
 struct LdsBitLookup {
     const uint32_t* bits;
-    WL_DEV bool operator()(int k) const { return (bits[k >> 5] >> (k & 31)) & 1u; }
+    WL_DEV bool masked(int k, bool on) const {
+        const int kk = on ? k : 0;
+        return on && ((bits[kk >> 5] >> (kk & 31)) & 1u);
+    }
 };
 constexpr int kMapWords = WL_VIS_LDS_MAP_CELLS / 32;   // 32 KB of LDS
 // all threads of the block copy the bit map into LDS (coalesced dwords; the caller syncs).  Every request of a thread is issued
@@ -336,7 +346,7 @@ WL_DEV int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i :
 // the 8-float window of a 4 x 4 output patch is two aligned ds_read_b128 and, 4 rows x 21 slots being 4 mod 16, the 16-lane
 // groups a b128 read is served in (lanes of one patch row + 8 lanes of the next) hit 16 distinct slots.  (With the
 // unpadded [40][80] image each of the 64 reads per thread was a 4-byte read at a lane stride of 4 floats: 8-way conflicts.)
-constexpr int kPitch = kImgW + 4, kImgFloats = kImgH * kPitch;
+constexpr int kPitch = kImgW + 4, kImgPix = kImgH * kPitch, kImgFloats = kImgPix + 8;   // + the blur's five tap weights (render_image)
 
 // VisualObsCfg.PolicyCfg (:38-58): camera (3200) | base_lin_vel (3) | base_ang_vel (3) | last_action clip +-1 (2) of ONE env,
 // by a group of GT threads (gt = thread in the group; `img` [kImgFloats] and `red` [GT / 64] are the group's LDS).  Two
@@ -376,7 +386,11 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
     const bool lane_on = tr < kRowsPerPass;
     const float dy = -(((float)tc + 0.5f - p.cx) * inv_fx), dz0 = -(((float)(tr + WL_VIS_CROP) + 0.5f - p.cy) * inv_fy);
     V3 d = fma3(dz0, c2, fma3(dy, c1, c0));
-    const V3 dstep = (-(float)kRowsPerPass * inv_fy) * c2;
+    // (a product of its own: under -ffp-contract=fast a bare product feeding the `d + dstep` below is fused into that add per
+    // instantiation -- the block = env kernel and the persistent kernel then disagree in the last bit of a ray direction and, one
+    // image in 20 000, about the map cell a pixel falls into)
+    const float kstep = -(float)kRowsPerPass * inv_fy;
+    const V3 dstep = v3(fmaf(kstep, c2.x, 0.f), fmaf(kstep, c2.y, 0.f), fmaf(kstep, c2.z, 0.f));
     const float mx = mf.off_x * mf.inv_rs, my = mf.off_y * mf.inv_cs;   // cell = (int)(h * inv + off * inv)
     bool cell[kIter];
     bool hit[kIter];
@@ -386,9 +400,11 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
         const float hx = fmaf(t, d.x, o.x), hy = fmaf(t, d.y, o.y);
         hit[it] = d.z < -1e-6f;                                         // else: sky
         const bool on_map = hit[it] && fabsf(hx) <= mf.half_w && fabsf(hy) <= mf.half_h;
-        const int xi = min(max((int)fmaf(hx, mf.inv_rs, mx), 0), m.rows - 1);
-        const int yi = min(max((int)fmaf(hy, mf.inv_cs, my), 0), m.cols - 1);
-        cell[it] = on_map ? lookup(yi * m.cols + xi) : false;           // white path on black (utils/__init__.py:47-50)
+        // on the map |h| <= half extent, so h * inv + (n / 2 + 0.5) lies in [0.5, n + 0.5]: the conversion truncates, only the upper
+        // clamp can bind (off the map the index is not used); 24-bit multiply (full rate; rows, cols < 2^23)
+        const int xi = min((int)fmaf(hx, mf.inv_rs, mx), m.rows - 1);
+        const int yi = min((int)fmaf(hy, mf.inv_cs, my), m.cols - 1);
+        cell[it] = lookup.masked(__mul24(yi, m.cols) + xi, on_map);     // white path on black (utils/__init__.py:47-50)
         d = d + dstep;
     }
 #pragma unroll
@@ -403,10 +419,7 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
                     else row[r * kImgW + tc] = (v * 0.9999f - 0.5f) * 2.f;
                 }
             } else {
-                float* line = img + r * kPitch + 2;
-                line[tc] = v;
-                if (tc == 1 || tc == 2) line[-tc] = v;                            // reflect padding (torchvision): -1 -> 1, -2 -> 2
-                if (tc == kImgW - 2 || tc == kImgW - 3) line[2 * kImgW - 2 - tc] = v;   // 80 -> 78, 81 -> 77
+                img[r * kPitch + 2 + tc] = v;      // (the two border columns on either side stay unwritten: the edge patches reflect when they read)
                 part += v;
             }
         }
@@ -415,19 +428,26 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
     // ---- augmentation on the LDS-resident image.  One 4 x 4 output patch per thread (10 x 20 patches = 200 threads):
     // the 8 x 8 input neighbourhood is read once (contrast blend applied on the fly), both passes of the separable 5-tap
     // Gaussian run in registers, and each patch row leaves as one 16-byte store.
-    const float mean = 0.9999f * group_sum<GT>(part, red, gt, sync) * (1.f / (float)(kImgH * kImgW));   // also orders the img writes
+    // GaussianBlur(5, sigma), torchvision's kernel1d: the five exponentials once per image (lanes 0 - 4, through LDS) instead of once per
+    // thread -- with the division and the normalisation they were 100 vector instructions + 11 quarter-rate ones of every thread's ~1000,
+    // in a launch that is bound by vector issue (round 6).  Same operations on the same values: same bits.
+    float* wl = img + kImgPix;
+    if (gt < 5 && p.blur_sigma > 0.f) {
+        const float x = (float)(gt - 2) / p.blur_sigma;
+        wl[gt] = __expf(-0.5f * x * x);
+    }
+    const float mean = 0.9999f * group_sum<GT>(part, red, gt, sync) * (1.f / (float)(kImgH * kImgW));   // also orders the img / weight writes
     const float cc = p.contrast, cm = (1.f - p.contrast) * mean;   // ColorJitter contrast: blend with the grey mean
     // a blend TOWARDS the mean (contrast <= 1) stays inside [0, 1], its clamp is the identity, and the blur is linear with
     // weights summing to one: blur(cc v + cm) = cc blur(v) + cm -- applied to the 16 outputs instead of the 64 inputs
     const bool fold = cc <= 1.f && cc >= 0.f && !cfirst;   // (contrast first: the brightness clamp sits between blend and blur)
     const float oc_ = fold ? cc : 1.f, om_ = fold ? cm : 0.f;
     float w[5] = {0.f, 0.f, 1.f, 0.f, 0.f};
-    if (p.blur_sigma > 0.f) {                                      // GaussianBlur(5, sigma): torchvision's kernel1d
+    if (p.blur_sigma > 0.f) {
         float wsum = 0.f;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const float x = (float)(j - 2) / p.blur_sigma;
-            w[j] = __expf(-0.5f * x * x);
+            w[j] = wl[j];
             wsum += w[j];
         }
         const float inv = 1.f / wsum;
@@ -437,12 +457,16 @@ WL_DEV void render_image(const WlVisualParams& p, const WlTravMap& m, const LOOK
     constexpr int kPatchCols = kImgW / 4, kPatches = (kImgH / 4) * kPatchCols;
     if (gt < kPatches && valid) {
         const int pr = (gt / kPatchCols) * 4, pc = (gt % kPatchCols) * 4;
+        // reflect padding (torchvision) of the columns, at READ time: only the first and last patch of a row see columns outside the
+        // image (-2 -> 2, -1 -> 1; 80 -> 78, 81 -> 77), four selects per row for them -- written at render time the four border
+        // columns cost every pixel of every thread two compound tests and two predicated LDS writes (round 6: ~110 instructions per thread)
+        const bool left = pc == 0, right = pc == kImgW - 4;
         float hrow[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float4* line = reinterpret_cast<const float4*>(img + reflect(pr + i - 2, kImgH) * kPitch + pc);   // columns pc - 2 .. pc + 5
             const float4 lo4 = line[0], hi4 = line[1];
-            float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            float v[8] = {left ? hi4.x : lo4.x, left ? lo4.w : lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, right ? hi4.x : hi4.z, right ? lo4.w : hi4.w};
             if (!fold) {   // contrast > 1 can leave [0, 1]: the clamp sits between the blend and the blur
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = clampf(fmaf(cc, v[j], cm), 0.f, 1.f);
@@ -502,7 +526,7 @@ __global__ void __launch_bounds__(kCam, MINW) visual_obs_kernel(const WlVisualPa
     const int e = blockIdx.x;
     const CamPose cp = load_cam_pose(make_rows(b.state, b.stride), e);
     BlockSync sync;
-    render_image<kCam, STREAM>(p, m, GlobalMapLookup{m.map}, cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img, red, (int)threadIdx.x, true, sync);
+    render_image<kCam, STREAM>(p, m, GlobalMapLookup(m), cp, obs + (int64_t)e * WL_VIS_OBS_DIM, img, red, (int)threadIdx.x, true, sync);
 }
 
 // (Round 3: the same camera with the whole map in LDS as one bit per cell -- persistent blocks of three render groups, map staged
@@ -608,7 +632,7 @@ __global__ void __launch_bounds__(kPersistThreads) visual_rollout_persistent_ker
                 render_image<GT>(p_arg, m, LdsBitLookup{mapbits}, cp, obs_k + (int64_t)(e0 + j) * WL_VIS_OBS_DIM, img + grp * kImgFloats,
                                  red + grp * (GT / 64), gtl, true, sync);
             else
-                render_image<GT>(p_arg, m, GlobalMapLookup{m.map}, cp, obs_k + (int64_t)(e0 + j) * WL_VIS_OBS_DIM, img + grp * kImgFloats,
+                render_image<GT>(p_arg, m, GlobalMapLookup(m), cp, obs_k + (int64_t)(e0 + j) * WL_VIS_OBS_DIM, img + grp * kImgFloats,
                                  red + grp * (GT / 64), gtl, true, sync);
         }
     }
