@@ -202,6 +202,14 @@ def test_device_heightfield_forms_and_quantisation():
     codes, zs = T.quantize_heights(r)
     assert zs == 2.0 ** -13 and np.array_equal(dr.codes.numpy(), codes) and np.array_equal(OH.quantize(r), codes)
     assert np.array_equal(T.decode_heights(codes, zs), OH.decode(codes, zs)) and np.array_equal(dr.heights.numpy(), OH.decode(codes))
+    # the row-pair table (ABI 23, include/wheeledlab_amd.h: pair[j][i] = code[j][i] | code[j + 1][i] << 16, the last row with itself)
+    pr = dr.pairs.numpy().view(np.uint32)
+    up = np.concatenate([codes[1:], codes[-1:]], 0)
+    assert pr.shape == codes.shape and np.array_equal((pr & 0xffff).astype(np.uint16).view(np.int16), codes)
+    assert np.array_equal((pr >> 16).astype(np.uint16).view(np.int16), up) and dr.struct.pair == dr.pairs.data_ptr()
+    from tests.depth_cases import hf_struct
+    _s, (_c, p_np) = hf_struct((dr.heights.numpy(), 0.0, 0.0, 0.1))
+    assert np.array_equal(p_np, pr)                                                # the host simulations' numpy builder: the same table
     # a range beyond +-4 m: the scale doubles until the codes fit
     tall = DeviceHeightField((r * 4.0, 0.0, 0.0, 0.1), "cpu")
     assert tall.z_scale == 2.0 ** -11 and int(tall.codes.abs().max()) <= 32767

@@ -766,8 +766,8 @@ inline bool scan_patch_fits(const WlElevParams* p, const WlHeightField* hf) {
 // Which form (round 6): the GATHER form at every size.  With the row-pair table a ray is one lane address instead of two and the
 // gather form passed the LDS form everywhere (us per observation launch, same box, gather / LDS: 16 384 envs 26.8 / 28.3, 65 536:
 // 94 / 95, 262 144: 345 / 356, 1 M: 1223 / 1252; rounds 4 - 5, two gathers per ray: 484 - 515 against 404 -> 334 at 262 144).  Both
-// are bound by the same unit from different sides -- the gather form by the texture unit's one lane address per cycle (676 per env),
-// the LDS form by the vector instructions its staging and unaligned LDS reads cost.  WL_FLAG_SCAN_LDS still selects the LDS form
+// the gather form is bound by the texture unit's one lane address per cycle (676 per env); what holds the LDS form at the same time
+// (its texture-unit and vector work are each ~half of its launch) was never pinned down.  WL_FLAG_SCAN_LDS still selects the LDS form
 // (BASELINE config 3's "heightfield patch in LDS"; the parity tests run both), WL_SCAN_LDS_MIN_ENVS (default: never) a size from
 // which it is the default.
 #ifndef WL_SCAN_LDS_MIN_ENVS
@@ -1003,7 +1003,8 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     // in front of them cost 1.8 - 2.9 us on top of an empty launch (tools/microbench/row_burst.hip), and that overlaps the phase --
     // but the TEXTURE UNIT's address rate: with two 4-byte gathers per ray the phase took 6.1 - 6.8 us, the unit was busy 16 000
     // cycles per CU (all of it), 57 cache accesses per 64-lane gather instruction, L1 hit rate 0.91.  One 8-byte gather per ray
-    // (the row-pair table): 4.2 - 4.4 us, what its ~1100 vector instructions per wavefront (two wavefronts per SIMD) cost to issue.
+    // (the row-pair table): 4.2 - 4.5 us = 10 816 lane addresses per CU; the phase's ~1000 vector instructions per wavefront are 1.8 us
+    // of pipe at two wavefronts per SIMD, so it is still the unit's -- fewer lane addresses (an LDS patch) would be the next step.
     // Measured and dropped in round 6: the same loop software-pipelined (quad k + 1 requested before quad k is blended and stored:
     // 21.0 against 20.5 us, and 19.1 against 18.6 with the pair table -- the older wavefronts of a SIMD run ahead and the younger
     // ones finish alone); store cache policies sc1 / nt / write-through (equal); a wavefront per env with the rays in 7 x 9 blocks of
