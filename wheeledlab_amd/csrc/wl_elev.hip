@@ -376,17 +376,24 @@ WL_DEV ElevBook load_elev_book(const WlElevParams& p, const WlEnvBuffers& b, con
 // one env.step() of env `e` (all LANES lanes of the env take part): the body of the step kernels below.
 // PERSIST: the env's rows and bookkeeping live in `rows` / `*carry` across calls (persistent rollout): nothing is loaded
 // from or stored to the state matrix here, both are updated in place.
-// POSE_HOOK: called with the env's pose as the step leaves it (AFTER a reset, if the env resets) as soon as that pose is known --
-// before the rewards are weighted, the outputs, the metrics and the state rows are written -- so that the fused launch can hand the
-// height scan its lattice frames and let the other wavefronts start while this one finishes its bookkeeping (round 6).
-struct NoPoseHook {
-    WL_DEV void operator()(const V3&, const Quat&) const {}
+// HOOKS (round 6): how the fused launch takes the step apart.  `pose(pos, q)` is called with the env's pose as the step leaves it
+// (AFTER a reset, if the env resets) as soon as that pose is known -- before the rewards are weighted, the outputs, the metrics and the
+// state rows are written -- so that the launch can hand the height scan its lattice frames and let the other wavefronts start while
+// this one finishes its bookkeeping.  `reset(...)` supplies a resetting env's draw: by default drawn here; the fused launch has an idle
+// wavefront draw all 16 envs' resets while the physics runs (the draw depends on (seed, env, step) and the terrain only) -- with a
+// reset somewhere in nearly every launch, the draw's ~0.9 us (two Philox blocks, a terrain sample's round trip, sin / cos) was on the
+// launch's critical path.
+struct NoStepHooks {
+    WL_DEV ElevReset reset(const WlElevParams& p, const HeightFieldGround& g, uint32_t gid, uint64_t step, uint64_t seed, int) const {
+        return draw_elev_reset(p, g, gid, step, seed);
+    }
+    WL_DEV void pose(const V3&, const Quat&) const {}
 };
-template <int LANES, bool PERSIST = false, class POSE_HOOK = NoPoseHook>
+template <int LANES, bool PERSIST = false, class HOOKS = NoStepHooks>
 WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const WlEnvBuffers& b, const HeightFieldGround& ground,
                               const float2 action, ElevRows<LANES>& rows, const WlStepOut& out, const uint64_t seed,
                               const uint64_t step, const Rows& S, const int e, const int wid, const bool lead, float* blk_metrics,
-                              ElevBook* carry = nullptr, float* prop2 = nullptr, const POSE_HOOK& pose_hook = POSE_HOOK()) {
+                              ElevBook* carry = nullptr, float* prop2 = nullptr, const HOOKS& hooks = HOOKS()) {
     const WlVehicleParams& vp = p.vehicle;
     const uint32_t gid = (uint32_t)(b.env_offset + e);
     float2 a = action;
@@ -471,14 +478,14 @@ WL_DEV ScanPose elev_env_step(const WlElevParams& p, const VehDerived& vd, const
     float cbx = cb_in[0], cby = cb_in[1];
     const ElevTerms tm = elev_terms(p, pos, R.r2.z, vb, s.v, wheel_sum, cbx, cby, truncated);
     const bool terminated = !finite || tm.flag[0] || tm.flag[1] || tm.flag[2] || tm.flag[3];
-    // the pose the step leaves behind first (a reset replaces it): whoever waits for it (pose_hook) is served before the bookkeeping
+    // the pose the step leaves behind first (a reset replaces it): whoever waits for it (hooks.pose) is served before the bookkeeping
     const bool reset_now = terminated || truncated;
     ElevReset rd{};
     if (reset_now) {
-        rd = draw_elev_reset(p, ground, gid, step, seed);
+        rd = hooks.reset(p, ground, gid, step, seed, e);
         pos = rd.pos;
     }
-    pose_hook(pos, reset_now ? rd.q : s.q);
+    hooks.pose(pos, reset_now ? rd.q : s.q);
     const float step_dt = p.sim_dt * (float)p.decimation;
     float reward = 0.f;
     float epsum[WL_ER_NTERMS];
@@ -830,8 +837,11 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
     __shared__ ScanFrame frame[kFusedEnvs];
     __shared__ __attribute__((aligned(16))) float hbuf[POLICY ? 2 * 3 * kMlpTiles * 64 * 4 : 4];   // partial accumulators [net][share - 1][tile][lane][4]
     __shared__ float2 act_lds[kFusedEnvs];
+    __shared__ ElevReset reset_lds[kFusedEnvs];     // the block's 16 reset draws, by wavefront 1 while wavefront 0 integrates (!POLICY)
+    __shared__ int reset_ready;
     const int tid = threadIdx.x;
     if (tid < 64) WL_TL(0);
+    if (tid == 0) reset_ready = 0;
     if (tid < WL_M_COUNT) blk_metrics[tid] = 0.f;
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
     if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
@@ -968,16 +978,31 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
                 // this one weights its rewards, writes outputs, metrics and state rows and then joins them for a smaller share
                 // (fused_scan_share).  Round 6, tools/fused_timeline.py: the bookkeeping was 1.1 us of every launch with seven
                 // wavefronts waiting behind it.  (Every block has an env, so wavefront 0 always gets here: one s_barrier per wavefront.)
-                auto publish = [&](const V3& pos_out, const Quat& q_out) {
-                    float yc, ys;
-                    yaw_cs(q_out, yc, ys);
-                    if (wid == 0) frame[tid >> 2] = scan_frame(p, ground, ScanPose{pos_out.x, pos_out.y, pos_out.z, yc, ys});
-                    WL_TL(3);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                struct FusedHooks {
+                    const WlElevParams& p;
+                    const HeightFieldGround& ground;
+                    ScanFrame* frame;
+                    const ElevReset* reset_lds;
+                    int* reset_ready;
+                    int tid, wid, e0;
+                    WL_DEV ElevReset reset(const WlElevParams& pp, const HeightFieldGround& g, uint32_t gid, uint64_t st, uint64_t sd, int e) const {
+                        if constexpr (POLICY) return draw_elev_reset(pp, g, gid, st, sd);      // (the collector's other wavefronts are busy with the nets)
+                        // wavefront 1 set the flag long ago (its draws take ~1.5 us, this is ~9 us into the launch): the loop is the guarantee
+                        while (__hip_atomic_load(reset_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+                        return reset_lds[e - e0];
+                    }
+                    WL_DEV void pose(const V3& pos_out, const Quat& q_out) const {
+                        float yc, ys;
+                        yaw_cs(q_out, yc, ys);
+                        if (wid == 0) frame[tid >> 2] = scan_frame(p, ground, ScanPose{pos_out.x, pos_out.y, pos_out.z, yc, ys});
+                        WL_TL(3);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
                 };
-                (void)elev_env_step<4, false, decltype(publish)>(p, vd, b, ground, a, rows, out, seed, step, S, e, wid, wid == 0, blk_metrics, nullptr, nullptr, publish);
+                const FusedHooks hooks{p, ground, frame, reset_lds, &reset_ready, tid, wid, e0};
+                (void)elev_env_step<4, false, FusedHooks>(p, vd, b, ground, a, rows, out, seed, step, S, e, wid, wid == 0, blk_metrics, nullptr, nullptr, hooks);
             }
         }
         WL_TL(4);
@@ -986,6 +1011,14 @@ __global__ void __launch_bounds__(kFusedThreads) elev_step_scan_kernel(const WlE
             if (m != 0.f) atomicAdd(metric_shard(b, m_slot) + tid, m);
         }
     } else {
+        if constexpr (!POLICY) {
+            if (tid < 128) {      // wavefront 1: the block's reset draws, in the shadow of the physics (FusedHooks::reset)
+                const int j = tid - 64;
+                if (j < kFusedEnvs && e0 + j < b.n_envs) reset_lds[j] = draw_elev_reset(p_arg, ground, (uint32_t)(b.env_offset + e0 + j), step, seed);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (j == 0) __hip_atomic_store(&reset_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
