@@ -87,10 +87,33 @@ struct CamPose {
 // reference's task, or a heightfield (the visual-depth extension task, BASELINE config 5: wheel contacts by bilinear gathers as in
 // the elevation task, reset poses lifted onto the terrain; `prop`: the env's 8 proprioceptive observation values are written
 // there -- the depth image next to them comes from wl_depth.hip)
-template <int LANES, class Ground = FlatGround>
+// a resetting env's new pose: the draw + (on a heightfield) the lift onto the terrain under the spawn cell
+template <class Ground>
+WL_DEV VisReset visual_reset_pose(const WlVisualParams& p, const WlTravMap& m, const Ground& ground, uint32_t gid, uint64_t step, uint64_t seed) {
+    VisReset rd = draw_visual_reset(p, m, gid, step, seed);
+    if constexpr (!Ground::kFlat) {     // z 0.1 above the plane -> 0.1 above the terrain under the spawn cell
+        float zt;
+        V3 nt;
+        ground.sample(rd.pos.x, rd.pos.y, zt, nt);
+        rd.pos.z += zt;
+    }
+    return rd;
+}
+// RESET_SRC: where a resetting env's pose comes from.  By default drawn on the spot; the quad-form step kernel of the small batches has
+// a helper wavefront draw the block's resets while the physics runs (round 6): the draw is two or three DEPENDENT memory round trips
+// (Philox -> the spawn-cell table -> on a heightfield the terrain under the cell) behind the last sub-step, with mean episodes of ~50
+// steps every other block of 32 envs has one per step, and the launch is as long as its slowest block.
+struct InlineVisualReset {
+    template <class Ground>
+    WL_DEV VisReset operator()(const WlVisualParams& p, const WlTravMap& m, const Ground& ground, uint32_t gid, uint64_t step, uint64_t seed, int) const {
+        return visual_reset_pose(p, m, ground, gid, step, seed);
+    }
+};
+template <int LANES, class Ground = FlatGround, class RESET_SRC = InlineVisualReset>
 WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, const WlEnvBuffers& b, const WlTravMap& m, float2 a,
                                const WlStepOut& out, const uint64_t seed, const uint64_t step, const Rows& S, const int e, const int wid,
-                               const bool lead, float* blk_metrics, const Ground ground = Ground{}, float* __restrict__ prop = nullptr) {
+                               const bool lead, float* blk_metrics, const Ground ground = Ground{}, float* __restrict__ prop = nullptr,
+                               const RESET_SRC& reset_src = RESET_SRC()) {
     const WlVehicleParams& vp = p.vehicle;
     {
         const uint32_t gid = (uint32_t)(b.env_offset + e);
@@ -196,14 +219,8 @@ WL_DEV CamPose visual_env_step(const WlVisualParams& p, const VehDerived& vd, co
                 for (int i = 0; i < 4; ++i) s.wheel[i] = 0.f;
                 s.th = s.om = 0.f;
             }
-            const VisReset rd = draw_visual_reset(p, m, gid, step, seed);
+            const VisReset rd = reset_src(p, m, ground, gid, step, seed, e);
             pos = rd.pos;
-            if constexpr (!Ground::kFlat) {     // z 0.1 above the plane -> 0.1 above the terrain under the spawn cell
-                float zt;
-                V3 nt;
-                ground.sample(pos.x, pos.y, zt, nt);
-                pos.z += zt;
-            }
             s.q = rd.q;
             s.v = v3(0.f, 0.f, 0.f);
             ww = v3(0.f, 0.f, 0.f);
@@ -258,17 +275,46 @@ __global__ void __launch_bounds__(kBlock) visual_step_kernel(const WlVisualParam
         vd.n_sub = vd_arg.n_sub;
     }
     constexpr int kEnvs = (LANES == 4 ? QB : kBlock) / LANES;
+    // heightfield ground only: launched with QB + 64 threads, the last wavefront draws the block's resets (on the plane the draw is one
+    // round trip shorter and the helper bought nothing: visual env.step 35.4 against 35.2 us, same box)
+    constexpr bool kHelper = LANES == 4 && QB == 128 && !Ground::kFlat;
+    __shared__ VisReset reset_lds[kHelper ? kEnvs : 1];
+    __shared__ int reset_ready;
     const int wid = LANES == 1 ? 0 : (threadIdx.x & 3);
     const bool lead = LANES == 1 || wid == 0;
     const int e = blockIdx.x * kEnvs + threadIdx.x / LANES;
     if (threadIdx.x < WL_M_COUNT) blk_metrics[threadIdx.x] = 0.f;
+    if (threadIdx.x == 0) reset_ready = 0;
     const int m_slot = b.metrics_slots > 1 ? (int)(step % (uint64_t)b.metrics_slots) : 0;
     if (b.metrics_slots > 1) clear_metric_slot(b, (m_slot + 1) % b.metrics_slots);
     __syncthreads();
     const Rows S = make_rows(b.state, b.stride);
-    if (e < b.n_envs)
-        visual_env_step<LANES, Ground>(p, vd, b, m, actions[e], out, seed, step, S, e, wid, lead, blk_metrics, ground,
-                                       prop_stride > 0 ? out.obs + (int64_t)e * prop_stride + prop_offset : nullptr);
+    if constexpr (kHelper) {
+        if (threadIdx.x >= QB) {
+            const int j = (int)threadIdx.x - QB, ej = blockIdx.x * kEnvs + j;
+            if (j < kEnvs && ej < b.n_envs) reset_lds[j] = visual_reset_pose(p_arg, m, ground, (uint32_t)(b.env_offset + ej), step, seed);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (j == 0) __hip_atomic_store(&reset_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (e < b.n_envs) {
+            struct HelperReset {
+                const VisReset* reset_lds;
+                int* reset_ready;
+                int e0;
+                WL_DEV VisReset operator()(const WlVisualParams&, const WlTravMap&, const Ground&, uint32_t, uint64_t, uint64_t, int e) const {
+                    // set ~1 us into the launch, read ~8 us into it: the loop is the guarantee
+                    while (__hip_atomic_load(reset_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+                    return reset_lds[e - e0];
+                }
+            };
+            const HelperReset hr{reset_lds, &reset_ready, (int)(blockIdx.x * kEnvs)};
+            visual_env_step<LANES, Ground, HelperReset>(p, vd, b, m, actions[e], out, seed, step, S, e, wid, lead, blk_metrics, ground,
+                                                        prop_stride > 0 ? out.obs + (int64_t)e * prop_stride + prop_offset : nullptr, hr);
+        }
+    } else {
+        if (e < b.n_envs)
+            visual_env_step<LANES, Ground>(p, vd, b, m, actions[e], out, seed, step, S, e, wid, lead, blk_metrics, ground,
+                                           prop_stride > 0 ? out.obs + (int64_t)e * prop_stride + prop_offset : nullptr);
+    }
     __syncthreads();
     if (threadIdx.x < WL_M_COUNT) {
         const float v = blk_metrics[threadIdx.x];
@@ -799,7 +845,7 @@ int wl_visual_step_hf(const WlVisualParams* p, const WlEnvBuffers* b, const WlTr
     clear_error();
     if (use_quad(b)) {
         const int lanes = n * 4;
-        if (n <= 8192) visual_step_kernel<4, 128, HeightFieldGround><<<(lanes + 127) / 128, 128, 0, hs>>>(*p, vd, *b, *m, a, *out, seed, step, g, WL_VISDEPTH_OBS_DIM, WL_VISDEPTH_NPIX);
+        if (n <= 8192) visual_step_kernel<4, 128, HeightFieldGround><<<(lanes + 127) / 128, 128 + 64, 0, hs>>>(*p, vd, *b, *m, a, *out, seed, step, g, WL_VISDEPTH_OBS_DIM, WL_VISDEPTH_NPIX);   // + the helper wavefront
         else visual_step_kernel<4, kBlock, HeightFieldGround><<<grid_for(lanes), kBlock, 0, hs>>>(*p, vd, *b, *m, a, *out, seed, step, g, WL_VISDEPTH_OBS_DIM, WL_VISDEPTH_NPIX);
     } else {
         visual_step_kernel<1, kBlock, HeightFieldGround><<<grid_for(n), kBlock, 0, hs>>>(*p, vd, *b, *m, a, *out, seed, step, g, WL_VISDEPTH_OBS_DIM, WL_VISDEPTH_NPIX);
