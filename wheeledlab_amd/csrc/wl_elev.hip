@@ -781,7 +781,7 @@ inline bool scan_patch_fits(const WlElevParams* p, const WlHeightField* hf) {
 #define WL_SCAN_LDS_MIN_ENVS 0x7fffffff
 #endif
 #ifndef WL_ELEV_FUSED_MAX_ENVS
-#define WL_ELEV_FUSED_MAX_ENVS 8192
+#define WL_ELEV_FUSED_MAX_ENVS 12288
 #endif
 #ifndef WL_ELEV_STREAM_BYTES
 #define WL_ELEV_STREAM_BYTES 0ll
@@ -1542,8 +1542,9 @@ int wl_elev_rollout(const WlElevParams* p, const WlEnvBuffers* b, const WlHeight
     if (!actions || !out || !out->obs || !out->reward || !out->terminated || !out->truncated || n_steps < 0) return WL_EINVAL;
     const HeightFieldGround g = make_ground(hf);
     const VehDerived vd = derive_vehicle(p->vehicle, p->sim_dt, p->decimation);
-    // step + scan in one launch while its 16-env blocks fit the chip twice over (256 CUs); beyond, the lane-form step + the scan launch
-    // (round 4, us per step: 8192 envs 48.5 fused; 16 384 envs 92.5 fused / 75.4 two launches; 32 768 envs 180.6 / 100.2)
+    // step + scan in one launch up to three 16-env blocks per CU; beyond, the lane-form step + the scan launch (round 6, us per step, fused /
+    // two launches, profiles/r06_fused_crossover.txt: 8192 envs 30.9 / 43.8, 12 288: 44.8 / 48.5, 16 384: 58.9 / 52.4, 32 768: 114.5 / 72.2;
+    // round 4: 8192 envs 48.5 fused; 16 384 envs 92.5 / 75.4)
     const bool quad = use_quad(b) && (b->lanes == 4 || b->n_envs <= WL_ELEV_FUSED_MAX_ENVS);
     clear_error();
     for (int k = 0; k < n_steps; ++k) {
