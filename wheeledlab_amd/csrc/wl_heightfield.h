@@ -25,12 +25,10 @@ WL_DEV void hf_decode_pair(uint32_t w, float z_scale, float& a, float& b) {
     a = (float)(int)(int16_t)(w & 0xffffu) * z_scale;
     b = (float)((int)w >> 16) * z_scale;
 }
-// two adjacent codes at grid index k (row-major), decoded: ONE 2-byte aligned dword gather.  (Round 5, same box: the aligned 8 bytes
-// around the pair + v_alignbit instead -- what the LDS patch reads need, wl_elev.hip -- is slower from global memory: the gather-form
-// scan at 262 144 envs 504 against 482 us per launch, the fused 4096-env step 25.2 against 25.0 us.)
-WL_DEV void hf_pair(const WlHeightField& f, int64_t k, float& a, float& b) {
-    hf_decode_pair(*reinterpret_cast<const wl_u32_u2*>(f.height + k), f.z_scale, a, b);
-}
+// (Rounds 4 - 5 read two adjacent codes as ONE 2-byte aligned dword gather from the code field, `hf_pair`, two per cell; the aligned
+// 8 bytes around the pair + v_alignbit instead -- what the LDS patch reads need, wl_elev.hip -- was slower from global memory: the
+// gather-form scan at 262 144 envs 504 against 482 us per launch, the fused 4096-env step 25.2 against 25.0 us.  The depth walk still
+// reads its code pairs that way, from its own copy of the codes: wl_depth_dev.h.)
 // a cell's four corner heights from the ROW-PAIR table (WlHeightField.pair, ABI 23: pair[j][i] = code[j][i] | code[j + 1][i] << 16):
 // ONE 8-byte gather at 4-byte alignment instead of two 4-byte ones from rows j and j + 1 of the code field -- half the lane addresses
 // the texture unit is charged for, and the contact samplers share the height scan's working set in L2 (with the scan on the pair
